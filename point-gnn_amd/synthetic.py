@@ -1,0 +1,116 @@
+"""Seeded synthetic KITTI-shaped LiDAR clouds.
+
+There is no KITTI data (and no network) on the build or GPU boxes, so every
+test and benchmark runs on a ray-cast stand-in for a camera-FOV-cropped
+HDL-64E scan: 64 beams (elevation +2 deg .. -24.8 deg), fixed azimuth step over
+the camera field of view, sensor 1.73 m above a ground plane, random
+car-sized boxes, far building-sized boxes and optional thin poles, 2-70 m
+range gate, 0.2 % multiplicative range noise.  Output is in the KITTI *camera* frame
+(x right, y down, z forward) as float32, which is what the reference feeds to
+its graph generator (run.py:219-222 passes ``cam_rgb_points.xyz``).
+
+This module is host-side input synthesis only; nothing here is on the
+measured path.
+"""
+import numpy as np
+
+__all__ = ["synthetic_cloud", "CLOUD_PRESETS"]
+
+# Scene = flat ground + groups of yawed boxes.  A group is
+# (count, r_lo, r_hi, footprint_lo, footprint_hi, height_lo, height_hi): boxes
+# placed uniformly in range/azimuth inside the field of view, resting on the
+# ground.  Far, tall "building" boxes intercept the upper beams and spread the
+# returns over many voxels, which is what sets K (keypoints) and E1.
+_CARS = (12, 6.0, 60.0, 1.6, 4.5, 1.4, 1.9)
+_FAR16 = (16, 40.0, 68.0, 10.0, 20.0, 6.0, 14.0)
+
+# name -> kwargs.  Shapes measured with the reference's own graph_gen.py at the
+# shipped inference kwargs (seed 0): see DESIGN.md "Workloads".
+CLOUD_PRESETS = {
+    # car_auto_T3 inference shape: N=20k, K~2.9k, E0~350k, E1~500k
+    "car": dict(n_points=20000, fov_deg=81.0, az_step_deg=0.1728,
+                groups=(_FAR16, _CARS)),
+    # config-5 stress: 150 deg FOV, ~50k points, ped_cyl radii/voxel
+    "ped_dense": dict(n_points=50000, fov_deg=150.0, az_step_deg=0.15,
+                      groups=((28, 35.0, 68.0, 10.0, 20.0, 6.0, 14.0),
+                              (30, 5.0, 40.0, 0.4, 0.9, 1.5, 1.9), _CARS)),
+    # unit-test size
+    "tiny": dict(n_points=1500, fov_deg=40.0, az_step_deg=0.7,
+                 groups=((3, 15.0, 30.0, 4.0, 8.0, 3.0, 6.0),
+                         (4, 5.0, 25.0, 1.6, 4.5, 1.4, 1.9))),
+    "small": dict(n_points=5000, fov_deg=60.0, az_step_deg=0.35,
+                  groups=((6, 25.0, 50.0, 6.0, 12.0, 4.0, 8.0),
+                          (6, 5.0, 40.0, 1.6, 4.5, 1.4, 1.9))),
+}
+
+
+def _ray_boxes(origin, dirs, centers, sizes, yaws):
+    """Slab test of R rays against B yawed boxes.  Returns [R] nearest hit t
+    (inf when no box is hit).  Lidar frame: x forward, y left, z up."""
+    t_best = np.full(dirs.shape[0], np.inf)
+    for c, s, yaw in zip(centers, sizes, yaws):
+        cy, sy = np.cos(yaw), np.sin(yaw)
+        # rotate ray into the box frame (rotation about z)
+        rot = np.array([[cy, sy, 0.0], [-sy, cy, 0.0], [0.0, 0.0, 1.0]])
+        o = (origin - c) @ rot.T
+        d = dirs @ rot.T
+        half = s * 0.5
+        with np.errstate(divide="ignore", invalid="ignore"):
+            inv = 1.0 / d
+            t0 = (-half - o) * inv
+            t1 = (half - o) * inv
+        tmin = np.minimum(t0, t1).max(axis=1)
+        tmax = np.maximum(t0, t1).min(axis=1)
+        hit = (tmax >= np.maximum(tmin, 0.0)) & np.isfinite(tmin)
+        t = np.where(hit & (tmin > 0), tmin, np.inf)
+        t_best = np.minimum(t_best, t)
+    return t_best
+
+
+def synthetic_cloud(seed=0, n_points=20000, fov_deg=81.0, az_step_deg=0.1728,
+                    groups=(_FAR16, _CARS), preset=None, noise=0.002):
+    """Returns (xyz float32 [N,3] camera frame, intensity float32 [N,1]).
+
+    Deterministic in ``seed``.  N = min(n_points, number of valid returns).
+    """
+    if preset is not None:
+        return synthetic_cloud(seed=seed, **CLOUD_PRESETS[preset])
+    rng = np.random.default_rng(seed)
+    sensor_h = 1.73
+    elev = np.deg2rad(np.linspace(2.0, -24.8, 64))
+    n_az = int(np.floor(fov_deg / az_step_deg)) + 1
+    az = np.deg2rad(-0.5 * fov_deg + az_step_deg * np.arange(n_az))
+    el, a = np.meshgrid(elev, az, indexing="ij")
+    el = el.ravel()
+    a = a.ravel()
+    # lidar frame: x forward, y left, z up
+    dirs = np.stack([np.cos(el) * np.cos(a), np.cos(el) * np.sin(a),
+                     np.sin(el)], axis=1)
+    origin = np.zeros(3)
+    with np.errstate(divide="ignore"):
+        t_hit = np.where(dirs[:, 2] < 0, -sensor_h / dirs[:, 2], np.inf)
+    half_fov = np.deg2rad(0.5 * fov_deg)
+    for (cnt, r_lo, r_hi, f_lo, f_hi, h_lo, h_hi) in groups:
+        if cnt <= 0:
+            continue
+        rad = r_lo + (r_hi - r_lo) * rng.random(cnt)
+        ang = (rng.random(cnt) * 2.0 - 1.0) * half_fov
+        sizes = np.stack([f_lo + (f_hi - f_lo) * rng.random(cnt),
+                          f_lo + (f_hi - f_lo) * rng.random(cnt),
+                          h_lo + (h_hi - h_lo) * rng.random(cnt)], axis=1)
+        centers = np.stack([rad * np.cos(ang), rad * np.sin(ang),
+                            -sensor_h + 0.5 * sizes[:, 2]], axis=1)
+        yaws = rng.random(cnt) * np.pi
+        t_hit = np.minimum(t_hit, _ray_boxes(origin, dirs, centers, sizes,
+                                             yaws))
+    valid = np.isfinite(t_hit) & (t_hit >= 2.0) & (t_hit <= 70.0)
+    t = t_hit[valid] * (1.0 + noise * rng.standard_normal(valid.sum()))
+    pts = dirs[valid] * t[:, None]
+    # lidar (x fwd, y left, z up) -> camera (x right, y down, z fwd)
+    cam = np.stack([-pts[:, 1], -pts[:, 2], pts[:, 0]], axis=1)
+    rng2 = np.random.default_rng(seed + 1)
+    n = min(n_points, cam.shape[0])
+    sel = np.sort(rng2.choice(cam.shape[0], size=n, replace=False))
+    xyz = np.ascontiguousarray(cam[sel].astype(np.float32))
+    intensity = rng2.random((n, 1)).astype(np.float32)
+    return xyz, intensity
