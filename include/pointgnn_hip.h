@@ -1,0 +1,199 @@
+/* pointgnn_hip.h -- C ABI of libpointgnn_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the hot path of WeijingShi/Point-GNN.  The reference has
+ * no FFI layer (everything is Python calling TensorFlow 1.15 / scikit-learn);
+ * each entry point below names the reference interface it replaces
+ * (file:line relative to the reference tree).  Host code (Python, ctypes) keeps
+ * the reference's operator names and only moves pointers: see INTEGRATION.md.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the parameter says `host`;
+ *   - the caller owns every buffer; the library never frees or retains a
+ *     pointer past the call; scratch comes from a caller-provided workspace
+ *     sized by the matching *_workspace_bytes() query;
+ *   - every entry takes a hipStream_t (as void*) and is asynchronous with
+ *     respect to the host: no hidden synchronisation, no global mutable state;
+ *   - return value: 0 = ok, negative = argument error (PGNN_E_*), positive =
+ *     hipError_t of the failing runtime call.  pgnn_last_error() returns a
+ *     thread-local message for the last non-zero return.  No C++ exception
+ *     crosses the ABI;
+ *   - indices are int32 on the wire (run.py:126-133, train.py:126-128), all
+ *     floating point is fp32 unless stated;
+ *   - must not be called in a forked child after HIP was initialised in the
+ *     parent (the reference forks graph workers, train.py:430).
+ */
+#ifndef POINTGNN_HIP_H_
+#define POINTGNN_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PGNN_E_INVALID (-1)   /* bad argument (null pointer, negative size...) */
+#define PGNN_E_WORKSPACE (-2) /* workspace too small                          */
+#define PGNN_E_UNSUPPORTED (-3) /* shape outside the implemented range        */
+#define PGNN_E_CAPACITY (-4)  /* output capacity too small                    */
+
+/* ---- library ---------------------------------------------------------- */
+int pgnn_version(void);
+const char *pgnn_last_error(void);
+/* Sanity probe used by the Python loader: 0 iff `device_ptr` is a device
+ * allocation visible to the HIP runtime this library is bound to. */
+int pgnn_check_device_pointer(const void *device_ptr);
+
+/* ---- scatter-max -------------------------------------------------------
+ * Replaces graph_scatter_max_fn = tf.math.unsorted_segment_max
+ * (models/gnn.py:106-109; call sites gnn.py:275-277, 362-365).
+ * out[s, c] = max over rows r with seg_ids[r] == s of data[r, c]; a segment
+ * with no rows gets the lowest finite float (TF semantics).  Ids outside
+ * [0, num_segments) are ignored.  `ids_sorted` != 0 promises that seg_ids is
+ * non-decreasing (what the radius-graph builder emits): whole-segment runs
+ * are then written with plain stores instead of atomics.  Any order is
+ * accepted when ids_sorted == 0.  ld_* are row strides in floats.
+ * Algorithmic bytes: n_rows*n_cols*4 + n_rows*4 + num_segments*n_cols*4. */
+int pgnn_scatter_max_f32(const float *data, int64_t ld_data,
+                         const int32_t *seg_ids, int64_t n_rows,
+                         int32_t n_cols, int32_t num_segments, float *out,
+                         int64_t ld_out, int32_t ids_sorted, void *stream);
+
+/* ---- radius graph ------------------------------------------------------
+ * Replaces gen_disjointed_rnn_local_graph_v3 (models/graph_gen.py:197-220):
+ * for every centre, all points with float64 squared distance <= radius^2
+ * (inclusive; scikit-learn ball-tree semantics).  Two phases, no hidden
+ * sync:  count -> caller reads offsets[n_centers] and allocates -> fill.
+ * `scale3` (host pointer to 3 doubles, may be NULL) is the reference's
+ * optional `scale` pre-division (graph_gen.py:203-206).
+ * Output rows are (point_idx, centre_idx), grouped by ascending centre.  */
+size_t pgnn_radius_graph_workspace_bytes(int64_t n_points, int64_t n_centers);
+int pgnn_radius_graph_count(const float *points, int64_t n_points,
+                            const float *centers, int64_t n_centers,
+                            double radius, const double *scale3_host,
+                            void *workspace, size_t workspace_bytes,
+                            int32_t *offsets /* [n_centers + 1] */,
+                            void *stream);
+int pgnn_radius_graph_fill(const float *points, int64_t n_points,
+                           const float *centers, int64_t n_centers,
+                           double radius, const double *scale3_host,
+                           void *workspace, size_t workspace_bytes,
+                           const int32_t *offsets /* from _count */,
+                           int32_t *edges /* [capacity, 2] */,
+                           int64_t capacity, void *stream);
+/* Training-time fan-in cap (graph_gen.py:210-214, num_neighbors > 0): keeps a
+ * uniformly random subset (without replacement) of `max_neighbors` edges for
+ * every centre whose fan-in exceeds it (counter-based RNG keyed by `seed`,
+ * centre and position).  Two phases like the builder: _count writes
+ * new_offsets[n_centers + 1] from the uncapped CSR offsets; the caller reads
+ * the total and allocates; _fill writes the surviving rows, same grouping. */
+int pgnn_cap_neighbors_count(const int32_t *offsets, int64_t n_centers,
+                             int32_t max_neighbors, int32_t *new_offsets,
+                             void *stream);
+int pgnn_cap_neighbors_fill(const int32_t *offsets, const int32_t *edges,
+                            int64_t n_centers, int32_t max_neighbors,
+                            uint64_t seed, const int32_t *new_offsets,
+                            int32_t *new_edges, int64_t new_capacity,
+                            void *stream);
+
+/* ---- keypoints ----------------------------------------------------------
+ * 'center' mode = multi_layer_downsampling_select (graph_gen.py:49-90) for one
+ * pooling level: open3d-0.7 voxel centroids (origin = min_bound - voxel/2,
+ * float64 means in point order) followed by an exact float64 1-NN back to a
+ * real point.  Keypoints are emitted in ascending voxel-hash order.
+ * 'random' mode = multi_layer_downsampling_random (graph_gen.py:92-153): one
+ * uniformly chosen point per occupied voxel of the grid anchored at the
+ * cloud minimum (+ `jitter3_host`, the reference's add_rnd3d origin shift,
+ * in units of metres; NULL = none), RNG keyed by `seed`.
+ * Capacity of both outputs is n_points rows; *num_keypoints (device) receives
+ * K.                                                                       */
+size_t pgnn_keypoints_workspace_bytes(int64_t n_points);
+int pgnn_voxel_keypoints_center(const float *points, int64_t n_points,
+                                double voxel_size, void *workspace,
+                                size_t workspace_bytes,
+                                int32_t *keypoint_indices, float *keypoint_xyz,
+                                int32_t *num_keypoints, void *stream);
+int pgnn_voxel_keypoints_random(const float *points, int64_t n_points,
+                                double voxel_size, const double *jitter3_host,
+                                uint64_t seed, void *workspace,
+                                size_t workspace_bytes,
+                                int32_t *keypoint_indices, float *keypoint_xyz,
+                                int32_t *num_keypoints, void *stream);
+
+/* ---- dense layers --------------------------------------------------------
+ * A fully connected layer y = act(x @ W + b) (slim.fully_connected with
+ * normalizer 'NONE', models/gnn.py:86-104 and :34-84) is held on the device in
+ * MFMA-fragment order: pgnn_pack_fc() converts the reference's [k_in, n_out]
+ * row-major weights + bias (HOST pointers) into `packed` (HOST, then copied to
+ * the device by the caller).  Layout: kq = ceil(k_in/16) K-groups, nt =
+ * ceil(n_out/16) column tiles; packed[((q*nt + t)*64 + lane)*4 + s] =
+ * W[16q + 4*(lane>>4) + s][16t + (lane&15)] (zero outside), followed by
+ * bias[16*nt] (zero padded).                                               */
+size_t pgnn_packed_fc_floats(int32_t k_in, int32_t n_out);
+int pgnn_pack_fc(const float *w_host, const float *b_host, int32_t k_in,
+                 int32_t n_out, float *packed_host);
+
+typedef struct pgnn_fc_layer {
+  const float *packed; /* device: pgnn_pack_fc image                         */
+  int32_t k_in;        /* logical input width (<= 16*kq)                     */
+  int32_t n_out;       /* logical output width                               */
+  int32_t relu_from;   /* ReLU on output columns >= relu_from; 0 = every
+                          column, >= n_out = linear layer (is_logits)        */
+} pgnn_fc_layer;
+
+#define PGNN_MAX_LAYERS 8
+
+/* Per-row MLP chain: y = MLP(concat(x[:, :nx], x2[:, :nx2])) (+ residual).
+ * Covers multi_layer_neural_network_fn / multi_layer_fc_fn on per-vertex
+ * inputs: PointSetPooling's output MLP (gnn.py:279-282), the auto-offset MLP
+ * (gnn.py:341-346), the update MLP + residual (gnn.py:367-372) and, with a
+ * block-diagonal packing, ClassAwarePredictor (gnn.py:133-163).  x2 / residual
+ * may be NULL.  y receives 16*ceil(n_out_last/16) columns per row (zero
+ * padded), so ld_y must be >= that.                                         */
+int pgnn_mlp_fwd(const float *x, int64_t ld_x, int32_t nx, const float *x2,
+                 int64_t ld_x2, int32_t nx2, int64_t n_rows,
+                 const pgnn_fc_layer *layers_host, int32_t n_layers,
+                 const float *residual, int64_t ld_res, float *y, int64_t ld_y,
+                 void *stream);
+
+/* Fused PointSetPooling front half (gnn.py:256-277): for every edge
+ * (point, keypoint) build [features(point), xyz(point) - xyz(keypoint)], run
+ * the point MLP (every layer ReLU) and scatter-max into the keypoint row.
+ * Nothing of size E x C touches HBM.  `edges` must be grouped by ascending
+ * keypoint when edges_sorted != 0.  out: [num_keypoints, ld_out], columns
+ * 16*ceil(n_out/16) written (zero padded); keypoints without edges get
+ * float lowest (TF unsorted_segment_max).                                   */
+int pgnn_point_set_pooling_fwd(const float *point_features, int32_t n_feat,
+                               const float *point_xyz,
+                               const int32_t *keypoint_indices,
+                               const int32_t *edges, int64_t n_edges,
+                               int32_t num_keypoints,
+                               const pgnn_fc_layer *layers_host,
+                               int32_t n_layers, int32_t edges_sorted,
+                               float *out, int64_t ld_out, void *stream);
+
+/* Fused GraphNetAutoCenter edge stage (gnn.py:338-365).  The first edge layer
+ * is linear before its ReLU, so with P = [h, x] @ W1 + b1 and Q = x' @ W1[C:]
+ * (both per vertex, computed by pgnn_mlp_fwd / pgnn_offset_apply) the
+ * per-edge hidden vector is ReLU(P[src] - Q[dst]); this entry gathers it,
+ * applies the remaining edge layers (ReLU) and scatter-maxes into dst rows.
+ * P, Q: [num_vertices, ld_pq] with ld_pq = 16*ceil(width/16), zero padded.  */
+int pgnn_edge_mlp_scatter_max_fwd(const float *P, const float *Q,
+                                  int64_t ld_pq, int32_t width,
+                                  const int32_t *edges, int64_t n_edges,
+                                  int32_t num_vertices,
+                                  const pgnn_fc_layer *layers_host,
+                                  int32_t n_layers, int32_t edges_sorted,
+                                  float *out, int64_t ld_out, void *stream);
+
+/* x' = x + delta (gnn.py:346) and Q = x' @ Wx where Wx = the last 3 rows of
+ * the first edge layer's weights (the rows that multiply the coordinate part
+ * of the concat, gnn.py:350-352).  wx: device [3, ld_q] (zero padded).      */
+int pgnn_offset_apply(const float *xyz, const float *delta, int64_t ld_delta,
+                      int64_t n_rows, const float *wx, float *xyz_out,
+                      float *Q, int64_t ld_q, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POINTGNN_HIP_H_ */

@@ -1,0 +1,121 @@
+"""ctypes binding of libpointgnn_hip.so (include/pointgnn_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing or a
+call fails, this module raises.  torch is imported first so that the library's
+`libamdhip64.so.7` dependency resolves to the HIP runtime PyTorch already
+loaded (one runtime per process: torch's streams and allocations are then
+valid inside the library).
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must precede CDLL, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpointgnn_hip.so")
+
+c_i32, c_i64, c_f64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_double
+c_vp, c_sz, c_u64 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint64
+
+PGNN_MAX_LAYERS = 8
+
+
+class FcLayer(ctypes.Structure):
+    """struct pgnn_fc_layer"""
+    _fields_ = [("packed", c_vp), ("k_in", c_i32), ("n_out", c_i32),
+                ("relu_from", c_i32)]
+
+
+class PointGnnHipError(RuntimeError):
+    pass
+
+
+_SIGNATURES = {
+    # name: (restype, argtypes)
+    "pgnn_version": (c_i32, []),
+    "pgnn_last_error": (ctypes.c_char_p, []),
+    "pgnn_check_device_pointer": (c_i32, [c_vp]),
+    "pgnn_set_tunable": (c_i32, [ctypes.c_char_p, c_i32]),
+    "pgnn_scatter_max_f32": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_i32,
+                                     c_vp, c_i64, c_i32, c_vp]),
+    "pgnn_radius_graph_workspace_bytes": (c_sz, [c_i64, c_i64]),
+    "pgnn_radius_graph_count": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_f64, c_vp,
+                                        c_vp, c_sz, c_vp, c_vp]),
+    "pgnn_radius_graph_fill": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_f64, c_vp,
+                                       c_vp, c_sz, c_vp, c_vp, c_i64, c_vp]),
+    "pgnn_cap_neighbors_count": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp]),
+    "pgnn_cap_neighbors_fill": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_u64, c_vp,
+                                        c_vp, c_i64, c_vp]),
+    "pgnn_keypoints_workspace_bytes": (c_sz, [c_i64]),
+    "pgnn_voxel_keypoints_center": (c_i32, [c_vp, c_i64, c_f64, c_vp, c_sz,
+                                            c_vp, c_vp, c_vp, c_vp]),
+    "pgnn_voxel_keypoints_random": (c_i32, [c_vp, c_i64, c_f64, c_vp, c_u64,
+                                            c_vp, c_sz, c_vp, c_vp, c_vp,
+                                            c_vp]),
+    "pgnn_packed_fc_floats": (c_sz, [c_i32, c_i32]),
+    "pgnn_pack_fc": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp]),
+    "pgnn_mlp_fwd": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_i64,
+                             ctypes.POINTER(FcLayer), c_i32, c_vp, c_i64, c_vp,
+                             c_i64, c_vp]),
+    "pgnn_point_set_pooling_fwd": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp,
+                                           c_i64, c_i32,
+                                           ctypes.POINTER(FcLayer), c_i32,
+                                           c_i32, c_vp, c_i64, c_vp]),
+    "pgnn_edge_mlp_scatter_max_fwd": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp,
+                                              c_i64, c_i32,
+                                              ctypes.POINTER(FcLayer), c_i32,
+                                              c_i32, c_vp, c_i64, c_vp]),
+    "pgnn_offset_apply": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp,
+                                  c_i64, c_vp]),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    """Names every entry point include/pointgnn_hip.h declares."""
+    return sorted(_SIGNATURES)
+
+
+def load():
+    """Load (once) and return the ctypes library.  Raises when it is missing:
+    build it with `python -m pointgnn_amd.build` (or __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PointGnnHipError(
+            "libpointgnn_hip.so not found at %s -- the HIP extension is "
+            "required (no CPU fallback); run `python -m pointgnn_amd.build`"
+            % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks the symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    """Raise on a non-zero return code of a pgnn_* call."""
+    if rc != 0:
+        msg = load().pgnn_last_error()
+        raise PointGnnHipError("%s failed (code %d): %s" % (
+            what or "pgnn call", rc, msg.decode() if msg else "?"))
+
+
+def stream_ptr():
+    """hipStream_t of torch's current stream as void* (0 = null stream)."""
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    if t is None:
+        return ctypes.c_void_p(0)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def set_tunable(key, value):
+    check(load().pgnn_set_tunable(key.encode(), int(value)), "pgnn_set_tunable")

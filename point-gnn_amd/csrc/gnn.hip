@@ -1,0 +1,461 @@
+// Fused GNN kernels (models/gnn.py): every kernel is "prologue -> MLP chain on
+// an LDS-resident row tile (mlp_engine.h) -> epilogue", persistent over tiles.
+//
+//   prologue ROWS : rows of a [n, ld] matrix (optionally concat of two)
+//            POOL : PointSetPooling edge features  [f(src), xyz(src)-xyz(kp(dst))]
+//                   (gnn.py:256-267)
+//            EDGE : GraphNetAutoCenter hidden vector ReLU(P[src] - Q[dst])
+//                   (first edge layer factored per vertex, gnn.py:338-356)
+//   epilogue ROWS : rows (+ residual) to HBM, coalesced
+//            SEGMAX: scatter-max over runs of equal dst inside the tile
+//                   (gnn.py:275-277, 362-365); runs wholly inside the tile are
+//                   complete segments (sorted edges) and are stored plainly,
+//                   boundary runs use float atomic-max.
+// The E x C activations never reach HBM.
+#include "mlp_engine.h"
+
+namespace pgnn {
+int g_mlp_blocks_per_cu = 2;
+}
+
+namespace {
+using namespace pgnn;
+
+enum { PRO_ROWS = 0, PRO_POOL = 1, PRO_EDGE = 2 };
+
+struct RowsArgs {
+  const float *x;
+  int64_t ldx;
+  int nx;
+  const float *x2;
+  int64_t ldx2;
+  int nx2;
+  const float *res;
+  int64_t ldres;
+  float *y;
+  int64_t ldy;
+};
+struct PoolArgs {
+  const float *feat;
+  int nfeat;
+  const float *xyz;
+  const int32_t *kp;
+  const int32_t *edges;
+};
+struct EdgeArgs {
+  const float *P;
+  const float *Q;
+  int64_t ldpq;
+  const int32_t *edges;
+};
+struct SegArgs {
+  float *out;
+  int64_t ldo;
+  int num_segments;
+  int sorted;
+};
+
+__host__ __device__ inline int ints_bytes(int rows) {
+  return ((rows + 2) * 4 + 15) / 16 * 16;
+}
+
+// Column-wise segmented max of stage[ROWS][ncols] keyed by dst[1..ROWS]
+// (dst[0] / dst[ROWS+1] = id of the edge before / after the tile, -1 if none).
+template <int ROWS>
+__device__ __forceinline__ void consume_segmax(const float *__restrict__ stage,
+                                               int ld, const int *__restrict__ dst,
+                                               int col0, int ncols,
+                                               const SegArgs &sa) {
+  for (int c = threadIdx.x; c < ncols; c += 256) {
+    int r = 0;
+    while (r < ROWS) {
+      const int d = dst[r + 1];
+      int re = r + 1;
+      while (re < ROWS && dst[re + 1] == d) ++re;
+      if (d >= 0 && d < sa.num_segments) {
+        float m = stage[r * ld + c];
+        for (int k = r + 1; k < re; ++k) m = fmaxf(m, stage[k * ld + c]);
+        const bool whole = sa.sorted && (r > 0 || dst[0] != d) &&
+                           (re < ROWS || dst[ROWS + 1] != d);
+        float *o = sa.out + (int64_t)d * sa.ldo + col0 + c;
+        if (whole)
+          *o = m;
+        else
+          atomic_max_f32(o, m + 0.0f);
+      }
+      r = re;
+    }
+  }
+}
+
+template <int ROWS>
+__device__ __forceinline__ void consume_rows(const float *__restrict__ stage,
+                                             int ld, int64_t row0, int rows_valid,
+                                             int col0, int ncols,
+                                             const RowsArgs &ra) {
+  const int total = rows_valid * ncols;
+  for (int idx = threadIdx.x; idx < total; idx += 256) {
+    const int r = idx / ncols, c = idx - r * ncols;
+    float v = stage[r * ld + c];
+    if (ra.res) v += ra.res[(row0 + r) * ra.ldres + col0 + c];
+    ra.y[(row0 + r) * ra.ldy + col0 + c] = v;
+  }
+}
+
+template <int MSUB, int PRO>
+__global__ __launch_bounds__(256, 2) void fused_mlp_kernel(
+    ChainDev chain, int64_t n_rows, RowsArgs ra, PoolArgs pa, EdgeArgs ea,
+    SegArgs sa, int stage_off /* floats from tile base; < 0: in place */) {
+  constexpr int ROWS = 16 * MSUB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int *dst = reinterpret_cast<int *>(smem);
+  float *tile = reinterpret_cast<float *>(smem + ints_bytes(ROWS));
+  float *stage = stage_off >= 0 ? tile + stage_off : tile;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t n_tiles = (n_rows + ROWS - 1) / ROWS;
+  const int ld0 = lds_ld(16 * chain.l[0].kq);
+
+  for (int64_t tile_id = blockIdx.x; tile_id < n_tiles; tile_id += gridDim.x) {
+    const int64_t row0 = tile_id * ROWS;
+    const int rows_valid =
+        (int)((n_rows - row0 < ROWS) ? (n_rows - row0) : ROWS);
+    // ------------------------------------------------------------ prologue
+    if (PRO == PRO_ROWS) {
+      const int kc = 16 * chain.l[0].kq;
+      for (int idx = threadIdx.x; idx < ROWS * kc; idx += 256) {
+        const int r = idx / kc, c = idx - r * kc;
+        float v = 0.0f;
+        if (r < rows_valid) {
+          if (c < ra.nx)
+            v = ra.x[(row0 + r) * ra.ldx + c];
+          else if (c < ra.nx + ra.nx2)
+            v = ra.x2[(row0 + r) * ra.ldx2 + (c - ra.nx)];
+        }
+        tile[r * ld0 + c] = v;
+      }
+    } else if (PRO == PRO_POOL) {  // first layer has kq == 1 (checked on host)
+      if (threadIdx.x < ROWS) {
+        const int r = threadIdx.x;
+        const int64_t e = row0 + r;
+        float f[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) f[i] = 0.0f;
+        int d = -1;
+        if (e < n_rows) {
+          const int s = pa.edges[2 * e];
+          d = pa.edges[2 * e + 1];
+          const int k = pa.kp[d];
+#pragma unroll
+          for (int i = 0; i < 13; ++i)
+            if (i < pa.nfeat) f[i] = pa.feat[(int64_t)s * pa.nfeat + i];
+          // points within a set use coordinates relative to its keypoint
+          const float rx = pa.xyz[3 * (int64_t)s] - pa.xyz[3 * (int64_t)k];
+          const float ry = pa.xyz[3 * (int64_t)s + 1] - pa.xyz[3 * (int64_t)k + 1];
+          const float rz = pa.xyz[3 * (int64_t)s + 2] - pa.xyz[3 * (int64_t)k + 2];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            if (i == pa.nfeat) f[i] = rx;
+            if (i == pa.nfeat + 1) f[i] = ry;
+            if (i == pa.nfeat + 2) f[i] = rz;
+          }
+        }
+        dst[r + 1] = d;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) tile[r * ld0 + c] = f[c];
+      }
+      if (threadIdx.x == 64)
+        dst[0] = row0 > 0 ? pa.edges[2 * (row0 - 1) + 1] : -1;
+      if (threadIdx.x == 65)
+        dst[ROWS + 1] =
+            row0 + ROWS < n_rows ? pa.edges[2 * (row0 + ROWS) + 1] : -1;
+    } else {  // PRO_EDGE
+      constexpr int RPW = ROWS / 4;  // rows per wave
+      const int ldv4 = (int)(ea.ldpq >> 2);
+      const v4f *__restrict__ P4 = reinterpret_cast<const v4f *>(ea.P);
+      const v4f *__restrict__ Q4 = reinterpret_cast<const v4f *>(ea.Q);
+      const int64_t ebase = row0 + wave * RPW;
+      int my_s = 0, my_d = -1;
+      if (lane < RPW && ebase + lane < n_rows) {
+        my_s = ea.edges[2 * (ebase + lane)];
+        my_d = ea.edges[2 * (ebase + lane) + 1];
+      }
+      if (lane < RPW) dst[wave * RPW + lane + 1] = my_d;
+      if (threadIdx.x == 0)
+        dst[0] = row0 > 0 ? ea.edges[2 * (row0 - 1) + 1] : -1;
+      if (threadIdx.x == 64)
+        dst[ROWS + 1] =
+            row0 + ROWS < n_rows ? ea.edges[2 * (row0 + ROWS) + 1] : -1;
+#pragma unroll
+      for (int r = 0; r < RPW; ++r) {
+        const int s = __builtin_amdgcn_readlane(my_s, r);
+        const int d = __builtin_amdgcn_readlane(my_d, r);
+        float *trow = tile + (wave * RPW + r) * ld0;
+        for (int c4 = lane; c4 < ldv4; c4 += 64) {
+          v4f h = (v4f){0.f, 0.f, 0.f, 0.f};
+          if (d >= 0) {
+            const v4f p = P4[(int64_t)s * ldv4 + c4];
+            const v4f q = Q4[(int64_t)d * ldv4 + c4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float t = p[i] - q[i];
+              h[i] = t > 0.0f ? t : 0.0f;
+            }
+          }
+          *reinterpret_cast<v4f *>(trow + 4 * c4) = h;
+        }
+      }
+    }
+    __syncthreads();
+    // ------------------------------------------------------------ hidden layers
+    for (int li = 0; li + 1 < chain.n; ++li) {
+      const LayerDev &L = chain.l[li];
+      layer_pass_dispatch<MSUB>(tile, lds_ld(16 * L.kq), tile, lds_ld(16 * L.nt),
+                                L, 0, wave, lane);
+    }
+    // ------------------------------------------------------------ last layer
+    {
+      const LayerDev &L = chain.l[chain.n - 1];
+      const int ld_in = lds_ld(16 * L.kq);
+      for (int t0 = 0; t0 < L.nt; t0 += kMaxTilesPerPass) {
+        int tiles = L.nt - t0;
+        if (tiles > kMaxTilesPerPass) tiles = kMaxTilesPerPass;
+        const int ncols = 16 * tiles;
+        const int ld_st = lds_ld(ncols);
+        layer_pass_dispatch<MSUB>(tile, ld_in, stage, ld_st, L, t0, wave, lane);
+        if (PRO == PRO_ROWS)
+          consume_rows<ROWS>(stage, ld_st, row0, rows_valid, 16 * t0, ncols, ra);
+        else
+          consume_segmax<ROWS>(stage, ld_st, dst, 16 * t0, ncols, sa);
+        __syncthreads();
+      }
+    }
+  }
+}
+
+__global__ void offset_apply_kernel(const float *__restrict__ xyz,
+                                    const float *__restrict__ delta,
+                                    int64_t ld_delta, int64_t n,
+                                    const float *__restrict__ wx,
+                                    float *__restrict__ xyz_out,
+                                    float *__restrict__ Q, int64_t ld_q) {
+  const int64_t total = n * ld_q;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = idx / ld_q;
+    const int c = (int)(idx - r * ld_q);
+    float x0 = xyz[3 * r], x1 = xyz[3 * r + 1], x2 = xyz[3 * r + 2];
+    if (delta) {
+      x0 = x0 + delta[r * ld_delta];
+      x1 = x1 + delta[r * ld_delta + 1];
+      x2 = x2 + delta[r * ld_delta + 2];
+    }
+    if (c < 3 && xyz_out) xyz_out[3 * r + c] = c == 0 ? x0 : (c == 1 ? x1 : x2);
+    Q[idx] = (x0 * wx[c] + x1 * wx[ld_q + c]) + x2 * wx[2 * ld_q + c];
+  }
+}
+
+// ---- host side -----------------------------------------------------------------
+struct Plan {
+  ChainDev chain;
+  int tile_floats_per_row;  // max ld over in-place activations
+  int stage_cols;           // 0: last layer in place; else staged pass width
+};
+
+int make_plan(const pgnn_fc_layer *layers, int32_t n_layers, int first_k,
+              Plan &p) {
+  PGNN_REQUIRE(layers && n_layers >= 1 && n_layers <= PGNN_MAX_LAYERS,
+               PGNN_E_INVALID, "mlp: 1..PGNN_MAX_LAYERS layers required");
+  p.chain.n = n_layers;
+  int prev_nt = -1;
+  int max_ld = 0;
+  for (int i = 0; i < n_layers; ++i) {
+    const pgnn_fc_layer &l = layers[i];
+    PGNN_REQUIRE(l.packed && l.k_in > 0 && l.n_out > 0, PGNN_E_INVALID,
+                 "mlp: bad layer");
+    LayerDev &d = p.chain.l[i];
+    d.wp = l.packed;
+    d.kq = (l.k_in + 15) / 16;
+    d.nt = (l.n_out + 15) / 16;
+    d.relu_from = l.relu_from;
+    if (i == 0) {
+      PGNN_REQUIRE(first_k <= l.k_in, PGNN_E_INVALID,
+                   "mlp: input wider than first layer");
+    } else {
+      PGNN_REQUIRE(d.kq == prev_nt, PGNN_E_INVALID,
+                   "mlp: layer widths do not chain");
+    }
+    if (i + 1 < n_layers)
+      PGNN_REQUIRE(d.nt <= kMaxTilesPerPass, PGNN_E_UNSUPPORTED,
+                   "mlp: hidden width > 320 not supported");
+    prev_nt = d.nt;
+    const int ld_in = lds_ld(16 * d.kq);
+    if (ld_in > max_ld) max_ld = ld_in;
+    if (i + 1 < n_layers || d.nt <= kMaxTilesPerPass) {
+      const int ld_out = lds_ld(16 * d.nt);
+      if (ld_out > max_ld) max_ld = ld_out;
+    }
+  }
+  p.tile_floats_per_row = max_ld;
+  p.stage_cols =
+      p.chain.l[n_layers - 1].nt > kMaxTilesPerPass ? 16 * kMaxTilesPerPass : 0;
+  return 0;
+}
+
+size_t plan_lds_bytes(const Plan &p, int rows) {
+  size_t floats = (size_t)rows * p.tile_floats_per_row;
+  if (p.stage_cols) floats += (size_t)rows * lds_ld(p.stage_cols);
+  return ints_bytes(rows) + floats * 4;
+}
+
+template <int MSUB, int PRO>
+int launch_fused(const Plan &p, int64_t n_rows, const RowsArgs &ra,
+                 const PoolArgs &pa, const EdgeArgs &ea, const SegArgs &sa,
+                 hipStream_t stream) {
+  constexpr int ROWS = 16 * MSUB;
+  const size_t lds = plan_lds_bytes(p, ROWS);
+  PGNN_REQUIRE(lds <= 160 * 1024, PGNN_E_UNSUPPORTED,
+               "mlp: layer too wide for the LDS tile");
+  auto kern = fused_mlp_kernel<MSUB, PRO>;
+  PGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                               hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)lds));
+  const int64_t n_tiles = (n_rows + ROWS - 1) / ROWS;
+  int per_cu = (int)((160 * 1024) / lds);
+  if (per_cu > g_mlp_blocks_per_cu) per_cu = g_mlp_blocks_per_cu;
+  if (per_cu < 1) per_cu = 1;
+  int64_t grid = (int64_t)device_cu_count() * per_cu;
+  if (grid > n_tiles) grid = n_tiles;
+  const int stage_off = p.stage_cols ? ROWS * p.tile_floats_per_row : -1;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, stream, p.chain,
+                     n_rows, ra, pa, ea, sa, stage_off);
+  PGNN_HIP(hipGetLastError());
+  return 0;
+}
+
+int fill_lowest(float *out, int64_t count, hipStream_t stream) {
+  PGNN_HIP(hipMemsetD32Async((hipDeviceptr_t)out, (int)kFloatLowestBits,
+                             (size_t)count, stream));
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int pgnn_mlp_fwd(const float *x, int64_t ld_x, int32_t nx,
+                            const float *x2, int64_t ld_x2, int32_t nx2,
+                            int64_t n_rows, const pgnn_fc_layer *layers,
+                            int32_t n_layers, const float *residual,
+                            int64_t ld_res, float *y, int64_t ld_y,
+                            void *stream_) {
+  PGNN_GUARD_BEGIN
+  hipStream_t stream = (hipStream_t)stream_;
+  PGNN_REQUIRE(n_rows >= 0 && nx > 0 && nx2 >= 0, PGNN_E_INVALID,
+               "mlp_fwd: bad sizes");
+  if (n_rows == 0) return 0;
+  PGNN_REQUIRE(x && y && ld_x >= nx && (nx2 == 0 || (x2 && ld_x2 >= nx2)),
+               PGNN_E_INVALID, "mlp_fwd: bad input");
+  Plan p;
+  int rc = make_plan(layers, n_layers, nx + nx2, p);
+  if (rc) return rc;
+  const int out_cols = 16 * p.chain.l[n_layers - 1].nt;
+  PGNN_REQUIRE(ld_y >= out_cols && (!residual || ld_res >= out_cols),
+               PGNN_E_INVALID, "mlp_fwd: ld_y/ld_res < padded output width");
+  RowsArgs ra = {x, ld_x, nx, x2, ld_x2, nx2, residual, ld_res, y, ld_y};
+  PoolArgs pa = {};
+  EdgeArgs ea = {};
+  SegArgs sa = {};
+  // small row counts: 16-row tiles keep all CUs busy; large: 64-row tiles
+  if (n_rows <= 64 * (int64_t)device_cu_count())
+    return launch_fused<1, PRO_ROWS>(p, n_rows, ra, pa, ea, sa, stream);
+  return launch_fused<4, PRO_ROWS>(p, n_rows, ra, pa, ea, sa, stream);
+  PGNN_GUARD_END
+}
+
+extern "C" int pgnn_point_set_pooling_fwd(
+    const float *point_features, int32_t n_feat, const float *point_xyz,
+    const int32_t *keypoint_indices, const int32_t *edges, int64_t n_edges,
+    int32_t num_keypoints, const pgnn_fc_layer *layers, int32_t n_layers,
+    int32_t edges_sorted, float *out, int64_t ld_out, void *stream_) {
+  PGNN_GUARD_BEGIN
+  hipStream_t stream = (hipStream_t)stream_;
+  PGNN_REQUIRE(n_edges >= 0 && num_keypoints >= 0 && n_feat >= 0 && n_feat <= 13,
+               PGNN_E_INVALID, "pooling: bad sizes (n_feat <= 13)");
+  Plan p;
+  int rc = make_plan(layers, n_layers, n_feat + 3, p);
+  if (rc) return rc;
+  PGNN_REQUIRE(p.chain.l[0].kq == 1, PGNN_E_UNSUPPORTED,
+               "pooling: first layer k_in must be <= 16");
+  const int out_cols = 16 * p.chain.l[n_layers - 1].nt;
+  PGNN_REQUIRE(out && ld_out >= out_cols, PGNN_E_INVALID,
+               "pooling: ld_out < padded output width");
+  if (num_keypoints == 0) return 0;
+  rc = fill_lowest(out, (int64_t)num_keypoints * ld_out, stream);
+  if (rc) return rc;
+  if (n_edges == 0) return 0;
+  PGNN_REQUIRE((n_feat == 0 || point_features) && point_xyz &&
+                   keypoint_indices && edges,
+               PGNN_E_INVALID, "pooling: null input");
+  RowsArgs ra = {};
+  PoolArgs pa = {point_features, n_feat, point_xyz, keypoint_indices, edges};
+  EdgeArgs ea = {};
+  SegArgs sa = {out, ld_out, num_keypoints, edges_sorted};
+  if (plan_lds_bytes(p, 64) <= 80 * 1024 || plan_lds_bytes(p, 32) > 80 * 1024)
+    return launch_fused<4, PRO_POOL>(p, n_edges, ra, pa, ea, sa, stream);
+  return launch_fused<2, PRO_POOL>(p, n_edges, ra, pa, ea, sa, stream);
+  PGNN_GUARD_END
+}
+
+extern "C" int pgnn_edge_mlp_scatter_max_fwd(
+    const float *P, const float *Q, int64_t ld_pq, int32_t width,
+    const int32_t *edges, int64_t n_edges, int32_t num_vertices,
+    const pgnn_fc_layer *layers, int32_t n_layers, int32_t edges_sorted,
+    float *out, int64_t ld_out, void *stream_) {
+  PGNN_GUARD_BEGIN
+  hipStream_t stream = (hipStream_t)stream_;
+  PGNN_REQUIRE(n_edges >= 0 && num_vertices >= 0 && width > 0, PGNN_E_INVALID,
+               "edge_mlp: bad sizes");
+  Plan p;
+  int rc = make_plan(layers, n_layers, width, p);
+  if (rc) return rc;
+  PGNN_REQUIRE(ld_pq == 16 * p.chain.l[0].kq, PGNN_E_INVALID,
+               "edge_mlp: ld_pq must equal the padded width 16*ceil(width/16)");
+  const int out_cols = 16 * p.chain.l[n_layers - 1].nt;
+  PGNN_REQUIRE(out && ld_out >= out_cols, PGNN_E_INVALID,
+               "edge_mlp: ld_out < padded output width");
+  if (num_vertices == 0) return 0;
+  rc = fill_lowest(out, (int64_t)num_vertices * ld_out, stream);
+  if (rc) return rc;
+  if (n_edges == 0) return 0;
+  PGNN_REQUIRE(P && Q && edges, PGNN_E_INVALID, "edge_mlp: null input");
+  PGNN_REQUIRE(((uintptr_t)P % 16 == 0) && ((uintptr_t)Q % 16 == 0),
+               PGNN_E_INVALID, "edge_mlp: P/Q must be 16-byte aligned");
+  RowsArgs ra = {};
+  PoolArgs pa = {};
+  EdgeArgs ea = {P, Q, ld_pq, edges};
+  SegArgs sa = {out, ld_out, num_vertices, edges_sorted};
+  if (plan_lds_bytes(p, 64) <= 80 * 1024 || plan_lds_bytes(p, 32) > 80 * 1024)
+    return launch_fused<4, PRO_EDGE>(p, n_edges, ra, pa, ea, sa, stream);
+  return launch_fused<2, PRO_EDGE>(p, n_edges, ra, pa, ea, sa, stream);
+  PGNN_GUARD_END
+}
+
+extern "C" int pgnn_offset_apply(const float *xyz, const float *delta,
+                                 int64_t ld_delta, int64_t n_rows,
+                                 const float *wx, float *xyz_out, float *Q,
+                                 int64_t ld_q, void *stream_) {
+  PGNN_GUARD_BEGIN
+  hipStream_t stream = (hipStream_t)stream_;
+  PGNN_REQUIRE(n_rows >= 0 && ld_q >= 3, PGNN_E_INVALID,
+               "offset_apply: bad sizes");
+  if (n_rows == 0) return 0;
+  PGNN_REQUIRE(xyz && wx && Q && (!delta || ld_delta >= 3), PGNN_E_INVALID,
+               "offset_apply: null input");
+  const int64_t total = n_rows * ld_q;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(offset_apply_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     stream, xyz, delta, ld_delta, n_rows, wx, xyz_out, Q, ld_q);
+  PGNN_HIP(hipGetLastError());
+  return 0;
+  PGNN_GUARD_END
+}

@@ -1,0 +1,750 @@
+// Graph construction on the device: counting-sort spatial hash + fixed-radius
+// search (models/graph_gen.py:197-220) and voxel keypoint selection
+// (graph_gen.py:41-45, 84-88, 92-153).
+//
+// Points are bucketed by hashing their integer cell coordinates
+// (cell edge = search radius, resp. voxel size) into 2^b buckets and stably
+// sorted by bucket (sort.hip), so every bucket is a contiguous, index-ordered
+// slice.  A query sweeps the cells that can contain a neighbour, visits each
+// cell's bucket slice with the 64 lanes of a wave (coalesced 32-byte records),
+// keeps candidates whose own cell equals the swept cell (hash collisions and
+// double visits drop out here) and applies the reference's predicate in
+// float64:  ((px-cx)^2 + (py-cy)^2) + (pz-cz)^2 <= r*r  -- three separately
+// rounded products, inclusive, exactly scikit-learn's ball-tree test on
+// float64 data.  This file is compiled with -ffp-contract=off.
+//
+// HBM traffic is a few MB per frame; these kernels are latency- and
+// launch-bound, not bandwidth-bound (DESIGN.md "Graph kernels").
+#include <math.h>
+
+#include "sort.h"
+
+namespace pgnn {
+namespace {
+
+struct __attribute__((aligned(32))) SortedPoint {
+  double x, y, z;
+  int32_t idx;
+  int32_t pad;
+};
+
+__device__ __forceinline__ uint32_t cell_hash(int cx, int cy, int cz,
+                                              uint32_t mask) {
+  uint32_t h = (uint32_t)cx * 73856093u ^ (uint32_t)cy * 19349663u ^
+               (uint32_t)cz * 83492791u;
+  h ^= h >> 15;  // fold the high bits into the bucket range
+  return h & mask;
+}
+
+// Cell coordinate of a float64 position in a grid of edge `cell` anchored at
+// `origin`.  The same function is used to build and to query, so membership
+// tests are exact regardless of rounding.
+__device__ __forceinline__ int cell_of(double v, double origin, double cell) {
+  return (int)floor((v - origin) / cell);
+}
+
+struct Scale3 {
+  double x, y, z;
+  int on;
+};
+
+__device__ __forceinline__ void load_point(const float *p, int64_t i,
+                                           const Scale3 &sc, double &x,
+                                           double &y, double &z) {
+  x = (double)p[3 * i];
+  y = (double)p[3 * i + 1];
+  z = (double)p[3 * i + 2];
+  if (sc.on) {  // graph_gen.py:203-206: float32 array / float64 scale
+    x = x / sc.x;
+    y = y / sc.y;
+    z = z / sc.z;
+  }
+}
+
+// ---- build -------------------------------------------------------------------
+__global__ void cell_keys_kernel(const float *__restrict__ pts, int64_t n,
+                                 Scale3 sc, double ox, double oy, double oz,
+                                 const double *__restrict__ origin_dev,
+                                 double cell, uint32_t mask,
+                                 uint32_t *__restrict__ keys,
+                                 uint32_t *__restrict__ vals) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (origin_dev) {
+    ox = origin_dev[0];
+    oy = origin_dev[1];
+    oz = origin_dev[2];
+  }
+  double x, y, z;
+  load_point(pts, i, sc, x, y, z);
+  keys[i] = cell_hash(cell_of(x, ox, cell), cell_of(y, oy, cell),
+                      cell_of(z, oz, cell), mask);
+  vals[i] = (uint32_t)i;
+}
+
+__global__ void cell_bounds_kernel(const uint32_t *__restrict__ keys,
+                                   const uint32_t *__restrict__ vals, int64_t n,
+                                   const float *__restrict__ pts, Scale3 sc,
+                                   int32_t *__restrict__ cell_start,
+                                   int32_t *__restrict__ cell_end,
+                                   SortedPoint *__restrict__ sorted) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t k = keys[i];
+  if (i == 0 || keys[i - 1] != k) cell_start[k] = (int32_t)i;
+  if (i == n - 1 || keys[i + 1] != k) cell_end[k] = (int32_t)(i + 1);
+  SortedPoint sp;
+  const uint32_t idx = vals[i];
+  load_point(pts, idx, sc, sp.x, sp.y, sp.z);
+  sp.idx = (int32_t)idx;
+  sp.pad = 0;
+  sorted[i] = sp;
+}
+
+// ---- radius search -------------------------------------------------------------
+// One wave per centre.  FILL = false: write the neighbour count; FILL = true:
+// write (point, centre) rows at offsets[centre].
+template <bool FILL>
+__global__ __launch_bounds__(256) void radius_query_kernel(
+    const float *__restrict__ centers, int64_t n_centers, Scale3 sc, double r,
+    uint32_t mask, const int32_t *__restrict__ cell_start,
+    const int32_t *__restrict__ cell_end,
+    const SortedPoint *__restrict__ sorted, int32_t *__restrict__ counts,
+    const int32_t *__restrict__ offsets, int32_t *__restrict__ edges,
+    int64_t capacity) {
+  const int lane = threadIdx.x & 63;
+  const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= n_centers) return;
+  double cx, cy, cz;
+  load_point(centers, q, sc, cx, cy, cz);
+  const double r2 = r * r;
+  // cells that can hold a point within r: widen by a relative 1e-9 so that
+  // rounding in (v - origin) / cell can never exclude a true neighbour
+  const double rr = r * (1.0 + 1e-9) + 1e-300;
+  const int x0 = cell_of(cx - rr, 0.0, r), x1 = cell_of(cx + rr, 0.0, r);
+  const int y0 = cell_of(cy - rr, 0.0, r), y1 = cell_of(cy + rr, 0.0, r);
+  const int z0 = cell_of(cz - rr, 0.0, r), z1 = cell_of(cz + rr, 0.0, r);
+  int64_t out_pos = FILL ? (int64_t)offsets[q] : 0;
+  int total = 0;
+  for (int iz = z0; iz <= z1; ++iz)
+    for (int iy = y0; iy <= y1; ++iy)
+      for (int ix = x0; ix <= x1; ++ix) {
+        const uint32_t b = cell_hash(ix, iy, iz, mask);
+        const int s = cell_start[b], e = cell_end[b];
+        for (int i0 = s; i0 < e; i0 += 64) {
+          const int i = i0 + lane;
+          bool hit = false;
+          int pidx = 0;
+          if (i < e) {
+            const SortedPoint sp = sorted[i];
+            pidx = sp.idx;
+            if (cell_of(sp.x, 0.0, r) == ix && cell_of(sp.y, 0.0, r) == iy &&
+                cell_of(sp.z, 0.0, r) == iz) {
+              const double dx = sp.x - cx, dy = sp.y - cy, dz = sp.z - cz;
+              const double d2 = (dx * dx + dy * dy) + dz * dz;
+              hit = d2 <= r2;
+            }
+          }
+          const unsigned long long m = __ballot(hit);
+          if (FILL) {
+            if (hit) {
+              const int64_t pos =
+                  out_pos + __popcll(m & ((1ull << lane) - 1ull));
+              if (pos < capacity) {
+                edges[2 * pos] = pidx;
+                edges[2 * pos + 1] = (int32_t)q;
+              }
+            }
+            out_pos += __popcll(m);
+          } else {
+            total += __popcll(m);
+          }
+        }
+      }
+  if (!FILL && lane == 0) counts[q] = total;
+}
+
+// ---- neighbour cap (training) ---------------------------------------------------
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+  x ^= x >> 30;
+  x *= 0xbf58476d1ce4e5b9ull;
+  x ^= x >> 27;
+  x *= 0x94d049bb133111ebull;
+  x ^= x >> 31;
+  return x;
+}
+
+__global__ void cap_counts_kernel(const int32_t *__restrict__ offsets,
+                                  int64_t n, int32_t cap,
+                                  int32_t *__restrict__ counts) {
+  int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  int c = offsets[q + 1] - offsets[q];
+  counts[q] = c > cap ? cap : c;
+}
+
+// One wave per centre.  Fan-in <= cap: copy.  Otherwise keep the `cap` edges
+// with the smallest 64-bit hash(seed, centre, position): a uniformly random
+// subset without replacement (np.random.choice(..., replace=False) semantics,
+// graph_gen.py:210-214), selected by counting, emitted in original order.
+__global__ __launch_bounds__(256) void cap_fill_kernel(
+    const int32_t *__restrict__ offsets, const int32_t *__restrict__ edges,
+    int64_t n, int32_t cap, uint64_t seed,
+    const int32_t *__restrict__ new_offsets, int32_t *__restrict__ new_edges,
+    int64_t capacity) {
+  const int lane = threadIdx.x & 63;
+  const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= n) return;
+  const int s = offsets[q], e = offsets[q + 1], cnt = e - s;
+  int64_t o = new_offsets[q];
+  if (cnt <= cap) {
+    for (int i = lane; i < cnt; i += 64) {
+      if (o + i < capacity) {
+        new_edges[2 * (o + i)] = edges[2 * (int64_t)(s + i)];
+        new_edges[2 * (o + i) + 1] = edges[2 * (int64_t)(s + i) + 1];
+      }
+    }
+    return;
+  }
+  const uint64_t base = mix64(seed ^ mix64((uint64_t)q + 0x9e3779b97f4a7c15ull));
+  for (int i0 = 0; i0 < cnt; i0 += 64) {
+    const int i = i0 + lane;
+    bool keep = false;
+    if (i < cnt) {
+      const uint64_t hi = mix64(base + (uint64_t)i);
+      int rank = 0;  // number of edges with a smaller (hash, position) key
+      for (int j = 0; j < cnt; ++j) {
+        const uint64_t hj = mix64(base + (uint64_t)j);
+        rank += (hj < hi) || (hj == hi && j < i);
+      }
+      keep = rank < cap;
+    }
+    const unsigned long long m = __ballot(keep);
+    if (keep) {
+      const int64_t pos = o + __popcll(m & ((1ull << lane) - 1ull));
+      if (pos < capacity) {
+        new_edges[2 * pos] = edges[2 * (int64_t)(s + i)];
+        new_edges[2 * pos + 1] = edges[2 * (int64_t)(s + i) + 1];
+      }
+    }
+    o += __popcll(m);
+  }
+}
+
+// ---- keypoints --------------------------------------------------------------------
+__device__ __forceinline__ uint32_t float_to_ordered(float f) {
+  uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ordered_to_float(uint32_t u) {
+  return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+__global__ void min_bound_kernel(const float *__restrict__ pts, int64_t n,
+                                 uint32_t *__restrict__ ordered_min) {
+  uint32_t m0 = 0xffffffffu, m1 = 0xffffffffu, m2 = 0xffffffffu;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    m0 = min(m0, float_to_ordered(pts[3 * i]));
+    m1 = min(m1, float_to_ordered(pts[3 * i + 1]));
+    m2 = min(m2, float_to_ordered(pts[3 * i + 2]));
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    m0 = min(m0, (uint32_t)__shfl_xor((int)m0, d));
+    m1 = min(m1, (uint32_t)__shfl_xor((int)m1, d));
+    m2 = min(m2, (uint32_t)__shfl_xor((int)m2, d));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMin(&ordered_min[0], m0);
+    atomicMin(&ordered_min[1], m1);
+    atomicMin(&ordered_min[2], m2);
+  }
+}
+
+// origin[0..2] = grid origin, from the float32 minimum:
+//   center mode (open3d 0.7): min - voxel/2
+//   random mode (graph_gen.py:108-128): min - jitter
+__global__ void grid_origin_kernel(const uint32_t *__restrict__ ordered_min,
+                                   double sub_x, double sub_y, double sub_z,
+                                   double *__restrict__ origin) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    origin[0] = (double)ordered_to_float(ordered_min[0]) - sub_x;
+    origin[1] = (double)ordered_to_float(ordered_min[1]) - sub_y;
+    origin[2] = (double)ordered_to_float(ordered_min[2]) - sub_z;
+  }
+}
+
+// Thread per sorted slot.  The first slot of a voxel inside its bucket (the
+// "leader") sums the voxel's points in index order -- the sort is stable, so
+// this is open3d's accumulation order -- and stores the float64 mean.
+__global__ void voxel_leader_kernel(const SortedPoint *__restrict__ sorted,
+                                    const uint32_t *__restrict__ keys, int64_t n,
+                                    const double *__restrict__ origin,
+                                    double voxel,
+                                    const int32_t *__restrict__ cell_start,
+                                    const int32_t *__restrict__ cell_end,
+                                    int32_t *__restrict__ is_leader,
+                                    double *__restrict__ centroid,
+                                    int32_t *__restrict__ member_count) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double ox = origin[0], oy = origin[1], oz = origin[2];
+  const SortedPoint me = sorted[i];
+  const int vx = cell_of(me.x, ox, voxel), vy = cell_of(me.y, oy, voxel),
+            vz = cell_of(me.z, oz, voxel);
+  const uint32_t b = keys[i];
+  const int s = cell_start[b], e = cell_end[b];
+  bool leader = true;
+  for (int j = s; j < (int)i; ++j) {
+    const SortedPoint o = sorted[j];
+    if (cell_of(o.x, ox, voxel) == vx && cell_of(o.y, oy, voxel) == vy &&
+        cell_of(o.z, oz, voxel) == vz) {
+      leader = false;
+      break;
+    }
+  }
+  is_leader[i] = leader ? 1 : 0;
+  if (!leader) return;
+  double sx = 0.0, sy = 0.0, sz = 0.0;
+  int cnt = 0;
+  for (int j = (int)i; j < e; ++j) {
+    const SortedPoint o = sorted[j];
+    if (cell_of(o.x, ox, voxel) == vx && cell_of(o.y, oy, voxel) == vy &&
+        cell_of(o.z, oz, voxel) == vz) {
+      sx += o.x;
+      sy += o.y;
+      sz += o.z;
+      ++cnt;
+    }
+  }
+  centroid[3 * i] = sx / (double)cnt;
+  centroid[3 * i + 1] = sy / (double)cnt;
+  centroid[3 * i + 2] = sz / (double)cnt;
+  member_count[i] = cnt;
+}
+
+// One wave per sorted slot that is a leader: exact float64 1-NN of the voxel
+// centroid among all points (graph_gen.py:84-88).  The nearest point is closer
+// than 0.87 voxel edges (it is at most the RMS spread of the voxel's own
+// points away), so the 27 surrounding voxels suffice.
+__global__ __launch_bounds__(256) void voxel_nn_kernel(
+    const SortedPoint *__restrict__ sorted, int64_t n,
+    const double *__restrict__ origin, double voxel, uint32_t mask,
+    const int32_t *__restrict__ cell_start, const int32_t *__restrict__ cell_end,
+    const int32_t *__restrict__ is_leader, const int32_t *__restrict__ slot,
+    const double *__restrict__ centroid, const float *__restrict__ pts,
+    int32_t *__restrict__ kp_idx, float *__restrict__ kp_xyz) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n || !is_leader[i]) return;
+  const double ox = origin[0], oy = origin[1], oz = origin[2];
+  const double cx = centroid[3 * i], cy = centroid[3 * i + 1],
+               cz = centroid[3 * i + 2];
+  const int vx = cell_of(cx, ox, voxel), vy = cell_of(cy, oy, voxel),
+            vz = cell_of(cz, oz, voxel);
+  double best = 1.0e300;
+  int best_idx = 0x7fffffff;
+  for (int dz = -1; dz <= 1; ++dz)
+    for (int dy = -1; dy <= 1; ++dy)
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int ix = vx + dx, iy = vy + dy, iz = vz + dz;
+        const uint32_t b = cell_hash(ix, iy, iz, mask);
+        const int s = cell_start[b], e = cell_end[b];
+        for (int j = s + lane; j < e; j += 64) {
+          const SortedPoint o = sorted[j];
+          if (cell_of(o.x, ox, voxel) == ix && cell_of(o.y, oy, voxel) == iy &&
+              cell_of(o.z, oz, voxel) == iz) {
+            const double ex = o.x - cx, ey = o.y - cy, ez = o.z - cz;
+            const double d2 = (ex * ex + ey * ey) + ez * ez;
+            if (d2 < best || (d2 == best && o.idx < best_idx)) {
+              best = d2;
+              best_idx = o.idx;
+            }
+          }
+        }
+      }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const double ob = __shfl_xor(best, d);
+    const int oi = __shfl_xor(best_idx, d);
+    if (ob < best || (ob == best && oi < best_idx)) {
+      best = ob;
+      best_idx = oi;
+    }
+  }
+  if (lane == 0) {
+    const int k = slot[i];
+    kp_idx[k] = best_idx;
+    kp_xyz[3 * k] = pts[3 * (int64_t)best_idx];
+    kp_xyz[3 * k + 1] = pts[3 * (int64_t)best_idx + 1];
+    kp_xyz[3 * k + 2] = pts[3 * (int64_t)best_idx + 2];
+  }
+}
+
+// random mode: the leader picks member floor(u * count) of its voxel
+__global__ void voxel_random_pick_kernel(
+    const SortedPoint *__restrict__ sorted, const uint32_t *__restrict__ keys,
+    int64_t n, const double *__restrict__ origin, double voxel,
+    const int32_t *__restrict__ cell_end, const int32_t *__restrict__ is_leader,
+    const int32_t *__restrict__ slot, const int32_t *__restrict__ member_count,
+    uint64_t seed, const float *__restrict__ pts, int32_t *__restrict__ kp_idx,
+    float *__restrict__ kp_xyz) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !is_leader[i]) return;
+  const double ox = origin[0], oy = origin[1], oz = origin[2];
+  const SortedPoint me = sorted[i];
+  const int vx = cell_of(me.x, ox, voxel), vy = cell_of(me.y, oy, voxel),
+            vz = cell_of(me.z, oz, voxel);
+  const int cnt = member_count[i];
+  const uint64_t h = mix64(seed ^ mix64((uint64_t)me.idx + 0x632be59bd9b4e019ull));
+  int target = (int)((h >> 11) * (1.0 / 9007199254740992.0) * (double)cnt);
+  if (target >= cnt) target = cnt - 1;
+  const int e = cell_end[keys[i]];
+  int chosen = me.idx, seen = 0;
+  for (int j = (int)i; j < e; ++j) {
+    const SortedPoint o = sorted[j];
+    if (cell_of(o.x, ox, voxel) == vx && cell_of(o.y, oy, voxel) == vy &&
+        cell_of(o.z, oz, voxel) == vz) {
+      if (seen == target) {
+        chosen = o.idx;
+        break;
+      }
+      ++seen;
+    }
+  }
+  const int k = slot[i];
+  kp_idx[k] = chosen;
+  kp_xyz[3 * k] = pts[3 * (int64_t)chosen];
+  kp_xyz[3 * k + 1] = pts[3 * (int64_t)chosen + 1];
+  kp_xyz[3 * k + 2] = pts[3 * (int64_t)chosen + 2];
+}
+
+__global__ void copy_total_kernel(const int32_t *src, int32_t *dst) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *dst = *src;
+}
+
+// ---- host-side helpers ---------------------------------------------------------------
+int hash_bits(int64_t n) {
+  int b = 10;
+  while (b < 22 && ((int64_t)1 << b) < 2 * n) ++b;
+  return b;  // >= 2 buckets per point on average, 2^10 .. 2^22 buckets
+}
+
+struct Grid {
+  uint32_t *keys_a, *vals_a, *keys_b, *vals_b;
+  uint32_t *keys, *vals;  // sorted result
+  int32_t *cell_start, *cell_end;
+  SortedPoint *sorted;
+  void *sort_scratch;
+  size_t sort_scratch_bytes;
+  uint32_t mask;
+  int bits;
+};
+
+size_t grid_bytes(int64_t n) {
+  const int bits = hash_bits(n);
+  size_t b = 0;
+  b += 4 * align_up((size_t)n * 4, 256);                     // keys/vals x2
+  b += 2 * align_up(((size_t)1 << bits) * 4, 256);           // start/end
+  b += align_up((size_t)n * sizeof(SortedPoint), 256);       // sorted copy
+  b += align_up(radix_sort_scratch_bytes(n), 256);
+  return b + 2048;
+}
+
+int grid_carve(Arena &a, int64_t n, Grid &g) {
+  g.bits = hash_bits(n);
+  g.mask = ((uint32_t)1 << g.bits) - 1u;
+  const size_t nn = (size_t)(n > 0 ? n : 1);
+  g.keys_a = a.take<uint32_t>(nn);
+  g.vals_a = a.take<uint32_t>(nn);
+  g.keys_b = a.take<uint32_t>(nn);
+  g.vals_b = a.take<uint32_t>(nn);
+  g.cell_start = a.take<int32_t>((size_t)1 << g.bits);
+  g.cell_end = a.take<int32_t>((size_t)1 << g.bits);
+  g.sorted = a.take<SortedPoint>(nn);
+  g.sort_scratch_bytes = radix_sort_scratch_bytes(n);
+  g.sort_scratch = a.take<char>(g.sort_scratch_bytes);
+  if (!g.keys_a || !g.vals_a || !g.keys_b || !g.vals_b || !g.cell_start ||
+      !g.cell_end || !g.sorted || !g.sort_scratch)
+    return fail(PGNN_E_WORKSPACE, "graph: workspace too small");
+  return 0;
+}
+
+int grid_build(const float *pts, int64_t n, const Scale3 &sc, double ox,
+               double oy, double oz, const double *origin_dev, double cell,
+               Grid &g, hipStream_t stream) {
+  const size_t nbuckets = (size_t)1 << g.bits;
+  PGNN_HIP(hipMemsetAsync(g.cell_start, 0, nbuckets * 4, stream));
+  PGNN_HIP(hipMemsetAsync(g.cell_end, 0, nbuckets * 4, stream));
+  if (n <= 0) return 0;
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(cell_keys_kernel, dim3(blocks), dim3(256), 0, stream, pts,
+                     n, sc, ox, oy, oz, origin_dev, cell, g.mask, g.keys_a,
+                     g.vals_a);
+  int rc = radix_sort_pairs(g.keys_a, g.vals_a, g.keys_b, g.vals_b, n, g.bits,
+                            g.sort_scratch, g.sort_scratch_bytes, &g.keys,
+                            &g.vals, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(cell_bounds_kernel, dim3(blocks), dim3(256), 0, stream,
+                     g.keys, g.vals, n, pts, sc, g.cell_start, g.cell_end,
+                     g.sorted);
+  PGNN_HIP(hipGetLastError());
+  return 0;
+}
+
+Scale3 make_scale(const double *scale3_host) {
+  Scale3 s;
+  s.on = scale3_host != nullptr;
+  s.x = s.on ? scale3_host[0] : 1.0;
+  s.y = s.on ? scale3_host[1] : 1.0;
+  s.z = s.on ? scale3_host[2] : 1.0;
+  return s;
+}
+
+}  // namespace
+}  // namespace pgnn
+
+using namespace pgnn;
+
+// workspace layout (radius graph): [Grid | counts[n_centers] | scan scratch]
+extern "C" size_t pgnn_radius_graph_workspace_bytes(int64_t n_points,
+                                                    int64_t n_centers) {
+  if (n_points < 0 || n_centers < 0) return 0;
+  return grid_bytes(n_points) + align_up((size_t)(n_centers + 1) * 4, 256) +
+         align_up(scan_scratch_bytes(n_centers), 256) + 1024;
+}
+
+namespace {
+struct RadiusWs {
+  Grid g;
+  int32_t *counts;
+  void *scan_scratch;
+  size_t scan_bytes;
+};
+int radius_carve(void *ws, size_t ws_bytes, int64_t n_points, int64_t n_centers,
+                 RadiusWs &r) {
+  PGNN_REQUIRE(ws != nullptr &&
+                   ws_bytes >= pgnn_radius_graph_workspace_bytes(n_points,
+                                                                 n_centers),
+               PGNN_E_WORKSPACE, "radius_graph: workspace too small");
+  Arena a(ws, ws_bytes);
+  int rc = grid_carve(a, n_points, r.g);
+  if (rc) return rc;
+  r.counts = a.take<int32_t>((size_t)n_centers + 1);
+  r.scan_bytes = scan_scratch_bytes(n_centers);
+  r.scan_scratch = a.take<char>(r.scan_bytes);
+  PGNN_REQUIRE(r.counts && r.scan_scratch, PGNN_E_WORKSPACE,
+               "radius_graph: workspace too small");
+  return 0;
+}
+}  // namespace
+
+extern "C" int pgnn_radius_graph_count(const float *points, int64_t n_points,
+                                       const float *centers, int64_t n_centers,
+                                       double radius, const double *scale3_host,
+                                       void *workspace, size_t workspace_bytes,
+                                       int32_t *offsets, void *stream_) {
+  PGNN_GUARD_BEGIN
+  hipStream_t stream = (hipStream_t)stream_;
+  PGNN_REQUIRE(n_points >= 0 && n_centers >= 0 && radius > 0.0 &&
+                   offsets != nullptr,
+               PGNN_E_INVALID, "radius_graph_count: bad argument");
+  PGNN_REQUIRE((n_points == 0 || points) && (n_centers == 0 || centers),
+               PGNN_E_INVALID, "radius_graph_count: null input");
+  RadiusWs w;
+  int rc = radius_carve(workspace, workspace_bytes, n_points, n_centers, w);
+  if (rc) return rc;
+  const Scale3 sc = make_scale(scale3_host);
+  rc = grid_build(points, n_points, sc, 0.0, 0.0, 0.0, nullptr, radius, w.g,
+                  stream);
+  if (rc) return rc;
+  if (n_centers > 0) {
+    hipLaunchKernelGGL(radius_query_kernel<false>,
+                       dim3((unsigned)((n_centers + 3) / 4)), dim3(256), 0,
+                       stream, centers, n_centers, sc, radius, w.g.mask,
+                       w.g.cell_start, w.g.cell_end, w.g.sorted, w.counts,
+                       (const int32_t *)nullptr, (int32_t *)nullptr,
+                       (int64_t)0);
+    PGNN_HIP(hipGetLastError());
+  }
+  return exclusive_scan_i32(w.counts, offsets, n_centers, w.scan_scratch,
+                            w.scan_bytes, stream);
+  PGNN_GUARD_END
+}
+
+extern "C" int pgnn_radius_graph_fill(const float *points, int64_t n_points,
+                                      const float *centers, int64_t n_centers,
+                                      double radius, const double *scale3_host,
+                                      void *workspace, size_t workspace_bytes,
+                                      const int32_t *offsets, int32_t *edges,
+                                      int64_t capacity, void *stream_) {
+  PGNN_GUARD_BEGIN
+  hipStream_t stream = (hipStream_t)stream_;
+  PGNN_REQUIRE(n_points >= 0 && n_centers >= 0 && radius > 0.0 && offsets &&
+                   capacity >= 0,
+               PGNN_E_INVALID, "radius_graph_fill: bad argument");
+  if (n_centers == 0 || capacity == 0) return 0;
+  PGNN_REQUIRE(edges && points && centers, PGNN_E_INVALID,
+               "radius_graph_fill: null pointer");
+  RadiusWs w;  // same carve as _count: the grid built there is reused
+  int rc = radius_carve(workspace, workspace_bytes, n_points, n_centers, w);
+  if (rc) return rc;
+  // keys/vals ping-pong: after an even number of passes the result is in *_a
+  const Scale3 sc = make_scale(scale3_host);
+  hipLaunchKernelGGL(radius_query_kernel<true>,
+                     dim3((unsigned)((n_centers + 3) / 4)), dim3(256), 0, stream,
+                     centers, n_centers, sc, radius, w.g.mask, w.g.cell_start,
+                     w.g.cell_end, w.g.sorted, (int32_t *)nullptr, offsets,
+                     edges, capacity);
+  PGNN_HIP(hipGetLastError());
+  return 0;
+  PGNN_GUARD_END
+}
+
+extern "C" int pgnn_cap_neighbors_count(const int32_t *offsets,
+                                        int64_t n_centers,
+                                        int32_t max_neighbors,
+                                        int32_t *new_offsets, void *stream_) {
+  PGNN_GUARD_BEGIN
+  hipStream_t stream = (hipStream_t)stream_;
+  PGNN_REQUIRE(offsets && new_offsets && n_centers >= 0 && max_neighbors > 0,
+               PGNN_E_INVALID, "cap_neighbors_count: bad argument");
+  PGNN_HIP(hipMemsetAsync(new_offsets + n_centers, 0, 4, stream));
+  if (n_centers == 0) return 0;
+  hipLaunchKernelGGL(cap_counts_kernel,
+                     dim3((unsigned)((n_centers + 255) / 256)), dim3(256), 0,
+                     stream, offsets, n_centers, max_neighbors, new_offsets);
+  PGNN_HIP(hipGetLastError());
+  // exclusive scan over n_centers + 1 entries leaves the total in the last one
+  return exclusive_scan_inplace_i32(new_offsets, n_centers + 1, stream);
+  PGNN_GUARD_END
+}
+
+extern "C" int pgnn_cap_neighbors_fill(const int32_t *offsets,
+                                       const int32_t *edges, int64_t n_centers,
+                                       int32_t max_neighbors, uint64_t seed,
+                                       const int32_t *new_offsets,
+                                       int32_t *new_edges, int64_t new_capacity,
+                                       void *stream_) {
+  PGNN_GUARD_BEGIN
+  hipStream_t stream = (hipStream_t)stream_;
+  PGNN_REQUIRE(offsets && new_offsets && n_centers >= 0 && max_neighbors > 0 &&
+                   new_capacity >= 0,
+               PGNN_E_INVALID, "cap_neighbors_fill: bad argument");
+  if (n_centers == 0 || new_capacity == 0) return 0;
+  PGNN_REQUIRE(edges && new_edges, PGNN_E_INVALID,
+               "cap_neighbors_fill: null edges");
+  hipLaunchKernelGGL(cap_fill_kernel, dim3((unsigned)((n_centers + 3) / 4)),
+                     dim3(256), 0, stream, offsets, edges, n_centers,
+                     max_neighbors, seed, new_offsets, new_edges, new_capacity);
+  PGNN_HIP(hipGetLastError());
+  return 0;
+  PGNN_GUARD_END
+}
+
+// workspace layout (keypoints): [Grid | ordered_min[4] | origin[3] |
+//   is_leader[n] | slot[n+1] | member_count[n] | centroid[3n] | scan scratch]
+extern "C" size_t pgnn_keypoints_workspace_bytes(int64_t n_points) {
+  if (n_points < 0) return 0;
+  const size_t n = (size_t)(n_points > 0 ? n_points : 1);
+  return grid_bytes(n_points) + 256 + 256 + 3 * align_up((n + 1) * 4, 256) +
+         align_up(3 * n * 8, 256) + align_up(scan_scratch_bytes(n_points), 256) +
+         2048;
+}
+
+namespace {
+int keypoints_impl(const float *points, int64_t n, double voxel, bool center,
+                   const double *jitter3, uint64_t seed, void *workspace,
+                   size_t workspace_bytes, int32_t *kp_idx, float *kp_xyz,
+                   int32_t *num_kp, hipStream_t stream) {
+  PGNN_REQUIRE(n >= 0 && voxel > 0.0 && kp_idx && kp_xyz && num_kp,
+               PGNN_E_INVALID, "keypoints: bad argument");
+  if (n == 0) {
+    PGNN_HIP(hipMemsetAsync(num_kp, 0, 4, stream));
+    return 0;
+  }
+  PGNN_REQUIRE(points != nullptr, PGNN_E_INVALID, "keypoints: null points");
+  PGNN_REQUIRE(workspace && workspace_bytes >= pgnn_keypoints_workspace_bytes(n),
+               PGNN_E_WORKSPACE, "keypoints: workspace too small");
+  Arena a(workspace, workspace_bytes);
+  Grid g;
+  int rc = grid_carve(a, n, g);
+  if (rc) return rc;
+  uint32_t *omin = a.take<uint32_t>(4);
+  double *origin = a.take<double>(3);
+  int32_t *is_leader = a.take<int32_t>((size_t)n + 1);
+  int32_t *slot = a.take<int32_t>((size_t)n + 1);
+  int32_t *members = a.take<int32_t>((size_t)n + 1);
+  double *centroid = a.take<double>(3 * (size_t)n);
+  const size_t scan_bytes = scan_scratch_bytes(n);
+  void *scan_scratch = a.take<char>(scan_bytes);
+  PGNN_REQUIRE(omin && origin && is_leader && slot && members && centroid &&
+                   scan_scratch,
+               PGNN_E_WORKSPACE, "keypoints: workspace too small");
+  PGNN_HIP(hipMemsetAsync(omin, 0xff, 16, stream));
+  int mb = (int)((n + 255) / 256);
+  if (mb > 1024) mb = 1024;
+  hipLaunchKernelGGL(min_bound_kernel, dim3(mb), dim3(256), 0, stream, points, n,
+                     omin);
+  double sx, sy, sz;
+  if (center) {
+    sx = sy = sz = voxel * 0.5;  // open3d 0.7: origin = min_bound - voxel/2
+  } else {
+    sx = jitter3 ? jitter3[0] : 0.0;  // graph_gen.py:126-128: + jitter
+    sy = jitter3 ? jitter3[1] : 0.0;
+    sz = jitter3 ? jitter3[2] : 0.0;
+  }
+  hipLaunchKernelGGL(grid_origin_kernel, dim3(1), dim3(64), 0, stream, omin, sx,
+                     sy, sz, origin);
+  Scale3 sc = make_scale(nullptr);
+  rc = grid_build(points, n, sc, 0.0, 0.0, 0.0, origin, voxel, g, stream);
+  if (rc) return rc;
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(voxel_leader_kernel, dim3(blocks), dim3(256), 0, stream,
+                     g.sorted, g.keys, n, origin, voxel, g.cell_start,
+                     g.cell_end, is_leader, centroid, members);
+  rc = exclusive_scan_i32(is_leader, slot, n, scan_scratch, scan_bytes, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(copy_total_kernel, dim3(1), dim3(64), 0, stream, slot + n,
+                     num_kp);
+  if (center) {
+    hipLaunchKernelGGL(voxel_nn_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256),
+                       0, stream, g.sorted, n, origin, voxel, g.mask,
+                       g.cell_start, g.cell_end, is_leader, slot, centroid,
+                       points, kp_idx, kp_xyz);
+  } else {
+    hipLaunchKernelGGL(voxel_random_pick_kernel, dim3(blocks), dim3(256), 0,
+                       stream, g.sorted, g.keys, n, origin, voxel, g.cell_end,
+                       is_leader, slot, members, seed, points, kp_idx, kp_xyz);
+  }
+  PGNN_HIP(hipGetLastError());
+  return 0;
+}
+}  // namespace
+
+extern "C" int pgnn_voxel_keypoints_center(const float *points, int64_t n_points,
+                                           double voxel_size, void *workspace,
+                                           size_t workspace_bytes,
+                                           int32_t *keypoint_indices,
+                                           float *keypoint_xyz,
+                                           int32_t *num_keypoints,
+                                           void *stream) {
+  PGNN_GUARD_BEGIN
+  return keypoints_impl(points, n_points, voxel_size, true, nullptr, 0,
+                        workspace, workspace_bytes, keypoint_indices,
+                        keypoint_xyz, num_keypoints, (hipStream_t)stream);
+  PGNN_GUARD_END
+}
+
+extern "C" int pgnn_voxel_keypoints_random(
+    const float *points, int64_t n_points, double voxel_size,
+    const double *jitter3_host, uint64_t seed, void *workspace,
+    size_t workspace_bytes, int32_t *keypoint_indices, float *keypoint_xyz,
+    int32_t *num_keypoints, void *stream) {
+  PGNN_GUARD_BEGIN
+  return keypoints_impl(points, n_points, voxel_size, false, jitter3_host, seed,
+                        workspace, workspace_bytes, keypoint_indices,
+                        keypoint_xyz, num_keypoints, (hipStream_t)stream);
+  PGNN_GUARD_END
+}

@@ -1,0 +1,138 @@
+// Workgroup-level fp32 MLP engine on MFMA (v_mfma_f32_16x16x4_f32).
+//
+// A workgroup (4 waves, one per SIMD) owns a tile of ROWS = 16*MSUB rows whose
+// activations live in LDS, row-major with leading dimension ld = width + 8
+// floats (ld == 8 mod 16: the four 16-lane groups of a ds_read_b128 A-fragment
+// read land on disjoint banks).  A layer y = act(x W + b) is computed as
+//   - A fragments: one ds_read_b128 per 16 rows per K-group of 16: lane l
+//     holds x[row = l&15][k = 16q + 4(l>>4) + s], s = 0..3;
+//   - B fragments: straight from global/L2 in the host-packed order
+//     (pgnn_pack_fc): lane l holds W[16q + 4(l>>4) + s][16t + (l&15)] --
+//     one coalesced 1 KiB load per (K-group, column tile), no LDS staging;
+//     weights are a few hundred KB and stay L2-resident;
+//   - 4 MFMA steps (s = 0..3) consume them; the k order inside a group is
+//     permuted identically on both operands, so the sum is over all k.
+// The N dimension is split across the 4 waves (column tile t = t0 + wave + 4j),
+// every wave reads the whole A tile from LDS (LDS traffic is ~1% of MFMA
+// time) and streams only its own quarter of W.  Accumulators stay in
+// registers; after a barrier the activated result overwrites the input tile
+// in place.  fp32 MFMA is bit-exact fp32 FMA, so results match an fp32
+// reference to rounding order.
+#pragma once
+#include "pgnn_common.h"
+
+namespace pgnn {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+struct LayerDev {
+  const float *wp;  // packed weights, bias follows at wp + kq*nt*256
+  int kq;           // K groups of 16
+  int nt;           // column tiles of 16
+  int relu_from;    // ReLU on columns >= relu_from
+};
+
+struct ChainDev {
+  int n;
+  LayerDev l[PGNN_MAX_LAYERS];
+};
+
+constexpr int kMaxTilesPerPass = 20;  // 4 waves x NT<=5 column tiles = 320 cols
+
+__host__ __device__ inline int lds_ld(int width16) { return width16 + 8; }
+
+// acc[m][j] += tile[16m.., :] @ W[:, tile t0 + wave + 4j]
+template <int MSUB, int NT>
+__device__ __forceinline__ void gemm_tile(const float *__restrict__ tile, int ld,
+                                          const LayerDev &L, int t0, int wave,
+                                          int lane, v4f (&acc)[MSUB][NT]) {
+#pragma unroll
+  for (int m = 0; m < MSUB; ++m)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[m][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+  int toff[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    int t = t0 + wave + 4 * j;
+    if (t > L.nt - 1) t = L.nt - 1;  // clamp: load something valid, discard later
+    toff[j] = t * 64;
+  }
+  const v4f *__restrict__ wp = reinterpret_cast<const v4f *>(L.wp) + lane;
+  const float *arow = tile + (lane & 15) * ld + 4 * (lane >> 4);
+  const int qstride = L.nt * 64;
+  for (int q = 0; q < L.kq; ++q) {
+    v4f a[MSUB], b[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) b[j] = wp[(size_t)q * qstride + toff[j]];
+#pragma unroll
+    for (int m = 0; m < MSUB; ++m)
+      a[m] = *reinterpret_cast<const v4f *>(arow + m * 16 * ld + 16 * q);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int m = 0; m < MSUB; ++m)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][s], b[j][s],
+                                                           acc[m][j], 0, 0, 0);
+  }
+}
+
+// out[row][col - 16*t0] = act(acc + bias[col]); C/D layout of the 16x16 MFMA:
+// col = lane & 15, row = 4*(lane >> 4) + r.
+template <int MSUB, int NT>
+__device__ __forceinline__ void store_acc(float *__restrict__ out, int ldo,
+                                          const LayerDev &L, int t0, int wave,
+                                          int lane, const v4f (&acc)[MSUB][NT]) {
+  const float *bias = L.wp + (size_t)L.kq * L.nt * 256;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int t = t0 + wave + 4 * j;
+    if (t < L.nt) {
+      const int col = t * 16 + (lane & 15);
+      const float bv = bias[col];
+      const bool relu = col >= L.relu_from;
+      float *o = out + (4 * (lane >> 4)) * ldo + (col - 16 * t0);
+#pragma unroll
+      for (int m = 0; m < MSUB; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[m][j][r] + bv;
+          if (relu) v = v > 0.0f ? v : 0.0f;
+          o[(m * 16 + r) * ldo] = v;
+        }
+    }
+  }
+}
+
+// One pass (<= 320 output columns starting at column tile t0) of layer L:
+// GEMM from `in`, barrier, activated store to `out` (may alias `in`), barrier.
+template <int MSUB, int NT>
+__device__ __forceinline__ void layer_pass(const float *in, int ld_in, float *out,
+                                           int ld_out, const LayerDev &L, int t0,
+                                           int wave, int lane) {
+  v4f acc[MSUB][NT];
+  gemm_tile<MSUB, NT>(in, ld_in, L, t0, wave, lane, acc);
+  __syncthreads();  // every wave is done reading `in` (in-place overwrite)
+  store_acc<MSUB, NT>(out, ld_out, L, t0, wave, lane, acc);
+  __syncthreads();
+}
+
+template <int MSUB>
+__device__ __forceinline__ void layer_pass_dispatch(const float *in, int ld_in,
+                                                    float *out, int ld_out,
+                                                    const LayerDev &L, int t0,
+                                                    int wave, int lane) {
+  int tiles = L.nt - t0;
+  if (tiles > kMaxTilesPerPass) tiles = kMaxTilesPerPass;
+  const int ntw = (tiles + 3) >> 2;  // column tiles per wave (wave-uniform)
+  switch (ntw) {
+    case 1: layer_pass<MSUB, 1>(in, ld_in, out, ld_out, L, t0, wave, lane); break;
+    case 2: layer_pass<MSUB, 2>(in, ld_in, out, ld_out, L, t0, wave, lane); break;
+    case 3: layer_pass<MSUB, 3>(in, ld_in, out, ld_out, L, t0, wave, lane); break;
+    case 4: layer_pass<MSUB, 4>(in, ld_in, out, ld_out, L, t0, wave, lane); break;
+    default: layer_pass<MSUB, 5>(in, ld_in, out, ld_out, L, t0, wave, lane); break;
+  }
+}
+
+}  // namespace pgnn

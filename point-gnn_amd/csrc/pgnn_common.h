@@ -1,0 +1,84 @@
+// Internal helpers shared by the HIP translation units of libpointgnn_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include <exception>
+#include <string>
+
+#include "pointgnn_hip.h"
+
+namespace pgnn {
+
+std::string &last_error();
+
+inline int fail(int code, const char *msg) {
+  last_error() = msg;
+  return code;
+}
+
+#define PGNN_HIP(expr)                                                        \
+  do {                                                                        \
+    hipError_t e_ = (expr);                                                   \
+    if (e_ != hipSuccess) {                                                   \
+      char buf_[256];                                                         \
+      snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #expr,             \
+               hipGetErrorString(e_), __FILE__, __LINE__);                    \
+      pgnn::last_error() = buf_;                                              \
+      return (int)e_;                                                         \
+    }                                                                         \
+  } while (0)
+
+#define PGNN_REQUIRE(cond, code, msg)                                         \
+  do {                                                                        \
+    if (!(cond)) return pgnn::fail(code, msg);                                \
+  } while (0)
+
+// every extern "C" entry wraps its body: no exception crosses the ABI
+#define PGNN_GUARD_BEGIN try {
+#define PGNN_GUARD_END                                                        \
+  }                                                                           \
+  catch (const std::exception &ex) {                                          \
+    return pgnn::fail(PGNN_E_INVALID, ex.what());                             \
+  }                                                                           \
+  catch (...) {                                                               \
+    return pgnn::fail(PGNN_E_INVALID, "unknown C++ exception");               \
+  }
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Bump allocator over the caller's workspace.
+struct Arena {
+  char *base;
+  size_t size, used;
+  Arena(void *p, size_t n) : base((char *)p), size(n), used(0) {}
+  template <typename T>
+  T *take(size_t count) {
+    size_t off = align_up(used, 256);
+    size_t end = off + count * sizeof(T);
+    used = end;
+    if (end > size || base == nullptr) return nullptr;
+    return (T *)(base + off);
+  }
+};
+
+constexpr float kFloatLowest = -3.402823466e+38f;  // numeric_limits<float>::lowest()
+constexpr uint32_t kFloatLowestBits = 0xFF7FFFFFu;
+
+// float atomic max on global memory that is correct for any sign mix, given
+// the target was initialised to a float value (lowest()): non-negative values
+// order like signed ints, negative values order inversely as unsigned ints.
+__device__ __forceinline__ void atomic_max_f32(float *addr, float v) {
+  if (v >= 0.0f) {
+    __hip_atomic_fetch_max((int *)addr, __float_as_int(v), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    __hip_atomic_fetch_min((unsigned int *)addr, __float_as_uint(v),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+int device_cu_count();
+
+}  // namespace pgnn

@@ -1,0 +1,540 @@
+"""GNN operators -- the reference's `models/gnn.py` surface (same class names,
+constructor/`apply_regular` signatures and kwargs) executing on the fused HIP
+kernels of csrc/gnn.hip through the ctypes C-ABI.
+
+TF1 builds a graph once and finds variables through `tf.variable_scope`; this
+implementation is eager, so the two implicit TF mechanisms are explicit here:
+
+  * `parameters(store)`  -- context manager binding a `ParamStore` (a state
+    dict keyed by the reference's TF variable names);
+  * `variable_scope(name)` -- context manager mirroring tf.variable_scope.
+
+    with gnn.parameters(store), gnn.variable_scope('layer2'):
+        h = gnn.GraphNetAutoCenter().apply_regular(h, xyz, None, edges, **kw)
+
+Only what every shipped config uses has a device path: activation 'ReLU',
+normalization 'NONE', scatter-max aggregation (other registry keys of
+gnn.py:17-32 raise NotImplementedError).  Tensors are torch CUDA float32 /
+int32; activations are kept zero-padded to a multiple of 16 columns
+(`padded_width`) between operators -- `.features(t, width)` strips the pad.
+"""
+import contextlib
+import ctypes
+from functools import partial
+
+import numpy as np
+import torch
+
+from . import _lib
+from .weights import mlp_names
+
+__all__ = ["PointSetPooling", "GraphNetAutoCenter", "ClassAwarePredictor",
+           "multi_layer_neural_network_fn", "multi_layer_fc_fn",
+           "graph_scatter_max_fn", "ParamStore", "parameters",
+           "variable_scope", "padded_width"]
+
+
+def padded_width(n):
+    return (int(n) + 15) // 16 * 16
+
+
+# --------------------------------------------------------------------------
+# parameter store / scopes
+# --------------------------------------------------------------------------
+class ParamStore(object):
+    """Holds the model's variables (NumPy, reference TF names) and the
+    device-side packed images derived from them (built lazily, cached)."""
+
+    def __init__(self, params, device=None):
+        self.params = {k: np.asarray(v) for k, v in params.items()}
+        self.device = device
+        self._cache = {}
+
+    def _dev(self):
+        if self.device is None:
+            if not torch.cuda.is_available():
+                raise _lib.PointGnnHipError(
+                    "pointgnn_amd needs a GPU: there is no CPU fallback")
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        return self.device
+
+    def has(self, name):
+        return name + '/weights' in self.params
+
+    def fc(self, name):
+        return (self.params[name + '/weights'].astype(np.float32),
+                self.params[name + '/biases'].astype(np.float32))
+
+    def mlp(self, scope, n_layers):
+        return [self.fc(n) for n in mlp_names(scope, n_layers)]
+
+    def pack(self, w, b):
+        """[k_in, n_out] weights + bias -> device tensor in MFMA fragment order
+        (pgnn_pack_fc)."""
+        lib = _lib.load()
+        w = np.ascontiguousarray(w, dtype=np.float32)
+        b = np.ascontiguousarray(b, dtype=np.float32)
+        k_in, n_out = w.shape
+        host = np.empty(lib.pgnn_packed_fc_floats(k_in, n_out), np.float32)
+        _lib.check(lib.pgnn_pack_fc(w.ctypes.data, b.ctypes.data, k_in, n_out,
+                                    host.ctypes.data), "pgnn_pack_fc")
+        return torch.from_numpy(host).to(self._dev())
+
+    def cached(self, key, builder):
+        if key not in self._cache:
+            self._cache[key] = builder()
+        return self._cache[key]
+
+    def invalidate(self):
+        self._cache.clear()
+
+
+class Chain(object):
+    """A packed MLP chain: keeps the device buffers alive next to the ctypes
+    array of `pgnn_fc_layer` descriptors that points at them."""
+
+    def __init__(self, store, layers):
+        """layers: [(W [k,n], b [n], relu_from)]"""
+        self.buffers = []
+        self.array = (_lib.FcLayer * len(layers))()
+        self.n = len(layers)
+        for i, (w, b, relu_from) in enumerate(layers):
+            buf = store.pack(w, b)
+            self.buffers.append(buf)
+            self.array[i].packed = buf.data_ptr()
+            self.array[i].k_in = int(w.shape[0])
+            self.array[i].n_out = int(w.shape[1])
+            self.array[i].relu_from = int(relu_from)
+        self.k_in = int(layers[0][0].shape[0])
+        self.n_out = int(layers[-1][0].shape[1])
+
+
+_state = {"store": None, "scope": []}
+
+
+@contextlib.contextmanager
+def parameters(store):
+    prev = _state["store"]
+    _state["store"] = store
+    try:
+        yield store
+    finally:
+        _state["store"] = prev
+
+
+@contextlib.contextmanager
+def variable_scope(name):
+    _state["scope"].append(name)
+    try:
+        yield
+    finally:
+        _state["scope"].pop()
+
+
+def _scope(*suffix):
+    return '/'.join(list(_state["scope"]) + list(suffix))
+
+
+def _store():
+    if _state["store"] is None:
+        raise RuntimeError("no ParamStore bound: wrap the call in "
+                           "`with pointgnn_amd.gnn.parameters(store):`")
+    return _state["store"]
+
+
+def _check_kinds(activation_type, normalization_type):
+    if normalization_type not in ('NONE', None):
+        raise NotImplementedError(
+            "normalization %r: only 'NONE' (what every shipped config uses) "
+            "has a device path" % (normalization_type,))
+    if activation_type != 'ReLU':
+        raise NotImplementedError(
+            "activation %r: only 'ReLU' has a device path" % (activation_type,))
+
+
+def _relu_chain(store, scope, widths, is_logits):
+    """Chain for multi_layer_neural_network_fn (gnn.py:86-104)."""
+    def build():
+        fcs = store.mlp(scope, len(widths))
+        layers = []
+        for i, (w, b) in enumerate(fcs):
+            if w.shape[1] != widths[i]:
+                raise ValueError("%s: layer %d has width %d, config says %d"
+                                 % (scope, i, w.shape[1], widths[i]))
+            linear = is_logits and i == len(fcs) - 1
+            layers.append((w, b, w.shape[1] if linear else 0))
+        return Chain(store, layers)
+    return store.cached(('mlp', scope, tuple(widths), bool(is_logits)), build)
+
+
+def _as_f32(t):
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        t = t.to(torch.float32).contiguous()
+    return t
+
+
+def _as_i32(t):
+    if t.dtype != torch.int32 or not t.is_contiguous():
+        t = t.to(torch.int32).contiguous()
+    return t
+
+
+def mlp_forward(chain, x, nx, x2=None, nx2=0, residual=None):
+    """y = chain(concat(x[:, :nx], x2[:, :nx2])) (+ residual); returns a
+    [rows, padded_width(n_out)] tensor (pad columns are zero)."""
+    lib = _lib.load()
+    x = _as_f32(x)
+    rows = int(x.shape[0])
+    out_w = padded_width(chain.n_out)
+    y = torch.empty((rows, out_w), dtype=torch.float32, device=x.device)
+    if x2 is not None:
+        x2 = _as_f32(x2)
+    if residual is not None:
+        residual = _as_f32(residual)
+        assert residual.shape[1] >= out_w
+    _lib.check(lib.pgnn_mlp_fwd(
+        _lib.ptr(x), x.stride(0), int(nx), _lib.ptr(x2),
+        x2.stride(0) if x2 is not None else 0, int(nx2), rows, chain.array,
+        chain.n, _lib.ptr(residual),
+        residual.stride(0) if residual is not None else 0, _lib.ptr(y),
+        y.stride(0), _lib.stream_ptr()), "pgnn_mlp_fwd")
+    return y
+
+
+# --------------------------------------------------------------------------
+# function-style API of the reference (eager equivalents)
+# --------------------------------------------------------------------------
+def multi_layer_neural_network_fn(features, Ks=(64, 32, 64), is_logits=False,
+                                  normalization_type="fused_BN_center",
+                                  activation_type='ReLU'):
+    """gnn.py:86-104.  Variables are `<scope>/fully_connected[_i]` of the
+    current variable scope.  Returns [rows, padded_width(Ks[-1])]."""
+    _check_kinds(activation_type, normalization_type)
+    assert features.dim() == 2
+    store = _store()
+    chain = _relu_chain(store, _scope(), list(Ks), is_logits)
+    return mlp_forward(chain, features, chain.k_in)
+
+
+def multi_layer_fc_fn(sv, mask=None, Ks=(64, 32, 64), num_classes=4,
+                      is_logits=False, num_layer=4,
+                      normalization_type="fused_BN_center",
+                      activation_type='ReLU'):
+    """gnn.py:34-84: Ks hidden layers then a `num_classes`-wide layer (linear
+    when is_logits)."""
+    assert sv.dim() == 2
+    assert len(Ks) == num_layer - 1
+    out = multi_layer_neural_network_fn(
+        sv, Ks=list(Ks) + [num_classes], is_logits=is_logits,
+        normalization_type=normalization_type,
+        activation_type=activation_type)
+    if mask is not None:
+        out = out * mask
+    return out
+
+
+def graph_scatter_max_fn(point_features, point_centers, num_centers,
+                         ids_sorted=False):
+    """gnn.py:106-109 = tf.math.unsorted_segment_max.  Standalone kernel
+    (csrc/scatter_max.hip); the layers below use the fused epilogue instead."""
+    lib = _lib.load()
+    data = _as_f32(point_features)
+    ids = _as_i32(point_centers.reshape(-1))
+    n_rows, n_cols = int(data.shape[0]), int(data.shape[1])
+    out = torch.empty((int(num_centers), n_cols), dtype=torch.float32,
+                      device=data.device)
+    _lib.check(lib.pgnn_scatter_max_f32(
+        _lib.ptr(data), data.stride(0) if n_rows else n_cols, _lib.ptr(ids),
+        n_rows, n_cols, int(num_centers), _lib.ptr(out), n_cols,
+        1 if ids_sorted else 0, _lib.stream_ptr()), "pgnn_scatter_max_f32")
+    return out
+
+
+def graph_scatter_sum_fn(point_features, point_centers, num_centers):
+    raise NotImplementedError("scatter_sum: no shipped config uses it")
+
+
+def graph_scatter_mean_fn(point_features, point_centers, num_centers):
+    raise NotImplementedError("scatter_mean: no shipped config uses it")
+
+
+def _edges_sorted_flag(edges):
+    """Edges produced by pointgnn_amd.graph_gen are grouped by ascending
+    destination; foreign edge lists are checked once (cheap device reduction,
+    one sync) so that unsorted input takes the all-atomic path."""
+    cached = getattr(edges, "_pgnn_sorted", None)
+    if cached is not None:
+        return cached
+    if edges.shape[0] < 2:
+        return 1
+    d = edges[:, 1]
+    flag = 1 if bool((d[1:] >= d[:-1]).all().item()) else 0
+    mark_sorted(edges, flag)
+    return flag
+
+
+def mark_sorted(edges, flag=1):
+    """Tag an edge tensor as grouped by ascending destination (skips the
+    check in the layers)."""
+    try:
+        edges._pgnn_sorted = int(flag)
+    except Exception:
+        pass
+    return edges
+
+
+# --------------------------------------------------------------------------
+# layers
+# --------------------------------------------------------------------------
+class PointSetPooling(object):
+    """gnn.py:211-283."""
+
+    def __init__(self, point_feature_fn=multi_layer_neural_network_fn,
+                 aggregation_fn=graph_scatter_max_fn,
+                 output_fn=multi_layer_neural_network_fn):
+        if aggregation_fn is not graph_scatter_max_fn:
+            raise NotImplementedError("only scatter-max aggregation is fused")
+        self._point_feature_fn = point_feature_fn
+        self._aggregation_fn = aggregation_fn
+        self._output_fn = output_fn
+
+    def apply_regular(self, point_features, point_coordinates,
+                      keypoint_indices, set_indices,
+                      point_MLP_depth_list=None,
+                      point_MLP_normalization_type='fused_BN_center',
+                      point_MLP_activation_type='ReLU',
+                      output_MLP_depth_list=None,
+                      output_MLP_normalization_type='fused_BN_center',
+                      output_MLP_activation_type='ReLU'):
+        """point_features [N,M], point_coordinates [N,3], keypoint_indices
+        [K,1], set_indices [S,2] (point, set) -> [K, padded_width(out)]."""
+        _check_kinds(point_MLP_activation_type, point_MLP_normalization_type)
+        _check_kinds(output_MLP_activation_type, output_MLP_normalization_type)
+        lib = _lib.load()
+        store = _store()
+        with variable_scope('extract_vertex_features'):
+            point_chain = _relu_chain(store, _scope(),
+                                      list(point_MLP_depth_list), False)
+        feats = _as_f32(point_features)
+        xyz = _as_f32(point_coordinates)
+        kp = _as_i32(keypoint_indices.reshape(-1))
+        edges = _as_i32(set_indices)
+        n_feat = int(feats.shape[1])
+        assert point_chain.k_in == n_feat + 3, \
+            "point MLP expects %d inputs" % point_chain.k_in
+        k = int(kp.shape[0])
+        agg = torch.empty((k, padded_width(point_chain.n_out)),
+                          dtype=torch.float32, device=xyz.device)
+        _lib.check(lib.pgnn_point_set_pooling_fwd(
+            _lib.ptr(feats), n_feat, _lib.ptr(xyz), _lib.ptr(kp),
+            _lib.ptr(edges), int(edges.shape[0]), k, point_chain.array,
+            point_chain.n, _edges_sorted_flag(set_indices), _lib.ptr(agg),
+            agg.stride(0), _lib.stream_ptr()), "pgnn_point_set_pooling_fwd")
+        with variable_scope('combined_features'):
+            out_chain = _relu_chain(store, _scope(),
+                                    list(output_MLP_depth_list), False)
+        return mlp_forward(out_chain, agg, point_chain.n_out)
+
+
+class GraphNetAutoCenter(object):
+    """gnn.py:285-373."""
+
+    def __init__(self, edge_feature_fn=multi_layer_neural_network_fn,
+                 aggregation_fn=graph_scatter_max_fn,
+                 update_fn=multi_layer_neural_network_fn,
+                 auto_offset_fn=multi_layer_neural_network_fn):
+        if aggregation_fn is not graph_scatter_max_fn:
+            raise NotImplementedError("only scatter-max aggregation is fused")
+        self._edge_feature_fn = edge_feature_fn
+        self._aggregation_fn = aggregation_fn
+        self._update_fn = update_fn
+        self._auto_offset_fn = auto_offset_fn
+
+    def apply_regular(self, input_vertex_features, input_vertex_coordinates,
+                      NOT_USED, edges, edge_MLP_depth_list=None,
+                      edge_MLP_normalization_type='fused_BN_center',
+                      edge_MLP_activation_type='ReLU',
+                      update_MLP_depth_list=None,
+                      update_MLP_normalization_type='fused_BN_center',
+                      update_MLP_activation_type='ReLU', auto_offset=False,
+                      auto_offset_MLP_depth_list=None,
+                      auto_offset_MLP_normalization_type='fused_BN_center',
+                      auto_offset_MLP_feature_activation_type='ReLU'):
+        """h [K, >=C] (zero-padded), x [K,3], edges [E,2] (src, dst) ->
+        [K, padded_width(C)]."""
+        _check_kinds(edge_MLP_activation_type, edge_MLP_normalization_type)
+        _check_kinds(update_MLP_activation_type, update_MLP_normalization_type)
+        lib = _lib.load()
+        store = _store()
+        scope = _scope()
+        st = _lib.stream_ptr()
+        h = _as_f32(input_vertex_features)
+        x = _as_f32(input_vertex_coordinates)
+        e = _as_i32(edges)
+        k = int(h.shape[0])
+
+        edge_widths = list(edge_MLP_depth_list)
+        edge_scope = scope + '/extract_vertex_features'
+
+        def build_edge():
+            fcs = store.mlp(edge_scope, len(edge_widths))
+            w1, b1 = fcs[0]
+            c = w1.shape[0] - 3
+            # vertex-side image of the first edge layer: P = [h, x] @ W1 + b1
+            p_chain = Chain(store, [(w1, b1, w1.shape[1])])
+            wq = padded_width(w1.shape[1])
+            wx = np.zeros((3, wq), np.float32)
+            wx[:, :w1.shape[1]] = w1[c:c + 3]
+            wx_dev = torch.from_numpy(wx).to(store._dev())
+            if len(fcs) > 1:
+                rest = Chain(store, [(w, b, 0) for (w, b) in fcs[1:]])
+            else:
+                rest = None
+            return c, p_chain, wx_dev, rest
+        c, p_chain, wx_dev, rest = store.cached(
+            ('edge', edge_scope, tuple(edge_widths)), build_edge)
+        if rest is None:
+            raise NotImplementedError("edge MLP needs at least two layers")
+        assert h.shape[1] >= c, "vertex features narrower than edge MLP input"
+
+        # [optional] coordinate offset (auto-registration), gnn.py:341-346
+        delta = None
+        if auto_offset:
+            _check_kinds(auto_offset_MLP_feature_activation_type,
+                         auto_offset_MLP_normalization_type)
+            off_chain = _relu_chain(store, scope,
+                                    list(auto_offset_MLP_depth_list), True)
+            delta = mlp_forward(off_chain, h, off_chain.k_in)
+        # Q = (x + delta) @ W1[C:], P = [h, x] @ W1 + b1  (per vertex)
+        wq = int(wx_dev.shape[1])
+        q = torch.empty((k, wq), dtype=torch.float32, device=h.device)
+        _lib.check(lib.pgnn_offset_apply(
+            _lib.ptr(x), _lib.ptr(delta),
+            delta.stride(0) if delta is not None else 0, k, _lib.ptr(wx_dev),
+            ctypes.c_void_p(0), _lib.ptr(q), wq, st), "pgnn_offset_apply")
+        p = mlp_forward(p_chain, h, c, x2=x, nx2=3)
+        # per-edge: ReLU(P[src] - Q[dst]) -> remaining edge layers -> max
+        agg = torch.empty((k, padded_width(rest.n_out)), dtype=torch.float32,
+                          device=h.device)
+        _lib.check(lib.pgnn_edge_mlp_scatter_max_fwd(
+            _lib.ptr(p), _lib.ptr(q), wq, int(rest.k_in), _lib.ptr(e),
+            int(e.shape[0]), k, rest.array, rest.n,
+            _edges_sorted_flag(edges), _lib.ptr(agg), agg.stride(0), st),
+            "pgnn_edge_mlp_scatter_max_fwd")
+        # update + residual, gnn.py:367-372
+        upd_chain = _relu_chain(store, scope + '/combined_features',
+                                list(update_MLP_depth_list), True)
+        assert upd_chain.n_out == c, "update MLP must preserve the width"
+        if h.shape[1] < padded_width(c):
+            hp = torch.zeros((k, padded_width(c)), dtype=torch.float32,
+                             device=h.device)
+            hp[:, :h.shape[1]] = h
+            h = hp
+        return mlp_forward(upd_chain, agg, rest.n_out, residual=h)
+
+
+class ClassAwarePredictor(object):
+    """gnn.py:121-163.  cls_fn / loc_fn are `partial(multi_layer_fc_fn,
+    Ks=..., num_layer=...)` exactly as in models.py:60-69; all heads run as one
+    fused block-diagonal MLP chain."""
+
+    def __init__(self, cls_fn, loc_fn):
+        self._cls_fn = cls_fn
+        self._loc_fn = loc_fn
+
+    @staticmethod
+    def _ks(fn):
+        kw = getattr(fn, 'keywords', None) or {}
+        if 'Ks' not in kw:
+            raise NotImplementedError(
+                "predictor heads must be partial(multi_layer_fc_fn, Ks=...)")
+        return tuple(kw['Ks'])
+
+    def apply_regular(self, features, num_classes, box_encoding_len,
+                      normalization_type='fused_BN_center',
+                      activation_type='ReLU'):
+        """features [K, >=C] -> (logits [K, num_classes], box_encodings
+        [K, num_classes, box_encoding_len])."""
+        _check_kinds(activation_type, normalization_type)
+        store = _store()
+        scope = _scope('predictor')
+        cls_ks, loc_ks = self._ks(self._cls_fn), self._ks(self._loc_fn)
+        if len(cls_ks) != 1 or len(loc_ks) != 2 or cls_ks[0] != loc_ks[0] \
+                or loc_ks[0] != loc_ks[1]:
+            raise NotImplementedError("head shapes other than (h,) / (h,h)")
+        hw = cls_ks[0]
+        f = _as_f32(features)
+        nc, bl = int(num_classes), int(box_encoding_len)
+        assert nc <= 16 and bl <= 8
+
+        def build():
+            cls = store.mlp(scope + '/cls', 2)
+            locs = [store.mlp(scope + '/loc/cls_%d' % j, 3) for j in range(nc)]
+            c = cls[0][0].shape[0]
+            per_group = max(1, (320 // hw) - 1)   # loc heads beside cls
+            groups = []   # (has_cls, [loc ids])
+            ids = list(range(nc))
+            groups.append((True, ids[:per_group]))
+            ids = ids[per_group:]
+            per_rest = max(1, 320 // hw)
+            while ids:
+                groups.append((False, ids[:per_rest]))
+                ids = ids[per_rest:]
+            chains = []
+            for has_cls, lids in groups:
+                nh = len(lids) + (1 if has_cls else 0)
+                base = 16 if has_cls else 0       # logits block in L2/L3 out
+                w1 = np.zeros((c, hw * nh), np.float32)
+                b1 = np.zeros(hw * nh, np.float32)
+                w2 = np.zeros((hw * nh, base + hw * len(lids)), np.float32)
+                b2 = np.zeros(base + hw * len(lids), np.float32)
+                w3 = np.zeros((base + hw * len(lids), base + 8 * len(lids)),
+                              np.float32)
+                b3 = np.zeros(base + 8 * len(lids), np.float32)
+                slot = 0
+                if has_cls:
+                    w1[:, :hw], b1[:hw] = cls[0]
+                    w2[:hw, :nc], b2[:nc] = cls[1]
+                    w3[np.arange(nc), np.arange(nc)] = 1.0  # pass logits on
+                    slot = 1
+                for i, j in enumerate(lids):
+                    s = slot + i
+                    w1[:, hw * s:hw * (s + 1)], b1[hw * s:hw * (s + 1)] = \
+                        locs[j][0]
+                    w2[hw * s:hw * (s + 1), base + hw * i:base + hw * (i + 1)], \
+                        b2[base + hw * i:base + hw * (i + 1)] = locs[j][1]
+                    w3[base + hw * i:base + hw * (i + 1),
+                       base + 8 * i:base + 8 * i + bl], \
+                        b3[base + 8 * i:base + 8 * i + bl] = locs[j][2]
+                chain = Chain(store, [(w1, b1, 0), (w2, b2, base),
+                                      (w3, b3, w3.shape[1])])
+                chains.append((has_cls, lids, base, chain))
+            return c, chains
+        c, chains = store.cached(('heads', scope, nc, bl, hw), build)
+        logits = None
+        boxes = torch.empty((f.shape[0], nc, bl), dtype=torch.float32,
+                            device=f.device)
+        for has_cls, lids, base, chain in chains:
+            y = mlp_forward(chain, f, c)
+            if has_cls:
+                logits = y[:, :nc]
+            blk = y[:, base:base + 8 * len(lids)].reshape(-1, len(lids), 8)
+            boxes[:, lids[0]:lids[0] + len(lids), :] = blk[:, :, :bl]
+        return logits, boxes
+
+
+class ClassAwareSeparatedPredictor(object):
+    """gnn.py:165-209 -- registered by the reference, used by no shipped
+    config."""
+
+    def __init__(self, cls_fn, loc_fn):
+        self._cls_fn = cls_fn
+        self._loc_fn = loc_fn
+
+    def apply_regular(self, *args, **kwargs):
+        raise NotImplementedError("classaware_separated_predictor")
+
+
+def features(t, width):
+    """Strip the zero padding: [rows, padded] -> [rows, width] view."""
+    return t[:, :width]

@@ -1,0 +1,235 @@
+"""Graph construction -- the reference's `models/graph_gen.py` operator surface on
+the MI355X kernels of csrc/graph.hip.
+
+Same function names, keyword arguments and registry keys as the reference
+(graph_gen.py:155-157, 197-200, 222-227), so `run.py`'s
+`get_graph_generate_fn(config['graph_gen_method'])(xyz, **config[
+'runtime_graph_gen_kwargs'])` call (run.py:219-222) works unchanged.
+
+Array contract: NumPy in -> NumPy out (host round trip, drop-in); torch CUDA
+tensors in -> torch CUDA tensors out (device-resident fast path used by
+bench.py and the model).  Edges are int32 [E,2] rows (point_idx, centre_idx)
+grouped by ascending centre -- the reference emits the same grouping
+(graph_gen.py:215-219) with an unspecified order inside a centre.  Keypoint
+order is ascending voxel-hash bucket (the reference's is open3d's hash-map
+order / dict order: only the *set* is defined).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+__all__ = ["gen_disjointed_rnn_local_graph_v3",
+           "gen_multi_level_local_graph_v3", "get_graph_generate_fn",
+           "multi_layer_downsampling_select", "multi_layer_downsampling_random"]
+
+
+def _device():
+    if not torch.cuda.is_available():
+        raise _lib.PointGnnHipError(
+            "pointgnn_amd.graph_gen needs a GPU: there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _to_dev_f32(a):
+    """-> (contiguous float32 CUDA tensor [n,3], was_numpy)"""
+    if isinstance(a, torch.Tensor):
+        return a.to(device=_device(), dtype=torch.float32).contiguous(), False
+    arr = np.ascontiguousarray(np.asarray(a), dtype=np.float32)
+    return torch.from_numpy(arr).to(_device()), True
+
+
+def _scale3(scale):
+    if scale is None:
+        return None, ctypes.c_void_p(0)
+    s = np.broadcast_to(np.asarray(scale, dtype=np.float64).reshape(-1), (3,))
+    s = np.ascontiguousarray(s)
+    return s, ctypes.c_void_p(s.ctypes.data)
+
+
+def radius_graph_device(points, centers, radius, scale=None, num_neighbors=-1,
+                        seed=0):
+    """Device tensors in/out.  Returns (edges int32 [E,2], offsets int32
+    [Q+1]).  One host sync (reading E) per call, two when capping."""
+    lib = _lib.load()
+    dev = points.device
+    n_p, n_c = int(points.shape[0]), int(centers.shape[0])
+    ws_bytes = lib.pgnn_radius_graph_workspace_bytes(n_p, n_c)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    offsets = torch.empty(n_c + 1, dtype=torch.int32, device=dev)
+    keep, sp = _scale3(scale)
+    st = _lib.stream_ptr()
+    _lib.check(lib.pgnn_radius_graph_count(
+        _lib.ptr(points), n_p, _lib.ptr(centers), n_c, float(radius), sp,
+        _lib.ptr(ws), ws_bytes, _lib.ptr(offsets), st),
+        "pgnn_radius_graph_count")
+    n_e = int(offsets[-1].item())  # the one host sync
+    edges = torch.empty((n_e, 2), dtype=torch.int32, device=dev)
+    _lib.check(lib.pgnn_radius_graph_fill(
+        _lib.ptr(points), n_p, _lib.ptr(centers), n_c, float(radius), sp,
+        _lib.ptr(ws), ws_bytes, _lib.ptr(offsets), _lib.ptr(edges), n_e, st),
+        "pgnn_radius_graph_fill")
+    del keep
+    if num_neighbors is not None and num_neighbors > 0:
+        new_off = torch.empty(n_c + 1, dtype=torch.int32, device=dev)
+        _lib.check(lib.pgnn_cap_neighbors_count(
+            _lib.ptr(offsets), n_c, int(num_neighbors), _lib.ptr(new_off), st),
+            "pgnn_cap_neighbors_count")
+        n_e2 = int(new_off[-1].item())
+        if n_e2 != n_e:
+            new_edges = torch.empty((n_e2, 2), dtype=torch.int32, device=dev)
+            _lib.check(lib.pgnn_cap_neighbors_fill(
+                _lib.ptr(offsets), _lib.ptr(edges), n_c, int(num_neighbors),
+                int(seed) & 0xFFFFFFFFFFFFFFFF, _lib.ptr(new_off),
+                _lib.ptr(new_edges), n_e2, st), "pgnn_cap_neighbors_fill")
+            edges, offsets = new_edges, new_off
+    edges._pgnn_sorted = 1  # grouped by ascending centre (see gnn.mark_sorted)
+    return edges, offsets
+
+
+def gen_disjointed_rnn_local_graph_v3(
+        points_xyz, center_xyz, radius, num_neighbors,
+        neighbors_downsample_method='random', scale=None, seed=None):
+    """graph_gen.py:197-220.  `seed` (extension) keys the random fan-in cap;
+    default: drawn from numpy's global RNG like the reference's choice."""
+    if num_neighbors > 0 and neighbors_downsample_method != 'random':
+        # the reference silently skips the cap for any other method name
+        num_neighbors = -1
+    p, was_np = _to_dev_f32(points_xyz)
+    c, _ = _to_dev_f32(center_xyz)
+    if seed is None and num_neighbors > 0:
+        seed = int(np.random.randint(0, 2 ** 31 - 1))
+    edges, _ = radius_graph_device(p, c, radius, scale, num_neighbors,
+                                   seed or 0)
+    if was_np:
+        return edges.cpu().numpy()
+    return edges
+
+
+def keypoints_device(points, voxel_size, method='center', jitter=None, seed=0):
+    """One pooling level.  Returns (coords float32 [K,3], indices int32 [K,1])
+    as device tensors.  One host sync (reading K)."""
+    lib = _lib.load()
+    dev = points.device
+    n = int(points.shape[0])
+    ws_bytes = lib.pgnn_keypoints_workspace_bytes(n)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    kp_idx = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    kp_xyz = torch.empty((max(n, 1), 3), dtype=torch.float32, device=dev)
+    num = torch.zeros(1, dtype=torch.int32, device=dev)
+    st = _lib.stream_ptr()
+    if method == 'center':
+        _lib.check(lib.pgnn_voxel_keypoints_center(
+            _lib.ptr(points), n, float(voxel_size), _lib.ptr(ws), ws_bytes,
+            _lib.ptr(kp_idx), _lib.ptr(kp_xyz), _lib.ptr(num), st),
+            "pgnn_voxel_keypoints_center")
+    elif method == 'random':
+        jit = None
+        jp = ctypes.c_void_p(0)
+        if jitter is not None:
+            jit = np.ascontiguousarray(np.asarray(jitter, np.float64).reshape(3))
+            jp = ctypes.c_void_p(jit.ctypes.data)
+        _lib.check(lib.pgnn_voxel_keypoints_random(
+            _lib.ptr(points), n, float(voxel_size), jp,
+            int(seed) & 0xFFFFFFFFFFFFFFFF, _lib.ptr(ws), ws_bytes,
+            _lib.ptr(kp_idx), _lib.ptr(kp_xyz), _lib.ptr(num), st),
+            "pgnn_voxel_keypoints_random")
+    else:
+        raise ValueError("unknown downsample method %r" % (method,))
+    k = int(num.item())
+    return kp_xyz[:k], kp_idx[:k].reshape(k, 1)
+
+
+def _multi_layer_downsampling(points_xyz, base_voxel_size, levels, add_rnd3d,
+                              method):
+    p, was_np = _to_dev_f32(points_xyz)
+    coords = [p]
+    kp_list = []
+    last_level = 0
+    for level in levels:
+        base = coords[-1]
+        if np.isclose(last_level, level):
+            # same scale (a GNN level): same vertices, identity keypoints
+            coords.append(base)
+            kp_list.append(torch.arange(base.shape[0], dtype=torch.int32,
+                                        device=base.device).reshape(-1, 1))
+        else:
+            if len(coords) != 1:
+                raise NotImplementedError(
+                    "only one pooling level is supported (every shipped "
+                    "config has exactly one)")
+            voxel = base_voxel_size * level
+            if np.ndim(voxel) != 0:
+                raise NotImplementedError("per-axis voxel sizes")
+            if method == 'center':
+                if add_rnd3d:
+                    raise NotImplementedError(
+                        "add_rnd3d with downsample_method='center'")
+                c, i = keypoints_device(base, voxel, 'center')
+            else:
+                jitter = None
+                if add_rnd3d:  # graph_gen.py:126-128
+                    jitter = voxel * np.random.random(3)
+                seed = int(np.random.randint(0, 2 ** 31 - 1))
+                c, i = keypoints_device(base, voxel, 'random', jitter, seed)
+            coords.append(c)
+            kp_list.append(i)
+        last_level = level
+    return coords, kp_list, was_np
+
+
+def multi_layer_downsampling_select(points_xyz, base_voxel_size, levels=[1],
+                                    add_rnd3d=False):
+    """graph_gen.py:49-90 ('center' keypoints)."""
+    coords, kps, was_np = _multi_layer_downsampling(
+        points_xyz, base_voxel_size, levels, add_rnd3d, 'center')
+    if was_np:
+        return ([c.cpu().numpy() for c in coords],
+                [k.cpu().numpy() for k in kps])
+    return coords, kps
+
+
+def multi_layer_downsampling_random(points_xyz, base_voxel_size, levels=[1],
+                                    add_rnd3d=False):
+    """graph_gen.py:92-153 ('random' keypoints)."""
+    coords, kps, was_np = _multi_layer_downsampling(
+        points_xyz, base_voxel_size, levels, add_rnd3d, 'random')
+    if was_np:
+        return ([c.cpu().numpy() for c in coords],
+                [k.cpu().numpy() for k in kps])
+    return coords, kps
+
+
+def gen_multi_level_local_graph_v3(points_xyz, base_voxel_size, level_configs,
+                                   add_rnd3d=False, downsample_method='center'):
+    """graph_gen.py:155-195.  Returns (vertex_coord_list,
+    keypoint_indices_list, edges_list)."""
+    if isinstance(base_voxel_size, list):
+        base_voxel_size = np.array(base_voxel_size)
+    scales = [cfg['graph_scale'] for cfg in level_configs]
+    if downsample_method not in ('center', 'random'):
+        raise ValueError("unknown downsample_method %r" % (downsample_method,))
+    coords, kps, was_np = _multi_layer_downsampling(
+        points_xyz, base_voxel_size, scales, add_rnd3d, downsample_method)
+    edges_list = []
+    for cfg in level_configs:
+        lvl = cfg['graph_level']
+        fn = get_graph_generate_fn(cfg['graph_gen_method'])
+        edges_list.append(fn(coords[lvl], coords[lvl + 1],
+                             **cfg['graph_gen_kwargs']))
+    if was_np:
+        return ([c.cpu().numpy() for c in coords],
+                [k.cpu().numpy() for k in kps],
+                [e.cpu().numpy() for e in edges_list])
+    return coords, kps, edges_list
+
+
+def get_graph_generate_fn(method_name):
+    """graph_gen.py:222-227."""
+    method_map = {
+        'disjointed_rnn_local_graph_v3': gen_disjointed_rnn_local_graph_v3,
+        'multi_level_local_graph_v3': gen_multi_level_local_graph_v3,
+    }
+    return method_map[method_name]

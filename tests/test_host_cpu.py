@@ -1,0 +1,182 @@
+"""Host-side logic that needs no GPU: configs, variable specs, checkpoint
+reader, synthetic input, C-ABI library load/symbols, weight packing layout."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+import pointgnn_amd  # noqa: F401
+from pointgnn_amd import configs, tf_bundle, weights
+from pointgnn_amd.synthetic import synthetic_cloud
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+REF = "/root/reference"
+
+
+def test_param_counts_match_reference_checkpoints():
+    # SURVEY.md §8c totals (include the int32 global-step scalar)
+    expect = {"car_auto_T0": 344933, "car_auto_T1": 726492,
+              "car_auto_T2": 1108051, "car_auto_T3": 1489610,
+              "ped_cyl_auto_T3": 1357274, "car_fixed_T3": 1431233}
+    for name, total in expect.items():
+        assert weights.count_params(configs.get_config(name)) + 1 == total
+
+
+def test_variable_names_match_golden_weights():
+    for t in (0, 1):
+        w = np.load(os.path.join(GOLD, "weights_car_auto_T%d.npz" % t))
+        spec = dict(weights.variable_specs(configs.car_auto_config(t)))
+        assert set(spec) == set(w.files)
+        for k, shape in spec.items():
+            assert w[k].shape == tuple(shape)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree absent")
+def test_generated_configs_equal_reference_json():
+    pairs = [("car_auto_T0", "car_auto_T0_train_config"),
+             ("car_auto_T1", "car_auto_T1_train_config"),
+             ("car_auto_T2", "car_auto_T2_train_config"),
+             ("car_auto_T3", "car_auto_T3_train_config"),
+             ("car_auto_T3", "car_auto_T3_trainval_config"),
+             ("car_fixed_T3", "car_fixed_T3_train_config"),
+             ("ped_cyl_auto_T3", "ped_cyl_auto_T3_trainval_config")]
+    for name, fname in pairs:
+        ref = configs.load_config(os.path.join(REF, "configs", fname))
+        assert ref == configs.get_config(name), fname
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree absent")
+def test_tf_bundle_reader_on_reference_checkpoints():
+    for t in (0, 1):
+        ck = tf_bundle.load_checkpoint(
+            os.path.join(REF, "checkpoints", "car_auto_T%d_train" % t))
+        assert int(ck["Variable"]) == 1400000
+        gold = np.load(os.path.join(GOLD, "weights_car_auto_T%d.npz" % t))
+        for k in gold.files:
+            assert np.array_equal(ck[k], gold[k])
+    # index-only checkpoints still list names/shapes
+    names = tf_bundle.list_variables(os.path.join(
+        REF, "checkpoints", "car_auto_T3_train", "model-1400000"))
+    spec = dict(weights.variable_specs(configs.car_auto_config(3)))
+    got = {n: s for n, _, s, _, _ in names if n != "Variable"}
+    assert got == {k: tuple(v) for k, v in spec.items()}
+
+
+def test_synthetic_cloud_is_deterministic_and_shaped():
+    a, ia = synthetic_cloud(seed=4, preset="tiny")
+    b, ib = synthetic_cloud(seed=4, preset="tiny")
+    assert np.array_equal(a, b) and np.array_equal(ia, ib)
+    assert a.dtype == np.float32 and a.shape == (1500, 3)
+    assert ia.shape == (1500, 1) and ia.min() >= 0 and ia.max() < 1
+    c, _ = synthetic_cloud(seed=5, preset="tiny")
+    assert not np.array_equal(a, c)
+    assert a[:, 2].min() > 0          # camera frame: z forward
+    rng = np.sqrt((a ** 2).sum(1))
+    assert rng.min() > 1.9 and rng.max() < 71
+
+
+def test_init_params_shapes_and_seed():
+    cfg = configs.car_auto_config(1)
+    p = weights.init_params(cfg, seed=1)
+    q = weights.init_params(cfg, seed=1)
+    for (name, shape) in weights.variable_specs(cfg):
+        assert p[name].shape == tuple(shape) and p[name].dtype == np.float32
+        assert np.array_equal(p[name], q[name])
+    w = p["layer2/extract_vertex_features/fully_connected/weights"]
+    assert w.shape == (303, 300)
+    assert np.abs(w).max() <= np.sqrt(6.0 / 603) + 1e-6
+
+
+# ---- C-ABI library ---------------------------------------------------------
+def _lib():
+    from pointgnn_amd import _lib as L
+    if not os.path.exists(L.LIB_PATH):
+        from pointgnn_amd import build
+        build.build(verbose=False)
+    return L, L.load()
+
+
+def test_library_exports_every_declared_symbol():
+    L, lib = _lib()
+    header = open(os.path.join(ROOT, "include", "pointgnn_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(pgnn_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(lib, name), "missing export: " + name
+    # the Python binding covers the header (plus the tuning hook)
+    assert declared <= set(L.exported_symbols())
+    assert lib.pgnn_version() >= 100
+
+
+def test_error_reporting_without_gpu():
+    L, lib = _lib()
+    # argument validation happens before any HIP call
+    rc = lib.pgnn_scatter_max_f32(None, 4, None, 5, 8, 3, None, 4, 0, None)
+    assert rc == -1
+    assert b"stride" in lib.pgnn_last_error()
+    assert lib.pgnn_pack_fc(None, None, 4, 4, None) == -1
+    assert lib.pgnn_packed_fc_floats(303, 300) == 19 * 19 * 256 + 19 * 16
+    with pytest.raises(L.PointGnnHipError):
+        L.check(-1, "demo")
+
+
+def _emulate_mfma_layer(x, packed, k_in, n_out):
+    """NumPy model of mlp_engine.h: A fragment = x[row][16q + 4g + s], B
+    fragment = packed[q][t][lane][s]; v_mfma_f32_16x16x4 sums the four k-slots
+    g = lane>>4; D[row][col] lives in lane = col + 16*(row//4), reg row%4."""
+    kq, nt = (k_in + 15) // 16, (n_out + 15) // 16
+    rows = x.shape[0]
+    assert rows % 16 == 0
+    xp = np.zeros((rows, 16 * kq), np.float32)
+    xp[:, :k_in] = x
+    w = packed[:kq * nt * 256].reshape(kq, nt, 64, 4)
+    bias = packed[kq * nt * 256:]
+    out = np.zeros((rows, 16 * nt), np.float32)
+    lanes = np.arange(64)
+    for m in range(rows // 16):
+        for t in range(nt):
+            acc = np.zeros((16, 16), np.float32)
+            for q in range(kq):
+                for s in range(4):
+                    a = np.zeros((16, 4), np.float32)   # A[i][kslot]
+                    b = np.zeros((4, 16), np.float32)   # B[kslot][j]
+                    a[lanes & 15, lanes >> 4] = xp[16 * m + (lanes & 15),
+                                                   16 * q + 4 * (lanes >> 4) + s]
+                    b[lanes >> 4, lanes & 15] = w[q, t, lanes, s]
+                    acc += a @ b
+            out[16 * m:16 * m + 16, 16 * t:16 * t + 16] = acc
+    return out + bias[None, :]
+
+
+@pytest.mark.parametrize("k_in,n_out", [(4, 32), (303, 300), (64, 3), (20, 17)])
+def test_pack_fc_layout_reproduces_matmul(k_in, n_out):
+    L, lib = _lib()
+    rng = np.random.default_rng(k_in * 1000 + n_out)
+    w = rng.standard_normal((k_in, n_out)).astype(np.float32)
+    b = rng.standard_normal(n_out).astype(np.float32)
+    n = lib.pgnn_packed_fc_floats(k_in, n_out)
+    packed = np.full(n, np.nan, np.float32)
+    assert lib.pgnn_pack_fc(w.ctypes.data, b.ctypes.data, k_in, n_out,
+                            packed.ctypes.data) == 0
+    assert np.isfinite(packed).all()
+    x = rng.standard_normal((16, k_in)).astype(np.float32)
+    got = _emulate_mfma_layer(x, packed, k_in, n_out)
+    ref = x.astype(np.float64) @ w.astype(np.float64) + b
+    np.testing.assert_allclose(got[:, :n_out], ref, atol=1e-4, rtol=1e-4)
+    assert np.all(got[:, n_out:] == 0)       # zero padding stays zero
+
+
+def test_product_path_has_no_oracle_import():
+    """The shipped package must never reach into oracle/ (or any CPU
+    fallback)."""
+    pkg = os.path.join(ROOT, "point-gnn_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f
