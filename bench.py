@@ -1,0 +1,340 @@
+#!/usr/bin/env python
+"""Benchmark of the Point-GNN hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one synthetic KITTI-shaped frame
+(~20k points): device-side graph construction (keypoints + two radius graphs)
++ PointSetPooling + T GraphNetAutoCenter iterations + prediction heads for
+`car_auto_T3` inference -- what run.py does per frame between "fetch input"
+and "decode box" (run.py:219-263).  Inputs (xyz, intensity) are resident in
+HBM before the timed region.  Frames are independent: rank r of N processes
+takes frames r, r+N, ... (weak scaling, no collective on the data path).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra
+objects: `roofline` (standalone scatter-max kernel, HBM-bound, timed with
+events on the launch stream) and `cpu_baseline` (the oracle = CPU port of the
+reference path, timed on the host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_MFMA_PEAK_TF = 157.3    # MI355X_MICROARCH.md: FP32 matrix peak
+
+
+def algorithmic_flops_per_frame(cfg, n_k, n_e0, n_e1):
+    """2*in*out per row per FC layer, un-factorised."""
+    lcs = cfg['model_kwargs']['layer_configs']
+    total = 0
+    dim = 1
+    for lc in lcs[:-1]:
+        kw = lc['kwargs']
+        if lc['type'] == 'scatter_max_point_set_pooling':
+            d = dim + 3
+            for w in kw['point_MLP_depth_list']:
+                total += 2 * d * w * n_e0
+                d = w
+            for w in kw['output_MLP_depth_list']:
+                total += 2 * d * w * n_k
+                d = w
+            dim = d
+        else:
+            if kw['auto_offset']:
+                d = dim
+                for w in kw['auto_offset_MLP_depth_list']:
+                    total += 2 * d * w * n_k
+                    d = w
+            d = dim + 3
+            for w in kw['edge_MLP_depth_list']:
+                total += 2 * d * w * n_e1
+                d = w
+            for w in kw['update_MLP_depth_list']:
+                total += 2 * d * w * n_k
+                d = w
+    nc = cfg['num_classes']
+    total += n_k * (2 * dim * 64 + 2 * 64 * nc)
+    total += n_k * nc * (2 * dim * 64 + 2 * 64 * 64 + 2 * 64 * 7)
+    return total
+
+
+def time_kernel(fn, reps, torch):
+    """Average duration (s) of fn() over reps launches, HIP events on the
+    current (launch) stream."""
+    for _ in range(3):
+        fn()
+    start = torch.cuda.Event(enable_timing=True)
+    stop = torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    start.record()
+    for _ in range(reps):
+        fn()
+    stop.record()
+    stop.synchronize()
+    return start.elapsed_time(stop) * 1e-3 / reps
+
+
+def roofline_scatter_max(torch, edges1, n_k, width, reps=30):
+    """Standalone scatter-max on an [E1, C] fp32 matrix resident in HBM, dst
+    ids of the real level-1 graph (sorted).  Algorithmic bytes per launch =
+    E*C*4 + E*4 + K*C*4."""
+    from pointgnn_amd import gnn
+    n_e = int(edges1.shape[0])
+    # several distinct buffers so that the 256 MiB Infinity Cache cannot serve
+    # the reads of the next launch
+    bufs = [torch.randn((n_e, width), device=edges1.device) for _ in range(3)]
+    dst = edges1[:, 1].contiguous()
+    state = {"i": 0}
+
+    def run():
+        gnn.graph_scatter_max_fn(bufs[state["i"] % 3], dst, n_k,
+                                 ids_sorted=True)
+        state["i"] += 1
+    dur = time_kernel(run, reps, torch)
+    alg = n_e * width * 4 + n_e * 4 + n_k * width * 4
+    return {
+        "kernel": "scatter_max_kernel (standalone, [E1,C] fp32, sorted dst)",
+        "bound": "hbm", "achieved": alg / dur / 1e9, "peak": HBM_PEAK_GBS,
+        "unit": "GB/s", "frac": alg / dur / 1e9 / HBM_PEAK_GBS,
+        "traffic": None, "algorithmic_bytes": alg,
+        "avg_launch_us": dur * 1e6,
+        "note": "duration includes the 4*K*C-byte lowest() fill memset",
+    }
+
+
+def roofline_edge_kernel(torch, engine, edges1, n_k, reps=10):
+    """Fused gather + edge-MLP layer 2 + scatter-max kernel (MFMA-bound)."""
+    from pointgnn_amd import _lib, gnn
+    lib = _lib.load()
+    store = engine.model._store
+    lc = [l for l in engine.config['model_kwargs']['layer_configs']
+          if l['type'] == 'scatter_max_graph_auto_center_net']
+    if not lc:
+        return None
+    key = [k for k in store._cache if k[0] == 'edge']
+    if not key:
+        return None
+    c, p_chain, wx_dev, rest = store._cache[key[0]]
+    wq = int(wx_dev.shape[1])
+    dev = edges1.device
+    p = torch.randn((n_k, wq), device=dev)
+    q = torch.randn((n_k, wq), device=dev) * 0.1
+    p[:, c:] = 0
+    q[:, c:] = 0
+    agg = torch.empty((n_k, gnn.padded_width(rest.n_out)), device=dev)
+    n_e = int(edges1.shape[0])
+
+    def run():
+        _lib.check(lib.pgnn_edge_mlp_scatter_max_fwd(
+            _lib.ptr(p), _lib.ptr(q), wq, int(rest.k_in), _lib.ptr(edges1),
+            n_e, n_k, rest.array, rest.n, 1, _lib.ptr(agg), agg.stride(0),
+            _lib.stream_ptr()), "edge kernel")
+    dur = time_kernel(run, reps, torch)
+    widths = lc[0]['kwargs']['edge_MLP_depth_list']
+    executed = sum(2 * a * b for a, b in zip(widths[:-1], widths[1:])) * n_e
+    return {
+        "kernel": "fused_mlp_kernel<EDGE> (gather + edge FC2 + scatter-max)",
+        "bound": "mfma", "achieved": executed / dur / 1e12,
+        "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+        "frac": executed / dur / 1e12 / FP32_MFMA_PEAK_TF,
+        "executed_flops": executed, "avg_launch_us": dur * 1e6,
+        "note": "fp32 MFMA (16x16x4); FLOPs = 2*E*sum(in*out) of the layers "
+                "this kernel executes (first edge layer is factored per vertex)",
+    }
+
+
+def cpu_baseline(cfg, params, xyz, inten, budget_s=20.0):
+    """The oracle (CPU port of the reference path: scikit-learn ball tree as
+    the reference calls it + NumPy/BLAS GNN) timed on this host.  Bounded: the
+    GNN part runs on the sub-graph of the first K' keypoints, K' chosen from a
+    short GEMM probe so the whole leg takes ~budget_s; throughput is scaled by
+    the edge fraction."""
+    from oracle import graph_oracle as go
+    from oracle import gnn_oracle as gn
+    t0 = time.perf_counter()
+    coords, kps, edges = go.multi_level_graph(xyz, **cfg['runtime_graph_gen_kwargs'])
+    t_graph = time.perf_counter() - t0
+    n_k = coords[1].shape[0]
+    e0, e1 = np.asarray(edges[0]), np.asarray(edges[1])
+    # GEMM probe -> sustained GFLOP/s of this host's BLAS
+    a = np.random.default_rng(0).standard_normal((4096, 304)).astype(np.float32)
+    b = np.random.default_rng(1).standard_normal((304, 304)).astype(np.float32)
+    a @ b
+    t = time.perf_counter()
+    for _ in range(5):
+        a @ b
+    gflops = 5 * 2 * 4096 * 304 * 304 / (time.perf_counter() - t) / 1e9
+    total = algorithmic_flops_per_frame(cfg, n_k, len(e0), len(e1))
+    est = total / (gflops * 1e9) * 1.5
+    frac = min(1.0, max(0.02, (budget_s - t_graph) / max(est, 1e-9)))
+    k_sub = max(16, int(n_k * frac))
+    m0 = e0[:, 1] < k_sub
+    # level-1 sub-graph induced by the first k_sub keypoints
+    m1 = (e1[:, 1] < k_sub) & (e1[:, 0] < k_sub)
+    sub_coords = [coords[0], coords[1][:k_sub], coords[2][:k_sub]]
+    sub_kps = [kps[0][:k_sub], kps[1][:k_sub]]
+    sub_edges = [e0[m0], e1[m1]]
+    t = time.perf_counter()
+    gn.predict(params, cfg, inten, sub_coords, sub_kps, sub_edges)
+    t_gnn_sub = time.perf_counter() - t
+    sub_flops = algorithmic_flops_per_frame(cfg, k_sub, int(m0.sum()),
+                                            int(m1.sum()))
+    t_gnn_full = t_gnn_sub * total / max(sub_flops, 1)
+    try:
+        import threadpoolctl
+        threads = max([p.get('num_threads', 1)
+                       for p in threadpoolctl.threadpool_info()] + [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    return {
+        "value": 1.0 / (t_graph + t_gnn_full), "unit": "frames/s",
+        "cores": int(threads), "kind": "port",
+        "sample": "1 frame: full graph build with the reference's sklearn "
+                  "calls, single-threaded as shipped (%.2f s); GNN oracle "
+                  "(NumPy fp32, BLAS threads=%d, %.0f GFLOP/s probe) on the "
+                  "sub-graph of the first %d of %d keypoints (%.1f%% of the "
+                  "frame's FLOPs, %.2f s) scaled to the full frame (%.1f s)"
+                  % (t_graph, threads, gflops, k_sub, n_k,
+                     100.0 * sub_flops / total, t_gnn_sub, t_gnn_full),
+        "gen_graph_s": t_graph, "gnn_inference_s_scaled": t_gnn_full,
+        "host_cpu_count": os.cpu_count(),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=48)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--config", default="car_auto_T3")
+    ap.add_argument("--preset", default="car")
+    ap.add_argument("--frames", type=int, default=8,
+                    help="distinct synthetic frames in the pool")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    args = ap.parse_args()
+
+    import torch
+    import pointgnn_amd  # noqa: F401
+    from pointgnn_amd import configs, weights
+    from pointgnn_amd.engine import InferenceEngine, shard_frames
+    from pointgnn_amd.synthetic import synthetic_cloud
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the hot path has no CPU "
+                         "fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    cfg = configs.get_config(args.config)
+    params = weights.init_params(cfg, seed=0, bias_scale=0.05)
+    engine = InferenceEngine(cfg, params, device=dev)
+
+    # frame pool resident in HBM; rank r owns frames r, r+W, ... of the stream
+    my_ids = shard_frames(world * (args.steps + args.warmup), rank, world)
+    seeds = sorted({i % args.frames for i in my_ids})
+    pool = {}
+    for s in seeds:
+        xyz, inten = synthetic_cloud(seed=s, preset=args.preset)
+        pool[s] = (torch.from_numpy(xyz).to(dev), torch.from_numpy(inten).to(dev),
+                   xyz, inten)
+
+    def step(i):
+        x, f, _, _ = pool[my_ids[i] % args.frames]
+        return engine.run_frame(x, f)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        out = step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(out[0]).all()
+
+    if rank == 0:
+        # shape of frame 0's graph + per-phase wall clock (outside the timed
+        # region; run.py's phase names)
+        x, f, xyz_np, inten_np = pool[seeds[0]]
+        engine.time_dict = {}
+        for _ in range(3):
+            engine.run_frame(x, f, timed=True)
+        coords, kps, edges = engine.last_graph
+        n_k = int(coords[1].shape[0])
+        n_e0, n_e1 = int(edges[0].shape[0]), int(edges[1].shape[0])
+        frames = engine.time_dict['frames']
+        total_flops = algorithmic_flops_per_frame(cfg, n_k, n_e0, n_e1)
+        fps = world * args.steps / elapsed
+        res = {
+            "metric": "KITTI-shaped frames/sec (%s inference: graph build + "
+                      "GNN, ~20k pts)" % args.config,
+            "value": fps, "unit": "frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": "%s inference, 1 frame/step/GPU, synthetic "
+                            "HDL-64E-shaped cloud preset '%s', seeded "
+                            "Xavier weights" % (args.config, args.preset),
+                "N": int(x.shape[0]), "K": n_k, "E0": n_e0, "E1": n_e1,
+                "frames_per_gpu_per_step": 1,
+                "parallelism": "frame-parallel x%d (no collective)" % world,
+                "frames_per_sec_per_gpu": fps / world,
+                "algorithmic_gflop_per_frame": total_flops / 1e9,
+                "algorithmic_tflops": total_flops * fps / world / 1e12,
+                "phase_ms": {
+                    "gen graph": engine.time_dict['gen graph'] / frames * 1e3,
+                    "gnn inference":
+                        engine.time_dict['gnn inference'] / frames * 1e3},
+            },
+        }
+        if not args.no_roofline:
+            width = cfg['model_kwargs']['layer_configs'][1]['kwargs'][
+                'edge_MLP_depth_list'][-1] if len(
+                cfg['model_kwargs']['layer_configs']) > 2 else 300
+            res["roofline"] = roofline_scatter_max(torch, edges[1], n_k, width)
+            mf = roofline_edge_kernel(torch, engine, edges[1], n_k)
+            if mf is not None:
+                res["roofline_mfma"] = mf
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(cfg, params, xyz_np, inten_np,
+                                               args.cpu_budget)
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

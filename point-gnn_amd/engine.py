@@ -1,0 +1,69 @@
+"""Frame-level driver of the hot path: what `run.py`'s per-frame loop does
+between "fetch input" and "decode box" (run.py:219-263), device-resident.
+
+    engine = InferenceEngine(config, params)
+    logits, boxes = engine.run_frame(xyz_cuda, intensity_cuda)
+
+Phase names follow run.py's `time_dict` keys ("gen graph", "gnn inference").
+`shard_frames` is the multi-GPU decomposition: frames are independent units,
+rank r takes frames r, r+W, ... -- inference needs no collective
+(SURVEY.md §8e).
+"""
+import time
+
+import torch
+
+from . import graph_gen, models
+
+__all__ = ["InferenceEngine", "shard_frames"]
+
+
+def shard_frames(num_frames, rank, world_size):
+    """Indices of the frames rank `rank` of `world_size` processes."""
+    if not (0 <= rank < world_size):
+        raise ValueError("rank %d outside world of %d" % (rank, world_size))
+    return list(range(rank, num_frames, world_size))
+
+
+class InferenceEngine(object):
+    def __init__(self, config, params, box_encoding_len=7, device=None):
+        self.config = config
+        self.model = models.get_model(config['model_name'])(
+            num_classes=config['num_classes'],
+            box_encoding_len=box_encoding_len, mode='test',
+            **config['model_kwargs'])
+        self.model.load_state_dict(params, device)
+        self.graph_fn = graph_gen.get_graph_generate_fn(
+            config['graph_gen_method'])
+        self.graph_kwargs = config['runtime_graph_gen_kwargs']
+        self.time_dict = {}
+        self.last_graph = None
+
+    def build_graph(self, xyz):
+        """(vertex_coord_list, keypoint_indices_list, edges_list) on the
+        device -- run.py:219-222."""
+        return self.graph_fn(xyz, **self.graph_kwargs)
+
+    def run_frame(self, xyz, intensity, timed=False):
+        """xyz [N,3] float32, intensity [N,F] float32 CUDA tensors ->
+        (logits [K,nc], box_encodings [K,nc,7]) CUDA tensors.  With
+        timed=True the two phases are wall-clocked (adds two device syncs)."""
+        if timed:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        graph = self.build_graph(xyz)
+        if timed:
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+        coords, kps, edges = graph
+        out = self.model.predict(intensity, coords, kps, edges,
+                                 is_training=False)
+        if timed:
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            d = self.time_dict
+            d['gen graph'] = d.get('gen graph', 0.0) + (t1 - t0)
+            d['gnn inference'] = d.get('gnn inference', 0.0) + (t2 - t1)
+            d['frames'] = d.get('frames', 0) + 1
+        self.last_graph = graph
+        return out
