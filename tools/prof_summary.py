@@ -4,7 +4,7 @@
     python tools/prof_summary.py gpurun_out/prof/bench_results.db profiles/r01_bench_kernel_stats
 
 rocprofv3 in ROCm 7.2 writes a rocpd database by default; its `top_kernels`
-view is the `--stats` table (name, calls, total/avg duration in ns)."""
+view is the `--stats` table (name, calls, total/avg duration in microseconds)."""
 import csv
 import sqlite3
 import sys
@@ -17,7 +17,7 @@ def main(db_path, out_prefix, note=""):
         "from top_kernels order by total_duration desc"))
     with open(out_prefix + ".csv", "w", newline="") as f:
         w = csv.writer(f)
-        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage"])
+        w.writerow(["Name", "Calls", "TotalDurationUs", "AverageUs", "Percentage"])
         for r in rows:
             w.writerow(r)
     with open(out_prefix + ".md", "w") as f:
@@ -29,7 +29,7 @@ def main(db_path, out_prefix, note=""):
             short = name.replace("(anonymous namespace)::", "").replace("pgnn::", "")
             short = short.split("(")[0][:70]
             f.write("| `%s` | %d | %.3f | %.2f | %.2f |\n" % (
-                short, calls, tot / 1e6, avg / 1e3, pct))
+                short, calls, tot / 1e3, avg, pct))
     print(out_prefix + ".md")
 
 
