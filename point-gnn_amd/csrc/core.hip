@@ -30,6 +30,9 @@ int device_cu_count() {
 
 extern int g_scatter_rows_per_wave;
 extern int g_mlp_blocks_per_cu;
+extern int g_edge_msub;
+extern int g_pool_msub;
+extern int g_mlp_debug;
 
 }  // namespace pgnn
 
@@ -55,13 +58,25 @@ extern "C" int pgnn_check_device_pointer(const void *p) {
 extern "C" int pgnn_set_tunable(const char *key, int value) {
   if (!key) return PGNN_E_INVALID;
   if (!strcmp(key, "scatter_rows_per_wave")) {
-    if (value < 1 || value > 4096) return PGNN_E_INVALID;
+    if (value < 0 || value > 65536) return PGNN_E_INVALID;
     pgnn::g_scatter_rows_per_wave = value;
     return 0;
   }
   if (!strcmp(key, "mlp_blocks_per_cu")) {
     if (value < 1 || value > 8) return PGNN_E_INVALID;
     pgnn::g_mlp_blocks_per_cu = value;
+    return 0;
+  }
+  if (!strcmp(key, "edge_msub")) {
+    pgnn::g_edge_msub = value;
+    return 0;
+  }
+  if (!strcmp(key, "mlp_debug")) {
+    pgnn::g_mlp_debug = value;
+    return 0;
+  }
+  if (!strcmp(key, "pool_msub")) {
+    pgnn::g_pool_msub = value;
     return 0;
   }
   return pgnn::fail(PGNN_E_INVALID, "unknown tunable");

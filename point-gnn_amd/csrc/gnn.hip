@@ -15,7 +15,11 @@
 #include "mlp_engine.h"
 
 namespace pgnn {
-int g_mlp_blocks_per_cu = 2;
+int g_mlp_blocks_per_cu = 4;  // upper bound; LDS usually allows fewer
+int g_edge_msub = 0;          // 0 = auto, else force 16*msub-row tiles
+int g_pool_msub = 0;
+int g_mlp_debug = 0;  // ablation mask (benchmarks only): 1 = no gather loads,
+                      // 2 = no last-layer GEMM, 4 = no epilogue
 }
 
 namespace {
@@ -56,36 +60,78 @@ struct SegArgs {
 };
 
 __host__ __device__ inline int ints_bytes(int rows) {
-  return ((rows + 2) * 4 + 15) / 16 * 16;
+  return ((2 * rows + 2) * 4 + 15) / 16 * 16;  // dst[rows+2] + src[rows]
 }
+
+// Open segment carried from one tile to the next inside a workgroup's
+// contiguous tile range (sorted edges only): id of the segment whose partial
+// max sits in the LDS `carry` row, and whether its first edge is known to lie
+// inside this workgroup's range.
+struct CarryState {
+  int id;           // -1: nothing carried
+  int left_closed;
+};
 
 // Column-wise segmented max of stage[ROWS][ncols] keyed by dst[1..ROWS]
 // (dst[0] / dst[ROWS+1] = id of the edge before / after the tile, -1 if none).
+// Runs wholly inside the workgroup's range are complete segments: one plain
+// coalesced row store.  A run that continues into the workgroup's next tile
+// is folded into `carry` instead of being flushed, so a segment spanning many
+// tiles costs one store in total; only the (at most two) runs that cross the
+// workgroup's range boundary use float atomic-max.  Unsorted ids: every run
+// is flushed atomically.  Control flow depends on dst[] only, so it is
+// uniform across the workgroup and every thread returns the same state.
 template <int ROWS>
-__device__ __forceinline__ void consume_segmax(const float *__restrict__ stage,
-                                               int ld, const int *__restrict__ dst,
-                                               int col0, int ncols,
-                                               const SegArgs &sa) {
-  for (int c = threadIdx.x; c < ncols; c += 256) {
-    int r = 0;
-    while (r < ROWS) {
-      const int d = dst[r + 1];
-      int re = r + 1;
-      while (re < ROWS && dst[re + 1] == d) ++re;
-      if (d >= 0 && d < sa.num_segments) {
-        float m = stage[r * ld + c];
-        for (int k = r + 1; k < re; ++k) m = fmaxf(m, stage[k * ld + c]);
-        const bool whole = sa.sorted && (r > 0 || dst[0] != d) &&
-                           (re < ROWS || dst[ROWS + 1] != d);
-        float *o = sa.out + (int64_t)d * sa.ldo + col0 + c;
-        if (whole)
-          *o = m;
-        else
-          atomic_max_f32(o, m + 0.0f);
+__device__ __forceinline__ CarryState consume_segmax(
+    const float *__restrict__ stT /* transposed+swizzled, see store_acc_T */,
+    const int *__restrict__ dst, int col0, int ncols, const SegArgs &sa,
+    float *__restrict__ carry, CarryState cs, bool keep_open) {
+  constexpr int G = ROWS / 4, SWZ = (G < 16 ? G : 16) - 1;
+  CarryState out = {-1, 0};
+  int r = 0;
+  while (r < ROWS) {
+    const int d = dst[r + 1];
+    int re = r + 1;
+    while (re < ROWS && dst[re + 1] == d) ++re;
+    if (d >= 0 && d < sa.num_segments) {
+      bool left_closed = (r > 0) || (dst[0] != d);
+      const bool merge = sa.sorted && r == 0 && cs.id == d;
+      if (merge) left_closed = cs.left_closed != 0;
+      const bool right_closed = (re < ROWS) || (dst[ROWS + 1] != d);
+      const bool defer = sa.sorted && !right_closed && keep_open;
+      const bool whole = sa.sorted && left_closed && right_closed;
+      const int g0 = r >> 2, g1 = (re - 1) >> 2;
+      for (int c = threadIdx.x; c < ncols; c += 256) {
+        const float *col = stT + c * ROWS;
+        const int sw = c & SWZ;
+        float m = kFloatLowest;
+        for (int g = g0; g <= g1; ++g) {
+          const v4f x = *reinterpret_cast<const v4f *>(col + ((g ^ sw) << 2));
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int row = 4 * g + i;
+            if (row >= r && row < re) m = fmaxf(m, x[i]);
+          }
+        }
+        if (merge) m = fmaxf(m, carry[col0 + c]);
+        if (defer) {
+          carry[col0 + c] = m;
+        } else {
+          float *o = sa.out + (int64_t)d * sa.ldo + col0 + c;
+          if (whole)
+            *o = m;
+          else
+            atomic_max_f32(o, m + 0.0f);
+        }
       }
-      r = re;
+      if (defer) {
+        out.id = d;
+        out.left_closed = left_closed ? 1 : 0;
+      }
     }
+    r = re;
   }
+  return out;
 }
 
 template <int ROWS>
@@ -105,18 +151,27 @@ __device__ __forceinline__ void consume_rows(const float *__restrict__ stage,
 template <int MSUB, int PRO>
 __global__ __launch_bounds__(256, 2) void fused_mlp_kernel(
     ChainDev chain, int64_t n_rows, RowsArgs ra, PoolArgs pa, EdgeArgs ea,
-    SegArgs sa, int stage_off /* floats from tile base; < 0: in place */) {
+    SegArgs sa, int stage_off /* floats from tile base; < 0: in place */,
+    int dbg) {
   constexpr int ROWS = 16 * MSUB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int *dst = reinterpret_cast<int *>(smem);
-  float *tile = reinterpret_cast<float *>(smem + ints_bytes(ROWS));
+  int *src = dst + ROWS + 2;
+  float *carry = reinterpret_cast<float *>(smem + ints_bytes(ROWS));
+  float *tile = carry + 16 * chain.l[chain.n - 1].nt;
   float *stage = stage_off >= 0 ? tile + stage_off : tile;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t n_tiles = (n_rows + ROWS - 1) / ROWS;
   const int ld0 = lds_ld(16 * chain.l[0].kq);
 
-  for (int64_t tile_id = blockIdx.x; tile_id < n_tiles; tile_id += gridDim.x) {
+  // contiguous tile range per workgroup (remainder spread over the first ones)
+  const int64_t tq = n_tiles / gridDim.x, trem = n_tiles % gridDim.x;
+  const int64_t tile_first =
+      blockIdx.x * tq + (blockIdx.x < trem ? blockIdx.x : trem);
+  const int64_t tile_last = tile_first + tq + (blockIdx.x < trem ? 1 : 0);
+  CarryState cs = {-1, 0};
+  for (int64_t tile_id = tile_first; tile_id < tile_last; ++tile_id) {
     const int64_t row0 = tile_id * ROWS;
     const int rows_valid =
         (int)((n_rows - row0 < ROWS) ? (n_rows - row0) : ROWS);
@@ -170,39 +225,56 @@ __global__ __launch_bounds__(256, 2) void fused_mlp_kernel(
         dst[ROWS + 1] =
             row0 + ROWS < n_rows ? pa.edges[2 * (row0 + ROWS) + 1] : -1;
     } else {  // PRO_EDGE
-      constexpr int RPW = ROWS / 4;  // rows per wave
       const int ldv4 = (int)(ea.ldpq >> 2);
       const v4f *__restrict__ P4 = reinterpret_cast<const v4f *>(ea.P);
       const v4f *__restrict__ Q4 = reinterpret_cast<const v4f *>(ea.Q);
-      const int64_t ebase = row0 + wave * RPW;
-      int my_s = 0, my_d = -1;
-      if (lane < RPW && ebase + lane < n_rows) {
-        my_s = ea.edges[2 * (ebase + lane)];
-        my_d = ea.edges[2 * (ebase + lane) + 1];
+      if (threadIdx.x < ROWS) {
+        const int64_t e = row0 + threadIdx.x;
+        int s_ = 0, d_ = -1;
+        if (e < n_rows) {
+          s_ = ea.edges[2 * e];
+          d_ = ea.edges[2 * e + 1];
+        }
+        src[threadIdx.x] = s_;
+        dst[threadIdx.x + 1] = d_;
       }
-      if (lane < RPW) dst[wave * RPW + lane + 1] = my_d;
-      if (threadIdx.x == 0)
-        dst[0] = row0 > 0 ? ea.edges[2 * (row0 - 1) + 1] : -1;
       if (threadIdx.x == 64)
+        dst[0] = row0 > 0 ? ea.edges[2 * (row0 - 1) + 1] : -1;
+      if (threadIdx.x == 65)
         dst[ROWS + 1] =
             row0 + ROWS < n_rows ? ea.edges[2 * (row0 + ROWS) + 1] : -1;
+      __syncthreads();
+      // The tile is ROWS x ldv4 float4 elements; thread t takes elements
+      // t, t+256, ... so every lane is busy on every load (row-per-wave
+      // mappings leave 52 of 64 lanes idle on the tail of a 76-float4 row).
+      constexpr int GU = 4;  // elements in flight per thread
+      const int total = ROWS * ldv4;
+      for (int e0 = threadIdx.x; e0 < total; e0 += 256 * GU) {
+        v4f p[GU], q[GU];
+        int rowi[GU], c4i[GU];
+        bool ok[GU];
 #pragma unroll
-      for (int r = 0; r < RPW; ++r) {
-        const int s = __builtin_amdgcn_readlane(my_s, r);
-        const int d = __builtin_amdgcn_readlane(my_d, r);
-        float *trow = tile + (wave * RPW + r) * ld0;
-        for (int c4 = lane; c4 < ldv4; c4 += 64) {
-          v4f h = (v4f){0.f, 0.f, 0.f, 0.f};
-          if (d >= 0) {
-            const v4f p = P4[(int64_t)s * ldv4 + c4];
-            const v4f q = Q4[(int64_t)d * ldv4 + c4];
+        for (int u = 0; u < GU; ++u) {
+          int e = e0 + 256 * u;
+          if (e > total - 1) e = total - 1;  // clamp: duplicate work, no branch
+          rowi[u] = e / ldv4;
+          c4i[u] = e - rowi[u] * ldv4;
+          const int s_ = src[rowi[u]];
+          const int d_ = dst[rowi[u] + 1];
+          ok[u] = d_ >= 0 && !(dbg & 1);
+          const int dd = d_ >= 0 ? d_ : 0;
+          p[u] = P4[(int64_t)s_ * ldv4 + c4i[u]];
+          q[u] = Q4[(int64_t)dd * ldv4 + c4i[u]];
+        }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const float t = p[i] - q[i];
-              h[i] = t > 0.0f ? t : 0.0f;
-            }
+        for (int u = 0; u < GU; ++u) {
+          v4f h;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float t = p[u][i] - q[u][i];
+            h[i] = (ok[u] && t > 0.0f) ? t : 0.0f;
           }
-          *reinterpret_cast<v4f *>(trow + 4 * c4) = h;
+          *reinterpret_cast<v4f *>(tile + rowi[u] * ld0 + 4 * c4i[u]) = h;
         }
       }
     }
@@ -210,8 +282,8 @@ __global__ __launch_bounds__(256, 2) void fused_mlp_kernel(
     // ------------------------------------------------------------ hidden layers
     for (int li = 0; li + 1 < chain.n; ++li) {
       const LayerDev &L = chain.l[li];
-      layer_pass_dispatch<MSUB>(tile, lds_ld(16 * L.kq), tile, lds_ld(16 * L.nt),
-                                L, 0, wave, lane);
+      layer_pass_dispatch<MSUB, false>(tile, lds_ld(16 * L.kq), tile,
+                                       lds_ld(16 * L.nt), L, 0, wave, lane);
     }
     // ------------------------------------------------------------ last layer
     {
@@ -222,12 +294,23 @@ __global__ __launch_bounds__(256, 2) void fused_mlp_kernel(
         if (tiles > kMaxTilesPerPass) tiles = kMaxTilesPerPass;
         const int ncols = 16 * tiles;
         const int ld_st = lds_ld(ncols);
-        layer_pass_dispatch<MSUB>(tile, ld_in, stage, ld_st, L, t0, wave, lane);
-        if (PRO == PRO_ROWS)
+        if (PRO == PRO_ROWS) {
+          layer_pass_dispatch<MSUB, false>(tile, ld_in, stage, ld_st, L, t0, wave,
+                                           lane, (dbg & 2) != 0);
           consume_rows<ROWS>(stage, ld_st, row0, rows_valid, 16 * t0, ncols, ra);
-        else
-          consume_segmax<ROWS>(stage, ld_st, dst, 16 * t0, ncols, sa);
-        __syncthreads();
+        } else {
+          layer_pass_dispatch<MSUB, true>(tile, ld_in, stage, ld_st, L, t0, wave,
+                                          lane, (dbg & 2) != 0);
+          if (!(dbg & 4)) {
+            const CarryState nxt = consume_segmax<ROWS>(
+                stage, dst, 16 * t0, ncols, sa, carry, cs,
+                tile_id + 1 < tile_last);
+            if (t0 + kMaxTilesPerPass >= L.nt) cs = nxt;  // after the last pass
+          }
+        }
+        // LDS-only barrier: the tile buffer may be overwritten by the next
+        // prologue, but the global stores / atomics above need not drain
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       }
     }
   }
@@ -304,6 +387,7 @@ int make_plan(const pgnn_fc_layer *layers, int32_t n_layers, int first_k,
 
 size_t plan_lds_bytes(const Plan &p, int rows) {
   size_t floats = (size_t)rows * p.tile_floats_per_row;
+  floats += 16 * (size_t)p.chain.l[p.chain.n - 1].nt;  // carry row
   if (p.stage_cols) floats += (size_t)rows * lds_ld(p.stage_cols);
   return ints_bytes(rows) + floats * 4;
 }
@@ -327,8 +411,15 @@ int launch_fused(const Plan &p, int64_t n_rows, const RowsArgs &ra,
   int64_t grid = (int64_t)device_cu_count() * per_cu;
   if (grid > n_tiles) grid = n_tiles;
   const int stage_off = p.stage_cols ? ROWS * p.tile_floats_per_row : -1;
+  if (g_mlp_debug & 16) {
+    int nb = -1;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(
+        &nb, reinterpret_cast<const void *>(kern), 256, lds);
+    fprintf(stderr, "[pgnn] fused<%d,%d> lds=%zu per_cu=%d occupancy_api=%d (%d) grid=%lld tiles=%lld\n",
+            MSUB, PRO, lds, per_cu, nb, (int)e, (long long)grid, (long long)n_tiles);
+  }
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, stream, p.chain,
-                     n_rows, ra, pa, ea, sa, stage_off);
+                     n_rows, ra, pa, ea, sa, stage_off, g_mlp_debug);
   PGNN_HIP(hipGetLastError());
   return 0;
 }
@@ -399,7 +490,11 @@ extern "C" int pgnn_point_set_pooling_fwd(
   PoolArgs pa = {point_features, n_feat, point_xyz, keypoint_indices, edges};
   EdgeArgs ea = {};
   SegArgs sa = {out, ld_out, num_keypoints, edges_sorted};
-  if (plan_lds_bytes(p, 64) <= 80 * 1024 || plan_lds_bytes(p, 32) > 80 * 1024)
+  int msub = g_pool_msub;
+  if (msub != 2 && msub != 4)
+    msub = (plan_lds_bytes(p, 64) <= 80 * 1024 ||
+            plan_lds_bytes(p, 32) > 80 * 1024) ? 4 : 2;
+  if (msub == 4)
     return launch_fused<4, PRO_POOL>(p, n_edges, ra, pa, ea, sa, stream);
   return launch_fused<2, PRO_POOL>(p, n_edges, ra, pa, ea, sa, stream);
   PGNN_GUARD_END
@@ -433,7 +528,11 @@ extern "C" int pgnn_edge_mlp_scatter_max_fwd(
   PoolArgs pa = {};
   EdgeArgs ea = {P, Q, ld_pq, edges};
   SegArgs sa = {out, ld_out, num_vertices, edges_sorted};
-  if (plan_lds_bytes(p, 64) <= 80 * 1024 || plan_lds_bytes(p, 32) > 80 * 1024)
+  int msub = g_edge_msub;
+  if (msub != 2 && msub != 4)
+    msub = (plan_lds_bytes(p, 64) <= 80 * 1024 ||
+            plan_lds_bytes(p, 32) > 80 * 1024) ? 4 : 2;
+  if (msub == 4)
     return launch_fused<4, PRO_EDGE>(p, n_edges, ra, pa, ea, sa, stream);
   return launch_fused<2, PRO_EDGE>(p, n_edges, ra, pa, ea, sa, stream);
   PGNN_GUARD_END

@@ -60,13 +60,22 @@ __device__ __forceinline__ void gemm_tile(const float *__restrict__ tile, int ld
   const v4f *__restrict__ wp = reinterpret_cast<const v4f *>(L.wp) + lane;
   const float *arow = tile + (lane & 15) * ld + 4 * (lane >> 4);
   const int qstride = L.nt * 64;
-  for (int q = 0; q < L.kq; ++q) {
-    v4f a[MSUB], b[NT];
+  const int kq = L.kq;
+  // Software pipeline, depth 1: the fragments of K-group q+1 are requested
+  // before the 4*MSUB*NT MFMAs of group q issue, so the L2 / LDS latency of the
+  // loads hides under ~2.5k cycles of matrix work instead of stalling each
+  // iteration.  Two named register sets (A/B) alternate; the index is clamped
+  // so the last prefetch re-reads a valid group instead of branching.
+  v4f aA[MSUB], bA[NT], aB[MSUB], bB[NT];
+  auto fetch = [&](int q, v4f (&a)[MSUB], v4f (&b)[NT]) {
+    if (q > kq - 1) q = kq - 1;
 #pragma unroll
     for (int j = 0; j < NT; ++j) b[j] = wp[(size_t)q * qstride + toff[j]];
 #pragma unroll
     for (int m = 0; m < MSUB; ++m)
       a[m] = *reinterpret_cast<const v4f *>(arow + m * 16 * ld + 16 * q);
+  };
+  auto mma = [&](const v4f (&a)[MSUB], const v4f (&b)[NT]) {
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -75,7 +84,16 @@ __device__ __forceinline__ void gemm_tile(const float *__restrict__ tile, int ld
         for (int j = 0; j < NT; ++j)
           acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][s], b[j][s],
                                                            acc[m][j], 0, 0, 0);
+  };
+  fetch(0, aA, bA);
+  int q = 0;
+  for (; q + 1 < kq; q += 2) {
+    fetch(q + 1, aB, bB);
+    mma(aA, bA);
+    fetch(q + 2, aA, bA);
+    mma(aB, bB);
   }
+  if (q < kq) mma(aA, bA);
 }
 
 // out[row][col - 16*t0] = act(acc + bias[col]); C/D layout of the 16x16 MFMA:
@@ -105,33 +123,83 @@ __device__ __forceinline__ void store_acc(float *__restrict__ out, int ldo,
   }
 }
 
+// Transposed, swizzled variant for the layer feeding the segmented max:
+// stT[c][g] (g = row group of 4) at float offset c*ROWS + ((g ^ (c & SWZ)) << 2).
+// A lane's four accumulator rows are contiguous here, so the whole C fragment
+// goes out as one ds_write_b128 (instead of four ds_write_b32), and the
+// column-wise reduction later reads 4 rows per ds_read_b128.  The XOR spreads
+// both the 8-lane write groups and the 16-lane read groups over distinct
+// 16-byte bank slots.
+template <int MSUB, int NT>
+__device__ __forceinline__ void store_acc_T(float *__restrict__ stT,
+                                            const LayerDev &L, int t0, int wave,
+                                            int lane, const v4f (&acc)[MSUB][NT]) {
+  constexpr int ROWS = 16 * MSUB, G = ROWS / 4, SWZ = (G < 16 ? G : 16) - 1;
+  const float *bias = L.wp + (size_t)L.kq * L.nt * 256;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int t = t0 + wave + 4 * j;
+    if (t < L.nt) {
+      const int col = t * 16 + (lane & 15);
+      const float bv = bias[col];
+      const bool relu = col >= L.relu_from;
+      const int c = col - 16 * t0;
+      float *o = stT + c * ROWS;
+      const int sw = c & SWZ;
+#pragma unroll
+      for (int m = 0; m < MSUB; ++m) {
+        const int g = 4 * m + (lane >> 4);
+        v4f v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float x = acc[m][j][r] + bv;
+          if (relu) x = x > 0.0f ? x : 0.0f;
+          v[r] = x;
+        }
+        *reinterpret_cast<v4f *>(o + ((g ^ sw) << 2)) = v;
+      }
+    }
+  }
+}
+
 // One pass (<= 320 output columns starting at column tile t0) of layer L:
 // GEMM from `in`, barrier, activated store to `out` (may alias `in`), barrier.
-template <int MSUB, int NT>
+template <int MSUB, int NT, bool TRANSPOSED>
 __device__ __forceinline__ void layer_pass(const float *in, int ld_in, float *out,
                                            int ld_out, const LayerDev &L, int t0,
-                                           int wave, int lane) {
+                                           int wave, int lane, bool skip_gemm) {
   v4f acc[MSUB][NT];
-  gemm_tile<MSUB, NT>(in, ld_in, L, t0, wave, lane, acc);
+  if (!skip_gemm) {
+    gemm_tile<MSUB, NT>(in, ld_in, L, t0, wave, lane, acc);
+  } else {  // ablation builds only
+#pragma unroll
+    for (int m = 0; m < MSUB; ++m)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[m][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+  }
   __syncthreads();  // every wave is done reading `in` (in-place overwrite)
-  store_acc<MSUB, NT>(out, ld_out, L, t0, wave, lane, acc);
+  if (TRANSPOSED)
+    store_acc_T<MSUB, NT>(out, L, t0, wave, lane, acc);
+  else
+    store_acc<MSUB, NT>(out, ld_out, L, t0, wave, lane, acc);
   __syncthreads();
 }
 
-template <int MSUB>
+template <int MSUB, bool TRANSPOSED>
 __device__ __forceinline__ void layer_pass_dispatch(const float *in, int ld_in,
                                                     float *out, int ld_out,
                                                     const LayerDev &L, int t0,
-                                                    int wave, int lane) {
+                                                    int wave, int lane,
+                                                    bool skip_gemm = false) {
   int tiles = L.nt - t0;
   if (tiles > kMaxTilesPerPass) tiles = kMaxTilesPerPass;
   const int ntw = (tiles + 3) >> 2;  // column tiles per wave (wave-uniform)
   switch (ntw) {
-    case 1: layer_pass<MSUB, 1>(in, ld_in, out, ld_out, L, t0, wave, lane); break;
-    case 2: layer_pass<MSUB, 2>(in, ld_in, out, ld_out, L, t0, wave, lane); break;
-    case 3: layer_pass<MSUB, 3>(in, ld_in, out, ld_out, L, t0, wave, lane); break;
-    case 4: layer_pass<MSUB, 4>(in, ld_in, out, ld_out, L, t0, wave, lane); break;
-    default: layer_pass<MSUB, 5>(in, ld_in, out, ld_out, L, t0, wave, lane); break;
+    case 1: layer_pass<MSUB, 1, TRANSPOSED>(in, ld_in, out, ld_out, L, t0, wave, lane, skip_gemm); break;
+    case 2: layer_pass<MSUB, 2, TRANSPOSED>(in, ld_in, out, ld_out, L, t0, wave, lane, skip_gemm); break;
+    case 3: layer_pass<MSUB, 3, TRANSPOSED>(in, ld_in, out, ld_out, L, t0, wave, lane, skip_gemm); break;
+    case 4: layer_pass<MSUB, 4, TRANSPOSED>(in, ld_in, out, ld_out, L, t0, wave, lane, skip_gemm); break;
+    default: layer_pass<MSUB, 5, TRANSPOSED>(in, ld_in, out, ld_out, L, t0, wave, lane, skip_gemm); break;
   }
 }
 

@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--config", default="car_auto_T3")
     ap.add_argument("--preset", default="car")
+    ap.add_argument("--tune", action="append", default=[],
+                    help="key=value tunable (repeatable)")
     args = ap.parse_args()
     import torch
     import pointgnn_amd  # noqa
@@ -33,6 +35,9 @@ def main():
     from pointgnn_amd.synthetic import synthetic_cloud
     import bench
     dev = torch.device("cuda", 0)
+    for kv in args.tune:
+        k, v = kv.split("=")
+        _lib.set_tunable(k, int(v))
     cfg = configs.get_config(args.config)
     params = weights.init_params(cfg, seed=0, bias_scale=0.05)
     eng = InferenceEngine(cfg, params, device=dev)
@@ -47,7 +52,7 @@ def main():
         if args.sweep:
             res = {}
             for rnd in range(3):
-                for rpw in (8, 16, 32, 64, 128, 256):
+                for rpw in (64, 128, 256, 512, 1024, 2048):
                     _lib.set_tunable("scatter_rows_per_wave", rpw)
                     r = bench.roofline_scatter_max(torch, edges[1], n_k, width,
                                                    reps=args.reps)
