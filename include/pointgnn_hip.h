@@ -193,6 +193,81 @@ int pgnn_offset_apply(const float *xyz, const float *delta, int64_t ld_delta,
                       int64_t n_rows, const float *wx, float *xyz_out,
                       float *Q, int64_t ld_q, void *stream);
 
+/* ---- training step (config 4: models.py:170-311, train.py:135-171,264-297,
+ * 375-405, util/tf_util.py:3-43) ------------------------------------------
+ * The backward pass needs the per-edge activations, so the training forward
+ * materialises them with the primitives below (plus pgnn_mlp_fwd one layer at
+ * a time and pgnn_scatter_max_f32); each primitive has an explicit adjoint.  */
+
+/* Device-side pgnn_pack_fc (weights change every step).  transpose != 0 packs
+ * W^T (the layer dX = dZ @ W^T of the backward pass; no bias).              */
+int pgnn_pack_fc_device(const float *w, const float *b, int32_t k_in,
+                        int32_t n_out, int32_t transpose, float *packed,
+                        void *stream);
+
+/* H1[e] = ReLU(P[src(e)] - Q[dst(e)]) materialised, [n_edges, ld_pq].       */
+int pgnn_edge_hidden_fwd(const float *P, const float *Q, int64_t ld_pq,
+                         const int32_t *edges, int64_t n_edges, float *H1,
+                         void *stream);
+/* Adjoint: dP[src] += dH1, dQ[dst] -= dH1 (dH1 already masked by H1 > 0).
+ * dP, dQ [n_vertices, ld] are zeroed by the call.                            */
+int pgnn_edge_hidden_bwd(const float *dH1, int64_t ld, const int32_t *edges,
+                         int64_t n_edges, int64_t n_vertices, float *dP,
+                         float *dQ, void *stream);
+/* PointSetPooling edge features [f(src), xyz(src) - xyz(kp(dst)), 0...] as a
+ * [n_edges, 16] matrix (gnn.py:256-267).                                     */
+int pgnn_pool_features_fwd(const float *point_features, int32_t n_feat,
+                           const float *point_xyz,
+                           const int32_t *keypoint_indices,
+                           const int32_t *edges, int64_t n_edges, float *F,
+                           void *stream);
+/* dY[i] = (Y[i] > 0) ? dY[i] : 0 in place (tf ReluGrad), over `count` floats. */
+int pgnn_relu_mask_mul(float *dY, const float *Y, int64_t count, void *stream);
+/* Gradient of tf.math.unsorted_segment_max (TF's
+ * _UnsortedSegmentMinOrMaxGrad): rows equal to their segment's max share the
+ * segment's gradient equally.  relu_mask != 0 additionally zeroes rows whose
+ * value is not > 0 (fused ReluGrad of the layer that produced `data`).
+ * tie_count_ws: int32 [num_segments * n_cols] scratch.                       */
+int pgnn_scatter_max_bwd_f32(const float *data, int64_t ld_data,
+                             const int32_t *seg_ids, int64_t n_rows,
+                             int32_t n_cols, int32_t num_segments,
+                             const float *out, int64_t ld_out,
+                             const float *grad_out, int64_t ld_grad_out,
+                             int32_t *tie_count_ws, float *grad_data,
+                             int64_t ld_grad_data, int32_t relu_mask,
+                             void *stream);
+/* dW [k_in, n_out] (= X^T dZ) and db [n_out] (= column sums of dZ; may be
+ * NULL) of y = x W + b, deterministic (fixed-order slice reduction).
+ * accumulate != 0 adds to dW/db.                                             */
+size_t pgnn_weight_grad_workspace_bytes(int32_t k_in, int32_t n_out,
+                                        int64_t n_rows);
+int pgnn_weight_grad_f32(const float *X, int64_t ld_x, int32_t k_in,
+                         const float *dZ, int64_t ld_dz, int32_t n_out,
+                         int64_t n_rows, float *dW, float *db,
+                         int32_t accumulate, void *workspace,
+                         size_t workspace_bytes, void *stream);
+/* models.py:212-255 (cls 'softmax', loc 'huber_loss', delta 1):
+ * sums4 (device, 4 doubles) = {sum_v CE_v, sum_v mean_7 huber_v*valid_v,
+ * n_vertices, sum valid}; dlogits [n, nc] / dpred_box [n, nc, box_len]
+ * receive the gradients of cls_grad_scale*sum CE + loc_grad_scale*sum loc
+ * (the caller folds loss weights and the global 1/N, 1/N_valid of
+ * train.py:264-288 into the two scales).                                     */
+int pgnn_loss_fwd_bwd(const float *logits, int64_t ld_logits,
+                      const int32_t *labels, const float *pred_box,
+                      int32_t box_len, const float *gt_box, const float *valid,
+                      int64_t n_vertices, int32_t num_classes,
+                      float cls_grad_scale, float loc_grad_scale,
+                      double *sums4, float *dlogits, float *dpred_box,
+                      void *stream);
+/* params -= lr * (grad_scale*grads + l1_scale*sign(params)*is_weight)
+ * (GradientDescentOptimizer + slim.l1_regularizer on FC weights only).       */
+int pgnn_sgd_step(float *params, const float *grads, const float *is_weight,
+                  int64_t n, float lr, float grad_scale, float l1_scale,
+                  void *stream);
+/* *out (device double) = sum |params| over is_weight entries (reg_loss/scale). */
+int pgnn_l1_norm(const float *params, const float *is_weight, int64_t n,
+                 double *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,126 @@
+"""ORACLE (test infrastructure only) -- CPU restatement of the reference's
+training step: forward (oracle/gnn_oracle.py semantics), loss
+(`models/models.py:170-311`), tower weighting (`train.py:264-288`) and
+gradients, in float64 on torch-CPU autograd.
+
+PARITY UNPINNED at the TensorFlow boundary (TF 1.15 not installable; the
+reference ships no gradient fixtures).  Documented TF semantics restated:
+  * tf.nn.sparse_softmax_cross_entropy_with_logits: logsumexp(z) - z[label];
+  * tf.losses.huber_loss(delta=1, weights=valid, reduction=NONE):
+    0.5*min(|e|,1)^2 + (|e| - min(|e|,1)), times valid;
+  * gradient of tf.math.unsorted_segment_max: split equally among the rows that
+    equal the segment max (torch's scatter_reduce 'amax' has the same rule);
+  * slim.l1_regularizer(scale)(W) = scale * sum|W| on FC weights only.
+Only tests/ may import this module.
+"""
+import numpy as np
+import torch
+
+
+def _mlp(x, params, scope, n_layers, is_logits):
+    for i in range(n_layers):
+        name = scope + '/fully_connected' + ('' if i == 0 else '_%d' % i)
+        x = x @ params[name + '/weights'] + params[name + '/biases']
+        if not (is_logits and i == n_layers - 1):
+            x = torch.relu(x)
+    return x
+
+
+def _segment_max(data, seg, num):
+    idx = seg.reshape(-1, 1).expand(-1, data.shape[1])
+    out = torch.full((num, data.shape[1]), float('-inf'), dtype=data.dtype)
+    return out.scatter_reduce(0, idx, data, 'amax', include_self=True)
+
+
+def forward(params, config, input_v, coords, kps, edges, dtype=torch.float64):
+    """params: {name: torch float64 tensor (requires_grad)}."""
+    t64 = lambda a: torch.as_tensor(np.asarray(a), dtype=dtype)
+    i64 = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.int64)
+    feats = t64(input_v)
+    coords = [t64(c) for c in coords]
+    for lc in config['model_kwargs']['layer_configs'][:-1]:
+        lvl, scope, kw = lc['graph_level'], lc['scope'], lc['kwargs']
+        e = i64(edges[lvl])
+        src, dst = e[:, 0], e[:, 1]
+        if lc['type'] == 'scatter_max_point_set_pooling':
+            kp = i64(kps[lvl]).reshape(-1)
+            x = coords[lvl]
+            f = torch.cat([feats[src], x[src] - x[kp[dst]]], dim=1)
+            f = _mlp(f, params, scope + '/extract_vertex_features',
+                     len(kw['point_MLP_depth_list']), False)
+            agg = _segment_max(f, dst, kp.shape[0])
+            feats = _mlp(agg, params, scope + '/combined_features',
+                         len(kw['output_MLP_depth_list']), False)
+        else:
+            x = coords[lvl]
+            h = feats
+            s_h, s_x = h[src], x[src]
+            if kw['auto_offset']:
+                x = x + _mlp(h, params, scope,
+                             len(kw['auto_offset_MLP_depth_list']), True)
+            ef = torch.cat([s_h, s_x - x[dst]], dim=1)
+            ef = _mlp(ef, params, scope + '/extract_vertex_features',
+                      len(kw['edge_MLP_depth_list']), False)
+            agg = _segment_max(ef, dst, h.shape[0])
+            feats = _mlp(agg, params, scope + '/combined_features',
+                         len(kw['update_MLP_depth_list']), True) + h
+    ps = config['model_kwargs']['layer_configs'][-1]['scope'] + '/predictor'
+    logits = _mlp(feats, params, ps + '/cls', 2, True)
+    boxes = [_mlp(feats, params, ps + '/loc/cls_%d' % j, 3, True)[:, None, :]
+             for j in range(config['num_classes'])]
+    return logits, torch.cat(boxes, dim=1)
+
+
+def loss_terms(config, logits, pred_box, labels, gt_box, valid,
+               dtype=torch.float64):
+    """Returns (sum CE, sum loc, n, n_valid) as torch scalars."""
+    lab = torch.as_tensor(np.asarray(labels), dtype=torch.int64).reshape(-1)
+    gt = torch.as_tensor(np.asarray(gt_box), dtype=dtype).reshape(
+        lab.shape[0], -1)
+    va = torch.as_tensor(np.asarray(valid), dtype=dtype).reshape(-1)
+    ce = torch.logsumexp(logits, dim=1) - logits[torch.arange(len(lab)), lab]
+    pb = pred_box[torch.arange(len(lab)), lab]
+    err = pb - gt
+    ae = err.abs()
+    quad = torch.clamp(ae, max=1.0)
+    hub = (0.5 * quad * quad + (ae - quad)) * va[:, None]
+    loc = hub.mean(dim=1)
+    return ce.sum(), loc.sum(), float(len(lab)), float(va.sum())
+
+
+def step_gradients(np_params, config, rank_batches, dtype=torch.float64):
+    """Global loss and gradients for a list of per-rank batches, following
+    train.py:264-297 + util/tf_util.py:3-43: every tower's cls/loc loss is
+    re-weighted by its share of (valid) endpoints and the tower gradients are
+    averaged -- which equals the gradient of the global per-vertex means.
+    Returns (loss dict, {name: ndarray grad of cls+loc}, {name: grad of reg})."""
+    params = {k: torch.tensor(np.asarray(v), dtype=dtype, requires_grad=True)
+              for k, v in np_params.items()}
+    cls_w = config['loss']['cls_loss_weight']
+    loc_w = config['loss']['loc_loss_weight']
+    terms = []
+    for (input_v, coords, kps, edges, labels, boxes, valid) in rank_batches:
+        logits, pred = forward(params, config, input_v, coords, kps, edges,
+                               dtype)
+        terms.append(loss_terms(config, logits, pred, labels, boxes, valid,
+                                dtype))
+    n_tot = sum(t[2] for t in terms)
+    nv_tot = sum(t[3] for t in terms)
+    cls = cls_w * sum(t[0] for t in terms) / n_tot
+    loc = loc_w * sum(t[1] for t in terms) / nv_tot if nv_tot > 0 else \
+        torch.zeros((), dtype=dtype)
+    scale = config['model_kwargs']['regularizer_kwargs']['scale']
+    reg = scale * sum(p.abs().sum() for k, p in params.items()
+                      if k.endswith('/weights'))
+    names = list(params)
+    g_data = torch.autograd.grad(cls + loc, [params[n] for n in names],
+                                 allow_unused=True, retain_graph=True)
+    g_reg = torch.autograd.grad(reg, [params[n] for n in names],
+                                allow_unused=True)
+    z = lambda g, n: (np.zeros(params[n].shape) if g is None
+                      else g.detach().numpy())
+    return ({'cls_loss': float(cls.detach()), 'loc_loss': float(loc.detach()),
+             'reg_loss': float(reg.detach()), 'num_endpoint': n_tot,
+             'num_valid_endpoint': nv_tot},
+            {n: z(g, n) for n, g in zip(names, g_data)},
+            {n: z(g, n) for n, g in zip(names, g_reg)})

@@ -67,6 +67,29 @@ _SIGNATURES = {
                                               c_i32, c_vp, c_i64, c_vp]),
     "pgnn_offset_apply": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp,
                                   c_i64, c_vp]),
+    # training step
+    "pgnn_pack_fc_device": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp,
+                                    c_vp]),
+    "pgnn_edge_hidden_fwd": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp,
+                                     c_vp]),
+    "pgnn_edge_hidden_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_vp,
+                                     c_vp, c_vp]),
+    "pgnn_pool_features_fwd": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i64,
+                                       c_vp, c_vp]),
+    "pgnn_relu_mask_mul": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
+    "pgnn_scatter_max_bwd_f32": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32,
+                                         c_i32, c_vp, c_i64, c_vp, c_i64, c_vp,
+                                         c_vp, c_i64, c_i32, c_vp]),
+    "pgnn_weight_grad_workspace_bytes": (c_sz, [c_i32, c_i32, c_i64]),
+    "pgnn_weight_grad_f32": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32,
+                                     c_i64, c_vp, c_vp, c_i32, c_vp, c_sz,
+                                     c_vp]),
+    "pgnn_loss_fwd_bwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i32, c_vp, c_vp,
+                                  c_i64, c_i32, ctypes.c_float, ctypes.c_float,
+                                  c_vp, c_vp, c_vp, c_vp]),
+    "pgnn_sgd_step": (c_i32, [c_vp, c_vp, c_vp, c_i64, ctypes.c_float,
+                              ctypes.c_float, ctypes.c_float, c_vp]),
+    "pgnn_l1_norm": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp]),
 }
 
 _lib = None

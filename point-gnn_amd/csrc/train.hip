@@ -1,0 +1,608 @@
+// Training-side kernels: materialising forward
+// pieces, their adjoints, weight gradients, loss and SGD.
+//
+// The inference path never writes an E x C matrix to HBM.  The backward pass
+// needs the per-edge activations, so the training forward materialises them
+// (E is ~5x smaller under the training graph kwargs: voxel 0.8 m, fan-in cap
+// 256) and every adjoint below is a plain, separately testable primitive:
+//   H1 = ReLU(P[src] - Q[dst])                  edge_hidden_fwd / _bwd
+//   scatter-max gradient with TF's tie rule      scatter_max_bwd (count + route)
+//   dW = X^T dZ, db = sum dZ                     weight_grad (MFMA, split over rows)
+//   dX = dZ W^T                                  pgnn_mlp_fwd on a transposed pack
+//   softmax-CE + Huber                           loss_fwd_bwd   (models.py:170-311)
+//   w -= lr (g + l1 sign(w))                     sgd_step       (train.py:375-405)
+#include "mlp_engine.h"
+
+namespace {
+using namespace pgnn;
+
+// ---------------------------------------------------------------- packing on device
+__global__ void pack_fc_device_kernel(const float *__restrict__ w,
+                                      const float *__restrict__ b, int k_in,
+                                      int n_out, int transpose,
+                                      float *__restrict__ packed) {
+  // logical layer: y = x W' + b with W' = W ([k_in,n_out]) or W^T (then the
+  // layer maps n_out -> k_in and has no bias)
+  const int K = transpose ? n_out : k_in, N = transpose ? k_in : n_out;
+  const int kq = (K + 15) / 16, nt = (N + 15) / 16;
+  const int64_t total = (int64_t)kq * nt * 256;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+       idx < total + nt * 16; idx += (int64_t)gridDim.x * blockDim.x) {
+    if (idx >= total) {
+      const int n = (int)(idx - total);
+      packed[idx] = (!transpose && b && n < N) ? b[n] : 0.0f;
+      continue;
+    }
+    const int s = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
+    const int64_t qt = idx >> 8;
+    const int t = (int)(qt % nt), q = (int)(qt / nt);
+    const int k = 16 * q + 4 * (lane >> 4) + s, n = 16 * t + (lane & 15);
+    float v = 0.0f;
+    if (k < K && n < N)
+      v = transpose ? w[(int64_t)n * n_out + k] : w[(int64_t)k * n_out + n];
+    packed[idx] = v;
+  }
+}
+
+// ---------------------------------------------------------------- edge hidden layer
+__global__ void edge_hidden_fwd_kernel(const float *__restrict__ P,
+                                       const float *__restrict__ Q, int ld4,
+                                       const int32_t *__restrict__ edges,
+                                       int64_t n_edges, float *__restrict__ H1) {
+  const v4f *P4 = reinterpret_cast<const v4f *>(P);
+  const v4f *Q4 = reinterpret_cast<const v4f *>(Q);
+  v4f *H4 = reinterpret_cast<v4f *>(H1);
+  const int64_t total = n_edges * ld4;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = idx / ld4;
+    const int c = (int)(idx - e * ld4);
+    const int s = edges[2 * e], d = edges[2 * e + 1];
+    const v4f p = P4[(int64_t)s * ld4 + c], q = Q4[(int64_t)d * ld4 + c];
+    v4f h;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float t = p[i] - q[i];
+      h[i] = t > 0.0f ? t : 0.0f;
+    }
+    H4[idx] = h;
+  }
+}
+
+// dP[src] += g, dQ[dst] -= g with g = dH1 (already masked by H1 > 0)
+__global__ void edge_hidden_bwd_kernel(const float *__restrict__ dH1, int ld,
+                                       const int32_t *__restrict__ edges,
+                                       int64_t n_edges, float *__restrict__ dP,
+                                       float *__restrict__ dQ) {
+  const int64_t total = n_edges * ld;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = idx / ld;
+    const int c = (int)(idx - e * ld);
+    const float g = dH1[idx];
+    if (g != 0.0f) {
+      atomicAdd(&dP[(int64_t)edges[2 * e] * ld + c], g);
+      atomicAdd(&dQ[(int64_t)edges[2 * e + 1] * ld + c], -g);
+    }
+  }
+}
+
+__global__ void pool_features_kernel(const float *__restrict__ feat, int nfeat,
+                                     const float *__restrict__ xyz,
+                                     const int32_t *__restrict__ kp,
+                                     const int32_t *__restrict__ edges,
+                                     int64_t n_edges, float *__restrict__ F) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_edges;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int s = edges[2 * e], d = edges[2 * e + 1];
+    const int k = kp[d];
+    float *o = F + e * 16;
+    for (int i = 0; i < 16; ++i) {
+      float v = 0.0f;
+      if (i < nfeat)
+        v = feat[(int64_t)s * nfeat + i];
+      else if (i < nfeat + 3)
+        v = xyz[3 * (int64_t)s + (i - nfeat)] - xyz[3 * (int64_t)k + (i - nfeat)];
+      o[i] = v;
+    }
+  }
+}
+
+__global__ void relu_mask_mul_kernel(float *__restrict__ dY,
+                                     const float *__restrict__ Y, int64_t total) {
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x)
+    if (!(Y[idx] > 0.0f)) dY[idx] = 0.0f;  // tf ReluGrad: pass where y > 0
+}
+
+// ---------------------------------------------------------------- scatter-max gradient
+// TF _UnsortedSegmentMinOrMaxGrad: selected = (data == out[seg]); the gradient
+// of a segment/channel is divided equally among its selected rows.
+__global__ void segmax_count_kernel(const float *__restrict__ data, int64_t ld,
+                                    const int32_t *__restrict__ seg, int64_t rows,
+                                    int cols, int nseg,
+                                    const float *__restrict__ out, int64_t ldo,
+                                    int32_t *__restrict__ count) {
+  const int64_t total = rows * cols;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = idx / cols;
+    const int c = (int)(idx - r * cols);
+    const int s = seg[r];
+    if (s < 0 || s >= nseg) continue;
+    if (data[r * ld + c] == out[(int64_t)s * ldo + c])
+      atomicAdd(&count[(int64_t)s * cols + c], 1);
+  }
+}
+
+__global__ void segmax_route_kernel(const float *__restrict__ data, int64_t ld,
+                                    const int32_t *__restrict__ seg, int64_t rows,
+                                    int cols, int nseg,
+                                    const float *__restrict__ out, int64_t ldo,
+                                    const float *__restrict__ gout, int64_t ldg,
+                                    const int32_t *__restrict__ count,
+                                    float *__restrict__ gdata, int64_t ldd,
+                                    int relu_mask) {
+  const int64_t total = rows * cols;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = idx / cols;
+    const int c = (int)(idx - r * cols);
+    const int s = seg[r];
+    float g = 0.0f;
+    if (s >= 0 && s < nseg) {
+      const float v = data[r * ld + c];
+      if (v == out[(int64_t)s * ldo + c] && (!relu_mask || v > 0.0f))
+        g = gout[(int64_t)s * ldg + c] / (float)count[(int64_t)s * cols + c];
+    }
+    gdata[r * ldd + c] = g;
+  }
+}
+
+// ---------------------------------------------------------------- weight gradient
+// dW[i][j] = sum_r X[r][i] dZ[r][j], db[j] = sum_r dZ[r][j] (a constant-one
+// input column at index k_in produces db as an extra row of the same GEMM).
+// Grid (in-blocks of 64 inputs, row slices); each workgroup accumulates its
+// [64 x <=320] block over the slice with MFMA (the reduction index is the data
+// row), writes one partial; a second kernel sums the slices in a fixed order
+// (deterministic, no float atomics).
+constexpr int kWgRows = 32;  // data rows staged per step
+
+template <int NT>
+__global__ __launch_bounds__(256) void weight_grad_kernel(
+    const float *__restrict__ X, int64_t ldx, int k_in,
+    const float *__restrict__ dZ, int64_t ldz, int n_out, int64_t rows,
+    int64_t rows_per_slice, int nt, float *__restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int ldxs = 68, ldzs = 16 * nt + 4;
+  float *Xs = reinterpret_cast<float *>(smem);
+  float *Zs = Xs + kWgRows * ldxs;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ib = blockIdx.x, slice = blockIdx.y;
+  const int in0 = 64 * ib;
+  const int64_t r_begin = (int64_t)slice * rows_per_slice;
+  int64_t r_end = r_begin + rows_per_slice;
+  if (r_end > rows) r_end = rows;
+  v4f acc[4][NT];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[m][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+  int toff[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    int t = wave + 4 * j;
+    if (t > nt - 1) t = nt - 1;
+    toff[j] = 16 * t + (lane & 15);
+  }
+  for (int64_t r0 = r_begin; r0 < r_end; r0 += kWgRows) {
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < kWgRows * 64; idx += 256) {
+      const int r = idx >> 6, c = idx & 63;
+      const int64_t row = r0 + r;
+      float v = 0.0f;
+      if (row < r_end) {
+        const int col = in0 + c;
+        if (col < k_in)
+          v = X[row * ldx + col];
+        else if (col == k_in)
+          v = 1.0f;  // bias "input"
+      }
+      Xs[r * ldxs + c] = v;
+    }
+    const int zc = 16 * nt;
+    for (int idx = threadIdx.x; idx < kWgRows * zc; idx += 256) {
+      const int r = idx / zc, c = idx - r * zc;
+      const int64_t row = r0 + r;
+      Zs[r * ldzs + c] = (row < r_end && c < n_out) ? dZ[row * ldz + c] : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kWgRows / 16; ++q) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int r = 16 * q + 4 * (lane >> 4) + s;
+        float a[4], b[NT];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) a[m] = Xs[r * ldxs + 16 * m + (lane & 15)];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) b[j] = Zs[r * ldzs + toff[j]];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[j],
+                                                             acc[m][j], 0, 0, 0);
+      }
+    }
+  }
+  // partial[slice][in][out], in padded to 64*gridDim.x, out padded to 16*nt
+  const int64_t kin_p = 64 * (int64_t)gridDim.x, nout_p = 16 * nt;
+  float *po = partial + (int64_t)slice * kin_p * nout_p;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int t = wave + 4 * j;
+    if (t < nt) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = in0 + 16 * m + 4 * (lane >> 4) + r;
+          po[(int64_t)i * nout_p + 16 * t + (lane & 15)] = acc[m][j][r];
+        }
+    }
+  }
+}
+
+__global__ void weight_grad_reduce_kernel(const float *__restrict__ partial,
+                                          int slices, int64_t kin_p, int nout_p,
+                                          int k_in, int n_out,
+                                          float *__restrict__ dW,
+                                          float *__restrict__ db, int accumulate) {
+  const int64_t total = (int64_t)(k_in + 1) * n_out;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = idx / n_out;
+    const int j = (int)(idx - i * n_out);
+    float s = 0.0f;
+    for (int sl = 0; sl < slices; ++sl)
+      s += partial[((int64_t)sl * kin_p + i) * nout_p + j];
+    if (i < k_in) {
+      float *o = dW + i * n_out + j;
+      *o = accumulate ? *o + s : s;
+    } else if (db) {
+      db[j] = accumulate ? db[j] + s : s;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- loss
+// models.py:212-255 with cls_loss_type 'softmax', loc_loss_type 'huber_loss'.
+// Per vertex: ce = logsumexp(z) - z[label]; loc = mean_7 huber(pred[label] - gt)
+// * valid.  sums[0] += ce, sums[1] += loc, sums[2] += 1, sums[3] += valid.
+// Gradients of (cls_scale * sum ce + loc_scale * sum loc) are written out.
+__global__ void loss_kernel(const float *__restrict__ logits, int64_t ldl,
+                            const int32_t *__restrict__ labels,
+                            const float *__restrict__ pred, int box_len,
+                            const float *__restrict__ gt,
+                            const float *__restrict__ valid, int64_t n, int nc,
+                            float cls_scale, float loc_scale,
+                            double *__restrict__ sums,
+                            float *__restrict__ dlogits,
+                            float *__restrict__ dpred) {
+  double s_ce = 0.0, s_loc = 0.0, s_n = 0.0, s_v = 0.0;
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n;
+       v += (int64_t)gridDim.x * blockDim.x) {
+    const float *z = logits + v * ldl;
+    const int lab = labels[v];
+    float zmax = z[0];
+    for (int c = 1; c < nc; ++c) zmax = fmaxf(zmax, z[c]);
+    float se = 0.0f;
+    for (int c = 0; c < nc; ++c) se += expf(z[c] - zmax);
+    const float lse = logf(se) + zmax;
+    s_ce += (double)(lse - z[lab]);
+    if (dlogits)
+      for (int c = 0; c < nc; ++c)
+        dlogits[v * nc + c] =
+            cls_scale * (expf(z[c] - lse) - (c == lab ? 1.0f : 0.0f));
+    const float w = valid[v];
+    const float *p = pred + (v * nc + lab) * box_len;
+    const float *g = gt + v * box_len;
+    float acc = 0.0f;
+    if (dpred)
+      for (int i = 0; i < nc * box_len; ++i) dpred[v * nc * box_len + i] = 0.0f;
+    for (int k = 0; k < box_len; ++k) {
+      const float err = p[k] - g[k];
+      const float ae = fabsf(err);
+      const float quad = fminf(ae, 1.0f);
+      const float lin = ae - quad;
+      acc += (0.5f * quad * quad + lin) * w;
+      if (dpred) {
+        // d/derr: err where |err| <= 1, sign(err) beyond (tf.losses.huber_loss)
+        const float d = ae <= 1.0f ? err : (err > 0.0f ? 1.0f : -1.0f);
+        dpred[(v * nc + lab) * box_len + k] = loc_scale * w * d / (float)box_len;
+      }
+    }
+    s_loc += (double)(acc / (float)box_len);
+    s_n += 1.0;
+    s_v += (double)w;
+  }
+  // block reduction (fp64 atomics at the end: 4 per wave)
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    s_ce += __shfl_xor(s_ce, d);
+    s_loc += __shfl_xor(s_loc, d);
+    s_n += __shfl_xor(s_n, d);
+    s_v += __shfl_xor(s_v, d);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&sums[0], s_ce);
+    atomicAdd(&sums[1], s_loc);
+    atomicAdd(&sums[2], s_n);
+    atomicAdd(&sums[3], s_v);
+  }
+}
+
+__global__ void sgd_kernel(float *__restrict__ w, const float *__restrict__ g,
+                           const float *__restrict__ is_weight, int64_t n,
+                           float lr, float grad_scale, float l1) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float wi = w[i];
+    float gi = g[i] * grad_scale;
+    if (is_weight[i] != 0.0f)  // l1_regularizer: d|w| = sign(w) (0 at 0)
+      gi += l1 * (wi > 0.0f ? 1.0f : (wi < 0.0f ? -1.0f : 0.0f));
+    w[i] = wi - lr * gi;
+  }
+}
+
+__global__ void l1_norm_kernel(const float *__restrict__ w,
+                               const float *__restrict__ is_weight, int64_t n,
+                               double *__restrict__ out) {
+  double s = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    if (is_weight[i] != 0.0f) s += (double)fabsf(w[i]);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+}
+
+inline unsigned grid_for(int64_t total, int cap = 4096) {
+  int64_t b = (total + 255) / 256;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" int pgnn_pack_fc_device(const float *w, const float *b, int32_t k_in,
+                                   int32_t n_out, int32_t transpose,
+                                   float *packed, void *stream_) {
+  PGNN_GUARD_BEGIN
+  PGNN_REQUIRE(w && packed && k_in > 0 && n_out > 0, PGNN_E_INVALID,
+               "pack_fc_device: bad argument");
+  const size_t total = transpose ? pgnn_packed_fc_floats(n_out, k_in)
+                                 : pgnn_packed_fc_floats(k_in, n_out);
+  hipLaunchKernelGGL(pack_fc_device_kernel, dim3(grid_for((int64_t)total)),
+                     dim3(256), 0, (hipStream_t)stream_, w, b, k_in, n_out,
+                     transpose, packed);
+  PGNN_HIP(hipGetLastError());
+  return 0;
+  PGNN_GUARD_END
+}
+
+extern "C" int pgnn_edge_hidden_fwd(const float *P, const float *Q,
+                                    int64_t ld_pq, const int32_t *edges,
+                                    int64_t n_edges, float *H1, void *stream_) {
+  PGNN_GUARD_BEGIN
+  PGNN_REQUIRE(ld_pq > 0 && ld_pq % 4 == 0 && n_edges >= 0, PGNN_E_INVALID,
+               "edge_hidden_fwd: ld must be a positive multiple of 4");
+  if (n_edges == 0) return 0;
+  PGNN_REQUIRE(P && Q && edges && H1, PGNN_E_INVALID,
+               "edge_hidden_fwd: null pointer");
+  hipLaunchKernelGGL(edge_hidden_fwd_kernel,
+                     dim3(grid_for(n_edges * (ld_pq / 4), 8192)), dim3(256), 0,
+                     (hipStream_t)stream_, P, Q, (int)(ld_pq / 4), edges,
+                     n_edges, H1);
+  PGNN_HIP(hipGetLastError());
+  return 0;
+  PGNN_GUARD_END
+}
+
+extern "C" int pgnn_edge_hidden_bwd(const float *dH1, int64_t ld,
+                                    const int32_t *edges, int64_t n_edges,
+                                    int64_t n_vertices, float *dP, float *dQ,
+                                    void *stream_) {
+  PGNN_GUARD_BEGIN
+  hipStream_t stream = (hipStream_t)stream_;
+  PGNN_REQUIRE(ld > 0 && n_edges >= 0 && n_vertices >= 0 && dP && dQ,
+               PGNN_E_INVALID, "edge_hidden_bwd: bad argument");
+  PGNN_HIP(hipMemsetAsync(dP, 0, (size_t)n_vertices * ld * 4, stream));
+  PGNN_HIP(hipMemsetAsync(dQ, 0, (size_t)n_vertices * ld * 4, stream));
+  if (n_edges == 0) return 0;
+  PGNN_REQUIRE(dH1 && edges, PGNN_E_INVALID, "edge_hidden_bwd: null pointer");
+  hipLaunchKernelGGL(edge_hidden_bwd_kernel, dim3(grid_for(n_edges * ld, 8192)),
+                     dim3(256), 0, stream, dH1, (int)ld, edges, n_edges, dP, dQ);
+  PGNN_HIP(hipGetLastError());
+  return 0;
+  PGNN_GUARD_END
+}
+
+extern "C" int pgnn_pool_features_fwd(const float *point_features,
+                                      int32_t n_feat, const float *point_xyz,
+                                      const int32_t *keypoint_indices,
+                                      const int32_t *edges, int64_t n_edges,
+                                      float *F, void *stream_) {
+  PGNN_GUARD_BEGIN
+  PGNN_REQUIRE(n_feat >= 0 && n_feat <= 13 && n_edges >= 0, PGNN_E_INVALID,
+               "pool_features: bad sizes");
+  if (n_edges == 0) return 0;
+  PGNN_REQUIRE(point_xyz && keypoint_indices && edges && F, PGNN_E_INVALID,
+               "pool_features: null pointer");
+  hipLaunchKernelGGL(pool_features_kernel, dim3(grid_for(n_edges)), dim3(256), 0,
+                     (hipStream_t)stream_, point_features, n_feat, point_xyz,
+                     keypoint_indices, edges, n_edges, F);
+  PGNN_HIP(hipGetLastError());
+  return 0;
+  PGNN_GUARD_END
+}
+
+extern "C" int pgnn_relu_mask_mul(float *dY, const float *Y, int64_t count,
+                                  void *stream_) {
+  PGNN_GUARD_BEGIN
+  if (count <= 0) return 0;
+  PGNN_REQUIRE(dY && Y, PGNN_E_INVALID, "relu_mask_mul: null pointer");
+  hipLaunchKernelGGL(relu_mask_mul_kernel, dim3(grid_for(count, 8192)),
+                     dim3(256), 0, (hipStream_t)stream_, dY, Y, count);
+  PGNN_HIP(hipGetLastError());
+  return 0;
+  PGNN_GUARD_END
+}
+
+extern "C" int pgnn_scatter_max_bwd_f32(
+    const float *data, int64_t ld_data, const int32_t *seg_ids, int64_t n_rows,
+    int32_t n_cols, int32_t num_segments, const float *out, int64_t ld_out,
+    const float *grad_out, int64_t ld_grad_out, int32_t *tie_count_ws,
+    float *grad_data, int64_t ld_grad_data, int32_t relu_mask, void *stream_) {
+  PGNN_GUARD_BEGIN
+  hipStream_t stream = (hipStream_t)stream_;
+  PGNN_REQUIRE(n_rows >= 0 && n_cols > 0 && num_segments >= 0, PGNN_E_INVALID,
+               "scatter_max_bwd: bad sizes");
+  if (n_rows == 0) return 0;
+  PGNN_REQUIRE(data && seg_ids && out && grad_out && tie_count_ws && grad_data,
+               PGNN_E_INVALID, "scatter_max_bwd: null pointer");
+  PGNN_HIP(hipMemsetAsync(tie_count_ws, 0, (size_t)num_segments * n_cols * 4,
+                          stream));
+  const unsigned g = grid_for(n_rows * n_cols, 8192);
+  hipLaunchKernelGGL(segmax_count_kernel, dim3(g), dim3(256), 0, stream, data,
+                     ld_data, seg_ids, n_rows, n_cols, num_segments, out, ld_out,
+                     tie_count_ws);
+  hipLaunchKernelGGL(segmax_route_kernel, dim3(g), dim3(256), 0, stream, data,
+                     ld_data, seg_ids, n_rows, n_cols, num_segments, out, ld_out,
+                     grad_out, ld_grad_out, tie_count_ws, grad_data,
+                     ld_grad_data, relu_mask);
+  PGNN_HIP(hipGetLastError());
+  return 0;
+  PGNN_GUARD_END
+}
+
+namespace {
+int wg_slices(int64_t rows) {
+  int64_t s = (rows + kWgRows - 1) / kWgRows;
+  if (s > 64) s = 64;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+}  // namespace
+
+extern "C" size_t pgnn_weight_grad_workspace_bytes(int32_t k_in, int32_t n_out,
+                                                   int64_t n_rows) {
+  if (k_in <= 0 || n_out <= 0 || n_rows < 0) return 0;
+  const size_t in_blocks = ((size_t)k_in + 1 + 63) / 64;
+  const size_t nt = ((size_t)n_out + 15) / 16;
+  return (size_t)wg_slices(n_rows) * in_blocks * 64 * nt * 16 * 4 + 256;
+}
+
+extern "C" int pgnn_weight_grad_f32(const float *X, int64_t ld_x, int32_t k_in,
+                                    const float *dZ, int64_t ld_dz,
+                                    int32_t n_out, int64_t n_rows, float *dW,
+                                    float *db, int32_t accumulate,
+                                    void *workspace, size_t workspace_bytes,
+                                    void *stream_) {
+  PGNN_GUARD_BEGIN
+  hipStream_t stream = (hipStream_t)stream_;
+  PGNN_REQUIRE(k_in > 0 && n_out > 0 && n_rows >= 0 && dW, PGNN_E_INVALID,
+               "weight_grad: bad argument");
+  PGNN_REQUIRE(n_out <= 320, PGNN_E_UNSUPPORTED, "weight_grad: n_out > 320");
+  PGNN_REQUIRE(workspace && workspace_bytes >= pgnn_weight_grad_workspace_bytes(
+                                                   k_in, n_out, n_rows),
+               PGNN_E_WORKSPACE, "weight_grad: workspace too small");
+  PGNN_REQUIRE(n_rows == 0 || (X && dZ && ld_x >= k_in && ld_dz >= n_out),
+               PGNN_E_INVALID, "weight_grad: bad input");
+  const int in_blocks = (k_in + 1 + 63) / 64;
+  const int nt = (n_out + 15) / 16;
+  const int slices = wg_slices(n_rows);
+  int64_t rps = (n_rows + slices - 1) / slices;
+  rps = (rps + kWgRows - 1) / kWgRows * kWgRows;
+  if (rps < kWgRows) rps = kWgRows;
+  float *partial = (float *)workspace;
+  const size_t lds = (size_t)kWgRows * (68 + 16 * nt + 4) * 4;
+  const int ntw = (nt + 3) / 4;
+  dim3 grid(in_blocks, slices);
+#define PGNN_WG(NTV)                                                          \
+  hipLaunchKernelGGL((weight_grad_kernel<NTV>), grid, dim3(256), lds, stream,  \
+                     X, ld_x, k_in, dZ, ld_dz, n_out, n_rows, rps, nt, partial)
+  switch (ntw) {
+    case 1: PGNN_WG(1); break;
+    case 2: PGNN_WG(2); break;
+    case 3: PGNN_WG(3); break;
+    case 4: PGNN_WG(4); break;
+    default: PGNN_WG(5); break;
+  }
+#undef PGNN_WG
+  hipLaunchKernelGGL(weight_grad_reduce_kernel,
+                     dim3(grid_for((int64_t)(k_in + 1) * n_out)), dim3(256), 0,
+                     stream, partial, slices, (int64_t)in_blocks * 64, nt * 16,
+                     k_in, n_out, dW, db, accumulate);
+  PGNN_HIP(hipGetLastError());
+  return 0;
+  PGNN_GUARD_END
+}
+
+extern "C" int pgnn_loss_fwd_bwd(const float *logits, int64_t ld_logits,
+                                 const int32_t *labels, const float *pred_box,
+                                 int32_t box_len, const float *gt_box,
+                                 const float *valid, int64_t n_vertices,
+                                 int32_t num_classes, float cls_grad_scale,
+                                 float loc_grad_scale, double *sums4,
+                                 float *dlogits, float *dpred_box,
+                                 void *stream_) {
+  PGNN_GUARD_BEGIN
+  hipStream_t stream = (hipStream_t)stream_;
+  PGNN_REQUIRE(n_vertices >= 0 && num_classes > 0 && box_len > 0 && sums4,
+               PGNN_E_INVALID, "loss: bad argument");
+  PGNN_HIP(hipMemsetAsync(sums4, 0, 4 * sizeof(double), stream));
+  if (n_vertices == 0) return 0;
+  PGNN_REQUIRE(logits && labels && pred_box && gt_box && valid, PGNN_E_INVALID,
+               "loss: null pointer");
+  hipLaunchKernelGGL(loss_kernel, dim3(grid_for(n_vertices, 1024)), dim3(256), 0,
+                     stream, logits, ld_logits, labels, pred_box, box_len, gt_box,
+                     valid, n_vertices, num_classes, cls_grad_scale,
+                     loc_grad_scale, sums4, dlogits, dpred_box);
+  PGNN_HIP(hipGetLastError());
+  return 0;
+  PGNN_GUARD_END
+}
+
+extern "C" int pgnn_sgd_step(float *params, const float *grads,
+                             const float *is_weight, int64_t n, float lr,
+                             float grad_scale, float l1_scale, void *stream_) {
+  PGNN_GUARD_BEGIN
+  if (n <= 0) return 0;
+  PGNN_REQUIRE(params && grads && is_weight, PGNN_E_INVALID,
+               "sgd_step: null pointer");
+  hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n)), dim3(256), 0,
+                     (hipStream_t)stream_, params, grads, is_weight, n, lr,
+                     grad_scale, l1_scale);
+  PGNN_HIP(hipGetLastError());
+  return 0;
+  PGNN_GUARD_END
+}
+
+extern "C" int pgnn_l1_norm(const float *params, const float *is_weight,
+                            int64_t n, double *out, void *stream_) {
+  PGNN_GUARD_BEGIN
+  hipStream_t stream = (hipStream_t)stream_;
+  PGNN_REQUIRE(out, PGNN_E_INVALID, "l1_norm: null out");
+  PGNN_HIP(hipMemsetAsync(out, 0, sizeof(double), stream));
+  if (n <= 0) return 0;
+  PGNN_REQUIRE(params && is_weight, PGNN_E_INVALID, "l1_norm: null pointer");
+  hipLaunchKernelGGL(l1_norm_kernel, dim3(grid_for(n, 1024)), dim3(256), 0,
+                     stream, params, is_weight, n, out);
+  PGNN_HIP(hipGetLastError());
+  return 0;
+  PGNN_GUARD_END
+}

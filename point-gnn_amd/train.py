@@ -1,0 +1,558 @@
+"""Training step of the hot path (BASELINE config 4; SURVEY.md §8 rows a11, a12
+and (e)): forward with saved activations, loss, backward, one flat gradient
+all-reduce, SGD -- the device-side equivalent of what `train.py` builds with
+TF towers:
+
+  * frame merging by index offset            train.py:135-171  -> batch_data()
+  * MultiLayerFastLocalGraphModelV2.loss     models.py:170-311 -> pgnn_loss_fwd_bwd
+  * unify_copies re-weighting                train.py:264-288  -> global 1/N, 1/N_valid
+  * average_gradients over towers            util/tf_util.py:3-43 -> ONE all-reduce(sum)
+    of the flat fp32 gradient buffer (RCCL over xGMI; 5.96 MB for car_auto_T3)
+  * GradientDescentOptimizer + staircase decay  train.py:375-405 -> pgnn_sgd_step
+
+Every arithmetic step runs in a HIP kernel behind the C ABI; torch is used for
+allocation, views/concatenation and the three residual-style tensor adds of the
+backward pass.  The inference path never materialises E x C activations; the
+training forward does (the backward needs them).
+
+Weights live in ONE flat device buffer (reference variable order, [in,out]
+layouts); gradients in a second one, so data-parallel synchronisation is a
+single collective.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from .gnn import padded_width
+from .weights import init_params, mlp_names, variable_specs
+
+__all__ = ["Trainer", "batch_data", "learning_rate"]
+
+
+def learning_rate(train_config, step):
+    """tf.train.exponential_decay(..., staircase=True), train.py:375-378."""
+    p = step // train_config['decay_step'] \
+        if train_config.get('is_staircase', True) \
+        else step / float(train_config['decay_step'])
+    return train_config['initial_lr'] * train_config['decay_factor'] ** p
+
+
+def batch_data(batch_list):
+    """train.py:135-171: merge frames into one disjoint graph by offsetting
+    point / centre indices.  Accepts NumPy arrays or torch tensors (same kind
+    for all frames); returns the same kind."""
+    (n_input_v, n_coords, n_kps, n_edges, n_labels, n_boxes,
+     n_valid) = zip(*batch_list)
+    is_torch = isinstance(n_input_v[0], torch.Tensor)
+    cat = (lambda xs: torch.cat(list(xs), dim=0)) if is_torch else \
+        (lambda xs: np.concatenate(list(xs), axis=0))
+    level_num = len(n_coords[0])
+    kp_out, edge_out = [], []
+    for lvl in range(level_num - 1):
+        kps, eds = [], []
+        point_counter = 0
+        center_counter = 0
+        for b in range(len(batch_list)):
+            kps.append(n_kps[b][lvl] + point_counter)
+            e = n_edges[b][lvl]
+            if is_torch:
+                off = torch.tensor([point_counter, center_counter],
+                                   dtype=e.dtype, device=e.device)
+            else:
+                off = np.array([point_counter, center_counter], dtype=e.dtype)
+            eds.append(e + off)
+            point_counter += n_coords[b][lvl].shape[0]
+            center_counter += n_kps[b][lvl].shape[0]
+        kp_out.append(cat(kps))
+        edge_out.append(cat(eds))
+    coords = [cat([n_coords[b][lvl] for b in range(len(batch_list))])
+              for lvl in range(level_num)]
+    return (cat(n_input_v), coords, kp_out, edge_out, cat(n_labels),
+            cat(n_boxes), cat(n_valid))
+
+
+class _Fc(object):
+    """One fully connected layer of the flat parameter buffer."""
+
+    def __init__(self, name, k_in, n_out, w, b, gw, gb):
+        self.name, self.k_in, self.n_out = name, k_in, n_out
+        self.w, self.b, self.gw, self.gb = w, b, gw, gb
+        self.packed = None    # forward image  (k_in -> n_out, bias)
+        self.packed_t = None  # backward image (n_out -> k_in, no bias)
+
+
+class Trainer(object):
+    def __init__(self, config, train_config=None, params=None, seed=0,
+                 device=None, box_encoding_len=7, process_group=None):
+        self.config = config
+        self.train_config = train_config or {
+            'initial_lr': 0.125, 'decay_step': 400000, 'decay_factor': 0.1,
+            'optimizer': 'sgd', 'unify_copies': True}
+        if self.train_config.get('optimizer', 'sgd') != 'sgd':
+            raise NotImplementedError("only the shipped 'sgd' optimizer")
+        if not torch.cuda.is_available():
+            raise _lib.PointGnnHipError("Trainer needs a GPU (no CPU fallback)")
+        self.device = device or torch.device("cuda",
+                                             torch.cuda.current_device())
+        self.lib = _lib.load()
+        self.box_len = box_encoding_len
+        self.nc = config['num_classes']
+        self.pg = process_group
+        self.global_step = 0
+        mk = config['model_kwargs']
+        if mk.get('regularizer_type') not in (None, 'l1'):
+            raise NotImplementedError("regularizer %r" % mk['regularizer_type'])
+        self.l1_scale = float(mk['regularizer_kwargs']['scale']) \
+            if mk.get('regularizer_type') == 'l1' else 0.0
+        self.cls_w = float(config['loss']['cls_loss_weight'])
+        self.loc_w = float(config['loss']['loc_loss_weight'])
+        if config['loss'].get('cls_loss_type', 'softmax') != 'softmax':
+            raise NotImplementedError("cls_loss_type")
+        # ---- flat parameter / gradient buffers --------------------------
+        self.specs = variable_specs(config, box_encoding_len=box_encoding_len)
+        if params is None:
+            params = init_params(config, seed=seed)
+        total = int(sum(int(np.prod(s)) for _, s in self.specs))
+        flat = np.empty(total, np.float32)
+        mask = np.zeros(total, np.float32)
+        self.offsets = {}
+        off = 0
+        for name, shape in self.specs:
+            n = int(np.prod(shape))
+            flat[off:off + n] = np.asarray(params[name], np.float32).reshape(-1)
+            if name.endswith('/weights'):
+                mask[off:off + n] = 1.0
+            self.offsets[name] = (off, shape)
+            off += n
+        self.flat = torch.from_numpy(flat).to(self.device)
+        self.grad = torch.zeros_like(self.flat)
+        self.is_weight = torch.from_numpy(mask).to(self.device)
+        self.fc = {}
+        for name, shape in self.specs:
+            if not name.endswith('/weights'):
+                continue
+            base = name[:-len('/weights')]
+            k, n = shape
+            self.fc[base] = _Fc(base, k, n, self._view(self.flat, name),
+                                self._view(self.flat, base + '/biases'),
+                                self._view(self.grad, name),
+                                self._view(self.grad, base + '/biases'))
+        self._ws = None
+        self.repack()
+
+    # ---- plumbing -----------------------------------------------------------
+    def _view(self, flat, name):
+        off, shape = self.offsets[name]
+        n = int(np.prod(shape))
+        return flat[off:off + n].view(*shape)
+
+    def state_dict(self):
+        return {name: self._view(self.flat, name).cpu().numpy()
+                for name, _ in self.specs}
+
+    def grad_dict(self):
+        return {name: self._view(self.grad, name).cpu().numpy()
+                for name, _ in self.specs}
+
+    def _st(self):
+        return _lib.stream_ptr()
+
+    def repack(self):
+        """Refresh the MFMA-fragment images of every layer (forward and
+        transposed) from the flat buffer -- after init and after every SGD
+        step."""
+        lib, st = self.lib, self._st()
+        for fc in self.fc.values():
+            if fc.packed is None:
+                fc.packed = torch.empty(
+                    lib.pgnn_packed_fc_floats(fc.k_in, fc.n_out),
+                    dtype=torch.float32, device=self.device)
+                fc.packed_t = torch.empty(
+                    lib.pgnn_packed_fc_floats(fc.n_out, fc.k_in),
+                    dtype=torch.float32, device=self.device)
+            _lib.check(lib.pgnn_pack_fc_device(
+                _lib.ptr(fc.w), _lib.ptr(fc.b), fc.k_in, fc.n_out, 0,
+                _lib.ptr(fc.packed), st), "pgnn_pack_fc_device")
+            _lib.check(lib.pgnn_pack_fc_device(
+                _lib.ptr(fc.w), None, fc.k_in, fc.n_out, 1,
+                _lib.ptr(fc.packed_t), st), "pgnn_pack_fc_device")
+
+    def _layer_array(self, packed, k_in, n_out, relu):
+        arr = (_lib.FcLayer * 1)()
+        arr[0].packed = packed.data_ptr()
+        arr[0].k_in, arr[0].n_out = int(k_in), int(n_out)
+        arr[0].relu_from = 0 if relu else int(n_out)
+        return arr
+
+    def _mlp1(self, packed, k_in, n_out, relu, x, nx, x2=None, nx2=0,
+              residual=None):
+        rows = int(x.shape[0])
+        y = torch.empty((rows, padded_width(n_out)), dtype=torch.float32,
+                        device=self.device)
+        arr = self._layer_array(packed, k_in, n_out, relu)
+        _lib.check(self.lib.pgnn_mlp_fwd(
+            _lib.ptr(x), x.stride(0), int(nx), _lib.ptr(x2),
+            x2.stride(0) if x2 is not None else 0, int(nx2), rows, arr, 1,
+            _lib.ptr(residual),
+            residual.stride(0) if residual is not None else 0, _lib.ptr(y),
+            y.stride(0), self._st()), "pgnn_mlp_fwd")
+        return y
+
+    def fc_fwd(self, name, x, relu, x2=None, nx2=0, residual=None):
+        fc = self.fc[name]
+        return self._mlp1(fc.packed, fc.k_in, fc.n_out, relu, x,
+                          fc.k_in - nx2, x2, nx2, residual)
+
+    def _weight_grad(self, x, ld_x, k_in, dz, n_out, gw_ptr, gb_ptr):
+        rows = int(dz.shape[0])
+        need = self.lib.pgnn_weight_grad_workspace_bytes(k_in, n_out, rows)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(int(need), dtype=torch.uint8,
+                                   device=self.device)
+        _lib.check(self.lib.pgnn_weight_grad_f32(
+            _lib.ptr(x), ld_x, k_in, _lib.ptr(dz), dz.stride(0), n_out, rows,
+            gw_ptr, gb_ptr, 1, _lib.ptr(self._ws), self._ws.numel(),
+            self._st()), "pgnn_weight_grad_f32")
+
+    def fc_bwd(self, name, x, y, dy, relu, need_dx=True):
+        """dy is consumed (masked in place when relu).  x: the saved input
+        [rows, >= k_in] (already concatenated for two-input layers)."""
+        fc = self.fc[name]
+        if relu:
+            _lib.check(self.lib.pgnn_relu_mask_mul(
+                _lib.ptr(dy), _lib.ptr(y), dy.numel(), self._st()),
+                "pgnn_relu_mask_mul")
+        self._weight_grad(x, x.stride(0), fc.k_in, dy, fc.n_out,
+                          _lib.ptr(fc.gw), _lib.ptr(fc.gb))
+        if not need_dx:
+            return None
+        return self._mlp1(fc.packed_t, fc.n_out, fc.k_in, False, dy, fc.n_out)
+
+    def _scatter_max(self, data, dst, k):
+        out = torch.empty((k, data.shape[1]), dtype=torch.float32,
+                          device=self.device)
+        _lib.check(self.lib.pgnn_scatter_max_f32(
+            _lib.ptr(data), data.stride(0), _lib.ptr(dst), int(data.shape[0]),
+            int(data.shape[1]), k, _lib.ptr(out), out.stride(0), 1,
+            self._st()), "pgnn_scatter_max_f32")
+        return out
+
+    def _scatter_max_bwd(self, data, dst, out, gout):
+        k, cols = int(out.shape[0]), int(data.shape[1])
+        ties = torch.empty(k * cols, dtype=torch.int32, device=self.device)
+        gdata = torch.empty_like(data)
+        _lib.check(self.lib.pgnn_scatter_max_bwd_f32(
+            _lib.ptr(data), data.stride(0), _lib.ptr(dst), int(data.shape[0]),
+            cols, k, _lib.ptr(out), out.stride(0), _lib.ptr(gout),
+            gout.stride(0), _lib.ptr(ties), _lib.ptr(gdata), gdata.stride(0),
+            1, self._st()), "pgnn_scatter_max_bwd_f32")
+        return gdata
+
+    @staticmethod
+    def _sorted_dst(edges):
+        d = edges[:, 1].contiguous()
+        return d
+
+    # ---- forward with saved activations ------------------------------------------
+    def forward(self, input_v, coords, kps, edges):
+        """Returns (logits [K,nc], pred_box [K,nc,L]) and keeps what backward
+        needs in self._saved."""
+        lib, st = self.lib, self._st()
+        dev = self.device
+        f32 = lambda t: torch.as_tensor(t).to(
+            device=dev, dtype=torch.float32).contiguous()
+        i32 = lambda t: torch.as_tensor(t).to(
+            device=dev, dtype=torch.int32).contiguous()
+        input_v = f32(input_v)
+        coords = [f32(c) for c in coords]
+        kps = [i32(k.reshape(-1)) for k in kps]
+        edges = [i32(e) for e in edges]
+        saved = []
+        h = None
+        for lc in self.config['model_kwargs']['layer_configs'][:-1]:
+            scope, kw, lvl = lc['scope'], lc['kwargs'], lc['graph_level']
+            if lc['type'] == 'scatter_max_point_set_pooling':
+                e = edges[lvl]
+                k = int(kps[lvl].shape[0])
+                feat = torch.empty((int(e.shape[0]), 16), dtype=torch.float32,
+                                   device=dev)
+                _lib.check(lib.pgnn_pool_features_fwd(
+                    _lib.ptr(input_v), int(input_v.shape[1]),
+                    _lib.ptr(coords[lvl]), _lib.ptr(kps[lvl]), _lib.ptr(e),
+                    int(e.shape[0]), _lib.ptr(feat), st),
+                    "pgnn_pool_features_fwd")
+                names = mlp_names(scope + '/extract_vertex_features',
+                                  len(kw['point_MLP_depth_list']))
+                acts = [feat]
+                for n in names:
+                    acts.append(self.fc_fwd(n, acts[-1], True))
+                dst = self._sorted_dst(e)
+                agg = self._scatter_max(acts[-1], dst, k)
+                onames = mlp_names(scope + '/combined_features',
+                                   len(kw['output_MLP_depth_list']))
+                oacts = [agg]
+                for n in onames:
+                    oacts.append(self.fc_fwd(n, oacts[-1], True))
+                h = oacts[-1]
+                saved.append(('pool', names, acts, dst, agg, onames, oacts))
+            elif lc['type'] == 'scatter_max_graph_auto_center_net':
+                e = edges[lvl]
+                x = coords[lvl]
+                k = int(h.shape[0])
+                enames = mlp_names(scope + '/extract_vertex_features',
+                                   len(kw['edge_MLP_depth_list']))
+                w1 = self.fc[enames[0]]
+                c = w1.k_in - 3
+                wq = padded_width(w1.n_out)
+                off_names, off_acts, delta = None, None, None
+                if kw['auto_offset']:
+                    off_names = mlp_names(
+                        scope, len(kw['auto_offset_MLP_depth_list']))
+                    off_acts = [h]
+                    for i, n in enumerate(off_names):
+                        off_acts.append(self.fc_fwd(
+                            n, off_acts[-1], i + 1 < len(off_names)))
+                    delta = off_acts[-1]
+                wx = torch.zeros((3, wq), dtype=torch.float32, device=dev)
+                wx[:, :w1.n_out] = w1.w[c:c + 3]
+                xo = torch.empty_like(x)
+                q = torch.empty((k, wq), dtype=torch.float32, device=dev)
+                _lib.check(lib.pgnn_offset_apply(
+                    _lib.ptr(x), _lib.ptr(delta),
+                    delta.stride(0) if delta is not None else 0, k,
+                    _lib.ptr(wx), _lib.ptr(xo), _lib.ptr(q), wq, st),
+                    "pgnn_offset_apply")
+                hx = torch.zeros((k, padded_width(c + 3)),
+                                 dtype=torch.float32, device=dev)
+                hx[:, :c] = h[:, :c]
+                hx[:, c:c + 3] = x
+                p = self.fc_fwd(enames[0], hx, False)
+                h1 = torch.empty((int(e.shape[0]), wq), dtype=torch.float32,
+                                 device=dev)
+                _lib.check(lib.pgnn_edge_hidden_fwd(
+                    _lib.ptr(p), _lib.ptr(q), wq, _lib.ptr(e),
+                    int(e.shape[0]), _lib.ptr(h1), st), "pgnn_edge_hidden_fwd")
+                eacts = [h1]
+                for n in enames[1:]:
+                    eacts.append(self.fc_fwd(n, eacts[-1], True))
+                dst = self._sorted_dst(e)
+                agg = self._scatter_max(eacts[-1], dst, k)
+                unames = mlp_names(scope + '/combined_features',
+                                   len(kw['update_MLP_depth_list']))
+                uacts = [agg]
+                for i, n in enumerate(unames):
+                    last = i + 1 == len(unames)
+                    uacts.append(self.fc_fwd(n, uacts[-1], not last,
+                                             residual=h if last else None))
+                saved.append(('gnn', enames, hx, xo, e, eacts, dst, agg,
+                              unames, uacts, off_names, off_acts, c))
+                h = uacts[-1]
+            else:
+                raise NotImplementedError(lc['type'])
+        pc = self.config['model_kwargs']['layer_configs'][-1]
+        if pc['type'] != 'classaware_predictor':
+            raise NotImplementedError(pc['type'])
+        ps = pc['scope'] + '/predictor'
+        cls_names = mlp_names(ps + '/cls', 2)
+        cacts = [h, self.fc_fwd(cls_names[0], h, True)]
+        cacts.append(self.fc_fwd(cls_names[1], cacts[-1], False))
+        logits = cacts[-1]
+        loc = []
+        k = int(h.shape[0])
+        pred = torch.empty((k, self.nc, self.box_len), dtype=torch.float32,
+                           device=dev)
+        for j in range(self.nc):
+            names = mlp_names(ps + '/loc/cls_%d' % j, 3)
+            a = [h]
+            for i, n in enumerate(names):
+                a.append(self.fc_fwd(n, a[-1], i < 2))
+            pred[:, j, :] = a[-1][:, :self.box_len]
+            loc.append((names, a))
+        saved.append(('heads', cls_names, cacts, loc))
+        self._saved = saved
+        self._h_width = int(h.shape[1])
+        return logits[:, :self.nc], pred
+
+    # ---- loss ---------------------------------------------------------------------
+    def loss_and_grads(self, logits, pred, labels, gt_box, valid, n_total,
+                       nv_total, want_grads=True):
+        """sums4 = [sum CE, sum loc, n, n_valid] (device double tensor),
+        dlogits [K,nc], dpred [K,nc,L] for the globally normalised loss."""
+        dev = self.device
+        k = int(logits.shape[0])
+        lg = logits.contiguous()
+        labels = labels.to(device=dev, dtype=torch.int32).reshape(-1).contiguous()
+        gt = gt_box.to(device=dev, dtype=torch.float32).reshape(
+            k, self.box_len).contiguous()
+        va = valid.to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
+        sums = torch.zeros(4, dtype=torch.float64, device=dev)
+        dlog = torch.empty((k, self.nc), dtype=torch.float32, device=dev) \
+            if want_grads else None
+        dpred = torch.empty((k, self.nc, self.box_len), dtype=torch.float32,
+                            device=dev) if want_grads else None
+        cls_scale = self.cls_w / n_total if n_total > 0 else 0.0
+        loc_scale = self.loc_w / nv_total if nv_total > 0 else 0.0  # div_no_nan
+        _lib.check(self.lib.pgnn_loss_fwd_bwd(
+            _lib.ptr(lg), lg.stride(0), _lib.ptr(labels), _lib.ptr(pred),
+            self.box_len, _lib.ptr(gt), _lib.ptr(va), k, self.nc,
+            ctypes.c_float(cls_scale), ctypes.c_float(loc_scale),
+            _lib.ptr(sums), _lib.ptr(dlog), _lib.ptr(dpred), self._st()),
+            "pgnn_loss_fwd_bwd")
+        return sums, dlog, dpred
+
+    def reg_loss(self):
+        out = torch.zeros(1, dtype=torch.float64, device=self.device)
+        _lib.check(self.lib.pgnn_l1_norm(
+            _lib.ptr(self.flat), _lib.ptr(self.is_weight), self.flat.numel(),
+            _lib.ptr(out), self._st()), "pgnn_l1_norm")
+        return self.l1_scale * float(out.item())
+
+    # ---- backward -----------------------------------------------------------------
+    def backward(self, dlogits, dpred):
+        lib, st, dev = self.lib, self._st(), self.device
+        saved = list(self._saved)
+        kind, cls_names, cacts, loc = saved.pop()
+        k = int(cacts[0].shape[0])
+        hw = self._h_width
+        dh = torch.zeros((k, hw), dtype=torch.float32, device=dev)
+
+        def add_dh(dx, width):
+            dh[:, :width] += dx[:, :width]
+
+        # heads
+        dy = torch.zeros((k, padded_width(self.nc)), dtype=torch.float32,
+                         device=dev)
+        dy[:, :self.nc] = dlogits
+        d1 = self.fc_bwd(cls_names[1], cacts[1], cacts[2], dy, False)
+        dx = self.fc_bwd(cls_names[0], cacts[0], cacts[1], d1, True)
+        cwidth = self.fc[cls_names[0]].k_in
+        add_dh(dx, cwidth)
+        for j, (names, a) in enumerate(loc):
+            dy = torch.zeros((k, padded_width(self.box_len)),
+                             dtype=torch.float32, device=dev)
+            dy[:, :self.box_len] = dpred[:, j, :]
+            d = self.fc_bwd(names[2], a[2], a[3], dy, False)
+            d = self.fc_bwd(names[1], a[1], a[2], d, True)
+            d = self.fc_bwd(names[0], a[0], a[1], d, True)
+            add_dh(d, cwidth)
+        # layers in reverse
+        while saved:
+            item = saved.pop()
+            if item[0] == 'gnn':
+                (_, enames, hx, xo, e, eacts, dst, agg, unames, uacts,
+                 off_names, off_acts, c) = item
+                d = dh            # gradient w.r.t. this layer's output
+                dh_in = dh.clone()  # residual branch (gnn.py:372)
+                for i in range(len(unames) - 1, -1, -1):
+                    last = i + 1 == len(unames)
+                    dcur = d if not last else d.clone()
+                    d = self.fc_bwd(unames[i], uacts[i], uacts[i + 1], dcur,
+                                    not last)
+                dagg = d
+                g = self._scatter_max_bwd(eacts[-1], dst, agg, dagg)
+                if getattr(self, 'debug', None) is not None:
+                    self.debug[enames[0] + '#z2'] = dict(
+                        gz2=g.clone(), h1=eacts[0].clone(), h2=eacts[-1].clone(),
+                        e=e.clone())
+                for i in range(len(enames) - 1, 0, -1):
+                    # g is already masked by the ReLU of layer i (relu_mask)
+                    g = self.fc_bwd(enames[i], eacts[i - 1], eacts[i], g,
+                                    relu=False)
+                    _lib.check(lib.pgnn_relu_mask_mul(
+                        _lib.ptr(g), _lib.ptr(eacts[i - 1]), g.numel(), st),
+                        "pgnn_relu_mask_mul")
+                kk = int(hx.shape[0])
+                wq = int(g.shape[1])
+                dp = torch.empty((kk, wq), dtype=torch.float32, device=dev)
+                dq = torch.empty((kk, wq), dtype=torch.float32, device=dev)
+                _lib.check(lib.pgnn_edge_hidden_bwd(
+                    _lib.ptr(g), wq, _lib.ptr(e), int(e.shape[0]), kk,
+                    _lib.ptr(dp), _lib.ptr(dq), st), "pgnn_edge_hidden_bwd")
+                w1 = self.fc[enames[0]]
+                if getattr(self, 'debug', None) is not None:
+                    self.debug[enames[0]] = dict(
+                        g1=g.clone(), dp=dp.clone(), dq=dq.clone(), dagg=dagg.clone(),
+                        dh_out=dh.clone(), hx=hx.clone(), agg=agg.clone())
+                # P = [h, x] W1 + b1
+                dhx = self.fc_bwd(enames[0], hx, None, dp, False)
+                dh_in[:, :c] += dhx[:, :c]
+                # Q = x' Wx, Wx = rows c..c+2 of W1 (pre-activation is P - Q; the
+                # minus sign is already in dq)
+                gwx_ptr = ctypes.c_void_p(w1.gw.data_ptr() + 4 * c * w1.n_out)
+                self._weight_grad(xo, 3, 3, dq, w1.n_out, gwx_ptr, None)
+                if off_names is not None:
+                    pk = torch.empty(lib.pgnn_packed_fc_floats(w1.n_out, 3),
+                                     dtype=torch.float32, device=dev)
+                    wx_ptr = ctypes.c_void_p(w1.w.data_ptr() + 4 * c * w1.n_out)
+                    _lib.check(lib.pgnn_pack_fc_device(
+                        wx_ptr, None, 3, w1.n_out, 1, _lib.ptr(pk), st),
+                        "pgnn_pack_fc_device")
+                    d = self._mlp1(pk, w1.n_out, 3, False, dq, w1.n_out)
+                    for i in range(len(off_names) - 1, -1, -1):
+                        d = self.fc_bwd(off_names[i], off_acts[i],
+                                        off_acts[i + 1], d,
+                                        i + 1 < len(off_names))
+                    dh_in[:, :c] += d[:, :c]
+                dh = dh_in
+            else:
+                _, names, acts, dst, agg, onames, oacts = item
+                d = dh
+                for i in range(len(onames) - 1, -1, -1):
+                    d = self.fc_bwd(onames[i], oacts[i], oacts[i + 1], d, True)
+                g = self._scatter_max_bwd(acts[-1], dst, agg, d)
+                for i in range(len(names) - 1, -1, -1):
+                    g = self.fc_bwd(names[i], acts[i], acts[i + 1], g,
+                                    relu=False, need_dx=i > 0)
+                    if i > 0:
+                        _lib.check(lib.pgnn_relu_mask_mul(
+                            _lib.ptr(g), _lib.ptr(acts[i]), g.numel(), st),
+                            "pgnn_relu_mask_mul")
+        self._saved = None
+
+    # ---- one training step ----------------------------------------------------------
+    def train_step(self, batch, apply=True):
+        """batch = (input_v, vertex_coord_list, keypoint_indices_list,
+        edges_list, cls_labels [K,1], encoded_boxes [K,1,L], valid_boxes
+        [K,1,1]) -- what train.py's batch_data returns for this rank.
+        Returns the loss dict of models.py:308-311 (global values)."""
+        import torch.distributed as dist
+        (input_v, coords, kps, edges, labels, boxes, valid) = batch
+        world = dist.get_world_size(self.pg) \
+            if (dist.is_available() and dist.is_initialized()) else 1
+        self.grad.zero_()
+        logits, pred = self.forward(input_v, coords, kps, edges)
+        k = int(logits.shape[0])
+        va = torch.as_tensor(valid).to(self.device, torch.float32).reshape(-1)
+        counts = torch.stack([torch.tensor(float(k), device=self.device,
+                                           dtype=torch.float64),
+                              va.sum().to(torch.float64)])
+        if world > 1:   # unify_copies: global endpoint counts (train.py:268-284)
+            dist.all_reduce(counts, group=self.pg)
+        n_total, nv_total = float(counts[0].item()), float(counts[1].item())
+        sums, dlog, dpred = self.loss_and_grads(
+            logits, pred, torch.as_tensor(labels), torch.as_tensor(boxes), va,
+            n_total, nv_total)
+        self.backward(dlog, dpred)
+        if world > 1:   # the one data-path collective: flat gradient sum
+            dist.all_reduce(self.grad, group=self.pg)
+            dist.all_reduce(sums, group=self.pg)
+        lr = learning_rate(self.train_config, self.global_step)
+        out = {
+            'cls_loss': self.cls_w * float(sums[0].item()) / max(n_total, 1.0),
+            'loc_loss': (self.loc_w * float(sums[1].item()) / nv_total)
+            if nv_total > 0 else 0.0,
+            'reg_loss': self.reg_loss(),
+            'num_endpoint': int(n_total), 'num_valid_endpoint': nv_total,
+            'learning_rate': lr,
+        }
+        if apply:
+            _lib.check(self.lib.pgnn_sgd_step(
+                _lib.ptr(self.flat), _lib.ptr(self.grad),
+                _lib.ptr(self.is_weight), self.flat.numel(),
+                ctypes.c_float(lr), ctypes.c_float(1.0),
+                ctypes.c_float(self.l1_scale), self._st()), "pgnn_sgd_step")
+            self.repack()
+            self.global_step += 1
+        return out

@@ -1,0 +1,249 @@
+"""Training-step parity (BASELINE config 4): HIP primitives and the full
+gradient against the float64 torch-autograd oracle (oracle/train_oracle.py)."""
+import os
+
+import numpy as np
+import pytest
+
+import pointgnn_amd  # noqa: F401
+from pointgnn_amd import configs, weights
+from oracle import train_oracle as to
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def gold(name):
+    return dict(np.load(os.path.join(GOLD, name)))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import torch
+    assert torch.cuda.is_available()
+    from pointgnn_amd import _lib
+    _lib.load()
+    return torch.device("cuda")
+
+
+def T(a, dev):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _tiny_batch(seed=0, fixture="graph_tiny.npz"):
+    g = gold(fixture)
+    k = g["kp_xyz"].shape[0]
+    coords = [g["xyz"], g["kp_xyz"], g["kp_xyz"]]
+    kps = [g["kp_idx"], np.arange(k, dtype=np.int32).reshape(-1, 1)]
+    edges = [g["ref_edges0"], g["ref_edges1"]]
+    rng = np.random.default_rng(seed)
+    labels = rng.integers(0, 4, (k, 1)).astype(np.int32)
+    labels[rng.random((k, 1)) < 0.5] = 0
+    boxes = (rng.standard_normal((k, 1, 7)) * 1.5).astype(np.float32)
+    valid = (labels > 0).astype(np.float32).reshape(k, 1, 1)
+    return (g["intensity"], coords, kps, edges, labels, boxes, valid)
+
+
+def test_pack_fc_device_matches_host_pack(dev):
+    import torch
+    from pointgnn_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(0)
+    for k_in, n_out in ((303, 300), (4, 32), (64, 3), (300, 64)):
+        w = rng.standard_normal((k_in, n_out)).astype(np.float32)
+        b = rng.standard_normal(n_out).astype(np.float32)
+        for tr in (0, 1):
+            ww, kk, nn = (w.T.copy(), n_out, k_in) if tr else (w, k_in, n_out)
+            host = np.empty(lib.pgnn_packed_fc_floats(kk, nn), np.float32)
+            bb = np.zeros(nn, np.float32) if tr else b
+            _lib.check(lib.pgnn_pack_fc(ww.ctypes.data, bb.ctypes.data, kk, nn,
+                                        host.ctypes.data))
+            out = torch.empty(host.size, dtype=torch.float32, device=dev)
+            wd, bd = T(w, dev), T(b, dev)     # keep alive across the call
+            _lib.check(lib.pgnn_pack_fc_device(
+                _lib.ptr(wd), None if tr else _lib.ptr(bd), k_in,
+                n_out, tr, _lib.ptr(out), _lib.stream_ptr()))
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy(), host)
+
+
+@pytest.mark.parametrize("rows,k_in,n_out", [(1000, 300, 300), (77, 4, 32),
+                                             (5000, 303, 300), (33, 64, 3),
+                                             (20000, 128, 300), (1, 16, 16)])
+def test_weight_grad_matches_numpy(dev, rows, k_in, n_out):
+    import torch
+    from pointgnn_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(rows)
+    x = rng.standard_normal((rows, k_in + 5)).astype(np.float32)
+    dz = rng.standard_normal((rows, n_out + 3)).astype(np.float32)
+    dw = torch.full((k_in, n_out), 0.5, dtype=torch.float32, device=dev)
+    db = torch.full((n_out,), -1.0, dtype=torch.float32, device=dev)
+    ws = torch.empty(lib.pgnn_weight_grad_workspace_bytes(k_in, n_out, rows),
+                     dtype=torch.uint8, device=dev)
+    xd, dzd = T(x, dev), T(dz, dev)
+    _lib.check(lib.pgnn_weight_grad_f32(
+        _lib.ptr(xd), xd.stride(0), k_in, _lib.ptr(dzd), dzd.stride(0), n_out,
+        rows, _lib.ptr(dw), _lib.ptr(db), 1, _lib.ptr(ws), ws.numel(),
+        _lib.stream_ptr()))
+    ref_w = x[:, :k_in].astype(np.float64).T @ dz[:, :n_out].astype(np.float64) + 0.5
+    ref_b = dz[:, :n_out].astype(np.float64).sum(0) - 1.0
+    tol = 2e-5 * np.sqrt(rows) + 1e-5
+    np.testing.assert_allclose(dw.cpu().numpy(), ref_w, atol=tol, rtol=1e-4)
+    np.testing.assert_allclose(db.cpu().numpy(), ref_b, atol=tol, rtol=1e-4)
+    # deterministic: same bits on a second run
+    dw2 = torch.zeros_like(dw)
+    dw3 = torch.zeros_like(dw)
+    for o in (dw2, dw3):
+        _lib.check(lib.pgnn_weight_grad_f32(
+            _lib.ptr(xd), xd.stride(0), k_in, _lib.ptr(dzd), dzd.stride(0),
+            n_out, rows, _lib.ptr(o), None, 0, _lib.ptr(ws), ws.numel(),
+            _lib.stream_ptr()))
+    assert torch.equal(dw2, dw3)
+
+
+def test_scatter_max_bwd_tie_rule(dev):
+    import torch
+    from pointgnn_amd import _lib, gnn
+    lib = _lib.load()
+    rng = np.random.default_rng(1)
+    rows, cols, nseg = 500, 20, 13
+    data = rng.integers(-2, 3, (rows, cols)).astype(np.float32)   # many ties
+    seg = np.sort(rng.integers(0, nseg, rows)).astype(np.int32)
+    gout = rng.standard_normal((nseg, cols)).astype(np.float32)
+    d = T(data, dev)
+    s = T(seg, dev)
+    out = gnn.graph_scatter_max_fn(d, s, nseg, ids_sorted=True)
+    for relu in (0, 1):
+        ties = torch.empty(nseg * cols, dtype=torch.int32, device=dev)
+        gd = torch.empty_like(d)
+        go = T(gout, dev)
+        _lib.check(lib.pgnn_scatter_max_bwd_f32(
+            _lib.ptr(d), cols, _lib.ptr(s), rows, cols, nseg, _lib.ptr(out),
+            cols, _lib.ptr(go), cols, _lib.ptr(ties), _lib.ptr(gd), cols, relu,
+            _lib.stream_ptr()))
+        td = torch.tensor(data, dtype=torch.float64, requires_grad=True)
+        o = to._segment_max(td, torch.tensor(seg, dtype=torch.int64), nseg)
+        o = torch.where(torch.isinf(o), torch.zeros_like(o), o)
+        (o * torch.tensor(gout, dtype=torch.float64)).sum().backward()
+        ref = td.grad.numpy()
+        if relu:
+            ref = ref * (data > 0)
+        np.testing.assert_allclose(gd.cpu().numpy(), ref, atol=1e-6)
+
+
+def test_loss_kernel_matches_oracle(dev):
+    import torch
+    from pointgnn_amd import train
+    cfg = configs.car_auto_config(0)
+    tr = train.Trainer(cfg, seed=0, device=dev)
+    rng = np.random.default_rng(2)
+    k = 300
+    logits = rng.standard_normal((k, 4)).astype(np.float32) * 3
+    pred = rng.standard_normal((k, 4, 7)).astype(np.float32) * 2
+    labels = rng.integers(0, 4, (k, 1)).astype(np.int32)
+    gt = rng.standard_normal((k, 1, 7)).astype(np.float32) * 2
+    valid = (rng.random((k, 1, 1)) < 0.6).astype(np.float32)
+    nv = float(valid.sum())
+    sums, dlog, dpred = tr.loss_and_grads(T(logits, dev), T(pred, dev),
+                                          T(labels, dev), T(gt, dev),
+                                          T(valid, dev), float(k), nv)
+    tl = torch.tensor(logits, dtype=torch.float64, requires_grad=True)
+    tp = torch.tensor(pred, dtype=torch.float64, requires_grad=True)
+    ce, loc, n, nvv = to.loss_terms(cfg, tl, tp, labels, gt, valid)
+    (0.1 * ce / n + 10.0 * loc / nvv).backward()
+    s = sums.cpu().numpy()
+    np.testing.assert_allclose(s, [float(ce), float(loc), k, nv], rtol=1e-5)
+    np.testing.assert_allclose(dlog.cpu().numpy(), tl.grad.numpy(), atol=1e-7,
+                               rtol=1e-4)
+    np.testing.assert_allclose(dpred.cpu().numpy(), tp.grad.numpy(), atol=1e-7,
+                               rtol=1e-4)
+
+
+def _grad_errors(got, ref):
+    """(max-abs error / max|ref|, Frobenius error / ||ref||)."""
+    scale = np.abs(ref).max() + 1e-12
+    return (np.abs(got - ref).max() / scale,
+            np.linalg.norm(got - ref) / (np.linalg.norm(ref) + 1e-12))
+
+
+@pytest.mark.parametrize("name", ["car_auto_T1", "car_auto_T3", "car_fixed_T3"])
+def test_full_gradient_matches_oracle(dev, name):
+    """Every variable's gradient of (cls + loc) against float64 autograd.
+
+    The loss is piecewise smooth: a pre-activation within float32 rounding of
+    zero (ReLU kink) or two edge features within rounding of each other
+    (arg-max flip) make single gradient *entries* of a deep model legitimately
+    differ between a float32 and a float64 evaluation (observed: 3 of 11.7M
+    ReLU masks differ in layer4 of car_auto_T3 on this fixture, one of them
+    carrying 5% of max|dP|).  The bar is therefore the Frobenius error per
+    variable (a wrong formula gives O(1)), with a loose max-entry bound; the
+    one-GNN-layer model has no such flip on this fixture and is held to 1e-4
+    entry-wise."""
+    from pointgnn_amd import train
+    cfg = configs.get_config(name)
+    params = weights.init_params(cfg, seed=5, bias_scale=0.1)
+    batch = _tiny_batch(seed=3)
+    tr = train.Trainer(cfg, params=params, device=dev)
+    out = tr.train_step(batch, apply=False)
+    loss, g_ref, _ = to.step_gradients(params, cfg, [batch])
+    assert abs(out['cls_loss'] - loss['cls_loss']) < 1e-4 * max(1, loss['cls_loss'])
+    assert abs(out['loc_loss'] - loss['loc_loss']) < 1e-4 * max(1, loss['loc_loss'])
+    assert abs(out['reg_loss'] - loss['reg_loss']) < 1e-5 * max(1, loss['reg_loss'])
+    got = tr.grad_dict()
+    worst_max, worst_fro = 0.0, 0.0
+    for n, ref in g_ref.items():
+        e_max, e_fro = _grad_errors(got[n], ref)
+        worst_max, worst_fro = max(worst_max, e_max), max(worst_fro, e_fro)
+        assert e_fro < 3e-3, "%s: Frobenius rel err %.3g" % (n, e_fro)
+        assert e_max < (1e-4 if name == "car_auto_T1" else 3e-2), \
+            "%s: max-entry rel err %.3g" % (n, e_max)
+    print(name, "worst gradient error: max-entry %.3g, Frobenius %.3g" % (
+        worst_max, worst_fro))
+
+
+def test_sgd_step_and_loss_decrease(dev):
+    from pointgnn_amd import train
+    cfg = configs.car_auto_config(1)
+    params = weights.init_params(cfg, seed=6, bias_scale=0.05)
+    batch = _tiny_batch(seed=4)
+    tcfg = {'initial_lr': 0.01, 'decay_step': 2, 'decay_factor': 0.5,
+            'optimizer': 'sgd', 'unify_copies': True}
+    tr = train.Trainer(cfg, train_config=tcfg, params=params, device=dev)
+    before = tr.state_dict()
+    out0 = tr.train_step(batch)
+    g = tr.grad_dict()
+    after = tr.state_dict()
+    scale = cfg['model_kwargs']['regularizer_kwargs']['scale']
+    for n in before:
+        upd = g[n] + (scale * np.sign(before[n]) if n.endswith('/weights') else 0)
+        np.testing.assert_allclose(after[n], before[n] - 0.01 * upd, atol=1e-7,
+                                   rtol=1e-5)
+    assert tr.global_step == 1
+    assert train.learning_rate(tcfg, 0) == 0.01
+    assert train.learning_rate(tcfg, 2) == 0.005          # staircase
+    losses = [out0['cls_loss'] + out0['loc_loss']]
+    for _ in range(8):
+        o = tr.train_step(batch)
+        losses.append(o['cls_loss'] + o['loc_loss'])
+    assert losses[-1] < losses[0], losses
+
+
+def test_two_frame_batch_equals_two_ranks(dev):
+    """Frame merging (train.py:135-171) and the rank decomposition give the
+    same global gradient: one process with a 2-frame batch == the sum of two
+    single-frame 'ranks' normalised by the global counts (what the all-reduce
+    computes)."""
+    from pointgnn_amd import train
+    cfg = configs.car_auto_config(1)
+    params = weights.init_params(cfg, seed=7, bias_scale=0.05)
+    b0, b1 = _tiny_batch(seed=5), _tiny_batch(seed=6, fixture="graph_small.npz")
+    merged = train.batch_data([b0, b1])
+    tr = train.Trainer(cfg, params=params, device=dev)
+    tr.train_step(merged, apply=False)
+    g_merged = tr.grad_dict()
+    loss, g_ref, _ = to.step_gradients(params, cfg, [b0, b1])
+    for n, ref in g_ref.items():
+        e_max, e_fro = _grad_errors(g_merged[n], ref)
+        assert e_fro < 3e-3 and e_max < 3e-2, (n, e_max, e_fro)
