@@ -210,6 +210,89 @@ def cpu_baseline(cfg, params, xyz, inten, budget_s=20.0):
     }
 
 
+def run_train(args, torch, dev, rank, world, dist):
+    """BASELINE config 4: car_auto_T3 training step -- per rank and step:
+    training-mode graph build (voxel 0.8 m, random keypoints + origin jitter,
+    level-1 fan-in capped at 256) for `frames_per_gpu` frames, frame merge,
+    forward, loss, backward, ONE all-reduce of the flat gradient, SGD."""
+    from pointgnn_amd import configs, graph_gen, train
+    from pointgnn_amd.synthetic import synthetic_cloud
+    cfg = configs.get_config(args.config)
+    pg = None
+    tr = train.Trainer(cfg, seed=0, device=dev, process_group=pg)
+    fpg = args.frames_per_gpu
+    n_steps = args.steps + args.warmup
+    pool = {}
+    for s in range(args.frames):
+        xyz, inten = synthetic_cloud(seed=s, preset=args.preset)
+        pool[s] = (torch.from_numpy(xyz).to(dev), torch.from_numpy(inten).to(dev))
+    fn = graph_gen.get_graph_generate_fn(cfg['graph_gen_method'])
+    gen = torch.Generator(device='cpu').manual_seed(1234 + rank)
+    np.random.seed(99 + rank)
+
+    def make_frame(i):
+        x, f = pool[i % args.frames]
+        coords, kps, edges = fn(x, **cfg['graph_gen_kwargs'])
+        k = int(coords[1].shape[0])
+        lab = (torch.rand(k, generator=gen) < 0.2).to(torch.int32) * \
+            torch.randint(1, 3, (k,), generator=gen, dtype=torch.int32)
+        lab = lab.reshape(k, 1).to(dev)
+        boxes = torch.randn((k, 1, 7), generator=gen).to(dev)
+        valid = (lab > 0).to(torch.float32).reshape(k, 1, 1)
+        return (f, coords, kps, edges, lab, boxes, valid)
+
+    shapes = {}
+
+    def step(i):
+        frames = [make_frame((rank + world * i) * fpg + j) for j in range(fpg)]
+        batch = train.batch_data(frames)
+        shapes['K'] = int(batch[1][1].shape[0])
+        shapes['E0'] = int(batch[3][0].shape[0])
+        shapes['E1'] = int(batch[3][1].shape[0])
+        return tr.train_step(batch)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, n_steps):
+        out = step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        res = {
+            "metric": "training frames/sec (%s, fwd+loss+bwd+allreduce+SGD, "
+                      "training graph kwargs)" % args.config,
+            "value": world * fpg * args.steps / elapsed, "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": "%s training step, %d frames/GPU/step (global "
+                            "batch %d), graph build included, synthetic labels"
+                            % (args.config, fpg, world * fpg),
+                "last_batch_shape": shapes,
+                "params": int(tr.flat.numel()),
+                "allreduce_bytes": int(tr.flat.numel()) * 4,
+                "last_loss": {k: out[k] for k in ('cls_loss', 'loc_loss',
+                                                  'reg_loss')},
+                "parallelism": "dp%d (frames sharded, one flat gradient "
+                               "all-reduce per step)" % world},
+        }
+        print(json.dumps(res), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -222,6 +305,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--train", action="store_true",
+                    help="BASELINE config 4: training step instead of inference")
+    ap.add_argument("--frames-per-gpu", type=int, default=2)
     args = ap.parse_args()
 
     import torch
@@ -244,6 +330,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
+
+    if args.train:
+        run_train(args, torch, dev, rank, world, dist)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     cfg = configs.get_config(args.config)
     params = weights.init_params(cfg, seed=0, bias_scale=0.05)

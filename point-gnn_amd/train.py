@@ -28,7 +28,8 @@ from . import _lib
 from .gnn import padded_width
 from .weights import init_params, mlp_names, variable_specs
 
-__all__ = ["Trainer", "batch_data", "learning_rate"]
+__all__ = ["Trainer", "batch_data", "learning_rate",
+           "allreduce_endpoint_counts", "allreduce_gradients"]
 
 
 def learning_rate(train_config, step):
@@ -71,6 +72,32 @@ def batch_data(batch_list):
               for lvl in range(level_num)]
     return (cat(n_input_v), coords, kp_out, edge_out, cat(n_labels),
             cat(n_boxes), cat(n_valid))
+
+
+def allreduce_endpoint_counts(n_local, nv_local, device, group=None):
+    """Global (num_endpoint, num_valid_endpoint) over all ranks: the
+    `unify_copies` normalisers of train.py:268-284.  One tiny all-reduce."""
+    import torch.distributed as dist
+    counts = torch.tensor([float(n_local), float(nv_local)],
+                          dtype=torch.float64, device=device)
+    if dist.is_available() and dist.is_initialized() and \
+            dist.get_world_size(group) > 1:
+        dist.all_reduce(counts, group=group)
+    return float(counts[0].item()), float(counts[1].item())
+
+
+def allreduce_gradients(flat_grad, sums=None, group=None):
+    """The one data-path collective of a training step: SUM of the flat fp32
+    gradient buffer over ranks (RCCL on GPUs, gloo in the CPU tests).  Because
+    every rank already scaled its loss by the GLOBAL 1/N and 1/N_valid, the
+    sum equals util/tf_util.py:average_gradients of the re-weighted towers."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and \
+            dist.get_world_size(group) > 1:
+        dist.all_reduce(flat_grad, group=group)
+        if sums is not None:
+            dist.all_reduce(sums, group=group)
+    return flat_grad
 
 
 class _Fc(object):
@@ -517,27 +544,19 @@ class Trainer(object):
         edges_list, cls_labels [K,1], encoded_boxes [K,1,L], valid_boxes
         [K,1,1]) -- what train.py's batch_data returns for this rank.
         Returns the loss dict of models.py:308-311 (global values)."""
-        import torch.distributed as dist
         (input_v, coords, kps, edges, labels, boxes, valid) = batch
-        world = dist.get_world_size(self.pg) \
-            if (dist.is_available() and dist.is_initialized()) else 1
         self.grad.zero_()
         logits, pred = self.forward(input_v, coords, kps, edges)
         k = int(logits.shape[0])
         va = torch.as_tensor(valid).to(self.device, torch.float32).reshape(-1)
-        counts = torch.stack([torch.tensor(float(k), device=self.device,
-                                           dtype=torch.float64),
-                              va.sum().to(torch.float64)])
-        if world > 1:   # unify_copies: global endpoint counts (train.py:268-284)
-            dist.all_reduce(counts, group=self.pg)
-        n_total, nv_total = float(counts[0].item()), float(counts[1].item())
+        # unify_copies: global endpoint counts (train.py:268-284)
+        n_total, nv_total = allreduce_endpoint_counts(
+            k, float(va.sum().item()), self.device, self.pg)
         sums, dlog, dpred = self.loss_and_grads(
             logits, pred, torch.as_tensor(labels), torch.as_tensor(boxes), va,
             n_total, nv_total)
         self.backward(dlog, dpred)
-        if world > 1:   # the one data-path collective: flat gradient sum
-            dist.all_reduce(self.grad, group=self.pg)
-            dist.all_reduce(sums, group=self.pg)
+        allreduce_gradients(self.grad, sums, self.pg)  # no-op for world 1
         lr = learning_rate(self.train_config, self.global_step)
         out = {
             'cls_loss': self.cls_w * float(sums[0].item()) / max(n_total, 1.0),

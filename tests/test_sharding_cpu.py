@@ -75,3 +75,76 @@ def test_two_process_gloo_sharding():
         assert elapsed == 1.5                              # MAX over ranks
         assert sum(g[1] for g in gathered) == n
         assert sum(g[0] for g in gathered) == sum(range(n))
+
+
+def _train_worker(rank, world, port, q):
+    """Each 'rank' holds one frame.  Gradients are computed by the CPU oracle
+    with the GLOBAL normalisers obtained through the product's collective
+    helpers (gloo here, RCCL on GPUs); their all-reduce SUM must equal the
+    oracle's global gradient (train.py:264-297 + util/tf_util.py:3-43)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import pointgnn_amd  # noqa: F401
+    from pointgnn_amd import configs, weights
+    from pointgnn_amd.train import (allreduce_endpoint_counts,
+                                    allreduce_gradients)
+    from oracle import train_oracle as to
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = configs.car_auto_config(0)
+    params = weights.init_params(cfg, seed=1, bias_scale=0.1)
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", "graph_tiny.npz")))
+    k = g["kp_xyz"].shape[0]
+    rng = np.random.default_rng(10 + rank)
+    labels = rng.integers(0, 4, (k, 1)).astype(np.int32)
+    boxes = rng.standard_normal((k, 1, 7)).astype(np.float32)
+    valid = (rng.random((k, 1, 1)) < (0.3 + 0.4 * rank)).astype(np.float32)
+    batch = (g["intensity"] * (1 + rank),
+             [g["xyz"], g["kp_xyz"], g["kp_xyz"]],
+             [g["kp_idx"], np.arange(k, dtype=np.int32).reshape(-1, 1)],
+             [g["ref_edges0"], g["ref_edges1"]], labels, boxes, valid)
+    n_tot, nv_tot = allreduce_endpoint_counts(k, float(valid.sum()),
+                                              torch.device("cpu"))
+    tp = {kk: torch.tensor(v, dtype=torch.float64, requires_grad=True)
+          for kk, v in params.items()}
+    logits, pred = to.forward(tp, cfg, *batch[:4])
+    ce, loc, n, nv = to.loss_terms(cfg, logits, pred, labels, boxes, valid)
+    local = 0.1 * ce / n_tot + 10.0 * loc / nv_tot
+    names = list(tp)
+    grads = torch.autograd.grad(local, [tp[n_] for n_ in names],
+                                allow_unused=True)
+    flat = torch.cat([(torch.zeros_like(tp[n_]) if g_ is None else g_).reshape(-1)
+                      for n_, g_ in zip(names, grads)])
+    allreduce_gradients(flat)
+    q.put((rank, batch, n_tot, nv_tot, flat.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_allreduce_equals_global_gradient():
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from pointgnn_amd import configs, weights
+    from oracle import train_oracle as to
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_worker, args=(r, world, port, q))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=600) for _ in range(world)],
+                     key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    cfg = configs.car_auto_config(0)
+    params = weights.init_params(cfg, seed=1, bias_scale=0.1)
+    _, g_ref, _ = to.step_gradients(params, cfg, [r[1] for r in results])
+    ref = np.concatenate([g_ref[n].reshape(-1) for n in params])
+    assert results[0][2] == results[1][2] == 2 * results[0][1][4].shape[0]
+    for _, _, _, _, flat in results:          # every rank holds the same sum
+        np.testing.assert_allclose(flat, ref, atol=1e-12, rtol=1e-9)
