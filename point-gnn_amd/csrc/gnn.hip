@@ -298,6 +298,26 @@ __global__ __launch_bounds__(256, 2) void fused_mlp_kernel(
           layer_pass_dispatch<MSUB, false>(tile, ld_in, stage, ld_st, L, t0, wave,
                                            lane, (dbg & 2) != 0);
           consume_rows<ROWS>(stage, ld_st, row0, rows_valid, 16 * t0, ncols, ra);
+        } else if (sa.sorted && !(dbg & (2 | 4 | 32)) && dst[1] >= 0 &&
+                   dst[1] < sa.num_segments && dst[1] == dst[ROWS]) {
+          // whole tile = one run of one segment: reduce in registers
+          const int d = dst[1];
+          const bool merge = cs.id == d;
+          const bool left_closed = merge ? cs.left_closed != 0 : dst[0] != d;
+          const bool right_closed = dst[ROWS + 1] != d;
+          const bool defer = !right_closed && tile_id + 1 < tile_last;
+          SegFast sf;
+          sf.carry = carry;
+          sf.out_row = sa.out + (int64_t)d * sa.ldo;
+          sf.merge = merge;
+          sf.defer = defer;
+          sf.whole = left_closed && right_closed;
+          layer_pass_segmax_fast_dispatch<MSUB>(tile, ld_in, L, t0, wave, lane,
+                                                sf);
+          if (t0 + kMaxTilesPerPass >= L.nt) {
+            cs.id = defer ? d : -1;
+            cs.left_closed = left_closed ? 1 : 0;
+          }
         } else {
           layer_pass_dispatch<MSUB, true>(tile, ld_in, stage, ld_st, L, t0, wave,
                                           lane, (dbg & 2) != 0);

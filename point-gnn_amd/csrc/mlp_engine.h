@@ -162,6 +162,71 @@ __device__ __forceinline__ void store_acc_T(float *__restrict__ stT,
   }
 }
 
+// Fast epilogue for the layer feeding a segmented max when ALL rows of the tile
+// belong to one segment (the common case at level 1: mean fan-in ~170 vs 64-row
+// tiles): the column max is taken straight from the accumulators -- 16 values
+// per lane, then two cross-lane steps over the four row groups -- so the tile
+// never goes back through LDS and two workgroup barriers disappear.
+// max_r act(a_r + b) == act(max_r a_r + b) because +b and ReLU are monotone.
+struct SegFast {
+  float *carry;      // LDS, one float per output column (absolute index)
+  float *out_row;    // global row of the segment (already offset to column 0)
+  int merge;         // fold carry[] in first
+  int defer;         // keep in carry[] instead of writing out
+  int whole;         // plain store (complete segment) vs atomic max
+};
+
+template <int MSUB, int NT>
+__device__ __forceinline__ void layer_pass_segmax_fast(
+    const float *in, int ld_in, const LayerDev &L, int t0, int wave, int lane,
+    const SegFast &sf) {
+  v4f acc[MSUB][NT];
+  gemm_tile<MSUB, NT>(in, ld_in, L, t0, wave, lane, acc);
+  const float *bias = L.wp + (size_t)L.kq * L.nt * 256;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int t = t0 + wave + 4 * j;
+    if (t < L.nt) {
+      float v = acc[0][j][0];
+#pragma unroll
+      for (int m = 0; m < MSUB; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v = fmaxf(v, acc[m][j][r]);
+      v = fmaxf(v, __shfl_xor(v, 16));
+      v = fmaxf(v, __shfl_xor(v, 32));
+      const int col = t * 16 + (lane & 15);
+      v += bias[col];
+      if (col >= L.relu_from) v = v > 0.0f ? v : 0.0f;
+      if (lane < 16) {
+        if (sf.merge) v = fmaxf(v, sf.carry[col]);
+        if (sf.defer) {
+          sf.carry[col] = v;
+        } else if (sf.whole) {
+          sf.out_row[col] = v;
+        } else {
+          atomic_max_f32(sf.out_row + col, v + 0.0f);
+        }
+      }
+    }
+  }
+}
+
+template <int MSUB>
+__device__ __forceinline__ void layer_pass_segmax_fast_dispatch(
+    const float *in, int ld_in, const LayerDev &L, int t0, int wave, int lane,
+    const SegFast &sf) {
+  int tiles = L.nt - t0;
+  if (tiles > kMaxTilesPerPass) tiles = kMaxTilesPerPass;
+  const int ntw = (tiles + 3) >> 2;
+  switch (ntw) {
+    case 1: layer_pass_segmax_fast<MSUB, 1>(in, ld_in, L, t0, wave, lane, sf); break;
+    case 2: layer_pass_segmax_fast<MSUB, 2>(in, ld_in, L, t0, wave, lane, sf); break;
+    case 3: layer_pass_segmax_fast<MSUB, 3>(in, ld_in, L, t0, wave, lane, sf); break;
+    case 4: layer_pass_segmax_fast<MSUB, 4>(in, ld_in, L, t0, wave, lane, sf); break;
+    default: layer_pass_segmax_fast<MSUB, 5>(in, ld_in, L, t0, wave, lane, sf); break;
+  }
+}
+
 // One pass (<= 320 output columns starting at column tile t0) of layer L:
 // GEMM from `in`, barrier, activated store to `out` (may alias `in`), barrier.
 template <int MSUB, int NT, bool TRANSPOSED>
