@@ -304,6 +304,8 @@ def main():
                     help="distinct synthetic frames in the pool")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="run frames strictly sequentially on one stream")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--train", action="store_true",
                     help="BASELINE config 4: training step instead of inference")
@@ -351,19 +353,29 @@ def main():
         pool[s] = (torch.from_numpy(xyz).to(dev), torch.from_numpy(inten).to(dev),
                    xyz, inten)
 
-    def step(i):
+    def frame(i):
         x, f, _, _ = pool[my_ids[i] % args.frames]
-        return engine.run_frame(x, f)
+        return x, f
 
-    for i in range(args.warmup):
-        step(i)
+    def run(lo, hi):
+        """Frames lo..hi-1 of this rank's stream.  Default: two-stream software
+        pipeline (graph build of frame i+1 overlaps the GNN of frame i);
+        --no-pipeline runs them strictly one after the other."""
+        if args.no_pipeline:
+            out = None
+            for i in range(lo, hi):
+                out = engine.run_frame(*frame(i))
+            return out
+        return engine.run_frames_pipelined([frame(i) for i in range(lo, hi)])[-1]
+
+    if args.warmup:
+        run(0, args.warmup)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.warmup, args.warmup + args.steps):
-        out = step(i)
+    out = run(args.warmup, args.warmup + args.steps)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -402,6 +414,9 @@ def main():
                             "Xavier weights" % (args.config, args.preset),
                 "N": int(x.shape[0]), "K": n_k, "E0": n_e0, "E1": n_e1,
                 "frames_per_gpu_per_step": 1,
+                "schedule": "sequential, 1 stream" if args.no_pipeline else
+                            "2 HIP streams: graph build of frame i+1 overlaps "
+                            "GNN of frame i",
                 "parallelism": "frame-parallel x%d (no collective)" % world,
                 "frames_per_sec_per_gpu": fps / world,
                 "algorithmic_gflop_per_frame": total_flops / 1e9,

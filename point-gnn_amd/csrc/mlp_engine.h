@@ -61,39 +61,44 @@ __device__ __forceinline__ void gemm_tile(const float *__restrict__ tile, int ld
   const float *arow = tile + (lane & 15) * ld + 4 * (lane >> 4);
   const int qstride = L.nt * 64;
   const int kq = L.kq;
-  // Software pipeline, depth 1: the fragments of K-group q+1 are requested
-  // before the 4*MSUB*NT MFMAs of group q issue, so the L2 / LDS latency of the
-  // loads hides under ~2.5k cycles of matrix work instead of stalling each
-  // iteration.  Two named register sets (A/B) alternate; the index is clamped
-  // so the last prefetch re-reads a valid group instead of branching.
-  v4f aA[MSUB], bA[NT], aB[MSUB], bB[NT];
-  auto fetch = [&](int q, v4f (&a)[MSUB], v4f (&b)[NT]) {
+  // Software pipeline over K-groups with PF register stages: a stage is
+  // refilled (fragments of group q + PF) right after its MFMAs consumed it, so
+  // L2 / LDS latency hides under PF-1 groups of matrix work.  Big tiles
+  // (MSUB = 4: 80 MFMAs ~ 2.5k cycles per group) need 2 stages; 16-row tiles
+  // (MSUB = 1: 20 MFMAs ~ 640 cycles per group, far less than an L2 round
+  // trip) get 4.  The prefetch index is clamped, so the tail re-reads a valid
+  // group instead of branching around loads.
+  constexpr int PF = MSUB >= 4 ? 2 : (MSUB == 2 ? 3 : 4);
+  v4f a[PF][MSUB], b[PF][NT];
+  auto fetch = [&](int q, v4f (&fa)[MSUB], v4f (&fb)[NT]) {
     if (q > kq - 1) q = kq - 1;
 #pragma unroll
-    for (int j = 0; j < NT; ++j) b[j] = wp[(size_t)q * qstride + toff[j]];
+    for (int j = 0; j < NT; ++j) fb[j] = wp[(size_t)q * qstride + toff[j]];
 #pragma unroll
     for (int m = 0; m < MSUB; ++m)
-      a[m] = *reinterpret_cast<const v4f *>(arow + m * 16 * ld + 16 * q);
+      fa[m] = *reinterpret_cast<const v4f *>(arow + m * 16 * ld + 16 * q);
   };
-  auto mma = [&](const v4f (&a)[MSUB], const v4f (&b)[NT]) {
+  auto mma = [&](const v4f (&fa)[MSUB], const v4f (&fb)[NT]) {
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
       for (int m = 0; m < MSUB; ++m)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
-          acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][s], b[j][s],
+          acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[m][s], fb[j][s],
                                                            acc[m][j], 0, 0, 0);
   };
-  fetch(0, aA, bA);
-  int q = 0;
-  for (; q + 1 < kq; q += 2) {
-    fetch(q + 1, aB, bB);
-    mma(aA, bA);
-    fetch(q + 2, aA, bA);
-    mma(aB, bB);
+#pragma unroll
+  for (int st = 0; st < PF; ++st) fetch(st, a[st], b[st]);
+  for (int q = 0; q < kq; q += PF) {
+#pragma unroll
+    for (int st = 0; st < PF; ++st) {
+      if (q + st < kq) {  // wave-uniform
+        mma(a[st], b[st]);
+        fetch(q + st + PF, a[st], b[st]);
+      }
+    }
   }
-  if (q < kq) mma(aA, bA);
 }
 
 // out[row][col - 16*t0] = act(acc + bias[col]); C/D layout of the 16x16 MFMA:

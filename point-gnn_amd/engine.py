@@ -44,6 +44,48 @@ class InferenceEngine(object):
         device -- run.py:219-222."""
         return self.graph_fn(xyz, **self.graph_kwargs)
 
+    def run_frames_pipelined(self, frames):
+        """Steady-state loop over independent frames on two HIP streams: while
+        stream C executes the GNN of frame i, stream G builds the graph of
+        frame i+1.  The graph builder needs three host reads per frame (K, E0,
+        E1 size its outputs); they synchronise stream G only, so the host waits
+        for them while the GPU is busy with frame i's message passing.
+        frames: iterable of (xyz, intensity) CUDA tensors.  Returns the list of
+        (logits, box_encodings); outputs are complete after
+        torch.cuda.synchronize() (or a wait on stream C)."""
+        frames = list(frames)
+        if not frames:
+            return []
+        if not hasattr(self, "_streams"):
+            self._streams = (torch.cuda.Stream(), torch.cuda.Stream())
+        sg, sc = self._streams
+        cur = torch.cuda.current_stream()
+        sg.wait_stream(cur)
+        sc.wait_stream(cur)
+
+        def build(i):
+            with torch.cuda.stream(sg):
+                g = self.build_graph(frames[i][0])
+                ev = torch.cuda.Event()
+                ev.record(sg)
+            return g, ev
+
+        outs = []
+        graph, ev = build(0)
+        for i in range(len(frames)):
+            sc.wait_event(ev)
+            with torch.cuda.stream(sc):
+                coords, kps, edges = graph
+                for t in list(coords) + list(kps) + list(edges):
+                    t.record_stream(sc)  # allocated on G, consumed on C
+                outs.append(self.model.predict(frames[i][1], coords, kps,
+                                               edges, is_training=False))
+            self.last_graph = graph
+            if i + 1 < len(frames):
+                graph, ev = build(i + 1)
+        cur.wait_stream(sc)
+        return outs
+
     def run_frame(self, xyz, intensity, timed=False):
         """xyz [N,3] float32, intensity [N,F] float32 CUDA tensors ->
         (logits [K,nc], box_encodings [K,nc,7]) CUDA tensors.  With

@@ -476,3 +476,25 @@ def test_full_size_properties(dev):
     ref = gn.point_set_pooling(params, "layer1", inten, c_np[0], kp0, sub,
                                dtype=np.float64)
     np.testing.assert_allclose(pooled[sel, :300], ref[sel], atol=FP_TOL, rtol=1e-4)
+
+
+def test_pipelined_frames_equal_sequential(dev):
+    """The two-stream schedule (engine.run_frames_pipelined) must return
+    bit-identical results to frame-at-a-time execution."""
+    import torch
+    from pointgnn_amd.engine import InferenceEngine
+    cfg = configs.car_auto_config(2)
+    params = weights.init_params(cfg, seed=9, bias_scale=0.05)
+    eng = InferenceEngine(cfg, params, device=dev)
+    frames = []
+    for s in range(5):
+        xyz, inten = synthetic_cloud(seed=s, preset="small" if s % 2 else "tiny")
+        frames.append((T(xyz, dev), T(inten, dev)))
+    seq = [eng.run_frame(x, f) for x, f in frames]
+    torch.cuda.synchronize()
+    for _ in range(2):
+        pip = eng.run_frames_pipelined(frames)
+        torch.cuda.synchronize()
+        assert len(pip) == len(seq)
+        for (l0, b0), (l1, b1) in zip(seq, pip):
+            assert torch.equal(l0, l1) and torch.equal(b0, b1)
