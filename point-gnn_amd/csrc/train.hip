@@ -490,9 +490,13 @@ extern "C" int pgnn_scatter_max_bwd_f32(
 }
 
 namespace {
-int wg_slices(int64_t rows) {
+int wg_slices(int64_t rows, int k_in) {
+  // ~4 workgroups per CU in flight: (in-blocks x slices) ~ 1024
+  const int64_t in_blocks = ((int64_t)k_in + 1 + 63) / 64;
   int64_t s = (rows + kWgRows - 1) / kWgRows;
-  if (s > 64) s = 64;
+  int64_t cap = 1024 / in_blocks;
+  if (cap < 1) cap = 1;
+  if (s > cap) s = cap;
   if (s < 1) s = 1;
   return (int)s;
 }
@@ -503,7 +507,7 @@ extern "C" size_t pgnn_weight_grad_workspace_bytes(int32_t k_in, int32_t n_out,
   if (k_in <= 0 || n_out <= 0 || n_rows < 0) return 0;
   const size_t in_blocks = ((size_t)k_in + 1 + 63) / 64;
   const size_t nt = ((size_t)n_out + 15) / 16;
-  return (size_t)wg_slices(n_rows) * in_blocks * 64 * nt * 16 * 4 + 256;
+  return (size_t)wg_slices(n_rows, k_in) * in_blocks * 64 * nt * 16 * 4 + 256;
 }
 
 extern "C" int pgnn_weight_grad_f32(const float *X, int64_t ld_x, int32_t k_in,
@@ -524,7 +528,7 @@ extern "C" int pgnn_weight_grad_f32(const float *X, int64_t ld_x, int32_t k_in,
                PGNN_E_INVALID, "weight_grad: bad input");
   const int in_blocks = (k_in + 1 + 63) / 64;
   const int nt = (n_out + 15) / 16;
-  const int slices = wg_slices(n_rows);
+  const int slices = wg_slices(n_rows, k_in);
   int64_t rps = (n_rows + slices - 1) / slices;
   rps = (rps + kWgRows - 1) / kWgRows * kWgRows;
   if (rps < kWgRows) rps = kWgRows;

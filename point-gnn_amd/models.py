@@ -135,10 +135,67 @@ class MultiLayerFastLocalGraphModelV2(object):
         e = np.exp(z)
         return e / e.sum(axis=-1, keepdims=True)
 
-    def loss(self, *args, **kwargs):
-        raise NotImplementedError(
-            "training loss (models.py:170-311) is scheduled after the "
-            "inference path: see DESIGN.md, scope row a11")
+    def loss(self, logits, labels, pred_box, gt_box, valid_box,
+             cls_loss_type='focal_sigmoid', cls_loss_kwargs={},
+             loc_loss_type='huber_loss', loc_loss_kwargs={},
+             loc_loss_weight=1.0, cls_loss_weight=1.0):
+        """models.py:170-311 for the loss types every shipped config uses
+        (cls 'softmax', loc 'huber_loss').  Same keys as the reference's
+        loss_dict; values are Python floats (classwise_loc_loss: list of
+        [box_len] tensors).  Device tensors in; the per-vertex arithmetic runs
+        in pgnn_loss_fwd_bwd.  Gradients: see pointgnn_amd.train.Trainer."""
+        import ctypes
+        from . import _lib
+        if isinstance(loc_loss_weight, dict):
+            loc_loss_weight = loc_loss_weight[self._mode]
+        if isinstance(cls_loss_weight, dict):
+            cls_loss_weight = cls_loss_weight[self._mode]
+        if isinstance(cls_loss_type, dict):
+            cls_loss_type = cls_loss_type[self._mode]
+        if isinstance(loc_loss_type, dict):
+            loc_loss_type = loc_loss_type[self._mode]
+        if cls_loss_type != 'softmax' or loc_loss_type != 'huber_loss':
+            raise NotImplementedError(
+                "loss types %r / %r: only 'softmax' + 'huber_loss' (all "
+                "shipped configs) have a device path"
+                % (cls_loss_type, loc_loss_type))
+        if 'classwise_loc_loss_weight' in loc_loss_kwargs:
+            raise NotImplementedError("classwise_loc_loss_weight")
+        lib = _lib.load()
+        dev = logits.device
+        k, nc = int(logits.shape[0]), int(logits.shape[1])
+        bl = int(pred_box.shape[-1])
+        lg = logits.to(torch.float32).contiguous()
+        lab = labels.to(device=dev, dtype=torch.int32).reshape(-1).contiguous()
+        pb = pred_box.to(torch.float32).contiguous()
+        gt = gt_box.to(device=dev, dtype=torch.float32).reshape(k, bl).contiguous()
+        va = valid_box.to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
+        sums = torch.zeros(4, dtype=torch.float64, device=dev)
+        _lib.check(lib.pgnn_loss_fwd_bwd(
+            _lib.ptr(lg), lg.stride(0), _lib.ptr(lab), _lib.ptr(pb), bl,
+            _lib.ptr(gt), _lib.ptr(va), k, nc, ctypes.c_float(0.0),
+            ctypes.c_float(0.0), _lib.ptr(sums), None, None,
+            _lib.stream_ptr()), "pgnn_loss_fwd_bwd")
+        s_ce, s_loc, n, nv = [float(v) for v in sums.cpu()]
+        reg = 0.0
+        if self._regularizer_type == 'l1' and self._store is not None:
+            scale = float(self._regularizer_kwargs['scale'])
+            reg = scale * float(sum(np.abs(v).sum() for name, v in
+                                    self._store.params.items()
+                                    if name.endswith('/weights')))
+        # per-class sums of the per-vertex Huber vectors (diagnostic only)
+        sel = pb[torch.arange(k, device=dev), lab.long()]
+        err = sel - gt
+        ae = err.abs()
+        quad = torch.clamp(ae, max=1.0)
+        all_loc = loc_loss_weight * (0.5 * quad * quad + (ae - quad)) * va[:, None]
+        classwise = [all_loc[lab == c].sum(dim=0) for c in range(self.num_classes)]
+        return {
+            'cls_loss': cls_loss_weight * s_ce / max(n, 1.0),
+            'loc_loss': loc_loss_weight * s_loc / nv if nv > 0 else 0.0,
+            'reg_loss': reg, 'num_endpoint': int(n), 'num_valid_endpoint': nv,
+            'classwise_loc_loss': classwise,
+        }
 
 
 def get_model(model_name):

@@ -161,6 +161,43 @@ def test_loss_kernel_matches_oracle(dev):
                                rtol=1e-4)
 
 
+def test_model_loss_api_matches_oracle(dev):
+    """models.MultiLayerFastLocalGraphModelV2.loss keeps the reference's
+    signature and loss_dict keys (models.py:170-175, 308-311)."""
+    import torch
+    from pointgnn_amd import models
+    cfg = configs.car_auto_config(0)
+    params = weights.init_params(cfg, seed=1)
+    model = models.get_model(cfg["model_name"])(
+        num_classes=4, box_encoding_len=7, mode="train",
+        **cfg["model_kwargs"]).load_state_dict(params, dev)
+    rng = np.random.default_rng(5)
+    k = 200
+    logits = rng.standard_normal((k, 4)).astype(np.float32)
+    pred = rng.standard_normal((k, 4, 7)).astype(np.float32) * 2
+    labels = rng.integers(0, 4, (k, 1)).astype(np.int32)
+    gt = rng.standard_normal((k, 1, 7)).astype(np.float32)
+    valid = (rng.random((k, 1, 1)) < 0.5).astype(np.float32)
+    d = model.loss(T(logits, dev), T(labels, dev), T(pred, dev), T(gt, dev),
+                   T(valid, dev), cls_loss_type='softmax',
+                   loc_loss_type='huber_loss', loc_loss_weight=10.0,
+                   cls_loss_weight=0.1)
+    assert set(d) == {'cls_loss', 'loc_loss', 'reg_loss', 'num_endpoint',
+                      'num_valid_endpoint', 'classwise_loc_loss'}
+    ce, loc, n, nv = to.loss_terms(cfg, torch.tensor(logits, dtype=torch.float64),
+                                   torch.tensor(pred, dtype=torch.float64),
+                                   labels, gt, valid)
+    assert abs(d['cls_loss'] - 0.1 * float(ce) / n) < 1e-5
+    assert abs(d['loc_loss'] - 10.0 * float(loc) / nv) < 1e-4
+    assert d['num_endpoint'] == k and d['num_valid_endpoint'] == nv
+    reg = 5e-7 * sum(np.abs(v).sum() for kk, v in params.items()
+                     if kk.endswith('/weights'))
+    assert abs(d['reg_loss'] - reg) < 1e-9
+    # classwise sums add up to 7 * num_valid * loc_loss
+    tot = sum(float(c.sum()) for c in d['classwise_loc_loss'])
+    assert abs(tot - 7 * nv * d['loc_loss']) < 1e-3 * max(1.0, tot)
+
+
 def _grad_errors(got, ref):
     """(max-abs error / max|ref|, Frobenius error / ||ref||)."""
     scale = np.abs(ref).max() + 1e-12
