@@ -33,6 +33,7 @@ extern int g_mlp_blocks_per_cu;
 extern int g_edge_msub;
 extern int g_pool_msub;
 extern int g_mlp_debug;
+extern int g_scatter_nt;
 
 }  // namespace pgnn
 
@@ -69,6 +70,10 @@ extern "C" int pgnn_set_tunable(const char *key, int value) {
   }
   if (!strcmp(key, "edge_msub")) {
     pgnn::g_edge_msub = value;
+    return 0;
+  }
+  if (!strcmp(key, "scatter_nt")) {
+    pgnn::g_scatter_nt = value;
     return 0;
   }
   if (!strcmp(key, "mlp_debug")) {

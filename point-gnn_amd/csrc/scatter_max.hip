@@ -14,6 +14,7 @@
 
 namespace pgnn {
 int g_scatter_rows_per_wave = 0;  // 0 = auto
+int g_scatter_nt = 1;            // non-temporal row loads
 }
 
 namespace {
@@ -24,6 +25,12 @@ template <>
 struct Vec<4> {
   typedef float4 type;
   static __device__ __forceinline__ type load(const float *p) {
+    // streamed once: non-temporal keeps the rows out of L2's way
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    const v4 v = __builtin_nontemporal_load(reinterpret_cast<const v4 *>(p));
+    return make_float4(v[0], v[1], v[2], v[3]);
+  }
+  static __device__ __forceinline__ type load_plain(const float *p) {
     return *reinterpret_cast<const float4 *>(p);
   }
   static __device__ __forceinline__ type vmax(type a, type b) {
@@ -43,7 +50,10 @@ struct Vec<4> {
 template <>
 struct Vec<1> {
   typedef float type;
-  static __device__ __forceinline__ type load(const float *p) { return *p; }
+  static __device__ __forceinline__ type load(const float *p) {
+    return __builtin_nontemporal_load(p);
+  }
+  static __device__ __forceinline__ type load_plain(const float *p) { return *p; }
   static __device__ __forceinline__ type vmax(type a, type b) {
     return fmaxf(a, b);
   }
@@ -55,7 +65,7 @@ struct Vec<1> {
 
 // VEC floats per lane per column group, NJ column groups per lane, BATCH rows
 // loaded before any is consumed (memory-level parallelism).
-template <int VEC, int NJ, int BATCH>
+template <int VEC, int NJ, int BATCH, bool NTL>
 __global__ __launch_bounds__(256) void scatter_max_kernel(
     const float *__restrict__ data, int64_t ld, const int32_t *__restrict__ seg,
     int64_t n_rows, int32_t n_colv /* columns in VEC units */,
@@ -117,7 +127,8 @@ __global__ __launch_bounds__(256) void scatter_max_kernel(
         if (row > r1 - 1) row = r1 - 1;
         const float *p = data + row * ld;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) v[k][j] = V::load(p + colv[j]);
+        for (int j = 0; j < NJ; ++j)
+          v[k][j] = NTL ? V::load(p + colv[j]) : V::load_plain(p + colv[j]);
       }
 #pragma unroll
       for (int k = 0; k < BATCH; ++k) {
@@ -166,9 +177,14 @@ int launch(const float *data, int64_t ld, const int32_t *seg, int64_t n_rows,
   int64_t cap = (int64_t)pgnn::device_cu_count() * 8;
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL((scatter_max_kernel<VEC, NJ, BATCH>), dim3((unsigned)blocks),
-                     dim3(256), 0, stream, data, ld, seg, n_rows, n_colv,
-                     num_segments, out, ldo, sorted, rpw);
+  if (pgnn::g_scatter_nt)
+    hipLaunchKernelGGL((scatter_max_kernel<VEC, NJ, BATCH, true>),
+                       dim3((unsigned)blocks), dim3(256), 0, stream, data, ld, seg,
+                       n_rows, n_colv, num_segments, out, ldo, sorted, rpw);
+  else
+    hipLaunchKernelGGL((scatter_max_kernel<VEC, NJ, BATCH, false>),
+                       dim3((unsigned)blocks), dim3(256), 0, stream, data, ld, seg,
+                       n_rows, n_colv, num_segments, out, ldo, sorted, rpw);
   PGNN_HIP(hipGetLastError());
   return 0;
 }
