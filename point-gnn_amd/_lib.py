@@ -36,6 +36,7 @@ _SIGNATURES = {
     "pgnn_last_error": (ctypes.c_char_p, []),
     "pgnn_check_device_pointer": (c_i32, [c_vp]),
     "pgnn_set_tunable": (c_i32, [ctypes.c_char_p, c_i32]),
+    "pgnn_set_debug_buffer": (c_i32, [c_vp]),
     "pgnn_scatter_max_f32": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_i32,
                                      c_vp, c_i64, c_i32, c_vp]),
     "pgnn_radius_graph_workspace_bytes": (c_sz, [c_i64, c_i64]),

@@ -33,6 +33,7 @@ extern int g_mlp_blocks_per_cu;
 extern int g_edge_msub;
 extern int g_pool_msub;
 extern int g_mlp_debug;
+extern void *g_mlp_ts;
 extern int g_scatter_nt;
 
 }  // namespace pgnn
@@ -85,6 +86,13 @@ extern "C" int pgnn_set_tunable(const char *key, int value) {
     return 0;
   }
   return pgnn::fail(PGNN_E_INVALID, "unknown tunable");
+}
+
+// Profiling hook: per-tile cycle stamps of the fused kernels are written to
+// this device buffer (int64 [grid * 32 * 4]); NULL disables.
+extern "C" int pgnn_set_debug_buffer(void *device_ptr) {
+  pgnn::g_mlp_ts = device_ptr;
+  return 0;
 }
 
 extern "C" size_t pgnn_packed_fc_floats(int32_t k_in, int32_t n_out) {

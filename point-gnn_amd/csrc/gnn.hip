@@ -18,6 +18,7 @@ namespace pgnn {
 int g_mlp_blocks_per_cu = 4;  // upper bound; LDS usually allows fewer
 int g_edge_msub = 0;          // 0 = auto, else force 16*msub-row tiles
 int g_pool_msub = 0;
+void *g_mlp_ts = nullptr;  // device buffer for per-tile timestamps (profiling)
 int g_mlp_debug = 0;  // ablation mask (benchmarks only): 1 = no gather loads,
                       // 2 = no last-layer GEMM, 4 = no epilogue
 }
@@ -152,7 +153,7 @@ template <int MSUB, int PRO>
 __global__ __launch_bounds__(256, 2) void fused_mlp_kernel(
     ChainDev chain, int64_t n_rows, RowsArgs ra, PoolArgs pa, EdgeArgs ea,
     SegArgs sa, int stage_off /* floats from tile base; < 0: in place */,
-    int dbg) {
+    int dbg, long long *ts /* optional per-tile timestamps (profiling) */) {
   constexpr int ROWS = 16 * MSUB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int *dst = reinterpret_cast<int *>(smem);
@@ -175,7 +176,20 @@ __global__ __launch_bounds__(256, 2) void fused_mlp_kernel(
     const int64_t row0 = tile_id * ROWS;
     const int rows_valid =
         (int)((n_rows - row0 < ROWS) ? (n_rows - row0) : ROWS);
+    long long *tsp = nullptr;
+    if (ts && tile_id - tile_first < 32 && threadIdx.x == 0) {
+      tsp = ts + ((int64_t)blockIdx.x * 32 + (tile_id - tile_first)) * 8;
+      tsp[0] = __builtin_readcyclecounter();
+      tsp[3] = 0;
+    }
     // ------------------------------------------------------------ prologue
+    // The co-resident workgroup is usually streaming MFMAs on the same SIMDs;
+    // measured (tools/tile_timeline.py): this short, latency-critical phase
+    // takes 9.4k cycles alone but 22k (p90 52k) next to a GEMM phase at equal
+    // priority.  Raising the wave priority here costs the partner a few
+    // hundred issue slots and gets this workgroup back to the matrix pipe
+    // sooner; priority returns to 0 before the MFMA loop.
+    if (!(dbg & 64)) __builtin_amdgcn_s_setprio(3);
     if (PRO == PRO_ROWS) {
       const int kc = 16 * chain.l[0].kq;
       for (int idx = threadIdx.x; idx < ROWS * kc; idx += 256) {
@@ -225,60 +239,123 @@ __global__ __launch_bounds__(256, 2) void fused_mlp_kernel(
         dst[ROWS + 1] =
             row0 + ROWS < n_rows ? pa.edges[2 * (row0 + ROWS) + 1] : -1;
     } else {  // PRO_EDGE
+      // Row-per-wave gather with scalar row addressing: a wave owns RPW rows;
+      // src/dst of a row are wave-uniform (readlane), so the row base lives in
+      // SGPRs and each lane only adds its fixed 16-byte column offset -- a few
+      // instructions per row instead of per-element index arithmetic (the tile
+      // timeline showed the prologue to be instruction-issue bound while the
+      // co-resident workgroup streams MFMAs).  Full 64-float4 column blocks of
+      // all RPW rows are requested first (the accumulators are not live yet, so
+      // ~160 VGPRs of loads can be in flight); a tail of <= 16 float4 per row
+      // (76 = 64 + 12 for C = 300) is fetched four rows per instruction.
+      constexpr int RPW = ROWS / 4;
       const int ldv4 = (int)(ea.ldpq >> 2);
       const v4f *__restrict__ P4 = reinterpret_cast<const v4f *>(ea.P);
       const v4f *__restrict__ Q4 = reinterpret_cast<const v4f *>(ea.Q);
-      if (threadIdx.x < ROWS) {
-        const int64_t e = row0 + threadIdx.x;
-        int s_ = 0, d_ = -1;
-        if (e < n_rows) {
-          s_ = ea.edges[2 * e];
-          d_ = ea.edges[2 * e + 1];
-        }
-        src[threadIdx.x] = s_;
-        dst[threadIdx.x + 1] = d_;
+      const int64_t ebase = row0 + wave * RPW;
+      int my_s = 0, my_d = -1;
+      if (lane < RPW && ebase + lane < n_rows) {
+        my_s = ea.edges[2 * (ebase + lane)];
+        my_d = ea.edges[2 * (ebase + lane) + 1];
       }
-      if (threadIdx.x == 64)
+      if (lane < RPW) dst[wave * RPW + lane + 1] = my_d;
+      if (threadIdx.x == 0)
         dst[0] = row0 > 0 ? ea.edges[2 * (row0 - 1) + 1] : -1;
-      if (threadIdx.x == 65)
+      if (threadIdx.x == 64)
         dst[ROWS + 1] =
             row0 + ROWS < n_rows ? ea.edges[2 * (row0 + ROWS) + 1] : -1;
-      __syncthreads();
-      // The tile is ROWS x ldv4 float4 elements; thread t takes elements
-      // t, t+256, ... so every lane is busy on every load (row-per-wave
-      // mappings leave 52 of 64 lanes idle on the tail of a 76-float4 row).
-      constexpr int GU = 4;  // elements in flight per thread
-      const int total = ROWS * ldv4;
-      for (int e0 = threadIdx.x; e0 < total; e0 += 256 * GU) {
-        v4f p[GU], q[GU];
-        int rowi[GU], c4i[GU];
-        bool ok[GU];
+      if (tsp) {
+        tsp[3] = __builtin_readcyclecounter();  // index loads issued
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        tsp[4] = __builtin_readcyclecounter();  // ... and landed
+      }
+      const bool no_loads = (dbg & 1) != 0;
+      const int nfull = ldv4 >> 6, tail = ldv4 & 63;
+      float *tbase = tile + (wave * RPW) * ld0;
+      // tail columns (<= 16 float4 per row), four rows per instruction: lanes
+      // 16*sub .. 16*sub+tail-1 serve row 4*r4+sub.  Requested first so they
+      // are in flight together with the full column blocks.
+      const bool tail4 = tail > 0 && tail <= 16;
+      const int sub = lane >> 4, tl = lane & 15;
+      const int c4t = tail4 ? 64 * nfull + (tl < tail ? tl : 0) : 0;
+      v4f pt[RPW / 4], qt[RPW / 4];
+      int ddt[RPW / 4];
 #pragma unroll
-        for (int u = 0; u < GU; ++u) {
-          int e = e0 + 256 * u;
-          if (e > total - 1) e = total - 1;  // clamp: duplicate work, no branch
-          rowi[u] = e / ldv4;
-          c4i[u] = e - rowi[u] * ldv4;
-          const int s_ = src[rowi[u]];
-          const int d_ = dst[rowi[u] + 1];
-          ok[u] = d_ >= 0 && !(dbg & 1);
-          const int dd = d_ >= 0 ? d_ : 0;
-          p[u] = P4[(int64_t)s_ * ldv4 + c4i[u]];
-          q[u] = Q4[(int64_t)dd * ldv4 + c4i[u]];
+      for (int r4 = 0; r4 < RPW / 4; ++r4) {
+        const int s_ = __shfl(my_s, 4 * r4 + sub);
+        ddt[r4] = __shfl(my_d, 4 * r4 + sub);
+        const int d_ = ddt[r4] < 0 ? 0 : ddt[r4];
+        pt[r4] = P4[(int64_t)s_ * ldv4 + c4t];
+        qt[r4] = Q4[(int64_t)d_ * ldv4 + c4t];
+      }
+      for (int fb = 0; fb < nfull; ++fb) {
+        v4f p[RPW], q[RPW];
+        const int c4 = 64 * fb + lane;
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+          const int s_ = __builtin_amdgcn_readlane(my_s, r);
+          int d_ = __builtin_amdgcn_readlane(my_d, r);
+          d_ = d_ < 0 ? 0 : d_;
+          p[r] = P4[(int64_t)s_ * ldv4 + c4];
+          q[r] = Q4[(int64_t)d_ * ldv4 + c4];
         }
+        // keep all 2*RPW loads in flight: without this fence hipcc software-
+        // pipelines the two loops at depth 1 with a vmcnt(0) per row pair,
+        // i.e. RPW serial L2 round trips (seen in the .s; 9k cycles per tile)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < GU; ++u) {
+        for (int r = 0; r < RPW; ++r) {
+          const bool ok = __builtin_amdgcn_readlane(my_d, r) >= 0 && !no_loads;
           v4f h;
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const float t = p[u][i] - q[u][i];
-            h[i] = (ok[u] && t > 0.0f) ? t : 0.0f;
+            const float t = p[r][i] - q[r][i];
+            h[i] = (ok && t > 0.0f) ? t : 0.0f;
           }
-          *reinterpret_cast<v4f *>(tile + rowi[u] * ld0 + 4 * c4i[u]) = h;
+          *reinterpret_cast<v4f *>(tbase + r * ld0 + 4 * c4) = h;
+        }
+      }
+      if (tail4) {
+        const int c4 = c4t;
+#pragma unroll
+        for (int r4 = 0; r4 < RPW / 4; ++r4) {
+          const bool ok = ddt[r4] >= 0 && !no_loads;
+          v4f h;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float t = pt[r4][i] - qt[r4][i];
+            h[i] = (ok && t > 0.0f) ? t : 0.0f;
+          }
+          if (tl < tail)
+            *reinterpret_cast<v4f *>(tbase + (4 * r4 + sub) * ld0 + 4 * c4) = h;
+        }
+      } else if (tail > 16) {
+        const int c4 = 64 * nfull + (lane < tail ? lane : 0);
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+          const int s_ = __builtin_amdgcn_readlane(my_s, r);
+          const int dr = __builtin_amdgcn_readlane(my_d, r);
+          const int d_ = dr < 0 ? 0 : dr;
+          const v4f p = P4[(int64_t)s_ * ldv4 + c4];
+          const v4f q = Q4[(int64_t)d_ * ldv4 + c4];
+          v4f h;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float t = p[i] - q[i];
+            h[i] = (dr >= 0 && !no_loads && t > 0.0f) ? t : 0.0f;
+          }
+          if (lane < tail)
+            *reinterpret_cast<v4f *>(tbase + r * ld0 + 4 * c4) = h;
         }
       }
     }
+    if (tsp) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      tsp[5] = __builtin_readcyclecounter();  // wave 0 finished its rows
+    }
     __syncthreads();
+    __builtin_amdgcn_s_setprio(0);
+    if (tsp) tsp[1] = __builtin_readcyclecounter();
     // ------------------------------------------------------------ hidden layers
     for (int li = 0; li + 1 < chain.n; ++li) {
       const LayerDev &L = chain.l[li];
@@ -331,6 +408,7 @@ __global__ __launch_bounds__(256, 2) void fused_mlp_kernel(
         // LDS-only barrier: the tile buffer may be overwritten by the next
         // prologue, but the global stores / atomics above need not drain
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (tsp) tsp[2] = __builtin_readcyclecounter();
       }
     }
   }
@@ -439,7 +517,8 @@ int launch_fused(const Plan &p, int64_t n_rows, const RowsArgs &ra,
             MSUB, PRO, lds, per_cu, nb, (int)e, (long long)grid, (long long)n_tiles);
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, stream, p.chain,
-                     n_rows, ra, pa, ea, sa, stage_off, g_mlp_debug);
+                     n_rows, ra, pa, ea, sa, stage_off, g_mlp_debug,
+                     (long long *)g_mlp_ts);
   PGNN_HIP(hipGetLastError());
   return 0;
 }
