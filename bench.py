@@ -101,11 +101,24 @@ def roofline_scatter_max(torch, edges1, n_k, width, reps=30):
         state["i"] += 1
     dur = time_kernel(run, reps, torch)
     alg = n_e * width * 4 + n_e * 4 + n_k * width * 4
+    # HBM traffic cannot be read from inside this process; it comes from the
+    # committed PMC pass of this same kernel (tools/pmc_scatter.sh) when that
+    # pass was taken on exactly this workload, else it stays null.
+    traffic, traffic_src = None, None
+    side = os.path.join(ROOT, "profiles", "r01_c_pmc_scatter_max.json")
+    if os.path.exists(side):
+        with open(side) as fh:
+            pm = json.load(fh)
+        wl = pm.get("workload", {})
+        if (wl.get("E"), wl.get("C"), wl.get("K")) == (n_e, width, n_k):
+            traffic = pm["hbm_bytes_per_launch"]
+            traffic_src = "profiles/r01_c_pmc_scatter_max.json: " + pm["method"]
     return {
+        "traffic_source": traffic_src,
         "kernel": "scatter_max_kernel (standalone, [E1,C] fp32, sorted dst)",
         "bound": "hbm", "achieved": alg / dur / 1e9, "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": alg / dur / 1e9 / HBM_PEAK_GBS,
-        "traffic": None, "algorithmic_bytes": alg,
+        "traffic": traffic, "algorithmic_bytes": alg,
         "avg_launch_us": dur * 1e6,
         "note": "duration includes the 4*K*C-byte lowest() fill memset",
     }
