@@ -1,4 +1,6 @@
-"""Pure-Python reader for TensorFlow "bundle" checkpoints (no TensorFlow).
+"""Pure-Python reader and writer for TensorFlow "bundle" checkpoints (no
+TensorFlow).  `save_checkpoint` re-encodes the reference's shipped checkpoints
+bit for bit (tests/test_host_cpu.py), so files written here restore in TF.
 
 The reference saves/restores its weights with `tf.train.Saver`
 (run.py:192-201, train.py:496,634-636).  A checkpoint `model-N` is
@@ -133,3 +135,179 @@ def load_checkpoint(ckpt_dir_or_prefix):
                             offset=off)
         out[name] = arr.reshape(shape).copy()
     return out
+
+
+# ---------------------------------------------------------------------------
+# writer (train.py:634-636 `saver.save`): same on-disk format, so a checkpoint
+# written here restores in the reference's run.py / train.py unchanged.
+# ---------------------------------------------------------------------------
+_DTYPE_ENUM = {np.dtype(np.float32): 1, np.dtype(np.float64): 2,
+               np.dtype(np.int32): 3, np.dtype(np.int64): 9}
+_BLOCK_SIZE = 262144       # tensorflow/core/lib/io/table_options.h
+_RESTART_INTERVAL = 16
+
+
+def _crc32c_table():
+    tab = []
+    for i in range(256):
+        c = i
+        for _ in range(8):
+            c = (c >> 1) ^ (0x82F63B78 if c & 1 else 0)
+        tab.append(c)
+    return tab
+
+
+_CRC_TAB = _crc32c_table()
+
+
+def crc32c(data, crc=0):
+    """CRC-32C (Castagnoli), the checksum of TF's bundle / table files."""
+    tab = _CRC_TAB
+    c = crc ^ 0xFFFFFFFF
+    for b in bytes(data):
+        c = tab[(c ^ b) & 0xFF] ^ (c >> 8)
+    return c ^ 0xFFFFFFFF
+
+
+def _mask_crc(crc):
+    """crc32c::Mask of tensorflow/core/lib/hash/crc32c.h."""
+    return (((crc >> 15) | (crc << 17)) + 0xa282ead8) & 0xFFFFFFFF
+
+
+def _put_varint(v):
+    out = bytearray()
+    while True:
+        b = v & 0x7F
+        v >>= 7
+        if v:
+            out.append(b | 0x80)
+        else:
+            out.append(b)
+            return bytes(out)
+
+
+def _entry_proto(dtype, shape, offset, size, crc_masked):
+    """BundleEntryProto; proto3 default values (offset 0, shard 0) are omitted
+    exactly like the C++ serializer does."""
+    dims = b"".join(b"\x12" + _put_varint(len(d)) + d for d in
+                    [b"\x08" + _put_varint(int(s)) for s in shape])
+    out = b"\x08" + _put_varint(_DTYPE_ENUM[np.dtype(dtype)])
+    out += b"\x12" + _put_varint(len(dims)) + dims
+    if offset:
+        out += b"\x20" + _put_varint(offset)
+    out += b"\x28" + _put_varint(size)
+    out += b"\x35" + struct.pack("<I", crc_masked)
+    return out
+
+
+class _BlockBuilder(object):
+    def __init__(self):
+        self.buf = bytearray()
+        self.restarts = [0]
+        self.counter = 0
+        self.last_key = b""
+
+    def add(self, key, value):
+        shared = 0
+        if self.counter < _RESTART_INTERVAL:
+            n = min(len(self.last_key), len(key))
+            while shared < n and self.last_key[shared] == key[shared]:
+                shared += 1
+        else:
+            self.restarts.append(len(self.buf))
+            self.counter = 0
+        self.buf += _put_varint(shared) + _put_varint(len(key) - shared) + \
+            _put_varint(len(value)) + key[shared:] + value
+        self.last_key = key
+        self.counter += 1
+
+    def size_estimate(self):
+        return len(self.buf) + 4 * len(self.restarts) + 4
+
+    def finish(self):
+        out = bytes(self.buf)
+        for r in self.restarts:
+            out += struct.pack("<I", r)
+        return out + struct.pack("<I", len(self.restarts))
+
+
+def _short_separator(a, b):
+    """BytewiseComparator::FindShortestSeparator."""
+    n = min(len(a), len(b))
+    i = 0
+    while i < n and a[i] == b[i]:
+        i += 1
+    if i < n and a[i] < 0xFF and a[i] + 1 < b[i]:
+        return a[:i] + bytes([a[i] + 1])
+    return a
+
+
+def _short_successor(a):
+    """BytewiseComparator::FindShortSuccessor."""
+    for i, c in enumerate(a):
+        if c != 0xFF:
+            return a[:i] + bytes([c + 1])
+    return a
+
+
+def save_checkpoint(ckpt_dir, variables, global_step=None, name="model"):
+    """Write `<ckpt_dir>/<name>-<global_step>.{index,data-00000-of-00001}` and
+    the `checkpoint` state file (tf.train.Saver.save with one shard).
+    variables: {TF variable name: ndarray}; when `global_step` is given it is
+    also stored as the int32 scalar `Variable`, as the reference's graph does
+    (train.py:375).  Returns the checkpoint prefix."""
+    os.makedirs(ckpt_dir, exist_ok=True)
+    items = {k: np.ascontiguousarray(v) for k, v in variables.items()}
+    if global_step is not None and "Variable" not in items:
+        items["Variable"] = np.array(global_step, dtype=np.int32)
+    base = name if global_step is None else "%s-%d" % (name, int(global_step))
+    prefix = os.path.join(ckpt_dir, base)
+    keys = sorted(items, key=lambda s: s.encode())
+    data = bytearray()
+    entries = [(b"", b"\x08\x01\x1a\x02\x08\x01")]   # BundleHeaderProto
+    for k in keys:
+        arr = items[k]
+        if arr.dtype.byteorder == '>':
+            arr = arr.astype(arr.dtype.newbyteorder('<'))
+        raw = arr.tobytes()
+        entries.append((k.encode(), _entry_proto(
+            arr.dtype, arr.shape, len(data), len(raw),
+            _mask_crc(crc32c(raw)))))
+        data += raw
+    # SSTable: data blocks, empty metaindex block, index block, footer
+    out = bytearray()
+    index = _BlockBuilder()
+
+    def write_block(contents):
+        handle = _put_varint(len(out)) + _put_varint(len(contents))
+        trailer_crc = _mask_crc(crc32c(b"\x00", crc32c(contents)))
+        out.extend(contents + b"\x00" + struct.pack("<I", trailer_crc))
+        return handle
+
+    block = _BlockBuilder()
+    pending = None      # (last key of the finished block, its handle)
+    for key, val in entries:
+        if pending is not None:
+            index.add(_short_separator(pending[0], key), pending[1])
+            pending = None
+        block.add(key, val)
+        if block.size_estimate() >= _BLOCK_SIZE:
+            pending = (block.last_key, write_block(block.finish()))
+            block = _BlockBuilder()
+    if block.buf:
+        pending = (block.last_key, write_block(block.finish()))
+    if pending is not None:
+        index.add(_short_successor(pending[0]), pending[1])
+    meta_handle = write_block(_BlockBuilder().finish())
+    index_handle = write_block(index.finish())
+    footer = meta_handle + index_handle
+    footer += b"\x00" * (40 - len(footer)) + struct.pack("<Q", _MAGIC)
+    out += footer
+    with open(prefix + ".data-00000-of-00001", "wb") as f:
+        f.write(bytes(data))
+    with open(prefix + ".index", "wb") as f:
+        f.write(bytes(out))
+    with open(os.path.join(ckpt_dir, "checkpoint"), "w") as f:
+        f.write('model_checkpoint_path: "%s"\n' % base)
+        f.write('all_model_checkpoint_paths: "%s"\n' % base)
+    return prefix

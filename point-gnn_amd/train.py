@@ -179,6 +179,26 @@ class Trainer(object):
         return {name: self._view(self.flat, name).cpu().numpy()
                 for name, _ in self.specs}
 
+    def save_checkpoint(self, train_dir):
+        """train.py:625-638: TF-bundle checkpoint `model-<global_step>` (weights
+        under their TF names + the int32 step `Variable`) that the reference's
+        run.py / train.py restore unchanged."""
+        from . import tf_bundle
+        return tf_bundle.save_checkpoint(train_dir, self.state_dict(),
+                                         global_step=self.global_step)
+
+    def load_checkpoint(self, train_dir):
+        """train.py:512-516: resume weights and step from `train_dir`."""
+        from . import tf_bundle
+        ck = tf_bundle.load_checkpoint(train_dir)
+        if 'Variable' in ck:
+            self.global_step = int(ck['Variable'])
+        for name, _ in self.specs:
+            self._view(self.flat, name).copy_(
+                torch.from_numpy(np.ascontiguousarray(ck[name], np.float32)))
+        self.repack()
+        return self
+
     def grad_dict(self):
         return {name: self._view(self.grad, name).cpu().numpy()
                 for name, _ in self.specs}

@@ -267,6 +267,34 @@ def test_sgd_step_and_loss_decrease(dev):
     assert losses[-1] < losses[0], losses
 
 
+def test_trainer_checkpoint_resume(dev, tmp_path):
+    """train.py:512-516, 625-638: save after a few steps, resume in a fresh
+    Trainer, and continue identically; the saved weights also drive inference
+    through models.load_state_dict (what run.py does)."""
+    import torch
+    from pointgnn_amd import models, tf_bundle, train
+    cfg = configs.car_auto_config(1)
+    batch = _tiny_batch(seed=8)
+    tcfg = {'initial_lr': 0.01, 'decay_step': 1000, 'decay_factor': 0.1,
+            'optimizer': 'sgd'}
+    a = train.Trainer(cfg, train_config=tcfg, seed=3, device=dev)
+    for _ in range(3):
+        a.train_step(batch)
+    a.save_checkpoint(str(tmp_path))
+    b = train.Trainer(cfg, train_config=tcfg, seed=99, device=dev)
+    b.load_checkpoint(str(tmp_path))
+    assert b.global_step == 3
+    assert torch.equal(a.flat, b.flat)
+    la, lb = a.train_step(batch), b.train_step(batch)
+    assert la['cls_loss'] == lb['cls_loss'] and la['loc_loss'] == lb['loc_loss']
+    ck = tf_bundle.load_checkpoint(str(tmp_path))
+    model = models.get_model(cfg["model_name"])(
+        num_classes=4, box_encoding_len=7, mode="test",
+        **cfg["model_kwargs"]).load_state_dict(ck, dev)
+    logits, boxes = model.predict(*batch[:4], is_training=False)
+    assert np.isfinite(logits).all() and logits.shape[1] == 4
+
+
 def test_two_frame_batch_equals_two_ranks(dev):
     """Frame merging (train.py:135-171) and the rank decomposition give the
     same global gradient: one process with a 2-frame batch == the sum of two
