@@ -12,7 +12,8 @@ import os
 import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpointgnn_hip.so")
+# PGNN_LIB selects another build of the same library (kernel A/B runs in tools/)
+LIB_PATH = os.environ.get("PGNN_LIB") or os.path.join(_HERE, "libpointgnn_hip.so")
 
 c_i32, c_i64, c_f64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_double
 c_vp, c_sz, c_u64 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint64

@@ -88,30 +88,54 @@ __device__ __forceinline__ CarryState consume_segmax(
     const int *__restrict__ dst, int col0, int ncols, const SegArgs &sa,
     float *__restrict__ carry, CarryState cs, bool keep_open) {
   constexpr int G = ROWS / 4, SWZ = (G < 16 ? G : 16) - 1;
+  static_assert(ROWS <= 64, "one lane per tile row");
   CarryState out = {-1, 0};
-  int r = 0;
-  while (r < ROWS) {
-    const int d = dst[r + 1];
-    int re = r + 1;
-    while (re < ROWS && dst[re + 1] == d) ++re;
-    if (d >= 0 && d < sa.num_segments) {
-      bool left_closed = (r > 0) || (dst[0] != d);
-      const bool merge = sa.sorted && r == 0 && cs.id == d;
-      if (merge) left_closed = cs.left_closed != 0;
-      const bool right_closed = (re < ROWS) || (dst[ROWS + 1] != d);
-      const bool defer = sa.sorted && !right_closed && keep_open;
-      const bool whole = sa.sorted && left_closed && right_closed;
-      const int g0 = r >> 2, g1 = (re - 1) >> 2;
-      for (int c = threadIdx.x; c < ncols; c += 256) {
-        const float *col = stT + c * ROWS;
-        const int sw = c & SWZ;
-        float m = kFloatLowest;
-        for (int g = g0; g <= g1; ++g) {
-          const v4f x = *reinterpret_cast<const v4f *>(col + ((g ^ sw) << 2));
+  // Runs of equal dst, found once per wave with a ballot (lane = tile row):
+  // bit r of `starts` is set where row r opens a run.  Everything derived from
+  // it (r, re, d, the closed/merge/defer flags) is wave-uniform and lives in
+  // SGPRs; the serial LDS walk this replaces cost ~64 dependent reads a tile.
+  const int lane = threadIdx.x & 63;
+  const int myd = lane < ROWS ? dst[lane + 1] : -2;
+  const int prevd = lane < ROWS ? dst[lane] : -2;
+  const unsigned long long starts =
+      __ballot(lane < ROWS && (lane == 0 || myd != prevd));
+  const int d_before = dst[0], d_after = dst[ROWS + 1];
+  // Columns outer (at most two trips for <= 320 columns), runs inner: the
+  // thread's whole column (ROWS values) is fetched into registers with all
+  // LDS reads in flight, then every run is reduced from registers; the
+  // row-group selection compiles to scalar branches around v_max chains.
+  for (int c = threadIdx.x; c < ncols; c += 256) {
+    const float *col = stT + c * ROWS;
+    const int sw = c & SWZ;
+    v4f x[G];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int row = 4 * g + i;
-            if (row >= r && row < re) m = fmaxf(m, x[i]);
+    for (int g = 0; g < G; ++g)
+      x[g] = *reinterpret_cast<const v4f *>(col + ((g ^ sw) << 2));
+    unsigned long long rem = starts;
+    while (rem) {
+      const int r = __builtin_ctzll(rem);
+      rem &= rem - 1;
+      const int re = rem ? __builtin_ctzll(rem) : ROWS;
+      const int d = __builtin_amdgcn_readlane(myd, r);
+      if (d >= 0 && d < sa.num_segments) {
+        bool left_closed = (r > 0) || (d_before != d);
+        const bool merge = sa.sorted && r == 0 && cs.id == d;
+        if (merge) left_closed = cs.left_closed != 0;
+        const bool right_closed = (re < ROWS) || (d_after != d);
+        const bool defer = sa.sorted && !right_closed && keep_open;
+        const bool whole = sa.sorted && left_closed && right_closed;
+        const int g0 = r >> 2, g1 = (re - 1) >> 2;
+        float m = kFloatLowest;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          if (g > g0 && g < g1) {
+            m = fmaxf(fmaxf(m, x[g][0]), fmaxf(x[g][1], fmaxf(x[g][2], x[g][3])));
+          } else if (g == g0 || g == g1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int row = 4 * g + i;
+              if (row >= r && row < re) m = fmaxf(m, x[g][i]);
+            }
           }
         }
         if (merge) m = fmaxf(m, carry[col0 + c]);
@@ -125,12 +149,20 @@ __device__ __forceinline__ CarryState consume_segmax(
             atomic_max_f32(o, m + 0.0f);
         }
       }
-      if (defer) {
-        out.id = d;
-        out.left_closed = left_closed ? 1 : 0;
-      }
     }
-    r = re;
+  }
+  // descriptor of the run left open at the tile's end (every thread, also
+  // those without a column)
+  {
+    const int r = 63 - __builtin_clzll(starts);  // row 0 always starts a run
+    const int d = __builtin_amdgcn_readlane(myd, r);
+    if (sa.sorted && keep_open && d >= 0 && d < sa.num_segments &&
+        d_after == d) {
+      bool left_closed = (r > 0) || (d_before != d);
+      if (r == 0 && cs.id == d) left_closed = cs.left_closed != 0;
+      out.id = d;
+      out.left_closed = left_closed ? 1 : 0;
+    }
   }
   return out;
 }
