@@ -268,6 +268,58 @@ int pgnn_sgd_step(float *params, const float *grads, const float *is_weight,
 int pgnn_l1_norm(const float *params, const float *is_weight, int64_t n,
                  double *out, void *stream);
 
+/* ---- detection post-processing (the step right after
+ * the path; run.py:264-326).  All arrays are device pointers.
+ *
+ * Box codec `classaware_all_class_box_encoding` (box_encoding.py:231-299), the
+ * method of every shipped config.  cls_labels [n_rows] int32; xyz [n_rows,3];
+ * boxes / encoded [n_rows, boxes_per_row, 7] = (x,y,z,l,h,w,yaw).  class_table
+ * [n_table,5] rows = {l, h, w, yaw_offset, active}: row `label` describes how a
+ * row with that label is (de)normalised -- the host builds it from label_map
+ * and median_object_size_map (label -> median size, yaw_offset 0; label+1 ->
+ * same size, yaw_offset pi/2).  Like the reference only box column 0 is class
+ * scaled; the xyz offset applies to every column. */
+int pgnn_box_decode_f32(const int32_t *cls_labels, const float *xyz,
+                        const float *encoded, const float *class_table,
+                        int32_t n_table, int64_t n_rows, int32_t boxes_per_row,
+                        float *decoded, void *stream);
+int pgnn_box_encode_f32(const int32_t *cls_labels, const float *xyz,
+                        const float *boxes, const float *class_table,
+                        int32_t n_table, int64_t n_rows, int32_t boxes_per_row,
+                        float *encoded, void *stream);
+/* run.py:266-290: candidates of probs [n_vertices, num_classes] = flat indices
+ * p = k*num_classes + c with 0 < c < num_classes-1 and prob > 1/num_classes,
+ * ascending (np.nonzero order).  out_label holds the merged class of
+ * run.py:287-289 (2->1, 4->3, 6->5).  *out_count (device) receives the full
+ * count even when it exceeds `capacity` (entries beyond it are dropped). */
+int pgnn_detection_candidates(const float *probs, int64_t n_vertices,
+                              int32_t num_classes, int32_t *out_index,
+                              int32_t *out_label, int64_t capacity,
+                              int32_t *out_count, void *stream);
+/* nms.py:241-300.  mode: 0 = nms_boxes_3d (plain; integer corners scaled by
+ * appr_factor, nms.py:113-115), 1 = nms_boxes_3d_uncertainty (median merge +
+ * score accumulation, what run.py uses), 2 = nms_boxes_3d_merge_only,
+ * 3 = nms_boxes_3d_score_only; the overlap is overlapped_boxes_3d_fast_poly
+ * (nms.py:64-88).  Boxes are ordered by descending score (ties: input order),
+ * cut to top_k when top_k > 0, then scanned like the reference loop.  Outputs
+ * (capacity n_boxes each) are the kept boxes in score order; attributes
+ * (nullable -> arange) ride along; *out_count (device) = number kept. */
+size_t pgnn_nms_workspace_bytes(int64_t n_boxes);
+int pgnn_nms_boxes_3d(const int32_t *class_labels, const float *boxes_3d,
+                      const float *scores, const int32_t *attributes,
+                      int64_t n_boxes, float overlapped_thres, int32_t mode,
+                      float appr_factor, int64_t top_k, void *workspace,
+                      size_t workspace_bytes, int32_t *out_labels,
+                      float *out_boxes, float *out_scores,
+                      int32_t *out_attributes, int32_t *out_count,
+                      void *stream);
+/* overlapped_boxes_3d_fast_poly(single_box, box_list) on (x,y,z,l,h,w,yaw)
+ * boxes (nms.py:64-88 after boxes_3d_to_corners :9-27); appr_factor > 0 applies
+ * the integer corner rounding of nms.py:115.  overlap [n_boxes] float64. */
+int pgnn_overlapped_boxes_3d(const float *single_box, const float *boxes_3d,
+                             int64_t n_boxes, float appr_factor,
+                             double *overlap, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

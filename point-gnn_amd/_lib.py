@@ -92,6 +92,20 @@ _SIGNATURES = {
     "pgnn_sgd_step": (c_i32, [c_vp, c_vp, c_vp, c_i64, ctypes.c_float,
                               ctypes.c_float, ctypes.c_float, c_vp]),
     "pgnn_l1_norm": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp]),
+    # detection post-processing
+    "pgnn_box_decode_f32": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i64,
+                                    c_i32, c_vp, c_vp]),
+    "pgnn_box_encode_f32": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i64,
+                                    c_i32, c_vp, c_vp]),
+    "pgnn_detection_candidates": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp,
+                                          c_i64, c_vp, c_vp]),
+    "pgnn_nms_workspace_bytes": (c_sz, [c_i64]),
+    "pgnn_nms_boxes_3d": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64,
+                                  ctypes.c_float, c_i32, ctypes.c_float, c_i64,
+                                  c_vp, c_sz, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                  c_vp]),
+    "pgnn_overlapped_boxes_3d": (c_i32, [c_vp, c_vp, c_i64, ctypes.c_float,
+                                         c_vp, c_vp]),
 }
 
 _lib = None

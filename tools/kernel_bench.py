@@ -20,7 +20,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["scatter", "edge", "frame"])
+    ap.add_argument("what", choices=["scatter", "edge", "frame", "detect"])
     ap.add_argument("--sweep", action="store_true")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--config", default="car_auto_T3")
@@ -68,6 +68,45 @@ def main():
         r = bench.roofline_edge_kernel(torch, eng, edges[1], n_k,
                                        reps=args.reps)
         print(json.dumps(r))
+    elif args.what == "detect":
+        # run.py:264-326 after the frame: decode + candidates + NMS.  Two
+        # inputs: the frame's own outputs under seeded weights (near-uniform
+        # probabilities: a stress case with thousands of candidates), and
+        # detection-like votes clustered on objects.
+        import time
+        from pointgnn_amd import nms
+        from oracle import detect_oracle as DO   # input generator only
+        logits, boxes = eng.run_frame(x, f)
+        probs = torch.softmax(logits, dim=1)
+        label_map = {'Background': 0, 'Car': 1, 'DontCare': 3}
+        xyz_k = coords[-1]
+
+        def timed(fn):
+            fn()
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(args.reps):
+                t0 = time.perf_counter()
+                out = fn()
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+            return out, 1e3 * float(np.median(ts))
+        out, ms = timed(lambda: nms.detect_boxes(probs, boxes, xyz_k,
+                                                 label_map, 0.01))
+        n_c = int(nms.select_candidates(probs)[0].numel())
+        print(json.dumps({"case": "frame outputs, seeded weights",
+                          "K": n_k, "candidates": n_c,
+                          "kept": int(out[0].numel()), "ms": ms}))
+        lab, bx, sc = DO.synthetic_detections(0, n_objects=30,
+                                              votes=(20, 120))
+        tl, tb, tsc = (torch.from_numpy(lab).to(dev),
+                       torch.from_numpy(bx).to(dev),
+                       torch.from_numpy(sc).to(dev))
+        out, ms = timed(lambda: nms.nms_boxes_3d_uncertainty(
+            tl, tb, tsc, overlapped_thres=0.01, appr_factor=100.0))
+        print(json.dumps({"case": "30 objects x 20-120 votes",
+                          "candidates": len(lab), "kept": int(out[0].numel()),
+                          "ms": ms}))
     else:
         for _ in range(args.reps):
             eng.run_frame(x, f)
