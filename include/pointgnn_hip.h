@@ -320,6 +320,25 @@ int pgnn_overlapped_boxes_3d(const float *single_box, const float *boxes_3d,
                              int64_t n_boxes, float appr_factor,
                              double *overlap, void *stream);
 
+/* ---- KITTI frame ingest (the step right before the
+ * path; dataset/kitti_dataset.py:587-609, 998-1006, 1036-1052, 666-689,
+ * 990-996 = get_cam_points_in_image[_with_rgb] without the file reads).
+ * velo_points [n,4] float32 (x,y,z,reflectance; the .bin layout) on the device;
+ * velo_to_cam_3x4 (float32) and cam_to_image_3x3 (float64 = P2[:, :3]) are
+ * HOST pointers, copied into the launch.  A point is kept when its camera-frame
+ * z > 0.1 and its projection lies strictly inside (0,width) x (0,height);
+ * kept points come out in scan order.  out_xyz [capacity,3]; out_attr
+ * [capacity,attr_dim]: attr_dim 1 = reflectance, 4 = reflectance + r,g,b
+ * sampled from image_bgr ([rows,cols,3] uint8, the cv2.imread layout; may be
+ * null -> zeros).  *out_count (device) = number kept (also beyond capacity). */
+size_t pgnn_kitti_ingest_workspace_bytes(int64_t n_points);
+int pgnn_kitti_cam_points_in_image(
+    const float *velo_points, int64_t n_points, const float *velo_to_cam_3x4,
+    const double *cam_to_image_3x3, double image_width, double image_height,
+    const uint8_t *image_bgr, int64_t image_rows, int64_t image_cols,
+    void *workspace, size_t workspace_bytes, float *out_xyz, float *out_attr,
+    int32_t attr_dim, int64_t capacity, int32_t *out_count, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,207 @@
+"""KITTI frame ingest of the reference (dataset/kitti_dataset.py) with the
+per-point work on the GPU: velodyne scan -> camera frame -> camera-image crop.
+
+`KittiDataset` keeps the reference's method names for this slice
+(`get_calib`, `get_velo_points`, `get_cam_points_in_image`,
+`get_cam_points_in_image_with_rgb`, `get_filename`); file reads and the
+calibration algebra stay on the host (a few 4x4 products per frame), the
+per-point transform / projection / crop / ordered compaction is
+`pgnn_kitti_cam_points_in_image`.  Results are `Points(xyz, attr)` with CUDA
+tensors, ready for `graph_gen` and the model.
+
+Not implemented here (raise or absent): labels, augmentation, voxel
+down-sampling (`downsample_by_voxel_size` is null in every shipped config),
+PNG decoding -- only the image SIZE is needed for the crop, read from the PNG
+header; for 'irgb' features pass a decoded BGR array.
+"""
+import os
+import struct
+from collections import namedtuple
+
+import numpy as np
+
+from . import _lib
+
+Points = namedtuple('Points', ['xyz', 'attr'])   # kitti_dataset.py:14
+
+
+def parse_calib(path_or_lines):
+    """kitti_dataset.py:483-522 `get_calib`: the dictionary of calibration
+    matrices with the reference's dtypes (P2 / R0_rect / Tr_velo_to_cam are
+    float32 as parsed; every derived matrix is float64)."""
+    if isinstance(path_or_lines, str):
+        with open(path_or_lines, 'r') as f:
+            lines = f.readlines()
+    else:
+        lines = list(path_or_lines)
+    calib = {}
+    for line in lines:
+        fields = line.split(' ')
+        name = fields[0].rstrip(':')
+        if not name.strip():
+            continue
+        calib[name] = np.array(fields[1:], dtype=np.float32)
+    p2 = calib['P2'].reshape(3, 4)
+    r0 = calib['R0_rect'].reshape(3, 3)
+    tr = calib['Tr_velo_to_cam'].reshape(3, 4)
+    calib['P2'], calib['R0_rect'], calib['Tr_velo_to_cam'] = p2, r0, tr
+    bottom = np.array([[0.0, 0.0, 0.0, 1.0]])
+    calib['velo_to_rect'] = np.concatenate([tr.astype(np.float64), bottom])
+    calib['cam_to_image'] = np.concatenate(
+        [p2[:, 0:3].astype(np.float64), np.zeros((3, 1))], axis=1)
+    # rectified -> camera-2 frame: rotation R0 and the baseline shift
+    # inv(P2[:, :3]) @ P2[:, 3], both evaluated in float32 like the reference
+    shift = np.matmul(np.linalg.inv(p2[:, 0:3]), p2[:, [3]])
+    rect_to_cam = np.concatenate([r0, shift], axis=1).astype(np.float64)
+    calib['rect_to_cam'] = np.concatenate([rect_to_cam, bottom])
+    calib['velo_to_cam'] = np.matmul(calib['rect_to_cam'],
+                                     calib['velo_to_rect'])
+    calib['cam_to_velo'] = np.linalg.inv(calib['velo_to_cam'])
+    calib['velo_to_image'] = np.matmul(calib['cam_to_image'],
+                                       calib['velo_to_cam'])
+    return calib
+
+
+def png_size(path):
+    """(height, width) from a PNG's IHDR chunk (no decoder needed)."""
+    with open(path, 'rb') as f:
+        head = f.read(24)
+    if len(head) < 24 or head[:8] != b'\x89PNG\r\n\x1a\n' or \
+            head[12:16] != b'IHDR':
+        raise ValueError("%s is not a PNG file" % path)
+    width, height = struct.unpack('>II', head[16:24])
+    return int(height), int(width)
+
+
+def cam_points_in_image(velo_data, calib, image_shape, image=None,
+                        with_rgb=False):
+    """velo_data [n,4] float32 (x,y,z,reflectance; NumPy or CUDA tensor) ->
+    Points(xyz [m,3], attr [m,1] or [m,4]) as CUDA tensors:
+    kitti_dataset.py:666-689 (`get_cam_points_in_image`) / :691-716 (`..._with_
+    rgb`) after the file reads.  image_shape = (height, width); image = decoded
+    BGR uint8 [H,W,3] (cv2.imread layout) when with_rgb."""
+    import torch
+    lib = _lib.load()
+    dev = velo_data.device if isinstance(velo_data, torch.Tensor) and \
+        velo_data.is_cuda else torch.device("cuda", 0)
+    v = torch.as_tensor(velo_data).to(device=dev, dtype=torch.float32)
+    v = v.reshape(-1, 4).contiguous()
+    n = int(v.shape[0])
+    height, width = int(image_shape[0]), int(image_shape[1])
+    # kitti_dataset.py:1002-1005: the float32 casts of the transposed blocks
+    rt = np.ascontiguousarray(calib['velo_to_cam'][:3, :4].astype(np.float32))
+    p = np.ascontiguousarray(calib['cam_to_image'][:3, :3].astype(np.float64))
+    attr_dim = 4 if with_rgb else 1
+    img_t = None
+    if with_rgb:
+        if image is None:
+            raise ValueError("with_rgb needs the decoded BGR image")
+        img_t = torch.as_tensor(image).to(device=dev, dtype=torch.uint8)
+        img_t = img_t.contiguous()
+        if img_t.dim() != 3 or img_t.shape[2] != 3:
+            raise ValueError("image must be [H, W, 3] uint8 (BGR)")
+    out_xyz = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    out_attr = torch.empty((n, attr_dim), dtype=torch.float32, device=dev)
+    count = torch.zeros((1,), dtype=torch.int32, device=dev)
+    ws_bytes = int(lib.pgnn_kitti_ingest_workspace_bytes(n))
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.pgnn_kitti_cam_points_in_image(
+            _lib.ptr(v), n, rt.ctypes.data, p.ctypes.data, float(width),
+            float(height), _lib.ptr(img_t) if img_t is not None else None,
+            int(img_t.shape[0]) if img_t is not None else 0,
+            int(img_t.shape[1]) if img_t is not None else 0,
+            _lib.ptr(ws), ws_bytes, _lib.ptr(out_xyz), _lib.ptr(out_attr),
+            attr_dim, n, _lib.ptr(count), _lib.stream_ptr()),
+            "pgnn_kitti_cam_points_in_image")
+        m = int(count.item())
+    return Points(xyz=out_xyz[:m], attr=out_attr[:m])
+
+
+class KittiDataset(object):
+    """The inference-side slice of kitti_dataset.py:187-216: an index of
+    frames under `image_dir` / `point_dir` / `calib_dir` (KITTI object layout:
+    <name>.png, <name>.bin, <name>.txt)."""
+
+    def __init__(self, image_dir, point_dir, calib_dir, label_dir=None,
+                 index_filename=None, is_training=False, is_raw=False,
+                 difficulty=-100, num_classes=8):
+        if is_training or is_raw:
+            raise NotImplementedError(
+                "labels / raw-sequence layouts are outside the ingest slice")
+        self._image_dir = image_dir
+        self._point_dir = point_dir
+        self._calib_dir = calib_dir
+        self._label_dir = label_dir
+        if index_filename:
+            with open(index_filename, 'r') as f:
+                self._file_list = [l.rstrip('\n') for l in f if l.strip()]
+        else:
+            self._file_list = sorted(
+                f[:-4] for f in os.listdir(point_dir) if f.endswith('.bin'))
+        self.num_classes = num_classes
+        self.difficulty = difficulty
+
+    @property
+    def num_files(self):
+        return len(self._file_list)
+
+    def get_filename(self, frame_idx):
+        return self._file_list[frame_idx]
+
+    def get_calib(self, frame_idx):
+        return parse_calib(os.path.join(
+            self._calib_dir, self._file_list[frame_idx]) + '.txt')
+
+    def get_velo_points(self, frame_idx, xyz_range=None):
+        """kitti_dataset.py:587-609 -> host Points (the crop runs later)."""
+        data = np.fromfile(os.path.join(
+            self._point_dir, self._file_list[frame_idx]) + '.bin',
+            dtype=np.float32).reshape(-1, 4)
+        if xyz_range is not None:
+            m = np.ones(len(data), bool)
+            for axis, (lo, hi) in enumerate(xyz_range):
+                m &= (data[:, axis] > lo) & (data[:, axis] < hi)
+            data = data[m]
+        return Points(xyz=data[:, :3], attr=data[:, [3]])
+
+    def _image_shape(self, frame_idx):
+        return png_size(os.path.join(
+            self._image_dir, self._file_list[frame_idx]) + '.png')
+
+    def get_cam_points_in_image(self, frame_idx, downsample_voxel_size=None,
+                                calib=None, xyz_range=None):
+        if downsample_voxel_size is not None:
+            raise NotImplementedError(
+                "downsample_by_voxel_size is null in every shipped config")
+        if calib is None:
+            calib = self.get_calib(frame_idx)
+        pts = self.get_velo_points(frame_idx, xyz_range=xyz_range)
+        velo = np.concatenate([pts.xyz, pts.attr], axis=1)
+        return cam_points_in_image(velo, calib, self._image_shape(frame_idx))
+
+    def get_cam_points_in_image_with_rgb(self, frame_idx,
+                                         downsample_voxel_size=None,
+                                         calib=None, xyz_range=None,
+                                         image=None):
+        """With `image` (decoded BGR array) the attributes are
+        [reflectance, r, g, b]; without one (PNG decoding is not part of this
+        package) the colour channels are zero -- enough for the 'i' / 'i000' /
+        '0' input features of the shipped configs (run.py:226-241)."""
+        if downsample_voxel_size is not None:
+            raise NotImplementedError(
+                "downsample_by_voxel_size is null in every shipped config")
+        if calib is None:
+            calib = self.get_calib(frame_idx)
+        pts = self.get_velo_points(frame_idx, xyz_range=xyz_range)
+        velo = np.concatenate([pts.xyz, pts.attr], axis=1)
+        shape = image.shape[:2] if image is not None \
+            else self._image_shape(frame_idx)
+        if image is None:
+            import torch
+            p = cam_points_in_image(velo, calib, shape)
+            zeros = torch.zeros((p.attr.shape[0], 3), dtype=torch.float32,
+                                device=p.attr.device)
+            return Points(xyz=p.xyz, attr=torch.cat([p.attr, zeros], dim=1))
+        return cam_points_in_image(velo, calib, shape, image=image,
+                                   with_rgb=True)
