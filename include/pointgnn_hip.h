@@ -331,6 +331,30 @@ int pgnn_overlapped_boxes_3d(const float *single_box, const float *boxes_3d,
  * [capacity,attr_dim]: attr_dim 1 = reflectance, 4 = reflectance + r,g,b
  * sampled from image_bgr ([rows,cols,3] uint8, the cv2.imread layout; may be
  * null -> zeros).  *out_count (device) = number kept (also beyond capacity). */
+/* ---- training targets (dataset/kitti_dataset.py
+ * :143-162 sel_xyz_in_box3d, :1132-1284 assign_classaware_*_label_to_points;
+ * train.py:100-130).  label_records [n_records,24] float64 on the device, one
+ * row per ground-truth box in file order: normals[9] (rows wx,wy,wz), lower[3],
+ * upper[3] (box3d_to_normals, :118-141, evaluated on the host), action
+ * (0 = skip, 1 = object: class + box + valid 1, 2 = class only: valid 0),
+ * class value, box[7] = (x3d,y3d,z3d,length,height,width,yaw wrapped into
+ * (-pi/4, 3pi/4]).  A vertex strictly inside several boxes keeps what the
+ * last one wrote, like the reference's slice assignments.  Outputs (each
+ * nullable): cls_labels [n] int32 (0 = background), boxes_3d [n,7] float64,
+ * valid_boxes [n] float32, owner [n] int32 = index of the last box containing
+ * the vertex or -1 (with one action-1 record: the sel_xyz_in_box3d mask). */
+int pgnn_assign_box_labels(const float *xyz, int64_t n_points,
+                           const double *label_records, int32_t n_records,
+                           int32_t *cls_labels, double *boxes_3d,
+                           float *valid_boxes, int32_t *owner, void *stream);
+/* pgnn_box_encode_f32 evaluated in float64 on float64 boxes and a float64
+ * class table, rounded to float32 once -- what train.py:120-130 computes
+ * (`box_encoding_fn(cls_labels, xyz, boxes_3d_f64, label_map).astype(f32)`). */
+int pgnn_box_encode_f64(const int32_t *cls_labels, const float *xyz,
+                        const double *boxes, const double *class_table,
+                        int32_t n_table, int64_t n_rows, int32_t boxes_per_row,
+                        float *encoded, void *stream);
+
 size_t pgnn_kitti_ingest_workspace_bytes(int64_t n_points);
 int pgnn_kitti_cam_points_in_image(
     const float *velo_points, int64_t n_points, const float *velo_to_cam_3x4,

@@ -289,3 +289,50 @@ def synthetic_detections(seed, n_objects=12, votes=(3, 40), noise_boxes=30,
     assert len(np.unique(scores)) == len(scores)
     perm = rng.permutation(len(boxes))
     return labels[perm], boxes[perm], scores[perm]
+
+
+# ---------------------------------------------------------------------------
+# run.py:360-412: NMS output -> KITTI label tuples
+CLASS_NAMES = {
+    'Car': ['Background', 'Car', 'Car', 'DontCare'],
+    'Pedestrian_and_Cyclist': ['Background', 'Pedestrian', 'Pedestrian',
+                               'Cyclist', 'Cyclist', 'DontCare'],
+}
+
+
+def kitti_labels(class_labels, boxes_3d, probs, cam_to_image, label_method,
+                 candidate_xyz, use_box_score=True):
+    """Restates run.py:360-412 with the helpers above and
+    oracle.labels_oracle (box normals / inside test, run.py:88-99 occlusion).
+    """
+    from oracle import labels_oracle as LO
+    out = []
+    corners = boxes_3d_to_corners(boxes_3d)
+    for i in range(len(boxes_3d)):
+        homo = np.hstack([corners[i], np.ones((8, 1))])
+        img = homo @ cam_to_image.T
+        xy = (img / img[:, 2:3])[:, :2]
+        lo, hi = xy.min(axis=0), xy.max(axis=0)
+        cl = np.maximum(lo, 0.0)
+        ch = np.minimum(hi, [1242.0, 375.0])
+        trunc = 1.0 - (ch[1] - cl[1]) * (ch[0] - cl[0]) / (
+            (hi[1] - lo[1]) * (hi[0] - lo[0]))
+        if trunc > 0.4:
+            continue
+        x, y, z, l, h, w, yaw = boxes_3d[i]
+        score = probs[i]
+        if use_box_score:
+            lab = {"x3d": x, "y3d": y, "z3d": z, "yaw": yaw, "height": h,
+                   "width": w, "length": l}
+            inside = candidate_xyz[LO.sel_xyz_in_box3d(lab, candidate_xyz)]
+            occ = 0
+            if len(inside):
+                n, lower, upper = LO.box_normals(lab)
+                p = inside @ n.T
+                occ = np.prod((p.max(axis=0) - p.min(axis=0)) /
+                              (upper - lower))
+            score = (1 + occ) * score
+        out.append((CLASS_NAMES[label_method][int(class_labels[i])], -1, -1,
+                    0, cl[0], cl[1], ch[0], ch[1], h, w, l, x, y, z, yaw,
+                    score))
+    return out

@@ -106,6 +106,11 @@ _SIGNATURES = {
                                   c_vp]),
     "pgnn_overlapped_boxes_3d": (c_i32, [c_vp, c_vp, c_i64, ctypes.c_float,
                                          c_vp, c_vp]),
+    # training targets
+    "pgnn_assign_box_labels": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_vp, c_vp,
+                                       c_vp, c_vp, c_vp]),
+    "pgnn_box_encode_f64": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i64,
+                                    c_i32, c_vp, c_vp]),
     # KITTI frame ingest
     "pgnn_kitti_ingest_workspace_bytes": (c_sz, [c_i64]),
     "pgnn_kitti_cam_points_in_image": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_f64,

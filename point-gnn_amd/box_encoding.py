@@ -29,8 +29,8 @@ median_object_size_map = {
 }
 
 
-def class_table(label_map):
-    """[n,5] float32 rows {l, h, w, yaw_offset, active} indexed by label value
+def class_table(label_map, dtype=np.float32):
+    """[n,5] rows {l, h, w, yaw_offset, active} indexed by label value
     (box_encoding.py:239-262,268-291: label -> horizontal anchor, label+1 ->
     the same size turned by pi/2).  Later label_map entries overwrite earlier
     ones like the reference's loop does."""
@@ -42,7 +42,7 @@ def class_table(label_map):
         rows[int(label)] = (l, h, w, 0.0)
         rows[int(label) + 1] = (l, h, w, 0.5 * math.pi)
     n = (max(rows) + 1) if rows else 0
-    table = np.zeros((n, 5), np.float32)
+    table = np.zeros((n, 5), dtype)
     for label, (l, h, w, yaw) in rows.items():
         table[label] = (l, h, w, yaw, 1.0)
     return table
@@ -61,6 +61,24 @@ def _run(entry, cls_labels, points_xyz, boxes, label_map):
         return torch.as_tensor(np.asarray(x) if not isinstance(
             x, torch.Tensor) else x).to(device=dev, dtype=dtype).contiguous()
 
+    # float64 ground-truth boxes (kitti_dataset.py:1199 np.zeros default) are
+    # encoded in float64 and rounded once, like train.py:120-130
+    wide = entry == "pgnn_box_encode_f32" and (
+        (as_numpy and np.asarray(boxes).dtype == np.float64) or
+        (not as_numpy and boxes.dtype == torch.float64))
+    if wide:
+        b = to(boxes, torch.float64)
+        rows, per_row = int(b.shape[0]), int(b.shape[1])
+        lab = to(cls_labels, torch.int32).reshape(-1)
+        xyz = to(points_xyz, torch.float32)
+        table = torch.from_numpy(class_table(label_map, np.float64)).to(dev)
+        out = torch.empty(tuple(b.shape), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.pgnn_box_encode_f64(
+                _lib.ptr(lab), _lib.ptr(xyz), _lib.ptr(b), _lib.ptr(table),
+                int(table.shape[0]), rows, per_row, _lib.ptr(out),
+                _lib.stream_ptr()), "pgnn_box_encode_f64")
+        return out.cpu().numpy() if as_numpy else out
     b = to(boxes, torch.float32)
     if b.dim() != 3 or b.shape[2] != 7:
         raise ValueError("boxes must be [R, B, 7]")

@@ -126,9 +126,11 @@ class KittiDataset(object):
     def __init__(self, image_dir, point_dir, calib_dir, label_dir=None,
                  index_filename=None, is_training=False, is_raw=False,
                  difficulty=-100, num_classes=8):
-        if is_training or is_raw:
+        if is_raw:
             raise NotImplementedError(
-                "labels / raw-sequence layouts are outside the ingest slice")
+                "the raw-sequence layout is outside the ingest slice")
+        if is_training and not label_dir:
+            raise ValueError("is_training needs label_dir")
         self._image_dir = image_dir
         self._point_dir = point_dir
         self._calib_dir = calib_dir
@@ -205,3 +207,194 @@ class KittiDataset(object):
             return Points(xyz=p.xyz, attr=torch.cat([p.attr, zeros], dim=1))
         return cam_points_in_image(velo, calib, shape, image=image,
                                    with_rgb=True)
+
+    # ---- labels and training targets (kitti_dataset.py:703-751, 1132-1284)
+    def get_label(self, frame_idx, no_orientation=False):
+        """kitti_dataset.py:703-751: list of label dictionaries of a frame."""
+        return read_label_file(os.path.join(
+            self._label_dir, self._file_list[frame_idx]) + '.txt',
+            self.difficulty)
+
+    def sel_xyz_in_box3d(self, label, xyz, expend_factor=(1.0, 1.0, 1.0)):
+        return sel_xyz_in_box3d(label, xyz, expend_factor)
+
+    def box3d_to_cam_points(self, label, expend_factor=(1.0, 1.0, 1.0)):
+        return box3d_to_cam_points(label, expend_factor)
+
+    def box3d_to_normals(self, label, expend_factor=(1.0, 1.0, 1.0)):
+        return box3d_to_normals(label, expend_factor)
+
+    def assign_classaware_label_to_points(self, labels, xyz, expend_factor):
+        """kitti_dataset.py:1132-1182 (label_method 'yaw', 8 classes)."""
+        assert self.num_classes == 8
+        return assign_label_to_points(labels, xyz, expend_factor, {
+            'Background': 0, 'Car': 1, 'Pedestrian': 3, 'Cyclist': 5,
+            'DontCare': 7})
+
+    def assign_classaware_car_label_to_points(self, labels, xyz,
+                                              expend_factor):
+        """kitti_dataset.py:1184-1232 (label_method 'Car', 4 classes)."""
+        assert self.num_classes == 4
+        return assign_label_to_points(labels, xyz, expend_factor, {
+            'Background': 0, 'Car': 1, 'DontCare': 3})
+
+    def assign_classaware_ped_and_cyc_label_to_points(self, labels, xyz,
+                                                      expend_factor):
+        """kitti_dataset.py:1234-1284 ('Pedestrian_and_Cyclist', 6)."""
+        assert self.num_classes == 6
+        return assign_label_to_points(labels, xyz, expend_factor, {
+            'Background': 0, 'Pedestrian': 1, 'Cyclist': 3, 'DontCare': 5})
+
+
+_LABEL_FIELDS = (('truncation', float), ('occlusion', int), ('alpha', float),
+                 ('xmin', float), ('ymin', float), ('xmax', float),
+                 ('ymax', float), ('height', float), ('width', float),
+                 ('length', float), ('x3d', float), ('y3d', float),
+                 ('z3d', float), ('yaw', float))
+
+
+def read_label_file(path, difficulty=-100):
+    """kitti_dataset.py:703-751: KITTI label txt -> list of dicts, filtered by
+    `difficulty` (0/1/2 = easy/moderate/hard limits; < 0 keeps everything)."""
+    min_height = (40, 25, 25)
+    max_occlusion = (0, 1, 2)
+    max_truncation = (0.15, 0.3, 0.5)
+    labels = []
+    with open(path, 'r') as f:
+        for line in f:
+            fields = line.strip().split(' ')
+            if fields == ['']:
+                continue
+            label = {'name': fields[0]}
+            for (key, conv), text in zip(_LABEL_FIELDS, fields[1:15]):
+                label[key] = conv(text)
+            if len(fields) > 15:
+                label['score'] = float(fields[15])
+            if difficulty > -1:
+                if label['truncation'] > max_truncation[difficulty] or \
+                        label['occlusion'] > max_occlusion[difficulty] or \
+                        label['ymax'] - label['ymin'] < min_height[difficulty]:
+                    continue
+            labels.append(label)
+    return labels
+
+
+def box3d_to_cam_points(label, expend_factor=(1.0, 1.0, 1.0)):
+    """kitti_dataset.py:85-116: the 8 corners [8,3] float64 of a label box in
+    camera coordinates (y down: the box bottom is at y3d), optionally
+    expanded: height by expend_factor[0] (half above, half below), width and
+    length by [1] and [2].  Returns Points(xyz, None)."""
+    yaw = label['yaw']
+    c, s = np.cos(yaw), np.sin(yaw)
+    h = label['height']
+    dh = h * (expend_factor[0] - 1)
+    hw = label['width'] * expend_factor[1] / 2
+    hl = label['length'] * expend_factor[2] / 2
+    top, bottom = dh / 2, -h - dh / 2
+    local = np.array([[hl, top, hw], [hl, top, -hw], [-hl, top, -hw],
+                      [-hl, top, hw], [hl, bottom, hw], [hl, bottom, -hw],
+                      [-hl, bottom, -hw], [-hl, bottom, hw]])
+    rot = np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]])
+    xyz = local.dot(rot.T) + np.array([label['x3d'], label['y3d'],
+                                       label['z3d']])
+    return Points(xyz=xyz, attr=None)
+
+
+def box3d_to_normals(label, expend_factor=(1.0, 1.0, 1.0)):
+    """kitti_dataset.py:118-141: edge directions of the box (rows wx, wy, wz)
+    and the [lower, upper] bounds of a point's projections on them."""
+    p = box3d_to_cam_points(label, expend_factor).xyz
+    normals, lower, upper = [], [], []
+    for far in (4, 1, 3):              # corner 0 against corners 4, 1, 3
+        w = p[[0], :] - p[[far], :]
+        normals.append(w)
+        lower.append(np.matmul(w, p[far, :]))
+        upper.append(np.matmul(w, p[0, :]))
+    return (np.concatenate(normals, axis=0), np.concatenate(lower),
+            np.concatenate(upper))
+
+
+def _label_records(labels, expend_factor, label_map):
+    """Host half of assign_*_label_to_points: one 24-double record per label
+    (layout in include/pointgnn_hip.h)."""
+    default = label_map['DontCare']
+    rec = np.zeros((len(labels), 24), np.float64)
+    for i, label in enumerate(labels):
+        name = label['name']
+        obj_cls = label_map.get(name, default)
+        if 1 <= obj_cls <= default - 1:
+            yaw = label['yaw']
+            while yaw < -0.25 * np.pi:
+                yaw += np.pi
+            while yaw > 0.75 * np.pi:
+                yaw -= np.pi
+            action = 1.0
+            cls = obj_cls if yaw < 0.25 * np.pi else obj_cls + 1
+            box = (label['x3d'], label['y3d'], label['z3d'], label['length'],
+                   label['height'], label['width'], yaw)
+        elif name != 'DontCare':
+            action, cls, box = 2.0, obj_cls, (0.0,) * 7
+        else:
+            continue                      # record stays action 0 (skipped)
+        normals, lower, upper = box3d_to_normals(label, expend_factor)
+        rec[i, 0:9] = normals.reshape(-1)
+        rec[i, 9:12] = lower
+        rec[i, 12:15] = upper
+        rec[i, 15] = action
+        rec[i, 16] = cls
+        rec[i, 17:24] = box
+    return rec
+
+
+def _assign(xyz, rec, want_boxes=True):
+    import torch
+    lib = _lib.load()
+    as_numpy = not isinstance(xyz, torch.Tensor)
+    dev = xyz.device if not as_numpy and xyz.is_cuda else \
+        torch.device("cuda", 0)
+    p = torch.as_tensor(xyz).to(device=dev, dtype=torch.float32).contiguous()
+    n = int(p.shape[0])
+    r = torch.from_numpy(np.ascontiguousarray(rec)).to(dev)
+    cls = torch.empty((n,), dtype=torch.int32, device=dev)
+    boxes = torch.empty((n, 7), dtype=torch.float64, device=dev) \
+        if want_boxes else None
+    valid = torch.empty((n,), dtype=torch.float32, device=dev)
+    owner = torch.empty((n,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.pgnn_assign_box_labels(
+            _lib.ptr(p), n, _lib.ptr(r), int(r.shape[0]), _lib.ptr(cls),
+            _lib.ptr(boxes) if boxes is not None else None, _lib.ptr(valid),
+            _lib.ptr(owner), _lib.stream_ptr()), "pgnn_assign_box_labels")
+    return as_numpy, cls, boxes, valid, owner
+
+
+def sel_xyz_in_box3d(label, xyz, expend_factor=(1.0, 1.0, 1.0)):
+    """kitti_dataset.py:143-162: bool mask of the points strictly inside the
+    (expanded) box.  NumPy in -> NumPy out, CUDA tensor in -> CUDA tensor."""
+    rec = np.zeros((1, 24), np.float64)
+    normals, lower, upper = box3d_to_normals(label, expend_factor)
+    rec[0, 0:9], rec[0, 9:12], rec[0, 12:15] = normals.reshape(-1), lower, upper
+    rec[0, 15] = 2.0
+    as_numpy, _, _, _, owner = _assign(xyz, rec, want_boxes=False)
+    mask = owner >= 0
+    return mask.cpu().numpy() if as_numpy else mask
+
+
+def assign_label_to_points(labels, xyz, expend_factor, label_map):
+    """The shared body of kitti_dataset.py:1132-1284 -> (cls_labels [K,1],
+    boxes_3d [K,1,7] float64, valid_boxes [K,1,1] float32, label_map).
+    Class values: an object of class c gets c (|yaw| "horizontal") or c+1
+    (vertical, yaw wrapped into (-pi/4, 3pi/4]); names outside the map get the
+    DontCare value with valid 0; 'DontCare' boxes are ignored."""
+    xyz_n = xyz.shape[0]
+    assert xyz_n > 0, "No point No prediction"
+    assert xyz.shape[1] == 3
+    rec = _label_records(labels, expend_factor, label_map)
+    as_numpy, cls, boxes, valid, _ = _assign(xyz, rec)
+    cls = cls.reshape(-1, 1)
+    boxes = boxes.reshape(-1, 1, 7)
+    valid = valid.reshape(-1, 1, 1)
+    if as_numpy:
+        return (cls.cpu().numpy().astype(np.int64), boxes.cpu().numpy(),
+                valid.cpu().numpy(), label_map)
+    return cls, boxes, valid, label_map

@@ -116,6 +116,73 @@ def main():
     out["geom_overlap_row0"] = nms.overlapped_boxes_3d_fast_poly(
         corners[0], corners[1:])
     np.savez_compressed(os.path.join(HERE, "detect_nms.npz"), **out)
+    make_output_fixture(nms)
+
+
+def make_output_fixture(nms):
+    """run.py:360-412 (NMS output -> KITTI label tuples) composed from the
+    reference's own functions in run.py's order: nms.boxes_3d_to_corners,
+    KittiDataset.cam_points_to_image / sel_xyz_in_box3d / box3d_to_normals;
+    run.py itself needs TensorFlow and cannot be imported, so the few lines
+    between those calls (clipping, truncation test, `occlusion`, run.py:88-99)
+    are restated here."""
+    from oracle import ingest_oracle as IO
+    for name in ("open3d",):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.path.insert(0, REF)
+    try:
+        from dataset import kitti_dataset as kd
+    finally:
+        sys.path.remove(REF)
+    ds = object.__new__(kd.KittiDataset)
+    calib = IO.get_calib(IO.CALIB_LINES)
+    labels, boxes, scores = DO.synthetic_detections(
+        5, n_objects=14, half_width=14.0, depth=(4.0, 45.0))
+    rng = np.random.default_rng(5)
+    cand_xyz = (boxes[:, :3] + rng.normal(0, 0.6, (len(boxes), 3))
+                ).astype(np.float32)
+    cl, bx, sc, at = nms.nms_boxes_3d_uncertainty(
+        labels.copy(), boxes.copy(), scores.copy(),
+        overlapped_fn=nms.overlapped_boxes_3d_fast_poly,
+        overlapped_thres=0.01, appr_factor=100.0, top_k=-1,
+        attributes=np.arange(len(labels)))
+    names = ['Background', 'Car', 'Car', 'DontCare']
+    corners_all = nms.boxes_3d_to_corners(bx)
+    rows, kept = [], []
+    for i in range(len(bx)):
+        img = ds.cam_points_to_image(
+            kd.Points(xyz=corners_all[i], attr=None), calib)
+        xy = img.xyz[:, :2]
+        xmin, ymin = np.amin(xy, axis=0)
+        xmax, ymax = np.amax(xy, axis=0)
+        cxmin, cymin = max(xmin, 0.0), max(ymin, 0.0)
+        cxmax, cymax = min(xmax, 1242.0), min(ymax, 375.0)
+        trunc = 1.0 - (cymax - cymin) * (cxmax - cxmin) / (
+            (ymax - ymin) * (xmax - xmin))
+        if trunc > 0.4:
+            continue
+        x3d, y3d, z3d, l, h, w, yaw = bx[i]
+        tmp = {"x3d": x3d, "y3d": y3d, "z3d": z3d, "yaw": yaw, "height": h,
+               "width": w, "length": l}
+        inside = ds.sel_xyz_in_box3d(tmp, cand_xyz)
+        pts = cand_xyz[inside]
+        occ = 0
+        if pts.shape[0]:
+            normals, lower, upper = ds.box3d_to_normals(tmp)
+            proj = np.matmul(pts, np.transpose(normals))
+            occ = 1.0
+            for k in range(3):
+                occ *= (np.max(proj[:, k]) - np.min(proj[:, k])) / (
+                    upper[k] - lower[k])
+        rows.append([cxmin, cymin, cxmax, cymax, h, w, l, x3d, y3d, z3d, yaw,
+                     (1 + occ) * sc[i], sc[i]])
+        kept.append(i)
+    print("kitti output:", len(bx), "boxes ->", len(rows), "lines")
+    np.savez_compressed(
+        os.path.join(HERE, "detect_output.npz"),
+        labels=cl, boxes=bx, scores=sc, cand_xyz=cand_xyz,
+        kept=np.array(kept), rows=np.array(rows, np.float64),
+        names=np.array([names[int(cl[i])] for i in kept]))
 
 
 if __name__ == "__main__":

@@ -125,3 +125,18 @@ def test_select_candidates_rule():
     # not > 1/4
     assert idx.tolist() == [1, 2, 10]
     assert lab.tolist() == [1, 1, 1]
+
+
+def test_kitti_label_tuples_oracle_equals_reference_composition():
+    """run.py:360-412 restated (oracle) vs the fixture composed from the
+    reference's own functions."""
+    from oracle import ingest_oracle as IO
+    fix = np.load(os.path.join(GOLD, "detect_output.npz"))
+    calib = IO.get_calib(IO.CALIB_LINES)
+    rows = DO.kitti_labels(fix["labels"], fix["boxes"], fix["scores"],
+                           calib['cam_to_image'], 'Car', fix["cand_xyz"])
+    assert len(rows) == len(fix["rows"]) < len(fix["boxes"])
+    assert [r[0] for r in rows] == list(fix["names"])
+    got = np.array([r[4:] for r in rows], np.float64)
+    np.testing.assert_allclose(got, fix["rows"][:, :12], rtol=1e-12)
+    assert np.any(got[:, 11] > fix["rows"][:, 12] * 1.0001)   # rescored

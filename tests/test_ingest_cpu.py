@@ -97,4 +97,6 @@ def test_png_size_and_dataset_index(tmp_path):
     assert np.array_equal(ds.get_calib(0)["P2"],
                           IO.get_calib(IO.CALIB_LINES)["P2"])
     with pytest.raises(NotImplementedError):
+        KD.KittiDataset(str(img), str(pts), str(cal), is_raw=True)
+    with pytest.raises(ValueError):
         KD.KittiDataset(str(img), str(pts), str(cal), is_training=True)
