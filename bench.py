@@ -411,6 +411,27 @@ def main():
         n_k = int(coords[1].shape[0])
         n_e0, n_e1 = int(edges[0].shape[0]), int(edges[1].shape[0])
         frames = engine.time_dict['frames']
+        # run.py's last two phases ("decode box", "nms", run.py:264-326) on
+        # this frame's outputs -- reported beside the metric, not part of it
+        # (the metric excludes NMS)
+        from pointgnn_amd import kitti_output, nms as pg_nms
+        logits, box_enc = engine.run_frame(x, f)
+        probs = torch.softmax(logits, dim=1)
+        lmap = kitti_output.LABEL_MAPS[cfg.get('label_method', 'Car')]
+        post_ms = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            tp = time.perf_counter()
+            det = pg_nms.detect_boxes(probs, box_enc, coords[-1], lmap,
+                                      cfg.get('nms_overlapped_thres', 0.01))
+            torch.cuda.synchronize()
+            post_ms.append((time.perf_counter() - tp) * 1e3)
+        post = {"ms": float(np.median(post_ms[1:])),
+                "candidates": int(pg_nms.select_candidates(probs)[0].numel()),
+                "kept": int(det[0].numel()),
+                "note": "seeded weights give near-uniform class "
+                        "probabilities: thousands of candidates, a stress "
+                        "case for the NMS"}
         total_flops = algorithmic_flops_per_frame(cfg, n_k, n_e0, n_e1)
         fps = world * args.steps / elapsed
         res = {
@@ -437,7 +458,9 @@ def main():
                 "phase_ms": {
                     "gen graph": engine.time_dict['gen graph'] / frames * 1e3,
                     "gnn inference":
-                        engine.time_dict['gnn inference'] / frames * 1e3},
+                        engine.time_dict['gnn inference'] / frames * 1e3,
+                    "decode box + nms": post["ms"]},
+                "postprocess": post,
             },
         }
         if not args.no_roofline:

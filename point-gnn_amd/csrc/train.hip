@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void weight_grad_kernel(
 
 __global__ void weight_grad_reduce_kernel(const float *__restrict__ partial,
                                           int slices, int64_t kin_p, int nout_p,
-                                          int k_in, int n_out,
+                                          int k_in, int n_out, int64_t ld_dw,
                                           float *__restrict__ dW,
                                           float *__restrict__ db, int accumulate) {
   const int64_t total = (int64_t)(k_in + 1) * n_out;
@@ -269,7 +269,7 @@ __global__ void weight_grad_reduce_kernel(const float *__restrict__ partial,
     for (int sl = 0; sl < slices; ++sl)
       s += partial[((int64_t)sl * kin_p + i) * nout_p + j];
     if (i < k_in) {
-      float *o = dW + i * n_out + j;
+      float *o = dW + i * ld_dw + j;
       *o = accumulate ? *o + s : s;
     } else if (db) {
       db[j] = accumulate ? db[j] + s : s;
@@ -520,37 +520,44 @@ extern "C" int pgnn_weight_grad_f32(const float *X, int64_t ld_x, int32_t k_in,
   hipStream_t stream = (hipStream_t)stream_;
   PGNN_REQUIRE(k_in > 0 && n_out > 0 && n_rows >= 0 && dW, PGNN_E_INVALID,
                "weight_grad: bad argument");
-  PGNN_REQUIRE(n_out <= 320, PGNN_E_UNSUPPORTED, "weight_grad: n_out > 320");
   PGNN_REQUIRE(workspace && workspace_bytes >= pgnn_weight_grad_workspace_bytes(
                                                    k_in, n_out, n_rows),
                PGNN_E_WORKSPACE, "weight_grad: workspace too small");
   PGNN_REQUIRE(n_rows == 0 || (X && dZ && ld_x >= k_in && ld_dz >= n_out),
                PGNN_E_INVALID, "weight_grad: bad input");
   const int in_blocks = (k_in + 1 + 63) / 64;
-  const int nt = (n_out + 15) / 16;
   const int slices = wg_slices(n_rows, k_in);
   int64_t rps = (n_rows + slices - 1) / slices;
   rps = (rps + kWgRows - 1) / kWgRows * kWgRows;
   if (rps < kWgRows) rps = kWgRows;
   float *partial = (float *)workspace;
-  const size_t lds = (size_t)kWgRows * (68 + 16 * nt + 4) * 4;
-  const int ntw = (nt + 3) / 4;
-  dim3 grid(in_blocks, slices);
+  // output columns in passes of <= 320 (4 waves x <= 5 column tiles), e.g. the
+  // 512-wide pooling layer of ped_cyl; the partial buffer is reused in stream
+  // order
+  for (int c0 = 0; c0 < n_out; c0 += 320) {
+    const int nc = n_out - c0 < 320 ? n_out - c0 : 320;
+    const int nt = (nc + 15) / 16;
+    const size_t lds = (size_t)kWgRows * (68 + 16 * nt + 4) * 4;
+    const int ntw = (nt + 3) / 4;
+    dim3 grid(in_blocks, slices);
 #define PGNN_WG(NTV)                                                          \
   hipLaunchKernelGGL((weight_grad_kernel<NTV>), grid, dim3(256), lds, stream,  \
-                     X, ld_x, k_in, dZ, ld_dz, n_out, n_rows, rps, nt, partial)
-  switch (ntw) {
-    case 1: PGNN_WG(1); break;
-    case 2: PGNN_WG(2); break;
-    case 3: PGNN_WG(3); break;
-    case 4: PGNN_WG(4); break;
-    default: PGNN_WG(5); break;
-  }
+                     X, ld_x, k_in, dZ + c0, ld_dz, nc, n_rows, rps, nt,       \
+                     partial)
+    switch (ntw) {
+      case 1: PGNN_WG(1); break;
+      case 2: PGNN_WG(2); break;
+      case 3: PGNN_WG(3); break;
+      case 4: PGNN_WG(4); break;
+      default: PGNN_WG(5); break;
+    }
 #undef PGNN_WG
-  hipLaunchKernelGGL(weight_grad_reduce_kernel,
-                     dim3(grid_for((int64_t)(k_in + 1) * n_out)), dim3(256), 0,
-                     stream, partial, slices, (int64_t)in_blocks * 64, nt * 16,
-                     k_in, n_out, dW, db, accumulate);
+    hipLaunchKernelGGL(weight_grad_reduce_kernel,
+                       dim3(grid_for((int64_t)(k_in + 1) * nc)), dim3(256), 0,
+                       stream, partial, slices, (int64_t)in_blocks * 64,
+                       nt * 16, k_in, nc, (int64_t)n_out, dW + c0,
+                       db ? db + c0 : nullptr, accumulate);
+  }
   PGNN_HIP(hipGetLastError());
   return 0;
   PGNN_GUARD_END

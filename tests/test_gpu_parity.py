@@ -437,21 +437,24 @@ def test_predict_end_to_end_device_graph(dev, name, preset, seed):
     np.testing.assert_allclose(boxes.cpu().numpy(), bx, atol=FP_TOL, rtol=1e-4)
 
 
-def test_full_size_properties(dev):
-    """BASELINE.json sizes (car T3, N=20k): properties that need no full-size
-    oracle run -- permutation invariance of the edge order (scatter-max is
-    order-free, so the all-atomic path must reproduce the sorted path bit for
-    bit), determinism, finiteness, and a sub-sampled oracle check of the
-    pooled features."""
+@pytest.mark.parametrize("name,preset", [("car_auto_T3", "car"),
+                                         ("ped_cyl_auto_T3", "ped_dense")])
+def test_full_size_properties(dev, name, preset):
+    """BASELINE.json sizes (config 3: car T3, N=20k; config 5: ped_cyl T3,
+    N=50k, 512-wide pooling = two column passes): properties that need no
+    full-size oracle run -- permutation invariance of the edge order
+    (scatter-max is order-free, so the all-atomic path must reproduce the
+    sorted path bit for bit), determinism, finiteness, and a sub-sampled
+    oracle check of the pooled features."""
     import torch
     from pointgnn_amd import graph_gen, models, gnn
-    cfg = configs.car_auto_config(3)
-    xyz, inten = synthetic_cloud(seed=0, preset="car")
+    cfg = configs.get_config(name)
+    xyz, inten = synthetic_cloud(seed=0, preset=preset)
     params = weights.init_params(cfg, seed=0, bias_scale=0.05)
     fn = graph_gen.get_graph_generate_fn(cfg["graph_gen_method"])
     coords, kps, edges = fn(T(xyz, dev), **cfg["runtime_graph_gen_kwargs"])
     model = models.get_model(cfg["model_name"])(
-        num_classes=4, box_encoding_len=7, mode="test",
+        num_classes=cfg["num_classes"], box_encoding_len=7, mode="test",
         **cfg["model_kwargs"]).load_state_dict(params)
     f = T(inten, dev)
     lg1, bx1 = model.predict(f, coords, kps, edges, False)
@@ -475,7 +478,8 @@ def test_full_size_properties(dev):
     sub = e0[mask]
     ref = gn.point_set_pooling(params, "layer1", inten, c_np[0], kp0, sub,
                                dtype=np.float64)
-    np.testing.assert_allclose(pooled[sel, :300], ref[sel], atol=FP_TOL, rtol=1e-4)
+    np.testing.assert_allclose(pooled[sel, :ref.shape[1]], ref[sel],
+                               atol=FP_TOL, rtol=1e-4)
 
 
 def test_pipelined_frames_equal_sequential(dev):

@@ -31,14 +31,14 @@ def T(a, dev):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
 
-def _tiny_batch(seed=0, fixture="graph_tiny.npz"):
+def _tiny_batch(seed=0, fixture="graph_tiny.npz", num_classes=4):
     g = gold(fixture)
     k = g["kp_xyz"].shape[0]
     coords = [g["xyz"], g["kp_xyz"], g["kp_xyz"]]
     kps = [g["kp_idx"], np.arange(k, dtype=np.int32).reshape(-1, 1)]
     edges = [g["ref_edges0"], g["ref_edges1"]]
     rng = np.random.default_rng(seed)
-    labels = rng.integers(0, 4, (k, 1)).astype(np.int32)
+    labels = rng.integers(0, num_classes, (k, 1)).astype(np.int32)
     labels[rng.random((k, 1)) < 0.5] = 0
     boxes = (rng.standard_normal((k, 1, 7)) * 1.5).astype(np.float32)
     valid = (labels > 0).astype(np.float32).reshape(k, 1, 1)
@@ -70,7 +70,9 @@ def test_pack_fc_device_matches_host_pack(dev):
 
 @pytest.mark.parametrize("rows,k_in,n_out", [(1000, 300, 300), (77, 4, 32),
                                              (5000, 303, 300), (33, 64, 3),
-                                             (20000, 128, 300), (1, 16, 16)])
+                                             (20000, 128, 300), (1, 16, 16),
+                                             (3000, 256, 512), (700, 512, 256),
+                                             (900, 40, 330)])
 def test_weight_grad_matches_numpy(dev, rows, k_in, n_out):
     import torch
     from pointgnn_amd import _lib
@@ -205,7 +207,8 @@ def _grad_errors(got, ref):
             np.linalg.norm(got - ref) / (np.linalg.norm(ref) + 1e-12))
 
 
-@pytest.mark.parametrize("name", ["car_auto_T1", "car_auto_T3", "car_fixed_T3"])
+@pytest.mark.parametrize("name", ["car_auto_T1", "car_auto_T3", "car_fixed_T3",
+                                  "ped_cyl_auto_T3"])
 def test_full_gradient_matches_oracle(dev, name):
     """Every variable's gradient of (cls + loc) against float64 autograd.
 
@@ -221,7 +224,7 @@ def test_full_gradient_matches_oracle(dev, name):
     from pointgnn_amd import train
     cfg = configs.get_config(name)
     params = weights.init_params(cfg, seed=5, bias_scale=0.1)
-    batch = _tiny_batch(seed=3)
+    batch = _tiny_batch(seed=3, num_classes=cfg["num_classes"])
     tr = train.Trainer(cfg, params=params, device=dev)
     out = tr.train_step(batch, apply=False)
     loss, g_ref, _ = to.step_gradients(params, cfg, [batch])
