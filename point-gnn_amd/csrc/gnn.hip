@@ -61,7 +61,7 @@ struct SegArgs {
 };
 
 __host__ __device__ inline int ints_bytes(int rows) {
-  return ((2 * rows + 2) * 4 + 15) / 16 * 16;  // dst[rows+2] + src[rows]
+  return ((2 * rows + 2) * 4 + 15) / 16 * 16;  // dst[rows+2] + part[<=rows]
 }
 
 // Open segment carried from one tile to the next inside a workgroup's
@@ -189,7 +189,10 @@ __global__ __launch_bounds__(256, 2) void fused_mlp_kernel(
   constexpr int ROWS = 16 * MSUB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int *dst = reinterpret_cast<int *>(smem);
-  int *src = dst + ROWS + 2;
+  // 16 * 3 floats behind dst[]: meeting point of the per-wave partial maxima of
+  // the balanced split's leftover column tiles (mlp_engine.h), armed to lowest()
+  float *part = reinterpret_cast<float *>(dst + ROWS + 2);
+  if (MSUB == 4 && threadIdx.x < 48) part[threadIdx.x] = kFloatLowest;
   float *carry = reinterpret_cast<float *>(smem + ints_bytes(ROWS));
   float *tile = carry + 16 * chain.l[chain.n - 1].nt;
   float *stage = stage_off >= 0 ? tile + stage_off : tile;
@@ -204,6 +207,8 @@ __global__ __launch_bounds__(256, 2) void fused_mlp_kernel(
       blockIdx.x * tq + (blockIdx.x < trem ? blockIdx.x : trem);
   const int64_t tile_last = tile_first + tq + (blockIdx.x < trem ? 1 : 0);
   CarryState cs = {-1, 0};
+  // prefetched (src, dst[, keypoint]) of the next tile's rows (EDGE / POOL)
+  int nxt_s = 0, nxt_d = -1, nxt_k = 0;
   for (int64_t tile_id = tile_first; tile_id < tile_last; ++tile_id) {
     const int64_t row0 = tile_id * ROWS;
     const int rows_valid =
@@ -213,6 +218,7 @@ __global__ __launch_bounds__(256, 2) void fused_mlp_kernel(
       tsp = ts + ((int64_t)blockIdx.x * 32 + (tile_id - tile_first)) * 8;
       tsp[0] = __builtin_readcyclecounter();
       tsp[3] = 0;
+      tsp[6] = __builtin_amdgcn_s_memrealtime();  // constant 100 MHz
     }
     // ------------------------------------------------------------ prologue
     // The co-resident workgroup is usually streaming MFMAs on the same SIMDs;
@@ -242,11 +248,23 @@ __global__ __launch_bounds__(256, 2) void fused_mlp_kernel(
         float f[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) f[i] = 0.0f;
+        // (src, dst, keypoint) of this row were requested during the previous
+        // tile (nxt_*): one global round trip here instead of three
+        if (tile_id == tile_first) {
+          nxt_s = 0;
+          nxt_d = -1;
+          nxt_k = 0;
+          if (e < n_rows) {
+            nxt_s = pa.edges[2 * e];
+            nxt_d = pa.edges[2 * e + 1];
+            nxt_k = pa.kp[nxt_d];
+          }
+        }
         int d = -1;
         if (e < n_rows) {
-          const int s = pa.edges[2 * e];
-          d = pa.edges[2 * e + 1];
-          const int k = pa.kp[d];
+          const int s = nxt_s;
+          d = nxt_d;
+          const int k = nxt_k;
 #pragma unroll
           for (int i = 0; i < 13; ++i)
             if (i < pa.nfeat) f[i] = pa.feat[(int64_t)s * pa.nfeat + i];
@@ -264,6 +282,13 @@ __global__ __launch_bounds__(256, 2) void fused_mlp_kernel(
         dst[r + 1] = d;
 #pragma unroll
         for (int c = 0; c < 16; ++c) tile[r * ld0 + c] = f[c];
+        nxt_s = 0;
+        nxt_d = -1;
+        nxt_k = 0;
+        if (e + ROWS < n_rows && tile_id + 1 < tile_last) {
+          nxt_s = pa.edges[2 * (e + ROWS)];
+          nxt_d = pa.edges[2 * (e + ROWS) + 1];
+        }
       }
       if (threadIdx.x == 64)
         dst[0] = row0 > 0 ? pa.edges[2 * (row0 - 1) + 1] : -1;
@@ -285,10 +310,25 @@ __global__ __launch_bounds__(256, 2) void fused_mlp_kernel(
       const v4f *__restrict__ P4 = reinterpret_cast<const v4f *>(ea.P);
       const v4f *__restrict__ Q4 = reinterpret_cast<const v4f *>(ea.Q);
       const int64_t ebase = row0 + wave * RPW;
-      int my_s = 0, my_d = -1;
-      if (lane < RPW && ebase + lane < n_rows) {
-        my_s = ea.edges[2 * (ebase + lane)];
-        my_d = ea.edges[2 * (ebase + lane) + 1];
+      // (src, dst) of this tile's rows were requested one tile ago (they sit
+      // in nxt_*), so the row gathers below start without a dependent index
+      // round trip; the next tile's pair is requested now and lands during
+      // this tile's gather + GEMM.
+      if (tile_id == tile_first) {
+        nxt_s = 0;
+        nxt_d = -1;
+        if (lane < RPW && ebase + lane < n_rows) {
+          nxt_s = ea.edges[2 * (ebase + lane)];
+          nxt_d = ea.edges[2 * (ebase + lane) + 1];
+        }
+      }
+      const int my_s = nxt_s, my_d = nxt_d;
+      nxt_s = 0;
+      nxt_d = -1;
+      if (lane < RPW && ebase + ROWS + lane < n_rows &&
+          tile_id + 1 < tile_last) {
+        nxt_s = ea.edges[2 * (ebase + ROWS + lane)];
+        nxt_d = ea.edges[2 * (ebase + ROWS + lane) + 1];
       }
       if (lane < RPW) dst[wave * RPW + lane + 1] = my_d;
       if (threadIdx.x == 0)
@@ -387,6 +427,8 @@ __global__ __launch_bounds__(256, 2) void fused_mlp_kernel(
     }
     __syncthreads();
     __builtin_amdgcn_s_setprio(0);
+    if (PRO == PRO_POOL && threadIdx.x < ROWS && nxt_d >= 0)
+      nxt_k = pa.kp[nxt_d];  // second level of the next tile's index chain
     if (tsp) tsp[1] = __builtin_readcyclecounter();
     // ------------------------------------------------------------ hidden layers
     for (int li = 0; li + 1 < chain.n; ++li) {
@@ -403,6 +445,8 @@ __global__ __launch_bounds__(256, 2) void fused_mlp_kernel(
         if (tiles > kMaxTilesPerPass) tiles = kMaxTilesPerPass;
         const int ncols = 16 * tiles;
         const int ld_st = lds_ld(ncols);
+        SegFast sf;
+        bool finish_split = false;
         if (PRO == PRO_ROWS) {
           layer_pass_dispatch<MSUB, false>(tile, ld_in, stage, ld_st, L, t0, wave,
                                            lane, (dbg & 2) != 0);
@@ -415,14 +459,13 @@ __global__ __launch_bounds__(256, 2) void fused_mlp_kernel(
           const bool left_closed = merge ? cs.left_closed != 0 : dst[0] != d;
           const bool right_closed = dst[ROWS + 1] != d;
           const bool defer = !right_closed && tile_id + 1 < tile_last;
-          SegFast sf;
           sf.carry = carry;
           sf.out_row = sa.out + (int64_t)d * sa.ldo;
           sf.merge = merge;
           sf.defer = defer;
           sf.whole = left_closed && right_closed;
-          layer_pass_segmax_fast_dispatch<MSUB>(tile, ld_in, L, t0, wave, lane,
-                                                sf);
+          finish_split = layer_pass_segmax_fast_auto<MSUB>(
+              tile, ld_in, L, t0, wave, lane, sf, part);
           if (t0 + kMaxTilesPerPass >= L.nt) {
             cs.id = defer ? d : -1;
             cs.left_closed = left_closed ? 1 : 0;
@@ -440,6 +483,12 @@ __global__ __launch_bounds__(256, 2) void fused_mlp_kernel(
         // LDS-only barrier: the tile buffer may be overwritten by the next
         // prologue, but the global stores / atomics above need not drain
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if constexpr (MSUB == 4) {
+          // leftover column tiles of the balanced split: every wave has added
+          // its 16 rows to `part`; emit them (next touch of carry / part is
+          // behind the next prologue's barrier)
+          if (finish_split) segfast_finish_split<4, 3>(L, t0, sf, part);
+        }
         if (tsp) tsp[2] = __builtin_readcyclecounter();
       }
     }

@@ -236,6 +236,221 @@ __device__ __forceinline__ void layer_pass_segmax_fast_dispatch(
   }
 }
 
+// ---------------------------------------------------------------------------
+// Balanced split for 64-row tiles whose pass has 4*NT + NR column tiles
+// (NR = 1..3; C = 300 -> 19 tiles = 4*4 + 3).  The plain scheme gives every
+// wave NT+1 tiles and lets the waves past the end compute a clamped duplicate
+// -- 80 instead of 76 tile-units of MFMA work per wave for 19 tiles.  Here a
+// wave owns NT full column tiles (all four 16-row sub-tiles) and, of each of
+// the NR leftover column tiles, only sub-tile m = wave: 4*NT + NR units per
+// wave, nothing discarded, all four waves equal.  The price is NR extra
+// B-fragment loads per K-group (each used by one MFMA group instead of four)
+// and one extra A fragment; both come from L2 / LDS with slack to spare.
+template <int NT, int NR>
+__device__ __forceinline__ void gemm_tile_split(
+    const float *__restrict__ tile, int ld, const LayerDev &L, int t0, int wave,
+    int lane, v4f (&acc)[4][NT], v4f (&accr)[NR]) {
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[m][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int r = 0; r < NR; ++r) accr[r] = (v4f){0.f, 0.f, 0.f, 0.f};
+  const v4f *__restrict__ wp = reinterpret_cast<const v4f *>(L.wp) + lane;
+  const float *arow = tile + (lane & 15) * ld + 4 * (lane >> 4);
+  const float *arow_mine = arow + wave * 16 * ld;
+  const int qstride = L.nt * 64;
+  const int kq = L.kq;
+  constexpr int PF = PGNN_PF4;
+  v4f a[PF][4], b[PF][NT], ar[PF], br[PF][NR];
+  auto fetch = [&](int q, v4f (&fa)[4], v4f (&fb)[NT], v4f &fa_r,
+                   v4f (&fb_r)[NR]) {
+    if (q > kq - 1) q = kq - 1;
+    const v4f *wq = wp + (size_t)q * qstride;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) fb[j] = wq[(t0 + wave + 4 * j) * 64];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) fb_r[r] = wq[(t0 + 4 * NT + r) * 64];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+      fa[m] = *reinterpret_cast<const v4f *>(arow + m * 16 * ld + 16 * q);
+    fa_r = *reinterpret_cast<const v4f *>(arow_mine + 16 * q);
+  };
+  auto mma = [&](const v4f (&fa)[4], const v4f (&fb)[NT], const v4f &fa_r,
+                 const v4f (&fb_r)[NR]) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[m][s], fb[j][s],
+                                                           acc[m][j], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < NR; ++r)
+        accr[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa_r[s], fb_r[r][s],
+                                                       accr[r], 0, 0, 0);
+    }
+  };
+#pragma unroll
+  for (int st = 0; st < PF; ++st) fetch(st, a[st], b[st], ar[st], br[st]);
+  for (int q = 0; q < kq; q += PF) {
+#pragma unroll
+    for (int st = 0; st < PF; ++st) {
+      if (q + st < kq) {  // wave-uniform
+        mma(a[st], b[st], ar[st], br[st]);
+        fetch(q + st + PF, a[st], b[st], ar[st], br[st]);
+      }
+    }
+  }
+}
+
+// activated value of accumulator `x` in column `col`
+__device__ __forceinline__ float activate(const LayerDev &L, const float *bias,
+                                          int col, float x) {
+  x += bias[col];
+  if (col >= L.relu_from) x = x > 0.0f ? x : 0.0f;
+  return x;
+}
+
+template <int NT, int NR, bool TRANSPOSED>
+__device__ __forceinline__ void store_split(float *__restrict__ out, int ldo,
+                                            const LayerDev &L, int t0, int wave,
+                                            int lane, const v4f (&acc)[4][NT],
+                                            const v4f (&accr)[NR]) {
+  if (TRANSPOSED)
+    store_acc_T<4, NT>(out, L, t0, wave, lane, acc);
+  else
+    store_acc<4, NT>(out, ldo, L, t0, wave, lane, acc);
+  const float *bias = L.wp + (size_t)L.kq * L.nt * 256;
+  constexpr int ROWS = 64, G = ROWS / 4, SWZ = 15;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const int col = (t0 + 4 * NT + r) * 16 + (lane & 15);
+    const int c = col - 16 * t0;
+    v4f v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = activate(L, bias, col, accr[r][i]);
+    if (TRANSPOSED) {
+      const int g = 4 * wave + (lane >> 4);
+      *reinterpret_cast<v4f *>(out + c * ROWS + ((g ^ (c & SWZ)) << 2)) = v;
+    } else {
+      float *o = out + (16 * wave + 4 * (lane >> 4)) * ldo + c;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i * ldo] = v[i];
+    }
+  }
+  (void)G;
+}
+
+template <int NT, int NR, bool TRANSPOSED>
+__device__ __forceinline__ void layer_pass_split(const float *in, int ld_in,
+                                                 float *out, int ld_out,
+                                                 const LayerDev &L, int t0,
+                                                 int wave, int lane) {
+  v4f acc[4][NT], accr[NR];
+  gemm_tile_split<NT, NR>(in, ld_in, L, t0, wave, lane, acc, accr);
+  __syncthreads();  // every wave is done reading `in` (in-place overwrite)
+  store_split<NT, NR, TRANSPOSED>(out, ld_out, L, t0, wave, lane, acc, accr);
+  __syncthreads();
+}
+
+// LDS float max that is correct for any sign mix (see atomic_max_f32)
+__device__ __forceinline__ void lds_atomic_max_f32(float *addr, float v) {
+  if (v >= 0.0f) {
+    __hip_atomic_fetch_max((int *)addr, __float_as_int(v), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_WORKGROUP);
+  } else {
+    __hip_atomic_fetch_min((unsigned int *)addr, __float_as_uint(v),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+}
+
+__device__ __forceinline__ void segfast_emit(const SegFast &sf, int col,
+                                             float v) {
+  if (sf.merge) v = fmaxf(v, sf.carry[col]);
+  if (sf.defer) {
+    sf.carry[col] = v;
+  } else if (sf.whole) {
+    sf.out_row[col] = v;
+  } else {
+    atomic_max_f32(sf.out_row + col, v + 0.0f);
+  }
+}
+
+// Fast (one-segment) epilogue with the split: full tiles as in
+// layer_pass_segmax_fast; of a leftover tile each wave holds only 16 of the 64
+// rows, so its column maxima (pre-bias) meet in `part` (16*NR floats of LDS,
+// preset to lowest()) through LDS atomics, and `segfast_finish_split` emits
+// them after the workgroup's end-of-tile barrier.
+template <int NT, int NR>
+__device__ __forceinline__ void layer_pass_segmax_fast_split(
+    const float *in, int ld_in, const LayerDev &L, int t0, int wave, int lane,
+    const SegFast &sf, float *part) {
+  v4f acc[4][NT], accr[NR];
+  gemm_tile_split<NT, NR>(in, ld_in, L, t0, wave, lane, acc, accr);
+  const float *bias = L.wp + (size_t)L.kq * L.nt * 256;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    float v = fmaxf(fmaxf(accr[r][0], accr[r][1]),
+                    fmaxf(accr[r][2], accr[r][3]));
+    v = fmaxf(v, __shfl_xor(v, 16));
+    v = fmaxf(v, __shfl_xor(v, 32));
+    if (lane < 16) lds_atomic_max_f32(part + r * 16 + lane, v + 0.0f);
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    float v = acc[0][j][0];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v = fmaxf(v, acc[m][j][i]);
+    v = fmaxf(v, __shfl_xor(v, 16));
+    v = fmaxf(v, __shfl_xor(v, 32));
+    const int col = (t0 + wave + 4 * j) * 16 + (lane & 15);
+    if (lane < 16) segfast_emit(sf, col, activate(L, bias, col, v));
+  }
+}
+
+// after the end-of-tile barrier: threads 0 .. 16*NR-1 finish the leftover
+// columns and re-arm `part`
+template <int NT, int NR>
+__device__ __forceinline__ void segfast_finish_split(const LayerDev &L, int t0,
+                                                     const SegFast &sf,
+                                                     float *part) {
+  if (threadIdx.x < 16 * NR) {
+    const float *bias = L.wp + (size_t)L.kq * L.nt * 256;
+    const int col = (t0 + 4 * NT) * 16 + threadIdx.x;
+    const float v = part[threadIdx.x];
+    part[threadIdx.x] = kFloatLowest;
+    segfast_emit(sf, col, activate(L, bias, col, v));
+  }
+}
+
+// the split applies to 64-row tiles with 19 column tiles in the pass (C = 300)
+__device__ __forceinline__ bool use_split(int msub, int tiles) {
+  return msub == 4 && tiles == 19;
+}
+
+// fast one-segment pass; returns true when the split was used, in which case
+// the caller runs segfast_finish_split<4, 3> after its end-of-tile barrier
+template <int MSUB>
+__device__ __forceinline__ bool layer_pass_segmax_fast_auto(
+    const float *in, int ld_in, const LayerDev &L, int t0, int wave, int lane,
+    const SegFast &sf, float *part) {
+  int tiles = L.nt - t0;
+  if (tiles > kMaxTilesPerPass) tiles = kMaxTilesPerPass;
+  if constexpr (MSUB == 4) {
+    if (use_split(MSUB, tiles)) {
+      layer_pass_segmax_fast_split<4, 3>(in, ld_in, L, t0, wave, lane, sf,
+                                         part);
+      return true;
+    }
+  }
+  layer_pass_segmax_fast_dispatch<MSUB>(in, ld_in, L, t0, wave, lane, sf);
+  return false;
+}
+
 // One pass (<= 320 output columns starting at column tile t0) of layer L:
 // GEMM from `in`, barrier, activated store to `out` (may alias `in`), barrier.
 template <int MSUB, int NT, bool TRANSPOSED>
@@ -267,6 +482,13 @@ __device__ __forceinline__ void layer_pass_dispatch(const float *in, int ld_in,
                                                     bool skip_gemm = false) {
   int tiles = L.nt - t0;
   if (tiles > kMaxTilesPerPass) tiles = kMaxTilesPerPass;
+  if constexpr (MSUB == 4) {
+    if (use_split(MSUB, tiles) && !skip_gemm) {
+      layer_pass_split<4, 3, TRANSPOSED>(in, ld_in, out, ld_out, L, t0, wave,
+                                         lane);
+      return;
+    }
+  }
   const int ntw = (tiles + 3) >> 2;  // column tiles per wave (wave-uniform)
   switch (ntw) {
     case 1: layer_pass<MSUB, 1, TRANSPOSED>(in, ld_in, out, ld_out, L, t0, wave, lane, skip_gemm); break;

@@ -74,3 +74,14 @@ for a in range(grid // 2):
     ov.append(both / max(tot, 1))
 print("fraction of a WG's GEMM+epilogue time overlapping its CU partner's: "
       "%.2f" % np.mean(ov))
+
+# shader clock during the kernel: cycle counter vs the constant 100 MHz counter
+t6 = ts[:, :, 6]
+clk = []
+for w in range(grid):
+    idx = [i for i in range(32) if valid[w, i]]
+    if len(idx) >= 4 and t6[w, idx[-1]] > t6[w, idx[0]]:
+        clk.append((t0[w, idx[-1]] - t0[w, idx[0]]) /
+                   (t6[w, idx[-1]] - t6[w, idx[0]]) * 0.1)
+print("cycle-counter rate during the kernel: %.3f GHz (p10 %.3f, p90 %.3f)"
+      % (np.mean(clk), np.percentile(clk, 10), np.percentile(clk, 90)))
