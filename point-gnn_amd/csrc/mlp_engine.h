@@ -82,9 +82,10 @@ __device__ __forceinline__ void gemm_tile(const float *__restrict__ tile, int ld
     for (int m = 0; m < MSUB; ++m)
       fa[m] = *reinterpret_cast<const v4f *>(arow + m * 16 * ld + 16 * q);
   };
-  auto mma = [&](const v4f (&fa)[MSUB], const v4f (&fb)[NT]) {
+  // k-steps [s0, s1) of one K-group
+  auto mma = [&](const v4f (&fa)[MSUB], const v4f (&fb)[NT], int s0, int s1) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+    for (int s = s0; s < s1; ++s)
 #pragma unroll
       for (int m = 0; m < MSUB; ++m)
 #pragma unroll
@@ -94,11 +95,16 @@ __device__ __forceinline__ void gemm_tile(const float *__restrict__ tile, int ld
   };
 #pragma unroll
   for (int st = 0; st < PF; ++st) fetch(st, a[st], b[st]);
+  // (A branch-free body with the kq % PF leftover groups peeled off lets hipcc
+  // place exact waits instead of vmcnt(0) at the loop header and looks better
+  // in tools/gemm_loop_bench.hip, but the fused kernels ran 3 % SLOWER with it
+  // in a same-box A/B -- 834 -> 863 us for the edge kernel -- so the guarded
+  // form stays.)
   for (int q = 0; q < kq; q += PF) {
 #pragma unroll
     for (int st = 0; st < PF; ++st) {
       if (q + st < kq) {  // wave-uniform
-        mma(a[st], b[st]);
+        mma(a[st], b[st], 0, 4);
         fetch(q + st + PF, a[st], b[st]);
       }
     }
@@ -277,9 +283,9 @@ __device__ __forceinline__ void gemm_tile_split(
     fa_r = *reinterpret_cast<const v4f *>(arow_mine + 16 * q);
   };
   auto mma = [&](const v4f (&fa)[4], const v4f (&fb)[NT], const v4f &fa_r,
-                 const v4f (&fb_r)[NR]) {
+                 const v4f (&fb_r)[NR], int s0, int s1) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = s0; s < s1; ++s) {
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -298,7 +304,7 @@ __device__ __forceinline__ void gemm_tile_split(
 #pragma unroll
     for (int st = 0; st < PF; ++st) {
       if (q + st < kq) {  // wave-uniform
-        mma(a[st], b[st], ar[st], br[st]);
+        mma(a[st], b[st], ar[st], br[st], 0, 4);
         fetch(q + st + PF, a[st], b[st], ar[st], br[st]);
       }
     }

@@ -1,0 +1,339 @@
+// Isolates the K-loop of mlp_engine.h (gemm_tile<4,5> / gemm_tile_split<4,3>):
+// every workgroup repeats the 64 x 304 x 304 tile GEMM on a resident LDS tile,
+// no gather, no epilogue.  Variants remove the B (weight) loads or the A (LDS)
+// loads to show what the loop is bound by.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -Iinclude \
+//     -Ipoint-gnn_amd/csrc tools/gemm_loop_bench.hip -o /tmp/glb && /tmp/glb
+#include "mlp_engine.h"
+
+#include <math.h>
+#include <vector>
+
+using namespace pgnn;
+
+namespace pgnn {
+std::string &last_error() {
+  static std::string s;
+  return s;
+}
+}  // namespace pgnn
+
+enum { V_REAL = 0, V_NO_B = 1, V_NO_A = 2, V_SPLIT = 3, V_B_L1 = 4, V_UNROLL = 5, V_UNROLL4 = 6, V_NO_AB = 7, V_ASM = 8, V_PEEL2 = 9, V_PEEL3 = 10 };
+
+
+// Compiler-managed loads, NS register stages, loop body WITHOUT inner
+// conditionals (kq = NS*n + tail handled after the loop), so that the waitcnt
+// pass sees identical pending-load states on the loop entry and back edge.
+template <int NS>
+__device__ __forceinline__ void gemm_tile_peel(const float *__restrict__ tile, int ld,
+                                               const LayerDev &L, int wave, int lane,
+                                               v4f (&acc)[4][5]) {
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int j = 0; j < 5; ++j) acc[m][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+  const v4f *__restrict__ wp = reinterpret_cast<const v4f *>(L.wp) + lane;
+  const float *arow = tile + (lane & 15) * ld + 4 * (lane >> 4);
+  const int qstride = L.nt * 64;
+  const int kq = L.kq;
+  int toff[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    int t = wave + 4 * j;
+    if (t > L.nt - 1) t = L.nt - 1;
+    toff[j] = t * 64;
+  }
+  v4f a[NS][4], b[NS][5];
+  auto fetch = [&](int q, v4f (&fa)[4], v4f (&fb)[5]) {
+    if (q > kq - 1) q = kq - 1;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) fb[j] = wp[(size_t)q * qstride + toff[j]];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+      fa[m] = *reinterpret_cast<const v4f *>(arow + m * 16 * ld + 16 * q);
+  };
+  auto mma = [&](const v4f (&fa)[4], const v4f (&fb)[5]) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+          acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[m][s], fb[j][s],
+                                                           acc[m][j], 0, 0, 0);
+  };
+#pragma unroll
+  for (int st = 0; st < NS; ++st) fetch(st, a[st], b[st]);
+  int q = 0;
+  for (; q + NS <= kq; q += NS) {
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+      mma(a[st], b[st]);
+      fetch(q + st + NS, a[st], b[st]);
+    }
+  }
+#pragma unroll
+  for (int st = 0; st < NS; ++st)
+    if (q + st < kq) mma(a[st], b[st]);
+}
+
+// Hand-scheduled K loop: B fragments through inline-asm global loads in THREE
+// register stages (prefetch distance two K-groups), explicit s_waitcnt vmcnt(N)
+// tied to the stage registers; A fragments (LDS) stay with the compiler.
+#define GLOAD(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
+#define WAIT_VM(N, B) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(B[0]), "+v"(B[1]), "+v"(B[2]), "+v"(B[3]), "+v"(B[4]) :: "memory")
+
+__device__ __forceinline__ void gemm_tile_asm(const float *__restrict__ tile, int ld,
+                                              const LayerDev &L, int wave, int lane,
+                                              v4f (&acc)[4][5]) {
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int j = 0; j < 5; ++j) acc[m][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+  const v4f *wp = reinterpret_cast<const v4f *>(L.wp) + lane;
+  const float *arow = tile + (lane & 15) * ld + 4 * (lane >> 4);
+  const int qstride = L.nt * 64;
+  const int kq = L.kq;
+  int toff[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    int t = wave + 4 * j;
+    if (t > L.nt - 1) t = L.nt - 1;
+    toff[j] = t * 64;
+  }
+  v4f b0[5], b1[5], b2[5], a0[4], a1[4];
+  auto loadb = [&](int q, v4f (&fb)[5]) {
+    if (q > kq - 1) q = kq - 1;
+    const v4f *wq = wp + (size_t)q * qstride;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) GLOAD(fb[j], wq + toff[j]);
+  };
+  auto loada = [&](int q, v4f (&fa)[4]) {
+    if (q > kq - 1) q = kq - 1;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+      fa[m] = *reinterpret_cast<const v4f *>(arow + m * 16 * ld + 16 * q);
+  };
+  auto mma = [&](const v4f (&fa)[4], const v4f (&fb)[5]) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+          acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[m][s], fb[j][s],
+                                                           acc[m][j], 0, 0, 0);
+  };
+  loadb(0, b0);
+  loadb(1, b1);
+  loadb(2, b2);
+  loada(0, a0);
+  loada(1, a1);
+  // groups in threes so that stage indices are static; two newer stages (10
+  // loads) may stay in flight when a stage is consumed
+  for (int q = 0; q < kq; q += 6) {
+#define STEP(QQ, BS, AS)                         \
+    if (q + QQ < kq) {                           \
+      WAIT_VM(10, BS);                           \
+      mma(AS, BS);                               \
+      loadb(q + QQ + 3, BS);                     \
+      loada(q + QQ + 2, AS);                     \
+    }
+    STEP(0, b0, a0)
+    STEP(1, b1, a1)
+    STEP(2, b2, a0)
+    STEP(3, b0, a1)
+    STEP(4, b1, a0)
+    STEP(5, b2, a1)
+#undef STEP
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int VARIANT>
+__global__ __launch_bounds__(256, 2) void loop_kernel(LayerDev L, int iters,
+                                                      float *out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float *tile = reinterpret_cast<float *>(smem);
+  const int ld = lds_ld(16 * L.kq);
+  for (int i = threadIdx.x; i < 64 * ld; i += 256)
+    tile[i] = (float)((i * 37 + blockIdx.x) % 97) * 0.01f - 0.4f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float sink = 0.f;
+  for (int it = 0; it < iters; ++it) {
+    if (VARIANT == V_SPLIT) {
+      v4f acc[4][4], accr[3];
+      gemm_tile_split<4, 3>(tile, ld, L, 0, wave, lane, acc, accr);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          sink += acc[m][j][0] + acc[m][j][1] + acc[m][j][2] + acc[m][j][3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+        sink += accr[r][0] + accr[r][1] + accr[r][2] + accr[r][3];
+    } else {
+      v4f acc[4][5];
+      if (VARIANT == V_PEEL2) {
+        gemm_tile_peel<2>(tile, ld, L, wave, lane, acc);
+      } else if (VARIANT == V_PEEL3) {
+        gemm_tile_peel<3>(tile, ld, L, wave, lane, acc);
+      } else if (VARIANT == V_ASM) {
+        gemm_tile_asm(tile, ld, L, wave, lane, acc);
+      } else if (VARIANT == V_REAL || VARIANT == V_B_L1) {
+        LayerDev l2 = L;
+        if (VARIANT == V_B_L1) l2.kq = L.kq;  // same code; weights shrunk by host
+        gemm_tile<4, 5>(tile, ld, l2, 0, wave, lane, acc);
+      } else {
+        // hand copy of gemm_tile's loop with one operand source removed
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int j = 0; j < 5; ++j) acc[m][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+        const v4f *wp = reinterpret_cast<const v4f *>(L.wp) + lane;
+        const float *arow = tile + (lane & 15) * ld + 4 * (lane >> 4);
+        const int qstride = L.nt * 64;
+        v4f a[2][4], b[2][5];
+        auto fetch = [&](int q, v4f(&fa)[4], v4f(&fb)[5]) {
+          if (q > L.kq - 1) q = L.kq - 1;
+#pragma unroll
+          for (int j = 0; j < 5; ++j) {
+            int t = wave + 4 * j;
+            if (t > L.nt - 1) t = L.nt - 1;
+            if (VARIANT == V_NO_B || VARIANT == V_NO_AB)
+              fb[j] = (v4f){0.5f + q, 0.25f, -0.5f, 1.0f + j};
+            else
+              fb[j] = wp[(size_t)q * qstride + t * 64];
+          }
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            if (VARIANT == V_NO_A || VARIANT == V_NO_AB)
+              fa[m] = (v4f){0.5f + q, 0.25f + m, -0.5f, 1.0f};
+            else
+              fa[m] = *reinterpret_cast<const v4f *>(arow + m * 16 * ld + 16 * q);
+          }
+        };
+        fetch(0, a[0], b[0]);
+        fetch(1, a[1], b[1]);
+        if (VARIANT == V_UNROLL || VARIANT == V_UNROLL4) {
+          constexpr int KQ = 19;
+          constexpr int U = VARIANT == V_UNROLL ? 20 : 4;
+#pragma unroll 1
+          for (int q0 = 0; q0 < KQ; q0 += U) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              const int q = q0 + u;
+              if (q < KQ) {
+                const int st = u & 1;
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                  for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int j = 0; j < 5; ++j)
+                      acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                          a[st][m][s], b[st][j][s], acc[m][j], 0, 0, 0);
+                fetch(q + 2, a[st], b[st]);
+              }
+            }
+          }
+        } else
+        for (int q = 0; q < L.kq; q += 2) {
+#pragma unroll
+          for (int st = 0; st < 2; ++st) {
+            if (q + st < L.kq) {
+#pragma unroll
+              for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                  for (int j = 0; j < 5; ++j)
+                    acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                        a[st][m][s], b[st][j][s], acc[m][j], 0, 0, 0);
+              fetch(q + st + 2, a[st], b[st]);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+          sink += acc[m][j][0] + acc[m][j][1] + acc[m][j][2] + acc[m][j][3];
+    }
+    __syncthreads();  // the real kernel has barriers between tiles too
+  }
+  if (blockIdx.x == 0) out[threadIdx.x] = sink;
+}
+
+static float g_ref[256];
+
+template <int VARIANT>
+void run(const LayerDev &L, int iters, double mfma_per_wave, const char *what) {
+  float *out;
+  hipMalloc(&out, 1024);
+  const size_t lds = (size_t)64 * lds_ld(16 * L.kq) * 4;
+  auto kern = loop_kernel<VARIANT>;
+  hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  float best = 1e9f;
+  for (int rep = 0; rep < 12; ++rep) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(kern, dim3(512), dim3(256), lds, 0, L, iters, out);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double flops = 512.0 * 4 * iters * mfma_per_wave * 2048.0;
+    if (ms < best) best = ms;
+    if (rep == 11)
+      printf("%-38s best %.3f ms  %.1f TFLOP/s issued\n", what, best,
+             flops / best / 1e9);
+  }
+  float h[256];
+  hipMemcpy(h, out, 1024, hipMemcpyDeviceToHost);
+  if (VARIANT == V_REAL) {
+    for (int i = 0; i < 256; ++i) g_ref[i] = h[i];
+  } else if (VARIANT == V_ASM || VARIANT == V_UNROLL || VARIANT == V_PEEL2 || VARIANT == V_PEEL3) {
+    double worst = 0;
+    for (int i = 0; i < 256; ++i) {
+      const double d = fabs((double)h[i] - g_ref[i]) / (fabs((double)g_ref[i]) + 1e-9);
+      if (d > worst) worst = d;
+    }
+    printf("    max relative difference to gemm_tile<4,5>: %.3g\n", worst);
+  }
+  hipFree(out);
+}
+
+int main() {
+  const int kq = 19, nt = 19;
+  std::vector<float> w((size_t)kq * nt * 256 + nt * 16);
+  for (size_t i = 0; i < w.size(); ++i) w[i] = (float)((i * 131) % 251) * 1e-3f;
+  float *dw;
+  hipMalloc(&dw, w.size() * 4);
+  hipMemcpy(dw, w.data(), w.size() * 4, hipMemcpyHostToDevice);
+  LayerDev L;
+  L.wp = dw;
+  L.kq = kq;
+  L.nt = nt;
+  L.relu_from = 0;
+  const int iters = 16;  // tiles per workgroup, as in the real launch
+  // clocks ramp over the first milliseconds of matrix work: warm up first
+  run<V_NO_AB>(L, 400, 19 * 80.0, "(warm-up)");
+  run<V_REAL>(L, iters, 19 * 80.0, "gemm_tile<4,5> (as shipped before)");
+  run<V_SPLIT>(L, iters, 19 * 76.0, "gemm_tile_split<4,3>");
+  run<V_NO_B>(L, iters, 19 * 80.0, "no weight loads (B in registers)");
+  run<V_NO_A>(L, iters, 19 * 80.0, "no LDS reads (A in registers)");
+  run<V_ASM>(L, iters, 19 * 80.0, "hand-scheduled: asm B loads, 3 stages");
+  run<V_PEEL2>(L, iters, 19 * 80.0, "no inner branches, 2 stages");
+  run<V_PEEL3>(L, iters, 19 * 80.0, "no inner branches, 3 stages");
+  run<V_NO_AB>(L, iters, 19 * 80.0, "no loads at all (loop + barrier only)");
+  run<V_UNROLL>(L, iters, 19 * 80.0, "K loop fully unrolled (19 groups)");
+  run<V_UNROLL4>(L, iters, 19 * 80.0, "K loop unrolled by 4 groups");
+  return 0;
+}
