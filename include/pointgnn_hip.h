@@ -177,7 +177,10 @@ int pgnn_point_set_pooling_fwd(const float *point_features, int32_t n_feat,
  * (both per vertex, computed by pgnn_mlp_fwd / pgnn_offset_apply) the
  * per-edge hidden vector is ReLU(P[src] - Q[dst]); this entry gathers it,
  * applies the remaining edge layers (ReLU) and scatter-maxes into dst rows.
- * P, Q: [num_vertices, ld_pq] with ld_pq = 16*ceil(width/16), zero padded.  */
+ * P, Q: [num_vertices, ld_pq] with ld_pq = 16*ceil(width/16), zero padded.
+ * edges_sorted: bit 0 = edges sorted by dst; bit 1 = `out` already holds
+ * float lowest() everywhere (pgnn_vertex_pre_edge_fwd filled it), skip the
+ * fill.                                                                      */
 int pgnn_edge_mlp_scatter_max_fwd(const float *P, const float *Q,
                                   int64_t ld_pq, int32_t width,
                                   const int32_t *edges, int64_t n_edges,
@@ -192,6 +195,23 @@ int pgnn_edge_mlp_scatter_max_fwd(const float *P, const float *Q,
 int pgnn_offset_apply(const float *xyz, const float *delta, int64_t ld_delta,
                       int64_t n_rows, const float *wx, float *xyz_out,
                       float *Q, int64_t ld_q, void *stream);
+
+/* Everything gnn.py:341-356 does per VERTEX before the per-edge work, in one
+ * launch: delta = offset MLP(h[:, :c]) (n_offset_layers = 0: no auto offset,
+ * delta = 0), Q = (xyz + delta) @ wx, P = [h[:, :c], xyz] @ W1 + b1
+ * (p_layer: k_in = c + 3), and -- when agg is non-null -- the lowest() fill
+ * of the [n_vertices, ld_agg] buffer the edge stage maxes into.  Equivalent
+ * to pgnn_mlp_fwd (offset chain) + pgnn_offset_apply + pgnn_mlp_fwd (P) + fill
+ * with identical arithmetic.  P, Q: [n_vertices, ld_pq], ld_pq = padded width
+ * of p_layer's output; wx: device [3, ld_pq].                               */
+int pgnn_vertex_pre_edge_fwd(const float *h, int64_t ld_h, int32_t c,
+                             const float *xyz,
+                             const pgnn_fc_layer *offset_layers_host,
+                             int32_t n_offset_layers,
+                             const pgnn_fc_layer *p_layer_host, const float *wx,
+                             int64_t n_vertices, float *P, float *Q,
+                             int64_t ld_pq, float *agg, int64_t ld_agg,
+                             void *stream);
 
 /* ---- training step (config 4: models.py:170-311, train.py:135-171,264-297,
  * 375-405, util/tf_util.py:3-43) ------------------------------------------

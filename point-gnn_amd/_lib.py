@@ -69,6 +69,11 @@ _SIGNATURES = {
                                               c_i32, c_vp, c_i64, c_vp]),
     "pgnn_offset_apply": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp,
                                   c_i64, c_vp]),
+    "pgnn_vertex_pre_edge_fwd": (c_i32, [c_vp, c_i64, c_i32, c_vp,
+                                         ctypes.POINTER(FcLayer), c_i32,
+                                         ctypes.POINTER(FcLayer), c_vp, c_i64,
+                                         c_vp, c_vp, c_i64, c_vp, c_i64,
+                                         c_vp]),
     # training step
     "pgnn_pack_fc_device": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp,
                                     c_vp]),

@@ -698,8 +698,10 @@ extern "C" int pgnn_edge_mlp_scatter_max_fwd(
   PGNN_REQUIRE(out && ld_out >= out_cols, PGNN_E_INVALID,
                "edge_mlp: ld_out < padded output width");
   if (num_vertices == 0) return 0;
-  rc = fill_lowest(out, (int64_t)num_vertices * ld_out, stream);
-  if (rc) return rc;
+  if (!(edges_sorted & 2)) {  // bit 1: caller already filled `out` with lowest()
+    rc = fill_lowest(out, (int64_t)num_vertices * ld_out, stream);
+    if (rc) return rc;
+  }
   if (n_edges == 0) return 0;
   PGNN_REQUIRE(P && Q && edges, PGNN_E_INVALID, "edge_mlp: null input");
   PGNN_REQUIRE(((uintptr_t)P % 16 == 0) && ((uintptr_t)Q % 16 == 0),
@@ -707,7 +709,7 @@ extern "C" int pgnn_edge_mlp_scatter_max_fwd(
   RowsArgs ra = {};
   PoolArgs pa = {};
   EdgeArgs ea = {P, Q, ld_pq, edges};
-  SegArgs sa = {out, ld_out, num_vertices, edges_sorted};
+  SegArgs sa = {out, ld_out, num_vertices, edges_sorted & 1};
   int msub = g_edge_msub;
   if (msub != 2 && msub != 4)
     msub = (plan_lds_bytes(p, 64) <= 80 * 1024 ||
@@ -715,6 +717,165 @@ extern "C" int pgnn_edge_mlp_scatter_max_fwd(
   if (msub == 4)
     return launch_fused<4, PRO_EDGE>(p, n_edges, ra, pa, ea, sa, stream);
   return launch_fused<2, PRO_EDGE>(p, n_edges, ra, pa, ea, sa, stream);
+  PGNN_GUARD_END
+}
+
+// ---- vertex side of one GraphNetAutoCenter iteration, before the edge kernel ----
+// gnn.py:341-356 per vertex: delta = offset MLP(h); Q = (x + delta) W1[C:];
+// P = [h, x] W1 + b1; plus the lowest() fill of the aggregation buffer.  Three
+// launches + a memset in the unfused form (~46 us per iteration at K = 2.9k,
+// each a 184-workgroup grid that ends before it fills the chip); here one
+// 16-row tile per workgroup keeps [h, x] in LDS for both chains.
+namespace {
+
+struct PreEdgeArgs {
+  const float *h;
+  int64_t ld_h;
+  int c;
+  const float *xyz;
+  const float *wx;
+  int64_t n;
+  float *P, *Q;
+  int64_t ld_pq;
+  float *agg;
+  int64_t ld_agg;
+  int ld_tile, ld_scratch;  // LDS leading dimensions
+};
+
+__global__ __launch_bounds__(256) void vertex_pre_edge_kernel(
+    ChainDev off, LayerDev pl, PreEdgeArgs a) {
+  constexpr int ROWS = 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float *tile = reinterpret_cast<float *>(smem);      // [16][ld_tile]: [h | x | 0]
+  float *scratch = tile + ROWS * a.ld_tile;           // offset-chain activations
+  float *stage = scratch + ROWS * a.ld_scratch;       // P before it leaves
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t row0 = (int64_t)blockIdx.x * ROWS;
+  const int rows_valid =
+      (int)((a.n - row0 < ROWS) ? (a.n - row0) : ROWS);
+  const int kc = 16 * pl.kq;
+  for (int idx = threadIdx.x; idx < ROWS * kc; idx += 256) {
+    const int r = idx / kc, c = idx - r * kc;
+    float v = 0.0f;
+    if (r < rows_valid) {
+      if (c < a.c)
+        v = a.h[(row0 + r) * a.ld_h + c];
+      else if (c < a.c + 3)
+        v = a.xyz[(row0 + r) * 3 + (c - a.c)];
+    }
+    tile[r * a.ld_tile + c] = v;
+  }
+  // lowest() rows of the aggregation buffer the edge kernel maxes into
+  if (a.agg) {
+    for (int idx = threadIdx.x; idx < rows_valid * (int)a.ld_agg; idx += 256)
+      a.agg[row0 * a.ld_agg + idx] = kFloatLowest;
+  }
+  __syncthreads();
+  // offset chain: first layer reads the h columns of the tile (its packed
+  // weights are zero beyond k_in, so the x columns do not contribute)
+  const float *delta = nullptr;
+  int ld_delta = 0;
+  for (int li = 0; li < off.n; ++li) {
+    const LayerDev &L = off.l[li];
+    const float *in = li == 0 ? tile : scratch;
+    const int ld_in = li == 0 ? a.ld_tile : lds_ld(16 * L.kq);
+    layer_pass_dispatch<1, false>(in, ld_in, scratch, lds_ld(16 * L.nt), L, 0,
+                                  wave, lane);
+    delta = scratch;
+    ld_delta = lds_ld(16 * L.nt);
+  }
+  // Q = (x + delta) @ wx, the same expression as offset_apply_kernel
+  for (int idx = threadIdx.x; idx < rows_valid * (int)a.ld_pq; idx += 256) {
+    const int r = idx / (int)a.ld_pq, c = idx - r * (int)a.ld_pq;
+    float x0 = a.xyz[(row0 + r) * 3], x1 = a.xyz[(row0 + r) * 3 + 1],
+          x2 = a.xyz[(row0 + r) * 3 + 2];
+    if (delta) {
+      x0 = x0 + delta[r * ld_delta];
+      x1 = x1 + delta[r * ld_delta + 1];
+      x2 = x2 + delta[r * ld_delta + 2];
+    }
+    a.Q[(row0 + r) * a.ld_pq + c] =
+        (x0 * a.wx[c] + x1 * a.wx[a.ld_pq + c]) + x2 * a.wx[2 * a.ld_pq + c];
+  }
+  // P = [h, x] @ W1 + b1
+  const int ld_st = lds_ld(16 * pl.nt);
+  layer_pass_dispatch<1, false>(tile, a.ld_tile, stage, ld_st, pl, 0, wave,
+                                lane);
+  RowsArgs ra = {};
+  ra.y = a.P;
+  ra.ldy = a.ld_pq;
+  consume_rows<ROWS>(stage, ld_st, row0, rows_valid, 0, 16 * pl.nt, ra);
+}
+
+}  // namespace
+
+extern "C" int pgnn_vertex_pre_edge_fwd(
+    const float *h, int64_t ld_h, int32_t c, const float *xyz,
+    const pgnn_fc_layer *offset_layers, int32_t n_offset_layers,
+    const pgnn_fc_layer *p_layer, const float *wx, int64_t n_vertices, float *P,
+    float *Q, int64_t ld_pq, float *agg, int64_t ld_agg, void *stream_) {
+  PGNN_GUARD_BEGIN
+  hipStream_t stream = (hipStream_t)stream_;
+  PGNN_REQUIRE(n_vertices >= 0 && c > 0 && ld_h >= c && n_offset_layers >= 0 &&
+                   n_offset_layers <= PGNN_MAX_LAYERS && p_layer,
+               PGNN_E_INVALID, "vertex_pre_edge: bad argument");
+  if (n_vertices == 0) return 0;
+  PGNN_REQUIRE(h && xyz && wx && P && Q && (!agg || ld_agg > 0), PGNN_E_INVALID,
+               "vertex_pre_edge: null pointer");
+  Plan pp;
+  int rc = make_plan(p_layer, 1, c + 3, pp);
+  if (rc) return rc;
+  const LayerDev pl = pp.chain.l[0];
+  PGNN_REQUIRE(p_layer->k_in == c + 3 && pl.nt <= kMaxTilesPerPass &&
+                   ld_pq == 16 * pl.nt,
+               PGNN_E_INVALID,
+               "vertex_pre_edge: P layer must be [c+3 -> n], ld_pq = padded n");
+  ChainDev off = {};
+  int scratch_ld = lds_ld(16);
+  if (n_offset_layers > 0) {
+    Plan po;
+    rc = make_plan(offset_layers, n_offset_layers, c, po);
+    if (rc) return rc;
+    off = po.chain;
+    PGNN_REQUIRE(offset_layers[0].k_in == c &&
+                     offset_layers[n_offset_layers - 1].n_out >= 3 &&
+                     off.l[0].kq <= pl.kq &&
+                     off.l[n_offset_layers - 1].nt <= kMaxTilesPerPass,
+                 PGNN_E_INVALID, "vertex_pre_edge: offset chain must be [c -> ... -> 3]");
+    for (int i = 0; i < n_offset_layers; ++i) {
+      const int ld = lds_ld(16 * off.l[i].nt);
+      if (ld > scratch_ld) scratch_ld = ld;
+      if (i > 0 && lds_ld(16 * off.l[i].kq) > scratch_ld)
+        scratch_ld = lds_ld(16 * off.l[i].kq);
+    }
+  }
+  PreEdgeArgs a;
+  a.h = h;
+  a.ld_h = ld_h;
+  a.c = c;
+  a.xyz = xyz;
+  a.wx = wx;
+  a.n = n_vertices;
+  a.P = P;
+  a.Q = Q;
+  a.ld_pq = ld_pq;
+  a.agg = agg;
+  a.ld_agg = ld_agg;
+  a.ld_tile = lds_ld(16 * pl.kq);
+  a.ld_scratch = scratch_ld;
+  const size_t lds =
+      (size_t)16 * (a.ld_tile + a.ld_scratch + lds_ld(16 * pl.nt)) * 4;
+  PGNN_REQUIRE(lds <= 160 * 1024, PGNN_E_UNSUPPORTED,
+               "vertex_pre_edge: layer too wide for the LDS tile");
+  auto kern = vertex_pre_edge_kernel;
+  PGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                               hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)lds));
+  hipLaunchKernelGGL(kern, dim3((unsigned)((n_vertices + 15) / 16)), dim3(256),
+                     lds, stream, off, pl, a);
+  PGNN_HIP(hipGetLastError());
+  return 0;
   PGNN_GUARD_END
 }
 

@@ -397,29 +397,32 @@ class GraphNetAutoCenter(object):
             raise NotImplementedError("edge MLP needs at least two layers")
         assert h.shape[1] >= c, "vertex features narrower than edge MLP input"
 
-        # [optional] coordinate offset (auto-registration), gnn.py:341-346
-        delta = None
+        # per vertex, one launch (gnn.py:341-356): [optional] coordinate offset
+        # delta = MLP(h) (auto-registration), Q = (x + delta) @ W1[C:],
+        # P = [h, x] @ W1 + b1, and the lowest() fill of the aggregation buffer
+        off_chain = None
         if auto_offset:
             _check_kinds(auto_offset_MLP_feature_activation_type,
                          auto_offset_MLP_normalization_type)
             off_chain = _relu_chain(store, scope,
                                     list(auto_offset_MLP_depth_list), True)
-            delta = mlp_forward(off_chain, h, off_chain.k_in)
-        # Q = (x + delta) @ W1[C:], P = [h, x] @ W1 + b1  (per vertex)
+            assert off_chain.k_in == c, "offset MLP input must be the features"
         wq = int(wx_dev.shape[1])
         q = torch.empty((k, wq), dtype=torch.float32, device=h.device)
-        _lib.check(lib.pgnn_offset_apply(
-            _lib.ptr(x), _lib.ptr(delta),
-            delta.stride(0) if delta is not None else 0, k, _lib.ptr(wx_dev),
-            ctypes.c_void_p(0), _lib.ptr(q), wq, st), "pgnn_offset_apply")
-        p = mlp_forward(p_chain, h, c, x2=x, nx2=3)
-        # per-edge: ReLU(P[src] - Q[dst]) -> remaining edge layers -> max
+        p = torch.empty((k, wq), dtype=torch.float32, device=h.device)
         agg = torch.empty((k, padded_width(rest.n_out)), dtype=torch.float32,
                           device=h.device)
+        _lib.check(lib.pgnn_vertex_pre_edge_fwd(
+            _lib.ptr(h), h.stride(0), c, _lib.ptr(x),
+            off_chain.array if off_chain is not None else None,
+            off_chain.n if off_chain is not None else 0, p_chain.array,
+            _lib.ptr(wx_dev), k, _lib.ptr(p), _lib.ptr(q), wq, _lib.ptr(agg),
+            agg.stride(0), st), "pgnn_vertex_pre_edge_fwd")
+        # per-edge: ReLU(P[src] - Q[dst]) -> remaining edge layers -> max
         _lib.check(lib.pgnn_edge_mlp_scatter_max_fwd(
             _lib.ptr(p), _lib.ptr(q), wq, int(rest.k_in), _lib.ptr(e),
             int(e.shape[0]), k, rest.array, rest.n,
-            _edges_sorted_flag(edges), _lib.ptr(agg), agg.stride(0), st),
+            _edges_sorted_flag(edges) | 2, _lib.ptr(agg), agg.stride(0), st),
             "pgnn_edge_mlp_scatter_max_fwd")
         # update + residual, gnn.py:367-372
         upd_chain = _relu_chain(store, scope + '/combined_features',

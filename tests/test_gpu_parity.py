@@ -375,6 +375,59 @@ def test_graphnet_auto_center_layer(dev, auto_offset, shuffle):
     np.testing.assert_allclose(out[:, :300], ref, atol=FP_TOL, rtol=1e-4)
 
 
+@pytest.mark.parametrize("auto_offset,k", [(True, 1000), (False, 37), (True, 16)])
+def test_vertex_pre_edge_equals_unfused_entries(dev, auto_offset, k):
+    """pgnn_vertex_pre_edge_fwd == pgnn_mlp_fwd (offset chain) +
+    pgnn_offset_apply + pgnn_mlp_fwd (P) + lowest() fill, bit for bit."""
+    import ctypes
+    import torch
+    from pointgnn_amd import gnn, _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(k)
+    c = 300
+    store = _store({
+        "s/fully_connected/weights": rng.standard_normal((c, 64)).astype(np.float32) * 0.1,
+        "s/fully_connected/biases": rng.standard_normal(64).astype(np.float32),
+        "s/fully_connected_1/weights": rng.standard_normal((64, 3)).astype(np.float32) * 0.1,
+        "s/fully_connected_1/biases": rng.standard_normal(3).astype(np.float32),
+    }, dev)
+    w1 = rng.standard_normal((c + 3, 300)).astype(np.float32) * 0.1
+    b1 = rng.standard_normal(300).astype(np.float32)
+    h = T(np.pad(rng.standard_normal((k, c)).astype(np.float32),
+                 ((0, 0), (0, 4))), dev)
+    x = T(rng.uniform(-20, 20, (k, 3)).astype(np.float32), dev)
+    with gnn.parameters(store):
+        off = gnn._relu_chain(store, "s", [64, 3], True) if auto_offset else None
+        p_chain = gnn.Chain(store, [(w1, b1, 300)])
+        wq = gnn.padded_width(300)
+        wx = np.zeros((3, wq), np.float32)
+        wx[:, :300] = w1[c:]
+        wx_dev = T(wx, dev)
+        st = _lib.stream_ptr()
+        # unfused
+        delta = gnn.mlp_forward(off, h, c) if off is not None else None
+        q0 = torch.empty((k, wq), dtype=torch.float32, device=dev)
+        _lib.check(lib.pgnn_offset_apply(
+            _lib.ptr(x), _lib.ptr(delta) if delta is not None else None,
+            delta.stride(0) if delta is not None else 0, k, _lib.ptr(wx_dev),
+            ctypes.c_void_p(0), _lib.ptr(q0), wq, st))
+        p0 = gnn.mlp_forward(p_chain, h, c, x2=x, nx2=3)
+        # fused
+        q1 = torch.full((k, wq), 7.0, dtype=torch.float32, device=dev)
+        p1 = torch.full((k, wq), 7.0, dtype=torch.float32, device=dev)
+        agg = torch.zeros((k + 2, 304), dtype=torch.float32, device=dev)
+        _lib.check(lib.pgnn_vertex_pre_edge_fwd(
+            _lib.ptr(h), h.stride(0), c, _lib.ptr(x),
+            off.array if off is not None else None,
+            off.n if off is not None else 0, p_chain.array, _lib.ptr(wx_dev),
+            k, _lib.ptr(p1), _lib.ptr(q1), wq, _lib.ptr(agg), 304, st))
+    assert torch.equal(q0, q1)
+    assert torch.equal(p0[:, :wq], p1)
+    lowest = np.finfo(np.float32).min
+    a = agg.cpu().numpy()
+    assert np.all(a[:k] == lowest) and np.all(a[k:] == 0.0)   # fills its rows only
+
+
 @pytest.mark.parametrize("t", [0, 1])
 def test_predict_real_weights_matches_golden(dev, t):
     """configs[0]/[1]: trained car_auto_T0/T1 weights, reference-built graph,
