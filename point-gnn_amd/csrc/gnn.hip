@@ -173,7 +173,7 @@ __device__ __forceinline__ void consume_rows(const float *__restrict__ stage,
                                              int col0, int ncols,
                                              const RowsArgs &ra) {
   const int total = rows_valid * ncols;
-  for (int idx = threadIdx.x; idx < total; idx += 256) {
+  for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
     const int r = idx / ncols, c = idx - r * ncols;
     float v = stage[r * ld + c];
     if (ra.res) v += ra.res[(row0 + r) * ra.ldres + col0 + c];
@@ -604,6 +604,78 @@ int launch_fused(const Plan &p, int64_t n_rows, const RowsArgs &ra,
   return 0;
 }
 
+// Plain row MLP (PRO_ROWS) for SMALL row counts: 16-row tiles and EIGHT waves
+// per workgroup.  With K ~ 3k vertices there are fewer tiles than CUs, so the
+// 4-wave kernel leaves one wave per SIMD running a serial chain of
+// (L2 load -> 20 MFMAs) groups with nothing to hide the latency behind; eight
+// waves split the output columns 8 ways (<= 3 column tiles each) and give
+// every SIMD two waves.
+constexpr int kRowsWaves = 8;
+
+__global__ __launch_bounds__(64 * kRowsWaves) void rows_mlp_kernel(
+    ChainDev chain, int64_t n_rows, RowsArgs ra, int stage_off) {
+  constexpr int ROWS = 16, NW = kRowsWaves;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float *tile = reinterpret_cast<float *>(smem);
+  float *stage = stage_off >= 0 ? tile + stage_off : tile;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t n_tiles = (n_rows + ROWS - 1) / ROWS;
+  const int ld0 = lds_ld(16 * chain.l[0].kq);
+  for (int64_t tile_id = blockIdx.x; tile_id < n_tiles; tile_id += gridDim.x) {
+    const int64_t row0 = tile_id * ROWS;
+    const int rows_valid =
+        (int)((n_rows - row0 < ROWS) ? (n_rows - row0) : ROWS);
+    const int kc = 16 * chain.l[0].kq;
+    for (int idx = threadIdx.x; idx < ROWS * kc; idx += 64 * NW) {
+      const int r = idx / kc, c = idx - r * kc;
+      float v = 0.0f;
+      if (r < rows_valid) {
+        if (c < ra.nx)
+          v = ra.x[(row0 + r) * ra.ldx + c];
+        else if (c < ra.nx + ra.nx2)
+          v = ra.x2[(row0 + r) * ra.ldx2 + (c - ra.nx)];
+      }
+      tile[r * ld0 + c] = v;
+    }
+    __syncthreads();
+    for (int li = 0; li + 1 < chain.n; ++li) {
+      const LayerDev &L = chain.l[li];
+      layer_pass_dispatch<1, false, NW>(tile, lds_ld(16 * L.kq), tile,
+                                        lds_ld(16 * L.nt), L, 0, wave, lane);
+    }
+    const LayerDev &L = chain.l[chain.n - 1];
+    const int ld_in = lds_ld(16 * L.kq);
+    for (int t0 = 0; t0 < L.nt; t0 += kMaxTilesPerPass) {
+      int tiles = L.nt - t0;
+      if (tiles > kMaxTilesPerPass) tiles = kMaxTilesPerPass;
+      const int ncols = 16 * tiles;
+      const int ld_st = lds_ld(ncols);
+      layer_pass_dispatch<1, false, NW>(tile, ld_in, stage, ld_st, L, t0, wave,
+                                        lane);
+      consume_rows<ROWS>(stage, ld_st, row0, rows_valid, 16 * t0, ncols, ra);
+      __syncthreads();
+    }
+  }
+}
+
+int launch_rows8(const Plan &p, int64_t n_rows, const RowsArgs &ra,
+                 hipStream_t stream) {
+  const size_t lds = plan_lds_bytes(p, 16);
+  PGNN_REQUIRE(lds <= 160 * 1024, PGNN_E_UNSUPPORTED,
+               "mlp: layer too wide for the LDS tile");
+  auto kern = rows_mlp_kernel;
+  PGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                               hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)lds));
+  const int64_t n_tiles = (n_rows + 15) / 16;
+  const int stage_off = p.stage_cols ? 16 * p.tile_floats_per_row : -1;
+  hipLaunchKernelGGL(kern, dim3((unsigned)n_tiles), dim3(64 * kRowsWaves), lds,
+                     stream, p.chain, n_rows, ra, stage_off);
+  PGNN_HIP(hipGetLastError());
+  return 0;
+}
+
 int fill_lowest(float *out, int64_t count, hipStream_t stream) {
   PGNN_HIP(hipMemsetD32Async((hipDeviceptr_t)out, (int)kFloatLowestBits,
                              (size_t)count, stream));
@@ -635,7 +707,10 @@ extern "C" int pgnn_mlp_fwd(const float *x, int64_t ld_x, int32_t nx,
   PoolArgs pa = {};
   EdgeArgs ea = {};
   SegArgs sa = {};
+  // fewer 16-row tiles than ~2 per CU: the 8-wave kernel (latency bound);
   // small row counts: 16-row tiles keep all CUs busy; large: 64-row tiles
+  if (n_rows <= 32 * (int64_t)device_cu_count() && !(g_mlp_debug & 512))
+    return launch_rows8(p, n_rows, ra, stream);
   if (n_rows <= 64 * (int64_t)device_cu_count())
     return launch_fused<1, PRO_ROWS>(p, n_rows, ra, pa, ea, sa, stream);
   return launch_fused<4, PRO_ROWS>(p, n_rows, ra, pa, ea, sa, stream);
@@ -725,7 +800,8 @@ extern "C" int pgnn_edge_mlp_scatter_max_fwd(
 // P = [h, x] W1 + b1; plus the lowest() fill of the aggregation buffer.  Three
 // launches + a memset in the unfused form (~46 us per iteration at K = 2.9k,
 // each a 184-workgroup grid that ends before it fills the chip); here one
-// 16-row tile per workgroup keeps [h, x] in LDS for both chains.
+// 16-row tile per (8-wave, see rows_mlp_kernel) workgroup keeps [h, x] in LDS
+// for both chains.
 namespace {
 
 struct PreEdgeArgs {
@@ -742,7 +818,7 @@ struct PreEdgeArgs {
   int ld_tile, ld_scratch;  // LDS leading dimensions
 };
 
-__global__ __launch_bounds__(256) void vertex_pre_edge_kernel(
+__global__ __launch_bounds__(64 * kRowsWaves) void vertex_pre_edge_kernel(
     ChainDev off, LayerDev pl, PreEdgeArgs a) {
   constexpr int ROWS = 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -755,7 +831,7 @@ __global__ __launch_bounds__(256) void vertex_pre_edge_kernel(
   const int rows_valid =
       (int)((a.n - row0 < ROWS) ? (a.n - row0) : ROWS);
   const int kc = 16 * pl.kq;
-  for (int idx = threadIdx.x; idx < ROWS * kc; idx += 256) {
+  for (int idx = threadIdx.x; idx < ROWS * kc; idx += 64 * kRowsWaves) {
     const int r = idx / kc, c = idx - r * kc;
     float v = 0.0f;
     if (r < rows_valid) {
@@ -768,7 +844,7 @@ __global__ __launch_bounds__(256) void vertex_pre_edge_kernel(
   }
   // lowest() rows of the aggregation buffer the edge kernel maxes into
   if (a.agg) {
-    for (int idx = threadIdx.x; idx < rows_valid * (int)a.ld_agg; idx += 256)
+    for (int idx = threadIdx.x; idx < rows_valid * (int)a.ld_agg; idx += 64 * kRowsWaves)
       a.agg[row0 * a.ld_agg + idx] = kFloatLowest;
   }
   __syncthreads();
@@ -780,13 +856,13 @@ __global__ __launch_bounds__(256) void vertex_pre_edge_kernel(
     const LayerDev &L = off.l[li];
     const float *in = li == 0 ? tile : scratch;
     const int ld_in = li == 0 ? a.ld_tile : lds_ld(16 * L.kq);
-    layer_pass_dispatch<1, false>(in, ld_in, scratch, lds_ld(16 * L.nt), L, 0,
+    layer_pass_dispatch<1, false, kRowsWaves>(in, ld_in, scratch, lds_ld(16 * L.nt), L, 0,
                                   wave, lane);
     delta = scratch;
     ld_delta = lds_ld(16 * L.nt);
   }
   // Q = (x + delta) @ wx, the same expression as offset_apply_kernel
-  for (int idx = threadIdx.x; idx < rows_valid * (int)a.ld_pq; idx += 256) {
+  for (int idx = threadIdx.x; idx < rows_valid * (int)a.ld_pq; idx += 64 * kRowsWaves) {
     const int r = idx / (int)a.ld_pq, c = idx - r * (int)a.ld_pq;
     float x0 = a.xyz[(row0 + r) * 3], x1 = a.xyz[(row0 + r) * 3 + 1],
           x2 = a.xyz[(row0 + r) * 3 + 2];
@@ -800,7 +876,7 @@ __global__ __launch_bounds__(256) void vertex_pre_edge_kernel(
   }
   // P = [h, x] @ W1 + b1
   const int ld_st = lds_ld(16 * pl.nt);
-  layer_pass_dispatch<1, false>(tile, a.ld_tile, stage, ld_st, pl, 0, wave,
+  layer_pass_dispatch<1, false, kRowsWaves>(tile, a.ld_tile, stage, ld_st, pl, 0, wave,
                                 lane);
   RowsArgs ra = {};
   ra.y = a.P;
@@ -872,8 +948,8 @@ extern "C" int pgnn_vertex_pre_edge_fwd(
   PGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)lds));
-  hipLaunchKernelGGL(kern, dim3((unsigned)((n_vertices + 15) / 16)), dim3(256),
-                     lds, stream, off, pl, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)((n_vertices + 15) / 16)),
+                     dim3(64 * kRowsWaves), lds, stream, off, pl, a);
   PGNN_HIP(hipGetLastError());
   return 0;
   PGNN_GUARD_END

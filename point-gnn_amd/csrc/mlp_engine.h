@@ -45,8 +45,9 @@ constexpr int kMaxTilesPerPass = 20;  // 4 waves x NT<=5 column tiles = 320 cols
 
 __host__ __device__ inline int lds_ld(int width16) { return width16 + 8; }
 
-// acc[m][j] += tile[16m.., :] @ W[:, tile t0 + wave + 4j]
-template <int MSUB, int NT>
+// acc[m][j] += tile[16m.., :] @ W[:, tile t0 + wave + NW*j]  (NW waves share
+// the N dimension; 4 by default, 8 for the latency-bound 16-row kernels)
+template <int MSUB, int NT, int NW = 4>
 __device__ __forceinline__ void gemm_tile(const float *__restrict__ tile, int ld,
                                           const LayerDev &L, int t0, int wave,
                                           int lane, v4f (&acc)[MSUB][NT]) {
@@ -57,7 +58,7 @@ __device__ __forceinline__ void gemm_tile(const float *__restrict__ tile, int ld
   int toff[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
-    int t = t0 + wave + 4 * j;
+    int t = t0 + wave + NW * j;
     if (t > L.nt - 1) t = L.nt - 1;  // clamp: load something valid, discard later
     toff[j] = t * 64;
   }
@@ -113,15 +114,16 @@ __device__ __forceinline__ void gemm_tile(const float *__restrict__ tile, int ld
 
 // out[row][col - 16*t0] = act(acc + bias[col]); C/D layout of the 16x16 MFMA:
 // col = lane & 15, row = 4*(lane >> 4) + r.
-template <int MSUB, int NT>
+template <int MSUB, int NT, int NW = 4>
 __device__ __forceinline__ void store_acc(float *__restrict__ out, int ldo,
                                           const LayerDev &L, int t0, int wave,
                                           int lane, const v4f (&acc)[MSUB][NT]) {
   const float *bias = L.wp + (size_t)L.kq * L.nt * 256;
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
-    const int t = t0 + wave + 4 * j;
-    if (t < L.nt) {
+    const int t = t0 + wave + NW * j;
+    // (with NW = 8 a wave's last tile can lie beyond this pass's 20 tiles)
+    if (t < L.nt && t - t0 < kMaxTilesPerPass) {
       const int col = t * 16 + (lane & 15);
       const float bv = bias[col];
       const bool relu = col >= L.relu_from;
@@ -459,13 +461,14 @@ __device__ __forceinline__ bool layer_pass_segmax_fast_auto(
 
 // One pass (<= 320 output columns starting at column tile t0) of layer L:
 // GEMM from `in`, barrier, activated store to `out` (may alias `in`), barrier.
-template <int MSUB, int NT, bool TRANSPOSED>
+template <int MSUB, int NT, bool TRANSPOSED, int NW = 4>
 __device__ __forceinline__ void layer_pass(const float *in, int ld_in, float *out,
                                            int ld_out, const LayerDev &L, int t0,
                                            int wave, int lane, bool skip_gemm) {
+  static_assert(!TRANSPOSED || NW == 4, "transposed stage is 4-wave only");
   v4f acc[MSUB][NT];
   if (!skip_gemm) {
-    gemm_tile<MSUB, NT>(in, ld_in, L, t0, wave, lane, acc);
+    gemm_tile<MSUB, NT, NW>(in, ld_in, L, t0, wave, lane, acc);
   } else {  // ablation builds only
 #pragma unroll
     for (int m = 0; m < MSUB; ++m)
@@ -473,14 +476,14 @@ __device__ __forceinline__ void layer_pass(const float *in, int ld_in, float *ou
       for (int j = 0; j < NT; ++j) acc[m][j] = (v4f){0.f, 0.f, 0.f, 0.f};
   }
   __syncthreads();  // every wave is done reading `in` (in-place overwrite)
-  if (TRANSPOSED)
+  if constexpr (TRANSPOSED)
     store_acc_T<MSUB, NT>(out, L, t0, wave, lane, acc);
   else
-    store_acc<MSUB, NT>(out, ld_out, L, t0, wave, lane, acc);
+    store_acc<MSUB, NT, NW>(out, ld_out, L, t0, wave, lane, acc);
   __syncthreads();
 }
 
-template <int MSUB, bool TRANSPOSED>
+template <int MSUB, bool TRANSPOSED, int NW = 4>
 __device__ __forceinline__ void layer_pass_dispatch(const float *in, int ld_in,
                                                     float *out, int ld_out,
                                                     const LayerDev &L, int t0,
@@ -488,20 +491,20 @@ __device__ __forceinline__ void layer_pass_dispatch(const float *in, int ld_in,
                                                     bool skip_gemm = false) {
   int tiles = L.nt - t0;
   if (tiles > kMaxTilesPerPass) tiles = kMaxTilesPerPass;
-  if constexpr (MSUB == 4) {
+  if constexpr (MSUB == 4 && NW == 4) {
     if (use_split(MSUB, tiles) && !skip_gemm) {
       layer_pass_split<4, 3, TRANSPOSED>(in, ld_in, out, ld_out, L, t0, wave,
                                          lane);
       return;
     }
   }
-  const int ntw = (tiles + 3) >> 2;  // column tiles per wave (wave-uniform)
+  const int ntw = (tiles + NW - 1) / NW;  // column tiles per wave (wave-uniform)
   switch (ntw) {
-    case 1: layer_pass<MSUB, 1, TRANSPOSED>(in, ld_in, out, ld_out, L, t0, wave, lane, skip_gemm); break;
-    case 2: layer_pass<MSUB, 2, TRANSPOSED>(in, ld_in, out, ld_out, L, t0, wave, lane, skip_gemm); break;
-    case 3: layer_pass<MSUB, 3, TRANSPOSED>(in, ld_in, out, ld_out, L, t0, wave, lane, skip_gemm); break;
-    case 4: layer_pass<MSUB, 4, TRANSPOSED>(in, ld_in, out, ld_out, L, t0, wave, lane, skip_gemm); break;
-    default: layer_pass<MSUB, 5, TRANSPOSED>(in, ld_in, out, ld_out, L, t0, wave, lane, skip_gemm); break;
+    case 1: layer_pass<MSUB, 1, TRANSPOSED, NW>(in, ld_in, out, ld_out, L, t0, wave, lane, skip_gemm); break;
+    case 2: layer_pass<MSUB, 2, TRANSPOSED, NW>(in, ld_in, out, ld_out, L, t0, wave, lane, skip_gemm); break;
+    case 3: layer_pass<MSUB, 3, TRANSPOSED, NW>(in, ld_in, out, ld_out, L, t0, wave, lane, skip_gemm); break;
+    case 4: layer_pass<MSUB, 4, TRANSPOSED, NW>(in, ld_in, out, ld_out, L, t0, wave, lane, skip_gemm); break;
+    default: layer_pass<MSUB, 5, TRANSPOSED, NW>(in, ld_in, out, ld_out, L, t0, wave, lane, skip_gemm); break;
   }
 }
 

@@ -293,6 +293,10 @@ def _store(params, dev):
     (1, [300, 64, 3], True), (17, [300, 300, 300], False),
     (2932, [303, 300], True), (70000, [20, 33, 7], False),
     (100, [512, 256, 256], False), (257, [4, 32, 64, 128, 300], False),
+    # > 320 output columns = two column passes, on the 8-wave small-row kernel
+    # (a wave's third tile lies beyond the first pass) and on the 4-wave ones
+    (352, [256, 512], False), (17, [16, 330], True), (352, [128, 256, 512], False),
+    (20000, [256, 512], False),
 ])
 def test_mlp_forward_matches_numpy(dev, rows, widths, is_logits):
     from pointgnn_amd import gnn
