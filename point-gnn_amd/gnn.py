@@ -336,6 +336,11 @@ class PointSetPooling(object):
         return mlp_forward(out_chain, agg, point_chain.n_out)
 
 
+# when set to a list, every GraphNetAutoCenter call appends its (P, Q) per-vertex
+# tensors: bench.py times the edge kernel on a frame's real inputs with it
+EDGE_INPUT_TAP = None
+
+
 class GraphNetAutoCenter(object):
     """gnn.py:285-373."""
 
@@ -418,6 +423,8 @@ class GraphNetAutoCenter(object):
             off_chain.n if off_chain is not None else 0, p_chain.array,
             _lib.ptr(wx_dev), k, _lib.ptr(p), _lib.ptr(q), wq, _lib.ptr(agg),
             agg.stride(0), st), "pgnn_vertex_pre_edge_fwd")
+        if EDGE_INPUT_TAP is not None:   # measurement hook (bench.py)
+            EDGE_INPUT_TAP.append((p, q))
         # per-edge: ReLU(P[src] - Q[dst]) -> remaining edge layers -> max
         _lib.check(lib.pgnn_edge_mlp_scatter_max_fwd(
             _lib.ptr(p), _lib.ptr(q), wq, int(rest.k_in), _lib.ptr(e),
