@@ -375,6 +375,22 @@ int pgnn_box_encode_f64(const int32_t *cls_labels, const float *xyz,
                         int32_t n_table, int64_t n_rows, int32_t boxes_per_row,
                         float *encoded, void *stream);
 
+/* Point-wise parts of the training augmentations (models/preprocess.py:44-78
+ * random_rotation_all / random_flip_all, :239-326 random_box_shift) on a
+ * float64 [n,3] device buffer (the reference's cloud is float64 from the first
+ * `xyz.dot(R.T)` until train.py:124).  rot_3x3 / shift_3 / box_record_24 are
+ * HOST pointers.  pgnn_points_affine_f64: xyz <- xyz @ rot^T + shift for the
+ * points with select[i] != 0 (select null: all; rot null: identity).
+ * pgnn_points_in_box_f64: inside[i] (nullable) = 1 when point i is strictly
+ * inside the box record (layout of pgnn_assign_box_labels), *count (nullable,
+ * device) = number of inside points with exclude[i] == 0 (exclude nullable). */
+int pgnn_points_affine_f64(double *xyz, int64_t n_points, const double *rot_3x3,
+                           const double *shift_3, const int32_t *select,
+                           void *stream);
+int pgnn_points_in_box_f64(const double *xyz, int64_t n_points,
+                           const double *box_record_24, const int32_t *exclude,
+                           int32_t *inside, int32_t *count, void *stream);
+
 size_t pgnn_kitti_ingest_workspace_bytes(int64_t n_points);
 int pgnn_kitti_cam_points_in_image(
     const float *velo_points, int64_t n_points, const float *velo_to_cam_3x4,

@@ -116,6 +116,9 @@ _SIGNATURES = {
                                        c_vp, c_vp, c_vp]),
     "pgnn_box_encode_f64": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i64,
                                     c_i32, c_vp, c_vp]),
+    "pgnn_points_affine_f64": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
+    "pgnn_points_in_box_f64": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp,
+                                       c_vp]),
     # KITTI frame ingest
     "pgnn_kitti_ingest_workspace_bytes": (c_sz, [c_i64]),
     "pgnn_kitti_cam_points_in_image": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_f64,

@@ -9,6 +9,8 @@
 // per vertex walks the (few dozen) boxes in the same order.  Float64 like the
 // reference (`np.matmul(xyz_f32, normals_f64.T)`); latency-bound, negligible
 // bytes.
+#include <string.h>
+
 #include "pgnn_common.h"
 
 namespace pgnn {
@@ -102,10 +104,114 @@ __global__ void box_encode_f64_kernel(const int32_t *__restrict__ labels,
   for (int i = 0; i < 7; ++i) out[idx * 7 + i] = (float)d[i];
 }
 
+// ---- augmentation primitives (models/preprocess.py) on float64 points -------
+// The reference's augmentations turn the float32 cloud into float64 with the
+// first `xyz.dot(R.T)` and keep it there until train.py:124 casts back; the
+// point-wise parts run here on a float64 [n,3] buffer.
+
+// xyz <- xyz @ rot^T + shift for the selected points (select null: all)
+__global__ void points_affine_kernel(double *__restrict__ xyz, int64_t n,
+                                     const double r0, const double r1,
+                                     const double r2, const double r3,
+                                     const double r4, const double r5,
+                                     const double r6, const double r7,
+                                     const double r8, const double s0,
+                                     const double s1, const double s2,
+                                     int has_rot,
+                                     const int32_t *__restrict__ select) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (select && select[i] == 0) return;
+  double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+  if (has_rot) {
+    const double nx = (x * r0 + y * r1) + z * r2;
+    const double ny = (x * r3 + y * r4) + z * r5;
+    const double nz = (x * r6 + y * r7) + z * r8;
+    x = nx;
+    y = ny;
+    z = nz;
+  }
+  xyz[3 * i] = x + s0;
+  xyz[3 * i + 1] = y + s1;
+  xyz[3 * i + 2] = z + s2;
+}
+
+// inside[i] = point i lies strictly inside box `rec` (sel_xyz_in_box3d on
+// float64 points); *count += number of inside points with exclude[i] == 0
+__global__ void points_in_box_f64_kernel(const double *__restrict__ xyz,
+                                         int64_t n, LabelRecord rec,
+                                         const int32_t *__restrict__ exclude,
+                                         int32_t *__restrict__ inside,
+                                         int32_t *__restrict__ count) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool in = false;
+  if (i < n) {
+    const double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+    in = true;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const double p = (x * rec.normals[3 * k] + y * rec.normals[3 * k + 1]) +
+                       z * rec.normals[3 * k + 2];
+      in = in && p > rec.lower[k] && p < rec.upper[k];
+    }
+    if (inside) inside[i] = in ? 1 : 0;
+    if (exclude && exclude[i] != 0) in = false;
+  }
+  if (count) {
+    const unsigned long long bal = __ballot(in);
+    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(count, (int)__popcll(bal));
+  }
+}
+
 }  // namespace
 }  // namespace pgnn
 
 using namespace pgnn;
+
+extern "C" int pgnn_points_affine_f64(double *xyz, int64_t n_points,
+                                      const double *rot_3x3,
+                                      const double *shift_3,
+                                      const int32_t *select, void *stream_) {
+  PGNN_GUARD_BEGIN
+  hipStream_t stream = (hipStream_t)stream_;
+  PGNN_REQUIRE(n_points >= 0, PGNN_E_INVALID, "points_affine: bad size");
+  if (n_points == 0) return 0;
+  PGNN_REQUIRE(xyz, PGNN_E_INVALID, "points_affine: null pointer");
+  double r[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, s[3] = {0, 0, 0};
+  if (rot_3x3)
+    for (int i = 0; i < 9; ++i) r[i] = rot_3x3[i];
+  if (shift_3)
+    for (int i = 0; i < 3; ++i) s[i] = shift_3[i];
+  hipLaunchKernelGGL(points_affine_kernel,
+                     dim3((unsigned)((n_points + 255) / 256)), dim3(256), 0,
+                     stream, xyz, n_points, r[0], r[1], r[2], r[3], r[4], r[5],
+                     r[6], r[7], r[8], s[0], s[1], s[2], rot_3x3 ? 1 : 0,
+                     select);
+  PGNN_HIP(hipGetLastError());
+  return 0;
+  PGNN_GUARD_END
+}
+
+extern "C" int pgnn_points_in_box_f64(const double *xyz, int64_t n_points,
+                                      const double *box_record_24,
+                                      const int32_t *exclude, int32_t *inside,
+                                      int32_t *count, void *stream_) {
+  PGNN_GUARD_BEGIN
+  hipStream_t stream = (hipStream_t)stream_;
+  PGNN_REQUIRE(n_points >= 0 && box_record_24, PGNN_E_INVALID,
+               "points_in_box: bad argument");
+  if (count) PGNN_HIP(hipMemsetAsync(count, 0, 4, stream));
+  if (n_points == 0) return 0;
+  PGNN_REQUIRE(xyz, PGNN_E_INVALID, "points_in_box: null pointer");
+  LabelRecord rec;
+  memcpy(&rec, box_record_24, sizeof rec);
+  hipLaunchKernelGGL(points_in_box_f64_kernel,
+                     dim3((unsigned)((n_points + 255) / 256)), dim3(256), 0,
+                     stream, xyz, n_points, rec, exclude, inside, count);
+  PGNN_HIP(hipGetLastError());
+  return 0;
+  PGNN_GUARD_END
+}
 
 extern "C" int pgnn_assign_box_labels(const float *xyz, int64_t n_points,
                                       const double *label_records,
