@@ -20,7 +20,9 @@ int g_edge_msub = 0;          // 0 = auto, else force 16*msub-row tiles
 int g_pool_msub = 0;
 void *g_mlp_ts = nullptr;  // device buffer for per-tile timestamps (profiling)
 int g_mlp_debug = 0;  // ablation mask (benchmarks only): 1 = no gather loads,
-                      // 2 = no last-layer GEMM, 4 = no epilogue
+                      // 2 = no last-layer GEMM, 4 = no epilogue, 16 = print
+                      // occupancy, 32 = no one-segment fast path, 64 = no
+                      // prologue priority, 512 = 4-wave kernel for small rows
 }
 
 namespace {

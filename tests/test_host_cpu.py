@@ -165,6 +165,29 @@ def test_error_reporting_without_gpu():
     assert lib.pgnn_packed_fc_floats(303, 300) == 19 * 19 * 256 + 19 * 16
     with pytest.raises(L.PointGnnHipError):
         L.check(-1, "demo")
+    # the widened entries validate before touching HIP as well
+    assert lib.pgnn_nms_boxes_3d(None, None, None, None, -1, 0.5, 1, 10.0, -1,
+                                 None, 0, None, None, None, None, None,
+                                 None) == -1
+    assert lib.pgnn_nms_boxes_3d(None, None, None, None, 5, 0.5, 9, 10.0, -1,
+                                 None, 0, None, None, None, None, None,
+                                 None) == -1          # mode out of range
+    assert b"nms_boxes_3d" in lib.pgnn_last_error()
+    assert lib.pgnn_nms_workspace_bytes(-1) == 0
+    assert 0 < lib.pgnn_nms_workspace_bytes(100) < \
+        lib.pgnn_nms_workspace_bytes(10000)
+    assert lib.pgnn_box_decode_f32(None, None, None, None, 0, 5, 0, None,
+                                   None) == -1        # boxes_per_row = 0
+    assert lib.pgnn_kitti_cam_points_in_image(
+        None, 10, None, None, 1242.0, 375.0, None, 0, 0, None, 0, None, None,
+        1, 10, None, None) == -1                       # no count pointer
+    assert lib.pgnn_kitti_ingest_workspace_bytes(120000) > 0
+    assert lib.pgnn_assign_box_labels(None, -1, None, 0, None, None, None,
+                                      None, None) == -1
+    assert lib.pgnn_vertex_pre_edge_fwd(None, 0, 0, None, None, 0, None, None,
+                                        5, None, None, 0, None, 0, None) == -1
+    assert lib.pgnn_points_in_box_f64(None, 5, None, None, None, None,
+                                      None) == -1
 
 
 def _emulate_mfma_layer(x, packed, k_in, n_out):
