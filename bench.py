@@ -333,6 +333,8 @@ def main():
     ap.add_argument("--train", action="store_true",
                     help="BASELINE config 4: training step instead of inference")
     ap.add_argument("--frames-per-gpu", type=int, default=2)
+    ap.add_argument("--tune", action="append", default=[],
+                    help="key=value library tunable (experiments; repeatable)")
     args = ap.parse_args()
 
     import torch
@@ -340,6 +342,10 @@ def main():
     from pointgnn_amd import configs, weights
     from pointgnn_amd.engine import InferenceEngine, shard_frames
     from pointgnn_amd.synthetic import synthetic_cloud
+    for kv in args.tune:
+        from pointgnn_amd import _lib as _pg_lib
+        key, val = kv.split("=")
+        _pg_lib.set_tunable(key, int(val))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -35,6 +35,7 @@ extern int g_pool_msub;
 extern int g_mlp_debug;
 extern void *g_mlp_ts;
 extern int g_scatter_nt;
+extern int g_wgrad_wg_target;
 
 }  // namespace pgnn
 
@@ -83,6 +84,11 @@ extern "C" int pgnn_set_tunable(const char *key, int value) {
   }
   if (!strcmp(key, "pool_msub")) {
     pgnn::g_pool_msub = value;
+    return 0;
+  }
+  if (!strcmp(key, "wgrad_wg_target")) {
+    if (value < 1) return pgnn::fail(PGNN_E_INVALID, "wgrad_wg_target < 1");
+    pgnn::g_wgrad_wg_target = value;
     return 0;
   }
   return pgnn::fail(PGNN_E_INVALID, "unknown tunable");

@@ -122,7 +122,8 @@ __global__ void segmax_count_kernel(const float *__restrict__ data, int64_t ld,
                                     const int32_t *__restrict__ seg, int64_t rows,
                                     int cols, int nseg,
                                     const float *__restrict__ out, int64_t ldo,
-                                    int32_t *__restrict__ count) {
+                                    int32_t *__restrict__ count,
+                                    int relu_mask) {
   const int64_t total = rows * cols;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
@@ -130,7 +131,12 @@ __global__ void segmax_count_kernel(const float *__restrict__ data, int64_t ld,
     const int c = (int)(idx - r * cols);
     const int s = seg[r];
     if (s < 0 || s >= nseg) continue;
-    if (data[r * ld + c] == out[(int64_t)s * ldo + c])
+    // With relu_mask the route kernel gives nothing to entries <= 0, and a
+    // maximum <= 0 selects only such entries, so their tie counts are never
+    // read: skipping them removes the hot atomics of all-zero (post-ReLU)
+    // segments, dozens of adds to one address each.
+    const float v = data[r * ld + c];
+    if (v == out[(int64_t)s * ldo + c] && (!relu_mask || v > 0.0f))
       atomicAdd(&count[(int64_t)s * cols + c], 1);
   }
 }
@@ -156,6 +162,59 @@ __global__ void segmax_route_kernel(const float *__restrict__ data, int64_t ld,
         g = gout[(int64_t)s * ldg + c] / (float)count[(int64_t)s * cols + c];
     }
     gdata[r * ldd + c] = g;
+  }
+}
+
+// float4 forms of the two kernels above (cols % 4 == 0, 16-byte aligned rows):
+// a thread owns 4 consecutive columns of one row; the scalar forms read the
+// [E, C] matrix at ~1.6 TB/s, these stream it.
+__global__ void segmax_count4_kernel(const float *__restrict__ data, int64_t ld,
+                                     const int32_t *__restrict__ seg,
+                                     int64_t rows, int cols4, int nseg,
+                                     const float *__restrict__ out, int64_t ldo,
+                                     int32_t *__restrict__ count,
+                                     int relu_mask) {
+  const int64_t total = rows * cols4;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = idx / cols4;
+    const int c = 4 * (int)(idx - r * cols4);
+    const int s = seg[r];
+    if (s < 0 || s >= nseg) continue;
+    const v4f d = *reinterpret_cast<const v4f *>(data + r * ld + c);
+    const v4f o = *reinterpret_cast<const v4f *>(out + (int64_t)s * ldo + c);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (d[i] == o[i] && (!relu_mask || d[i] > 0.0f))
+        atomicAdd(&count[(int64_t)s * (4 * cols4) + c + i], 1);
+  }
+}
+
+__global__ void segmax_route4_kernel(const float *__restrict__ data, int64_t ld,
+                                     const int32_t *__restrict__ seg,
+                                     int64_t rows, int cols4, int nseg,
+                                     const float *__restrict__ out, int64_t ldo,
+                                     const float *__restrict__ gout, int64_t ldg,
+                                     const int32_t *__restrict__ count,
+                                     float *__restrict__ gdata, int64_t ldd,
+                                     int relu_mask) {
+  const int64_t total = rows * cols4;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = idx / cols4;
+    const int c = 4 * (int)(idx - r * cols4);
+    const int s = seg[r];
+    v4f g = (v4f){0.f, 0.f, 0.f, 0.f};
+    if (s >= 0 && s < nseg) {
+      const v4f d = *reinterpret_cast<const v4f *>(data + r * ld + c);
+      const v4f o = *reinterpret_cast<const v4f *>(out + (int64_t)s * ldo + c);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (d[i] == o[i] && (!relu_mask || d[i] > 0.0f))
+          g[i] = gout[(int64_t)s * ldg + c + i] /
+                 (float)count[(int64_t)s * (4 * cols4) + c + i];
+    }
+    *reinterpret_cast<v4f *>(gdata + r * ldd + c) = g;
   }
 }
 
@@ -476,10 +535,26 @@ extern "C" int pgnn_scatter_max_bwd_f32(
                PGNN_E_INVALID, "scatter_max_bwd: null pointer");
   PGNN_HIP(hipMemsetAsync(tie_count_ws, 0, (size_t)num_segments * n_cols * 4,
                           stream));
+  const bool vec4 =
+      n_cols % 4 == 0 && ld_data % 4 == 0 && ld_out % 4 == 0 &&
+      ld_grad_data % 4 == 0 && (uintptr_t)data % 16 == 0 &&
+      (uintptr_t)out % 16 == 0 && (uintptr_t)grad_data % 16 == 0;
+  if (vec4) {
+    const unsigned g4 = grid_for(n_rows * (n_cols / 4), 8192);
+    hipLaunchKernelGGL(segmax_count4_kernel, dim3(g4), dim3(256), 0, stream,
+                       data, ld_data, seg_ids, n_rows, n_cols / 4, num_segments,
+                       out, ld_out, tie_count_ws, relu_mask);
+    hipLaunchKernelGGL(segmax_route4_kernel, dim3(g4), dim3(256), 0, stream,
+                       data, ld_data, seg_ids, n_rows, n_cols / 4, num_segments,
+                       out, ld_out, grad_out, ld_grad_out, tie_count_ws,
+                       grad_data, ld_grad_data, relu_mask);
+    PGNN_HIP(hipGetLastError());
+    return 0;
+  }
   const unsigned g = grid_for(n_rows * n_cols, 8192);
   hipLaunchKernelGGL(segmax_count_kernel, dim3(g), dim3(256), 0, stream, data,
                      ld_data, seg_ids, n_rows, n_cols, num_segments, out, ld_out,
-                     tie_count_ws);
+                     tie_count_ws, relu_mask);
   hipLaunchKernelGGL(segmax_route_kernel, dim3(g), dim3(256), 0, stream, data,
                      ld_data, seg_ids, n_rows, n_cols, num_segments, out, ld_out,
                      grad_out, ld_grad_out, tie_count_ws, grad_data,
@@ -489,12 +564,19 @@ extern "C" int pgnn_scatter_max_bwd_f32(
   PGNN_GUARD_END
 }
 
+namespace pgnn {
+// workgroups (in-blocks x row slices) one weight-gradient launch aims for
+// (768 = 256 CUs x 3 resident workgroups of 48 KB LDS: exactly one wave of
+// workgroups; 1024 left a quarter-filled second wave and cost 6 % of the step)
+int g_wgrad_wg_target = 768;
+}  // namespace pgnn
+
 namespace {
 int wg_slices(int64_t rows, int k_in) {
-  // ~4 workgroups per CU in flight: (in-blocks x slices) ~ 1024
+  // one full wave of workgroups: (in-blocks x slices) ~ g_wgrad_wg_target
   const int64_t in_blocks = ((int64_t)k_in + 1 + 63) / 64;
   int64_t s = (rows + kWgRows - 1) / kWgRows;
-  int64_t cap = 1024 / in_blocks;
+  int64_t cap = g_wgrad_wg_target / in_blocks;
   if (cap < 1) cap = 1;
   if (s > cap) s = cap;
   if (s < 1) s = 1;
