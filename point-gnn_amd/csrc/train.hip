@@ -314,25 +314,38 @@ __global__ __launch_bounds__(256) void weight_grad_kernel(
   }
 }
 
-__global__ void weight_grad_reduce_kernel(const float *__restrict__ partial,
-                                          int slices, int64_t kin_p, int nout_p,
-                                          int k_in, int n_out, int64_t ld_dw,
-                                          float *__restrict__ dW,
-                                          float *__restrict__ db, int accumulate) {
+// 64 outputs x 4 slice groups per workgroup: group g adds slices g, g+4, ...;
+// the four partial sums meet in LDS and are added in a fixed order, so the
+// result does not depend on timing (a thread per output walking all slices
+// serially ran at 1.8 TB/s: too few threads for the ~150 slices)
+__global__ __launch_bounds__(256) void weight_grad_reduce_kernel(
+    const float *__restrict__ partial, int slices, int64_t kin_p, int nout_p,
+    int k_in, int n_out, int64_t ld_dw, float *__restrict__ dW,
+    float *__restrict__ db, int accumulate) {
+  __shared__ float part[4][64];
   const int64_t total = (int64_t)(k_in + 1) * n_out;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * blockDim.x) {
+  const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+  for (int64_t base = (int64_t)blockIdx.x * 64; base < total;
+       base += (int64_t)gridDim.x * 64) {
+    const int64_t idx = base + o;
     const int64_t i = idx / n_out;
     const int j = (int)(idx - i * n_out);
     float s = 0.0f;
-    for (int sl = 0; sl < slices; ++sl)
-      s += partial[((int64_t)sl * kin_p + i) * nout_p + j];
-    if (i < k_in) {
-      float *o = dW + i * ld_dw + j;
-      *o = accumulate ? *o + s : s;
-    } else if (db) {
-      db[j] = accumulate ? db[j] + s : s;
+    if (idx < total)
+      for (int sl = g; sl < slices; sl += 4)
+        s += partial[((int64_t)sl * kin_p + i) * nout_p + j];
+    part[g][o] = s;
+    __syncthreads();
+    if (g == 0 && idx < total) {
+      s = ((part[0][o] + part[1][o]) + part[2][o]) + part[3][o];
+      if (i < k_in) {
+        float *w = dW + i * ld_dw + j;
+        *w = accumulate ? *w + s : s;
+      } else if (db) {
+        db[j] = accumulate ? db[j] + s : s;
+      }
     }
+    __syncthreads();
   }
 }
 
@@ -635,7 +648,7 @@ extern "C" int pgnn_weight_grad_f32(const float *X, int64_t ld_x, int32_t k_in,
     }
 #undef PGNN_WG
     hipLaunchKernelGGL(weight_grad_reduce_kernel,
-                       dim3(grid_for((int64_t)(k_in + 1) * nc)), dim3(256), 0,
+                       dim3(grid_for((int64_t)(k_in + 1) * nc * 4)), dim3(256), 0,
                        stream, partial, slices, (int64_t)in_blocks * 64,
                        nt * 16, k_in, nc, (int64_t)n_out, dW + c0,
                        db ? db + c0 : nullptr, accumulate);
