@@ -311,6 +311,10 @@ __device__ __forceinline__ void gemm_tile_split(
       }
     }
   }
+  // (Inline-asm weight loads with hand-placed s_waitcnt vmcnt(7) -- exact waits,
+  // both stages truly in flight -- were tried here: +5 % in the bare-loop
+  // micro-benchmark, but 1.5 % SLOWER in the fused kernel and the compiler,
+  // unaware of the asynchronous register writes, broke a parity test.)
 }
 
 // activated value of accumulator `x` in column `col`
