@@ -333,6 +333,8 @@ def main():
     ap.add_argument("--train", action="store_true",
                     help="BASELINE config 4: training step instead of inference")
     ap.add_argument("--frames-per-gpu", type=int, default=2)
+    ap.add_argument("--compute-streams", type=int, default=2,
+                    help="GNN streams of the frame pipeline (1 or 2)")
     ap.add_argument("--tune", action="append", default=[],
                     help="key=value library tunable (experiments; repeatable)")
     args = ap.parse_args()
@@ -395,7 +397,9 @@ def main():
             for i in range(lo, hi):
                 out = engine.run_frame(*frame(i))
             return out
-        return engine.run_frames_pipelined([frame(i) for i in range(lo, hi)])[-1]
+        return engine.run_frames_pipelined(
+            [frame(i) for i in range(lo, hi)],
+            compute_streams=args.compute_streams)[-1]
 
     if args.warmup:
         run(0, args.warmup)
@@ -465,8 +469,12 @@ def main():
                 "N": int(x.shape[0]), "K": n_k, "E0": n_e0, "E1": n_e1,
                 "frames_per_gpu_per_step": 1,
                 "schedule": "sequential, 1 stream" if args.no_pipeline else
-                            "2 HIP streams: graph build of frame i+1 overlaps "
-                            "GNN of frame i",
+                            "%d HIP streams: graph build of frame i+1 overlaps "
+                            "the GNN of frame i%s" % (
+                                1 + args.compute_streams,
+                                "; consecutive frames alternate between two "
+                                "GNN streams" if args.compute_streams > 1
+                                else ""),
                 "parallelism": "frame-parallel x%d (no collective)" % world,
                 "frames_per_sec_per_gpu": fps / world,
                 "algorithmic_gflop_per_frame": total_flops / 1e9,

@@ -44,24 +44,29 @@ class InferenceEngine(object):
         device -- run.py:219-222."""
         return self.graph_fn(xyz, **self.graph_kwargs)
 
-    def run_frames_pipelined(self, frames):
-        """Steady-state loop over independent frames on two HIP streams: while
-        stream C executes the GNN of frame i, stream G builds the graph of
-        frame i+1.  The graph builder needs three host reads per frame (K, E0,
-        E1 size its outputs); they synchronise stream G only, so the host waits
-        for them while the GPU is busy with frame i's message passing.
+    def run_frames_pipelined(self, frames, compute_streams=1):
+        """Steady-state loop over independent frames on HIP streams: while a
+        compute stream executes the GNN of frame i, stream G builds the graph
+        of frame i+1.  The graph builder needs three host reads per frame (K,
+        E0, E1 size its outputs); they synchronise stream G only, so the host
+        waits for them while the GPU is busy with frame i's message passing.
+        With compute_streams = 2 consecutive frames alternate between two
+        compute streams, so the under-filled per-vertex kernels and the tail
+        of one frame's edge kernel overlap the next frame's work.
         frames: iterable of (xyz, intensity) CUDA tensors.  Returns the list of
         (logits, box_encodings); outputs are complete after
-        torch.cuda.synchronize() (or a wait on stream C)."""
+        torch.cuda.synchronize() (or a wait on the compute streams)."""
         frames = list(frames)
         if not frames:
             return []
         if not hasattr(self, "_streams"):
-            self._streams = (torch.cuda.Stream(), torch.cuda.Stream())
-        sg, sc = self._streams
+            self._streams = (torch.cuda.Stream(), torch.cuda.Stream(),
+                             torch.cuda.Stream())
+        sg = self._streams[0]
+        scs = self._streams[1:1 + max(1, min(2, int(compute_streams)))]
         cur = torch.cuda.current_stream()
-        sg.wait_stream(cur)
-        sc.wait_stream(cur)
+        for s in (sg,) + tuple(scs):
+            s.wait_stream(cur)
 
         def build(i):
             with torch.cuda.stream(sg):
@@ -73,6 +78,7 @@ class InferenceEngine(object):
         outs = []
         graph, ev = build(0)
         for i in range(len(frames)):
+            sc = scs[i % len(scs)]
             sc.wait_event(ev)
             with torch.cuda.stream(sc):
                 coords, kps, edges = graph
@@ -83,7 +89,8 @@ class InferenceEngine(object):
             self.last_graph = graph
             if i + 1 < len(frames):
                 graph, ev = build(i + 1)
-        cur.wait_stream(sc)
+        for s in scs:
+            cur.wait_stream(s)
         return outs
 
     def run_frame(self, xyz, intensity, timed=False):

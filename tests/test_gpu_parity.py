@@ -540,8 +540,9 @@ def test_full_size_properties(dev, name, preset):
 
 
 def test_pipelined_frames_equal_sequential(dev):
-    """The two-stream schedule (engine.run_frames_pipelined) must return
-    bit-identical results to frame-at-a-time execution."""
+    """The multi-stream schedules (engine.run_frames_pipelined, one or two
+    GNN streams) must return bit-identical results to frame-at-a-time
+    execution."""
     import torch
     from pointgnn_amd.engine import InferenceEngine
     cfg = configs.car_auto_config(2)
@@ -553,8 +554,8 @@ def test_pipelined_frames_equal_sequential(dev):
         frames.append((T(xyz, dev), T(inten, dev)))
     seq = [eng.run_frame(x, f) for x, f in frames]
     torch.cuda.synchronize()
-    for _ in range(2):
-        pip = eng.run_frames_pipelined(frames)
+    for rep in range(4):
+        pip = eng.run_frames_pipelined(frames, compute_streams=1 + rep % 2)
         torch.cuda.synchronize()
         assert len(pip) == len(seq)
         for (l0, b0), (l1, b1) in zip(seq, pip):
