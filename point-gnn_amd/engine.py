@@ -60,10 +60,9 @@ class InferenceEngine(object):
         if not frames:
             return []
         if not hasattr(self, "_streams"):
-            self._streams = (torch.cuda.Stream(), torch.cuda.Stream(),
-                             torch.cuda.Stream())
+            self._streams = tuple(torch.cuda.Stream() for _ in range(5))
         sg = self._streams[0]
-        scs = self._streams[1:1 + max(1, min(2, int(compute_streams)))]
+        scs = self._streams[1:1 + max(1, min(4, int(compute_streams)))]
         cur = torch.cuda.current_stream()
         for s in (sg,) + tuple(scs):
             s.wait_stream(cur)
