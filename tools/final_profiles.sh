@@ -9,8 +9,9 @@ rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
 timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 timeout 600 python bench.py --train --no-cpu-baseline > $OUT/bench_train.json 2> $OUT/bench_train.err
-for what in infer train detect; do
+for what in bench infer train detect; do
   case $what in
+    bench) CMD="python $ROOT/bench.py --no-cpu-baseline";;
     infer) CMD="python $ROOT/bench.py --steps 16 --warmup 2 --no-cpu-baseline --no-pipeline";;
     train) CMD="python $ROOT/bench.py --train --steps 6 --warmup 2 --no-cpu-baseline";;
     detect) CMD="python $ROOT/tools/kernel_bench.py detect";;
