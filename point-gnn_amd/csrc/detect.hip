@@ -11,10 +11,14 @@
 //   3. one wave per (row, 64 columns) evaluates the pairwise test
 //      "same class and overlap > threshold" for j > i and stores it as a bit
 //      matrix (ballot), so the part that is quadratic runs on the whole chip;
-//   4. a single workgroup replays the reference's sequential scan over rows
-//      that have any bit set: removed set = row & keep, per-component median
-//      by rank counting, IoU of the merged box against the removed ones,
-//      float64 score accumulation, keep-bit update, ordered compaction.
+//   4. the reference's loop is sequential only through the keep flags: ONE
+//      WAVE replays it on the bit matrix (removed set = row & keep, keep &=
+//      ~removed) and writes every surviving row back masked;
+//   5. the per-row arithmetic depends only on that removed set and on
+//      untouched inputs, so it runs for all survivors in parallel, a workgroup
+//      each: per-component median by rank counting, overlap of the merged box
+//      with the removed ones, float64 score sum in a fixed-shape tree;
+//   6. ordered compaction of the survivors.
 // Everything is HBM/latency-bound integer and float64 work; no MFMA.
 #include "pgnn_common.h"
 #include "sort.h"
@@ -310,7 +314,8 @@ __global__ void gather_sorted_kernel(const uint32_t *__restrict__ order,
                                      int64_t m, double appr, int32_t *s_label,
                                      float *s_box, float *s_score,
                                      int32_t *s_attr, Geom *geom,
-                                     int32_t *row_flag) {
+                                     int32_t *row_flag, int32_t *active,
+                                     int32_t *spill_cursor) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m) return;
   const uint32_t o = order[i];
@@ -325,6 +330,8 @@ __global__ void gather_sorted_kernel(const uint32_t *__restrict__ order,
   }
   geom[i] = box_geometry(b, appr);
   row_flag[i] = 0;
+  active[i] = 0;
+  if (i == 0) *spill_cursor = 0;
 }
 
 // bit j of mask[i*words + j/64] <=> j > i, same class, overlap(i, j) > thr
@@ -368,18 +375,20 @@ __global__ __launch_bounds__(64) void overlap_mask_kernel(
 struct ScanArgs {
   int64_t m;
   int words;
-  const unsigned long long *mask;
+  unsigned long long *mask;  // rows of survivors are rewritten masked
   const int32_t *row_flag;
+  int32_t *active;       // [m] survivor with a non-empty removed set
+  int32_t *spill_cursor;  // bump allocator of the spill buffers
   const Geom *geom;
   const int32_t *s_label;
   float *s_box;     // [m,7], merged boxes written in place
   float *s_score;   // [m], accumulated scores written in place
   const int32_t *s_attr;
   int merge, rescore;
-  int32_t *big_list;  // m ints   (used when a removed set exceeds kListCap)
-  float *big_vals;    // 7*(m+1) floats
-  double *big_dbl;    // m doubles
-  unsigned long long *keep_ws;  // words (used when words > kKeepLds)
+  int32_t *big_list;  // 2m ints  (removed sets larger than kListCap)
+  float *big_vals;    // 14m floats
+  double *big_dbl;    // 2m doubles
+  unsigned long long *keep_ws;  // words: the final keep bits
   int32_t *out_label;
   float *out_box;
   float *out_score;
@@ -412,150 +421,166 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int *wave_tot,
   return before + x - v;
 }
 
-__global__ __launch_bounds__(kScanThreads) void nms_scan_kernel(ScanArgs a) {
+// ---- phase 1 of the scan: which boxes survive, and who removed whom ---------
+// The reference loop (nms.py:142-166) is sequential only through the keep
+// flags: box i's removed set is row_i & keep, and the boxes it removes are
+// never looked at again.  One WAVE replays exactly that on the bit matrix --
+// keep words in LDS, no workgroup barriers, the mask row of the next flagged
+// candidate requested while the current one is processed -- and writes each
+// surviving row back MASKED (its removed set).  The per-row arithmetic (median,
+// overlaps, score sum) depends only on that set and on untouched inputs, so it
+// runs afterwards for all rows in parallel (nms_merge_kernel).
+__global__ __launch_bounds__(64) void nms_resolve_kernel(ScanArgs a) {
   __shared__ unsigned long long keep_lds[kKeepLds];
-  __shared__ int list_lds[kListCap];
-  __shared__ float vals_lds[7 * (kListCap + 1)];
-  __shared__ double dbl_lds[kListCap];
-  __shared__ unsigned long long chunk_bits[kScanThreads / 64];
-  __shared__ int wave_tot[kScanThreads / 64];
-  __shared__ float med[7][2];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = threadIdx.x;
   unsigned long long *keep = a.words <= kKeepLds ? keep_lds : a.keep_ws;
-  for (int w = tid; w < a.words; w += kScanThreads) {
+  for (int w = lane; w < a.words; w += 64) {
     const int64_t left = a.m - (int64_t)w * 64;
     keep[w] = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
   }
-  __syncthreads();
-  int64_t pre_row = -1;              // row whose mask words sit in pre_bits
+  int64_t pre_row = -1;  // row whose first 64 mask words sit in pre_bits
   unsigned long long pre_bits = 0ull;
-  for (int64_t i0 = 0; i0 < a.m; i0 += kScanThreads) {
-    // rows of this chunk that can remove anything, in order
-    const bool flagged = i0 + tid < a.m && a.row_flag[i0 + tid] != 0;
-    const unsigned long long fb = __ballot(flagged);
-    if (lane == 0) chunk_bits[wave] = fb;
-    __syncthreads();
-    for (int cw = 0; cw < kScanThreads / 64; ++cw) {
-      // flagged AND still kept; the keep word is re-read after every row that
-      // removed something, so removed rows cost no iteration at all
-      const int64_t kw = (i0 >> 6) + cw;
-      if (kw >= a.words) break;
-      unsigned long long rem = chunk_bits[cw] & keep[kw];
-      while (rem) {
-        const int bit = __builtin_ctzll(rem);
-        rem &= rem - 1;
-        const int64_t i = i0 + cw * 64 + bit;
-        // ---- removed set = row i & keep, compacted in ascending order
-        int n = 0;
-        for (int w0 = 0; w0 < a.words; w0 += kScanThreads) {
-          const int w = w0 + tid;
-          unsigned long long bits = 0ull;
-          if (w < a.words) {
-            const unsigned long long row_bits =
-                (w0 == 0 && pre_row == i) ? pre_bits : a.mask[i * a.words + w];
-            bits = row_bits & keep[w];
-          }
-          // the single workgroup is latency bound: request the next flagged
-          // row of this word now (it may get removed meanwhile; harmless)
-          if (w0 == 0 && rem) {
-            pre_row = i0 + cw * 64 + __builtin_ctzll(rem);
-            if (w < a.words) pre_bits = a.mask[pre_row * a.words + w];
-          }
-          int tot;
-          int pos = n + block_exclusive_scan(__popcll(bits), wave_tot, &tot);
-          if (bits) {
-            keep[w] &= ~bits;
-            while (bits) {
-              const int b = __builtin_ctzll(bits);
-              bits &= bits - 1;
-              const int j = w * 64 + b;
-              if (pos < kListCap) list_lds[pos] = j;
-              a.big_list[pos] = j;
-              ++pos;
-            }
-          }
-          n += tot;
+  int next_flag = lane < a.m ? a.row_flag[lane] : 0;
+  for (int64_t i0 = 0; i0 < a.m; i0 += 64) {
+    const unsigned long long fb = __ballot(next_flag != 0);
+    if (i0 + 64 < a.m)  // the next chunk's flags travel during this chunk
+      next_flag = i0 + 64 + lane < a.m ? a.row_flag[i0 + 64 + lane] : 0;
+    const int64_t kw = i0 >> 6;
+    unsigned long long rem = fb & keep[kw];
+    while (rem) {
+      const int bit = __builtin_ctzll(rem);
+      rem &= rem - 1;
+      const int64_t i = i0 + bit;
+      bool any = false;
+      for (int w = lane; w < a.words; w += 64) {
+        const unsigned long long row_bits =
+            (w == lane && pre_row == i) ? pre_bits : a.mask[i * a.words + w];
+        if (w == lane && rem) {  // speculative: it may get removed meanwhile
+          pre_row = i0 + __builtin_ctzll(rem);
+          pre_bits = a.mask[pre_row * a.words + w];
         }
-        __syncthreads();
-        if (n == 0) continue;
-        const bool small = n <= kListCap;
-        const int *list = small ? list_lds : a.big_list;
-        float *vals = small ? vals_lds : a.big_vals;
-        double *dbl = small ? dbl_lds : a.big_dbl;
-        const int n1 = n + 1;
-        float newbox[7];
-        // geometry and score of this thread's first removed box travel
-        // together with the median's box loads (one global round trip)
-        Geom first_geom;
-        float first_score = 0.0f;
-        if (a.rescore && tid < n) {
-          first_geom = a.geom[list[tid]];
-          first_score = a.s_score[list[tid]];
-        }
-        if (a.merge) {
-          // np.median over [removed..., box i] per component (nms.py:155-157)
-          for (int t = tid; t < 7 * n1; t += kScanThreads) {
-            const int c = t / n1, u = t - c * n1;
-            const int64_t row = u < n ? list[u] : i;
-            vals[t] = a.s_box[row * 7 + c];
-          }
-          __syncthreads();
-          const int r_lo = (n1 - 1) >> 1, r_hi = n1 >> 1;
-          for (int t = tid; t < 7 * n1; t += kScanThreads) {
-            const int c = t / n1, u = t - c * n1;
-            const float *v = vals + c * n1;
-            const float x = v[u];
-            int rank = 0;
-            for (int q = 0; q < n1; ++q) {
-              const float y = v[q];
-              rank += (y < x || (y == x && q < u)) ? 1 : 0;
-            }
-            if (rank == r_lo) med[c][0] = x;
-            if (rank == r_hi) med[c][1] = x;
-          }
-          __syncthreads();
-#pragma unroll
-          for (int c = 0; c < 7; ++c)
-            newbox[c] = (n1 & 1) ? med[c][0] : (med[c][0] + med[c][1]) / 2.0f;
-        } else {
-#pragma unroll
-          for (int c = 0; c < 7; ++c) newbox[c] = a.s_box[i * 7 + c];
-        }
-        if (a.rescore) {
-          // scores[i] += sum(scores[removed] * overlap(mean box, removed))
-          const Geom g = box_geometry(newbox, 0.0);
-          if (tid < n) dbl[tid] = (double)first_score * overlap_3d(g, first_geom);
-          for (int u = tid + kScanThreads; u < n; u += kScanThreads) {
-            const int j = list[u];
-            const Geom o = a.geom[j];
-            dbl[u] = (double)a.s_score[j] * overlap_3d(g, o);
-          }
-          __syncthreads();
-          // fixed-shape tree: deterministic regardless of timing
-          int len = n;
-          while (len > 1) {
-            const int half = (len + 1) >> 1;
-            for (int u = tid; u + half < len; u += kScanThreads)
-              dbl[u] += dbl[u + half];
-            __syncthreads();
-            len = half;
-          }
-          if (tid == 0)
-            a.s_score[i] = (float)((double)a.s_score[i] + dbl[0]);
-        }
-        if (a.merge && tid < 7) a.s_box[i * 7 + tid] = newbox[tid];
-        __syncthreads();
-        rem &= keep[kw];
+        const unsigned long long r = row_bits & keep[w];
+        if (r) keep[w] &= ~r;
+        a.mask[i * a.words + w] = r;
+        any = any || r != 0ull;
       }
+      const unsigned long long act = __ballot(any);
+      if (lane == 0) a.active[i] = act != 0ull ? 1 : 0;
+      // the keep words other lanes just updated (LDS, or global for > 65 536
+      // boxes) must be visible before the next candidate is chosen
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      rem &= keep[kw];
     }
+  }
+  if (keep != a.keep_ws)
+    for (int w = lane; w < a.words; w += 64) a.keep_ws[w] = keep[w];
+}
+
+// ---- phase 2: one workgroup per surviving row with a non-empty removed set ---
+__global__ __launch_bounds__(kScanThreads) void nms_merge_kernel(ScanArgs a) {
+  const int64_t i = blockIdx.x;
+  if (!a.active[i]) return;
+  __shared__ int list_lds[kListCap];
+  __shared__ float vals_lds[7 * (kListCap + 1)];
+  __shared__ double dbl_lds[kListCap];
+  __shared__ int wave_tot[kScanThreads / 64];
+  __shared__ float med[7][2];
+  __shared__ int seg_base;
+  const int tid = threadIdx.x;
+  // size of the removed set, then its members in ascending order
+  int n = 0;
+  for (int w0 = 0; w0 < a.words; w0 += kScanThreads) {
+    const int w = w0 + tid;
+    int tot;
+    block_exclusive_scan(w < a.words ? __popcll(a.mask[i * a.words + w]) : 0,
+                         wave_tot, &tot);
+    n += tot;
+  }
+  const bool small = n <= kListCap;
+  if (!small) {  // disjoint sets: a private segment of the spill buffers
+    if (tid == 0) seg_base = atomicAdd(a.spill_cursor, n + 1);
     __syncthreads();
   }
-  // ---- kept boxes, in score order
+  int *list = small ? list_lds : a.big_list + seg_base;
+  float *vals = small ? vals_lds : a.big_vals + (int64_t)7 * seg_base;
+  double *dbl = small ? dbl_lds : a.big_dbl + seg_base;
   int base = 0;
   for (int w0 = 0; w0 < a.words; w0 += kScanThreads) {
     const int w = w0 + tid;
-    unsigned long long bits = w < a.words ? keep[w] : 0ull;
+    unsigned long long bits = w < a.words ? a.mask[i * a.words + w] : 0ull;
+    int tot;
+    int pos = base + block_exclusive_scan(__popcll(bits), wave_tot, &tot);
+    while (bits) {
+      const int bb = __builtin_ctzll(bits);
+      bits &= bits - 1;
+      list[pos++] = w * 64 + bb;
+    }
+    base += tot;
+  }
+  __syncthreads();
+  const int n1 = n + 1;
+  float newbox[7];
+  if (a.merge) {
+    // np.median over [removed..., box i] per component (nms.py:155-157)
+    for (int t = tid; t < 7 * n1; t += kScanThreads) {
+      const int c = t / n1, u = t - c * n1;
+      const int64_t row = u < n ? list[u] : i;
+      vals[t] = a.s_box[row * 7 + c];
+    }
+    __syncthreads();
+    const int r_lo = (n1 - 1) >> 1, r_hi = n1 >> 1;
+    for (int t = tid; t < 7 * n1; t += kScanThreads) {
+      const int c = t / n1, u = t - c * n1;
+      const float *v = vals + c * n1;
+      const float x = v[u];
+      int rank = 0;
+      for (int q = 0; q < n1; ++q) {
+        const float y = v[q];
+        rank += (y < x || (y == x && q < u)) ? 1 : 0;
+      }
+      if (rank == r_lo) med[c][0] = x;
+      if (rank == r_hi) med[c][1] = x;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 7; ++c)
+      newbox[c] = (n1 & 1) ? med[c][0] : (med[c][0] + med[c][1]) / 2.0f;
+  } else {
+#pragma unroll
+    for (int c = 0; c < 7; ++c) newbox[c] = a.s_box[i * 7 + c];
+  }
+  if (a.rescore) {
+    // scores[i] += sum(scores[removed] * overlap(mean box, removed))
+    const Geom g = box_geometry(newbox, 0.0);
+    for (int u = tid; u < n; u += kScanThreads) {
+      const int j = list[u];
+      const Geom o = a.geom[j];
+      dbl[u] = (double)a.s_score[j] * overlap_3d(g, o);
+    }
+    __syncthreads();
+    // fixed-shape tree: deterministic regardless of timing
+    int len = n;
+    while (len > 1) {
+      const int half = (len + 1) >> 1;
+      for (int u = tid; u + half < len; u += kScanThreads)
+        dbl[u] += dbl[u + half];
+      __syncthreads();
+      len = half;
+    }
+    if (tid == 0) a.s_score[i] = (float)((double)a.s_score[i] + dbl[0]);
+  }
+  // row i is a survivor: no other workgroup reads or writes its box / score
+  if (a.merge && tid < 7) a.s_box[i * 7 + tid] = newbox[tid];
+}
+
+// ---- phase 3: kept boxes, in score order --------------------------------------
+__global__ __launch_bounds__(kScanThreads) void nms_output_kernel(ScanArgs a) {
+  __shared__ int wave_tot[kScanThreads / 64];
+  const int tid = threadIdx.x;
+  int base = 0;
+  for (int w0 = 0; w0 < a.words; w0 += kScanThreads) {
+    const int w = w0 + tid;
+    unsigned long long bits = w < a.words ? a.keep_ws[w] : 0ull;
     int tot;
     int pos = base + block_exclusive_scan(__popcll(bits), wave_tot, &tot);
     while (bits) {
@@ -589,7 +614,7 @@ struct NmsLayout {
   uint32_t *keys_a, *vals_a, *keys_b, *vals_b;
   void *sort_scratch;
   size_t sort_bytes;
-  int32_t *s_label, *s_attr, *row_flag, *big_list;
+  int32_t *s_label, *s_attr, *row_flag, *active, *big_list;
   float *s_box, *s_score, *big_vals;
   double *big_dbl;
   Geom *geom;
@@ -608,12 +633,13 @@ bool carve_nms(Arena &ar, int64_t n, NmsLayout *L) {
   L->sort_scratch = ar.take<char>(L->sort_bytes);
   L->s_label = ar.take<int32_t>(m);
   L->s_attr = ar.take<int32_t>(m);
-  L->row_flag = ar.take<int32_t>(m);
-  L->big_list = ar.take<int32_t>(m);
+  L->row_flag = ar.take<int32_t>(m + 1);  // + the spill cursor
+  L->active = ar.take<int32_t>(m);
+  L->big_list = ar.take<int32_t>(2 * m);
   L->s_box = ar.take<float>(7 * m);
   L->s_score = ar.take<float>(m);
-  L->big_vals = ar.take<float>(7 * (m + 1));
-  L->big_dbl = ar.take<double>(m);
+  L->big_vals = ar.take<float>(14 * m);
+  L->big_dbl = ar.take<double>(2 * m);
   L->geom = ar.take<Geom>(m);
   L->keep_ws = ar.take<unsigned long long>((size_t)L->words);
   L->mask = ar.take<unsigned long long>(m * (size_t)L->words);
@@ -745,7 +771,8 @@ extern "C" int pgnn_nms_boxes_3d(const int32_t *class_labels,
   hipLaunchKernelGGL(gather_sorted_kernel, dim3((unsigned)((m + 255) / 256)),
                      dim3(256), 0, stream, order, class_labels, boxes_3d,
                      scores, attributes, m, appr, L.s_label, L.s_box,
-                     L.s_score, L.s_attr, L.geom, L.row_flag);
+                     L.s_score, L.s_attr, L.geom, L.row_flag, L.active,
+                     L.row_flag + n_boxes);
   PGNN_HIP(hipGetLastError());
   const int64_t pair_blocks = m * words;
   hipLaunchKernelGGL(overlap_mask_kernel,
@@ -759,6 +786,8 @@ extern "C" int pgnn_nms_boxes_3d(const int32_t *class_labels,
   sa.words = words;
   sa.mask = L.mask;
   sa.row_flag = L.row_flag;
+  sa.active = L.active;
+  sa.spill_cursor = L.row_flag + n_boxes;
   sa.geom = L.geom;
   sa.s_label = L.s_label;
   sa.s_box = L.s_box;
@@ -775,7 +804,11 @@ extern "C" int pgnn_nms_boxes_3d(const int32_t *class_labels,
   sa.out_score = out_scores;
   sa.out_attr = out_attributes;
   sa.out_count = out_count;
-  hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(kScanThreads), 0, stream,
+  hipLaunchKernelGGL(nms_resolve_kernel, dim3(1), dim3(64), 0, stream, sa);
+  if (sa.merge || sa.rescore)
+    hipLaunchKernelGGL(nms_merge_kernel, dim3((unsigned)m), dim3(kScanThreads),
+                       0, stream, sa);
+  hipLaunchKernelGGL(nms_output_kernel, dim3(1), dim3(kScanThreads), 0, stream,
                      sa);
   PGNN_HIP(hipGetLastError());
   return 0;
