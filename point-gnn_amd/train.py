@@ -559,23 +559,34 @@ class Trainer(object):
         self._saved = None
 
     # ---- one training step ----------------------------------------------------------
-    def train_step(self, batch, apply=True):
+    def train_step(self, batch, apply=True, num_valid=None,
+                   after_enqueue=None):
         """batch = (input_v, vertex_coord_list, keypoint_indices_list,
         edges_list, cls_labels [K,1], encoded_boxes [K,1,L], valid_boxes
         [K,1,1]) -- what train.py's batch_data returns for this rank.
-        Returns the loss dict of models.py:308-311 (global values)."""
+        Returns the loss dict of models.py:308-311 (global values).
+
+        num_valid: sum(valid_boxes) when the caller already knows it on the
+        host (the data loader does): saves the one device read that otherwise
+        sits between forward and backward.  after_enqueue: called once forward,
+        loss and backward are all queued and before the host waits for the loss
+        sums -- the place to build the NEXT batch's graph on another stream."""
         (input_v, coords, kps, edges, labels, boxes, valid) = batch
         self.grad.zero_()
         logits, pred = self.forward(input_v, coords, kps, edges)
         k = int(logits.shape[0])
         va = torch.as_tensor(valid).to(self.device, torch.float32).reshape(-1)
+        if num_valid is None:
+            num_valid = float(va.sum().item())
         # unify_copies: global endpoint counts (train.py:268-284)
         n_total, nv_total = allreduce_endpoint_counts(
-            k, float(va.sum().item()), self.device, self.pg)
+            k, float(num_valid), self.device, self.pg)
         sums, dlog, dpred = self.loss_and_grads(
             logits, pred, torch.as_tensor(labels), torch.as_tensor(boxes), va,
             n_total, nv_total)
         self.backward(dlog, dpred)
+        if after_enqueue is not None:
+            after_enqueue()
         allreduce_gradients(self.grad, sums, self.pg)  # no-op for world 1
         lr = learning_rate(self.train_config, self.global_step)
         out = {
