@@ -573,14 +573,21 @@ class Trainer(object):
         sums -- the place to build the NEXT batch's graph on another stream."""
         (input_v, coords, kps, edges, labels, boxes, valid) = batch
         self.grad.zero_()
-        logits, pred = self.forward(input_v, coords, kps, edges)
-        k = int(logits.shape[0])
         va = torch.as_tensor(valid).to(self.device, torch.float32).reshape(-1)
-        if num_valid is None:
-            num_valid = float(va.sum().item())
+        k = int(va.shape[0])
+        counts = None
+        if num_valid is not None:
+            # known up front: exchange the counts BEFORE the forward is queued,
+            # so the tiny collective (and its host read) does not wait for it
+            counts = allreduce_endpoint_counts(k, float(num_valid), self.device,
+                                               self.pg)
+        logits, pred = self.forward(input_v, coords, kps, edges)
+        assert int(logits.shape[0]) == k, "labels do not match the vertices"
+        if counts is None:
+            counts = allreduce_endpoint_counts(k, float(va.sum().item()),
+                                               self.device, self.pg)
         # unify_copies: global endpoint counts (train.py:268-284)
-        n_total, nv_total = allreduce_endpoint_counts(
-            k, float(num_valid), self.device, self.pg)
+        n_total, nv_total = counts
         sums, dlog, dpred = self.loss_and_grads(
             logits, pred, torch.as_tensor(labels), torch.as_tensor(boxes), va,
             n_total, nv_total)
