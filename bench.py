@@ -273,8 +273,9 @@ def run_train(args, torch, dev, rank, world, dist):
 
     def make_batch(i):
         with torch.cuda.stream(sg):
-            frames = [make_frame((rank + world * i) * fpg + j)
-                      for j in range(fpg)]
+            # every rank walks the whole frame pool (offset by its rank): the
+            # same mix of graph sizes per GPU at every N
+            frames = [make_frame((rank + i) * fpg + j) for j in range(fpg)]
             batch = train.batch_data(frames)
             nv = float(sum(float(fr[6].sum().item()) for fr in frames))
         return batch, nv
@@ -410,7 +411,13 @@ def main():
 
     # frame pool resident in HBM; rank r owns frames r, r+W, ... of the stream
     my_ids = shard_frames(world * (args.steps + args.warmup), rank, world)
-    seeds = sorted({i % args.frames for i in my_ids})
+
+    def seed_of(i):
+        # every rank cycles through ALL pool frames (rank r starts at frame r),
+        # so the per-GPU work is the same mix at every N (weak scaling); with a
+        # plain `id % frames` rank 0 of 8 would see frame 0 only
+        return (my_ids[i] // world + rank) % args.frames
+    seeds = sorted({seed_of(i) for i in range(len(my_ids))})
     pool = {}
     for s in seeds:
         xyz, inten = synthetic_cloud(seed=s, preset=args.preset)
@@ -418,7 +425,7 @@ def main():
                    xyz, inten)
 
     def frame(i):
-        x, f, _, _ = pool[my_ids[i] % args.frames]
+        x, f, _, _ = pool[seed_of(i)]
         return x, f
 
     def run(lo, hi):
