@@ -1,0 +1,140 @@
+"""One frame through every row of SURVEY.md §8 on the device, the way run.py
+strings them together (run.py:203-433): KITTI files -> camera-frame crop ->
+graph -> GNN with the reference's TRAINED car_auto_T1 weights (read from a TF
+checkpoint written by our writer) -> softmax -> decode + NMS -> KITTI txt; the
+oracle walks the same chain on the host from the same files."""
+import os
+
+import numpy as np
+import pytest
+
+import pointgnn_amd  # noqa: F401
+from pointgnn_amd import configs
+from oracle import detect_oracle as DO
+from oracle import gnn_oracle as gn
+from oracle import graph_oracle as go
+from oracle import ingest_oracle as IO
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _velodyne_scan(seed):
+    """The ray-cast synthetic scene (camera frame) mapped back into the
+    velodyne frame, plus returns behind the car that the crop must drop."""
+    from pointgnn_amd.synthetic import synthetic_cloud
+    xyz_cam, inten = synthetic_cloud(seed=seed, preset="small")
+    calib = IO.get_calib(IO.CALIB_LINES)
+    homo = np.hstack([xyz_cam.astype(np.float64), np.ones((len(xyz_cam), 1))])
+    front = (homo @ calib["cam_to_velo"].T)[:, :3]
+    back = IO.synthetic_velo_scan(seed, n=15000)
+    back = back[back[:, 0] < -1.0]
+    scan = np.vstack([np.hstack([front, inten]), back]).astype(np.float32)
+    return scan[np.random.default_rng(seed).permutation(len(scan))]
+
+
+@pytest.mark.parametrize("weights_kind", ["trained", "seeded"])
+def test_files_to_kitti_txt(tmp_path, weights_kind):
+    import torch
+    from test_ingest_cpu import _write_png_header_only
+    from pointgnn_amd import weights
+    from pointgnn_amd import (kitti_dataset as KD, graph_gen, models, nms,
+                              kitti_output as KO, tf_bundle)
+    cfg = configs.get_config("car_auto_T1")
+    # ---- a KITTI-layout directory and a TF checkpoint on disk
+    for d in ("image_2", "velodyne", "calib", "ckpt"):
+        (tmp_path / d).mkdir()
+    velo = _velodyne_scan(21)
+    velo.tofile(str(tmp_path / "velodyne" / "000042.bin"))
+    (tmp_path / "calib" / "000042.txt").write_text("".join(IO.CALIB_LINES))
+    _write_png_header_only(str(tmp_path / "image_2" / "000042.png"), 375, 1242)
+    if weights_kind == "trained":
+        gold_w = np.load(os.path.join(GOLD, "weights_car_auto_T1.npz"))
+        gold_w = {k: gold_w[k] for k in gold_w.files}
+    else:   # near-uniform probabilities: the detection tail has work to do
+        gold_w = weights.init_params(cfg, seed=3, bias_scale=0.05)
+    tf_bundle.save_checkpoint(str(tmp_path / "ckpt"), gold_w,
+                              global_step=1400000)
+    # ---- device chain
+    ds = KD.KittiDataset(str(tmp_path / "image_2"), str(tmp_path / "velodyne"),
+                         str(tmp_path / "calib"))
+    calib = ds.get_calib(0)
+    pts = ds.get_cam_points_in_image_with_rgb(0)
+    params = tf_bundle.load_checkpoint(str(tmp_path / "ckpt"))
+    params.pop("Variable")
+    model = models.get_model(cfg["model_name"])(
+        num_classes=cfg["num_classes"], box_encoding_len=7, mode="test",
+        **cfg["model_kwargs"]).load_state_dict(params)
+    fn = graph_gen.get_graph_generate_fn(cfg["graph_gen_method"])
+    coords, kps, edges = fn(pts.xyz, **cfg["runtime_graph_gen_kwargs"])
+    logits, box_enc = model.predict(pts.attr[:, :1], coords, kps, edges, False)
+    probs = model.postprocess(logits)
+    lmap = KO.LABEL_MAPS[cfg["label_method"]]
+    labels, boxes, scores, idx = nms.detect_boxes(
+        probs, box_enc, coords[-1], lmap, cfg["nms_overlapped_thres"])
+    cand_idx, _ = nms.select_candidates(probs)
+    cand_xyz = coords[-1][(cand_idx // cfg["num_classes"]).long()]
+    rows = KO.detections_to_kitti_labels(labels, boxes, scores, calib,
+                                         cfg["label_method"],
+                                         candidate_xyz=cand_xyz)
+    out_file = str(tmp_path / "out" / "data" / (ds.get_filename(0) + ".txt"))
+    KO.write_kitti_txt(out_file, rows)
+
+    # ---- the same chain in the oracle (GNN on the device-built graph: the
+    # 'center' keypoint pick has legitimate ties)
+    o_xyz, o_attr, _ = IO.cam_points_in_image(velo, IO.get_calib(IO.CALIB_LINES),
+                                              (375, 1242))
+    assert np.array_equal(pts.attr[:, :1].cpu().numpy(), o_attr)
+    assert np.array_equal(pts.xyz.cpu().numpy(), o_xyz)
+    c_np = [c.cpu().numpy() for c in coords]
+    k_np = [k.cpu().numpy() for k in kps]
+    e_np = [e.cpu().numpy() for e in edges]
+    lcfg = cfg["runtime_graph_gen_kwargs"]["level_configs"]
+    for lvl in (0, 1):
+        ref_e = go.radius_graph_c(c_np[lvl], c_np[lvl + 1],
+                                  lcfg[lvl]["graph_gen_kwargs"]["radius"])
+        assert np.array_equal(go.canonical_edges(e_np[lvl]),
+                              go.canonical_edges(ref_e))
+    o_logits, o_enc = gn.predict(dict(params), cfg, o_attr, c_np, k_np, e_np,
+                                 dtype=np.float64)
+    np.testing.assert_allclose(logits.cpu().numpy(), o_logits, atol=2e-4,
+                               rtol=1e-4)
+    o_probs = gn.softmax(o_logits).astype(np.float32)
+    if weights_kind == "seeded":
+        # probabilities sit right at the 1/nc threshold here: give the oracle
+        # tail the device's float32 outputs, so that it checks the detection
+        # stage and not which side of 0.25 a 1e-7 difference falls
+        o_probs = probs.cpu().numpy()
+        o_enc = box_enc.cpu().numpy()
+    w_idx, w_lab = DO.select_candidates(o_probs)
+    assert np.array_equal(cand_idx.cpu().numpy(), w_idx)
+    nc = cfg["num_classes"]
+    dec = DO.box_decoding(np.tile(np.arange(nc), len(c_np[-1])).reshape(-1, 1),
+                          np.repeat(c_np[-1], nc, axis=0),
+                          o_enc.astype(np.float32).reshape(-1, 1, 7), lmap)
+    want = DO.nms_boxes_3d(w_lab, dec[w_idx, 0], o_probs.reshape(-1)[w_idx],
+                           cfg["nms_overlapped_thres"], "uncertainty")
+    assert np.array_equal(idx.cpu().numpy(), want[3])
+    assert np.array_equal(labels.cpu().numpy(), want[0])
+    np.testing.assert_allclose(boxes.cpu().numpy(), want[1], atol=1e-3)
+    np.testing.assert_allclose(scores.cpu().numpy(), want[2], rtol=1e-3)
+    o_rows = DO.kitti_labels(want[0], want[1], want[2],
+                             IO.get_calib(IO.CALIB_LINES)["cam_to_image"],
+                             cfg["label_method"],
+                             c_np[-1][w_idx // nc])
+    assert [r[0] for r in rows] == [r[0] for r in o_rows]
+    if rows:
+        np.testing.assert_allclose(
+            np.array([r[4:] for r in rows], np.float64),
+            np.array([r[4:] for r in o_rows], np.float64), rtol=2e-3,
+            atol=2e-3)
+    # ---- the file is KITTI-shaped
+    lines = [l for l in open(out_file).read().split("\n") if l.strip()]
+    assert len(lines) == len(rows)
+    for l in lines:
+        f = l.split()
+        assert len(f) == 16 and f[0] in ("Car", "DontCare", "Background")
+    if weights_kind == "seeded":
+        assert len(w_idx) > 100 and 0 < len(rows) <= len(want[3])
+    print("N %d K %d candidates %d kept %d lines %d" % (
+        len(o_xyz), len(c_np[-1]), len(w_idx), len(want[3]), len(rows)))
