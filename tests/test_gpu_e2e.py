@@ -138,3 +138,72 @@ def test_files_to_kitti_txt(tmp_path, weights_kind):
         assert len(w_idx) > 100 and 0 < len(rows) <= len(want[3])
     print("N %d K %d candidates %d kept %d lines %d" % (
         len(o_xyz), len(c_np[-1]), len(w_idx), len(want[3]), len(rows)))
+
+
+def test_training_sample_from_kitti_files(tmp_path):
+    """train.py:78-133 (`fetch_data`) on the device: KITTI files + label file
+    -> crop -> augmentations -> training-mode graph -> label assignment ->
+    box encoding -> one Trainer step; targets checked against the oracle on
+    the same augmented cloud."""
+    import copy
+    import torch
+    from test_ingest_cpu import _write_png_header_only
+    from oracle import labels_oracle as LO
+    from pointgnn_amd import (kitti_dataset as KD, graph_gen, preprocess as PP,
+                              box_encoding as BE, train, weights)
+    cfg = configs.get_config("car_auto_T1")
+    for d in ("image_2", "velodyne", "calib", "label_2"):
+        (tmp_path / d).mkdir()
+    velo = _velodyne_scan(5)
+    velo.tofile(str(tmp_path / "velodyne" / "000001.bin"))
+    (tmp_path / "calib" / "000001.txt").write_text("".join(IO.CALIB_LINES))
+    _write_png_header_only(str(tmp_path / "image_2" / "000001.png"), 375, 1242)
+    cam, _, _ = IO.cam_points_in_image(velo, IO.get_calib(IO.CALIB_LINES),
+                                       (375, 1242))
+    gt = LO.synthetic_labels(5, cam, n_boxes=12)
+    LO.write_label_file(str(tmp_path / "label_2" / "000001.txt"), gt)
+    ds = KD.KittiDataset(str(tmp_path / "image_2"), str(tmp_path / "velodyne"),
+                         str(tmp_path / "calib"), str(tmp_path / "label_2"),
+                         is_training=True, num_classes=cfg["num_classes"])
+    pts = ds.get_cam_points_in_image_with_rgb(0)
+    labels = ds.get_label(0)
+    assert labels == gt
+    aug = PP.get_data_aug([
+        {"method_name": "random_rotation_all",
+         "method_kwargs": {"method_name": "normal", "yaw_std": 0.39,
+                           "expend_factor": (1.0, 1.0, 1.0)}},
+        {"method_name": "random_flip_all", "method_kwargs": {"flip_prob": 0.5}},
+        {"method_name": "random_box_shift",
+         "method_kwargs": {"appr_factor": 10, "expend_factor": (1.1, 1.1, 1.1),
+                           "max_overlap_num_allowed": 100,
+                           "max_overlap_rate": 0.01, "max_trails": 100,
+                           "method_name": "normal", "xyz_std": (3, 0, 3)}}])
+    np.random.seed(5)
+    pts, labels = aug(pts, copy.deepcopy(labels))
+    pts = PP.finish(pts)
+    fn = graph_gen.get_graph_generate_fn(cfg["graph_gen_method"])
+    coords, kps, edges = fn(pts.xyz, **cfg["graph_gen_kwargs"])
+    last = coords[-1]
+    cls, boxes3d, valid, lmap = ds.assign_classaware_car_label_to_points(
+        labels, last, expend_factor=(1.0, 1.0, 1.0))
+    enc = BE.get_box_encoding_fn(cfg["box_encoding_method"])(
+        cls, last, boxes3d, lmap)
+    # oracle targets on the same vertices / labels
+    o_cls, o_boxes, o_valid, _ = LO.assign_labels(labels, last.cpu().numpy(),
+                                                  (1.0, 1.0, 1.0), "Car")
+    assert np.array_equal(cls.cpu().numpy(), o_cls)
+    assert np.array_equal(boxes3d.cpu().numpy(), o_boxes)
+    assert np.array_equal(valid.cpu().numpy(), o_valid)
+    o_enc = DO.box_encoding(o_cls, last.cpu().numpy(), o_boxes, lmap
+                            ).astype(np.float32)
+    tol = np.spacing(np.maximum(np.abs(o_enc), 1e-30))
+    assert np.all(np.abs(enc.cpu().numpy().astype(np.float64) - o_enc) <= tol)
+    assert int((o_cls > 0).sum()) > 0
+    # one optimisation step on this sample
+    tr = train.Trainer(cfg, params=weights.init_params(cfg, seed=1),
+                       device=last.device)
+    batch = (pts.attr[:, :1].contiguous(), coords, kps, edges, cls, enc, valid)
+    out = tr.train_step(batch, num_valid=float(o_valid.sum()))
+    assert np.isfinite([out['cls_loss'], out['loc_loss'], out['reg_loss']]).all()
+    assert out['num_endpoint'] == len(o_cls)
+    assert out['num_valid_endpoint'] == float(o_valid.sum())
