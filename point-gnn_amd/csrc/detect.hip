@@ -8,9 +8,10 @@
 //   1. a radix sort orders boxes by descending score;
 //   2. one thread per box builds its float64 corner geometry exactly the way
 //      boxes_3d_to_corners does (float32 cos/sin and half sizes, float64 rest);
-//   3. one wave per (row, 64 columns) evaluates the pairwise test
-//      "same class and overlap > threshold" for j > i and stores it as a bit
-//      matrix (ballot), so the part that is quadratic runs on the whole chip;
+//   3. one workgroup per 64 x 64 block of pairs (bounds and labels staged in
+//      LDS) evaluates the pairwise test "same class and overlap > threshold"
+//      for j > i and stores it as a bit matrix (ballot), so the part that is
+//      quadratic runs on the whole chip;
 //   4. the reference's loop is sequential only through the keep flags: ONE
 //      WAVE replays it on the bit matrix (removed set = row & keep, keep &=
 //      ~removed) and writes every surviving row back masked;
@@ -334,40 +335,70 @@ __global__ void gather_sorted_kernel(const uint32_t *__restrict__ order,
   if (i == 0) *spill_cursor = 0;
 }
 
-// bit j of mask[i*words + j/64] <=> j > i, same class, overlap(i, j) > thr
-__global__ __launch_bounds__(64) void overlap_mask_kernel(
+// bit j of mask[i*words + j/64] <=> j > i, same class, overlap(i, j) > thr.
+// One 256-thread workgroup per 64 x 64 block of pairs: the 64 row and 64
+// column bounds/labels are staged in LDS once (the per-row form re-read 3 KB
+// per 64 pairs from L2), wave w covers rows 16w..16w+15, lane = column, and
+// only pairs that pass the label and bounds test fetch the full geometry.
+__global__ __launch_bounds__(256) void overlap_mask_kernel(
     const Geom *__restrict__ geom, const int32_t *__restrict__ label,
     int64_t m, int words, double thr, unsigned long long *__restrict__ mask,
     int32_t *__restrict__ row_flag) {
-  // grid-stride over the m*words (row, column block) pairs: a launch may not
-  // exceed 2^32 threads (larger grids wrap silently)
-  const int64_t total = m * words;
+  __shared__ double rlo[64][3], rhi[64][3], clo[64][3], chi[64][3];
+  __shared__ int rlab[64], clab[64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // grid-stride over the words*words blocks: a launch may not exceed 2^32
+  // threads (larger grids wrap silently)
+  const int64_t total = (int64_t)words * words;
   for (int64_t blk = blockIdx.x; blk < total; blk += gridDim.x) {
-    const int64_t i = blk / words;
-    const int jb = (int)(blk - i * words);
-    const int64_t j = (int64_t)jb * 64 + threadIdx.x;
-    if ((int64_t)jb * 64 + 63 <= i) {
-      if (threadIdx.x == 0) mask[blk] = 0ull;
+    const int bi = (int)(blk / words), bj = (int)(blk - (int64_t)bi * words);
+    if (bj < bi) {  // below the diagonal: the rows still need their zeros
+      if (threadIdx.x < 64 && (int64_t)bi * 64 + threadIdx.x < m)
+        mask[((int64_t)bi * 64 + threadIdx.x) * words + bj] = 0ull;
       continue;
     }
-    bool hit = false;
-    if (j > i && j < m && label[j] == label[i]) {
-      // bounds first (48 of the 120 bytes); most pairs end here
-      const Geom *pa = geom + i, *pb = geom + j;
-      bool apart = false;
+    __syncthreads();
+    if (threadIdx.x < 128) {
+      const bool col = threadIdx.x >= 64;
+      const int t = threadIdx.x & 63;
+      const int64_t g = (int64_t)(col ? bj : bi) * 64 + t;
+      double(*lo)[3] = col ? clo : rlo;
+      double(*hi)[3] = col ? chi : rhi;
+      int *lab = col ? clab : rlab;
+      if (g < m) {
 #pragma unroll
-      for (int k = 0; k < 3; ++k)
-        apart |= pa->hi[k] < pb->lo[k] || pa->lo[k] > pb->hi[k];
-      if (!apart) {
-        const Geom a = *pa;
-        const Geom b = *pb;
-        hit = overlap_3d(a, b) > thr;
+        for (int k = 0; k < 3; ++k) {
+          lo[t][k] = geom[g].lo[k];
+          hi[t][k] = geom[g].hi[k];
+        }
+        lab[t] = label[g];
+      } else {
+        lab[t] = -0x7fffffff - (col ? 1 : 0);  // never equal to anything
       }
     }
-    const unsigned long long bal = __ballot(hit);
-    if (threadIdx.x == 0) {
-      mask[blk] = bal;
-      if (bal) row_flag[i] = 1;
+    __syncthreads();
+    const int64_t j = (int64_t)bj * 64 + lane;
+    for (int rr = 0; rr < 16; ++rr) {
+      const int r = 16 * wave + rr;
+      const int64_t i = (int64_t)bi * 64 + r;
+      if (i >= m) break;  // wave-uniform
+      bool hit = false;
+      if (j > i && j < m && clab[lane] == rlab[r]) {
+        bool apart = false;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          apart |= rhi[r][k] < clo[lane][k] || rlo[r][k] > chi[lane][k];
+        if (!apart) {
+          const Geom a = geom[i];
+          const Geom b = geom[j];
+          hit = overlap_3d(a, b) > thr;
+        }
+      }
+      const unsigned long long bal = __ballot(hit);
+      if (lane == 0) {
+        mask[i * words + bj] = bal;
+        if (bal) row_flag[i] = 1;
+      }
     }
   }
 }
@@ -774,11 +805,11 @@ extern "C" int pgnn_nms_boxes_3d(const int32_t *class_labels,
                      L.s_score, L.s_attr, L.geom, L.row_flag, L.active,
                      L.row_flag + n_boxes);
   PGNN_HIP(hipGetLastError());
-  const int64_t pair_blocks = m * words;
+  const int64_t pair_blocks = (int64_t)words * words;
   hipLaunchKernelGGL(overlap_mask_kernel,
                      dim3((unsigned)(pair_blocks < (1 << 22) ? pair_blocks
                                                              : (1 << 22))),
-                     dim3(64), 0, stream, L.geom, L.s_label, m, words,
+                     dim3(256), 0, stream, L.geom, L.s_label, m, words,
                      (double)overlapped_thres, L.mask, L.row_flag);
   PGNN_HIP(hipGetLastError());
   ScanArgs sa;
