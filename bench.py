@@ -312,6 +312,7 @@ def run_train(args, torch, dev, rank, world, dist):
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    tr.allreduce_events = []
     t0 = time.perf_counter()
     for i in range(args.warmup, n_steps):
         out = step(i)
@@ -320,10 +321,12 @@ def run_train(args, torch, dev, rank, world, dist):
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    ar_ms = (sum(a.elapsed_time(b) for a, b in tr.allreduce_events) /
+             max(1, len(tr.allreduce_events)))
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, ar_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, ar_ms = float(t[0].item()), float(t[1].item())
     if rank == 0:
         res = {
             "metric": "training frames/sec (%s, fwd+loss+bwd+allreduce+SGD, "
@@ -342,6 +345,10 @@ def run_train(args, torch, dev, rank, world, dist):
                 "last_batch_shape": shapes,
                 "params": int(tr.flat.numel()),
                 "allreduce_bytes": int(tr.flat.numel()) * 4,
+                # device time between the events that bracket the gradient
+                # all-reduce (+ the 2-scalar loss all-reduce); includes any
+                # wait for the slowest rank to arrive; 0 at world 1 (no call)
+                "allreduce_ms": ar_ms,
                 "last_loss": {k: out[k] for k in ('cls_loss', 'loc_loss',
                                                   'reg_loss')},
                 "parallelism": "dp%d (frames sharded, one flat gradient "

@@ -391,6 +391,25 @@ int pgnn_points_in_box_f64(const double *xyz, int64_t n_points,
                            const double *box_record_24, const int32_t *exclude,
                            int32_t *inside, int32_t *count, void *stream);
 
+/* Streaming classification metrics of the training / evaluation loops
+ * (train.py:301-368, eval.py:176-245): per class tf.metrics.recall and
+ * tf.metrics.precision of argmax(probs) against the labels, and
+ * tf.metrics.auc(labels == c, probs[:, c], num_thresholds, curve='PR',
+ * summation_method='careful_interpolation').  `state` is a caller-owned device
+ * buffer of pgnn_metrics_state_bytes() bytes, zeroed by the caller to reset
+ * (the reference re-initialises its local variables per epoch); it holds int64
+ * counters only, so states of several ranks add up with one integer
+ * all-reduce.  pgnn_metrics_update folds one batch in; pgnn_metrics_compute
+ * writes out[c*3 + {0,1,2}] = recall, precision, PR-AUC of class c (float32
+ * arithmetic as TensorFlow's). */
+size_t pgnn_metrics_state_bytes(int32_t n_classes, int32_t n_thresholds);
+int pgnn_metrics_update(const float *probs, int64_t ld_probs,
+                        const int32_t *labels, int64_t n_rows,
+                        int32_t n_classes, int32_t n_thresholds, void *state,
+                        void *stream);
+int pgnn_metrics_compute(const void *state, int32_t n_classes,
+                         int32_t n_thresholds, float *out, void *stream);
+
 size_t pgnn_kitti_ingest_workspace_bytes(int64_t n_points);
 int pgnn_kitti_cam_points_in_image(
     const float *velo_points, int64_t n_points, const float *velo_to_cam_3x4,

@@ -125,6 +125,11 @@ _SIGNATURES = {
                                                c_f64, c_vp, c_i64, c_i64, c_vp,
                                                c_sz, c_vp, c_vp, c_i32, c_i64,
                                                c_vp, c_vp]),
+    # streaming metrics
+    "pgnn_metrics_state_bytes": (c_sz, [c_i32, c_i32]),
+    "pgnn_metrics_update": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_i32,
+                                    c_vp, c_vp]),
+    "pgnn_metrics_compute": (c_i32, [c_vp, c_i32, c_i32, c_vp, c_vp]),
 }
 
 _lib = None

@@ -594,7 +594,15 @@ class Trainer(object):
         self.backward(dlog, dpred)
         if after_enqueue is not None:
             after_enqueue()
+        ev = getattr(self, 'allreduce_events', None)
+        if ev is not None:  # bench.py: device time of the collective
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
         allreduce_gradients(self.grad, sums, self.pg)  # no-op for world 1
+        if ev is not None:
+            e1.record()
+            ev.append((e0, e1))
         lr = learning_rate(self.train_config, self.global_step)
         out = {
             'cls_loss': self.cls_w * float(sums[0].item()) / max(n_total, 1.0),

@@ -188,6 +188,13 @@ def test_error_reporting_without_gpu():
                                         5, None, None, 0, None, 0, None) == -1
     assert lib.pgnn_points_in_box_f64(None, 5, None, None, None, None,
                                       None) == -1
+    assert lib.pgnn_metrics_state_bytes(4, 200) == 4 * (3 + 2 * 201) * 8
+    assert lib.pgnn_metrics_state_bytes(0, 200) == 0
+    assert lib.pgnn_metrics_update(None, 4, None, 10, 4, 5000, None,
+                                   None) == -1        # too many thresholds
+    assert lib.pgnn_metrics_update(None, 2, None, 10, 4, 200, None,
+                                   None) == -1        # stride < classes
+    assert lib.pgnn_metrics_compute(None, 4, 200, None, None) == -1
 
 
 def _emulate_mfma_layer(x, packed, k_in, n_out):

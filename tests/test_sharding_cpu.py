@@ -148,3 +148,43 @@ def test_two_rank_gradient_allreduce_equals_global_gradient():
     assert results[0][2] == results[1][2] == 2 * results[0][1][4].shape[0]
     for _, _, _, _, flat in results:          # every rank holds the same sum
         np.testing.assert_allclose(flat, ref, atol=1e-12, rtol=1e-9)
+
+
+def _metrics_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import pointgnn_amd  # noqa: F401
+    from pointgnn_amd.metrics import allreduce_state
+    from oracle import metrics_oracle as mo
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    p, l = mo.synthetic_step(40 + rank, 900 + 50 * rank, 4)
+    state = torch.from_numpy(mo.state_counts(p, l, 4))
+    allreduce_state(state)
+    q.put((rank, state.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_metric_counters_add_up():
+    """The class counters are integers: the all-reduce SUM of the per-rank
+    states is the state of the concatenated batch."""
+    import numpy as np
+    from oracle import metrics_oracle as mo
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_metrics_worker, args=(r, world, port, q))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    parts = [mo.synthetic_step(40 + r, 900 + 50 * r, 4) for r in range(world)]
+    whole = mo.state_counts(np.concatenate([a for a, _ in parts]),
+                            np.concatenate([b for _, b in parts]), 4)
+    for _, st in results:
+        assert np.array_equal(st, whole)
