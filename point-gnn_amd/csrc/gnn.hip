@@ -22,13 +22,17 @@ void *g_mlp_ts = nullptr;  // device buffer for per-tile timestamps (profiling)
 int g_mlp_debug = 0;  // ablation mask (benchmarks only): 1 = no gather loads,
                       // 2 = no last-layer GEMM, 4 = no epilogue, 16 = print
                       // occupancy, 32 = no one-segment fast path, 64 = no
-                      // prologue priority, 512 = 4-wave kernel for small rows
+                      // prologue priority, 128 = no few-runs register epilogue,
+                      // 512 = 4-wave kernel for small rows
 }
 
 namespace {
 using namespace pgnn;
 
 enum { PRO_ROWS = 0, PRO_POOL = 1, PRO_EDGE = 2 };
+// tiles with at most this many runs of equal dst reduce in registers
+// (layer_pass_segmax_runs); more runs go through the LDS stage
+constexpr int kMaxRegisterRuns = 6;
 
 struct RowsArgs {
   const float *x;
@@ -75,6 +79,25 @@ struct CarryState {
   int left_closed;
 };
 
+// The run left open at a tile's end (sorted ids, the workgroup owns the next
+// tile too, the next edge has the same dst): it is carried instead of flushed.
+// starts / myd as in consume_segmax; wave-uniform.
+__device__ __forceinline__ CarryState carry_after(unsigned long long starts,
+                                                  int myd, int d_before,
+                                                  int d_after, const SegArgs &sa,
+                                                  CarryState cs, bool keep_open) {
+  CarryState out = {-1, 0};
+  const int r = 63 - __builtin_clzll(starts);  // row 0 always starts a run
+  const int d = __builtin_amdgcn_readlane(myd, r);
+  if (sa.sorted && keep_open && d >= 0 && d < sa.num_segments && d_after == d) {
+    bool left_closed = (r > 0) || (d_before != d);
+    if (r == 0 && cs.id == d) left_closed = cs.left_closed != 0;
+    out.id = d;
+    out.left_closed = left_closed ? 1 : 0;
+  }
+  return out;
+}
+
 // Column-wise segmented max of stage[ROWS][ncols] keyed by dst[1..ROWS]
 // (dst[0] / dst[ROWS+1] = id of the edge before / after the tile, -1 if none).
 // Runs wholly inside the workgroup's range are complete segments: one plain
@@ -91,7 +114,6 @@ __device__ __forceinline__ CarryState consume_segmax(
     float *__restrict__ carry, CarryState cs, bool keep_open) {
   constexpr int G = ROWS / 4, SWZ = (G < 16 ? G : 16) - 1;
   static_assert(ROWS <= 64, "one lane per tile row");
-  CarryState out = {-1, 0};
   // Runs of equal dst, found once per wave with a ballot (lane = tile row):
   // bit r of `starts` is set where row r opens a run.  Everything derived from
   // it (r, re, d, the closed/merge/defer flags) is wave-uniform and lives in
@@ -155,18 +177,7 @@ __device__ __forceinline__ CarryState consume_segmax(
   }
   // descriptor of the run left open at the tile's end (every thread, also
   // those without a column)
-  {
-    const int r = 63 - __builtin_clzll(starts);  // row 0 always starts a run
-    const int d = __builtin_amdgcn_readlane(myd, r);
-    if (sa.sorted && keep_open && d >= 0 && d < sa.num_segments &&
-        d_after == d) {
-      bool left_closed = (r > 0) || (d_before != d);
-      if (r == 0 && cs.id == d) left_closed = cs.left_closed != 0;
-      out.id = d;
-      out.left_closed = left_closed ? 1 : 0;
-    }
-  }
-  return out;
+  return carry_after(starts, myd, d_before, d_after, sa, cs, keep_open);
 }
 
 template <int ROWS>
@@ -438,10 +449,19 @@ __global__ __launch_bounds__(256, 2) void fused_mlp_kernel(
       layer_pass_dispatch<MSUB, false>(tile, lds_ld(16 * L.kq), tile,
                                        lds_ld(16 * L.nt), L, 0, wave, lane);
     }
+    if (tsp) tsp[7] = __builtin_readcyclecounter();  // hidden layers done
     // ------------------------------------------------------------ last layer
     {
       const LayerDev &L = chain.l[chain.n - 1];
       const int ld_in = lds_ld(16 * L.kq);
+      // runs of equal dst among the tile's rows (lane = row), once per wave
+      unsigned long long starts = 1;
+      int myd = -2;
+      if (PRO != PRO_ROWS) {
+        myd = lane < ROWS ? dst[lane + 1] : -2;
+        const int prevd = lane < ROWS ? dst[lane] : -2;
+        starts = __ballot(lane < ROWS && (lane == 0 || myd != prevd));
+      }
       for (int t0 = 0; t0 < L.nt; t0 += kMaxTilesPerPass) {
         int tiles = L.nt - t0;
         if (tiles > kMaxTilesPerPass) tiles = kMaxTilesPerPass;
@@ -456,6 +476,7 @@ __global__ __launch_bounds__(256, 2) void fused_mlp_kernel(
         } else if (sa.sorted && !(dbg & (2 | 4 | 32)) && dst[1] >= 0 &&
                    dst[1] < sa.num_segments && dst[1] == dst[ROWS]) {
           // whole tile = one run of one segment: reduce in registers
+          if (tsp && PRO == PRO_POOL) tsp[3] = 1;
           const int d = dst[1];
           const bool merge = cs.id == d;
           const bool left_closed = merge ? cs.left_closed != 0 : dst[0] != d;
@@ -472,6 +493,27 @@ __global__ __launch_bounds__(256, 2) void fused_mlp_kernel(
             cs.id = defer ? d : -1;
             cs.left_closed = left_closed ? 1 : 0;
           }
+        } else if (sa.sorted && !(dbg & (2 | 4 | 32 | 128)) &&
+                   __builtin_popcountll(starts) <= kMaxRegisterRuns) {
+          // a few runs: masked column maxima straight from the accumulators
+          if (tsp && PRO == PRO_POOL) tsp[3] = 2;
+          SegRuns sr;
+          sr.starts = starts;
+          sr.myd = myd;
+          sr.d_before = dst[0];
+          sr.d_after = dst[ROWS + 1];
+          sr.carry_id = cs.id;
+          sr.carry_left_closed = cs.left_closed;
+          sr.keep_open = tile_id + 1 < tile_last;
+          sr.carry = carry;
+          sr.out = sa.out;
+          sr.ldo = sa.ldo;
+          sr.num_segments = sa.num_segments;
+          layer_pass_segmax_runs_dispatch<MSUB>(tile, ld_in, L, t0, wave, lane,
+                                                sr);
+          if (t0 + kMaxTilesPerPass >= L.nt)
+            cs = carry_after(starts, myd, sr.d_before, sr.d_after, sa, cs,
+                             sr.keep_open != 0);
         } else {
           layer_pass_dispatch<MSUB, true>(tile, ld_in, stage, ld_st, L, t0, wave,
                                           lane, (dbg & 2) != 0);

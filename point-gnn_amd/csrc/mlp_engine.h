@@ -244,6 +244,102 @@ __device__ __forceinline__ void layer_pass_segmax_fast_dispatch(
   }
 }
 
+// Epilogue for a tile that holds a FEW runs of equal dst (sorted edges; mean
+// fan-in 120-170 vs 64-row tiles: about a third of the tiles contain one or two
+// segment boundaries).  Same idea as the one-segment path, once per run with a
+// row mask: a lane's accumulator element (m, i) is tile row 16m + 4(lane>>4) + i,
+// so "row in [r, re)" is 4*MSUB compares per run shared by all column tiles,
+// then v_cndmask/v_max over the accumulators and the two cross-lane steps.
+// Replaces, for those tiles, the transposed LDS stage + two barriers + the
+// column walk of consume_segmax (tools/pool_timeline.py: 24k cycles a tile).
+struct SegRuns {
+  unsigned long long starts;  // bit r: tile row r opens a run (row 0 always)
+  int myd;                    // lane r: dst of tile row r (-1 past the end)
+  int d_before, d_after;      // dst of the edge before / after the tile, or -1
+  int carry_id, carry_left_closed;  // CarryState coming into the tile
+  int keep_open;              // the workgroup owns the next tile too
+  float *carry;               // LDS, one float per output column
+  float *out;
+  int64_t ldo;
+  int num_segments;
+};
+
+template <int MSUB, int NT>
+__device__ __forceinline__ void layer_pass_segmax_runs(
+    const float *in, int ld_in, const LayerDev &L, int t0, int wave, int lane,
+    const SegRuns &sr) {
+  constexpr int ROWS = 16 * MSUB;
+  v4f acc[MSUB][NT];
+  gemm_tile<MSUB, NT>(in, ld_in, L, t0, wave, lane, acc);
+  const float *bias = L.wp + (size_t)L.kq * L.nt * 256;
+  const int g4 = 4 * (lane >> 4);
+  unsigned long long rem = sr.starts;
+  while (rem) {  // wave-uniform
+    const int r = __builtin_ctzll(rem);
+    rem &= rem - 1;
+    const int re = rem ? __builtin_ctzll(rem) : ROWS;
+    const int d = __builtin_amdgcn_readlane(sr.myd, r);
+    if (d < 0 || d >= sr.num_segments) continue;
+    bool left_closed = (r > 0) || (sr.d_before != d);
+    const bool merge = r == 0 && sr.carry_id == d;
+    if (merge) left_closed = sr.carry_left_closed != 0;
+    const bool right_closed = (re < ROWS) || (sr.d_after != d);
+    const bool defer = !right_closed && sr.keep_open;
+    const bool whole = left_closed && right_closed;
+    float *out_row = sr.out + (int64_t)d * sr.ldo;
+    const int lo = r - g4, hi = re - g4;
+    bool inside[MSUB][4];
+#pragma unroll
+    for (int m = 0; m < MSUB; ++m)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        inside[m][i] = (16 * m + i >= lo) && (16 * m + i < hi);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int t = t0 + wave + 4 * j;
+      if (t < L.nt) {
+        float v = kFloatLowest;
+#pragma unroll
+        for (int m = 0; m < MSUB; ++m)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            v = fmaxf(v, inside[m][i] ? acc[m][j][i] : kFloatLowest);
+        v = fmaxf(v, __shfl_xor(v, 16));
+        v = fmaxf(v, __shfl_xor(v, 32));
+        const int col = t * 16 + (lane & 15);
+        v += bias[col];
+        if (col >= L.relu_from) v = v > 0.0f ? v : 0.0f;
+        if (lane < 16) {
+          if (merge) v = fmaxf(v, sr.carry[col]);
+          if (defer) {
+            sr.carry[col] = v;
+          } else if (whole) {
+            out_row[col] = v;
+          } else {
+            atomic_max_f32(out_row + col, v + 0.0f);
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int MSUB>
+__device__ __forceinline__ void layer_pass_segmax_runs_dispatch(
+    const float *in, int ld_in, const LayerDev &L, int t0, int wave, int lane,
+    const SegRuns &sr) {
+  int tiles = L.nt - t0;
+  if (tiles > kMaxTilesPerPass) tiles = kMaxTilesPerPass;
+  const int ntw = (tiles + 3) >> 2;
+  switch (ntw) {
+    case 1: layer_pass_segmax_runs<MSUB, 1>(in, ld_in, L, t0, wave, lane, sr); break;
+    case 2: layer_pass_segmax_runs<MSUB, 2>(in, ld_in, L, t0, wave, lane, sr); break;
+    case 3: layer_pass_segmax_runs<MSUB, 3>(in, ld_in, L, t0, wave, lane, sr); break;
+    case 4: layer_pass_segmax_runs<MSUB, 4>(in, ld_in, L, t0, wave, lane, sr); break;
+    default: layer_pass_segmax_runs<MSUB, 5>(in, ld_in, L, t0, wave, lane, sr); break;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // Balanced split for 64-row tiles whose pass has 4*NT + NR column tiles
 // (NR = 1..3; C = 300 -> 19 tiles = 4*4 + 3).  The plain scheme gives every

@@ -66,3 +66,11 @@ stat("4 layers + epilogue", t2 - t1)
 per = (t2[:, 1:] - t2[:, :-1])[valid[:, 1:] & valid[:, :-1]]
 print("%-28s mean %7.0f  p50 %7.0f" % ("tile period", per.mean(), np.median(per)))
 print("MFMA floor per tile and wave: 784 MFMAs x 32 cycles = 25088 cycles")
+t7, kind = ts[:, :, 7], ts[:, :, 3]
+stat("  3 hidden layers", t7 - t1)
+for name, m in (("fast (one segment)", kind == 1), ("few runs (registers)", kind == 2),
+                ("general epilogue", kind == 0)):
+    a = (t2 - t7)[valid & m]
+    if a.size:
+        print("  last layer, %-18s n %5d  mean %7.0f  p50 %7.0f  p90 %7.0f" % (
+            name, a.size, a.mean(), np.median(a), np.percentile(a, 90)))
