@@ -379,6 +379,65 @@ def test_graphnet_auto_center_layer(dev, auto_offset, shuffle):
     np.testing.assert_allclose(out[:, :300], ref, atol=FP_TOL, rtol=1e-4)
 
 
+@pytest.mark.parametrize("layer", ["pool", "gnn"])
+def test_segmax_epilogue_paths_are_bit_identical(dev, layer):
+    """The scatter-max epilogue has three forms -- whole tile = one run
+    (registers), a few runs (masked, registers), any tile (transposed LDS
+    stage) -- chosen per 64-row tile.  Fan-ins from 1 to 300 put all three to
+    work in one launch; switching the register forms off (ablation bits of
+    `mlp_debug`) must not change a single bit, and the result matches the
+    oracle."""
+    from pointgnn_amd import _lib, gnn
+    rng = np.random.default_rng(5)
+    k, n_pts = 700, 5000
+    deg = rng.choice([1, 2, 3, 5, 9, 40, 64, 65, 130, 300], size=k,
+                     p=[.15, .1, .1, .1, .1, .15, .05, .05, .1, .1])
+    dst = np.repeat(np.arange(k), deg).astype(np.int32)
+    cfg = configs.car_auto_config(1)
+    params = weights.init_params(cfg, seed=6, bias_scale=0.1)
+    store = _store(params, dev)
+    if layer == "pool":
+        src = rng.integers(0, n_pts, dst.shape[0]).astype(np.int32)
+        xyz = rng.standard_normal((n_pts, 3)).astype(np.float32)
+        inten = rng.random((n_pts, 1)).astype(np.float32)
+        kp = rng.choice(n_pts, k, replace=False).astype(np.int32).reshape(-1, 1)
+        edges = np.stack([src, dst], axis=1)
+        kw = cfg["model_kwargs"]["layer_configs"][0]["kwargs"]
+
+        def run():
+            with gnn.parameters(store), gnn.variable_scope("layer1"):
+                return gnn.PointSetPooling().apply_regular(
+                    T(inten, dev), T(xyz, dev), T(kp, dev), T(edges, dev),
+                    **kw).cpu().numpy()
+        ref = gn.point_set_pooling(params, "layer1", inten, xyz, kp, edges,
+                                   dtype=np.float64)
+    else:
+        src = rng.integers(0, k, dst.shape[0]).astype(np.int32)
+        xyz = rng.standard_normal((k, 3)).astype(np.float32)
+        h = np.zeros((k, 304), np.float32)
+        h[:, :300] = rng.standard_normal((k, 300)).astype(np.float32)
+        edges = np.stack([src, dst], axis=1)
+        kw = cfg["model_kwargs"]["layer_configs"][1]["kwargs"]
+
+        def run():
+            with gnn.parameters(store), gnn.variable_scope("layer2"):
+                return gnn.GraphNetAutoCenter().apply_regular(
+                    T(h, dev), T(xyz, dev), None, T(edges, dev),
+                    **kw).cpu().numpy()
+        ref = gn.graphnet_auto_center(params, "layer2", h[:, :300], xyz, edges,
+                                      auto_offset=True, dtype=np.float64)
+    outs = {}
+    try:
+        for bits in (0, 32, 128, 32 | 128):
+            _lib.set_tunable("mlp_debug", bits)
+            outs[bits] = run()
+    finally:
+        _lib.set_tunable("mlp_debug", 0)
+    for bits in (32, 128, 32 | 128):
+        assert np.array_equal(outs[0], outs[bits]), bits
+    np.testing.assert_allclose(outs[0][:, :300], ref, atol=FP_TOL, rtol=1e-4)
+
+
 @pytest.mark.parametrize("auto_offset,k", [(True, 1000), (False, 37), (True, 16)])
 def test_vertex_pre_edge_equals_unfused_entries(dev, auto_offset, k):
     """pgnn_vertex_pre_edge_fwd == pgnn_mlp_fwd (offset chain) +
