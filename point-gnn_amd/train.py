@@ -28,8 +28,8 @@ from . import _lib
 from .gnn import padded_width
 from .weights import init_params, mlp_names, variable_specs
 
-__all__ = ["Trainer", "batch_data", "learning_rate",
-           "allreduce_endpoint_counts", "allreduce_gradients"]
+__all__ = ["Trainer", "batch_data", "learning_rate", "fetch_data",
+           "train_epochs", "allreduce_endpoint_counts", "allreduce_gradients"]
 
 
 def learning_rate(train_config, step):
@@ -98,6 +98,131 @@ def allreduce_gradients(flat_grad, sums=None, group=None):
         if sums is not None:
             dist.all_reduce(sums, group=group)
     return flat_grad
+
+
+_ASSIGN = {'yaw': 'assign_classaware_label_to_points',
+           'Car': 'assign_classaware_car_label_to_points',
+           'Pedestrian_and_Cyclist':
+               'assign_classaware_ped_and_cyc_label_to_points'}
+
+
+def fetch_data(dataset, frame_idx, config, train_config, aug_fn=None):
+    """train.py:78-133 with every per-point step on the device: crop to the
+    image, augmentations, training-mode graph, label assignment, box
+    encoding.  Returns the 7-tuple `batch_data` / `Trainer.train_step` take
+    (device tensors)."""
+    from . import box_encoding, graph_gen, preprocess
+    from .run import _input_features
+    points = dataset.get_cam_points_in_image_with_rgb(
+        frame_idx, config['downsample_by_voxel_size'])
+    labels = dataset.get_label(frame_idx)
+    if 'crop_aug' in train_config:
+        raise NotImplementedError("crop_aug: no shipped train config uses it")
+    if aug_fn is None:
+        aug_fn = preprocess.get_data_aug(
+            train_config.get('data_aug_configs', []))
+    points, labels = aug_fn(points, labels)
+    points = preprocess.finish(points)
+    fn = graph_gen.get_graph_generate_fn(config['graph_gen_method'])
+    coords, kps, edges = fn(points.xyz, **config['graph_gen_kwargs'])
+    input_v = _input_features(config, points).contiguous()
+    level = config['model_kwargs']['layer_configs'][-1]['graph_level']
+    last_xyz = coords[level + 1]
+    cls_labels, boxes_3d, valid, label_map = getattr(
+        dataset, _ASSIGN[config['label_method']])(
+        labels, last_xyz,
+        expend_factor=train_config.get('expend_factor', (1.0, 1.0, 1.0)))
+    encoded = box_encoding.get_box_encoding_fn(config['box_encoding_method'])(
+        cls_labels, last_xyz, boxes_3d, label_map)
+    return (input_v, coords, kps, edges, cls_labels, encoded, valid)
+
+
+def train_epochs(dataset, config, train_config, trainer=None, max_epoch=None,
+                 log=None, process_group=None):
+    """The epoch loop of train.py:500-650 for THIS rank (one process per GPU;
+    the reference drives NUM_GPU towers from one process): resume from
+    `train_dir`, a fresh random frame order per epoch (drawn by rank 0), each
+    rank fetching its `batch_size / world` frames of every batch, train_step,
+    the streaming metrics and the reference's report lines, a checkpoint +
+    config files every `save_every_epoch` epochs, at `max_steps` and at the
+    end.  Returns (trainer, last results dict)."""
+    import json
+    import os
+    import time
+    import torch.distributed as dist
+    from . import metrics as metrics_mod, preprocess
+    world, rank = 1, 0
+    if dist.is_available() and dist.is_initialized():
+        world, rank = dist.get_world_size(process_group), \
+            dist.get_rank(process_group)
+    if trainer is None:
+        trainer = Trainer(config, train_config, process_group=process_group)
+    train_dir = train_config['train_dir']
+    if os.path.isdir(train_dir) and any(
+            f.endswith('.index') for f in os.listdir(train_dir)):
+        trainer.load_checkpoint(train_dir)
+    aug_fn = preprocess.get_data_aug(train_config.get('data_aug_configs', []))
+    n_samples = train_config.get('NUM_TEST_SAMPLE', -1)
+    if n_samples is None or n_samples < 0:
+        n_samples = dataset.num_files
+    batch_size = int(train_config.get('batch_size', 1))
+    per_rank = batch_size // world
+    assert per_rank >= 1, "batch_size smaller than the number of ranks"
+    meter = metrics_mod.StreamingMetrics(config['num_classes'],
+                                         device=trainer.device)
+    if max_epoch is None:
+        max_epoch = train_config['max_epoch']
+
+    def save():
+        if rank != 0:
+            return
+        trainer.save_checkpoint(train_dir)
+        with open(os.path.join(train_dir, train_config.get(
+                'config_path', 'config')), 'w') as f:
+            json.dump(config, f, sort_keys=True, indent=4)   # save_config
+        with open(os.path.join(train_dir, 'train_config'), 'w') as f:
+            json.dump(train_config, f, sort_keys=True, indent=4)
+
+    results = {}
+    first = (trainer.global_step * batch_size) // max(n_samples, 1)
+    for epoch_idx in range(first, max_epoch):
+        meter.reset()
+        start = time.time()
+        order = torch.from_numpy(np.random.permutation(n_samples))
+        if world > 1:
+            order = order.to(trainer.device)
+            dist.broadcast(order, 0, group=process_group)
+            order = order.cpu()
+        order = order.numpy()
+        for b0 in range(0, n_samples - batch_size + 1, batch_size):
+            mine = order[b0 + rank * per_rank:b0 + (rank + 1) * per_rank]
+            frames = [fetch_data(dataset, int(i), config, train_config, aug_fn)
+                      for i in mine]
+            batch = batch_data(frames)
+            results = trainer.train_step(batch)
+            results['total_loss'] = results['cls_loss'] + \
+                results['loc_loss'] + results['reg_loss']
+            probs = torch.softmax(
+                trainer.last_logits[:, :config['num_classes']], dim=1)
+            results.update(meter.update(probs, batch[4], results))
+            results['step'] = trainer.global_step
+            max_steps = train_config.get('max_steps', -1)
+            if max_steps and max_steps > 0 and \
+                    trainer.global_step >= max_steps:
+                save()
+                return trainer, results
+        if log is not None and results:
+            log('STEP: %d, epoch_idx: %d, lr: %f, time cost: %f' % (
+                results['step'], epoch_idx, results['learning_rate'],
+                time.time() - start))
+            log('cls:%f, loc:%f, reg:%f, loss: %f' % (
+                results['cls_loss'], results['loc_loss'], results['reg_loss'],
+                results['total_loss']))
+            log(meter.format(results))
+        if (epoch_idx + 1) % train_config.get('save_every_epoch', 1) == 0:
+            save()
+    save()
+    return trainer, results
 
 
 class _Fc(object):
@@ -582,6 +707,7 @@ class Trainer(object):
             counts = allreduce_endpoint_counts(k, float(num_valid), self.device,
                                                self.pg)
         logits, pred = self.forward(input_v, coords, kps, edges)
+        self.last_logits = logits   # for the streaming metrics (train.py:299)
         assert int(logits.shape[0]) == k, "labels do not match the vertices"
         if counts is None:
             counts = allreduce_endpoint_counts(k, float(va.sum().item()),

@@ -55,30 +55,28 @@ def test_files_to_kitti_txt(tmp_path, weights_kind):
         gold_w = weights.init_params(cfg, seed=3, bias_scale=0.05)
     tf_bundle.save_checkpoint(str(tmp_path / "ckpt"), gold_w,
                               global_step=1400000)
-    # ---- device chain
+    # ---- device chain: pointgnn_amd.run = run.py's frame loop
+    from pointgnn_amd import run as RUN
     ds = KD.KittiDataset(str(tmp_path / "image_2"), str(tmp_path / "velodyne"),
                          str(tmp_path / "calib"))
-    calib = ds.get_calib(0)
-    pts = ds.get_cam_points_in_image_with_rgb(0)
+    td = RUN.run_dataset(ds, cfg, str(tmp_path / "ckpt"), str(tmp_path / "out"))
+    assert td['frames'] == 1 and td['gnn inference'] > 0
+    out_file = str(tmp_path / "out" / "data" / (ds.get_filename(0) + ".txt"))
+    model = RUN.build_model(cfg, str(tmp_path / "ckpt"))
+    rows, st = RUN.detect_frame(ds, 0, model, cfg)
     params = tf_bundle.load_checkpoint(str(tmp_path / "ckpt"))
     params.pop("Variable")
-    model = models.get_model(cfg["model_name"])(
-        num_classes=cfg["num_classes"], box_encoding_len=7, mode="test",
-        **cfg["model_kwargs"]).load_state_dict(params)
-    fn = graph_gen.get_graph_generate_fn(cfg["graph_gen_method"])
-    coords, kps, edges = fn(pts.xyz, **cfg["runtime_graph_gen_kwargs"])
-    logits, box_enc = model.predict(pts.attr[:, :1], coords, kps, edges, False)
-    probs = model.postprocess(logits)
+    pts, coords, kps, edges = st['points'], st['coords'], st['kps'], st['edges']
+    logits, box_enc, probs = st['logits'], st['box_encodings'], st['probs']
+    labels, boxes, scores, idx = (st['class_labels'], st['boxes_3d'],
+                                  st['scores'], st['nms_indices'])
+    cand_idx = st['candidate_indices']
     lmap = KO.LABEL_MAPS[cfg["label_method"]]
-    labels, boxes, scores, idx = nms.detect_boxes(
-        probs, box_enc, coords[-1], lmap, cfg["nms_overlapped_thres"])
-    cand_idx, _ = nms.select_candidates(probs)
-    cand_xyz = coords[-1][(cand_idx // cfg["num_classes"]).long()]
-    rows = KO.detections_to_kitti_labels(labels, boxes, scores, calib,
-                                         cfg["label_method"],
-                                         candidate_xyz=cand_xyz)
-    out_file = str(tmp_path / "out" / "data" / (ds.get_filename(0) + ".txt"))
-    KO.write_kitti_txt(out_file, rows)
+    # the file run_dataset wrote holds exactly these rows
+    import io
+    buf = str(tmp_path / "again.txt")
+    KO.write_kitti_txt(buf, rows)
+    assert open(buf).read() == open(out_file).read()
 
     # ---- the same chain in the oracle (GNN on the device-built graph: the
     # 'center' keypoint pick has legitimate ties)
@@ -207,3 +205,69 @@ def test_training_sample_from_kitti_files(tmp_path):
     assert np.isfinite([out['cls_loss'], out['loc_loss'], out['reg_loss']]).all()
     assert out['num_endpoint'] == len(o_cls)
     assert out['num_valid_endpoint'] == float(o_valid.sum())
+
+
+def test_train_epochs_on_kitti_files(tmp_path):
+    """train.py's epoch loop (pointgnn_amd.train.train_epochs) on a three-frame
+    KITTI directory: fetch_data -> batch_data -> train_step -> metrics ->
+    checkpoints; a second call resumes from the checkpoint it finds."""
+    import torch
+    from test_ingest_cpu import _write_png_header_only
+    from oracle import labels_oracle as LO
+    from pointgnn_amd import kitti_dataset as KD, tf_bundle, train
+    cfg = configs.get_config("car_auto_T1")
+    for d in ("image_2", "velodyne", "calib", "label_2"):
+        (tmp_path / d).mkdir()
+    for i in range(3):
+        name = "%06d" % i
+        velo = _velodyne_scan(30 + i)
+        velo.tofile(str(tmp_path / "velodyne" / (name + ".bin")))
+        (tmp_path / "calib" / (name + ".txt")).write_text("".join(IO.CALIB_LINES))
+        _write_png_header_only(str(tmp_path / "image_2" / (name + ".png")),
+                               375, 1242)
+        cam, _, _ = IO.cam_points_in_image(velo, IO.get_calib(IO.CALIB_LINES),
+                                           (375, 1242))
+        LO.write_label_file(str(tmp_path / "label_2" / (name + ".txt")),
+                            LO.synthetic_labels(30 + i, cam, n_boxes=10))
+    ds = KD.KittiDataset(str(tmp_path / "image_2"), str(tmp_path / "velodyne"),
+                         str(tmp_path / "calib"), str(tmp_path / "label_2"),
+                         is_training=True, num_classes=cfg["num_classes"])
+    tcfg = {
+        'train_dir': str(tmp_path / "ckpt"), 'batch_size': 1, 'max_epoch': 2,
+        'save_every_epoch': 1, 'initial_lr': 0.05, 'decay_step': 4,
+        'decay_factor': 0.5, 'optimizer': 'sgd', 'unify_copies': True,
+        'NUM_TEST_SAMPLE': -1, 'config_path': 'config',
+        'data_aug_configs': [
+            {"method_name": "random_rotation_all",
+             "method_kwargs": {"method_name": "normal", "yaw_std": 0.39,
+                               "expend_factor": (1.0, 1.0, 1.0)}},
+            {"method_name": "random_flip_all",
+             "method_kwargs": {"flip_prob": 0.5}}]}
+    np.random.seed(3)
+    # one sample by itself: the 7-tuple of train.py:78-133
+    sample = train.fetch_data(ds, 1, cfg, tcfg)
+    k = int(sample[1][-1].shape[0])
+    assert sample[0].shape[1] == 1 and sample[4].shape == (k, 1)
+    assert sample[5].shape == (k, 1, 7) and sample[6].shape == (k, 1, 1)
+    assert sample[5].dtype == torch.float32 and sample[4].dtype == torch.int32
+    lines = []
+    tr, res = train.train_epochs(ds, cfg, tcfg, log=lines.append)
+    assert tr.global_step == 6 and res['step'] == 6
+    assert res['learning_rate'] == pytest.approx(0.05 * 0.5)   # step 5 // 4
+    for key in ('cls_loss', 'loc_loss', 'reg_loss', 'total_loss', 'recall_0',
+                'precision_1', 'mAP_1'):
+        assert np.isfinite(res[key]), key
+    assert any(l.startswith('STEP: 6, epoch_idx: 1') for l in lines)
+    assert any('Class_1: recall=' in l for l in lines)
+    ck = tf_bundle.load_checkpoint(tcfg['train_dir'])
+    assert int(ck['Variable']) == 6
+    assert os.path.exists(os.path.join(tcfg['train_dir'], 'config'))
+    assert os.path.exists(os.path.join(tcfg['train_dir'], 'train_config'))
+    w6 = tr.state_dict()
+    for name, v in w6.items():
+        assert np.array_equal(ck[name], v), name
+    # resume: a new trainer picks the checkpoint up and runs epoch 2 only
+    tcfg2 = dict(tcfg, max_epoch=3)
+    tr2, res2 = train.train_epochs(ds, cfg, tcfg2)
+    assert tr2.global_step == 9
+    assert int(tf_bundle.load_checkpoint(tcfg['train_dir'])['Variable']) == 9
