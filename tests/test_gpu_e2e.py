@@ -271,3 +271,15 @@ def test_train_epochs_on_kitti_files(tmp_path):
     tr2, res2 = train.train_epochs(ds, cfg, tcfg2)
     assert tr2.global_step == 9
     assert int(tf_bundle.load_checkpoint(tcfg['train_dir'])['Variable']) == 9
+    # ---- eval.py's pass over the same files with the last checkpoint
+    from pointgnn_amd import eval as EV
+    ev_lines = []
+    ev = EV.eval_once(ds, cfg, {'data_aug_configs': [], 'NUM_TEST_SAMPLE': -1},
+                      checkpoint_dir=tcfg['train_dir'], log=ev_lines.append)
+    assert ev['step'] == 9
+    for c in range(cfg['num_classes']):
+        for key in ('recall_%d', 'precision_%d', 'mAP_%d', 'loc_loss_cls_%d'):
+            assert np.isfinite(ev[key % c])
+        assert 'loc_loss_cls_%d_box_6' % c in ev
+    assert np.isfinite(ev['total_loss']) and ev['total_loss'] > 0
+    assert ev_lines[0].startswith('STEP: 9')
