@@ -140,12 +140,33 @@ def exported_symbols():
     return sorted(_SIGNATURES)
 
 
+def _build_missing():
+    """A source checkout without the built library (the .so is git-ignored):
+    compile it once with hipcc if there is one.  Ranks of one node serialise
+    on a lock file so that `torch.distributed.run` does not start N builds."""
+    import fcntl
+    import shutil
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        return
+    lock = os.path.join(os.path.dirname(LIB_PATH), ".build.lock")
+    with open(lock, "w") as f:
+        fcntl.flock(f, fcntl.LOCK_EX)
+        try:
+            if not os.path.exists(LIB_PATH):
+                from . import build as _build
+                _build.build(verbose=False)
+        finally:
+            fcntl.flock(f, fcntl.LOCK_UN)
+
+
 def load():
     """Load (once) and return the ctypes library.  Raises when it is missing:
     build it with `python -m pointgnn_amd.build` (or __graft_entry__.build())."""
     global _lib
     if _lib is not None:
         return _lib
+    if not os.path.exists(LIB_PATH) and not os.environ.get("PGNN_LIB"):
+        _build_missing()
     if not os.path.exists(LIB_PATH):
         raise PointGnnHipError(
             "libpointgnn_hip.so not found at %s -- the HIP extension is "
