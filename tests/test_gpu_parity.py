@@ -598,6 +598,41 @@ def test_full_size_properties(dev, name, preset):
                                atol=FP_TOL, rtol=1e-4)
 
 
+@pytest.mark.parametrize("name", ["car_auto_T3", "ped_cyl_auto_T3"])
+def test_large_scan_edges_equal_oracle(dev, name):
+    """Far above the bench size: a 170-degree scan at 0.03-degree azimuth
+    steps (363 k returns -> 5-8 M level-0 edges, up to 1.4 M level-1 edges).
+    Both edge lists still equal the oracle's brute-force predicate, and the
+    whole model runs to finite, repeatable outputs."""
+    import torch
+    from pointgnn_amd import graph_gen, models
+    cfg = configs.get_config(name)
+    xyz, inten = synthetic_cloud(
+        seed=0, n_points=400000, fov_deg=170.0, az_step_deg=0.03,
+        groups=((40, 20.0, 68.0, 10.0, 20.0, 6.0, 14.0),
+                (60, 5.0, 60.0, 1.6, 4.5, 1.4, 1.9)))
+    assert len(xyz) > 300000
+    fn = graph_gen.get_graph_generate_fn(cfg["graph_gen_method"])
+    coords, kps, edges = fn(T(xyz, dev), **cfg["runtime_graph_gen_kwargs"])
+    assert int(edges[0].shape[0]) > 4000000
+    c_np = [c.cpu().numpy() for c in coords]
+    lcfg = cfg["runtime_graph_gen_kwargs"]["level_configs"]
+    for lvl in (0, 1):
+        ref = go.radius_graph_c(c_np[lvl], c_np[lvl + 1],
+                                lcfg[lvl]["graph_gen_kwargs"]["radius"])
+        assert np.array_equal(go.canonical_edges(edges[lvl].cpu().numpy()),
+                              go.canonical_edges(ref)), lvl
+    params = weights.init_params(cfg, seed=0, bias_scale=0.05)
+    model = models.get_model(cfg["model_name"])(
+        num_classes=cfg["num_classes"], box_encoding_len=7, mode="test",
+        **cfg["model_kwargs"]).load_state_dict(params)
+    f = T(inten, dev)
+    lg1, bx1 = model.predict(f, coords, kps, edges, False)
+    lg2, bx2 = model.predict(f, coords, kps, edges, False)
+    assert torch.isfinite(lg1).all() and torch.isfinite(bx1).all()
+    assert torch.equal(lg1, lg2) and torch.equal(bx1, bx2)
+
+
 def test_pipelined_frames_equal_sequential(dev):
     """The multi-stream schedules (engine.run_frames_pipelined, one or two
     GNN streams) must return bit-identical results to frame-at-a-time
