@@ -121,6 +121,10 @@ def roofline_scatter_max(torch, edges1, n_k, width, reps=30):
         "traffic": traffic, "algorithmic_bytes": alg,
         "avg_launch_us": dur * 1e6,
         "note": "duration includes the 4*K*C-byte lowest() fill memset",
+        "scope": "the kernel BASELINE.json's metric and SURVEY 8(d) name "
+                 "(standalone scatter-max, HBM-bound); the kernel with the "
+                 "largest share of GPU time in the frame is the fused edge "
+                 "kernel, whose MFMA roofline is in `roofline_mfma`",
     }
 
 
