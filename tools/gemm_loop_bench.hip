@@ -18,7 +18,7 @@ std::string &last_error() {
 }
 }  // namespace pgnn
 
-enum { V_REAL = 0, V_NO_B = 1, V_NO_A = 2, V_SPLIT = 3, V_B_L1 = 4, V_UNROLL = 5, V_UNROLL4 = 6, V_NO_AB = 7, V_ASM = 8, V_PEEL2 = 9, V_PEEL3 = 10 };
+enum { V_REAL = 0, V_NO_B = 1, V_NO_A = 2, V_SPLIT = 3, V_B_L1 = 4, V_UNROLL = 5, V_UNROLL4 = 6, V_NO_AB = 7, V_ASM = 8, V_PEEL2 = 9, V_PEEL3 = 10, V_M32 = 11, V_M32_NOAB = 12, V_EARLY3 = 13, V_EARLY3B = 14 };
 
 
 // Compiler-managed loads, NS register stages, loop body WITHOUT inner
@@ -150,6 +150,161 @@ __device__ __forceinline__ void gemm_tile_asm(const float *__restrict__ tile, in
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// Three register stages, refill issued BEFORE the MFMAs of the stage being
+// consumed (prefetch distance two K-groups), no inner branches: whatever wait
+// the compiler puts at the loop header only covers loads that have had a full
+// K-group of matrix work to land.  B3: only the B (global) operand has three
+// stages, A (LDS) keeps two.
+template <bool A3>
+__device__ __forceinline__ void gemm_tile_early3(const float *__restrict__ tile, int ld,
+                                                 const LayerDev &L, int wave, int lane,
+                                                 v4f (&acc)[4][5]) {
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int j = 0; j < 5; ++j) acc[m][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+  const v4f *__restrict__ wp = reinterpret_cast<const v4f *>(L.wp) + lane;
+  const float *arow = tile + (lane & 15) * ld + 4 * (lane >> 4);
+  const int qstride = L.nt * 64;
+  const int kq = L.kq;
+  int toff[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    int t = wave + 4 * j;
+    if (t > L.nt - 1) t = L.nt - 1;
+    toff[j] = t * 64;
+  }
+  v4f a[3][4], b[3][5];
+  auto fetchb = [&](int q, v4f (&fb)[5]) {
+    if (q > kq - 1) q = kq - 1;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) fb[j] = wp[(size_t)q * qstride + toff[j]];
+  };
+  auto fetcha = [&](int q, v4f (&fa)[4]) {
+    if (q > kq - 1) q = kq - 1;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+      fa[m] = *reinterpret_cast<const v4f *>(arow + m * 16 * ld + 16 * q);
+  };
+  auto mma = [&](const v4f (&fa)[4], const v4f (&fb)[5]) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+          acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[m][s], fb[j][s],
+                                                           acc[m][j], 0, 0, 0);
+  };
+  fetchb(0, b[0]);
+  fetchb(1, b[1]);
+  fetcha(0, a[0]);
+  fetcha(1, a[1]);
+  int q = 0;
+  for (; q + 3 <= kq; q += 3) {
+#pragma unroll
+    for (int st = 0; st < 3; ++st) {
+      fetchb(q + st + 2, b[(st + 2) % 3]);
+      if (A3) {
+        fetcha(q + st + 2, a[(st + 2) % 3]);
+        mma(a[st], b[st]);
+      } else {
+        // A: two stages, indexed by parity of the absolute group number is not
+        // static here; keep three A slots but refill one group ahead only
+        mma(a[st], b[st]);
+        fetcha(q + st + 2, a[(st + 2) % 3]);
+      }
+    }
+  }
+#pragma unroll
+  for (int st = 0; st < 3; ++st)
+    if (q + st < kq) mma(a[st], b[st]);
+}
+
+// Same FLOPs and the same number of operand loads per K-group as
+// gemm_tile_split<4,3>, but the 16 full column tiles of a wave are computed as
+// 2 x 2 blocks of v_mfma_f32_32x32x2_f32 (64-cycle instructions, half as many
+// to issue, half the operand-register reads per FLOP); the three leftover
+// 16x16 pieces stay 16x16x4.  Timing experiment only: fragment layouts are
+// not the real ones, values are meaningless.
+typedef float v16f __attribute__((ext_vector_type(16)));
+template <bool LOADS>
+__device__ __forceinline__ float gemm_tile_m32(const float *__restrict__ tile, int ld,
+                                               const LayerDev &L, int wave, int lane) {
+  v16f acc[2][2];
+  v4f accr[3];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[r][c][i] = 0.f;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) accr[r] = (v4f){0.f, 0.f, 0.f, 0.f};
+  const v4f *__restrict__ wp = reinterpret_cast<const v4f *>(L.wp) + lane;
+  const float *arow = tile + (lane & 15) * ld + 4 * (lane >> 4);
+  const int qstride = L.nt * 64;
+  const int kq = L.kq;
+  v4f a[2][2][2], b[2][2][2], ar[2], br[2][3];
+  auto fetch = [&](int q, int st) {
+    if (q > kq - 1) q = kq - 1;
+    const v4f *wq = wp + (size_t)q * qstride;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        b[st][c][h] = LOADS ? wq[(wave + 4 * (2 * c + h)) * 64]
+                            : (v4f){0.5f + q, 0.25f, -0.5f, 1.0f + c};
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+      br[st][r] = LOADS ? wq[(16 + r) * 64] : (v4f){0.5f + q, 0.25f, -0.5f, 1.0f + r};
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        a[st][r][h] = LOADS ? *reinterpret_cast<const v4f *>(arow + (2 * r + h) * 16 * ld + 16 * q)
+                            : (v4f){0.5f + q, 0.25f + r, -0.5f, 1.0f};
+    ar[st] = LOADS ? *reinterpret_cast<const v4f *>(arow + wave * 16 * ld + 16 * q)
+                   : (v4f){0.5f, 0.25f + q, -0.5f, 1.0f};
+  };
+  fetch(0, 0);
+  fetch(1, 1);
+  for (int q = 0; q < kq; q += 2) {
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      if (q + st < kq) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+              for (int c = 0; c < 2; ++c)
+                acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                    a[st][r][h][s], b[st][c][h][s], acc[r][c], 0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int r = 0; r < 3; ++r)
+            accr[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[st][s], br[st][r][s],
+                                                           accr[r], 0, 0, 0);
+        fetch(q + st + 2, st);
+      }
+    }
+  }
+  float sink = 0.f;
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sink += acc[r][c][i];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) sink += accr[r][0] + accr[r][1] + accr[r][2] + accr[r][3];
+  return sink;
+}
+
 template <int VARIANT>
 __global__ __launch_bounds__(256, 2) void loop_kernel(LayerDev L, int iters,
                                                       float *out) {
@@ -163,7 +318,9 @@ __global__ __launch_bounds__(256, 2) void loop_kernel(LayerDev L, int iters,
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float sink = 0.f;
   for (int it = 0; it < iters; ++it) {
-    if (VARIANT == V_SPLIT) {
+    if (VARIANT == V_M32 || VARIANT == V_M32_NOAB) {
+      sink += gemm_tile_m32<VARIANT == V_M32>(tile, ld, L, wave, lane);
+    } else if (VARIANT == V_SPLIT) {
       v4f acc[4][4], accr[3];
       gemm_tile_split<4, 3>(tile, ld, L, 0, wave, lane, acc, accr);
 #pragma unroll
@@ -176,7 +333,11 @@ __global__ __launch_bounds__(256, 2) void loop_kernel(LayerDev L, int iters,
         sink += accr[r][0] + accr[r][1] + accr[r][2] + accr[r][3];
     } else {
       v4f acc[4][5];
-      if (VARIANT == V_PEEL2) {
+      if (VARIANT == V_EARLY3) {
+        gemm_tile_early3<true>(tile, ld, L, wave, lane, acc);
+      } else if (VARIANT == V_EARLY3B) {
+        gemm_tile_early3<false>(tile, ld, L, wave, lane, acc);
+      } else if (VARIANT == V_PEEL2) {
         gemm_tile_peel<2>(tile, ld, L, wave, lane, acc);
       } else if (VARIANT == V_PEEL3) {
         gemm_tile_peel<3>(tile, ld, L, wave, lane, acc);
@@ -299,7 +460,7 @@ void run(const LayerDev &L, int iters, double mfma_per_wave, const char *what) {
   hipMemcpy(h, out, 1024, hipMemcpyDeviceToHost);
   if (VARIANT == V_REAL) {
     for (int i = 0; i < 256; ++i) g_ref[i] = h[i];
-  } else if (VARIANT == V_ASM || VARIANT == V_UNROLL || VARIANT == V_PEEL2 || VARIANT == V_PEEL3) {
+  } else if (VARIANT == V_ASM || VARIANT == V_UNROLL || VARIANT == V_PEEL2 || VARIANT == V_PEEL3 || VARIANT == V_EARLY3 || VARIANT == V_EARLY3B) {
     double worst = 0;
     for (int i = 0; i < 256; ++i) {
       const double d = fabs((double)h[i] - g_ref[i]) / (fabs((double)g_ref[i]) + 1e-9);
@@ -327,9 +488,17 @@ int main() {
   run<V_NO_AB>(L, 400, 19 * 80.0, "(warm-up)");
   run<V_REAL>(L, iters, 19 * 80.0, "gemm_tile<4,5> (as shipped before)");
   run<V_SPLIT>(L, iters, 19 * 76.0, "gemm_tile_split<4,3>");
+  run<V_M32>(L, iters, 19 * 76.0, "split with 32x32x2 blocks (timing only)");
+  run<V_M32_NOAB>(L, iters, 19 * 76.0, "32x32x2 blocks, no loads at all");
+  run<V_SPLIT>(L, iters, 19 * 76.0, "gemm_tile_split<4,3> (again)");
+  run<V_M32>(L, iters, 19 * 76.0, "split with 32x32x2 blocks (again)");
   run<V_NO_B>(L, iters, 19 * 80.0, "no weight loads (B in registers)");
   run<V_NO_A>(L, iters, 19 * 80.0, "no LDS reads (A in registers)");
   run<V_ASM>(L, iters, 19 * 80.0, "hand-scheduled: asm B loads, 3 stages");
+  run<V_EARLY3>(L, iters, 19 * 80.0, "3 stages, refill before the MFMAs");
+  run<V_EARLY3B>(L, iters, 19 * 80.0, "3 stages, B refill before, A after");
+  run<V_REAL>(L, iters, 19 * 80.0, "gemm_tile<4,5> (again)");
+  run<V_EARLY3>(L, iters, 19 * 80.0, "3 stages, refill before (again)");
   run<V_PEEL2>(L, iters, 19 * 80.0, "no inner branches, 2 stages");
   run<V_PEEL3>(L, iters, 19 * 80.0, "no inner branches, 3 stages");
   run<V_NO_AB>(L, iters, 19 * 80.0, "no loads at all (loop + barrier only)");
