@@ -258,19 +258,20 @@ struct SegRuns {
   int d_before, d_after;      // dst of the edge before / after the tile, or -1
   int carry_id, carry_left_closed;  // CarryState coming into the tile
   int keep_open;              // the workgroup owns the next tile too
+  int sorted;                 // ids non-decreasing: closed runs are whole segments
   float *carry;               // LDS, one float per output column
   float *out;
   int64_t ldo;
   int num_segments;
 };
 
+// acc[m][j] = pre-bias accumulators of rows 16m.. and column tile t0+wave+4j
 template <int MSUB, int NT>
-__device__ __forceinline__ void layer_pass_segmax_runs(
-    const float *in, int ld_in, const LayerDev &L, int t0, int wave, int lane,
-    const SegRuns &sr) {
+__device__ __forceinline__ void segmax_runs_emit(const v4f (&acc)[MSUB][NT],
+                                                 const LayerDev &L, int t0,
+                                                 int wave, int lane,
+                                                 const SegRuns &sr) {
   constexpr int ROWS = 16 * MSUB;
-  v4f acc[MSUB][NT];
-  gemm_tile<MSUB, NT>(in, ld_in, L, t0, wave, lane, acc);
   const float *bias = L.wp + (size_t)L.kq * L.nt * 256;
   const int g4 = 4 * (lane >> 4);
   unsigned long long rem = sr.starts;
@@ -285,7 +286,7 @@ __device__ __forceinline__ void layer_pass_segmax_runs(
     if (merge) left_closed = sr.carry_left_closed != 0;
     const bool right_closed = (re < ROWS) || (sr.d_after != d);
     const bool defer = !right_closed && sr.keep_open;
-    const bool whole = left_closed && right_closed;
+    const bool whole = sr.sorted && left_closed && right_closed;
     float *out_row = sr.out + (int64_t)d * sr.ldo;
     const int lo = r - g4, hi = re - g4;
     bool inside[MSUB][4];
@@ -322,6 +323,15 @@ __device__ __forceinline__ void layer_pass_segmax_runs(
       }
     }
   }
+}
+
+template <int MSUB, int NT>
+__device__ __forceinline__ void layer_pass_segmax_runs(
+    const float *in, int ld_in, const LayerDev &L, int t0, int wave, int lane,
+    const SegRuns &sr) {
+  v4f acc[MSUB][NT];
+  gemm_tile<MSUB, NT>(in, ld_in, L, t0, wave, lane, acc);
+  segmax_runs_emit<MSUB, NT>(acc, L, t0, wave, lane, sr);
 }
 
 template <int MSUB>
