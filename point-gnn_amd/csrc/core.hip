@@ -35,7 +35,6 @@ extern int g_pool_msub;
 extern int g_mlp_debug;
 extern void *g_mlp_ts;
 extern int g_scatter_nt;
-extern int g_edge_kernel;
 extern int g_wgrad_wg_target;
 
 }  // namespace pgnn
@@ -81,10 +80,6 @@ extern "C" int pgnn_set_tunable(const char *key, int value) {
   }
   if (!strcmp(key, "mlp_debug")) {
     pgnn::g_mlp_debug = value;
-    return 0;
-  }
-  if (!strcmp(key, "edge_kernel")) {
-    pgnn::g_edge_kernel = value;
     return 0;
   }
   if (!strcmp(key, "pool_msub")) {

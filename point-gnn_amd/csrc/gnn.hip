@@ -18,7 +18,6 @@ namespace pgnn {
 int g_mlp_blocks_per_cu = 4;  // upper bound; LDS usually allows fewer
 int g_edge_msub = 0;          // 0 = auto, else force 16*msub-row tiles
 int g_pool_msub = 0;
-int g_edge_kernel = 0;        // 2 = edge_stream_kernel (128-row tiles, A in K-chunks)
 void *g_mlp_ts = nullptr;  // device buffer for per-tile timestamps (profiling)
 int g_mlp_debug = 0;  // ablation mask (benchmarks only): 1 = no gather loads,
                       // 2 = no last-layer GEMM, 4 = no epilogue, 16 = print
@@ -541,262 +540,6 @@ __global__ __launch_bounds__(256, 2) void fused_mlp_kernel(
   }
 }
 
-// ---------------------------------------------------------------------------
-// Edge kernel, streaming form (opt-in: tunable edge_kernel = 2).
-//
-// The A operand of the one GEMM the edge kernel runs is ReLU(P[src] - Q[dst]),
-// i.e. it can be produced a few columns at a time.  One 8-wave workgroup per CU
-// owns a 128-row tile; the A tile never exists as a whole: 64-column chunks go
-// through a double-buffered 2 x 36 KB LDS stage.  While the MFMAs of chunk c
-// run, the P/Q rows of chunk c+1 (or of the next tile's chunk 0) are in flight
-// into registers; they are subtracted, clamped and written to the other buffer
-// behind the MFMAs, one barrier per chunk.  Waves 0-3 and 4-7 hold rows 0-63 /
-// 64-127 and the same four column groups, in lock-step through the barriers,
-// so the second half's weight fragments are L1 hits.  Weight prefetch wraps
-// from the last K-group of a tile to the first of the next (the weights do not
-// change), so the operand pipeline never drains.  The scatter-max comes straight
-// from the accumulators (segmax_runs_emit per 64-row half; runs that cross a
-// half or tile boundary use atomic max, no carry between tiles).
-constexpr int kStreamLd = 72 /* 64 + 8 floats */;
-constexpr int kStreamDstInts = 132;  // dst[0 .. rows + 1] + pad
-
-__host__ __device__ inline size_t stream_lds_bytes(int rows) {
-  return (size_t)2 * rows * kStreamLd * 4 + 2 * kStreamDstInts * 4;
-}
-
-// HALVES = 2: the 128-row / 8-wave form described above; HALVES = 1: 64-row
-// tiles, 4 waves, two workgroups per CU in independent phase (no L1 sharing,
-// but the two waves of a SIMD do not stall in step).
-template <int HALVES>
-__global__ __launch_bounds__(256 * HALVES, HALVES == 1 ? 2 : 1) void
-edge_stream_kernel(LayerDev L, int64_t n_rows, EdgeArgs ea, SegArgs sa) {
-  constexpr int kStreamRows = 64 * HALVES;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float *buf0 = reinterpret_cast<float *>(smem);
-  float *buf1 = buf0 + kStreamRows * kStreamLd;
-  int *dst0 = reinterpret_cast<int *>(buf1 + kStreamRows * kStreamLd);
-  int *dst1 = dst0 + kStreamDstInts;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // 0..7
-  const int half = wave >> 2, cg = wave & 3;  // half == 0 when HALVES == 1
-  const int sub = lane >> 4, tl = lane & 15;
-  const int kq = L.kq, nt = L.nt;
-  const int nchunks = (kq + 3) >> 2;
-  const int ldv4 = (int)(ea.ldpq >> 2);
-  const v4f *__restrict__ P4 = reinterpret_cast<const v4f *>(ea.P);
-  const v4f *__restrict__ Q4 = reinterpret_cast<const v4f *>(ea.Q);
-  const int64_t n_tiles = (n_rows + kStreamRows - 1) / kStreamRows;
-  const int64_t tq = n_tiles / gridDim.x, trem = n_tiles % gridDim.x;
-  const int64_t tile_first =
-      blockIdx.x * tq + (blockIdx.x < trem ? blockIdx.x : trem);
-  const int64_t tile_last = tile_first + tq + (blockIdx.x < trem ? 1 : 0);
-  if (tile_first >= tile_last) return;  // uniform per workgroup
-
-  // ---- B operand (weights): stage s holds the next K-group of parity s
-  const v4f *__restrict__ wp = reinterpret_cast<const v4f *>(L.wp) + lane;
-  const int qstride = nt * 64;
-  int toff[5];
-#pragma unroll
-  for (int j = 0; j < 5; ++j) {
-    int t = cg + 4 * j;
-    if (t > nt - 1) t = nt - 1;  // clamp: computed, discarded by the epilogue
-    toff[j] = t * 64;
-  }
-  auto load_b = [&](int q, v4f (&fb)[5]) {
-#pragma unroll
-    for (int j = 0; j < 5; ++j) fb[j] = wp[(size_t)q * qstride + toff[j]];
-  };
-
-  // ---- gather: lane (sub, tl) serves rows 16*wave + 4i + sub, i = 0..3
-  auto load_idx = [&](int64_t row0, int (&s)[4], int (&d)[4], int &edge_id) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int64_t e = row0 + 16 * wave + 4 * i + sub;
-      s[i] = 0;
-      d[i] = -1;
-      if (e < n_rows) {
-        s[i] = ea.edges[2 * e];
-        d[i] = ea.edges[2 * e + 1];
-      }
-    }
-    edge_id = -1;  // dst of the edge before (lane 0) / after (lane 1) the tile
-    if (wave == 0 && lane == 0 && row0 > 0) edge_id = ea.edges[2 * (row0 - 1) + 1];
-    if (wave == 0 && lane == 1 && row0 + kStreamRows < n_rows)
-      edge_id = ea.edges[2 * (row0 + kStreamRows) + 1];
-  };
-  auto gather_issue = [&](const int (&s)[4], const int (&d)[4], int c,
-                          v4f (&p)[4], v4f (&qv)[4]) {
-    int c4 = 16 * c + tl;
-    if (c4 > ldv4 - 1) c4 = ldv4 - 1;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      p[i] = P4[(int64_t)s[i] * ldv4 + c4];
-      qv[i] = Q4[(int64_t)(d[i] < 0 ? 0 : d[i]) * ldv4 + c4];
-    }
-  };
-  auto gather_store = [&](float *buf, const int (&d)[4], int c,
-                          const v4f (&p)[4], const v4f (&qv)[4]) {
-    const bool col_ok = 16 * c + tl < 4 * kq;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      v4f h;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float t = p[i][k] - qv[i][k];
-        h[k] = (d[i] >= 0 && t > 0.0f) ? t : 0.0f;
-      }
-      if (col_ok)
-        *reinterpret_cast<v4f *>(buf + (16 * wave + 4 * i + sub) * kStreamLd +
-                                 4 * tl) = h;
-    }
-  };
-  auto store_ids = [&](int *dstb, const int (&d)[4], int edge_id) {
-    if (tl == 0) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) dstb[1 + 16 * wave + 4 * i + sub] = d[i];
-    }
-    if (wave == 0 && lane == 0) dstb[0] = edge_id;
-    if (wave == 0 && lane == 1) dstb[kStreamRows + 1] = edge_id;
-  };
-
-  int cs[4], cd[4], ns[4], nd[4], cur_id, nxt_id = -1;
-  load_idx(tile_first * kStreamRows, cs, cd, cur_id);
-  {
-    v4f p[4], qv[4];
-    gather_issue(cs, cd, 0, p, qv);
-    gather_store(buf0, cd, 0, p, qv);
-    store_ids(dst0, cd, cur_id);
-  }
-  v4f b[2][5];
-  load_b(0, b[0]);
-  load_b(kq > 1 ? 1 : 0, b[1]);
-  __syncthreads();
-  int cbuf = 0, par = 0;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    ns[i] = 0;
-    nd[i] = -1;
-  }
-
-  for (int64_t tile_id = tile_first; tile_id < tile_last; ++tile_id) {
-    const bool has_next = tile_id + 1 < tile_last;
-    if (has_next) load_idx((tile_id + 1) * kStreamRows, ns, nd, nxt_id);
-    v4f acc[4][5];
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-      for (int j = 0; j < 5; ++j) acc[m][j] = (v4f){0.f, 0.f, 0.f, 0.f};
-
-    for (int c = 0; c < nchunks; ++c) {
-      const int nq = (kq - 4 * c) < 4 ? (kq - 4 * c) : 4;
-      const bool last = c + 1 == nchunks;
-      const bool do_g = !last || has_next;
-      // (1) operands of the next chunk: in flight during this chunk's MFMAs
-      v4f p[4], qv[4];
-      if (do_g) {
-        if (!last)
-          gather_issue(cs, cd, c + 1, p, qv);
-        else
-          gather_issue(ns, nd, 0, p, qv);
-      }
-      // (2) this chunk's K-groups
-      const float *A = (cbuf ? buf1 : buf0) +
-                       (64 * half + (lane & 15)) * kStreamLd + 4 * (lane >> 4);
-      v4f a[2][4];
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-        a[0][m] = *reinterpret_cast<const v4f *>(A + m * 16 * kStreamLd);
-#pragma unroll
-      for (int qq = 0; qq < 4; ++qq) {
-        if (qq < nq) {  // wave-uniform
-          if (qq + 1 < nq) {
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-              a[(qq + 1) & 1][m] = *reinterpret_cast<const v4f *>(
-                  A + m * 16 * kStreamLd + 16 * (qq + 1));
-          }
-#pragma unroll
-          for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-              for (int j = 0; j < 5; ++j)
-                acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                    a[qq & 1][m][s], b[qq & 1][j][s], acc[m][j], 0, 0, 0);
-          int qn = 4 * c + qq + 2;  // wraps into the next tile: same weights
-          while (qn >= kq) qn -= kq;
-          load_b(qn, b[qq & 1]);
-        }
-      }
-      // (3) next chunk -> the other buffer (last read before the previous barrier)
-      if (do_g) {
-        float *nbuf = cbuf ? buf0 : buf1;
-        if (!last) {
-          gather_store(nbuf, cd, c + 1, p, qv);
-        } else {
-          gather_store(nbuf, nd, 0, p, qv);
-          store_ids(par ? dst0 : dst1, nd, nxt_id);
-        }
-      }
-      __syncthreads();
-      cbuf ^= 1;
-    }
-    if (kq & 1) {  // stage parity flips over an odd number of K-groups
-#pragma unroll
-      for (int j = 0; j < 5; ++j) {
-        const v4f t = b[0][j];
-        b[0][j] = b[1][j];
-        b[1][j] = t;
-      }
-    }
-    // ---- scatter-max of this wave's 64 rows x 5 column tiles, from registers
-    {
-      const int *dstb = par ? dst1 : dst0;
-      const int base = 64 * half;
-      SegRuns sr;
-      sr.myd = dstb[1 + base + lane];
-      const int prevd = dstb[base + lane];
-      sr.starts = __ballot(lane == 0 || sr.myd != prevd);
-      sr.d_before = dstb[base];
-      sr.d_after = dstb[base + 65];
-      sr.carry_id = -1;
-      sr.carry_left_closed = 0;
-      sr.keep_open = 0;
-      sr.sorted = sa.sorted;
-      sr.carry = nullptr;
-      sr.out = sa.out;
-      sr.ldo = sa.ldo;
-      sr.num_segments = sa.num_segments;
-      segmax_runs_emit<4, 5>(acc, L, 0, cg, lane, sr);
-    }
-    par ^= 1;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      cs[i] = ns[i];
-      cd[i] = nd[i];
-    }
-    cur_id = nxt_id;
-  }
-}
-
-template <int HALVES>
-int launch_edge_stream(const LayerDev &L, int64_t n_rows, const EdgeArgs &ea,
-                       const SegArgs &sa, hipStream_t stream) {
-  constexpr int kStreamRows = 64 * HALVES;
-  const size_t lds = stream_lds_bytes(kStreamRows);
-  auto kern = edge_stream_kernel<HALVES>;
-  PGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                               hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)lds));
-  const int64_t n_tiles = (n_rows + kStreamRows - 1) / kStreamRows;
-  int64_t grid = (int64_t)device_cu_count() * (HALVES == 1 ? 2 : 1);
-  if (grid > n_tiles) grid = n_tiles;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256 * HALVES), lds, stream,
-                     L, n_rows, ea, sa);
-  PGNN_HIP(hipGetLastError());
-  return 0;
-}
-
 __global__ void offset_apply_kernel(const float *__restrict__ xyz,
                                     const float *__restrict__ delta,
                                     int64_t ld_delta, int64_t n,
@@ -1087,11 +830,6 @@ extern "C" int pgnn_edge_mlp_scatter_max_fwd(
   PoolArgs pa = {};
   EdgeArgs ea = {P, Q, ld_pq, edges};
   SegArgs sa = {out, ld_out, num_vertices, edges_sorted & 1};
-  if ((g_edge_kernel == 2 || g_edge_kernel == 3) && p.chain.n == 1 &&
-      p.chain.l[0].kq >= 5 && p.chain.l[0].nt <= kMaxTilesPerPass)
-    return g_edge_kernel == 2
-               ? launch_edge_stream<2>(p.chain.l[0], n_edges, ea, sa, stream)
-               : launch_edge_stream<1>(p.chain.l[0], n_edges, ea, sa, stream);
   int msub = g_edge_msub;
   if (msub != 2 && msub != 4)
     msub = (plan_lds_bytes(p, 64) <= 80 * 1024 ||

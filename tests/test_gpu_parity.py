@@ -438,60 +438,6 @@ def test_segmax_epilogue_paths_are_bit_identical(dev, layer):
     np.testing.assert_allclose(outs[0][:, :300], ref, atol=FP_TOL, rtol=1e-4)
 
 
-@pytest.mark.parametrize("case", ["fanins", "fanins_unsorted", "frame", "ped"])
-def test_edge_stream_kernel_equals_tile_kernel(dev, case):
-    """The streaming edge kernel (128-row tiles, A operand produced in K-chunks;
-    tunable edge_kernel = 2) accumulates every output in the same order as the
-    tile kernel, so the two must agree bit for bit -- on crafted fan-ins 1..300
-    (runs crossing half and tile boundaries), an unsorted edge list
-    (all-atomic), a real frame graph and the 256-wide ped layer (kq = 16)."""
-    from pointgnn_amd import _lib, gnn, graph_gen
-    rng = np.random.default_rng(11)
-    cfg = configs.get_config("ped_cyl_auto_T3" if case == "ped" else "car_auto_T1")
-    width = 256 if case == "ped" else 300
-    pw = gnn.padded_width(width)
-    params = weights.init_params(cfg, seed=6, bias_scale=0.1)
-    store = _store(params, dev)
-    if case in ("frame", "ped"):
-        xyz, _ = synthetic_cloud(seed=2, preset="small")
-        fn = graph_gen.get_graph_generate_fn(cfg["graph_gen_method"])
-        coords, kps, edges = fn(T(xyz, dev), **cfg["runtime_graph_gen_kwargs"])
-        e1, x = edges[1], coords[1]
-        k = int(x.shape[0])
-    else:
-        k = 900
-        deg = rng.choice([1, 2, 3, 5, 9, 40, 63, 64, 65, 127, 128, 129, 300],
-                         size=k)
-        dst = np.repeat(np.arange(k), deg).astype(np.int32)
-        src = rng.integers(0, k, dst.shape[0]).astype(np.int32)
-        e = np.stack([src, dst], axis=1)
-        if case == "fanins_unsorted":
-            e = e[rng.permutation(len(e))]
-        e1 = T(e, dev)
-        x = T(rng.standard_normal((k, 3)).astype(np.float32), dev)
-    h = np.zeros((k, pw), np.float32)
-    h[:, :width] = rng.standard_normal((k, width)).astype(np.float32)
-    kw = cfg["model_kwargs"]["layer_configs"][1]["kwargs"]
-
-    def run():
-        with gnn.parameters(store), gnn.variable_scope("layer2"):
-            return gnn.GraphNetAutoCenter().apply_regular(
-                T(h, dev), x, None, e1, **kw).cpu().numpy()
-    try:
-        _lib.set_tunable("edge_kernel", 0)
-        ref = run()
-        outs = {}
-        for variant in (2, 3):
-            _lib.set_tunable("edge_kernel", variant)
-            outs[variant] = (run(), run())
-    finally:
-        _lib.set_tunable("edge_kernel", 0)
-    assert np.isfinite(ref).all()
-    for variant, (got, again) in outs.items():
-        assert np.array_equal(got, again), variant
-        assert np.array_equal(ref, got), variant
-
-
 @pytest.mark.parametrize("auto_offset,k", [(True, 1000), (False, 37), (True, 16)])
 def test_vertex_pre_edge_equals_unfused_entries(dev, auto_offset, k):
     """pgnn_vertex_pre_edge_fwd == pgnn_mlp_fwd (offset chain) +
