@@ -139,3 +139,81 @@ def get_config(name):
         "ped_cyl_auto_T3": lambda: ped_cyl_auto_config(3),
     }
     return table[name]()
+
+
+# ---- train / eval configs (configs/*_train_config, *_eval_config) -----------
+def load_train_config(path):
+    """util/config_util.py:16-20."""
+    return load_config(path)
+
+
+def save_config(path, config):
+    """util/config_util.py:11-14 (also used for train configs, :22-25)."""
+    with open(path, 'w') as f:
+        json.dump(config, f, sort_keys=True, indent=4)
+
+
+save_train_config = save_config
+
+
+def _data_aug_configs():
+    """The augmentation chain every shipped train config uses
+    (preprocess.py:44-78, 239-326)."""
+    return [
+        {"method_name": "random_rotation_all",
+         "method_kwargs": {"method_name": "normal",
+                           "yaw_std": 0.39269908169872414,
+                           "expend_factor": [1.0, 1.0, 1.0]}},
+        {"method_name": "random_flip_all",
+         "method_kwargs": {"flip_prob": 0.5}},
+        {"method_name": "random_box_shift",
+         "method_kwargs": {"method_name": "normal", "xyz_std": [3, 0, 3],
+                           "appr_factor": 10,
+                           "expend_factor": [1.1, 1.1, 1.1],
+                           "max_overlap_num_allowed": 100,
+                           "max_overlap_rate": 0.01, "max_trails": 100}},
+    ]
+
+
+_TRAIN_TABLE = {
+    # name: (train_dataset, max_epoch, initial_lr, decay_factor, max_steps)
+    "car_auto_T0_train": ("train_car.txt", 1718, 0.125, 0.1, 1400000),
+    "car_auto_T1_train": ("train_car.txt", 1718, 0.125, 0.1, 1400000),
+    "car_auto_T2_train": ("train_car.txt", 1718, 0.125, 0.1, 1400000),
+    "car_auto_T3_train": ("train_car.txt", 1718, 0.125, 0.1, 1400000),
+    "car_auto_T3_trainval": ("trainval_car.txt", 838, 0.125, 0.1, 1400000),
+    "car_fixed_T3_train": ("train_car.txt", 1718, 0.125, 0.1, 1400000),
+    "ped_cyl_auto_T3_trainval": ("trainval_pedestrian_cyclist.txt", 1611,
+                                 0.32, 0.25, 1000000),
+}
+
+
+def get_train_config(name):
+    """configs/<name>_train_config, e.g. name = 'car_auto_T3_train'."""
+    dataset, max_epoch, lr, decay, max_steps = _TRAIN_TABLE[name]
+    return {
+        "NUM_GPU": 2, "NUM_TEST_SAMPLE": -1, "batch_size": 4, "capacity": 1,
+        "checkpoint_path": "model", "config_path": "config",
+        "data_aug_configs": _data_aug_configs(), "decay_factor": decay,
+        "decay_step": 400000, "gpu_memusage": -1, "initial_lr": lr,
+        "load_dataset_every_N_time": 0, "load_dataset_to_mem": True,
+        "max_epoch": max_epoch, "max_steps": max_steps,
+        "num_load_dataset_workers": 16, "optimizer": "sgd",
+        "optimizer_kwargs": {}, "save_every_epoch": 20,
+        "train_dataset": dataset, "train_dir": "./checkpoints/" + name,
+        "unify_copies": True, "visualization": False,
+    }
+
+
+def get_eval_config(name):
+    """configs/<name>_eval_config for the same names as get_train_config."""
+    max_step = {"car_auto_T3_trainval": 1400298,
+                "ped_cyl_auto_T3_trainval": 1000000}.get(name, 1400170)
+    return {
+        "NUM_TEST_SAMPLE": -1, "checkpoint_path": "model",
+        "config_path": "config", "data_aug_configs": [],
+        "eval_dataset": "val.txt",
+        "eval_dir": "./checkpoints/%s_eval" % name, "eval_every_second": 60,
+        "gpu_memusage": -1, "max_step": max_step,
+        "train_dir": "./checkpoints/" + name, "visualization": False,
+    }

@@ -146,11 +146,10 @@ def train_epochs(dataset, config, train_config, trainer=None, max_epoch=None,
     the streaming metrics and the reference's report lines, a checkpoint +
     config files every `save_every_epoch` epochs, at `max_steps` and at the
     end.  Returns (trainer, last results dict)."""
-    import json
     import os
     import time
     import torch.distributed as dist
-    from . import metrics as metrics_mod, preprocess
+    from . import configs as configs_mod, metrics as metrics_mod, preprocess
     world, rank = 1, 0
     if dist.is_available() and dist.is_initialized():
         world, rank = dist.get_world_size(process_group), \
@@ -177,11 +176,10 @@ def train_epochs(dataset, config, train_config, trainer=None, max_epoch=None,
         if rank != 0:
             return
         trainer.save_checkpoint(train_dir)
-        with open(os.path.join(train_dir, train_config.get(
-                'config_path', 'config')), 'w') as f:
-            json.dump(config, f, sort_keys=True, indent=4)   # save_config
-        with open(os.path.join(train_dir, 'train_config'), 'w') as f:
-            json.dump(train_config, f, sort_keys=True, indent=4)
+        configs_mod.save_config(os.path.join(
+            train_dir, train_config.get('config_path', 'config')), config)
+        configs_mod.save_train_config(os.path.join(train_dir, 'train_config'),
+                                      train_config)
 
     results = {}
     first = (trainer.global_step * batch_size) // max(n_samples, 1)

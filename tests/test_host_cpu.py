@@ -50,6 +50,22 @@ def test_generated_configs_equal_reference_json():
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree absent")
+def test_generated_train_and_eval_configs_equal_reference_json(tmp_path):
+    for name in configs._TRAIN_TABLE:
+        ref = configs.load_train_config(
+            os.path.join(REF, "configs", name + "_train_config"))
+        assert ref == configs.get_train_config(name), name
+        ev = configs.load_config(os.path.join(REF, "configs",
+                                              name + "_eval_config"))
+        assert ev == configs.get_eval_config(name), name
+    # save/load round trip in the reference's JSON form
+    path = str(tmp_path / "train_config")
+    configs.save_train_config(path, configs.get_train_config("car_auto_T3_train"))
+    assert configs.load_train_config(path) == \
+        configs.get_train_config("car_auto_T3_train")
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree absent")
 def test_tf_bundle_reader_on_reference_checkpoints():
     for t in (0, 1):
         ck = tf_bundle.load_checkpoint(
