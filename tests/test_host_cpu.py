@@ -268,3 +268,39 @@ def test_product_path_has_no_oracle_import():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_input_features_switch_matches_run_py():
+    """run.py:226-241 / train.py:91-104: the `input_features` config key."""
+    import torch
+    from pointgnn_amd.kitti_dataset import Points
+    from pointgnn_amd.run import _input_features
+    attr = torch.arange(20, dtype=torch.float32).reshape(5, 4) + 1
+    pts = Points(xyz=torch.zeros(5, 3), attr=attr)
+    a = attr.numpy()
+    want = {
+        'irgb': a,
+        '0rgb': np.hstack([np.zeros((5, 1)), a[:, 1:]]),
+        '0000': np.zeros_like(a),
+        'i000': np.hstack([a[:, [0]], np.zeros((5, 3))]),
+        'i': a[:, [0]],
+        '0': np.zeros((5, 1)),
+    }
+    for kind, ref in want.items():
+        got = _input_features({'input_features': kind}, pts).numpy()
+        assert got.shape == ref.shape and np.array_equal(got, ref), kind
+    assert np.array_equal(attr.numpy(), a)        # the cloud is not modified
+    with pytest.raises(ValueError):
+        _input_features({'input_features': 'rgb'}, pts)
+
+
+def test_learning_rate_schedule_matches_tf_exponential_decay():
+    """train.py:375-378: tf.train.exponential_decay(staircase=True)."""
+    from pointgnn_amd.train import learning_rate
+    tc = configs.get_train_config("car_auto_T3_train")
+    assert learning_rate(tc, 0) == 0.125
+    assert learning_rate(tc, 399999) == 0.125
+    assert learning_rate(tc, 400000) == pytest.approx(0.0125)
+    assert learning_rate(tc, 1399999) == pytest.approx(0.125 * 0.1 ** 3)
+    ped = configs.get_train_config("ped_cyl_auto_T3_trainval")
+    assert learning_rate(ped, 800000) == pytest.approx(0.32 * 0.25 ** 2)
