@@ -388,15 +388,15 @@ __global__ __launch_bounds__(256, 2) void fused_mlp_kernel(
         // pipelines the two loops at depth 1 with a vmcnt(0) per row pair,
         // i.e. RPW serial L2 round trips (seen in the .s; 9k cycles per tile)
         __builtin_amdgcn_sched_barrier(0);
+        // rows past the end (dst < 0) gathered row 0 of P and Q: finite values
+        // in MFMA rows that no segment ever reads, so no validity select here
+        // (v_sub + v_max per element; measured equal to the select form)
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
-          const bool ok = __builtin_amdgcn_readlane(my_d, r) >= 0 && !no_loads;
           v4f h;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float t = p[r][i] - q[r][i];
-            h[i] = (ok && t > 0.0f) ? t : 0.0f;
-          }
+          for (int i = 0; i < 4; ++i)
+            h[i] = no_loads ? 0.0f : fmaxf(p[r][i] - q[r][i], 0.0f);
           *reinterpret_cast<v4f *>(tbase + r * ld0 + 4 * c4) = h;
         }
       }
@@ -404,13 +404,10 @@ __global__ __launch_bounds__(256, 2) void fused_mlp_kernel(
         const int c4 = c4t;
 #pragma unroll
         for (int r4 = 0; r4 < RPW / 4; ++r4) {
-          const bool ok = ddt[r4] >= 0 && !no_loads;
           v4f h;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float t = pt[r4][i] - qt[r4][i];
-            h[i] = (ok && t > 0.0f) ? t : 0.0f;
-          }
+          for (int i = 0; i < 4; ++i)
+            h[i] = no_loads ? 0.0f : fmaxf(pt[r4][i] - qt[r4][i], 0.0f);
           if (tl < tail)
             *reinterpret_cast<v4f *>(tbase + (4 * r4 + sub) * ld0 + 4 * c4) = h;
         }
