@@ -59,6 +59,17 @@ int pgnn_scatter_max_f32(const float *data, int64_t ld_data,
                          int32_t n_cols, int32_t num_segments, float *out,
                          int64_t ld_out, int32_t ids_sorted, void *stream);
 
+/* graph_scatter_sum_fn / graph_scatter_mean_fn = tf.math.unsorted_segment_sum /
+ * unsorted_segment_mean (models/gnn.py:111-119; registered by the reference,
+ * used by no shipped config).  Same arguments as pgnn_scatter_max_f32; `mean`
+ * != 0 divides every segment by max(count, 1) (empty segments give 0, as in
+ * TF) and needs `counts_ws`, int32[num_segments] of scratch.  Float atomic
+ * adds: the summation order is unspecified, as on TensorFlow's GPU kernel. */
+int pgnn_scatter_sum_f32(const float *data, int64_t ld_data,
+                         const int32_t *seg_ids, int64_t n_rows, int32_t n_cols,
+                         int32_t num_segments, float *out, int64_t ld_out,
+                         int32_t mean, int32_t *counts_ws, void *stream);
+
 /* ---- radius graph ------------------------------------------------------
  * Replaces gen_disjointed_rnn_local_graph_v3 (models/graph_gen.py:197-220):
  * for every centre, all points with float64 squared distance <= radius^2

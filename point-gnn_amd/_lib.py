@@ -40,6 +40,8 @@ _SIGNATURES = {
     "pgnn_set_debug_buffer": (c_i32, [c_vp]),
     "pgnn_scatter_max_f32": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_i32,
                                      c_vp, c_i64, c_i32, c_vp]),
+    "pgnn_scatter_sum_f32": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_i32,
+                                     c_vp, c_i64, c_i32, c_vp, c_vp]),
     "pgnn_radius_graph_workspace_bytes": (c_sz, [c_i64, c_i64]),
     "pgnn_radius_graph_count": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_f64, c_vp,
                                         c_vp, c_sz, c_vp, c_vp]),

@@ -251,3 +251,85 @@ extern "C" int pgnn_scatter_max_f32(const float *data, int64_t ld_data,
                     "scatter_max: unaligned n_cols > 1024");
   PGNN_GUARD_END
 }
+
+// ---- unsorted_segment_sum / unsorted_segment_mean (models/gnn.py:111-119) ----
+// Registered by the reference next to scatter-max but used by no shipped config:
+// a plain float atomic-add per element (TensorFlow's GPU kernel does the same,
+// so the summation order is unspecified there too); mean = sum / max(count, 1).
+namespace {
+
+__global__ void scatter_add_kernel(const float *__restrict__ data, int64_t ld,
+                                   const int32_t *__restrict__ seg, int64_t n_rows,
+                                   int32_t n_cols, int32_t num_segments,
+                                   float *__restrict__ out, int64_t ldo,
+                                   int32_t *__restrict__ counts) {
+  const int64_t total = n_rows * n_cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / n_cols;
+    const int c = (int)(i - r * n_cols);
+    const int s = seg[r];
+    if (s < 0 || s >= num_segments) continue;
+    atomicAdd(out + (int64_t)s * ldo + c, data[r * ld + c]);
+    if (counts && c == 0) atomicAdd(counts + s, 1);
+  }
+}
+
+__global__ void scatter_mean_finish_kernel(float *__restrict__ out, int64_t ldo,
+                                           int32_t n_cols, int32_t num_segments,
+                                           const int32_t *__restrict__ counts) {
+  const int64_t total = (int64_t)num_segments * n_cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t s = i / n_cols;
+    const int c = (int)(i - s * n_cols);
+    const int n = counts[s];
+    out[s * ldo + c] = out[s * ldo + c] / (float)(n > 1 ? n : 1);
+  }
+}
+
+}  // namespace
+
+extern "C" int pgnn_scatter_sum_f32(const float *data, int64_t ld_data,
+                                    const int32_t *seg_ids, int64_t n_rows,
+                                    int32_t n_cols, int32_t num_segments,
+                                    float *out, int64_t ld_out, int32_t mean,
+                                    int32_t *counts_ws, void *stream_) {
+  PGNN_GUARD_BEGIN
+  hipStream_t stream = (hipStream_t)stream_;
+  PGNN_REQUIRE(n_rows >= 0 && n_cols > 0 && num_segments >= 0, PGNN_E_INVALID,
+               "scatter_sum: negative size");
+  PGNN_REQUIRE(ld_data >= n_cols && ld_out >= n_cols, PGNN_E_INVALID,
+               "scatter_sum: row stride smaller than n_cols");
+  PGNN_REQUIRE(!mean || counts_ws, PGNN_E_INVALID,
+               "scatter_sum: mean needs the int32[num_segments] workspace");
+  if (num_segments == 0) return 0;
+  PGNN_REQUIRE(out != nullptr, PGNN_E_INVALID, "scatter_sum: out is null");
+  PGNN_HIP(hipMemset2DAsync(out, (size_t)ld_out * 4, 0, (size_t)n_cols * 4,
+                            (size_t)num_segments, stream));
+  if (mean)
+    PGNN_HIP(hipMemsetAsync(counts_ws, 0, (size_t)num_segments * 4, stream));
+  if (n_rows > 0) {
+    PGNN_REQUIRE(data != nullptr && seg_ids != nullptr, PGNN_E_INVALID,
+                 "scatter_sum: null input");
+    const int64_t total = n_rows * n_cols;
+    int64_t blocks = (total + 255) / 256;
+    const int64_t cap = (int64_t)pgnn::device_cu_count() * 16;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(scatter_add_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                       stream, data, ld_data, seg_ids, n_rows, n_cols,
+                       num_segments, out, ld_out, mean ? counts_ws : nullptr);
+    PGNN_HIP(hipGetLastError());
+  }
+  if (mean) {
+    const int64_t total = (int64_t)num_segments * n_cols;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(scatter_mean_finish_kernel, dim3((unsigned)blocks),
+                       dim3(256), 0, stream, out, ld_out, n_cols, num_segments,
+                       counts_ws);
+    PGNN_HIP(hipGetLastError());
+  }
+  return 0;
+  PGNN_GUARD_END
+}

@@ -250,12 +250,32 @@ def graph_scatter_max_fn(point_features, point_centers, num_centers,
     return out
 
 
+def _scatter_sum(point_features, point_centers, num_centers, mean):
+    lib = _lib.load()
+    data = _as_f32(point_features)
+    ids = _as_i32(point_centers.reshape(-1))
+    n_rows, n_cols = int(data.shape[0]), int(data.shape[1])
+    out = torch.empty((int(num_centers), n_cols), dtype=torch.float32,
+                      device=data.device)
+    counts = torch.empty((int(num_centers),), dtype=torch.int32,
+                         device=data.device) if mean else None
+    _lib.check(lib.pgnn_scatter_sum_f32(
+        _lib.ptr(data), data.stride(0) if n_rows else n_cols, _lib.ptr(ids),
+        n_rows, n_cols, int(num_centers), _lib.ptr(out), n_cols,
+        1 if mean else 0, _lib.ptr(counts), _lib.stream_ptr()),
+        "pgnn_scatter_sum_f32")
+    return out
+
+
 def graph_scatter_sum_fn(point_features, point_centers, num_centers):
-    raise NotImplementedError("scatter_sum: no shipped config uses it")
+    """gnn.py:111-114 = tf.math.unsorted_segment_sum (standalone op; the fused
+    layers implement scatter-max only, like every shipped config)."""
+    return _scatter_sum(point_features, point_centers, num_centers, False)
 
 
 def graph_scatter_mean_fn(point_features, point_centers, num_centers):
-    raise NotImplementedError("scatter_mean: no shipped config uses it")
+    """gnn.py:116-119 = tf.math.unsorted_segment_mean."""
+    return _scatter_sum(point_features, point_centers, num_centers, True)
 
 
 def _edges_sorted_flag(edges):

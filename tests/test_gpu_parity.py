@@ -106,6 +106,32 @@ def _edges_equal(got, ref):
         got[bad[:5]], ref[bad[:5]])
 
 
+@pytest.mark.parametrize("mean", [False, True])
+def test_scatter_sum_and_mean_match_numpy(dev, mean):
+    """graph_scatter_sum_fn / graph_scatter_mean_fn (gnn.py:111-119): float
+    atomics, so within rounding of a float64 NumPy sum; empty segments give 0,
+    out-of-range ids are dropped, an empty input is all zeros."""
+    from pointgnn_amd import gnn
+    rng = np.random.default_rng(4)
+    rows, cols, k = 5000, 37, 300
+    data = rng.standard_normal((rows, cols)).astype(np.float32)
+    ids = rng.integers(-2, k + 3, rows).astype(np.int32)
+    ids[ids == 7] = 8                                   # segment 7 stays empty
+    fn = gnn.graph_scatter_mean_fn if mean else gnn.graph_scatter_sum_fn
+    got = fn(T(data, dev), T(ids, dev), k).cpu().numpy()
+    ref = np.zeros((k, cols))
+    cnt = np.zeros(k)
+    ok = (ids >= 0) & (ids < k)
+    np.add.at(ref, ids[ok], data[ok].astype(np.float64))
+    np.add.at(cnt, ids[ok], 1)
+    if mean:
+        ref = ref / np.maximum(cnt, 1)[:, None]
+    np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-4)
+    assert np.all(got[7] == 0)
+    empty = fn(T(data[:0], dev), T(ids[:0], dev), 5).cpu().numpy()
+    assert empty.shape == (5, cols) and np.all(empty == 0)
+
+
 @pytest.mark.parametrize("fixture", ["graph_tiny.npz", "graph_small.npz"])
 def test_radius_graph_equals_reference_golden(dev, fixture):
     from pointgnn_amd import graph_gen
