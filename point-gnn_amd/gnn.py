@@ -554,15 +554,40 @@ class ClassAwarePredictor(object):
 
 
 class ClassAwareSeparatedPredictor(object):
-    """gnn.py:165-209 -- registered by the reference, used by no shipped
-    config."""
+    """gnn.py:165-209 -- registered by the reference (models.py:70), used by no
+    shipped config: the class head sees all features, the box head of class j
+    only the j-th of `num_classes` equal column groups.  Composed from the
+    injected `cls_fn` / `loc_fn` exactly as the reference does."""
 
     def __init__(self, cls_fn, loc_fn):
         self._cls_fn = cls_fn
         self._loc_fn = loc_fn
 
-    def apply_regular(self, *args, **kwargs):
-        raise NotImplementedError("classaware_separated_predictor")
+    def apply_regular(self, features, num_classes, box_encoding_len,
+                      normalization_type='fused_BN_center',
+                      activation_type='ReLU'):
+        _check_kinds(activation_type, normalization_type)
+        f = _as_f32(features)
+        nc, bl = int(num_classes), int(box_encoding_len)
+        kw = dict(is_logits=True, normalization_type=normalization_type,
+                  activation_type=activation_type)
+        boxes = []
+        with variable_scope('predictor'):
+            with variable_scope('cls'):
+                y = self._cls_fn(f, num_classes=nc, **kw)
+                logits = y[:, :nc]
+            # tf.split(features, num_classes, axis=-1): the true width is what
+            # the stored first-layer weights of the class head expect
+            width = int(_store().mlp(_scope('cls'), 1)[0][0].shape[0])
+            assert width % nc == 0, "features do not split into num_classes"
+            step = width // nc
+            with variable_scope('loc'):
+                for j in range(nc):
+                    with variable_scope('cls_%d' % j):
+                        b = self._loc_fn(f[:, j * step:(j + 1) * step],
+                                         num_classes=bl, **kw)
+                        boxes.append(b[:, :bl].unsqueeze(1))
+        return logits, torch.cat(boxes, dim=1)
 
 
 def features(t, width):

@@ -106,6 +106,58 @@ def _edges_equal(got, ref):
         got[bad[:5]], ref[bad[:5]])
 
 
+def test_classaware_separated_predictor(dev):
+    """gnn.py:165-209: class head on all features, box head j on the j-th
+    column group; composed from the injected cls_fn / loc_fn like the
+    reference (models.py:70-75)."""
+    from functools import partial
+    from pointgnn_amd import gnn
+    rng = np.random.default_rng(8)
+    k, c, nc, bl = 500, 300, 4, 7
+    params = {}
+
+    def fc(name, a, b):
+        params[name + "/weights"] = (rng.standard_normal((a, b)) /
+                                     np.sqrt(a)).astype(np.float32)
+        params[name + "/biases"] = (0.1 * rng.standard_normal(b)).astype(np.float32)
+    for n, (a, b) in zip(weights.mlp_names("output/predictor/cls", 2),
+                         [(c, 64), (64, nc)]):
+        fc(n, a, b)
+    for j in range(nc):
+        for n, (a, b) in zip(weights.mlp_names("output/predictor/loc/cls_%d" % j, 3),
+                             [(c // nc, 64), (64, 64), (64, bl)]):
+            fc(n, a, b)
+    x = np.zeros((k, gnn.padded_width(c)), np.float32)
+    x[:, :c] = rng.standard_normal((k, c)).astype(np.float32)
+    pred = gnn.ClassAwareSeparatedPredictor(
+        partial(gnn.multi_layer_fc_fn, Ks=(64,), num_layer=2),
+        partial(gnn.multi_layer_fc_fn, Ks=(64, 64), num_layer=3))
+    with gnn.parameters(_store(params, dev)), gnn.variable_scope("output"):
+        logits, boxes = pred.apply_regular(T(x, dev), nc, bl,
+                                           normalization_type='NONE',
+                                           activation_type='ReLU')
+    assert logits.shape == (k, nc) and boxes.shape == (k, nc, bl)
+
+    def mlp(v, scope, n):
+        names = weights.mlp_names(scope, n)
+        for i, nm in enumerate(names):
+            v = v @ params[nm + "/weights"].astype(np.float64) + \
+                params[nm + "/biases"].astype(np.float64)
+            if i + 1 < n:
+                v = np.maximum(v, 0)
+        return v
+    xr = x[:, :c].astype(np.float64)
+    np.testing.assert_allclose(logits.cpu().numpy(),
+                               mlp(xr, "output/predictor/cls", 2),
+                               atol=FP_TOL, rtol=1e-4)
+    step = c // nc
+    for j in range(nc):
+        np.testing.assert_allclose(
+            boxes[:, j].cpu().numpy(),
+            mlp(xr[:, j * step:(j + 1) * step], "output/predictor/loc/cls_%d" % j, 3),
+            atol=FP_TOL, rtol=1e-4)
+
+
 @pytest.mark.parametrize("mean", [False, True])
 def test_scatter_sum_and_mean_match_numpy(dev, mean):
     """graph_scatter_sum_fn / graph_scatter_mean_fn (gnn.py:111-119): float
