@@ -105,14 +105,17 @@ def roofline_scatter_max(torch, edges1, n_k, width, reps=30):
     # committed PMC pass of this same kernel (tools/pmc_scatter.sh) when that
     # pass was taken on exactly this workload, else it stays null.
     traffic, traffic_src = None, None
-    side = os.path.join(ROOT, "profiles", "r01_c_pmc_scatter_max.json")
-    if os.path.exists(side):
+    import glob
+    for side in sorted(glob.glob(os.path.join(
+            ROOT, "profiles", "r*pmc_scatter_max*.json")), reverse=True):
         with open(side) as fh:
             pm = json.load(fh)
         wl = pm.get("workload", {})
         if (wl.get("E"), wl.get("C"), wl.get("K")) == (n_e, width, n_k):
             traffic = pm["hbm_bytes_per_launch"]
-            traffic_src = "profiles/r01_c_pmc_scatter_max.json: " + pm["method"]
+            traffic_src = "profiles/%s: %s" % (os.path.basename(side),
+                                               pm["method"])
+            break
     return {
         "traffic_source": traffic_src,
         "kernel": "scatter_max_kernel (standalone, [E1,C] fp32, sorted dst)",
@@ -176,6 +179,50 @@ def roofline_edge_kernel(torch, engine, edges1, n_k, reps=10, frame=None):
         "executed_flops": executed, "avg_launch_us": dur * 1e6,
         "note": "fp32 MFMA (16x16x4); FLOPs = 2*E*sum(in*out) of the layers "
                 "this kernel executes (first edge layer is factored per vertex)",
+    }
+
+
+def roofline_pool_kernel(torch, engine, reps=10, frame=None):
+    """Fused PointSetPooling kernel: per-edge gather [f, dxyz] -> point MLP ->
+    segmented max (MFMA-bound; the kernel furthest below its roofline)."""
+    from pointgnn_amd import _lib, gnn
+    lib = _lib.load()
+    store = engine.model._store
+    lc = engine.config['model_kwargs']['layer_configs'][0]
+    if lc['type'] != 'scatter_max_point_set_pooling' or frame is None:
+        return None
+    widths = list(lc['kwargs']['point_MLP_depth_list'])
+    key = ('mlp', lc['scope'] + '/extract_vertex_features', tuple(widths),
+           False)
+    if key not in store._cache:
+        return None
+    chain = store._cache[key]
+    x, f = frame
+    engine.run_frame(x, f)
+    coords, kps, edges = engine.last_graph
+    e0 = edges[0]
+    kp = kps[0].reshape(-1).to(torch.int32).contiguous()
+    n_feat = int(f.shape[1])
+    k = int(kp.shape[0])
+    agg = torch.empty((k, gnn.padded_width(chain.n_out)), device=x.device)
+    n_e = int(e0.shape[0])
+
+    def run():
+        _lib.check(lib.pgnn_point_set_pooling_fwd(
+            _lib.ptr(f), n_feat, _lib.ptr(x), _lib.ptr(kp), _lib.ptr(e0), n_e,
+            k, chain.array, chain.n, 1, _lib.ptr(agg), agg.stride(0),
+            _lib.stream_ptr()), "pooling kernel")
+    dur = time_kernel(run, reps, torch)
+    dims = [n_feat + 3] + widths
+    flops = sum(2 * a * b for a, b in zip(dims[:-1], dims[1:])) * n_e
+    return {
+        "kernel": "fused_mlp_kernel<POOL> (gather + point MLP %s + "
+                  "scatter-max)" % "->".join(map(str, dims)),
+        "bound": "mfma", "achieved": flops / dur / 1e12,
+        "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+        "frac": flops / dur / 1e12 / FP32_MFMA_PEAK_TF,
+        "algorithmic_flops": flops, "avg_launch_us": dur * 1e6,
+        "workload": {"E0": n_e, "K": k},
     }
 
 
@@ -353,6 +400,7 @@ def run_train(args, torch, dev, rank, world, dist):
                 # all-reduce (+ the 2-scalar loss all-reduce); includes any
                 # wait for the slowest rank to arrive; 0 at world 1 (no call)
                 "allreduce_ms": ar_ms,
+                "distributed": dist_info(dist, world),
                 "last_loss": {k: out[k] for k in ('cls_loss', 'loc_loss',
                                                   'reg_loss')},
                 "parallelism": "dp%d (frames sharded, one flat gradient "
@@ -361,17 +409,52 @@ def run_train(args, torch, dev, rank, world, dist):
         print(json.dumps(res), flush=True)
 
 
-def main():
+def executed_flops_per_frame(cfg, n_k, n_e0, n_e1):
+    """FLOPs the kernels actually issue: like the algorithmic count, but the
+    first edge layer is evaluated per vertex (P = [h,x]W1+b, Q = x'Wx:
+    2*(C+3)*C + 2*3*C per vertex instead of 2*(C+3)*C per edge)."""
+    total = algorithmic_flops_per_frame(cfg, n_k, n_e0, n_e1)
+    dim = None
+    for lc in cfg['model_kwargs']['layer_configs'][:-1]:
+        kw = lc['kwargs']
+        if lc['type'] == 'scatter_max_point_set_pooling':
+            dim = kw['output_MLP_depth_list'][-1]
+        else:
+            w1 = kw['edge_MLP_depth_list'][0]
+            total -= 2 * (dim + 3) * w1 * n_e1
+            total += (2 * (dim + 3) * w1 + 2 * 3 * w1) * n_k
+    return total
+
+
+def pool_statistics(cfg, shapes):
+    """mean/min/max of K, E0, E1 and the mean FLOPs per frame over exactly the
+    frames of the timed region (`shapes` = engine.frame_shapes)."""
+    a = np.asarray(shapes, dtype=np.float64)
+    alg = [algorithmic_flops_per_frame(cfg, *map(int, r[:3])) for r in a]
+    exe = [executed_flops_per_frame(cfg, *map(int, r[:3])) for r in a]
+    stat = lambda c: {"mean": float(a[:, c].mean()), "min": int(a[:, c].min()),
+                      "max": int(a[:, c].max())}
+    return {"frames": int(a.shape[0]), "K": stat(0), "E0": stat(1),
+            "E1": stat(2), "alg_flops_mean": float(np.mean(alg)),
+            "exe_flops_mean": float(np.mean(exe))}
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=48)
+    ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--config", default="car_auto_T3")
-    ap.add_argument("--preset", default="car")
+    ap.add_argument("--preset", default=None,
+                    help="synthetic cloud preset (default: car_600k, the "
+                         "north-star ~20k-point / ~600k-edge shape; ped_dense "
+                         "for ped_cyl configs)")
     ap.add_argument("--frames", type=int, default=8,
                     help="distinct synthetic frames in the pool")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the extra `car`-preset measurement")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run frames strictly sequentially on one stream")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
@@ -382,9 +465,162 @@ def main():
                     help="GNN streams of the frame pipeline (1 or 2)")
     ap.add_argument("--tune", action="append", default=[],
                     help="key=value library tunable (experiments; repeatable)")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
+    if args.preset is None:
+        args.preset = "ped_dense" if args.config.startswith("ped") else (
+            "car" if args.train else "car_600k")
+    return args
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with no launcher around it: become the
+    launcher.  One process per GPU via torch.distributed.run on 127.0.0.1;
+    rank 0 of the children prints the JSON line."""
+    import subprocess
+    if not STUB:
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            raise SystemExit(
+                "bench.py: --gpus %d but only %d GPU(s) visible; refusing to "
+                "report an n_gpus it did not run on" % (args.gpus, have))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
+# PGNN_BENCH_STUB=1: the launcher / rank plumbing / JSON contract exercised on
+# CPU with gloo and a sleep in place of the engine (tests/test_sharding_cpu.py).
+# The line it prints says "data": "stub" and carries no rates.
+STUB = os.environ.get("PGNN_BENCH_STUB") == "1"
+
+
+class _StubEngine(object):
+    def __init__(self):
+        self.frame_shapes = []
+
+    def run_frames(self, frames):
+        for f in frames:
+            time.sleep(0.002)
+            self.frame_shapes.append((100 + f, 1000 + f, 2000 + f))
+
+
+def init_ranks(args, torch):
+    """(rank, world, local_rank, device, dist).  Ranks exist before this
+    point: created by the driver's torch.distributed.run or by self_launch."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    dist = None
+    if STUB:
+        dev = torch.device("cpu")
+        backend = "gloo"
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (the hot path has no CPU "
+                             "fallback)")
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        backend = "nccl"
+    if world > 1:
+        import torch.distributed as dist
+        if STUB:
+            dist.init_process_group(backend)
+        else:
+            dist.init_process_group(backend, device_id=dev)
+        assert dist.get_world_size() == world
+    return rank, world, local_rank, dev, dist
+
+
+def _sync(torch, dist):
+    if not STUB:
+        torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    if not STUB:
+        torch.cuda.synchronize()
+
+
+def _max_over_ranks(torch, dist, dev, values):
+    if dist is None:
+        return values
+    t = torch.tensor(values, dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return [float(v) for v in t.tolist()]
+
+
+def _gather_shapes(torch, dist, dev, shapes, world):
+    """All ranks' per-frame (K, E0, E1) rows on rank 0 (sizes only, after the
+    timed region)."""
+    a = torch.tensor(shapes, dtype=torch.int64, device=dev).reshape(-1, 3)
+    if dist is None:
+        return a.tolist()
+    out = [torch.zeros_like(a) for _ in range(world)]
+    dist.all_gather(out, a)
+    return torch.cat(out).tolist()
+
+
+def dist_info(dist, world):
+    if dist is None:
+        return {"world_size": 1, "backend": None}
+    return {"world_size": int(dist.get_world_size()),
+            "backend": dist.get_backend() + (
+                " (RCCL)" if dist.get_backend() == "nccl" else "")}
+
+
+def run_stub(args, torch, dev, rank, world, dist):
+    eng = _StubEngine()
+    ids = list(range(rank, world * (args.steps + args.warmup), world))
+    eng.run_frames(ids[:args.warmup])
+    eng.frame_shapes = []
+    _sync(torch, dist)
+    t0 = time.perf_counter()
+    eng.run_frames(ids[args.warmup:])
+    _sync(torch, dist)
+    elapsed, = _max_over_ranks(torch, dist, dev, [time.perf_counter() - t0])
+    shapes = _gather_shapes(torch, dist, dev, eng.frame_shapes, world)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "stub frames/sec (launcher self-test, no kernels)",
+            "value": world * args.steps / elapsed, "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "none", "data": "stub",
+            "config": {"workload": "stub", "frames_timed": len(shapes),
+                       "distributed": dist_info(dist, world)}}), flush=True)
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args, argv))
 
     import torch
+    rank, world, local_rank, dev, dist = init_ranks(args, torch)
+    if STUB:
+        run_stub(args, torch, dev, rank, world, dist)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
     import pointgnn_amd  # noqa: F401
     from pointgnn_amd import configs, weights
     from pointgnn_amd.engine import InferenceEngine, shard_frames
@@ -393,21 +629,6 @@ def main():
         from pointgnn_amd import _lib as _pg_lib
         key, val = kv.split("=")
         _pg_lib.set_tunable(key, int(val))
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the hot path has no CPU "
-                         "fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
 
     if args.train:
         run_train(args, torch, dev, rank, world, dist)
@@ -420,67 +641,77 @@ def main():
     params = weights.init_params(cfg, seed=0, bias_scale=0.05)
     engine = InferenceEngine(cfg, params, device=dev)
 
-    # frame pool resident in HBM; rank r owns frames r, r+W, ... of the stream
-    my_ids = shard_frames(world * (args.steps + args.warmup), rank, world)
+    def measure(preset, steps, warmup):
+        """Time `steps` frames per rank of `preset`; returns (elapsed max over
+        ranks, all ranks' per-frame shapes, this rank's pool, last output)."""
+        # frame stream: rank r owns frames r, r+W, ...
+        my_ids = shard_frames(world * (steps + warmup), rank, world)
 
-    def seed_of(i):
-        # every rank cycles through ALL pool frames (rank r starts at frame r),
-        # so the per-GPU work is the same mix at every N (weak scaling); with a
-        # plain `id % frames` rank 0 of 8 would see frame 0 only
-        return (my_ids[i] // world + rank) % args.frames
-    seeds = sorted({seed_of(i) for i in range(len(my_ids))})
-    pool = {}
-    for s in seeds:
-        xyz, inten = synthetic_cloud(seed=s, preset=args.preset)
-        pool[s] = (torch.from_numpy(xyz).to(dev), torch.from_numpy(inten).to(dev),
-                   xyz, inten)
+        def seed_of(i):
+            # every rank cycles through ALL pool frames (rank r starts at
+            # frame r), so the per-GPU work is the same mix at every N (weak
+            # scaling); with `id % frames` rank 0 of 8 would see frame 0 only
+            return (my_ids[i] // world + rank) % args.frames
+        pool = {}
+        for s in sorted({seed_of(i) for i in range(len(my_ids))}):
+            xyz, inten = synthetic_cloud(seed=s, preset=preset)
+            pool[s] = (torch.from_numpy(xyz).to(dev),
+                       torch.from_numpy(inten).to(dev), xyz, inten)
 
-    def frame(i):
-        x, f, _, _ = pool[seed_of(i)]
-        return x, f
+        def run(lo, hi):
+            """Frames lo..hi-1 of this rank's stream.  Default: software
+            pipeline on HIP streams (graph build of frame i+1 overlaps the GNN
+            of frame i); --no-pipeline runs them strictly one after the other."""
+            fr = [pool[seed_of(i)][:2] for i in range(lo, hi)]
+            if args.no_pipeline:
+                out = None
+                for x, f in fr:
+                    out = engine.run_frame(x, f)
+                return out
+            return engine.run_frames_pipelined(
+                fr, compute_streams=args.compute_streams)[-1]
 
-    def run(lo, hi):
-        """Frames lo..hi-1 of this rank's stream.  Default: two-stream software
-        pipeline (graph build of frame i+1 overlaps the GNN of frame i);
-        --no-pipeline runs them strictly one after the other."""
-        if args.no_pipeline:
-            out = None
-            for i in range(lo, hi):
-                out = engine.run_frame(*frame(i))
-            return out
-        return engine.run_frames_pipelined(
-            [frame(i) for i in range(lo, hi)],
-            compute_streams=args.compute_streams)[-1]
+        if warmup:
+            run(0, warmup)
+        engine.frame_shapes = []
+        _sync(torch, dist)
+        t0 = time.perf_counter()
+        out = run(warmup, warmup + steps)
+        _sync(torch, dist)
+        elapsed, = _max_over_ranks(torch, dist, dev,
+                                   [time.perf_counter() - t0])
+        assert torch.isfinite(out[0]).all()
+        assert len(engine.frame_shapes) == steps
+        shapes = _gather_shapes(torch, dist, dev,
+                                [s[:3] for s in engine.frame_shapes], world)
+        return elapsed, shapes, pool
 
-    if args.warmup:
-        run(0, args.warmup)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    out = run(args.warmup, args.warmup + args.steps)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    assert torch.isfinite(out[0]).all()
+    elapsed, shapes, pool = measure(args.preset, args.steps, args.warmup)
+    second = None
+    if world == 1 and not args.no_secondary and args.preset == "car_600k":
+        s2 = max(8, args.steps // 2)
+        e2, sh2, _ = measure("car", s2, 4)
+        st2 = pool_statistics(cfg, sh2)
+        second = {
+            "workload": "%s inference, preset 'car' (round-1 headline shape)"
+                        % args.config,
+            "steps": s2, "frames_per_sec": s2 / e2, "ms_per_frame": e2 / s2 * 1e3,
+            "K": st2["K"], "E0": st2["E0"], "E1": st2["E1"],
+            "algorithmic_gflop_per_frame": st2["alg_flops_mean"] / 1e9,
+            "algorithmic_tflops": st2["alg_flops_mean"] * s2 / e2 / 1e12}
 
     if rank == 0:
-        # shape of frame 0's graph + per-phase wall clock (outside the timed
-        # region; run.py's phase names)
-        x, f, xyz_np, inten_np = pool[seeds[0]]
+        # per-phase wall clock of the pool's first frame (outside the timed
+        # region; run.py's phase names) and that frame's graph for the
+        # standalone kernel measurements
+        first = sorted(pool)[0]
+        x, f, xyz_np, inten_np = pool[first]
         engine.time_dict = {}
         for _ in range(3):
             engine.run_frame(x, f, timed=True)
         coords, kps, edges = engine.last_graph
         n_k = int(coords[1].shape[0])
-        n_e0, n_e1 = int(edges[0].shape[0]), int(edges[1].shape[0])
+        n_e1 = int(edges[1].shape[0])
         frames = engine.time_dict['frames']
         # run.py's last two phases ("decode box", "nms", run.py:264-326) on
         # this frame's outputs -- reported beside the metric, not part of it
@@ -503,11 +734,14 @@ def main():
                 "note": "seeded weights give near-uniform class "
                         "probabilities: thousands of candidates, a stress "
                         "case for the NMS"}
-        total_flops = algorithmic_flops_per_frame(cfg, n_k, n_e0, n_e1)
+        st = pool_statistics(cfg, shapes)
+        assert st["frames"] == world * args.steps
         fps = world * args.steps / elapsed
+        n_pts = int(x.shape[0])
         res = {
             "metric": "KITTI-shaped frames/sec (%s inference: graph build + "
-                      "GNN, ~20k pts)" % args.config,
+                      "GNN, %d pts/frame, mean E1 %.0fk)" % (
+                          args.config, n_pts, st["E1"]["mean"] / 1e3),
             "value": fps, "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
@@ -515,9 +749,12 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": "%s inference, 1 frame/step/GPU, synthetic "
-                            "HDL-64E-shaped cloud preset '%s', seeded "
-                            "Xavier weights" % (args.config, args.preset),
-                "N": int(x.shape[0]), "K": n_k, "E0": n_e0, "E1": n_e1,
+                            "HDL-64E-shaped cloud preset '%s' (%d seeded "
+                            "frames cycled), seeded Xavier weights"
+                            % (args.config, args.preset, args.frames),
+                # statistics over exactly the world*steps timed frames
+                "N": n_pts, "K": st["K"], "E0": st["E0"], "E1": st["E1"],
+                "frames_timed": st["frames"],
                 "frames_per_gpu_per_step": 1,
                 "schedule": "sequential, 1 stream" if args.no_pipeline else
                             "%d HIP streams: graph build of frame i+1 overlaps "
@@ -527,10 +764,16 @@ def main():
                                 "GNN streams" if args.compute_streams > 1
                                 else ""),
                 "parallelism": "frame-parallel x%d (no collective)" % world,
+                "distributed": dist_info(dist, world),
                 "frames_per_sec_per_gpu": fps / world,
-                "algorithmic_gflop_per_frame": total_flops / 1e9,
-                "algorithmic_tflops": total_flops * fps / world / 1e12,
-                "phase_ms": {
+                # mean over the timed frames; x frames/s/GPU = the two rates
+                "algorithmic_gflop_per_frame": st["alg_flops_mean"] / 1e9,
+                "executed_gflop_per_frame": st["exe_flops_mean"] / 1e9,
+                "algorithmic_tflops": st["alg_flops_mean"] * fps / world / 1e12,
+                "executed_tflops": st["exe_flops_mean"] * fps / world / 1e12,
+                "executed_frac_of_fp32_mfma_peak":
+                    st["exe_flops_mean"] * fps / world / 1e12 / FP32_MFMA_PEAK_TF,
+                "phase_ms_frame_seed%d" % first: {
                     "gen graph": engine.time_dict['gen graph'] / frames * 1e3,
                     "gnn inference":
                         engine.time_dict['gnn inference'] / frames * 1e3,
@@ -538,15 +781,23 @@ def main():
                 "postprocess": post,
             },
         }
+        if second is not None:
+            res["config"]["secondary"] = second
         if not args.no_roofline:
             width = cfg['model_kwargs']['layer_configs'][1]['kwargs'][
                 'edge_MLP_depth_list'][-1] if len(
                 cfg['model_kwargs']['layer_configs']) > 2 else 300
             res["roofline"] = roofline_scatter_max(torch, edges[1], n_k, width)
+            res["roofline"]["workload"] = {
+                "frame_seed": first, "E": n_e1, "C": width, "K": n_k}
             mf = roofline_edge_kernel(torch, engine, edges[1], n_k,
                                       frame=(x, f))
             if mf is not None:
+                mf["workload"] = {"frame_seed": first, "E": n_e1, "K": n_k}
                 res["roofline_mfma"] = mf
+            pl = roofline_pool_kernel(torch, engine, frame=(x, f))
+            if pl is not None:
+                res["roofline_pool"] = pl
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, params, xyz_np, inten_np,
                                                args.cpu_budget)

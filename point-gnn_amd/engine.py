@@ -38,6 +38,14 @@ class InferenceEngine(object):
         self.graph_kwargs = config['runtime_graph_gen_kwargs']
         self.time_dict = {}
         self.last_graph = None
+        # (K, E0, E1, ...) of every frame processed since the caller last
+        # cleared it: the sizes are host-known as soon as the graph is built
+        self.frame_shapes = []
+
+    def _note_shape(self, graph):
+        coords, _, edges = graph
+        self.frame_shapes.append(
+            (int(coords[1].shape[0]),) + tuple(int(e.shape[0]) for e in edges))
 
     def build_graph(self, xyz):
         """(vertex_coord_list, keypoint_indices_list, edges_list) on the
@@ -59,6 +67,14 @@ class InferenceEngine(object):
         frames = list(frames)
         if not frames:
             return []
+        if not getattr(self, "_warm", False):
+            # first use: the packed weight images are built lazily (host pack +
+            # pageable upload) on whichever stream runs first; do that on the
+            # CURRENT stream, which every forked stream waits for below, so no
+            # compute stream can read a half-uploaded image
+            self.run_frame(*frames[0])
+            self.frame_shapes.pop()
+            self._warm = True
         if not hasattr(self, "_streams"):
             self._streams = tuple(torch.cuda.Stream() for _ in range(5))
         sg = self._streams[0]
@@ -86,6 +102,7 @@ class InferenceEngine(object):
                 outs.append(self.model.predict(frames[i][1], coords, kps,
                                                edges, is_training=False))
             self.last_graph = graph
+            self._note_shape(graph)
             if i + 1 < len(frames):
                 graph, ev = build(i + 1)
         for s in scs:
@@ -114,4 +131,5 @@ class InferenceEngine(object):
             d['gnn inference'] = d.get('gnn inference', 0.0) + (t2 - t1)
             d['frames'] = d.get('frames', 0) + 1
         self.last_graph = graph
+        self._note_shape(graph)
         return out

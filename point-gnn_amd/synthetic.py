@@ -4,8 +4,9 @@ There is no KITTI data (and no network) on the build or GPU boxes, so every
 test and benchmark runs on a ray-cast stand-in for a camera-FOV-cropped
 HDL-64E scan: 64 beams (elevation +2 deg .. -24.8 deg), fixed azimuth step over
 the camera field of view, sensor 1.73 m above a ground plane, random
-car-sized boxes, far building-sized boxes and optional thin poles, 2-70 m
-range gate, 0.2 % multiplicative range noise.  Output is in the KITTI *camera* frame
+car-sized boxes, far building-sized boxes, optional semi-transparent
+vegetation volumes ("canopy": a ray is stopped at a uniformly random depth
+inside the volume with probability 1-exp(-density*path)), 2-70 m range gate, 0.2 % multiplicative range noise.  Output is in the KITTI *camera* frame
 (x right, y down, z forward) as float32, which is what the reference feeds to
 its graph generator (run.py:219-222 passes ``cam_rgb_points.xyz``).
 
@@ -30,6 +31,13 @@ CLOUD_PRESETS = {
     # car_auto_T3 inference shape: N=20k, K~2.9k, E0~350k, E1~500k
     "car": dict(n_points=20000, fov_deg=81.0, az_step_deg=0.1728,
                 groups=(_FAR16, _CARS)),
+    # north-star shape (BASELINE.json: ~20k points / ~600k level-1 edges):
+    # the `car` scene plus ten tree canopies, whose volumetric returns occupy
+    # many voxels inside one 4 m ball (mean over seeds 0..7: K~2.9k, E0~377k,
+    # E1~602k; E1 ranges 417k..918k)
+    "car_600k": dict(n_points=20000, fov_deg=81.0, az_step_deg=0.1728,
+                     groups=(_FAR16, _CARS),
+                     canopy=((10, 10.0, 45.0, 4.0, 8.0, 4.0, 8.0, 1.5, 0.3),)),
     # config-5 stress: 150 deg FOV, ~50k points, ped_cyl radii/voxel
     "ped_dense": dict(n_points=50000, fov_deg=150.0, az_step_deg=0.15,
                       groups=((28, 35.0, 68.0, 10.0, 20.0, 6.0, 14.0),
@@ -67,8 +75,27 @@ def _ray_boxes(origin, dirs, centers, sizes, yaws):
     return t_best
 
 
+def _ray_box_span(origin, dirs, center, size, yaw):
+    """Entry/exit parameters of R rays through ONE yawed box: (hit, t_in,
+    t_out)."""
+    cy, sy = np.cos(yaw), np.sin(yaw)
+    rot = np.array([[cy, sy, 0.0], [-sy, cy, 0.0], [0.0, 0.0, 1.0]])
+    o = (origin - center) @ rot.T
+    d = dirs @ rot.T
+    half = size * 0.5
+    with np.errstate(divide="ignore", invalid="ignore"):
+        inv = 1.0 / d
+        t0 = (-half - o) * inv
+        t1 = (half - o) * inv
+    tmin = np.minimum(t0, t1).max(axis=1)
+    tmax = np.maximum(t0, t1).min(axis=1)
+    hit = (tmax >= np.maximum(tmin, 0.0)) & np.isfinite(tmin) & (tmin > 0)
+    return hit, tmin, tmax
+
+
 def synthetic_cloud(seed=0, n_points=20000, fov_deg=81.0, az_step_deg=0.1728,
-                    groups=(_FAR16, _CARS), preset=None, noise=0.002):
+                    groups=(_FAR16, _CARS), preset=None, noise=0.002,
+                    canopy=()):
     """Returns (xyz float32 [N,3] camera frame, intensity float32 [N,1]).
 
     Deterministic in ``seed``.  N = min(n_points, number of valid returns).
@@ -103,6 +130,25 @@ def synthetic_cloud(seed=0, n_points=20000, fov_deg=81.0, az_step_deg=0.1728,
         yaws = rng.random(cnt) * np.pi
         t_hit = np.minimum(t_hit, _ray_boxes(origin, dirs, centers, sizes,
                                              yaws))
+    # vegetation: (count, r_lo, r_hi, footprint_lo, footprint_hi, height_lo,
+    # height_hi, base height above ground, density 1/m).  Drawn after the solid
+    # groups, so presets without canopy keep their random stream.
+    for (cnt, r_lo, r_hi, f_lo, f_hi, h_lo, h_hi, base, dens) in canopy:
+        rad = r_lo + (r_hi - r_lo) * rng.random(cnt)
+        ang = (rng.random(cnt) * 2.0 - 1.0) * half_fov
+        sizes = np.stack([f_lo + (f_hi - f_lo) * rng.random(cnt),
+                          f_lo + (f_hi - f_lo) * rng.random(cnt),
+                          h_lo + (h_hi - h_lo) * rng.random(cnt)], axis=1)
+        centers = np.stack([rad * np.cos(ang), rad * np.sin(ang),
+                            -sensor_h + base + 0.5 * sizes[:, 2]], axis=1)
+        yaws = rng.random(cnt) * np.pi
+        for c, s, yaw in zip(centers, sizes, yaws):
+            hit, t_in, t_out = _ray_box_span(origin, dirs, c, s, yaw)
+            path = np.where(hit, t_out - t_in, 0.0)
+            stop = hit & (rng.random(hit.shape[0]) < 1.0 - np.exp(-dens * path))
+            t = np.where(stop, t_in + rng.random(hit.shape[0]) * (t_out - t_in),
+                         np.inf)
+            t_hit = np.minimum(t_hit, t)
     valid = np.isfinite(t_hit) & (t_hit >= 2.0) & (t_hit <= 70.0)
     t = t_hit[valid] * (1.0 + noise * rng.standard_normal(valid.sum()))
     pts = dirs[valid] * t[:, None]

@@ -188,3 +188,87 @@ def test_two_rank_metric_counters_add_up():
                             np.concatenate([b for _, b in parts]), 4)
     for _, st in results:
         assert np.array_equal(st, whole)
+
+
+def _run_bench(argv, env_extra, timeout=240):
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv,
+                       env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    return p, [json.loads(l) for l in lines]
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` with no launcher around it creates its two
+    ranks itself (the driver's plain command line); rank 0 prints exactly one
+    JSON line whose n_gpus is what the process group saw.  PGNN_BENCH_STUB
+    swaps the engine for a sleep and RCCL for gloo -- the launcher, the rank
+    plumbing, the barrier + MAX timing rule and the JSON contract are the
+    real code."""
+    p, lines = _run_bench(["--gpus", "2", "--steps", "6", "--warmup", "2"],
+                          {"PGNN_BENCH_STUB": "1"})
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len(lines) == 1
+    r = lines[0]
+    assert r["n_gpus"] == 2 and r["steps"] == 6 and r["warmup"] == 2
+    assert r["config"]["distributed"] == {"world_size": 2, "backend": "gloo"}
+    assert r["config"]["frames_timed"] == 12          # all ranks' frames
+    assert r["data"] == "stub" and r["scaling"] == "weak"
+    # whole-job value: 2 ranks x 6 steps over the slowest rank's time
+    assert abs(r["value"] - 2 * 6 / (r["ms_per_step"] * 6e-3)) < 1e-6 * r["value"]
+
+
+def test_bench_under_an_external_launcher_and_mismatch():
+    """The driver's multi-GPU form: ranks exist already (torch.distributed.run);
+    bench.py must not launch again, and a WORLD_SIZE that differs from --gpus is
+    refused instead of reported."""
+    import json
+    import subprocess
+    env = dict(os.environ, PGNN_BENCH_STUB="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "4", "--warmup", "1"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2
+    p, lines = _run_bench(["--gpus", "1", "--steps", "2", "--warmup", "0"],
+                          {"PGNN_BENCH_STUB": "1", "WORLD_SIZE": "2",
+                           "RANK": "0", "LOCAL_RANK": "0"})
+    assert p.returncode != 0 and not lines
+    assert "WORLD_SIZE=2" in p.stderr
+
+
+def test_bench_refuses_gpus_it_does_not_have():
+    import torch as _t
+    if _t.cuda.is_available() and _t.cuda.device_count() >= 2:
+        pytest.skip("two GPUs visible")
+    p, lines = _run_bench(["--gpus", "2", "--steps", "2"], {})
+    assert p.returncode != 0 and not lines
+    assert "refusing" in p.stderr
+
+
+def test_bench_flop_accounting_matches_survey():
+    """97 536 FLOP/edge(E0), 361 800 FLOP/edge(E1) per iteration,
+    360 000 / 38 784 / 228 864 per vertex; pool statistics are means over the
+    timed frames."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from pointgnn_amd import configs
+    cfg = configs.car_auto_config(3)
+    k, e0, e1 = 3213, 323939, 415621
+    want = 97536 * e0 + 360000 * k + 3 * (38784 * k + 361800 * e1 + 360000 * k) \
+        + 228864 * k
+    assert bench.algorithmic_flops_per_frame(cfg, k, e0, e1) == want
+    exe = bench.executed_flops_per_frame(cfg, k, e0, e1)
+    assert exe == want - 3 * (2 * 303 * 300 * e1) + 3 * (2 * 303 * 300 + 1800) * k
+    st = bench.pool_statistics(cfg, [(k, e0, e1), (k, e0, e1 + 2000)])
+    assert st["frames"] == 2 and st["E1"] == {"mean": e1 + 1000.0, "min": e1,
+                                              "max": e1 + 2000}
+    assert abs(st["alg_flops_mean"] - (want + 3 * 361800 * 1000)) < 1
