@@ -61,6 +61,26 @@ def scatter_max(data, seg_ids, num_segments):
 
 
 # ------------------------------------------------------------------ layers
+CHUNK_ROWS = 1 << 18
+
+
+def _edge_mlp_scatter_max(gather, layers, dst, num_segments, dtype):
+    """max over segments of MLP(gather(rows)) evaluated in row chunks, so a
+    full-size frame ([E,300] float64 activations) fits in host memory.  max is
+    exact and order-free: chunking changes nothing in the result."""
+    n = dst.shape[0]
+    if n <= CHUNK_ROWS:
+        return scatter_max(multi_layer_neural_network(
+            gather(slice(0, n)), layers, is_logits=False), dst, num_segments)
+    out = None
+    for lo in range(0, n, CHUNK_ROWS):
+        sl = slice(lo, min(n, lo + CHUNK_ROWS))
+        part = scatter_max(multi_layer_neural_network(
+            gather(sl), layers, is_logits=False), dst[sl], num_segments)
+        out = part if out is None else np.maximum(out, part)
+    return out
+
+
 def _layers(params, scope, dtype):
     """Collect (W, b) of `scope/fully_connected[_i]` in creation order."""
     out = []
@@ -80,15 +100,18 @@ def point_set_pooling(params, scope, point_features, point_coordinates,
     """PointSetPooling.apply_regular, gnn.py:222-283."""
     src = set_indices[:, 0].astype(np.int64)
     dst = set_indices[:, 1].astype(np.int64)
-    pf = point_features.astype(dtype)[src]
-    pc = point_coordinates.astype(dtype)[src]
-    kp = keypoint_indices.reshape(-1).astype(np.int64)[dst]
-    kc = point_coordinates.astype(dtype)[kp]
-    feats = np.concatenate([pf, pc - kc], axis=-1)
-    feats = multi_layer_neural_network(
-        feats, _layers(params, scope + '/extract_vertex_features', dtype),
-        is_logits=False)
-    agg = scatter_max(feats, dst, keypoint_indices.shape[0])
+    pf_all = point_features.astype(dtype)
+    pc_all = point_coordinates.astype(dtype)
+    kp_all = keypoint_indices.reshape(-1).astype(np.int64)
+
+    def gather(sl):
+        pf = pf_all[src[sl]]
+        pc = pc_all[src[sl]]
+        kc = pc_all[kp_all[dst[sl]]]
+        return np.concatenate([pf, pc - kc], axis=-1)
+    agg = _edge_mlp_scatter_max(
+        gather, _layers(params, scope + '/extract_vertex_features', dtype),
+        dst, keypoint_indices.shape[0], dtype)
     return multi_layer_neural_network(
         agg, _layers(params, scope + '/combined_features', dtype),
         is_logits=False)
@@ -102,18 +125,18 @@ def graphnet_auto_center(params, scope, vertex_features, vertex_coordinates,
     x = vertex_coordinates.astype(dtype)
     src = edges[:, 0].astype(np.int64)
     dst = edges[:, 1].astype(np.int64)
-    s_h = h[src]
-    s_x = x[src]
-    if auto_offset:
+    x_src = x          # source coordinates are gathered BEFORE the offset
+    if auto_offset:    # (gnn.py:338-346)
         offset = multi_layer_neural_network(h, _layers(params, scope, dtype),
                                             is_logits=True)
         x = x + offset
-    d_x = x[dst]
-    e = np.concatenate([s_h, s_x - d_x], axis=-1)
-    e = multi_layer_neural_network(
-        e, _layers(params, scope + '/extract_vertex_features', dtype),
-        is_logits=False)
-    agg = scatter_max(e, dst, h.shape[0])
+
+    def gather(sl):
+        return np.concatenate([h[src[sl]], x_src[src[sl]] - x[dst[sl]]],
+                              axis=-1)
+    agg = _edge_mlp_scatter_max(
+        gather, _layers(params, scope + '/extract_vertex_features', dtype),
+        dst, h.shape[0], dtype)
     upd = multi_layer_neural_network(
         agg, _layers(params, scope + '/combined_features', dtype),
         is_logits=True)

@@ -98,6 +98,11 @@ class MultiLayerFastLocalGraphModelV2(object):
                 None if k is None else up(k, np.int32)
                 for k in t_keypoint_indices_list]
             t_edges_list = [up(e, np.int32) for e in t_edges_list]
+        # set `model.keep_features = True` to keep every layer's output
+        # (models.py:113-147's `tfeatures` after each layer) in
+        # `model.feature_list` -- per-layer parity checks
+        keep = getattr(self, 'keep_features', False)
+        self.feature_list = []
         with gnn.parameters(self._store):
             tfeatures = t_initial_vertex_features
             for idx in range(len(self._layer_configs) - 1):
@@ -111,6 +116,8 @@ class MultiLayerFastLocalGraphModelV2(object):
                         t_keypoint_indices_list[graph_level],
                         t_edges_list[graph_level],
                         **layer_config['kwargs'])
+                if keep:
+                    self.feature_list.append(tfeatures)
             predictor_config = self._layer_configs[-1]
             assert (predictor_config['type'] == 'classaware_predictor' or
                     predictor_config['type'] == 'classaware_predictor_128' or

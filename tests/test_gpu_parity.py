@@ -667,13 +667,57 @@ def test_full_size_properties(dev, name, preset):
         pooled = gnn.PointSetPooling().apply_regular(
             f, coords[0], kps[0], edges[0],
             **cfg["model_kwargs"]["layer_configs"][0]["kwargs"]).cpu().numpy()
-    sel = np.random.default_rng(0).choice(len(kp0), 64, replace=False)
-    mask = np.isin(e0[:, 1], sel)
-    sub = e0[mask]
-    ref = gn.point_set_pooling(params, "layer1", inten, c_np[0], kp0, sub,
+    sel = np.sort(np.random.default_rng(0).choice(len(kp0), 64, replace=False))
+    remap = np.full(len(kp0), -1, np.int64)
+    remap[sel] = np.arange(64)
+    sub = e0[np.isin(e0[:, 1], sel)].astype(np.int64)
+    sub[:, 1] = remap[sub[:, 1]]       # the 64 keypoints as their own graph
+    ref = gn.point_set_pooling(params, "layer1", inten, c_np[0], kp0[sel], sub,
                                dtype=np.float64)
-    np.testing.assert_allclose(pooled[sel, :ref.shape[1]], ref[sel],
+    np.testing.assert_allclose(pooled[sel, :ref.shape[1]], ref,
                                atol=FP_TOL, rtol=1e-4)
+
+
+@pytest.mark.parametrize("name,preset", [("car_auto_T3", "car"),
+                                         ("car_auto_T3", "car_600k"),
+                                         ("ped_cyl_auto_T3", "ped_dense")])
+def test_full_size_logits_match_oracle(dev, name, preset):
+    """BASELINE configs 3 and 5 at their full sizes (20k / 50k points, the
+    bench presets): the WHOLE frame -- device-built graph, pooling, T = 3
+    iterations, heads -- against the float64 oracle, with the deviation of
+    every layer's output so a drift is attributable.  The oracle evaluates the
+    edge MLPs in row chunks (exact: max is order-free)."""
+    from pointgnn_amd import graph_gen, models
+    cfg = configs.get_config(name)
+    xyz, inten = synthetic_cloud(seed=0, preset=preset)
+    params = weights.init_params(cfg, seed=0, bias_scale=0.05)
+    fn = graph_gen.get_graph_generate_fn(cfg["graph_gen_method"])
+    coords, kps, edges = fn(T(xyz, dev), **cfg["runtime_graph_gen_kwargs"])
+    model = models.get_model(cfg["model_name"])(
+        num_classes=cfg["num_classes"], box_encoding_len=7, mode="test",
+        **cfg["model_kwargs"]).load_state_dict(params)
+    model.keep_features = True
+    logits, boxes = model.predict(T(inten, dev), coords, kps, edges, False)
+    c_np = [c.cpu().numpy() for c in coords]
+    k_np = [k.cpu().numpy() for k in kps]
+    e_np = [e.cpu().numpy() for e in edges]
+    lg, bx, feats = gn.predict(params, cfg, inten, c_np, k_np, e_np,
+                               dtype=np.float64, return_features=True)
+    assert len(model.feature_list) == len(feats) - 1
+    report = []
+    for i, (got, ref) in enumerate(zip(model.feature_list, feats[1:])):
+        got = got.cpu().numpy()[:, :ref.shape[1]]
+        err = np.abs(got - ref).max()
+        report.append("layer%d %.2g (|h|max %.3g)" % (i + 1, err,
+                                                      np.abs(ref).max()))
+        np.testing.assert_allclose(got, ref, atol=FP_TOL, rtol=1e-4)
+    d_l = np.abs(logits.cpu().numpy() - lg).max()
+    d_b = np.abs(boxes.cpu().numpy() - bx).max()
+    print("%s/%s N %d K %d E0 %d E1 %d: max|dlogit| %.3g max|dbox| %.3g; %s" % (
+        name, preset, len(xyz), len(c_np[1]), len(e_np[0]), len(e_np[1]), d_l,
+        d_b, ", ".join(report)))
+    np.testing.assert_allclose(logits.cpu().numpy(), lg, atol=FP_TOL, rtol=1e-4)
+    np.testing.assert_allclose(boxes.cpu().numpy(), bx, atol=FP_TOL, rtol=1e-4)
 
 
 @pytest.mark.parametrize("name", ["car_auto_T3", "ped_cyl_auto_T3"])

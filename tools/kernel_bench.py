@@ -63,6 +63,8 @@ def main():
         else:
             r = bench.roofline_scatter_max(torch, edges[1], n_k, width,
                                            reps=args.reps)
+            r["workload"] = {"E": int(edges[1].shape[0]), "C": int(width),
+                             "K": n_k}
             print(json.dumps(r))
     elif args.what == "edge":
         r = bench.roofline_edge_kernel(torch, eng, edges[1], n_k,
