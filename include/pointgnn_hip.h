@@ -111,13 +111,35 @@ int pgnn_cap_neighbors_fill(const int32_t *offsets, const int32_t *edges,
  * 'center' mode = multi_layer_downsampling_select (graph_gen.py:49-90) for one
  * pooling level: open3d-0.7 voxel centroids (origin = min_bound - voxel/2,
  * float64 means in point order) followed by an exact float64 1-NN back to a
- * real point.  Keypoints are emitted in ascending voxel-hash order.
+ * real point; exact distance ties are broken like scikit-learn's kd-tree
+ * query does (see pgnn_kdtree_replica).  Keypoints are emitted in ascending
+ * voxel-hash order.
  * 'random' mode = multi_layer_downsampling_random (graph_gen.py:92-153): one
  * uniformly chosen point per occupied voxel of the grid anchored at the
  * cloud minimum (+ `jitter3_host`, the reference's add_rnd3d origin shift,
  * in units of metres; NULL = none), RNG keyed by `seed`.
  * Capacity of both outputs is n_points rows; *num_keypoints (device) receives
  * K.                                                                       */
+/* Replica of scikit-learn's KDTree(points, leaf_size=30) node order -- what
+ * decides which of several exactly equidistant points
+ * NearestNeighbors(algorithm='kd_tree').kneighbors returns (graph_gen.py:84-88)
+ * and therefore the reference's keypoint in every 2-point voxel.
+ * pgnn_voxel_keypoints_center builds it internally; this entry exposes the
+ * arrays (device pointers) for tests against KDTree.get_arrays():
+ *   idx_array   [n_points]      int32   (sklearn: intp)
+ *   node_bounds [n_nodes][6]    float64 (lo x,y,z, hi x,y,z; sklearn stores
+ *                                        [2][n_nodes][3])
+ *   status      [1]             int32   0, or 1 if std::nth_element's
+ *                                        heap-select fallback would have been
+ *                                        taken (not replicated)
+ * pgnn_kdtree_shape returns sklearn's n_levels / n_nodes for n_points (host
+ * pointers).                                                              */
+int pgnn_kdtree_shape(int64_t n_points, int32_t *n_levels, int32_t *n_nodes);
+size_t pgnn_kdtree_workspace_bytes(int64_t n_points);
+int pgnn_kdtree_replica(const float *points, int64_t n_points, void *workspace,
+                        size_t workspace_bytes, int32_t *idx_array,
+                        double *node_bounds, int32_t *status, void *stream);
+
 size_t pgnn_keypoints_workspace_bytes(int64_t n_points);
 int pgnn_voxel_keypoints_center(const float *points, int64_t n_points,
                                 double voxel_size, void *workspace,

@@ -56,6 +56,10 @@ _SIGNATURES = {
     "pgnn_voxel_keypoints_random": (c_i32, [c_vp, c_i64, c_f64, c_vp, c_u64,
                                             c_vp, c_sz, c_vp, c_vp, c_vp,
                                             c_vp]),
+    "pgnn_kdtree_shape": (c_i32, [c_i64, c_vp, c_vp]),
+    "pgnn_kdtree_workspace_bytes": (c_sz, [c_i64]),
+    "pgnn_kdtree_replica": (c_i32, [c_vp, c_i64, c_vp, c_sz, c_vp, c_vp, c_vp,
+                                    c_vp]),
     "pgnn_packed_fc_floats": (c_sz, [c_i32, c_i32]),
     "pgnn_pack_fc": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp]),
     "pgnn_mlp_fwd": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_i64,

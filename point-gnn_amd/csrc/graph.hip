@@ -17,6 +17,7 @@
 // launch-bound, not bandwidth-bound (DESIGN.md "Graph kernels").
 #include <math.h>
 
+#include "kdtree.h"
 #include "sort.h"
 
 namespace pgnn {
@@ -327,14 +328,16 @@ __global__ void voxel_leader_kernel(const SortedPoint *__restrict__ sorted,
 // One wave per sorted slot that is a leader: exact float64 1-NN of the voxel
 // centroid among all points (graph_gen.py:84-88).  The nearest point is closer
 // than 0.87 voxel edges (it is at most the RMS spread of the voxel's own
-// points away), so the 27 surrounding voxels suffice.
+// points away), so the 27 surrounding voxels suffice.  Exact distance ties
+// (every 2-point voxel) go to the point scikit-learn's kd-tree query meets
+// first (kdtree.h), which is the reference's pick.
 __global__ __launch_bounds__(256) void voxel_nn_kernel(
     const SortedPoint *__restrict__ sorted, int64_t n,
     const double *__restrict__ origin, double voxel, uint32_t mask,
     const int32_t *__restrict__ cell_start, const int32_t *__restrict__ cell_end,
     const int32_t *__restrict__ is_leader, const int32_t *__restrict__ slot,
     const double *__restrict__ centroid, const float *__restrict__ pts,
-    int32_t *__restrict__ kp_idx, float *__restrict__ kp_xyz) {
+    KdView kd, int32_t *__restrict__ kp_idx, float *__restrict__ kp_xyz) {
   const int lane = threadIdx.x & 63;
   const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n || !is_leader[i]) return;
@@ -357,7 +360,9 @@ __global__ __launch_bounds__(256) void voxel_nn_kernel(
               cell_of(o.z, oz, voxel) == iz) {
             const double ex = o.x - cx, ey = o.y - cy, ez = o.z - cz;
             const double d2 = (ex * ex + ey * ey) + ez * ez;
-            if (d2 < best || (d2 == best && o.idx < best_idx)) {
+            if (d2 < best ||
+                (d2 == best && kd_met_before(kd, kd.pos[o.idx],
+                                             kd.pos[best_idx], cx, cy, cz))) {
               best = d2;
               best_idx = o.idx;
             }
@@ -368,7 +373,9 @@ __global__ __launch_bounds__(256) void voxel_nn_kernel(
   for (int d = 32; d >= 1; d >>= 1) {
     const double ob = __shfl_xor(best, d);
     const int oi = __shfl_xor(best_idx, d);
-    if (ob < best || (ob == best && oi < best_idx)) {
+    if (ob < best ||
+        (ob == best && oi != best_idx && oi != 0x7fffffff &&
+         kd_met_before(kd, kd.pos[oi], kd.pos[best_idx], cx, cy, cz))) {
       best = ob;
       best_idx = oi;
     }
@@ -650,7 +657,7 @@ extern "C" size_t pgnn_keypoints_workspace_bytes(int64_t n_points) {
   const size_t n = (size_t)(n_points > 0 ? n_points : 1);
   return grid_bytes(n_points) + 256 + 256 + 3 * align_up((n + 1) * 4, 256) +
          align_up(3 * n * 8, 256) + align_up(scan_scratch_bytes(n_points), 256) +
-         2048;
+         kd_workspace_bytes(n_points) + 2048;
 }
 
 namespace {
@@ -709,10 +716,19 @@ int keypoints_impl(const float *points, int64_t n, double voxel, bool center,
   hipLaunchKernelGGL(copy_total_kernel, dim3(1), dim3(64), 0, stream, slot + n,
                      num_kp);
   if (center) {
+    // scikit-learn's kd-tree node order over the points: decides exact ties
+    KdBuild kb;
+    rc = kd_build(points, n, a, kb, stream);
+    if (rc) return rc;
+    KdView kd;
+    kd.pos = kb.pos;
+    kd.bounds = kb.bounds;
+    kd.n = (int32_t)n;
+    kd.n_nodes = kb.n_nodes;
     hipLaunchKernelGGL(voxel_nn_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256),
                        0, stream, g.sorted, n, origin, voxel, g.mask,
                        g.cell_start, g.cell_end, is_leader, slot, centroid,
-                       points, kp_idx, kp_xyz);
+                       points, kd, kp_idx, kp_xyz);
   } else {
     hipLaunchKernelGGL(voxel_random_pick_kernel, dim3(blocks), dim3(256), 0,
                        stream, g.sorted, g.keys, n, origin, voxel, g.cell_end,

@@ -142,6 +142,35 @@ def keypoints_device(points, voxel_size, method='center', jitter=None, seed=0):
     return kp_xyz[:k], kp_idx[:k].reshape(k, 1)
 
 
+def kdtree_replica(points):
+    """scikit-learn's KDTree(points, leaf_size=30) arrays rebuilt on the
+    device (csrc/kdtree.hip): returns (idx_array int32 [n], node_bounds float64
+    [n_nodes, 6] = lo xyz | hi xyz, status int).  Diagnostic / test entry; the
+    'center' keypoint kernel builds the same tree internally to break exact
+    nearest-neighbour ties the way graph_gen.py:84-88's sklearn call does."""
+    lib = _lib.load()
+    p, was_np = _to_dev_f32(points)
+    n = int(p.shape[0])
+    lv = ctypes.c_int32()
+    nodes = ctypes.c_int32()
+    _lib.check(lib.pgnn_kdtree_shape(n, ctypes.byref(lv), ctypes.byref(nodes)),
+               "pgnn_kdtree_shape")
+    ws_bytes = lib.pgnn_kdtree_workspace_bytes(n)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=p.device)
+    idx = torch.empty(max(n, 1), dtype=torch.int32, device=p.device)
+    bounds = torch.empty((nodes.value, 6), dtype=torch.float64,
+                         device=p.device)
+    status = torch.zeros(1, dtype=torch.int32, device=p.device)
+    _lib.check(lib.pgnn_kdtree_replica(
+        _lib.ptr(p), n, _lib.ptr(ws), ws_bytes, _lib.ptr(idx),
+        _lib.ptr(bounds), _lib.ptr(status), _lib.stream_ptr()),
+        "pgnn_kdtree_replica")
+    idx = idx[:n]
+    if was_np:
+        return idx.cpu().numpy(), bounds.cpu().numpy(), int(status.item())
+    return idx, bounds, int(status.item())
+
+
 def _multi_layer_downsampling(points_xyz, base_voxel_size, levels, add_rnd3d,
                               method):
     p, was_np = _to_dev_f32(points_xyz)

@@ -150,3 +150,45 @@ def test_gnn_oracle_golden_logits(t):
     edges2 = [edges[0], edges[1][perm]]
     lg2, _ = gn.predict(w, cfg, g["intensity"], coords, kps, edges2)
     assert np.array_equal(lg, lg2)
+
+
+# ---------------------------------------------------------------- kd-tree ties
+@pytest.mark.parametrize("preset,seed,voxel", [("tiny", 1, 0.4), ("small", 0, 0.4),
+                                               ("tiny", 2, 0.2), ("car", 0, 0.4)])
+def test_kdtree_oracle_is_sklearn(preset, seed, voxel):
+    """oracle/kdtree_oracle.py (the rule csrc/kdtree.hip implements) against
+    the real scikit-learn: idx_array / node_bounds of KDTree.get_arrays() and
+    the tie winners of NearestNeighbors.kneighbors, i.e. the reference's own
+    call at graph_gen.py:84-88."""
+    from sklearn.neighbors import KDTree
+    from oracle import kdtree_oracle as ko
+    from pointgnn_amd.synthetic import synthetic_cloud
+    xyz, _ = synthetic_cloud(seed=seed, preset=preset)
+    data = xyz.astype(np.float64)
+    tree = KDTree(data, leaf_size=30)
+    _, idx_ref, node_data, node_bounds = tree.get_arrays()
+    idx, ranges, bounds = ko.build(data)
+    assert ko.tree_shape(len(data))[1] == node_data.shape[0]
+    assert np.array_equal(idx, idx_ref)
+    assert np.array_equal(bounds[:, :3], node_bounds[0])
+    assert np.array_equal(bounds[:, 3:], node_bounds[1])
+    cent, _ = go.voxel_centroids_open3d07(xyz, voxel)
+    _, kp_idx = go.keypoints_center(xyz, xyz, voxel)      # real kneighbors
+    got, ties = ko.nearest_with_ties(data, cent, voxel * 0.9)
+    assert ties > 0.1 * len(cent)          # ties are common (2-point voxels)
+    assert np.array_equal(got, kp_idx[:, 0])
+
+
+def test_kdtree_shape_abi_matches_sklearn():
+    """pgnn_kdtree_shape (host arithmetic, no GPU) == sklearn's n_nodes."""
+    import ctypes
+    from sklearn.neighbors import KDTree
+    from pointgnn_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(0)
+    for n in (1, 2, 30, 31, 60, 61, 62, 121, 122, 500, 961, 962, 15361, 15362,
+              20000, 30721, 30722, 50000):
+        lv, nodes = ctypes.c_int32(), ctypes.c_int32()
+        assert lib.pgnn_kdtree_shape(n, ctypes.byref(lv), ctypes.byref(nodes)) == 0
+        t = KDTree(rng.random((n, 3)), leaf_size=30)
+        assert nodes.value == t.get_arrays()[2].shape[0], n
