@@ -372,6 +372,18 @@ int pgnn_nms_boxes_3d(const int32_t *class_labels, const float *boxes_3d,
 int pgnn_overlapped_boxes_3d(const float *single_box, const float *boxes_3d,
                              int64_t n_boxes, float appr_factor,
                              double *overlap, void *stream);
+/* overlapped_boxes_3d(single_box, box_list) (nms.py:29-62), the cv2.fillPoly
+ * raster overlap random_box_shift calls under every shipped train config
+ * (preprocess.py:281-301): integer corner arrays [8,3] / [n_boxes,8,3] int32
+ * (np.int32(appr_factor * boxes_3d_to_corners(.))), device pointers; overlap
+ * [n_boxes] float64 = np.float32(intersection) / (union - intersection) with
+ * pixel counts identical to cv2.fillPoly(LINE_8) + cv2.countNonZero on the
+ * (z extent) x (x extent) buffers the reference allocates (OpenCV 4.2
+ * drawing.cpp semantics: Bresenham outline after clipLine + 16.16 fixed-point
+ * scan-line fill), evaluated in closed form per image row. */
+int pgnn_overlapped_boxes_3d_raster(const int32_t *single_box_corners,
+                                    const int32_t *box_corners, int64_t n_boxes,
+                                    double *overlap, void *stream);
 
 /* ---- KITTI frame ingest (the step right before the
  * path; dataset/kitti_dataset.py:587-609, 998-1006, 1036-1052, 666-689,

@@ -117,6 +117,8 @@ _SIGNATURES = {
                                   c_vp]),
     "pgnn_overlapped_boxes_3d": (c_i32, [c_vp, c_vp, c_i64, ctypes.c_float,
                                          c_vp, c_vp]),
+    "pgnn_overlapped_boxes_3d_raster": (c_i32, [c_vp, c_vp, c_i64, c_vp,
+                                                c_vp]),
     # training targets
     "pgnn_assign_box_labels": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_vp, c_vp,
                                        c_vp, c_vp, c_vp]),

@@ -9,10 +9,12 @@ overlapped_fn=..., appr_factor=10.0, top_k=-1, attributes=None) ->
 (class_labels, detection_boxes_3d, detection_scores, attributes)`.
 
 Differences a caller can observe:
-  * `overlapped_fn` must be `overlapped_boxes_3d_fast_poly` (what run.py
-    passes, :295-322); the cv2 raster variant `overlapped_boxes_3d` is not
-    implemented.  Here that name is a callable on (x,y,z,l,h,w,yaw) boxes --
-    the corner geometry is built on the device.
+  * the NMS entries take `overlapped_fn=overlapped_boxes_3d_fast_poly` only
+    (what run.py passes, :295-322); that name is here a callable on
+    (x,y,z,l,h,w,yaw) boxes -- the corner geometry is built on the device.
+    The cv2 raster variant `overlapped_boxes_3d` (nms.py:29-62) exists as a
+    standalone function on integer corner arrays, for its one caller on the
+    path: random_box_shift (preprocess.py:281-301).
   * inputs are not modified (the reference edits `bboxes`/`scores` in place on
     its sorted copies only, so neither does it in effect);
   * boxes with EQUAL scores keep their input order (np.argsort(-scores),
@@ -44,6 +46,23 @@ def _to(x, dtype, dev):
     return x.to(device=dev, dtype=dtype).contiguous()
 
 
+def boxes_3d_to_corners(boxes_3d):
+    """nms.py:9-27 on the host, float64 like the reference (its callers pass a
+    handful of label boxes): [n,7] (x,y,z,l,h,w,yaw) -> [n,8,3].  The rotation
+    goes through the same `corners.dot(R.T)` NumPy product, so the values the
+    integer truncation of preprocess.py:291-298 sees are the reference's."""
+    out = []
+    for x3d, y3d, z3d, l, h, w, yaw in np.asarray(boxes_3d).reshape(-1, 7):
+        c, s = np.cos(yaw), np.sin(yaw)
+        rot = np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]])
+        half = np.array([[l / 2, 0.0, w / 2], [l / 2, 0.0, -w / 2],
+                         [-l / 2, 0.0, -w / 2], [-l / 2, 0.0, w / 2],
+                         [l / 2, -h, w / 2], [l / 2, -h, -w / 2],
+                         [-l / 2, -h, -w / 2], [-l / 2, -h, w / 2]])
+        out.append(half.dot(np.transpose(rot)) + np.array([x3d, y3d, z3d]))
+    return np.array(out)
+
+
 def overlapped_boxes_3d_fast_poly(single_box, box_list, appr_factor=0.0):
     """nms.py:64-88 for boxes given as (x,y,z,l,h,w,yaw): overlap of
     `single_box` [7] with every row of `box_list` [n,7] -> [n] float64."""
@@ -63,9 +82,28 @@ def overlapped_boxes_3d_fast_poly(single_box, box_list, appr_factor=0.0):
 
 
 def overlapped_boxes_3d(single_box, box_list):
-    raise NotImplementedError(
-        "the cv2 raster overlap (nms.py:29-62) has no HIP implementation; "
-        "run.py uses overlapped_boxes_3d_fast_poly")
+    """nms.py:29-62, the cv2.fillPoly raster overlap: `single_box` [8,3] and
+    `box_list` [n,8,3] are INTEGER corner arrays
+    (np.int32(appr_factor * boxes_3d_to_corners(.)), as the reference's callers
+    pass them) -> [n] float64.  Pixel counts are those of cv2.fillPoly +
+    cv2.countNonZero on the buffers the reference allocates
+    (pgnn_overlapped_boxes_3d_raster; closed form per image row)."""
+    import torch
+    lib = _lib.load()
+    as_numpy = not isinstance(box_list, torch.Tensor)
+    dev = _device_of(box_list, single_box)
+    many = _to(box_list, torch.int32, dev)
+    n = int(many.shape[0]) if many.dim() == 3 else 0
+    if as_numpy and n == 0:
+        return np.zeros(0)
+    one = _to(single_box, torch.int32, dev).reshape(8, 3)
+    many = many.reshape(n, 8, 3)
+    out = torch.empty((n,), dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.pgnn_overlapped_boxes_3d_raster(
+            _lib.ptr(one), _lib.ptr(many), n, _lib.ptr(out),
+            _lib.stream_ptr()), "pgnn_overlapped_boxes_3d_raster")
+    return out.cpu().numpy() if as_numpy else out
 
 
 def _nms(mode, class_labels, detection_boxes_3d, detection_scores,

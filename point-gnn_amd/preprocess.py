@@ -13,10 +13,12 @@ reference's array after its first `xyz.dot(R.T)` (preprocess.py:55);
 are edited on the host exactly where the reference edits them.
 
 `random_box_shift` tests a candidate position against the already placed boxes
-with the exact polygon overlap on the integer corner grid
-(`pgnn_overlapped_boxes_3d`, appr_factor) where the reference rasterises the
-same integer polygons with cv2.fillPoly (`nms.overlapped_boxes_3d`); cv2 is
-absent from the image, so that one test is not pinned.  The other
+with the reference's raster overlap (`nms.overlapped_boxes_3d`, nms.py:29-62:
+cv2.fillPoly on the integer corner grid): `pgnn_overlapped_boxes_3d_raster`
+produces cv2's pixel counts in closed form.  cv2 itself is absent from the
+image; the fill rule is restated from OpenCV 4.2's drawing.cpp
+(oracle/raster_oracle.py) and the fixtures come from the reference's own
+preprocess.py / nms.py running on that restatement.  The other
 registry entries raise NotImplementedError.
 """
 import random
@@ -173,10 +175,16 @@ def random_box_shift(cam_rgb_points, labels, max_overlap_num_allowed=0.1,
             _, extra = _in_box(xyz, moved, expend_factor, exclude=own)
             ok = int(extra.item()) < max_overlap_num_allowed
             if max_overlap_rate is not None and placed:
-                overlap = nms.overlapped_boxes_3d_fast_poly(
-                    np.array(_box7(moved), np.float64),
-                    np.array([_box7(l) for l in placed], np.float64),
-                    appr_factor=float(appr_factor))
+                # preprocess.py:281-301: integer corner grids (truncation of
+                # appr_factor * corners), cv2 raster overlap against every
+                # label placed so far -- shifted or not
+                new_corners = np.int32(appr_factor * nms.boxes_3d_to_corners(
+                    np.array([_box7(moved)])))
+                placed_corners = np.int32(
+                    appr_factor * nms.boxes_3d_to_corners(
+                        np.array([_box7(l) for l in placed])))
+                overlap = nms.overlapped_boxes_3d(new_corners[0],
+                                                  placed_corners)
                 ok = ok and bool(np.all(overlap < max_overlap_rate))
             if ok:
                 _affine(xyz, shift=delta, select=own)
