@@ -167,7 +167,7 @@ def roofline_edge_kernel(torch, engine, edges1, n_k, reps=10, frame=None):
         _lib.check(lib.pgnn_edge_mlp_scatter_max_fwd(
             _lib.ptr(p), _lib.ptr(q), wq, int(rest.k_in), _lib.ptr(edges1),
             n_e, n_k, rest.array, rest.n, 1, _lib.ptr(agg), agg.stride(0),
-            _lib.stream_ptr()), "edge kernel")
+            _lib.ptr(_lib.sched_ws()), _lib.stream_ptr()), "edge kernel")
     dur = time_kernel(run, reps, torch)
     widths = lc[0]['kwargs']['edge_MLP_depth_list']
     executed = sum(2 * a * b for a, b in zip(widths[:-1], widths[1:])) * n_e
@@ -211,7 +211,7 @@ def roofline_pool_kernel(torch, engine, reps=10, frame=None):
         _lib.check(lib.pgnn_point_set_pooling_fwd(
             _lib.ptr(f), n_feat, _lib.ptr(x), _lib.ptr(kp), _lib.ptr(e0), n_e,
             k, chain.array, chain.n, 1, _lib.ptr(agg), agg.stride(0),
-            _lib.stream_ptr()), "pooling kernel")
+            _lib.ptr(_lib.sched_ws()), _lib.stream_ptr()), "pooling kernel")
     dur = time_kernel(run, reps, torch)
     dims = [n_feat + 3] + widths
     flops = sum(2 * a * b for a, b in zip(dims[:-1], dims[1:])) * n_e

@@ -141,11 +141,17 @@ int pgnn_kdtree_replica(const float *points, int64_t n_points, void *workspace,
                         double *node_bounds, int32_t *status, void *stream);
 
 size_t pgnn_keypoints_workspace_bytes(int64_t n_points);
+/* aux_stream (nullable): a second caller-owned stream.  When given, the
+ * kd-tree replica (a latency-bound chain of ~10 dependent launches that only
+ * needs the points) is issued there, forked from and joined back into `stream`
+ * with two events, so it overlaps the voxel hashing; NULL = everything in
+ * order on `stream`.  The results are identical. */
 int pgnn_voxel_keypoints_center(const float *points, int64_t n_points,
                                 double voxel_size, void *workspace,
                                 size_t workspace_bytes,
                                 int32_t *keypoint_indices, float *keypoint_xyz,
-                                int32_t *num_keypoints, void *stream);
+                                int32_t *num_keypoints, void *stream,
+                                void *aux_stream);
 int pgnn_voxel_keypoints_random(const float *points, int64_t n_points,
                                 double voxel_size, const double *jitter3_host,
                                 uint64_t seed, void *workspace,
@@ -196,6 +202,13 @@ int pgnn_mlp_fwd(const float *x, int64_t ld_x, int32_t nx, const float *x2,
  * keypoint when edges_sorted != 0.  out: [num_keypoints, ld_out], columns
  * 16*ceil(n_out/16) written (zero padded); keypoints without edges get
  * float lowest (TF unsorted_segment_max).                                   */
+/* sched_ws (both fused entries; nullable): two int32 on the device, zero before
+ * the first use; the kernel leaves them zero.  When given, the persistent
+ * workgroups take their row tiles in small chunks through an atomic counter
+ * instead of one fixed range each (robust against kernels of other streams
+ * occupying CUs when the grid starts, evens out the tail).  Launches that may
+ * run concurrently (different streams) need different sched_ws.  Results do
+ * not depend on it (max is exact). */
 int pgnn_point_set_pooling_fwd(const float *point_features, int32_t n_feat,
                                const float *point_xyz,
                                const int32_t *keypoint_indices,
@@ -203,7 +216,8 @@ int pgnn_point_set_pooling_fwd(const float *point_features, int32_t n_feat,
                                int32_t num_keypoints,
                                const pgnn_fc_layer *layers_host,
                                int32_t n_layers, int32_t edges_sorted,
-                               float *out, int64_t ld_out, void *stream);
+                               float *out, int64_t ld_out, int32_t *sched_ws,
+                               void *stream);
 
 /* Fused GraphNetAutoCenter edge stage (gnn.py:338-365).  The first edge layer
  * is linear before its ReLU, so with P = [h, x] @ W1 + b1 and Q = x' @ W1[C:]
@@ -220,7 +234,8 @@ int pgnn_edge_mlp_scatter_max_fwd(const float *P, const float *Q,
                                   int32_t num_vertices,
                                   const pgnn_fc_layer *layers_host,
                                   int32_t n_layers, int32_t edges_sorted,
-                                  float *out, int64_t ld_out, void *stream);
+                                  float *out, int64_t ld_out, int32_t *sched_ws,
+                                  void *stream);
 
 /* x' = x + delta (gnn.py:346) and Q = x' @ Wx where Wx = the last 3 rows of
  * the first edge layer's weights (the rows that multiply the coordinate part
@@ -360,7 +375,7 @@ int pgnn_detection_candidates(const float *probs, int64_t n_vertices,
 size_t pgnn_nms_workspace_bytes(int64_t n_boxes);
 int pgnn_nms_boxes_3d(const int32_t *class_labels, const float *boxes_3d,
                       const float *scores, const int32_t *attributes,
-                      int64_t n_boxes, float overlapped_thres, int32_t mode,
+                      int64_t n_boxes, double overlapped_thres, int32_t mode,
                       float appr_factor, int64_t top_k, void *workspace,
                       size_t workspace_bytes, int32_t *out_labels,
                       float *out_boxes, float *out_scores,

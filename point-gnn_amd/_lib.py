@@ -52,7 +52,7 @@ _SIGNATURES = {
                                         c_vp, c_i64, c_vp]),
     "pgnn_keypoints_workspace_bytes": (c_sz, [c_i64]),
     "pgnn_voxel_keypoints_center": (c_i32, [c_vp, c_i64, c_f64, c_vp, c_sz,
-                                            c_vp, c_vp, c_vp, c_vp]),
+                                            c_vp, c_vp, c_vp, c_vp, c_vp]),
     "pgnn_voxel_keypoints_random": (c_i32, [c_vp, c_i64, c_f64, c_vp, c_u64,
                                             c_vp, c_sz, c_vp, c_vp, c_vp,
                                             c_vp]),
@@ -68,11 +68,12 @@ _SIGNATURES = {
     "pgnn_point_set_pooling_fwd": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp,
                                            c_i64, c_i32,
                                            ctypes.POINTER(FcLayer), c_i32,
-                                           c_i32, c_vp, c_i64, c_vp]),
+                                           c_i32, c_vp, c_i64, c_vp, c_vp]),
     "pgnn_edge_mlp_scatter_max_fwd": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp,
                                               c_i64, c_i32,
                                               ctypes.POINTER(FcLayer), c_i32,
-                                              c_i32, c_vp, c_i64, c_vp]),
+                                              c_i32, c_vp, c_i64, c_vp,
+                                              c_vp]),
     "pgnn_offset_apply": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp,
                                   c_i64, c_vp]),
     "pgnn_vertex_pre_edge_fwd": (c_i32, [c_vp, c_i64, c_i32, c_vp,
@@ -112,7 +113,7 @@ _SIGNATURES = {
                                           c_i64, c_vp, c_vp]),
     "pgnn_nms_workspace_bytes": (c_sz, [c_i64]),
     "pgnn_nms_boxes_3d": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64,
-                                  ctypes.c_float, c_i32, ctypes.c_float, c_i64,
+                                  c_f64, c_i32, ctypes.c_float, c_i64,
                                   c_vp, c_sz, c_vp, c_vp, c_vp, c_vp, c_vp,
                                   c_vp]),
     "pgnn_overlapped_boxes_3d": (c_i32, [c_vp, c_vp, c_i64, ctypes.c_float,
@@ -195,6 +196,24 @@ def check(rc, what=""):
         msg = load().pgnn_last_error()
         raise PointGnnHipError("%s failed (code %d): %s" % (
             what or "pgnn call", rc, msg.decode() if msg else "?"))
+
+
+_SCHED_WS = {}
+
+
+def sched_ws(device=None):
+    """The two zeroed int32 counters the fused kernels' dynamic tile scheduling
+    uses (sched_ws of pgnn_point_set_pooling_fwd / pgnn_edge_mlp_scatter_max_fwd):
+    one pair per (device, current stream), because launches of one stream are
+    serialised and the kernel hands the counters back zeroed."""
+    import torch
+    dev = torch.device("cuda", torch.cuda.current_device()) \
+        if device is None else device
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    t = _SCHED_WS.get(key)
+    if t is None:
+        t = _SCHED_WS[key] = torch.zeros(2, dtype=torch.int32, device=dev)
+    return t
 
 
 def stream_ptr():

@@ -32,6 +32,8 @@ extern int g_scatter_rows_per_wave;
 extern int g_mlp_blocks_per_cu;
 extern int g_edge_msub;
 extern int g_pool_msub;
+extern int g_mlp_chunks_per_wg;
+extern int g_graph_debug;
 extern int g_mlp_debug;
 extern void *g_mlp_ts;
 extern int g_scatter_nt;
@@ -80,6 +82,15 @@ extern "C" int pgnn_set_tunable(const char *key, int value) {
   }
   if (!strcmp(key, "mlp_debug")) {
     pgnn::g_mlp_debug = value;
+    return 0;
+  }
+  if (!strcmp(key, "mlp_chunks_per_wg")) {
+    if (value < 0 || value > 64) return PGNN_E_INVALID;
+    pgnn::g_mlp_chunks_per_wg = value;
+    return 0;
+  }
+  if (!strcmp(key, "graph_debug")) {
+    pgnn::g_graph_debug = value;
     return 0;
   }
   if (!strcmp(key, "pool_msub")) {

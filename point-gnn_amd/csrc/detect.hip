@@ -763,7 +763,7 @@ extern "C" size_t pgnn_nms_workspace_bytes(int64_t n_boxes) {
 extern "C" int pgnn_nms_boxes_3d(const int32_t *class_labels,
                                  const float *boxes_3d, const float *scores,
                                  const int32_t *attributes, int64_t n_boxes,
-                                 float overlapped_thres, int32_t mode,
+                                 double overlapped_thres, int32_t mode,
                                  float appr_factor, int64_t top_k,
                                  void *workspace, size_t workspace_bytes,
                                  int32_t *out_labels, float *out_boxes,
@@ -810,7 +810,7 @@ extern "C" int pgnn_nms_boxes_3d(const int32_t *class_labels,
                      dim3((unsigned)(pair_blocks < (1 << 22) ? pair_blocks
                                                              : (1 << 22))),
                      dim3(256), 0, stream, L.geom, L.s_label, m, words,
-                     (double)overlapped_thres, L.mask, L.row_flag);
+                     overlapped_thres, L.mask, L.row_flag);
   PGNN_HIP(hipGetLastError());
   ScanArgs sa;
   sa.m = m;

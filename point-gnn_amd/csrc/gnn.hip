@@ -18,6 +18,7 @@ namespace pgnn {
 int g_mlp_blocks_per_cu = 4;  // upper bound; LDS usually allows fewer
 int g_edge_msub = 0;          // 0 = auto, else force 16*msub-row tiles
 int g_pool_msub = 0;
+int g_mlp_chunks_per_wg = 5;  // dynamic tile scheduling; 0 = static ranges
 void *g_mlp_ts = nullptr;  // device buffer for per-tile timestamps (profiling)
 int g_mlp_debug = 0;  // ablation mask (benchmarks only): 1 = no gather loads,
                       // 2 = no last-layer GEMM, 4 = no epilogue, 16 = print
@@ -198,7 +199,9 @@ template <int MSUB, int PRO>
 __global__ __launch_bounds__(256, 2) void fused_mlp_kernel(
     ChainDev chain, int64_t n_rows, RowsArgs ra, PoolArgs pa, EdgeArgs ea,
     SegArgs sa, int stage_off /* floats from tile base; < 0: in place */,
-    int dbg, long long *ts /* optional per-tile timestamps (profiling) */) {
+    int dbg, long long *ts /* optional per-tile timestamps (profiling) */,
+    int32_t *sched /* nullable: {next chunk, finished workgroups}, both 0 */,
+    int chunk_tiles) {
   constexpr int ROWS = 16 * MSUB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int *dst = reinterpret_cast<int *>(smem);
@@ -214,14 +217,36 @@ __global__ __launch_bounds__(256, 2) void fused_mlp_kernel(
   const int64_t n_tiles = (n_rows + ROWS - 1) / ROWS;
   const int ld0 = lds_ld(16 * chain.l[0].kq);
 
-  // contiguous tile range per workgroup (remainder spread over the first ones)
+  // Tile ranges.  Static (sched == nullptr): one contiguous range per workgroup,
+  // remainder spread over the first ones.  Dynamic: chunks of `chunk_tiles`
+  // contiguous tiles handed out through an atomic counter -- workgroup b starts
+  // with chunk b, every further chunk is claimed while the current one is being
+  // processed (the atomic's round trip hides under a whole chunk).  A kernel of
+  // another stream holding LDS on some CU when this grid starts (the 2 x 80 KB
+  // tiles fill a CU's LDS exactly) then costs that CU's share of the chunks, not
+  // a whole second pass of the late workgroup; the same mechanism evens out
+  // tiles of different epilogue cost.  A chunk is treated like a workgroup
+  // range: the open segment is carried inside it and flushed atomically at its
+  // two ends.  The last workgroup to finish re-arms the two counters.
   const int64_t tq = n_tiles / gridDim.x, trem = n_tiles % gridDim.x;
-  const int64_t tile_first =
-      blockIdx.x * tq + (blockIdx.x < trem ? blockIdx.x : trem);
-  const int64_t tile_last = tile_first + tq + (blockIdx.x < trem ? 1 : 0);
-  CarryState cs = {-1, 0};
+  const int n_chunks =
+      sched ? (int)((n_tiles + chunk_tiles - 1) / chunk_tiles) : (int)gridDim.x;
+  __shared__ int s_next_chunk;
   // prefetched (src, dst[, keypoint]) of the next tile's rows (EDGE / POOL)
   int nxt_s = 0, nxt_d = -1, nxt_k = 0;
+  for (int chunk = blockIdx.x; chunk < n_chunks;) {  // `chunk` stays in an SGPR
+  int claimed = n_chunks;
+  if (sched && threadIdx.x == 0)
+    claimed = (int)gridDim.x +
+              __hip_atomic_fetch_add(&sched[0], 1, __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT);
+  const int64_t tile_first =
+      sched ? (int64_t)chunk * chunk_tiles
+            : chunk * tq + (chunk < trem ? chunk : trem);
+  int64_t tile_last = sched ? tile_first + chunk_tiles
+                            : tile_first + tq + (chunk < trem ? 1 : 0);
+  if (tile_last > n_tiles) tile_last = n_tiles;
+  CarryState cs = {-1, 0};
   for (int64_t tile_id = tile_first; tile_id < tile_last; ++tile_id) {
     const int64_t row0 = tile_id * ROWS;
     const int rows_valid =
@@ -535,6 +560,21 @@ __global__ __launch_bounds__(256, 2) void fused_mlp_kernel(
       }
     }
   }
+  if (!sched) break;  // static: the one range of this workgroup is done
+  // hand the claimed chunk to the whole workgroup (the previous value of
+  // s_next_chunk was read before at least one tile's barriers)
+  if (threadIdx.x == 0) s_next_chunk = claimed;
+  __syncthreads();
+  chunk = __builtin_amdgcn_readfirstlane(s_next_chunk);
+  }
+  if (sched && threadIdx.x == 0) {
+    const int done = __hip_atomic_fetch_add(&sched[1], 1, __ATOMIC_ACQ_REL,
+                                            __HIP_MEMORY_SCOPE_AGENT);
+    if (done == (int)gridDim.x - 1) {  // every claim of this launch has landed
+      __hip_atomic_store(&sched[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&sched[1], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 __global__ void offset_apply_kernel(const float *__restrict__ xyz,
@@ -616,7 +656,7 @@ size_t plan_lds_bytes(const Plan &p, int rows) {
 template <int MSUB, int PRO>
 int launch_fused(const Plan &p, int64_t n_rows, const RowsArgs &ra,
                  const PoolArgs &pa, const EdgeArgs &ea, const SegArgs &sa,
-                 hipStream_t stream) {
+                 hipStream_t stream, int32_t *sched = nullptr) {
   constexpr int ROWS = 16 * MSUB;
   const size_t lds = plan_lds_bytes(p, ROWS);
   PGNN_REQUIRE(lds <= 160 * 1024, PGNN_E_UNSUPPORTED,
@@ -630,6 +670,17 @@ int launch_fused(const Plan &p, int64_t n_rows, const RowsArgs &ra,
   if (per_cu > g_mlp_blocks_per_cu) per_cu = g_mlp_blocks_per_cu;
   if (per_cu < 1) per_cu = 1;
   int64_t grid = (int64_t)device_cu_count() * per_cu;
+  // dynamic scheduling: ~g_mlp_chunks_per_wg chunks per workgroup, 1..8 tiles
+  // each (long enough to amortise the per-chunk index round trip and the two
+  // atomic boundary flushes, short enough to even out the tail)
+  int chunk_tiles = 1;
+  if (g_mlp_ts || g_mlp_chunks_per_wg <= 0) sched = nullptr;
+  if (sched) {
+    int64_t ct = n_tiles / (grid * g_mlp_chunks_per_wg);
+    chunk_tiles = (int)(ct < 1 ? 1 : (ct > 8 ? 8 : ct));
+    const int64_t n_chunks = (n_tiles + chunk_tiles - 1) / chunk_tiles;
+    if (grid > n_chunks) grid = n_chunks;
+  }
   if (grid > n_tiles) grid = n_tiles;
   const int stage_off = p.stage_cols ? ROWS * p.tile_floats_per_row : -1;
   if (g_mlp_debug & 16) {
@@ -641,7 +692,7 @@ int launch_fused(const Plan &p, int64_t n_rows, const RowsArgs &ra,
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, stream, p.chain,
                      n_rows, ra, pa, ea, sa, stage_off, g_mlp_debug,
-                     (long long *)g_mlp_ts);
+                     (long long *)g_mlp_ts, sched, chunk_tiles);
   PGNN_HIP(hipGetLastError());
   return 0;
 }
@@ -763,7 +814,8 @@ extern "C" int pgnn_point_set_pooling_fwd(
     const float *point_features, int32_t n_feat, const float *point_xyz,
     const int32_t *keypoint_indices, const int32_t *edges, int64_t n_edges,
     int32_t num_keypoints, const pgnn_fc_layer *layers, int32_t n_layers,
-    int32_t edges_sorted, float *out, int64_t ld_out, void *stream_) {
+    int32_t edges_sorted, float *out, int64_t ld_out, int32_t *sched_ws,
+    void *stream_) {
   PGNN_GUARD_BEGIN
   hipStream_t stream = (hipStream_t)stream_;
   PGNN_REQUIRE(n_edges >= 0 && num_keypoints >= 0 && n_feat >= 0 && n_feat <= 13,
@@ -792,8 +844,9 @@ extern "C" int pgnn_point_set_pooling_fwd(
     msub = (plan_lds_bytes(p, 64) <= 80 * 1024 ||
             plan_lds_bytes(p, 32) > 80 * 1024) ? 4 : 2;
   if (msub == 4)
-    return launch_fused<4, PRO_POOL>(p, n_edges, ra, pa, ea, sa, stream);
-  return launch_fused<2, PRO_POOL>(p, n_edges, ra, pa, ea, sa, stream);
+    return launch_fused<4, PRO_POOL>(p, n_edges, ra, pa, ea, sa, stream,
+                                     sched_ws);
+  return launch_fused<2, PRO_POOL>(p, n_edges, ra, pa, ea, sa, stream, sched_ws);
   PGNN_GUARD_END
 }
 
@@ -801,7 +854,7 @@ extern "C" int pgnn_edge_mlp_scatter_max_fwd(
     const float *P, const float *Q, int64_t ld_pq, int32_t width,
     const int32_t *edges, int64_t n_edges, int32_t num_vertices,
     const pgnn_fc_layer *layers, int32_t n_layers, int32_t edges_sorted,
-    float *out, int64_t ld_out, void *stream_) {
+    float *out, int64_t ld_out, int32_t *sched_ws, void *stream_) {
   PGNN_GUARD_BEGIN
   hipStream_t stream = (hipStream_t)stream_;
   PGNN_REQUIRE(n_edges >= 0 && num_vertices >= 0 && width > 0, PGNN_E_INVALID,
@@ -832,8 +885,9 @@ extern "C" int pgnn_edge_mlp_scatter_max_fwd(
     msub = (plan_lds_bytes(p, 64) <= 80 * 1024 ||
             plan_lds_bytes(p, 32) > 80 * 1024) ? 4 : 2;
   if (msub == 4)
-    return launch_fused<4, PRO_EDGE>(p, n_edges, ra, pa, ea, sa, stream);
-  return launch_fused<2, PRO_EDGE>(p, n_edges, ra, pa, ea, sa, stream);
+    return launch_fused<4, PRO_EDGE>(p, n_edges, ra, pa, ea, sa, stream,
+                                     sched_ws);
+  return launch_fused<2, PRO_EDGE>(p, n_edges, ra, pa, ea, sa, stream, sched_ws);
   PGNN_GUARD_END
 }
 

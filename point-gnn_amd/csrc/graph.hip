@@ -660,11 +660,16 @@ extern "C" size_t pgnn_keypoints_workspace_bytes(int64_t n_points) {
          kd_workspace_bytes(n_points) + 2048;
 }
 
+namespace pgnn {
+int g_graph_debug = 0;  // benchmarks only: 1 = skip the kd-tree replica (exact
+                        // ties then go to idx_array-free slot order)
+}
 namespace {
 int keypoints_impl(const float *points, int64_t n, double voxel, bool center,
                    const double *jitter3, uint64_t seed, void *workspace,
                    size_t workspace_bytes, int32_t *kp_idx, float *kp_xyz,
-                   int32_t *num_kp, hipStream_t stream) {
+                   int32_t *num_kp, hipStream_t stream,
+                   hipStream_t aux = nullptr) {
   PGNN_REQUIRE(n >= 0 && voxel > 0.0 && kp_idx && kp_xyz && num_kp,
                PGNN_E_INVALID, "keypoints: bad argument");
   if (n == 0) {
@@ -689,6 +694,41 @@ int keypoints_impl(const float *points, int64_t n, double voxel, bool center,
   PGNN_REQUIRE(omin && origin && is_leader && slot && members && centroid &&
                    scan_scratch,
                PGNN_E_WORKSPACE, "keypoints: workspace too small");
+  // scikit-learn's kd-tree node order over the points decides exact ties
+  // ('center' only).  It depends on nothing but the points: with an aux
+  // stream it runs beside the voxel hashing (fork here, join before the
+  // nearest-neighbour kernel).
+  KdBuild kb;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  kb.pos = nullptr;
+  kb.bounds = nullptr;
+  kb.n_nodes = 0;
+  const bool use_kd = center && !(g_graph_debug & 1);
+  if (!use_kd && center) {  // ablation: a valid (all-zero) slot table
+    kb.pos = a.take<int32_t>((size_t)n);
+    PGNN_REQUIRE(kb.pos, PGNN_E_WORKSPACE, "keypoints: workspace too small");
+    PGNN_HIP(hipMemsetAsync(kb.pos, 0, (size_t)n * 4, stream));
+  }
+  if (use_kd) {
+    hipStream_t kd_stream = stream;
+    if (aux && aux != stream) {
+      PGNN_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+      PGNN_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+      PGNN_HIP(hipEventRecord(ev_fork, stream));
+      PGNN_HIP(hipStreamWaitEvent(aux, ev_fork, 0));
+      kd_stream = aux;
+    }
+    rc = kd_build(points, n, a, kb, kd_stream);
+    if (ev_join) {
+      // join even when kd_build failed half-way: nothing may be left running
+      // on aux that `stream`'s later work does not wait for
+      hipEventRecord(ev_join, aux);
+      hipStreamWaitEvent(stream, ev_join, 0);
+      hipEventDestroy(ev_fork);
+      hipEventDestroy(ev_join);
+    }
+    if (rc) return rc;
+  }
   PGNN_HIP(hipMemsetAsync(omin, 0xff, 16, stream));
   int mb = (int)((n + 255) / 256);
   if (mb > 1024) mb = 1024;
@@ -716,10 +756,6 @@ int keypoints_impl(const float *points, int64_t n, double voxel, bool center,
   hipLaunchKernelGGL(copy_total_kernel, dim3(1), dim3(64), 0, stream, slot + n,
                      num_kp);
   if (center) {
-    // scikit-learn's kd-tree node order over the points: decides exact ties
-    KdBuild kb;
-    rc = kd_build(points, n, a, kb, stream);
-    if (rc) return rc;
     KdView kd;
     kd.pos = kb.pos;
     kd.bounds = kb.bounds;
@@ -745,11 +781,12 @@ extern "C" int pgnn_voxel_keypoints_center(const float *points, int64_t n_points
                                            int32_t *keypoint_indices,
                                            float *keypoint_xyz,
                                            int32_t *num_keypoints,
-                                           void *stream) {
+                                           void *stream, void *aux_stream) {
   PGNN_GUARD_BEGIN
   return keypoints_impl(points, n_points, voxel_size, true, nullptr, 0,
                         workspace, workspace_bytes, keypoint_indices,
-                        keypoint_xyz, num_keypoints, (hipStream_t)stream);
+                        keypoint_xyz, num_keypoints, (hipStream_t)stream,
+                        (hipStream_t)aux_stream);
   PGNN_GUARD_END
 }
 

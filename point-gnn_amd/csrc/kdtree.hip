@@ -35,9 +35,19 @@ constexpr int KD_NW = KD_NT / 64;
 constexpr int KD_LDS_CAP = 5120;   // records a workgroup keeps in LDS (80 KB)
 constexpr int KD_BATCH = 2048;     // swap-list entries per batch, block mode
 constexpr int KD_WBATCH = 256;     // ... per wave, wave mode (same storage)
-constexpr int KD_WAVE_TAIL = 256;  // block mode hands ranges this short to wave 0
+#ifndef PGNN_KD_WAVE_TAIL
+#define PGNN_KD_WAVE_TAIL 512
+#endif
+#ifndef PGNN_KD_TOP_LEN
+#define PGNN_KD_TOP_LEN 640
+#endif
+constexpr int KD_WAVE_TAIL = PGNN_KD_WAVE_TAIL;  // block mode hands ranges this short to wave 0
 constexpr int KD_WAVE_NODE = 1536; // subtree nodes this short get one wave each
-constexpr int KD_MASK_WORDS = 4;   // chunk <= 256 elements per thread
+// levels whose nodes are longer than this get one launch each (one workgroup
+// per node); the rest of the tree is one launch with a workgroup per subtree
+constexpr int KD_TOP_LEN = PGNN_KD_TOP_LEN;
+static_assert(KD_TOP_LEN <= KD_LDS_CAP, "a subtree must fit the LDS buffer");
+constexpr int KD_MASK_WORDS = 8;   // chunk <= 512 elements per thread
 constexpr int64_t KD_MAX_POINTS = (int64_t)KD_NT * 64 * KD_MASK_WORDS;
 
 // (value, index) strict total order of IndexComparator
@@ -591,7 +601,8 @@ size_t kd_workspace_bytes(int64_t n) {
 int kd_build(const float *pts, int64_t n, Arena &a, KdBuild &kd,
              hipStream_t stream) {
   PGNN_REQUIRE(n >= 0 && n <= KD_MAX_POINTS, PGNN_E_INVALID,
-               "kdtree: more than 262144 points are not supported");
+               "kdtree: more than 524288 points are not supported");
+  static_assert(KD_MAX_POINTS == 524288, "keep the message in step");
   kd_shape(n, &kd.n_levels, &kd.n_nodes);
   const size_t nn = (size_t)(n > 0 ? n : 1);
   kd.idx = a.take<int32_t>(nn);
@@ -621,7 +632,7 @@ int kd_build(const float *pts, int64_t n, Arena &a, KdBuild &kd,
   // levels whose nodes can exceed the LDS capacity: one launch each
   int level0 = 0;
   while (level0 < kd.n_levels - 1 &&
-         ((n + ((int64_t)1 << level0) - 1) >> level0) > KD_LDS_CAP) {
+         ((n + ((int64_t)1 << level0) - 1) >> level0) > KD_TOP_LEN) {
     hipLaunchKernelGGL(kd_top_kernel, dim3(1u << level0), dim3(KD_NT), dyn,
                        stream, rec, (int)n, level0, kd.n_nodes, kd.bounds,
                        kd.status);

@@ -349,7 +349,8 @@ class PointSetPooling(object):
             _lib.ptr(feats), n_feat, _lib.ptr(xyz), _lib.ptr(kp),
             _lib.ptr(edges), int(edges.shape[0]), k, point_chain.array,
             point_chain.n, _edges_sorted_flag(set_indices), _lib.ptr(agg),
-            agg.stride(0), _lib.stream_ptr()), "pgnn_point_set_pooling_fwd")
+            agg.stride(0), _lib.ptr(_lib.sched_ws(xyz.device)),
+            _lib.stream_ptr()), "pgnn_point_set_pooling_fwd")
         with variable_scope('combined_features'):
             out_chain = _relu_chain(store, _scope(),
                                     list(output_MLP_depth_list), False)
@@ -449,7 +450,8 @@ class GraphNetAutoCenter(object):
         _lib.check(lib.pgnn_edge_mlp_scatter_max_fwd(
             _lib.ptr(p), _lib.ptr(q), wq, int(rest.k_in), _lib.ptr(e),
             int(e.shape[0]), k, rest.array, rest.n,
-            _edges_sorted_flag(edges) | 2, _lib.ptr(agg), agg.stride(0), st),
+            _edges_sorted_flag(edges) | 2, _lib.ptr(agg), agg.stride(0),
+            _lib.ptr(_lib.sched_ws(h.device)), st),
             "pgnn_edge_mlp_scatter_max_fwd")
         # update + residual, gnn.py:367-372
         upd_chain = _relu_chain(store, scope + '/combined_features',

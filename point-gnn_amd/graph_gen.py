@@ -108,6 +108,19 @@ def gen_disjointed_rnn_local_graph_v3(
     return edges
 
 
+_AUX_STREAMS = {}
+
+
+def _aux_stream(dev):
+    """A side stream per (device, current stream): the kd-tree replica of the
+    'center' keypoints is forked onto it (pgnn_voxel_keypoints_center)."""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    s = _AUX_STREAMS.get(key)
+    if s is None:
+        s = _AUX_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return s
+
+
 def keypoints_device(points, voxel_size, method='center', jitter=None, seed=0):
     """One pooling level.  Returns (coords float32 [K,3], indices int32 [K,1])
     as device tensors.  One host sync (reading K)."""
@@ -123,7 +136,8 @@ def keypoints_device(points, voxel_size, method='center', jitter=None, seed=0):
     if method == 'center':
         _lib.check(lib.pgnn_voxel_keypoints_center(
             _lib.ptr(points), n, float(voxel_size), _lib.ptr(ws), ws_bytes,
-            _lib.ptr(kp_idx), _lib.ptr(kp_xyz), _lib.ptr(num), st),
+            _lib.ptr(kp_idx), _lib.ptr(kp_xyz), _lib.ptr(num), st,
+            ctypes.c_void_p(_aux_stream(dev).cuda_stream)),
             "pgnn_voxel_keypoints_center")
     elif method == 'random':
         jit = None

@@ -569,6 +569,16 @@ def test_segmax_epilogue_paths_are_bit_identical(dev, layer):
     for bits in (32, 128, 32 | 128):
         assert np.array_equal(outs[0], outs[bits]), bits
     np.testing.assert_allclose(outs[0][:, :300], ref, atol=FP_TOL, rtol=1e-4)
+    # tile scheduling: static ranges (0), the default chunking, one-tile chunks
+    # (64: every tile boundary flushes atomically) -- same bits, and the two
+    # scheduling counters come back zeroed every time
+    try:
+        for chunks in (0, 1, 64):
+            _lib.set_tunable("mlp_chunks_per_wg", chunks)
+            assert np.array_equal(run(), outs[0]), chunks
+            assert int(_lib.sched_ws(dev).abs().sum().item()) == 0
+    finally:
+        _lib.set_tunable("mlp_chunks_per_wg", 5)
 
 
 @pytest.mark.parametrize("auto_offset,k", [(True, 1000), (False, 37), (True, 16)])

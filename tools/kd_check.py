@@ -22,6 +22,8 @@ clouds = {"n1": rng.random((1, 3)), "n31": rng.random((31, 3)),
           "n3000": rng.random((3000, 3)), "n9000": rng.random((9000, 3))}
 for name in ("tiny", "small", "car", "car_600k", "ped_dense"):
     clouds[name] = synthetic_cloud(seed=0, preset=name)[0]
+if len(sys.argv) > 1:      # kd_check.py car ped_dense ...
+    clouds = {k: v for k, v in clouds.items() if k in sys.argv[1:]}
 for name, xyz in clouds.items():
     xyz = np.ascontiguousarray(xyz, np.float32)
     idx, bounds, status = graph_gen.kdtree_replica(xyz)
