@@ -463,6 +463,12 @@ def parse_args(argv=None):
     ap.add_argument("--frames-per-gpu", type=int, default=2)
     ap.add_argument("--compute-streams", type=int, default=2,
                     help="GNN streams of the frame pipeline (1 or 2)")
+    ap.add_argument("--lookahead", type=int, default=0,
+                    help="frames the graph-builder thread may run ahead of the "
+                         "GNN (0 = build inline on the calling thread)")
+    ap.add_argument("--graph-cus", type=int, default=0,
+                    help="CUs reserved for the graph-build stream of the frame "
+                         "pipeline (CU-masked streams; 0 = shared device)")
     ap.add_argument("--tune", action="append", default=[],
                     help="key=value library tunable (experiments; repeatable)")
     args = ap.parse_args(argv)
@@ -669,7 +675,8 @@ def main(argv=None):
                     out = engine.run_frame(x, f)
                 return out
             return engine.run_frames_pipelined(
-                fr, compute_streams=args.compute_streams)[-1]
+                fr, compute_streams=args.compute_streams,
+                graph_cus=args.graph_cus, lookahead=args.lookahead)[-1]
 
         if warmup:
             run(0, warmup)
@@ -760,9 +767,13 @@ def main(argv=None):
                             "%d HIP streams: graph build of frame i+1 overlaps "
                             "the GNN of frame i%s" % (
                                 1 + args.compute_streams,
-                                "; consecutive frames alternate between two "
-                                "GNN streams" if args.compute_streams > 1
-                                else ""),
+                                ("; consecutive frames alternate between two "
+                                 "GNN streams" if args.compute_streams > 1
+                                 else "") +
+                                ("; graph stream on %d reserved CUs, GNN "
+                                 "streams on the other CUs (CU-masked "
+                                 "streams)" % args.graph_cus
+                                 if args.graph_cus > 0 else "")),
                 "parallelism": "frame-parallel x%d (no collective)" % world,
                 "distributed": dist_info(dist, world),
                 "frames_per_sec_per_gpu": fps / world,

@@ -44,6 +44,20 @@ const char *pgnn_last_error(void);
  * allocation visible to the HIP runtime this library is bound to. */
 int pgnn_check_device_pointer(const void *device_ptr);
 
+/* A stream whose kernels run on CUs [cu_first, cu_first + cu_count) only, or
+ * (complement != 0) on all the others.  The frame pipeline builds the next
+ * frame's graph on a few reserved CUs while the fused MFMA kernels of the
+ * current frame own the rest: they fill a CU completely (VGPRs and LDS), so
+ * without the split a kernel of another stream waits for their kernel
+ * boundaries and then displaces one of their persistent workgroups.  Mask bits
+ * are striped over the XCDs (bit i -> XCD i % 8): a contiguous range takes the
+ * same number of CUs from every XCD.  *stream_out is a hipStream_t; destroy it
+ * with pgnn_stream_destroy.  Every other entry takes such a stream like any
+ * other. */
+int pgnn_stream_create_cu_mask(int32_t cu_first, int32_t cu_count,
+                               int32_t complement, void **stream_out);
+int pgnn_stream_destroy(void *stream);
+
 /* ---- scatter-max -------------------------------------------------------
  * Replaces graph_scatter_max_fn = tf.math.unsorted_segment_max
  * (models/gnn.py:106-109; call sites gnn.py:275-277, 362-365).
@@ -203,12 +217,13 @@ int pgnn_mlp_fwd(const float *x, int64_t ld_x, int32_t nx, const float *x2,
  * 16*ceil(n_out/16) written (zero padded); keypoints without edges get
  * float lowest (TF unsorted_segment_max).                                   */
 /* sched_ws (both fused entries; nullable): two int32 on the device, zero before
- * the first use; the kernel leaves them zero.  When given, the persistent
- * workgroups take their row tiles in small chunks through an atomic counter
- * instead of one fixed range each (robust against kernels of other streams
- * occupying CUs when the grid starts, evens out the tail).  Launches that may
- * run concurrently (different streams) need different sched_ws.  Results do
- * not depend on it (max is exact). */
+ * the first use; the kernel leaves them zero.  When given, the last ~12 % of
+ * the row tiles are not part of the workgroups' fixed ranges but a pool they
+ * take one tile at a time through an atomic counter when their own range is
+ * done: slack that absorbs a late start of some workgroups (kernels of other
+ * streams occupying CUs when the grid starts).  Launches that may run
+ * concurrently (different streams) need different sched_ws.  Results do not
+ * depend on it (max is exact). */
 int pgnn_point_set_pooling_fwd(const float *point_features, int32_t n_feat,
                                const float *point_xyz,
                                const int32_t *keypoint_indices,

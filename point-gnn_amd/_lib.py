@@ -35,6 +35,9 @@ _SIGNATURES = {
     # name: (restype, argtypes)
     "pgnn_version": (c_i32, []),
     "pgnn_last_error": (ctypes.c_char_p, []),
+    "pgnn_stream_create_cu_mask": (c_i32, [c_i32, c_i32, c_i32,
+                                           ctypes.POINTER(c_vp)]),
+    "pgnn_stream_destroy": (c_i32, [c_vp]),
     "pgnn_check_device_pointer": (c_i32, [c_vp]),
     "pgnn_set_tunable": (c_i32, [ctypes.c_char_p, c_i32]),
     "pgnn_set_debug_buffer": (c_i32, [c_vp]),
@@ -202,10 +205,10 @@ _SCHED_WS = {}
 
 
 def sched_ws(device=None):
-    """The two zeroed int32 counters the fused kernels' dynamic tile scheduling
-    uses (sched_ws of pgnn_point_set_pooling_fwd / pgnn_edge_mlp_scatter_max_fwd):
-    one pair per (device, current stream), because launches of one stream are
-    serialised and the kernel hands the counters back zeroed."""
+    """The two zeroed int32 counters of the fused kernels' tile pool (sched_ws
+    of pgnn_point_set_pooling_fwd / pgnn_edge_mlp_scatter_max_fwd): one pair
+    per (device, current stream) -- launches of one stream are serialised and
+    the kernel hands the counters back zeroed."""
     import torch
     dev = torch.device("cuda", torch.cuda.current_device()) \
         if device is None else device

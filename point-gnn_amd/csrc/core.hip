@@ -28,12 +28,31 @@ int device_cu_count() {
   return cached[dev];
 }
 
+// CUs the kernels of `stream` may run on: the popcount of its CU mask
+// (pgnn_stream_create_cu_mask), the whole device for ordinary streams.  The
+// persistent kernels size their grids with it: a grid of 2 workgroups per
+// DEVICE CU on a stream that owns fewer CUs would run in two waves.
+int stream_cu_count(hipStream_t stream) {
+  const int total = device_cu_count();
+  if (stream == nullptr) return total;
+  uint32_t mask[32] = {0};
+  const int words = (total + 31) / 32;
+  if (words > 32 ||
+      hipExtStreamGetCUMask(stream, (uint32_t)words, mask) != hipSuccess) {
+    (void)hipGetLastError();
+    return total;
+  }
+  int n = 0;
+  for (int i = 0; i < total; ++i) n += (mask[i >> 5] >> (i & 31)) & 1u;
+  return n > 0 ? n : total;
+}
+
 extern int g_scatter_rows_per_wave;
 extern int g_mlp_blocks_per_cu;
 extern int g_edge_msub;
 extern int g_pool_msub;
-extern int g_mlp_chunks_per_wg;
 extern int g_graph_debug;
+extern int g_mlp_pool_pct;
 extern int g_mlp_debug;
 extern void *g_mlp_ts;
 extern int g_scatter_nt;
@@ -55,6 +74,51 @@ extern "C" int pgnn_check_device_pointer(const void *p) {
   PGNN_REQUIRE(attr.type == hipMemoryTypeDevice ||
                    attr.type == hipMemoryTypeManaged,
                PGNN_E_INVALID, "not a device pointer");
+  return 0;
+  PGNN_GUARD_END
+}
+
+// Streams restricted to a set of CUs (hipExtStreamCreateWithCUMask).  The
+// frame pipeline uses two disjoint sets: a handful of CUs for the latency-bound
+// graph construction of the next frame, the rest for the message passing of the
+// current one.  Why: the fused MFMA kernels occupy every CU completely (two
+// workgroups = all 512 VGPRs per SIMD lane and 159.4 of 160 KB LDS), so a
+// kernel of another stream can only start at their kernel boundaries, ~1 ms
+// apart -- a 40-launch dependent chain then takes several milliseconds -- and
+// every workgroup it does get delays one persistent workgroup of the next
+// fused kernel by its whole duration.  Mask bits are striped over the XCDs
+// first (bit i -> XCD i % 8), so a contiguous bit range takes the same number
+// of CUs from every XCD and the per-XCD round-robin of workgroups stays even.
+extern "C" int pgnn_stream_create_cu_mask(int32_t cu_first, int32_t cu_count,
+                                          int32_t complement,
+                                          void **stream_out) {
+  PGNN_GUARD_BEGIN
+  PGNN_REQUIRE(stream_out, PGNN_E_INVALID, "stream_create_cu_mask: null output");
+  *stream_out = nullptr;
+  const int total = pgnn::device_cu_count();
+  PGNN_REQUIRE(cu_first >= 0 && cu_count > 0 && cu_first + cu_count <= total,
+               PGNN_E_INVALID, "stream_create_cu_mask: CU range outside the device");
+  PGNN_REQUIRE(!complement || cu_count < total, PGNN_E_INVALID,
+               "stream_create_cu_mask: empty complement");
+  uint32_t mask[32] = {0};
+  const int words = (total + 31) / 32;
+  PGNN_REQUIRE(words <= 32, PGNN_E_UNSUPPORTED,
+               "stream_create_cu_mask: more than 1024 CUs");
+  for (int i = 0; i < total; ++i) {
+    const bool in_range = i >= cu_first && i < cu_first + cu_count;
+    if (in_range != (complement != 0)) mask[i >> 5] |= 1u << (i & 31);
+  }
+  hipStream_t s = nullptr;
+  PGNN_HIP(hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask));
+  *stream_out = (void *)s;
+  return 0;
+  PGNN_GUARD_END
+}
+
+extern "C" int pgnn_stream_destroy(void *stream) {
+  PGNN_GUARD_BEGIN
+  PGNN_REQUIRE(stream, PGNN_E_INVALID, "stream_destroy: null stream");
+  PGNN_HIP(hipStreamDestroy((hipStream_t)stream));
   return 0;
   PGNN_GUARD_END
 }
@@ -84,9 +148,9 @@ extern "C" int pgnn_set_tunable(const char *key, int value) {
     pgnn::g_mlp_debug = value;
     return 0;
   }
-  if (!strcmp(key, "mlp_chunks_per_wg")) {
-    if (value < 0 || value > 64) return PGNN_E_INVALID;
-    pgnn::g_mlp_chunks_per_wg = value;
+  if (!strcmp(key, "mlp_pool_pct")) {
+    if (value < 0 || value > 90) return PGNN_E_INVALID;
+    pgnn::g_mlp_pool_pct = value;
     return 0;
   }
   if (!strcmp(key, "graph_debug")) {

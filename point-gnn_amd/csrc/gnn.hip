@@ -18,7 +18,7 @@ namespace pgnn {
 int g_mlp_blocks_per_cu = 4;  // upper bound; LDS usually allows fewer
 int g_edge_msub = 0;          // 0 = auto, else force 16*msub-row tiles
 int g_pool_msub = 0;
-int g_mlp_chunks_per_wg = 5;  // dynamic tile scheduling; 0 = static ranges
+int g_mlp_pool_pct = 12;  // share of the row tiles handed out dynamically
 void *g_mlp_ts = nullptr;  // device buffer for per-tile timestamps (profiling)
 int g_mlp_debug = 0;  // ablation mask (benchmarks only): 1 = no gather loads,
                       // 2 = no last-layer GEMM, 4 = no epilogue, 16 = print
@@ -200,8 +200,8 @@ __global__ __launch_bounds__(256, 2) void fused_mlp_kernel(
     ChainDev chain, int64_t n_rows, RowsArgs ra, PoolArgs pa, EdgeArgs ea,
     SegArgs sa, int stage_off /* floats from tile base; < 0: in place */,
     int dbg, long long *ts /* optional per-tile timestamps (profiling) */,
-    int32_t *sched /* nullable: {next chunk, finished workgroups}, both 0 */,
-    int chunk_tiles) {
+    int32_t *sched /* nullable: {next pool tile, finished workgroups}, zero */,
+    int64_t n_static /* tiles below this index are partitioned statically */) {
   constexpr int ROWS = 16 * MSUB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int *dst = reinterpret_cast<int *>(smem);
@@ -217,43 +217,49 @@ __global__ __launch_bounds__(256, 2) void fused_mlp_kernel(
   const int64_t n_tiles = (n_rows + ROWS - 1) / ROWS;
   const int ld0 = lds_ld(16 * chain.l[0].kq);
 
-  // Tile ranges.  Static (sched == nullptr): one contiguous range per workgroup,
-  // remainder spread over the first ones.  Dynamic: chunks of `chunk_tiles`
-  // contiguous tiles handed out through an atomic counter -- workgroup b starts
-  // with chunk b, every further chunk is claimed while the current one is being
-  // processed (the atomic's round trip hides under a whole chunk).  A kernel of
-  // another stream holding LDS on some CU when this grid starts (the 2 x 80 KB
-  // tiles fill a CU's LDS exactly) then costs that CU's share of the chunks, not
-  // a whole second pass of the late workgroup; the same mechanism evens out
-  // tiles of different epilogue cost.  A chunk is treated like a workgroup
-  // range: the open segment is carried inside it and flushed atomically at its
-  // two ends.  The last workgroup to finish re-arms the two counters.
-  const int64_t tq = n_tiles / gridDim.x, trem = n_tiles % gridDim.x;
-  const int n_chunks =
-      sched ? (int)((n_tiles + chunk_tiles - 1) / chunk_tiles) : (int)gridDim.x;
-  __shared__ int s_next_chunk;
+  // Contiguous tile range per workgroup (remainder spread over the first ones)
+  // over the first n_static tiles; the tiles behind them form a POOL that the
+  // workgroups take one at a time through an atomic counter once their own
+  // range is done.  The static part keeps the cheap contiguous-range machinery
+  // (open segment carried from tile to tile, next tile's indices prefetched);
+  // the pool is the slack that absorbs a late start: these kernels fill every
+  // CU completely, so a workgroup of another stream's kernel that holds a CU
+  // when the grid starts delays one persistent workgroup by its whole duration
+  // -- with a purely static partition the kernel then ends that much later,
+  // with a pool the others pick up the difference, a tile (~30 us) at a time.
+  // A pool tile is a range of its own: nothing carried in or out, boundary
+  // runs flushed atomically.  sched == nullptr: everything static.
+  if (!sched) n_static = n_tiles;
+  const int64_t tq = n_static / gridDim.x, trem = n_static % gridDim.x;
+  const int64_t tile_first =
+      blockIdx.x * tq + (blockIdx.x < trem ? blockIdx.x : trem);
+  int64_t tile_last = tile_first + tq + (blockIdx.x < trem ? 1 : 0);
+  __shared__ int s_claim;
+  CarryState cs = {-1, 0};
   // prefetched (src, dst[, keypoint]) of the next tile's rows (EDGE / POOL)
   int nxt_s = 0, nxt_d = -1, nxt_k = 0;
-  for (int chunk = blockIdx.x; chunk < n_chunks;) {  // `chunk` stays in an SGPR
-  int claimed = n_chunks;
-  if (sched && threadIdx.x == 0)
-    claimed = (int)gridDim.x +
-              __hip_atomic_fetch_add(&sched[0], 1, __ATOMIC_RELAXED,
-                                     __HIP_MEMORY_SCOPE_AGENT);
-  const int64_t tile_first =
-      sched ? (int64_t)chunk * chunk_tiles
-            : chunk * tq + (chunk < trem ? chunk : trem);
-  int64_t tile_last = sched ? tile_first + chunk_tiles
-                            : tile_first + tq + (chunk < trem ? 1 : 0);
-  if (tile_last > n_tiles) tile_last = n_tiles;
-  CarryState cs = {-1, 0};
-  for (int64_t tile_id = tile_first; tile_id < tile_last; ++tile_id) {
+  bool fresh = true;  // first tile of a contiguous range: fetch its own indices
+  int tile_seq = 0;
+  for (int64_t tile_id = tile_first;; ++tile_id, ++tile_seq) {
+    if (tile_id >= tile_last) {  // wave-uniform
+      if (tile_id >= n_tiles || !sched) break;
+      if (threadIdx.x == 0)
+        s_claim = __hip_atomic_fetch_add(&sched[0], 1, __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      tile_id = n_static + __builtin_amdgcn_readfirstlane(s_claim);
+      if (tile_id >= n_tiles) break;
+      tile_last = tile_id + 1;
+      cs.id = -1;
+      cs.left_closed = 0;
+      fresh = true;
+    }
     const int64_t row0 = tile_id * ROWS;
     const int rows_valid =
         (int)((n_rows - row0 < ROWS) ? (n_rows - row0) : ROWS);
     long long *tsp = nullptr;
-    if (ts && tile_id - tile_first < 32 && threadIdx.x == 0) {
-      tsp = ts + ((int64_t)blockIdx.x * 32 + (tile_id - tile_first)) * 8;
+    if (ts && tile_seq < 32 && threadIdx.x == 0) {
+      tsp = ts + ((int64_t)blockIdx.x * 32 + tile_seq) * 8;
       tsp[0] = __builtin_readcyclecounter();
       tsp[3] = 0;
       tsp[6] = __builtin_amdgcn_s_memrealtime();  // constant 100 MHz
@@ -288,7 +294,7 @@ __global__ __launch_bounds__(256, 2) void fused_mlp_kernel(
         for (int i = 0; i < 16; ++i) f[i] = 0.0f;
         // (src, dst, keypoint) of this row were requested during the previous
         // tile (nxt_*): one global round trip here instead of three
-        if (tile_id == tile_first) {
+        if (fresh) {
           nxt_s = 0;
           nxt_d = -1;
           nxt_k = 0;
@@ -352,7 +358,7 @@ __global__ __launch_bounds__(256, 2) void fused_mlp_kernel(
       // in nxt_*), so the row gathers below start without a dependent index
       // round trip; the next tile's pair is requested now and lands during
       // this tile's gather + GEMM.
-      if (tile_id == tile_first) {
+      if (fresh) {
         nxt_s = 0;
         nxt_d = -1;
         if (lane < RPW && ebase + lane < n_rows) {
@@ -462,6 +468,7 @@ __global__ __launch_bounds__(256, 2) void fused_mlp_kernel(
     }
     __syncthreads();
     __builtin_amdgcn_s_setprio(0);
+    fresh = false;
     if (PRO == PRO_POOL && threadIdx.x < ROWS && nxt_d >= 0)
       nxt_k = pa.kp[nxt_d];  // second level of the next tile's index chain
     if (tsp) tsp[1] = __builtin_readcyclecounter();
@@ -560,17 +567,12 @@ __global__ __launch_bounds__(256, 2) void fused_mlp_kernel(
       }
     }
   }
-  if (!sched) break;  // static: the one range of this workgroup is done
-  // hand the claimed chunk to the whole workgroup (the previous value of
-  // s_next_chunk was read before at least one tile's barriers)
-  if (threadIdx.x == 0) s_next_chunk = claimed;
-  __syncthreads();
-  chunk = __builtin_amdgcn_readfirstlane(s_next_chunk);
-  }
   if (sched && threadIdx.x == 0) {
+    // the last workgroup to get here re-arms the two counters: every claim of
+    // this launch was consumed before its workgroup counted itself done
     const int done = __hip_atomic_fetch_add(&sched[1], 1, __ATOMIC_ACQ_REL,
                                             __HIP_MEMORY_SCOPE_AGENT);
-    if (done == (int)gridDim.x - 1) {  // every claim of this launch has landed
+    if (done == (int)gridDim.x - 1) {
       __hip_atomic_store(&sched[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&sched[1], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -669,19 +671,13 @@ int launch_fused(const Plan &p, int64_t n_rows, const RowsArgs &ra,
   int per_cu = (int)((160 * 1024) / lds);
   if (per_cu > g_mlp_blocks_per_cu) per_cu = g_mlp_blocks_per_cu;
   if (per_cu < 1) per_cu = 1;
-  int64_t grid = (int64_t)device_cu_count() * per_cu;
-  // dynamic scheduling: ~g_mlp_chunks_per_wg chunks per workgroup, 1..8 tiles
-  // each (long enough to amortise the per-chunk index round trip and the two
-  // atomic boundary flushes, short enough to even out the tail)
-  int chunk_tiles = 1;
-  if (g_mlp_ts || g_mlp_chunks_per_wg <= 0) sched = nullptr;
-  if (sched) {
-    int64_t ct = n_tiles / (grid * g_mlp_chunks_per_wg);
-    chunk_tiles = (int)(ct < 1 ? 1 : (ct > 8 ? 8 : ct));
-    const int64_t n_chunks = (n_tiles + chunk_tiles - 1) / chunk_tiles;
-    if (grid > n_chunks) grid = n_chunks;
-  }
+  int64_t grid = (int64_t)stream_cu_count(stream) * per_cu;
   if (grid > n_tiles) grid = n_tiles;
+  // tile pool (see the kernel): g_mlp_pool_pct % of the tiles, when every
+  // workgroup still keeps a static range of a few tiles
+  int64_t n_static = n_tiles;
+  if (g_mlp_ts || g_mlp_pool_pct <= 0 || n_tiles < 6 * grid) sched = nullptr;
+  if (sched) n_static = n_tiles - n_tiles * g_mlp_pool_pct / 100;
   const int stage_off = p.stage_cols ? ROWS * p.tile_floats_per_row : -1;
   if (g_mlp_debug & 16) {
     int nb = -1;
@@ -692,7 +688,7 @@ int launch_fused(const Plan &p, int64_t n_rows, const RowsArgs &ra,
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, stream, p.chain,
                      n_rows, ra, pa, ea, sa, stage_off, g_mlp_debug,
-                     (long long *)g_mlp_ts, sched, chunk_tiles);
+                     (long long *)g_mlp_ts, sched, n_static);
   PGNN_HIP(hipGetLastError());
   return 0;
 }

@@ -80,5 +80,6 @@ __device__ __forceinline__ void atomic_max_f32(float *addr, float v) {
 }
 
 int device_cu_count();
+int stream_cu_count(hipStream_t stream);
 
 }  // namespace pgnn

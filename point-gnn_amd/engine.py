@@ -52,7 +52,39 @@ class InferenceEngine(object):
         device -- run.py:219-222."""
         return self.graph_fn(xyz, **self.graph_kwargs)
 
-    def run_frames_pipelined(self, frames, compute_streams=1):
+    def _pipeline_streams(self, graph_cus):
+        """(graph stream, [compute streams]).  graph_cus > 0: the graph stream
+        (and the aux stream its kd-tree build forks onto) may only use CUs
+        [0, graph_cus) -- mask bits are striped over the XCDs, so that is
+        graph_cus / 8 CUs of every XCD -- and the compute streams only the
+        others (pgnn_stream_create_cu_mask); 0: ordinary streams sharing the
+        whole device."""
+        key = int(graph_cus)
+        cache = self.__dict__.setdefault("_stream_sets", {})
+        if key in cache:
+            return cache[key]
+        if key <= 0:
+            streams = [torch.cuda.Stream() for _ in range(5)]
+            cache[key] = (streams[0], streams[1:])
+            return cache[key]
+        import ctypes
+        from . import _lib
+        lib = _lib.load()
+        dev = torch.device("cuda", torch.cuda.current_device())
+
+        def make(complement):
+            p = ctypes.c_void_p()
+            _lib.check(lib.pgnn_stream_create_cu_mask(
+                0, key, complement, ctypes.byref(p)),
+                "pgnn_stream_create_cu_mask")
+            return torch.cuda.ExternalStream(p.value, device=dev)
+        sg, aux = make(0), make(0)
+        graph_gen._AUX_STREAMS[(dev.index, sg.cuda_stream)] = aux
+        cache[key] = (sg, [make(1) for _ in range(4)])
+        return cache[key]
+
+    def run_frames_pipelined(self, frames, compute_streams=1, graph_cus=0,
+                             lookahead=0):
         """Steady-state loop over independent frames on HIP streams: while a
         compute stream executes the GNN of frame i, stream G builds the graph
         of frame i+1.  The graph builder needs three host reads per frame (K,
@@ -61,6 +93,8 @@ class InferenceEngine(object):
         With compute_streams = 2 consecutive frames alternate between two
         compute streams, so the under-filled per-vertex kernels and the tail
         of one frame's edge kernel overlap the next frame's work.
+        graph_cus > 0 gives stream G that many CUs of its own and keeps the
+        compute streams off them (see _pipeline_streams).
         frames: iterable of (xyz, intensity) CUDA tensors.  Returns the list of
         (logits, box_encodings); outputs are complete after
         torch.cuda.synchronize() (or a wait on the compute streams)."""
@@ -75,10 +109,8 @@ class InferenceEngine(object):
             self.run_frame(*frames[0])
             self.frame_shapes.pop()
             self._warm = True
-        if not hasattr(self, "_streams"):
-            self._streams = tuple(torch.cuda.Stream() for _ in range(5))
-        sg = self._streams[0]
-        scs = self._streams[1:1 + max(1, min(4, int(compute_streams)))]
+        sg, scs = self._pipeline_streams(graph_cus)
+        scs = scs[:max(1, min(4, int(compute_streams)))]
         cur = torch.cuda.current_stream()
         for s in (sg,) + tuple(scs):
             s.wait_stream(cur)
@@ -90,21 +122,64 @@ class InferenceEngine(object):
                 ev.record(sg)
             return g, ev
 
+        # lookahead > 0: graphs come from a builder thread that runs up to
+        # that many frames ahead, so the three count reads block only that
+        # thread.  Measured: no gain over lookahead = 0 (the
+        # calling thread builds graph i+1 right after enqueueing frame i; its
+        # reads complete long before frame i's message passing does), so 0 is
+        # the default.
+        ready = None
+        worker = None
+        if lookahead > 0 and len(frames) > 1:
+            import queue
+            import threading
+            ready = queue.Queue(maxsize=int(lookahead))
+            dev_index = torch.cuda.current_device()
+
+            def produce():
+                try:
+                    torch.cuda.set_device(dev_index)
+                    for j in range(len(frames)):
+                        ready.put(build(j))
+                except BaseException as exc:  # re-raised by the consumer
+                    ready.put(exc)
+            worker = threading.Thread(target=produce, daemon=True)
+            worker.start()
+
+        def next_graph(i):
+            if ready is None:
+                return build(i)
+            item = ready.get()
+            if isinstance(item, BaseException):
+                raise item
+            return item
+
         outs = []
-        graph, ev = build(0)
-        for i in range(len(frames)):
-            sc = scs[i % len(scs)]
-            sc.wait_event(ev)
-            with torch.cuda.stream(sc):
-                coords, kps, edges = graph
-                for t in list(coords) + list(kps) + list(edges):
-                    t.record_stream(sc)  # allocated on G, consumed on C
-                outs.append(self.model.predict(frames[i][1], coords, kps,
-                                               edges, is_training=False))
-            self.last_graph = graph
-            self._note_shape(graph)
-            if i + 1 < len(frames):
-                graph, ev = build(i + 1)
+        try:
+            graph, ev = next_graph(0)
+            for i in range(len(frames)):
+                sc = scs[i % len(scs)]
+                sc.wait_event(ev)
+                with torch.cuda.stream(sc):
+                    coords, kps, edges = graph
+                    for t in list(coords) + list(kps) + list(edges):
+                        t.record_stream(sc)  # allocated on G, consumed on C
+                    outs.append(self.model.predict(frames[i][1], coords, kps,
+                                                   edges, is_training=False))
+                self.last_graph = graph
+                self._note_shape(graph)
+                if i + 1 < len(frames):
+                    graph, ev = next_graph(i + 1)
+        finally:
+            if worker is not None:
+                # drain so that a failing consumer cannot leave the builder
+                # blocked on a full queue
+                while worker.is_alive():
+                    try:
+                        ready.get(timeout=0.05)
+                    except Exception:
+                        pass
+                worker.join()
         for s in scs:
             cur.wait_stream(s)
         return outs

@@ -569,16 +569,18 @@ def test_segmax_epilogue_paths_are_bit_identical(dev, layer):
     for bits in (32, 128, 32 | 128):
         assert np.array_equal(outs[0], outs[bits]), bits
     np.testing.assert_allclose(outs[0][:, :300], ref, atol=FP_TOL, rtol=1e-4)
-    # tile scheduling: static ranges (0), the default chunking, one-tile chunks
-    # (64: every tile boundary flushes atomically) -- same bits, and the two
-    # scheduling counters come back zeroed every time
+
+
+    # tile scheduling: everything static (0), the default pool, most tiles from
+    # the pool (each a range of its own: boundary runs flushed atomically) --
+    # same bits, and the two scheduling counters come back zeroed every time
     try:
-        for chunks in (0, 1, 64):
-            _lib.set_tunable("mlp_chunks_per_wg", chunks)
-            assert np.array_equal(run(), outs[0]), chunks
+        for pct in (0, 12, 90):
+            _lib.set_tunable("mlp_pool_pct", pct)
+            assert np.array_equal(run(), outs[0]), pct
             assert int(_lib.sched_ws(dev).abs().sum().item()) == 0
     finally:
-        _lib.set_tunable("mlp_chunks_per_wg", 5)
+        _lib.set_tunable("mlp_pool_pct", 12)
 
 
 @pytest.mark.parametrize("auto_offset,k", [(True, 1000), (False, 37), (True, 16)])
@@ -822,8 +824,8 @@ def test_large_scan_edges_equal_oracle(dev, name):
 
 def test_pipelined_frames_equal_sequential(dev):
     """The multi-stream schedules (engine.run_frames_pipelined, one or two
-    GNN streams) must return bit-identical results to frame-at-a-time
-    execution."""
+    GNN streams, shared device or CU-partitioned streams) must return
+    bit-identical results to frame-at-a-time execution."""
     import torch
     from pointgnn_amd.engine import InferenceEngine
     cfg = configs.car_auto_config(2)
@@ -835,8 +837,12 @@ def test_pipelined_frames_equal_sequential(dev):
         frames.append((T(xyz, dev), T(inten, dev)))
     seq = [eng.run_frame(x, f) for x, f in frames]
     torch.cuda.synchronize()
-    for rep in range(4):
-        pip = eng.run_frames_pipelined(frames, compute_streams=1 + rep % 2)
+    for rep in range(6):
+        # reps 4, 5: graph stream on 16 reserved CUs, GNN streams on the rest
+        # and every second round without the builder thread
+        pip = eng.run_frames_pipelined(frames, compute_streams=1 + rep % 2,
+                                       graph_cus=16 if rep >= 4 else 0,
+                                       lookahead=2 * (rep // 2 % 2))
         torch.cuda.synchronize()
         assert len(pip) == len(seq)
         for (l0, b0), (l1, b1) in zip(seq, pip):
