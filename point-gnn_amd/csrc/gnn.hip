@@ -24,13 +24,21 @@ int g_mlp_debug = 0;  // ablation mask (benchmarks only): 1 = no gather loads,
                       // 2 = no last-layer GEMM, 4 = no epilogue, 16 = print
                       // occupancy, 32 = no one-segment fast path, 64 = no
                       // prologue priority, 128 = no few-runs register epilogue,
-                      // 512 = 4-wave kernel for small rows
+                      // 512 = 4-wave kernel for small rows, 1024 = pooling's
+                      // hidden layers through the LDS tile (not registers)
 }
 
 namespace {
 using namespace pgnn;
 
-enum { PRO_ROWS = 0, PRO_POOL = 1, PRO_EDGE = 2 };
+enum { PRO_ROWS = 0, PRO_POOL = 1, PRO_EDGE = 2,
+       // PRO_POOL with the hidden layers in registers (mlp_engine.h RegChain):
+       // hidden column tiles 2-4-8 = car's 32-64-128.  (ped's 32-64-128-256
+       // chain would fit the same scheme, but its 512-wide last layer needs
+       // the 32-row tile, where only two waves own rows.)
+       PRO_POOL_R3 = 3 };
+constexpr bool is_pool(int pro) { return pro == PRO_POOL || pro == PRO_POOL_R3; }
+constexpr bool is_pool_reg(int pro) { return pro == PRO_POOL_R3; }
 // tiles with at most this many runs of equal dst reduce in registers
 // (layer_pass_segmax_runs); more runs go through the LDS stage
 constexpr int kMaxRegisterRuns = 6;
@@ -53,6 +61,8 @@ struct PoolArgs {
   const float *xyz;
   const int32_t *kp;
   const int32_t *edges;
+  int reg_hidden;  // 0: hidden layers through the LDS tile; 1: 2-4-8 column
+                   // tiles in registers (mlp_engine.h RegChain)
 };
 struct EdgeArgs {
   const float *P;
@@ -272,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void fused_mlp_kernel(
     // hundred issue slots and gets this workgroup back to the matrix pipe
     // sooner; priority returns to 0 before the MFMA loop.
     if (!(dbg & 64)) __builtin_amdgcn_s_setprio(3);
-    if (PRO == PRO_ROWS) {
+    if constexpr (PRO == PRO_ROWS) {
       const int kc = 16 * chain.l[0].kq;
       for (int idx = threadIdx.x; idx < ROWS * kc; idx += 256) {
         const int r = idx / kc, c = idx - r * kc;
@@ -285,7 +295,62 @@ __global__ __launch_bounds__(256, 2) void fused_mlp_kernel(
         }
         tile[r * ld0 + c] = v;
       }
-    } else if (PRO == PRO_POOL) {  // first layer has kq == 1 (checked on host)
+    } else if constexpr (is_pool_reg(PRO)) {
+      // wave w owns rows 16w .. 16w+15; lane (g, n) holds input features
+      // 4g .. 4g+3 of row 16w + n, which IS the B operand of the first layer
+      const int g = lane >> 4;
+      const int r = 16 * wave + (lane & 15);
+      const int64_t e = row0 + r;
+      if (fresh) {
+        nxt_s = 0;
+        nxt_d = -1;
+        nxt_k = 0;
+        if (e < n_rows) {
+          nxt_s = pa.edges[2 * e];
+          nxt_d = pa.edges[2 * e + 1];
+          nxt_k = pa.kp[nxt_d];
+        }
+      }
+      const int s_ = nxt_s, d_ = nxt_d, k_ = nxt_k;
+      v4f x[1];
+      x[0] = (v4f){0.f, 0.f, 0.f, 0.f};
+      if (e < n_rows) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int c = 4 * g + i;  // input column
+          float v = 0.0f;
+          if (c < pa.nfeat) {
+            v = pa.feat[(int64_t)s_ * pa.nfeat + c];
+          } else if (c < pa.nfeat + 3) {
+            // points within a set use coordinates relative to its keypoint
+            const int a = c - pa.nfeat;
+            v = pa.xyz[3 * (int64_t)s_ + a] - pa.xyz[3 * (int64_t)k_ + a];
+          }
+          x[0][i] = v;
+        }
+      }
+      if (g == 0) dst[r + 1] = e < n_rows ? d_ : -1;
+      nxt_s = 0;
+      nxt_d = -1;
+      nxt_k = 0;
+      if (e + ROWS < n_rows && tile_id + 1 < tile_last) {
+        nxt_s = pa.edges[2 * (e + ROWS)];
+        nxt_d = pa.edges[2 * (e + ROWS) + 1];
+      }
+      if (threadIdx.x == 64)
+        dst[0] = row0 > 0 ? pa.edges[2 * (row0 - 1) + 1] : -1;
+      if (threadIdx.x == 65)
+        dst[ROWS + 1] =
+            row0 + ROWS < n_rows ? pa.edges[2 * (row0 + ROWS) + 1] : -1;
+      __builtin_amdgcn_s_setprio(0);  // the MFMA chain below is not a prologue
+      const int ld_last = lds_ld(16 * chain.l[chain.n - 1].kq);
+      float *rows16 = tile + 16 * wave * ld_last;
+      // keep the compiler from hoisting the last layer's weight prefetch over
+      // the chain (it spills otherwise: both want ~150 VGPRs)
+      __builtin_amdgcn_sched_barrier(0);
+      RegChain<1, 2, 4, 8>::run(chain, 0, lane, x, rows16, ld_last);
+      __builtin_amdgcn_sched_barrier(0);
+    } else if constexpr (PRO == PRO_POOL) {  // first layer has kq == 1 (host check)
       if (threadIdx.x < ROWS) {
         const int r = threadIdx.x;
         const int64_t e = row0 + r;
@@ -469,11 +534,12 @@ __global__ __launch_bounds__(256, 2) void fused_mlp_kernel(
     __syncthreads();
     __builtin_amdgcn_s_setprio(0);
     fresh = false;
-    if (PRO == PRO_POOL && threadIdx.x < ROWS && nxt_d >= 0)
+    if (is_pool(PRO) && (threadIdx.x < ROWS || is_pool_reg(PRO)) && nxt_d >= 0)
       nxt_k = pa.kp[nxt_d];  // second level of the next tile's index chain
     if (tsp) tsp[1] = __builtin_readcyclecounter();
     // ------------------------------------------------------------ hidden layers
-    for (int li = 0; li + 1 < chain.n; ++li) {
+    constexpr bool hidden_done = is_pool_reg(PRO);
+    for (int li = 0; li + 1 < chain.n && !hidden_done; ++li) {
       const LayerDev &L = chain.l[li];
       layer_pass_dispatch<MSUB, false>(tile, lds_ld(16 * L.kq), tile,
                                        lds_ld(16 * L.nt), L, 0, wave, lane);
@@ -505,7 +571,7 @@ __global__ __launch_bounds__(256, 2) void fused_mlp_kernel(
         } else if (sa.sorted && !(dbg & (2 | 4 | 32)) && dst[1] >= 0 &&
                    dst[1] < sa.num_segments && dst[1] == dst[ROWS]) {
           // whole tile = one run of one segment: reduce in registers
-          if (tsp && PRO == PRO_POOL) tsp[3] = 1;
+          if (tsp && is_pool(PRO)) tsp[3] = 1;
           const int d = dst[1];
           const bool merge = cs.id == d;
           const bool left_closed = merge ? cs.left_closed != 0 : dst[0] != d;
@@ -525,7 +591,7 @@ __global__ __launch_bounds__(256, 2) void fused_mlp_kernel(
         } else if (sa.sorted && !(dbg & (2 | 4 | 32 | 128)) &&
                    __builtin_popcountll(starts) <= kMaxRegisterRuns) {
           // a few runs: masked column maxima straight from the accumulators
-          if (tsp && PRO == PRO_POOL) tsp[3] = 2;
+          if (tsp && is_pool(PRO)) tsp[3] = 2;
           SegRuns sr;
           sr.starts = starts;
           sr.myd = myd;
@@ -832,13 +898,24 @@ extern "C" int pgnn_point_set_pooling_fwd(
                    keypoint_indices && edges,
                PGNN_E_INVALID, "pooling: null input");
   RowsArgs ra = {};
-  PoolArgs pa = {point_features, n_feat, point_xyz, keypoint_indices, edges};
+  PoolArgs pa = {point_features, n_feat, point_xyz, keypoint_indices, edges, 0};
   EdgeArgs ea = {};
   SegArgs sa = {out, ld_out, num_keypoints, edges_sorted};
   int msub = g_pool_msub;
   if (msub != 2 && msub != 4)
     msub = (plan_lds_bytes(p, 64) <= 80 * 1024 ||
             plan_lds_bytes(p, 32) > 80 * 1024) ? 4 : 2;
+  // hidden layers in registers when their widths are car's 32-64-128 and the
+  // tile has 64 rows; anything else takes the LDS tile
+  if (msub == 4 && !(g_mlp_debug & 1024)) {
+    const ChainDev &c = p.chain;
+    auto nts = [&](int i) { return c.l[i].nt; };
+    if (c.n == 4 && nts(0) == 2 && nts(1) == 4 && nts(2) == 8)
+      pa.reg_hidden = 1;
+  }
+  if (msub == 4 && pa.reg_hidden == 1)
+    return launch_fused<4, PRO_POOL_R3>(p, n_edges, ra, pa, ea, sa, stream,
+                                        sched_ws);
   if (msub == 4)
     return launch_fused<4, PRO_POOL>(p, n_edges, ra, pa, ea, sa, stream,
                                      sched_ws);

@@ -569,6 +569,112 @@ __device__ __forceinline__ bool layer_pass_segmax_fast_auto(
   return false;
 }
 
+// ---------------------------------------------------------------------------
+// Hidden layers of a narrow chain kept in REGISTERS (PointSetPooling's point
+// MLP 4 -> 32 -> 64 -> 128 before its wide last layer).  The LDS-tile scheme
+// above splits the N dimension over the four waves; with 2 / 4 / 8 column
+// tiles that leaves waves idle and still pays two workgroup barriers and an
+// LDS round trip per layer.  Here every wave owns 16 rows of the tile and
+// computes the TRANSPOSED product  H'^T = W^T H^T : the weights are the MFMA
+// A operand, the activations the B operand.  The 16x16x4 MFMA's C/D layout
+// (lane (g, n), register r  <->  output feature 16t + 4g + r, row n) is
+// exactly the B-operand layout of the next layer's K-group t, k-step r -- and
+// the host-packed weight fragment packed[((q nt + t) 64 + lane) 4 + s] =
+// W[16q + 4(lane>>4) + s][16t + (lane&15)] is exactly the A operand -- so a
+// layer's accumulators, after bias + ReLU in place, ARE the next layer's
+// operand registers: no barrier, no LDS, no shuffles between the layers, all
+// four waves busy.  Every output element sees the same sequence of (K-group,
+// k-step) MFMA updates as in gemm_tile, with the same four products each, so
+// the values are those of the LDS path (tested bit for bit).  The price is
+// that each wave streams ALL weights of these layers (42 KB for 4-32-64-128)
+// instead of a quarter -- small next to the last layer's 156 KB per tile.
+template <int KQ, int NT>
+__device__ __forceinline__ void reg_layer(const LayerDev &L, int lane,
+                                          const v4f (&in)[KQ], v4f (&out)[NT]) {
+  // An opaque zero keeps the fragment addresses from being hoisted out of the
+  // caller's tile loop: loop-invariant as they are, LLVM otherwise carries one
+  // precomputed address per fragment (42+) across the whole loop and spills.
+  int zero;
+  asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
+  const v4f *__restrict__ wp =
+      reinterpret_cast<const v4f *>(L.wp) + lane + zero;
+  const float *bias = L.wp + (size_t)KQ * NT * 256 + zero;
+  const int g4 = 4 * (lane >> 4);
+  // column tiles in blocks of <= 8: two stages of 8 weight fragments (64
+  // VGPRs) in flight, whatever the layer width
+  constexpr int TB = NT < 8 ? NT : 8;
+  static_assert(NT % TB == 0, "column tiles come in blocks");
+#pragma unroll
+  for (int t0 = 0; t0 < NT; t0 += TB) {
+    v4f w[2][TB];
+#pragma unroll
+    for (int j = 0; j < TB; ++j) {
+      out[t0 + j] = (v4f){0.f, 0.f, 0.f, 0.f};
+      w[0][j] = wp[(size_t)(t0 + j) * 64];
+    }
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+      if (q + 1 < KQ) {
+#pragma unroll
+        for (int j = 0; j < TB; ++j)
+          w[(q + 1) & 1][j] = wp[((size_t)(q + 1) * NT + t0 + j) * 64];
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int j = 0; j < TB; ++j)
+          out[t0 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+              w[q & 1][j][s], in[q][s], out[t0 + j], 0, 0, 0);
+      // one K-group of weight prefetch in flight, no more: left alone, the
+      // scheduler hoists the (address-independent) loads of ALL layers to the
+      // top and spills
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int j = 0; j < TB; ++j) {
+      const int t = t0 + j;
+      const v4f b = *reinterpret_cast<const v4f *>(bias + 16 * t + g4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = out[t][r] + b[r];
+        if (16 * t + g4 + r >= L.relu_from) v = v > 0.0f ? v : 0.0f;
+        out[t][r] = v;
+      }
+    }
+  }
+}
+
+// chain.l[li], chain.l[li+1], ... with NTS... column tiles each, then the rows
+// go to the LDS tile (row-major, leading dimension ld) for the wide last layer
+template <int KQ, int... NTS>
+struct RegChain;
+
+template <int KQ>
+struct RegChain<KQ> {
+  static __device__ __forceinline__ void run(const ChainDev &, int, int lane,
+                                             const v4f (&in)[KQ],
+                                             float *__restrict__ rows16,
+                                             int ld) {
+    // lane (g, n): row n, columns 16q + 4g .. 16q + 4g + 3 -- the mapping of
+    // gemm_tile's A-fragment reads, conflict-free for ld = 8 mod 16
+    float *o = rows16 + (lane & 15) * ld + 4 * (lane >> 4);
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) *reinterpret_cast<v4f *>(o + 16 * q) = in[q];
+  }
+};
+
+template <int KQ, int NT, int... REST>
+struct RegChain<KQ, NT, REST...> {
+  static __device__ __forceinline__ void run(const ChainDev &chain, int li,
+                                             int lane, const v4f (&in)[KQ],
+                                             float *__restrict__ rows16,
+                                             int ld) {
+    v4f out[NT];
+    reg_layer<KQ, NT>(chain.l[li], lane, in, out);
+    RegChain<NT, REST...>::run(chain, li + 1, lane, out, rows16, ld);
+  }
+};
+
 // One pass (<= 320 output columns starting at column tile t0) of layer L:
 // GEMM from `in`, barrier, activated store to `out` (may alias `in`), barrier.
 template <int MSUB, int NT, bool TRANSPOSED, int NW = 4>

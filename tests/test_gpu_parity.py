@@ -487,6 +487,53 @@ def test_point_set_pooling_layer(dev, shuffle):
     assert np.all(out[:, 300:] == 0)
 
 
+@pytest.mark.parametrize("name", ["car_auto_T3", "ped_cyl_auto_T3"])
+@pytest.mark.parametrize("shuffle", [False, True])
+def test_pooling_hidden_layers_in_registers_are_bit_identical(dev, name,
+                                                              shuffle):
+    """PointSetPooling's point MLP keeps its hidden layers in registers
+    (transposed MFMA chain: a layer's accumulators are the next layer's
+    operands; car's 4-32-64-128|300 -- ped's chain runs on 32-row tiles and
+    stays on the LDS path, so its two runs are the same kernel).  Every output
+    element sees the same MFMA update sequence as through the LDS tile
+    (`mlp_debug` bit 1024 switches the register form off): identical bits, on
+    fan-ins 1..300, sorted and foreign edge lists, and within tolerance of the
+    float64 oracle."""
+    from pointgnn_amd import _lib, gnn
+    rng = np.random.default_rng(8)
+    k, n_pts = 500, 4000
+    deg = rng.choice([1, 2, 3, 7, 40, 64, 65, 130, 300], size=k)
+    dst = np.repeat(np.arange(k), deg).astype(np.int32)
+    src = rng.integers(0, n_pts, dst.shape[0]).astype(np.int32)
+    edges = np.stack([src, dst], axis=1)
+    if shuffle:
+        edges = edges[rng.permutation(len(edges))]
+    xyz = rng.standard_normal((n_pts, 3)).astype(np.float32)
+    inten = rng.random((n_pts, 1)).astype(np.float32)
+    kp = rng.choice(n_pts, k, replace=False).astype(np.int32).reshape(-1, 1)
+    cfg = configs.get_config(name)
+    params = weights.init_params(cfg, seed=2, bias_scale=0.1)
+    store = _store(params, dev)
+    kw = cfg["model_kwargs"]["layer_configs"][0]["kwargs"]
+    width = kw["output_MLP_depth_list"][-1]
+
+    def run():
+        with gnn.parameters(store), gnn.variable_scope("layer1"):
+            return gnn.PointSetPooling().apply_regular(
+                T(inten, dev), T(xyz, dev), T(kp, dev), T(edges, dev),
+                **kw).cpu().numpy()
+    try:
+        _lib.set_tunable("mlp_debug", 1024)
+        lds = run()
+    finally:
+        _lib.set_tunable("mlp_debug", 0)
+    reg = run()
+    assert np.array_equal(reg, lds)
+    ref = gn.point_set_pooling(params, "layer1", inten, xyz, kp, edges,
+                               dtype=np.float64)
+    np.testing.assert_allclose(reg[:, :width], ref, atol=FP_TOL, rtol=1e-4)
+
+
 @pytest.mark.parametrize("auto_offset,shuffle", [(True, False), (False, False),
                                                  (True, True)])
 def test_graphnet_auto_center_layer(dev, auto_offset, shuffle):
