@@ -13,19 +13,25 @@
 //                   boundary runs use float atomic-max.
 // The E x C activations never reach HBM.
 #include "mlp_engine.h"
+#include "edge_ws.h"
 
 namespace pgnn {
 int g_mlp_blocks_per_cu = 4;  // upper bound; LDS usually allows fewer
 int g_edge_msub = 0;          // 0 = auto, else force 16*msub-row tiles
 int g_pool_msub = 0;
 int g_mlp_pool_pct = 12;  // share of the row tiles handed out dynamically
+int g_ws_xcds = 8;        // edge_ws.h: row slices (8 = one per XCD, 1 = none)
+int g_ws_prio = 0;        // edge_ws.h: static priority for waves 4..7
 void *g_mlp_ts = nullptr;  // device buffer for per-tile timestamps (profiling)
 int g_mlp_debug = 0;  // ablation mask (benchmarks only): 1 = no gather loads,
                       // 2 = no last-layer GEMM, 4 = no epilogue, 16 = print
                       // occupancy, 32 = no one-segment fast path, 64 = no
                       // prologue priority, 128 = no few-runs register epilogue,
                       // 512 = 4-wave kernel for small rows, 1024 = pooling's
-                      // hidden layers through the LDS tile (not registers)
+                      // hidden layers through the LDS tile (not registers),
+                      // 2048 = edge stage always on the LDS-tile kernel,
+                      // 4096 = ... always on the weights-stationary kernel
+                      // (edge_ws.h) when the layer shape allows
 }
 
 namespace {
@@ -831,6 +837,81 @@ int launch_rows8(const Plan &p, int64_t n_rows, const RowsArgs &ra,
   return 0;
 }
 
+// Weights-stationary edge kernel (edge_ws.h): one workgroup per CU, the column
+// tiles in groups that fit the LDS, the 16-row tiles in one slice per XCD.
+template <int KQ, int NTMAX>
+int launch_edge_ws(const LayerDev &L, const EdgeArgs &ea, int64_t n_edges,
+                   const SegArgs &sa, int cus, hipStream_t stream) {
+  EdgeWsArgs a = {};
+  a.P = ea.P;
+  a.Q = ea.Q;
+  a.ldv4 = (int)(ea.ldpq >> 2);
+  a.edges = ea.edges;
+  a.n_edges = n_edges;
+  a.wp = L.wp;
+  a.nt = L.nt;
+  a.relu_from = L.relu_from;
+  a.out = sa.out;
+  a.ldo = sa.ldo;
+  a.num_segments = sa.num_segments;
+  a.sorted = sa.sorted;
+  a.xcds = (g_ws_xcds >= 1 && cus % g_ws_xcds == 0) ? g_ws_xcds : 8;
+  a.prio = g_ws_prio;
+  a.ts = (long long *)g_mlp_ts;
+  a.groups = (L.nt + NTMAX - 1) / NTMAX;
+  const int per_slice = cus / a.xcds;
+  PGNN_REQUIRE(a.groups <= kWsMaxGroups && per_slice >= a.groups,
+               PGNN_E_UNSUPPORTED, "edge_ws: too few CUs for the column groups");
+  // column tiles as evenly as possible (C = 300: 7/6/6, C = 256: 8/8) and the
+  // slice's workgroups in proportion (largest remainder)
+  const int base = L.nt / a.groups, extra = L.nt % a.groups;
+  int size[kWsMaxGroups], cnt[kWsMaxGroups], frac[kWsMaxGroups], used = 0;
+  a.tile0[0] = 0;
+  for (int g = 0; g < a.groups; ++g) {
+    size[g] = base + (g < extra ? 1 : 0);
+    a.tile0[g + 1] = a.tile0[g] + size[g];
+    cnt[g] = per_slice * size[g] / L.nt;
+    if (cnt[g] < 1) cnt[g] = 1;
+    frac[g] = per_slice * size[g] % L.nt;
+    used += cnt[g];
+  }
+  PGNN_REQUIRE(base >= NTMAX - 1 && base + (extra ? 1 : 0) <= NTMAX &&
+                   used <= per_slice,
+               PGNN_E_UNSUPPORTED, "edge_ws: column tiles do not group");
+  while (used < per_slice) {
+    int best = 0;
+    for (int g = 1; g < a.groups; ++g)
+      if (frac[g] > frac[best]) best = g;
+    ++cnt[best];
+    frac[best] = -1;
+    ++used;
+  }
+  a.wg0[0] = 0;
+  for (int g = 0; g < a.groups; ++g) a.wg0[g + 1] = a.wg0[g] + cnt[g];
+  const size_t lds = (size_t)KQ * NTMAX * 1024;
+  auto kern = edge_ws_kernel<KQ, NTMAX>;
+  PGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                               hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)lds));
+  hipLaunchKernelGGL(kern, dim3((unsigned)(per_slice * a.xcds)),
+                     dim3(64 * kWsWaves), lds, stream, a);
+  PGNN_HIP(hipGetLastError());
+  return 0;
+}
+
+// the shapes edge_ws.h is instantiated for: one square layer of 19 (C = 300)
+// or 16 (C = 256) column tiles, a CU count that splits into 8 slices
+bool edge_ws_applies(const Plan &p, int64_t n_edges, int cus) {
+  if (g_mlp_debug & 2048) return false;
+  const LayerDev &L = p.chain.l[0];
+  if (p.chain.n != 1 || L.kq != L.nt || (L.nt != 19 && L.nt != 16)) return false;
+  if (cus < 64 || cus % 8 != 0) return false;
+  if (g_mlp_debug & 4096) return true;
+  // below ~2 tiles per wave the fixed cost (133 KiB of weights per workgroup
+  // into LDS) is not amortised
+  return n_edges >= (int64_t)16 * 2 * kWsWaves * cus;
+}
+
 int fill_lowest(float *out, int64_t count, hipStream_t stream) {
   PGNN_HIP(hipMemsetD32Async((hipDeviceptr_t)out, (int)kFloatLowestBits,
                              (size_t)count, stream));
@@ -953,6 +1034,14 @@ extern "C" int pgnn_edge_mlp_scatter_max_fwd(
   PoolArgs pa = {};
   EdgeArgs ea = {P, Q, ld_pq, edges};
   SegArgs sa = {out, ld_out, num_vertices, edges_sorted & 1};
+  {
+    const int cus = stream_cu_count(stream);
+    if (edge_ws_applies(p, n_edges, cus)) {
+      if (p.chain.l[0].nt == 19)
+        return launch_edge_ws<19, 7>(p.chain.l[0], ea, n_edges, sa, cus, stream);
+      return launch_edge_ws<16, 8>(p.chain.l[0], ea, n_edges, sa, cus, stream);
+    }
+  }
   int msub = g_edge_msub;
   if (msub != 2 && msub != 4)
     msub = (plan_lds_bytes(p, 64) <= 80 * 1024 ||

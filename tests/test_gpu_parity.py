@@ -630,6 +630,70 @@ def test_segmax_epilogue_paths_are_bit_identical(dev, layer):
         _lib.set_tunable("mlp_pool_pct", 12)
 
 
+@pytest.mark.parametrize("name", ["car_auto_T3", "ped_cyl_auto_T3"])
+@pytest.mark.parametrize("case", ["fanins", "shuffled", "ragged", "five_edges",
+                                  "one_segment"])
+def test_edge_weights_stationary_kernel_is_bit_identical(dev, name, case):
+    """The edge stage has two kernels: the LDS-tile kernel (activation tile in
+    LDS, weights streamed from L2) and the weights-stationary kernel
+    (csrc/edge_ws.h: a third / half of the layer's weights resident in LDS per
+    workgroup, activations in registers, transposed MFMA, per-lane running
+    max).  Every output element sees the same MFMA update sequence in both,
+    so `mlp_debug` 2048 (tile kernel) and 4096 (weights-stationary, forced
+    also below its size threshold) must agree bit for bit -- on fan-ins
+    1..300, foreign (unsorted) edge lists, edge counts that are not a
+    multiple of 16, fewer 16-row tiles than waves, one segment spanning every
+    wave's range -- and match the float64 oracle."""
+    from pointgnn_amd import _lib, gnn
+    rng = np.random.default_rng(11)
+    cfg = configs.get_config(name)
+    kw = cfg["model_kwargs"]["layer_configs"][1]["kwargs"]
+    c = kw["edge_MLP_depth_list"][-1]
+    cp = 16 * ((c + 15) // 16)
+    k = 700
+    if case == "five_edges":
+        dst = np.array([3, 3, 3, 9, 600], np.int32)
+    elif case == "one_segment":
+        dst = np.full(70001, 5, np.int32)
+    else:
+        deg = rng.choice([1, 2, 3, 5, 9, 16, 17, 40, 64, 65, 130, 300], size=k)
+        dst = np.repeat(np.arange(k), deg).astype(np.int32)
+        if case == "ragged":
+            dst = dst[:len(dst) - len(dst) % 16 - 3]
+    src = rng.integers(0, k, dst.shape[0]).astype(np.int32)
+    edges = np.stack([src, dst], axis=1)
+    if case == "shuffled":
+        edges = edges[rng.permutation(len(edges))]
+    xyz = rng.standard_normal((k, 3)).astype(np.float32)
+    h = np.zeros((k, cp), np.float32)
+    h[:, :c] = rng.standard_normal((k, c)).astype(np.float32)
+    params = weights.init_params(cfg, seed=6, bias_scale=0.1)
+    store = _store(params, dev)
+
+    def run():
+        with gnn.parameters(store), gnn.variable_scope("layer2"):
+            return gnn.GraphNetAutoCenter().apply_regular(
+                T(h, dev), T(xyz, dev), None, T(edges, dev),
+                **kw).cpu().numpy()
+    outs = {}
+    try:
+        for bits in (2048, 4096, 0):
+            _lib.set_tunable("mlp_debug", bits)
+            outs[bits] = run()
+    finally:
+        _lib.set_tunable("mlp_debug", 0)
+    # (vertices without edges aggregate to float lowest() as in TF; the update
+    # MLP then overflows identically in both kernels: compare with equal_nan)
+    assert np.array_equal(outs[2048], outs[4096], equal_nan=True)
+    assert np.array_equal(outs[2048], outs[0], equal_nan=True)
+    with np.errstate(all="ignore"):
+        ref = gn.graphnet_auto_center(params, "layer2", h[:, :c], xyz, edges,
+                                      auto_offset=True, dtype=np.float64)
+    fed = np.unique(dst)
+    np.testing.assert_allclose(outs[4096][fed, :c], ref[fed], atol=FP_TOL,
+                               rtol=1e-4)
+
+
 @pytest.mark.parametrize("auto_offset,k", [(True, 1000), (False, 37), (True, 16)])
 def test_vertex_pre_edge_equals_unfused_entries(dev, auto_offset, k):
     """pgnn_vertex_pre_edge_fwd == pgnn_mlp_fwd (offset chain) +

@@ -1,0 +1,89 @@
+#!/usr/bin/env python
+"""Phase timeline of the weights-stationary edge kernel (csrc/edge_ws.h):
+s_memtime stamps written by the kernel itself (pgnn_set_debug_buffer) at the
+four phase boundaries of each wave's first 38 tiles, plus every wave's begin /
+end on the shader clock and on the constant 100 MHz clock.
+
+    python tools/ws_timeline.py [--preset car_600k] [--tune=key=value ...]
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import pointgnn_amd  # noqa: E402,F401
+from pointgnn_amd import _lib, configs, weights  # noqa: E402
+from pointgnn_amd.engine import InferenceEngine  # noqa: E402
+from pointgnn_amd.synthetic import synthetic_cloud  # noqa: E402
+import bench  # noqa: E402
+
+preset = "car_600k"
+for i, a in enumerate(sys.argv):
+    if a == "--preset":
+        preset = sys.argv[i + 1]
+dev = torch.device("cuda", 0)
+cfg = configs.get_config("car_auto_T3")
+eng = InferenceEngine(cfg, weights.init_params(cfg, seed=0, bias_scale=0.05),
+                      device=dev)
+xyz, inten = synthetic_cloud(seed=0, preset=preset)
+x, f = torch.from_numpy(xyz).to(dev), torch.from_numpy(inten).to(dev)
+eng.run_frame(x, f)
+coords, kps, edges = eng.last_graph
+n_k = int(coords[1].shape[0])
+lib = _lib.load()
+for a in sys.argv[1:]:
+    if a.startswith("--tune="):
+        k, v = a[len("--tune="):].split("=")
+        _lib.set_tunable(k, int(v))
+STAMP, STRIDE, WAVES, GRID = 38, 8 + 4 * 38, 8, 256
+buf = torch.zeros(GRID * WAVES * STRIDE, dtype=torch.int64, device=dev)
+r0 = bench.roofline_edge_kernel(torch, eng, edges[1], n_k, reps=10, frame=(x, f))
+lib.pgnn_set_debug_buffer(_lib.ptr(buf))
+r = bench.roofline_edge_kernel(torch, eng, edges[1], n_k, reps=1, frame=(x, f))
+torch.cuda.synchronize()
+lib.pgnn_set_debug_buffer(None)
+ts = buf.cpu().numpy().reshape(GRID * WAVES, STRIDE)
+hdr, tiles = ts[:, :8], ts[:, 8:].reshape(-1, STAMP, 4)
+live = hdr[:, 0] > 0
+print("E1 %d K %d; kernel %.1f us (%.1f us with stamps); waves stamped %d" % (
+    edges[1].shape[0], n_k, r0["avg_launch_us"], r["avg_launch_us"], live.sum()))
+if not live.any():
+    sys.exit("no stamps: the weights-stationary kernel did not run")
+hdr, tiles = hdr[live], tiles[live]
+cyc = hdr[:, 1] - hdr[:, 0]
+rt0, rt1 = hdr[:, 2], hdr[:, 3]
+ghz = cyc / np.maximum(rt1 - rt0, 1) * 0.1
+print("shader clock during the kernel: %.3f GHz (p10 %.3f p90 %.3f)" % (
+    ghz.mean(), np.percentile(ghz, 10), np.percentile(ghz, 90)))
+t_begin = (rt0 - rt0.min()) / 100.0   # us
+t_end = (rt1 - rt0.min()) / 100.0
+print("wave begin (after weights->LDS) us: min %.1f p50 %.1f max %.1f" % (
+    t_begin.min(), np.median(t_begin), t_begin.max()))
+print("wave end us: min %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f" % (
+    t_end.min(), np.percentile(t_end, 10), np.median(t_end),
+    np.percentile(t_end, 90), t_end.max()))
+for ntg in sorted(set(hdr[:, 5])):
+    m = hdr[:, 5] == ntg
+    nt = hdr[m, 4]
+    print("-- column group of %d tiles: %d waves, %d..%d row tiles per wave, "
+          "wave duration us p50 %.1f max %.1f" % (
+              ntg, m.sum(), nt.min(), nt.max(),
+              np.median(t_end[m] - t_begin[m]), (t_end[m] - t_begin[m]).max()))
+    tl = tiles[m]
+    ok = tl[:, :, 3] > 0
+
+    def stat(name, a, ok=ok):
+        a = a[ok]
+        print("   %-30s mean %7.0f  p50 %7.0f  p90 %7.0f  max %7.0f" % (
+            name, a.mean(), np.median(a), np.percentile(a, 90), a.max()))
+    stat("gather (cycles)", tl[:, :, 1] - tl[:, :, 0])
+    stat("MFMA phase", tl[:, :, 2] - tl[:, :, 1])
+    stat("scatter-max", tl[:, :, 3] - tl[:, :, 2])
+    per = tl[:, 1:, 0] - tl[:, :-1, 0]
+    stat("tile period", per, ok[:, 1:] & ok[:, :-1])
+    mf = 4 * 19 * ntg * 32
+    print("   MFMA issue floor per tile: %d cycles alone, %d sharing the SIMD"
+          % (mf, 2 * mf))
