@@ -216,14 +216,16 @@ int pgnn_mlp_fwd(const float *x, int64_t ld_x, int32_t nx, const float *x2,
  * keypoint when edges_sorted != 0.  out: [num_keypoints, ld_out], columns
  * 16*ceil(n_out/16) written (zero padded); keypoints without edges get
  * float lowest (TF unsorted_segment_max).                                   */
-/* sched_ws (both fused entries; nullable): two int32 on the device, zero before
- * the first use; the kernel leaves them zero.  When given, the last ~12 % of
- * the row tiles are not part of the workgroups' fixed ranges but a pool they
- * take one tile at a time through an atomic counter when their own range is
- * done: slack that absorbs a late start of some workgroups (kernels of other
- * streams occupying CUs when the grid starts).  Launches that may run
- * concurrently (different streams) need different sched_ws.  Results do not
- * depend on it (max is exact). */
+/* sched_ws (both fused entries; nullable): PGNN_SCHED_WS_INTS int32 on the
+ * device, zero before the first use; the kernels leave them zero.  When given,
+ * the last part of the row tiles (~12-15 %) is not part of the workgroups' /
+ * waves' fixed ranges but a pool they take a tile or a small chunk at a time
+ * through atomic counters when their own range is done: slack that absorbs
+ * uneven ranges and a late start of some workgroups (kernels of other streams
+ * occupying CUs when the grid starts).  Launches that may run concurrently
+ * (different streams) need different sched_ws.  Results do not depend on it
+ * (max is exact). */
+#define PGNN_SCHED_WS_INTS 64
 int pgnn_point_set_pooling_fwd(const float *point_features, int32_t n_feat,
                                const float *point_xyz,
                                const int32_t *keypoint_indices,

@@ -202,20 +202,23 @@ def check(rc, what=""):
 
 
 _SCHED_WS = {}
+SCHED_WS_INTS = 64   # PGNN_SCHED_WS_INTS of include/pointgnn_hip.h
 
 
 def sched_ws(device=None):
-    """The two zeroed int32 counters of the fused kernels' tile pool (sched_ws
-    of pgnn_point_set_pooling_fwd / pgnn_edge_mlp_scatter_max_fwd): one pair
-    per (device, current stream) -- launches of one stream are serialised and
-    the kernel hands the counters back zeroed."""
+    """The zeroed int32 counters of the fused kernels' tile pools (sched_ws of
+    pgnn_point_set_pooling_fwd / pgnn_edge_mlp_scatter_max_fwd;
+    PGNN_SCHED_WS_INTS of them): one set per (device, current stream) --
+    launches of one stream are serialised and the kernels hand the counters
+    back zeroed."""
     import torch
     dev = torch.device("cuda", torch.cuda.current_device()) \
         if device is None else device
     key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
     t = _SCHED_WS.get(key)
     if t is None:
-        t = _SCHED_WS[key] = torch.zeros(2, dtype=torch.int32, device=dev)
+        t = _SCHED_WS[key] = torch.zeros(SCHED_WS_INTS, dtype=torch.int32,
+                                         device=dev)
     return t
 
 

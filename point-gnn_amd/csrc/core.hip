@@ -55,6 +55,8 @@ extern int g_graph_debug;
 extern int g_mlp_pool_pct;
 extern int g_ws_xcds;
 extern int g_ws_prio;
+extern int g_ws_pool_pct;
+extern int g_ws_chunk;
 extern int g_mlp_debug;
 extern void *g_mlp_ts;
 extern int g_scatter_nt;
@@ -158,6 +160,16 @@ extern "C" int pgnn_set_tunable(const char *key, int value) {
   if (!strcmp(key, "ws_xcds")) {
     if (value < 1 || value > 64) return PGNN_E_INVALID;
     pgnn::g_ws_xcds = value;
+    return 0;
+  }
+  if (!strcmp(key, "ws_pool_pct")) {
+    if (value < 0 || value > 90) return PGNN_E_INVALID;
+    pgnn::g_ws_pool_pct = value;
+    return 0;
+  }
+  if (!strcmp(key, "ws_chunk")) {
+    if (value < 1 || value > 64) return PGNN_E_INVALID;
+    pgnn::g_ws_chunk = value;
     return 0;
   }
   if (!strcmp(key, "ws_prio")) {

@@ -46,6 +46,10 @@ namespace pgnn {
 
 constexpr int kWsMaxGroups = 4;
 constexpr int kWsWaves = 8;
+constexpr int kWsMaxSlices = 8;
+// sched_ws layout: [0], [1] as in the LDS-tile kernels (claims, done count),
+// then one pool counter per (row slice, column group)
+constexpr int kWsSchedInts = 2 + kWsMaxSlices * kWsMaxGroups;
 constexpr int kWsStampTiles = 38;
 constexpr int kWsStampStride = 8 + 4 * kWsStampTiles;  // int64 per wave
 
@@ -62,15 +66,68 @@ struct EdgeWsArgs {
   int num_segments;
   int sorted;
   int xcds;                          // row slices (workgroup b -> slice b % xcds)
-  int prio;                          // static s_setprio 1 for waves 4..7
+  int prio;                          // raise the wave priority outside the MFMA loop
   long long *ts;                     // profiling stamps (tools/ws_timeline.py) or null
+  int32_t *sched;                    // tile-pool counters (kWsSchedInts, zero) or null
+  int pool_pct;                      // share of a slice's tiles handed out dynamically
+  int chunk;                         // ... in chunks of this many tiles
   int groups;                        // column groups
   int tile0[kWsMaxGroups + 1];       // group g owns column tiles [tile0[g], tile0[g+1])
   int wg0[kWsMaxGroups + 1];         // ... and local workgroups [wg0[g], wg0[g+1]) of a slice
 };
 
+// max over the 16 lanes of a DPP row (the 16 tile rows of one feature), result
+// in every lane: xor-butterfly out of quad_perm [1,0,3,2], quad_perm [2,3,0,1],
+// row_half_mirror, row_mirror -- four v_max_f32 with a DPP operand, no LDS
+// crossbar (ds_bpermute costs a ~100-cycle lgkmcnt round trip per step: the
+// first version of this flush took 15-60k cycles, tools/ws_timeline.py).
+// max(a, b) as ONE instruction: fmaxf() first canonicalises operands the
+// compiler cannot prove quiet (accumulators, loop-carried values) with a
+// v_max_f32 x, x each -- three VALU instructions per max.  v_med3_f32 with +inf
+// needs none (no NaN can occur here: finite inputs, float lowest() identity);
+// the +inf comes out of an asm so that instcombine cannot turn the median back
+// into maxnum.
+__device__ __forceinline__ float opaque_inf() {
+  float inf;
+  asm("v_mov_b32 %0, 0x7f800000" : "=v"(inf));
+  return inf;
+}
+__device__ __forceinline__ float max_nc(float a, float b, float inf) {
+  return __builtin_amdgcn_fmed3f(a, b, inf);
+}
+
+// a - b on two floats with one v_pk_add_f32 (hipcc scalarises the vector
+// subtraction in front of the per-element ReLU; VALU slots next to the partner
+// wave's MFMA stream are what this kernel is short of)
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f pk_sub(v2f a, v2f b) {
+  v2f d;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]"
+      : "=v"(d)
+      : "v"(a), "v"(b));
+  return d;
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_max(float x, float inf) {
+  const int y =
+      __builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false);
+  return max_nc(x, __int_as_float(y), inf);
+}
+__device__ __forceinline__ float row16_max(float x, float inf) {
+  x = dpp_max<0xB1>(x, inf);
+  x = dpp_max<0x4E>(x, inf);
+  x = dpp_max<0x141>(x, inf);
+  return dpp_max<0x140>(x, inf);
+}
+
+// `v`: per-lane partial maxima (pre-bias) of the run of segment d; reduce over
+// the rows, add bias, ReLU, and write the group's columns of row d -- plainly
+// when the run is a whole segment, with float atomic-max otherwise.
+// `bias_lds`: the group's 16*NTG bias values.
 template <int NTG>
-__device__ __forceinline__ void ws_flush(const EdgeWsArgs &a, int t0, int lane,
+__device__ __forceinline__ void ws_flush(const EdgeWsArgs &a,
+                                         const float *bias_lds, int t0, int lane,
                                          int d, const v4f (&v)[NTG],
                                          bool whole) {
   if (d < 0 || d >= a.num_segments) return;  // wave-uniform
@@ -80,22 +137,17 @@ __device__ __forceinline__ void ws_flush(const EdgeWsArgs &a, int t0, int lane,
   int zero;
   asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
   const int g = (lane >> 4) + zero;
-  const float *bias = a.wp + (size_t)a.nt * a.nt * 256;
+  const float inf = opaque_inf();
   float *orow = a.out + (int64_t)d * a.ldo;
 #pragma unroll
   for (int t = 0; t < NTG; ++t) {
     const int col = 16 * (t0 + t) + 4 * g;
-    const v4f b = *reinterpret_cast<const v4f *>(bias + col);
+    const v4f b = *reinterpret_cast<const v4f *>(bias_lds + 16 * t + 4 * g);
     v4f x;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      float m = v[t][r];
-      m = fmaxf(m, __shfl_xor(m, 1));
-      m = fmaxf(m, __shfl_xor(m, 2));
-      m = fmaxf(m, __shfl_xor(m, 4));
-      m = fmaxf(m, __shfl_xor(m, 8));
       // max_r act(a_r + b) == act(max_r a_r + b): +b and ReLU are monotone
-      m += b[r];
+      float m = row16_max(v[t][r], inf) + b[r];
       if (col + r >= a.relu_from) m = m > 0.0f ? m : 0.0f;
       x[r] = m;
     }
@@ -115,18 +167,18 @@ __device__ __forceinline__ void ws_flush(const EdgeWsArgs &a, int t0, int lane,
 template <int KQ, int NTG>
 __device__ __forceinline__ void edge_ws_body(const EdgeWsArgs &a,
                                              const v4f *__restrict__ wl, int t0,
+                                             const float *bias_lds,
                                              int64_t tile_first,
                                              int64_t tile_last, int lane,
-                                             long long *tsw) {
+                                             long long *tsw, int &stamped) {
   if (tile_first >= tile_last) return;
-  const int g = lane >> 4, n = lane & 15;
+  const int n = lane & 15;
   const int64_t E = a.n_edges;
   const int64_t e_first = tile_first * 16;
   const int64_t e_end = tile_last * 16 < E ? tile_last * 16 : E;
   const v4f *__restrict__ P4 = reinterpret_cast<const v4f *>(a.P);
   const v4f *__restrict__ Q4 = reinterpret_cast<const v4f *>(a.Q);
   const int2 *__restrict__ e2 = reinterpret_cast<const int2 *>(a.edges);
-  const v4f *__restrict__ wlane = wl + lane;
 
   // the open run: the run of equal dst that contains the previous edge.  At
   // the start of the range that is the run of the edge BEFORE the range
@@ -142,33 +194,55 @@ __device__ __forceinline__ void edge_ws_body(const EdgeWsArgs &a,
   for (int t = 0; t < NTG; ++t)
     carry[t] = (v4f){kFloatLowest, kFloatLowest, kFloatLowest, kFloatLowest};
 
-  int nxt_s = 0, nxt_d = -1;
-  if (e_first + n < E) {
-    const int2 sd = e2[e_first + n];
-    nxt_s = sd.x;
-    nxt_d = sd.y;
-  }
+  // (src, dst) of a tile's rows are requested one tile ahead.  The request is
+  // unconditional (clamped index) and the validity select happens where the
+  // pair is USED, a tile later: with the select -- or an if around the load --
+  // next to the request, hipcc waits for it on the spot (vmcnt(0)) and the
+  // index round trip is exposed in front of every gather.
+  const float inf = opaque_inf();
+  bool nxt_ok = e_first + n < E;
+  int2 nxt = e2[nxt_ok ? e_first + n : 0];
   for (int64_t tile = tile_first; tile < tile_last; ++tile) {
     const int64_t e0 = tile * 16;
+    // The kernel sits at the 256-VGPR limit.  Left alone, hipcc keeps every
+    // loop-invariant per-lane value (g, n + 16, P + 16 g, Q + 16 g, the LDS
+    // fragment address ...) in registers across the tile loop and SPILLS two
+    // of them -- reloaded here with an s_waitcnt vmcnt(0) that serialises the
+    // index prefetch behind it with the gather (gather phase 5.3k -> 9.1k
+    // cycles, tools/ws_timeline.py).  An opaque copy of the lane id makes them
+    // cheap per-tile recomputations instead.
+    // Everything outside the MFMA loop runs at raised priority.  The two waves
+    // of a SIMD share its VALU issue by priority, then age: next to a partner
+    // that streams MFMAs at equal priority, this wave's VALU instructions get
+    // about one issue slot per MFMA (measured: ~85 cycles per instruction, a
+    // segment-closing tile took 60-90k cycles, tools/ws_timeline.py).  With
+    // priority they issue at the VALU rate and cost the partner a few cycles
+    // of issue each while its MFMA in flight keeps the matrix pipe busy.
+    if (a.prio) __builtin_amdgcn_s_setprio(3);
+    int lz;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(lz) : "v"(lane));
+    const int g = lz >> 4;
+    // fragment f of the group: wfrag[f >> 6] + (f & 63) * 64 float4 -- the
+    // ds_read immediate offset reaches 64 KiB, so three bases cover 133 KiB
+    // (opaque indices: hipcc otherwise folds the bases back into one and pays
+    // a v_add per fragment beyond 64 KiB)
+    int lz1 = lz + 64 * 64, lz2 = lz + 128 * 64;
+    asm volatile("" : "+v"(lz1));
+    asm volatile("" : "+v"(lz2));
+    const v4f *__restrict__ wfrag[3] = {wl + lz, wl + lz1, wl + lz2};
     // profiling builds only: s_memtime at the four phase boundaries of the
     // first 38 tiles of every wave
     long long *tst = nullptr;
-    if (tsw && tile - tile_first < kWsStampTiles)
-      tst = tsw + 8 + 4 * (tile - tile_first);
+    if (tsw && stamped < kWsStampTiles) tst = tsw + 8 + 4 * stamped++;
     if (tst) {
       __builtin_amdgcn_sched_barrier(0);
       const long long c = __builtin_readcyclecounter();
       if (lane == 0) tst[0] = c;
       __builtin_amdgcn_sched_barrier(0);
     }
-    const int my_s = nxt_s, my_d = nxt_d;
-    nxt_s = 0;
-    nxt_d = -1;
-    if (tile + 1 < tile_last && e0 + 16 + n < E) {
-      const int2 sd = e2[e0 + 16 + n];
-      nxt_s = sd.x;
-      nxt_d = sd.y;
-    }
+    const int my_s = nxt_ok ? nxt.x : 0, my_d = nxt_ok ? nxt.y : -1;
+    nxt_ok = tile + 1 < tile_last && e0 + 16 + n < E;
+    nxt = e2[nxt_ok ? e0 + 16 + n : 0];
     // ---- gather: B operands of all K groups ------------------------------
     // rows past the end / foreign ids gather row 0 (finite values in rows the
     // epilogue never reads)
@@ -185,10 +259,17 @@ __device__ __forceinline__ void edge_ws_body(const EdgeWsArgs &a,
       }
       // all 2*KQ loads in flight before the first use
       __builtin_amdgcn_sched_barrier(0);
+      // (vector subtraction: two v_pk_add_f32 per float4 -- VALU slots are
+      // what this kernel is short of next to the partner wave's MFMA stream)
 #pragma unroll
-      for (int q = 0; q < KQ; ++q)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) in[q][i] = fmaxf(in[q][i] - pq[q][i], 0.0f);
+      for (int q = 0; q < KQ; ++q) {
+        const v2f lo = pk_sub((v2f){in[q][0], in[q][1]}, (v2f){pq[q][0], pq[q][1]});
+        const v2f hi = pk_sub((v2f){in[q][2], in[q][3]}, (v2f){pq[q][2], pq[q][3]});
+        in[q][0] = max_nc(lo[0], 0.0f, inf);
+        in[q][1] = max_nc(lo[1], 0.0f, inf);
+        in[q][2] = max_nc(hi[0], 0.0f, inf);
+        in[q][3] = max_nc(hi[1], 0.0f, inf);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     if (tst) {
@@ -197,13 +278,14 @@ __device__ __forceinline__ void edge_ws_body(const EdgeWsArgs &a,
       __builtin_amdgcn_sched_barrier(0);
     }
     // ---- out^T = W^T h^T --------------------------------------------------
+    __builtin_amdgcn_s_setprio(0);
     v4f acc[NTG];
     {
       v4f w[2][NTG];
 #pragma unroll
       for (int t = 0; t < NTG; ++t) {
         acc[t] = (v4f){0.f, 0.f, 0.f, 0.f};
-        w[0][t] = wlane[t * 64];
+        w[0][t] = wfrag[0][t * 64];
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -211,7 +293,8 @@ __device__ __forceinline__ void edge_ws_body(const EdgeWsArgs &a,
         if (q + 1 < KQ) {
 #pragma unroll
           for (int t = 0; t < NTG; ++t)
-            w[(q + 1) & 1][t] = wlane[((q + 1) * NTG + t) * 64];
+            w[(q + 1) & 1][t] = wfrag[((q + 1) * NTG + t) >> 6]
+                                     [(((q + 1) * NTG + t) & 63) * 64];
         }
 #pragma unroll
         for (int s = 0; s < 4; ++s)
@@ -234,6 +317,7 @@ __device__ __forceinline__ void edge_ws_body(const EdgeWsArgs &a,
       __builtin_amdgcn_sched_barrier(0);
     }
     // ---- segmented max over the 16 rows ------------------------------------
+    if (a.prio) __builtin_amdgcn_s_setprio(3);
     // bit r of `starts`: row r does not continue the run of the edge before it
     const int up = __shfl_up(my_d, 1);
     const int prev = n == 0 ? cur_d : up;
@@ -247,7 +331,7 @@ __device__ __forceinline__ void edge_ws_body(const EdgeWsArgs &a,
         for (int t = 0; t < NTG; ++t)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            carry[t][r] = fmaxf(carry[t][r], acc[t][r]);
+            carry[t][r] = max_nc(carry[t][r], acc[t][r], inf);
       } else {
         const bool in_run = n < f;
 #pragma unroll
@@ -255,7 +339,7 @@ __device__ __forceinline__ void edge_ws_body(const EdgeWsArgs &a,
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             carry[t][r] =
-                fmaxf(carry[t][r], in_run ? acc[t][r] : kFloatLowest);
+                max_nc(carry[t][r], in_run ? acc[t][r] : kFloatLowest, inf);
       }
       cur_has = true;
       pos = f;
@@ -263,7 +347,8 @@ __device__ __forceinline__ void edge_ws_body(const EdgeWsArgs &a,
     while (pos < 16) {  // wave-uniform; `pos` opens a run
       // the open run ends in front of row `pos`: the next edge has another dst
       if (cur_has)
-        ws_flush<NTG>(a, t0, lane, cur_d, carry, a.sorted && cur_left_closed);
+        ws_flush<NTG>(a, bias_lds, t0, lane, cur_d, carry,
+                      a.sorted && cur_left_closed);
       const unsigned rest = starts & ~((2u << pos) - 1u);
       const int nextpos = rest ? __builtin_ctz(rest) : 16;
       const bool in_run = n >= pos && n < nextpos;
@@ -285,14 +370,16 @@ __device__ __forceinline__ void edge_ws_body(const EdgeWsArgs &a,
   }
   // the run left open at the end of the range
   if (cur_has)
-    ws_flush<NTG>(a, t0, lane, cur_d, carry,
+    ws_flush<NTG>(a, bias_lds, t0, lane, cur_d, carry,
                   a.sorted && cur_left_closed && d_after != cur_d);
+  __builtin_amdgcn_s_setprio(0);
 }
 
 template <int KQ, int NTMAX>
 __global__ __launch_bounds__(64 * kWsWaves) void edge_ws_kernel(EdgeWsArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   v4f *wl = reinterpret_cast<v4f *>(smem);
+  float *bias_lds = reinterpret_cast<float *>(wl + KQ * NTMAX * 64);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int slice = blockIdx.x % a.xcds;
@@ -301,27 +388,37 @@ __global__ __launch_bounds__(64 * kWsWaves) void edge_ws_kernel(EdgeWsArgs a) {
   while (grp + 1 < a.groups && local >= a.wg0[grp + 1]) ++grp;
   const int t0 = a.tile0[grp];
   const int ntg = a.tile0[grp + 1] - t0;
-  // this group's weight fragments -> LDS, [q][t][lane] float4 (1 KiB each)
+  // this group's weight fragments -> LDS, [q][t][lane] float4 (1 KiB each),
+  // and its bias values
   {
     const v4f *__restrict__ src = reinterpret_cast<const v4f *>(a.wp);
     for (int f = wave; f < KQ * ntg; f += kWsWaves) {
       const int q = f / ntg, t = f - q * ntg;
       wl[(size_t)f * 64 + lane] = src[((size_t)q * a.nt + t0 + t) * 64 + lane];
     }
+    if ((int)threadIdx.x < 16 * ntg)
+      bias_lds[threadIdx.x] =
+          a.wp[(size_t)a.nt * a.nt * 256 + 16 * t0 + threadIdx.x];
   }
   __syncthreads();
-  // the second-dispatched half of an 8-wave workgroup loses every arbitration
-  // against the older half (MI355X_MICROARCH.md, two waves per SIMD)
-  if (a.prio && wave >= 4) __builtin_amdgcn_s_setprio(1);
-  // 16-row tiles of this slice, divided among the group's waves
+  // 16-row tiles of this slice.  The first (100 - pool_pct) % of them are
+  // divided statically among the group's waves (contiguous ranges: an open
+  // segment is carried in registers from tile to tile); the rest is a pool the
+  // waves take `chunk` tiles at a time when their own range is done -- slack
+  // for waves that hit more segment boundaries, slower CUs, or a late start
+  // behind another stream's kernels.  A pool chunk is a range of its own.
   const int64_t n_wt = (a.n_edges + 15) / 16;
   const int64_t s_first = n_wt * slice / a.xcds;
   const int64_t s_last = n_wt * (slice + 1) / a.xcds;
   const int64_t nw = (int64_t)(a.wg0[grp + 1] - a.wg0[grp]) * kWsWaves;
   const int64_t wi = (int64_t)(local - a.wg0[grp]) * kWsWaves + wave;
-  const int64_t span = s_last - s_first;
-  const int64_t tile_first = s_first + span * wi / nw;
-  const int64_t tile_last = s_first + span * (wi + 1) / nw;
+  int64_t span = s_last - s_first;
+  int64_t pool = a.sched ? span * a.pool_pct / 100 : 0;
+  if (span - pool < 4 * nw) pool = 0;  // too little work to bother
+  span -= pool;
+  const int64_t pool_first = s_first + span;
+  int64_t tile_first = s_first + span * wi / nw;
+  int64_t tile_last = s_first + span * (wi + 1) / nw;
   long long *tsw = nullptr;
   if (a.ts) {
     tsw = a.ts + ((int64_t)blockIdx.x * kWsWaves + wave) * kWsStampStride;
@@ -333,13 +430,43 @@ __global__ __launch_bounds__(64 * kWsWaves) void edge_ws_kernel(EdgeWsArgs a) {
       tsw[6] = slice;
     }
   }
-  if (ntg == NTMAX)
-    edge_ws_body<KQ, NTMAX>(a, wl, t0, tile_first, tile_last, lane, tsw);
-  else if (ntg == NTMAX - 1)
-    edge_ws_body<KQ, NTMAX - 1>(a, wl, t0, tile_first, tile_last, lane, tsw);
+  int stamped = 0;
+  int32_t *counter = a.sched ? a.sched + 2 + slice * kWsMaxGroups + grp : nullptr;
+  for (;;) {
+    if (ntg == NTMAX)
+      edge_ws_body<KQ, NTMAX>(a, wl, t0, bias_lds, tile_first, tile_last, lane,
+                              tsw, stamped);
+    else
+      edge_ws_body<KQ, NTMAX - 1>(a, wl, t0, bias_lds, tile_first, tile_last,
+                                  lane, tsw, stamped);
+    if (pool == 0) break;
+    int c = 0;
+    if (lane == 0)
+      c = __hip_atomic_fetch_add(counter, a.chunk, __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+    c = __builtin_amdgcn_readfirstlane(c);
+    if (c >= pool) break;
+    tile_first = pool_first + c;
+    tile_last = tile_first + a.chunk < s_last ? tile_first + a.chunk : s_last;
+  }
   if (tsw && lane == 0) {
     tsw[1] = __builtin_readcyclecounter();
     tsw[3] = __builtin_amdgcn_s_memrealtime();
+    tsw[7] = stamped;
+  }
+  if (a.sched && lane == 0) {
+    // the last wave to get here re-arms the counters: every claim of this
+    // launch was made before its wave counted itself done
+    const int total = (int)gridDim.x * kWsWaves;
+    const int done = __hip_atomic_fetch_add(&a.sched[1], 1, __ATOMIC_ACQ_REL,
+                                            __HIP_MEMORY_SCOPE_AGENT);
+    if (done == total - 1) {
+      for (int i = 0; i < a.xcds * kWsMaxGroups; ++i)
+        __hip_atomic_store(&a.sched[2 + i], 0, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&a.sched[1], 0, __ATOMIC_RELEASE,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 

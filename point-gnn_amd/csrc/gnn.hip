@@ -21,7 +21,9 @@ int g_edge_msub = 0;          // 0 = auto, else force 16*msub-row tiles
 int g_pool_msub = 0;
 int g_mlp_pool_pct = 12;  // share of the row tiles handed out dynamically
 int g_ws_xcds = 8;        // edge_ws.h: row slices (8 = one per XCD, 1 = none)
-int g_ws_prio = 0;        // edge_ws.h: static priority for waves 4..7
+int g_ws_prio = 1;        // edge_ws.h: raised wave priority outside the MFMA loop
+int g_ws_pool_pct = 15;   // edge_ws.h: share of a slice's tiles in the pool
+int g_ws_chunk = 2;       // edge_ws.h: pool chunk (16-row tiles)
 void *g_mlp_ts = nullptr;  // device buffer for per-tile timestamps (profiling)
 int g_mlp_debug = 0;  // ablation mask (benchmarks only): 1 = no gather loads,
                       // 2 = no last-layer GEMM, 4 = no epilogue, 16 = print
@@ -841,7 +843,8 @@ int launch_rows8(const Plan &p, int64_t n_rows, const RowsArgs &ra,
 // tiles in groups that fit the LDS, the 16-row tiles in one slice per XCD.
 template <int KQ, int NTMAX>
 int launch_edge_ws(const LayerDev &L, const EdgeArgs &ea, int64_t n_edges,
-                   const SegArgs &sa, int cus, hipStream_t stream) {
+                   const SegArgs &sa, int cus, int32_t *sched,
+                   hipStream_t stream) {
   EdgeWsArgs a = {};
   a.P = ea.P;
   a.Q = ea.Q;
@@ -858,6 +861,9 @@ int launch_edge_ws(const LayerDev &L, const EdgeArgs &ea, int64_t n_edges,
   a.xcds = (g_ws_xcds >= 1 && cus % g_ws_xcds == 0) ? g_ws_xcds : 8;
   a.prio = g_ws_prio;
   a.ts = (long long *)g_mlp_ts;
+  a.sched = (g_ws_pool_pct > 0 && a.xcds <= kWsMaxSlices) ? sched : nullptr;
+  a.pool_pct = g_ws_pool_pct;
+  a.chunk = g_ws_chunk;
   a.groups = (L.nt + NTMAX - 1) / NTMAX;
   const int per_slice = cus / a.xcds;
   PGNN_REQUIRE(a.groups <= kWsMaxGroups && per_slice >= a.groups,
@@ -888,7 +894,7 @@ int launch_edge_ws(const LayerDev &L, const EdgeArgs &ea, int64_t n_edges,
   }
   a.wg0[0] = 0;
   for (int g = 0; g < a.groups; ++g) a.wg0[g + 1] = a.wg0[g] + cnt[g];
-  const size_t lds = (size_t)KQ * NTMAX * 1024;
+  const size_t lds = (size_t)KQ * NTMAX * 1024 + 16 * NTMAX * sizeof(float);
   auto kern = edge_ws_kernel<KQ, NTMAX>;
   PGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1038,8 +1044,10 @@ extern "C" int pgnn_edge_mlp_scatter_max_fwd(
     const int cus = stream_cu_count(stream);
     if (edge_ws_applies(p, n_edges, cus)) {
       if (p.chain.l[0].nt == 19)
-        return launch_edge_ws<19, 7>(p.chain.l[0], ea, n_edges, sa, cus, stream);
-      return launch_edge_ws<16, 8>(p.chain.l[0], ea, n_edges, sa, cus, stream);
+        return launch_edge_ws<19, 7>(p.chain.l[0], ea, n_edges, sa, cus,
+                                     sched_ws, stream);
+      return launch_edge_ws<16, 8>(p.chain.l[0], ea, n_edges, sa, cus, sched_ws,
+                                   stream);
     }
   }
   int msub = g_edge_msub;

@@ -692,6 +692,21 @@ def test_edge_weights_stationary_kernel_is_bit_identical(dev, name, case):
     fed = np.unique(dst)
     np.testing.assert_allclose(outs[4096][fed, :c], ref[fed], atol=FP_TOL,
                                rtol=1e-4)
+    # tile pool of the weights-stationary kernel: everything static (0), the
+    # default, most tiles from the pool in chunks of 1 and 5 (every chunk a
+    # range of its own: boundary runs flushed atomically) -- same bits, and
+    # the scheduling counters come back zeroed every time
+    try:
+        _lib.set_tunable("mlp_debug", 4096)
+        for pct, chunk in ((0, 2), (15, 2), (80, 1), (80, 5)):
+            _lib.set_tunable("ws_pool_pct", pct)
+            _lib.set_tunable("ws_chunk", chunk)
+            assert np.array_equal(run(), outs[2048], equal_nan=True), (pct, chunk)
+            assert int(_lib.sched_ws(dev).abs().sum().item()) == 0
+    finally:
+        _lib.set_tunable("mlp_debug", 0)
+        _lib.set_tunable("ws_pool_pct", 15)
+        _lib.set_tunable("ws_chunk", 2)
 
 
 @pytest.mark.parametrize("auto_offset,k", [(True, 1000), (False, 37), (True, 16)])

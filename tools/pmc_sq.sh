@@ -1,6 +1,7 @@
 #!/bin/bash
-# SQ-level PMC passes for the two MFMA-bound kernels (edge: fused_mlp_kernel<4, 2>,
-# pooling: fused_mlp_kernel<4, 1>) on whole frames of a preset.  One counter set
+# SQ-level PMC passes for the MFMA-bound kernels (edge: edge_ws_kernel, or
+# fused_mlp_kernel<4, 2> under PGNN_TUNE="mlp_debug=2048"; pooling:
+# fused_mlp_kernel<4, 1|3>) on whole frames of a preset.  One counter set
 # per run, kernel-trace only (gpurun refuses --pmc with other trace domains; the
 # TA_*/TCP_* sets abort rocprofv3 on this pool -- do not add them).
 # usage: tools/pmc_sq.sh [preset] ; prints per-launch averages, writes
@@ -22,13 +23,14 @@ for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_V
            "SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA SQ_LEVEL_WAVES SQ_IFETCH_LEVEL"; do
   i=$((i+1))
   (cd /tmp && timeout 120 rocprofv3 --kernel-trace --pmc $set -d $OUT/p$i -o pmc -- \
-      python $ROOT/tools/kernel_bench.py frame --reps 6 --preset $PRESET > $OUT/p$i.log 2>&1)
+      python $ROOT/tools/kernel_bench.py frame --reps 6 --preset $PRESET ${PGNN_TUNE:+--tune $PGNN_TUNE} > $OUT/p$i.log 2>&1)
   echo "set $i rc=$?: $set" >> $RES
   db=$(find $OUT/p$i -name "*.db" | head -1)
   python - "$db" >> $RES <<'EOF2'
 import sqlite3, sys
 db = sqlite3.connect(sys.argv[1])
-for pat, tag in (("fused_mlp_kernel<4, 2>", "edge"), ("fused_mlp_kernel<4, 1>", "pool")):
+for pat, tag in (("edge_ws_kernel", "edgews"), ("fused_mlp_kernel<4, 2>", "edge"),
+                 ("fused_mlp_kernel<4, 1>", "pool"), ("fused_mlp_kernel<4, 3>", "pool")):
     rows = db.execute("select counter_name, count(*), avg(value) from counters_collection "
                       "where kernel_name like ? group by counter_name", ("%" + pat + "%",))
     n = db.execute("select count(distinct dispatch_id) from counters_collection where "

@@ -33,6 +33,11 @@ x, f = torch.from_numpy(xyz).to(dev), torch.from_numpy(inten).to(dev)
 eng.run_frame(x, f)
 coords, kps, edges = eng.last_graph
 n_k = int(coords[1].shape[0])
+if "--local-src" in sys.argv:
+    # experiment: what if keypoints were numbered spatially (src close to dst)?
+    e1 = edges[1].clone()
+    e1[:, 0] = torch.clamp(e1[:, 1] + (e1[:, 0] % 128) - 64, 0, n_k - 1)
+    edges = [edges[0], e1.contiguous()]
 lib = _lib.load()
 for a in sys.argv[1:]:
     if a.startswith("--tune="):
