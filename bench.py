@@ -172,7 +172,8 @@ def roofline_edge_kernel(torch, engine, edges1, n_k, reps=10, frame=None):
     widths = lc[0]['kwargs']['edge_MLP_depth_list']
     executed = sum(2 * a * b for a, b in zip(widths[:-1], widths[1:])) * n_e
     return {
-        "kernel": "fused_mlp_kernel<EDGE> (gather + edge FC2 + scatter-max)",
+        "kernel": "edge_ws_kernel (weights-stationary fused gather + edge "
+                  "FC2 + scatter-max; csrc/edge_ws.h)",
         "bound": "mfma", "achieved": executed / dur / 1e12,
         "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
         "frac": executed / dur / 1e12 / FP32_MFMA_PEAK_TF,
@@ -216,8 +217,8 @@ def roofline_pool_kernel(torch, engine, reps=10, frame=None):
     dims = [n_feat + 3] + widths
     flops = sum(2 * a * b for a, b in zip(dims[:-1], dims[1:])) * n_e
     return {
-        "kernel": "fused_mlp_kernel<POOL> (gather + point MLP %s + "
-                  "scatter-max)" % "->".join(map(str, dims)),
+        "kernel": "pool_ws_kernel / fused_mlp_kernel<POOL> (gather + point "
+                  "MLP %s + scatter-max)" % "->".join(map(str, dims)),
         "bound": "mfma", "achieved": flops / dur / 1e12,
         "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
         "frac": flops / dur / 1e12 / FP32_MFMA_PEAK_TF,

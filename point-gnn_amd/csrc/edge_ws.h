@@ -76,11 +76,6 @@ struct EdgeWsArgs {
   int wg0[kWsMaxGroups + 1];         // ... and local workgroups [wg0[g], wg0[g+1]) of a slice
 };
 
-// max over the 16 lanes of a DPP row (the 16 tile rows of one feature), result
-// in every lane: xor-butterfly out of quad_perm [1,0,3,2], quad_perm [2,3,0,1],
-// row_half_mirror, row_mirror -- four v_max_f32 with a DPP operand, no LDS
-// crossbar (ds_bpermute costs a ~100-cycle lgkmcnt round trip per step: the
-// first version of this flush took 15-60k cycles, tools/ws_timeline.py).
 // max(a, b) as ONE instruction: fmaxf() first canonicalises operands the
 // compiler cannot prove quiet (accumulators, loop-carried values) with a
 // v_max_f32 x, x each -- three VALU instructions per max.  v_med3_f32 with +inf
@@ -108,58 +103,157 @@ __device__ __forceinline__ v2f pk_sub(v2f a, v2f b) {
   return d;
 }
 
+// ---- closing a run ---------------------------------------------------------
+// `v`: per-lane partial maxima (pre-bias) of the run of segment d, 4 * NTG
+// registers V[i], i = 4t + r, each with 16 row values in the 16 lanes of a DPP
+// row.  A butterfly that reduced every register over all 16 lanes would take
+// 4 steps x 4 NTG registers (and did: ~700 instructions per flush, three copies
+// per kernel body -- cold code that had to come through the instruction cache
+// every ~12 tiles: a segment-closing tile took 45-90k cycles,
+// tools/ws_timeline.py).  Here the reduction HALVES the register set at every
+// step (reduce-scatter): at the step over lane bit k, a lane keeps the half of
+// the registers whose index has bit k equal to its own lane bit k and sends
+// the other half to its partner n ^ (1 << k).  After four steps two registers
+// are left and lane n holds max over the rows of V[n] and V[16 + n]: ~120
+// instructions, and every lane finishes (bias, ReLU, store) its own two
+// columns instead of lanes n == 0 finishing all of them.
+//   steps over bits 0, 1: quad_perm DPP operand; bits 2, 3: ds_bpermute
+//   (__shfl_xor), six of them.
 template <int CTRL>
-__device__ __forceinline__ float dpp_max(float x, float inf) {
-  const int y =
-      __builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false);
-  return max_nc(x, __int_as_float(y), inf);
-}
-__device__ __forceinline__ float row16_max(float x, float inf) {
-  x = dpp_max<0xB1>(x, inf);
-  x = dpp_max<0x4E>(x, inf);
-  x = dpp_max<0x141>(x, inf);
-  return dpp_max<0x140>(x, inf);
+__device__ __forceinline__ float dpp_mov(float x) {
+  return __int_as_float(
+      __builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false));
 }
 
-// `v`: per-lane partial maxima (pre-bias) of the run of segment d; reduce over
-// the rows, add bias, ReLU, and write the group's columns of row d -- plainly
-// when the run is a whole segment, with float atomic-max otherwise.
-// `bias_lds`: the group's 16*NTG bias values.
 template <int NTG>
-__device__ __forceinline__ void ws_flush(const EdgeWsArgs &a,
-                                         const float *bias_lds, int t0, int lane,
-                                         int d, const v4f (&v)[NTG],
-                                         bool whole) {
+__device__ __forceinline__ float ws_v(const v4f (&v)[NTG], int i) {
+  return i < 4 * NTG ? v[i >> 2][i & 3] : kFloatLowest;
+}
+
+// out[d][16 (t0 + t) + 4 g + r] <- act(max over rows + bias): plainly when the
+// run is a whole segment, with float atomic-max otherwise.
+// `bias_lds`: the group's 16 * NTG bias values.
+template <int NTG, class ARGS>
+__device__ __forceinline__ void ws_flush(const ARGS &a, const float *bias_lds,
+                                         int t0, int lane, int d,
+                                         const v4f (&v)[NTG], bool whole,
+                                         float inf) {
   if (d < 0 || d >= a.num_segments) return;  // wave-uniform
-  // An opaque zero keeps the column indices, bias addresses and ReLU
-  // predicates of this (rare) path from being hoisted out of the caller's tile
-  // loop, where they would sit in ~60 registers across the MFMA phase.
+  // An opaque zero keeps the lane predicates and addresses of this (rare) path
+  // from being hoisted out of the caller's tile loop.
   int zero;
   asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
-  const int g = (lane >> 4) + zero;
-  const float inf = opaque_inf();
-  float *orow = a.out + (int64_t)d * a.ldo;
+  const int n = (lane & 15) + zero, g = lane >> 4;
+  const bool b0 = n & 1, b1 = n & 2, b2 = n & 4, b3 = n & 8;
+  float A[16], B[8], C[4], D[2];
 #pragma unroll
-  for (int t = 0; t < NTG; ++t) {
-    const int col = 16 * (t0 + t) + 4 * g;
-    const v4f b = *reinterpret_cast<const v4f *>(bias_lds + 16 * t + 4 * g);
-    v4f x;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      // max_r act(a_r + b) == act(max_r a_r + b): +b and ReLU are monotone
-      float m = row16_max(v[t][r], inf) + b[r];
-      if (col + r >= a.relu_from) m = m > 0.0f ? m : 0.0f;
-      x[r] = m;
-    }
-    if ((lane & 15) == 0) {
-      if (whole) {
-        *reinterpret_cast<v4f *>(orow + col) = x;
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) atomic_max_f32(orow + col + r, x[r] + 0.0f);
-      }
+  for (int j = 0; j < 16; ++j) {
+    if (2 * j < 4 * NTG) {
+      const float x0 = ws_v<NTG>(v, 2 * j), x1 = ws_v<NTG>(v, 2 * j + 1);
+      A[j] = max_nc(b0 ? x1 : x0, dpp_mov<0xB1>(b0 ? x0 : x1), inf);
+    } else {
+      A[j] = kFloatLowest;
     }
   }
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    B[k] = max_nc(b1 ? A[2 * k + 1] : A[2 * k],
+                  dpp_mov<0x4E>(b1 ? A[2 * k] : A[2 * k + 1]), inf);
+#pragma unroll
+  for (int l = 0; l < 4; ++l)
+    C[l] = max_nc(b2 ? B[2 * l + 1] : B[2 * l],
+                  __shfl_xor(b2 ? B[2 * l] : B[2 * l + 1], 4), inf);
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+    D[m] = max_nc(b3 ? C[2 * m + 1] : C[2 * m],
+                  __shfl_xor(b3 ? C[2 * m] : C[2 * m + 1], 8), inf);
+  float *orow = a.out + (int64_t)d * a.ldo + 16 * t0;
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int i = 16 * m + n;  // register index this lane finishes
+    if (i < 4 * NTG) {
+      const int c = 16 * (i >> 2) + 4 * g + (i & 3);  // column inside the group
+      // max_r act(a_r + b) == act(max_r a_r + b): +b and ReLU are monotone
+      float x = D[m] + bias_lds[c];
+      if (16 * t0 + c >= a.relu_from) x = x > 0.0f ? x : 0.0f;
+      if (whole)
+        orow[c] = x;
+      else
+        atomic_max_f32(orow + c, x + 0.0f);
+    }
+  }
+}
+
+// ---- segmented max of one 16-row tile ----------------------------------------
+// The open run: the run of equal dst that contains the previous edge; its
+// per-lane partial maxima sit in `carry`.
+struct WsRun {
+  int cur_d;         // its segment (-1 / foreign ids: never written)
+  bool left_closed;  // its first edge lies inside this wave's range
+  bool has;          // something was accumulated
+};
+
+// acc: out^T of the tile (lane (g, n), register r <-> feature 16t + 4g + r of
+// row n); starts: bit r set where row r does not continue the run of the edge
+// before it; my_d: lane (., n) holds dst of row n.  fin: the virtual tile
+// behind the range (starts = 1): close the open run against d_after.
+template <int NTG, class ARGS>
+__device__ __forceinline__ void ws_epilogue(const ARGS &a, const float *bias_lds,
+                                            int t0, int lane,
+                                            const v4f (&acc)[NTG],
+                                            v4f (&carry)[NTG], unsigned starts,
+                                            int my_d, WsRun &st, bool fin,
+                                            int d_after, float inf) {
+  const int n = lane & 15;
+  int cur_d = st.cur_d;
+  bool cur_left_closed = st.left_closed, cur_has = st.has;
+  int pos = 0;
+  if (!(starts & 1u)) {
+    // rows [0, f) continue the open run
+    const int f = starts ? __builtin_ctz(starts) : 16;
+    if (f == 16) {
+#pragma unroll
+      for (int t = 0; t < NTG; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          carry[t][r] = max_nc(carry[t][r], acc[t][r], inf);
+    } else {
+      const bool in_run = n < f;
+#pragma unroll
+      for (int t = 0; t < NTG; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          carry[t][r] =
+              max_nc(carry[t][r], in_run ? acc[t][r] : kFloatLowest, inf);
+    }
+    cur_has = true;
+    pos = f;
+  }
+  while (pos < 16) {  // wave-uniform; `pos` opens a run
+    // the open run ends in front of row `pos`: the next edge has another dst
+    // (virtual tile: the next edge is the one behind the range)
+    if (cur_has)
+      ws_flush<NTG>(a, bias_lds, t0, lane, cur_d, carry,
+                    a.sorted && cur_left_closed &&
+                        (!fin || d_after != cur_d),
+                    inf);
+    if (fin) break;
+    const unsigned rest = starts & ~((2u << pos) - 1u);
+    const int nextpos = rest ? __builtin_ctz(rest) : 16;
+    const bool in_run = n >= pos && n < nextpos;
+#pragma unroll
+    for (int t = 0; t < NTG; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        carry[t][r] = in_run ? acc[t][r] : kFloatLowest;
+    cur_d = __builtin_amdgcn_readlane(my_d, pos);
+    cur_left_closed = true;
+    cur_has = true;
+    pos = nextpos;
+  }
+  st.cur_d = cur_d;
+  st.left_closed = cur_left_closed;
+  st.has = cur_has;
 }
 
 // tiles [tile_first, tile_last) of 16 edge rows, column tiles t0 .. t0+NTG-1
@@ -202,7 +296,11 @@ __device__ __forceinline__ void edge_ws_body(const EdgeWsArgs &a,
   const float inf = opaque_inf();
   bool nxt_ok = e_first + n < E;
   int2 nxt = e2[nxt_ok ? e_first + n : 0];
-  for (int64_t tile = tile_first; tile < tile_last; ++tile) {
+  // (one more trip than tiles: the virtual tile behind the range closes the
+  // run left open -- the same flush call site, so the flush code exists once
+  // per kernel body)
+  for (int64_t tile = tile_first;; ++tile) {
+    const bool fin = tile >= tile_last;
     const int64_t e0 = tile * 16;
     // The kernel sits at the 256-VGPR limit.  Left alone, hipcc keeps every
     // loop-invariant per-lane value (g, n + 16, P + 16 g, Q + 16 g, the LDS
@@ -240,7 +338,17 @@ __device__ __forceinline__ void edge_ws_body(const EdgeWsArgs &a,
       if (lane == 0) tst[0] = c;
       __builtin_amdgcn_sched_barrier(0);
     }
-    const int my_s = nxt_ok ? nxt.x : 0, my_d = nxt_ok ? nxt.y : -1;
+    v4f acc[NTG];
+    unsigned starts = 1u;  // virtual tile: "row 0 opens a run"
+    int my_d = -1;
+    if (fin) {
+      // (defined on both paths: an undef phi keeps the accumulators live
+      // round the whole loop)
+#pragma unroll
+      for (int t = 0; t < NTG; ++t) acc[t] = (v4f){0.f, 0.f, 0.f, 0.f};
+    } else {
+    const int my_s = nxt_ok ? nxt.x : 0;
+    my_d = nxt_ok ? nxt.y : -1;
     nxt_ok = tile + 1 < tile_last && e0 + 16 + n < E;
     nxt = e2[nxt_ok ? e0 + 16 + n : 0];
     // ---- gather: B operands of all K groups ------------------------------
@@ -279,7 +387,6 @@ __device__ __forceinline__ void edge_ws_body(const EdgeWsArgs &a,
     }
     // ---- out^T = W^T h^T --------------------------------------------------
     __builtin_amdgcn_s_setprio(0);
-    v4f acc[NTG];
     {
       v4f w[2][NTG];
 #pragma unroll
@@ -321,59 +428,24 @@ __device__ __forceinline__ void edge_ws_body(const EdgeWsArgs &a,
     // bit r of `starts`: row r does not continue the run of the edge before it
     const int up = __shfl_up(my_d, 1);
     const int prev = n == 0 ? cur_d : up;
-    const unsigned starts = (unsigned)(__ballot(my_d != prev) & 0xFFFFull);
-    int pos = 0;
-    if (!(starts & 1u)) {
-      // rows [0, f) continue the open run
-      const int f = starts ? __builtin_ctz(starts) : 16;
-      if (f == 16) {
-#pragma unroll
-        for (int t = 0; t < NTG; ++t)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            carry[t][r] = max_nc(carry[t][r], acc[t][r], inf);
-      } else {
-        const bool in_run = n < f;
-#pragma unroll
-        for (int t = 0; t < NTG; ++t)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            carry[t][r] =
-                max_nc(carry[t][r], in_run ? acc[t][r] : kFloatLowest, inf);
-      }
-      cur_has = true;
-      pos = f;
-    }
-    while (pos < 16) {  // wave-uniform; `pos` opens a run
-      // the open run ends in front of row `pos`: the next edge has another dst
-      if (cur_has)
-        ws_flush<NTG>(a, bias_lds, t0, lane, cur_d, carry,
-                      a.sorted && cur_left_closed);
-      const unsigned rest = starts & ~((2u << pos) - 1u);
-      const int nextpos = rest ? __builtin_ctz(rest) : 16;
-      const bool in_run = n >= pos && n < nextpos;
-#pragma unroll
-      for (int t = 0; t < NTG; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          carry[t][r] = in_run ? acc[t][r] : kFloatLowest;
-      cur_d = __builtin_amdgcn_readlane(my_d, pos);
-      cur_left_closed = true;
-      cur_has = true;
-      pos = nextpos;
-    }
+    starts = (unsigned)(__ballot(my_d != prev) & 0xFFFFull);
+    }  // !fin
+    WsRun st = {cur_d, cur_left_closed, cur_has};
+    ws_epilogue<NTG>(a, bias_lds, t0, lane, acc, carry, starts, my_d, st, fin,
+                     d_after, inf);
+    cur_d = st.cur_d;
+    cur_left_closed = st.left_closed;
+    cur_has = st.has;
+    if (fin) break;
     if (tst) {
       __builtin_amdgcn_sched_barrier(0);
       const long long c = __builtin_readcyclecounter();
       if (lane == 0) tst[3] = c;
     }
   }
-  // the run left open at the end of the range
-  if (cur_has)
-    ws_flush<NTG>(a, bias_lds, t0, lane, cur_d, carry,
-                  a.sorted && cur_left_closed && d_after != cur_d);
   __builtin_amdgcn_s_setprio(0);
 }
+
 
 template <int KQ, int NTMAX>
 __global__ __launch_bounds__(64 * kWsWaves) void edge_ws_kernel(EdgeWsArgs a) {

@@ -14,6 +14,7 @@
 // The E x C activations never reach HBM.
 #include "mlp_engine.h"
 #include "edge_ws.h"
+#include "pool_ws.h"
 
 namespace pgnn {
 int g_mlp_blocks_per_cu = 4;  // upper bound; LDS usually allows fewer
@@ -22,7 +23,10 @@ int g_pool_msub = 0;
 int g_mlp_pool_pct = 12;  // share of the row tiles handed out dynamically
 int g_ws_xcds = 8;        // edge_ws.h: row slices (8 = one per XCD, 1 = none)
 int g_ws_prio = 1;        // edge_ws.h: raised wave priority outside the MFMA loop
-int g_ws_pool_pct = 15;   // edge_ws.h: share of a slice's tiles in the pool
+int g_ws_pool_pct = 0;    // edge_ws.h / pool_ws.h: share of the tiles handed out
+                          // dynamically (measured: a pool costs more in extra
+                          // range boundaries than it returns; kept as a tested
+                          // option for streams that share the GPU)
 int g_ws_chunk = 2;       // edge_ws.h: pool chunk (16-row tiles)
 void *g_mlp_ts = nullptr;  // device buffer for per-tile timestamps (profiling)
 int g_mlp_debug = 0;  // ablation mask (benchmarks only): 1 = no gather loads,
@@ -33,7 +37,9 @@ int g_mlp_debug = 0;  // ablation mask (benchmarks only): 1 = no gather loads,
                       // hidden layers through the LDS tile (not registers),
                       // 2048 = edge stage always on the LDS-tile kernel,
                       // 4096 = ... always on the weights-stationary kernel
-                      // (edge_ws.h) when the layer shape allows
+                      // (edge_ws.h) when the layer shape allows,
+                      // 8192 / 16384 = the same pair for the pooling stage
+                      // (pool_ws.h)
 }
 
 namespace {
@@ -918,6 +924,55 @@ bool edge_ws_applies(const Plan &p, int64_t n_edges, int cus) {
   return n_edges >= (int64_t)16 * 2 * kWsWaves * cus;
 }
 
+// Weights-stationary pooling kernel (pool_ws.h): car's 4-32-64-128-300 chain.
+bool pool_ws_applies(const Plan &p, int64_t n_edges, int cus) {
+  if (g_mlp_debug & (8192 | 1024)) return false;
+  const ChainDev &c = p.chain;
+  if (c.n != 4 || c.l[0].kq != 1 || c.l[0].nt != 2 || c.l[1].nt != 4 ||
+      c.l[2].nt != 8 || c.l[3].kq != 8 || c.l[3].nt != 19)
+    return false;
+  if (cus < 8) return false;
+  if (g_mlp_debug & 16384) return true;
+  return n_edges >= (int64_t)16 * 2 * kWsWaves * cus;
+}
+
+int launch_pool_ws(const Plan &p, const PoolArgs &pa, int64_t n_edges,
+                   const SegArgs &sa, int cus, int32_t *sched,
+                   hipStream_t stream) {
+  PoolWsArgs a = {};
+  a.feat = pa.feat;
+  a.nfeat = pa.nfeat;
+  a.xyz = pa.xyz;
+  a.kp = pa.kp;
+  a.edges = pa.edges;
+  a.n_edges = n_edges;
+  a.l0 = p.chain.l[0];
+  a.l1 = p.chain.l[1];
+  a.l2 = p.chain.l[2];
+  a.wp = p.chain.l[3].wp;
+  a.kq = p.chain.l[3].kq;
+  a.nt = p.chain.l[3].nt;
+  a.relu_from = p.chain.l[3].relu_from;
+  a.out = sa.out;
+  a.ldo = sa.ldo;
+  a.num_segments = sa.num_segments;
+  a.sorted = sa.sorted;
+  a.prio = g_ws_prio;
+  a.ts = (long long *)g_mlp_ts;
+  a.sched = g_ws_pool_pct > 0 ? sched : nullptr;
+  a.pool_pct = g_ws_pool_pct;
+  a.chunk = 1;
+  const size_t lds = (size_t)8 * 19 * 1024 + 16 * 19 * sizeof(float);
+  auto kern = pool_ws_kernel;
+  PGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                               hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)lds));
+  hipLaunchKernelGGL(kern, dim3((unsigned)cus), dim3(64 * kWsWaves), lds, stream,
+                     a);
+  PGNN_HIP(hipGetLastError());
+  return 0;
+}
+
 int fill_lowest(float *out, int64_t count, hipStream_t stream) {
   PGNN_HIP(hipMemsetD32Async((hipDeviceptr_t)out, (int)kFloatLowestBits,
                              (size_t)count, stream));
@@ -999,6 +1054,11 @@ extern "C" int pgnn_point_set_pooling_fwd(
     auto nts = [&](int i) { return c.l[i].nt; };
     if (c.n == 4 && nts(0) == 2 && nts(1) == 4 && nts(2) == 8)
       pa.reg_hidden = 1;
+  }
+  {
+    const int cus = stream_cu_count(stream);
+    if (pool_ws_applies(p, n_edges, cus))
+      return launch_pool_ws(p, pa, n_edges, sa, cus, sched_ws, stream);
   }
   if (msub == 4 && pa.reg_hidden == 1)
     return launch_fused<4, PRO_POOL_R3>(p, n_edges, ra, pa, ea, sa, stream,

@@ -588,7 +588,7 @@ __device__ __forceinline__ bool layer_pass_segmax_fast_auto(
 // the values are those of the LDS path (tested bit for bit).  The price is
 // that each wave streams ALL weights of these layers (42 KB for 4-32-64-128)
 // instead of a quarter -- small next to the last layer's 156 KB per tile.
-template <int KQ, int NT>
+template <int KQ, int NT, int TBMAX = 8>
 __device__ __forceinline__ void reg_layer(const LayerDev &L, int lane,
                                           const v4f (&in)[KQ], v4f (&out)[NT]) {
   // An opaque zero keeps the fragment addresses from being hoisted out of the
@@ -599,10 +599,12 @@ __device__ __forceinline__ void reg_layer(const LayerDev &L, int lane,
   const v4f *__restrict__ wp =
       reinterpret_cast<const v4f *>(L.wp) + lane + zero;
   const float *bias = L.wp + (size_t)KQ * NT * 256 + zero;
-  const int g4 = 4 * (lane >> 4);
+  // (+ zero: the per-column ReLU predicates below are loop-invariant too --
+  // 56 SGPR pairs for 2 + 4 + 8 column tiles when hoisted)
+  const int g4 = 4 * (lane >> 4) + zero;
   // column tiles in blocks of <= 8: two stages of 8 weight fragments (64
   // VGPRs) in flight, whatever the layer width
-  constexpr int TB = NT < 8 ? NT : 8;
+  constexpr int TB = NT < TBMAX ? NT : TBMAX;
   static_assert(NT % TB == 0, "column tiles come in blocks");
 #pragma unroll
   for (int t0 = 0; t0 < NT; t0 += TB) {

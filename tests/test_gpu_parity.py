@@ -705,8 +705,69 @@ def test_edge_weights_stationary_kernel_is_bit_identical(dev, name, case):
             assert int(_lib.sched_ws(dev).abs().sum().item()) == 0
     finally:
         _lib.set_tunable("mlp_debug", 0)
-        _lib.set_tunable("ws_pool_pct", 15)
+        _lib.set_tunable("ws_pool_pct", 0)
         _lib.set_tunable("ws_chunk", 2)
+
+
+@pytest.mark.parametrize("case", ["fanins", "shuffled", "ragged", "five_edges",
+                                  "one_segment"])
+def test_pool_weights_stationary_kernel_is_bit_identical(dev, case):
+    """PointSetPooling (car's 4-32-64-128-300 point MLP) has the same pair of
+    kernels as the edge stage: the LDS-tile kernel and the weights-stationary
+    one (csrc/pool_ws.h: last layer resident in LDS, hidden layers in
+    registers, per-lane running max).  `mlp_debug` 8192 (tile kernel) and
+    16384 (weights-stationary, forced below its size threshold) must agree bit
+    for bit and match the float64 oracle."""
+    from pointgnn_amd import _lib, gnn
+    rng = np.random.default_rng(12)
+    cfg = configs.get_config("car_auto_T3")
+    kw = cfg["model_kwargs"]["layer_configs"][0]["kwargs"]
+    k, n_pts = 700, 6000
+    if case == "five_edges":
+        dst = np.array([3, 3, 3, 9, 600], np.int32)
+    elif case == "one_segment":
+        dst = np.full(70001, 5, np.int32)
+    else:
+        deg = rng.choice([1, 2, 3, 5, 9, 16, 17, 40, 64, 65, 130, 300], size=k)
+        dst = np.repeat(np.arange(k), deg).astype(np.int32)
+        if case == "ragged":
+            dst = dst[:len(dst) - len(dst) % 16 - 3]
+    src = rng.integers(0, n_pts, dst.shape[0]).astype(np.int32)
+    edges = np.stack([src, dst], axis=1)
+    if case == "shuffled":
+        edges = edges[rng.permutation(len(edges))]
+    xyz = rng.standard_normal((n_pts, 3)).astype(np.float32)
+    inten = rng.random((n_pts, 1)).astype(np.float32)
+    kp = rng.choice(n_pts, k, replace=False).astype(np.int32).reshape(-1, 1)
+    params = weights.init_params(cfg, seed=2, bias_scale=0.1)
+    store = _store(params, dev)
+
+    def run():
+        with gnn.parameters(store), gnn.variable_scope("layer1"):
+            return gnn.PointSetPooling().apply_regular(
+                T(inten, dev), T(xyz, dev), T(kp, dev), T(edges, dev),
+                **kw).cpu().numpy()
+    outs = {}
+    try:
+        for bits in (8192, 16384, 0):
+            _lib.set_tunable("mlp_debug", bits)
+            outs[bits] = run()
+        _lib.set_tunable("mlp_debug", 16384)
+        for pct in (0, 60):
+            _lib.set_tunable("ws_pool_pct", pct)
+            assert np.array_equal(run(), outs[8192], equal_nan=True), pct
+            assert int(_lib.sched_ws(dev).abs().sum().item()) == 0
+    finally:
+        _lib.set_tunable("mlp_debug", 0)
+        _lib.set_tunable("ws_pool_pct", 0)
+    assert np.array_equal(outs[8192], outs[16384], equal_nan=True)
+    assert np.array_equal(outs[8192], outs[0], equal_nan=True)
+    with np.errstate(all="ignore"):
+        ref = gn.point_set_pooling(params, "layer1", inten, xyz, kp, edges,
+                                   dtype=np.float64)
+    fed = np.unique(dst)
+    np.testing.assert_allclose(outs[16384][fed, :300], ref[fed], atol=FP_TOL,
+                               rtol=1e-4)
 
 
 @pytest.mark.parametrize("auto_offset,k", [(True, 1000), (False, 37), (True, 16)])

@@ -92,3 +92,11 @@ for ntg in sorted(set(hdr[:, 5])):
     mf = 4 * 19 * ntg * 32
     print("   MFMA issue floor per tile: %d cycles alone, %d sharing the SIMD"
           % (mf, 2 * mf))
+
+if "--dump" in sys.argv:
+    for w in (0, 333, 1500):
+        tl = tiles[w]
+        print("wave %d (group of %d tiles, %d row tiles): gather / MFMA / "
+              "scatter-max cycles per tile" % (w, hdr[w, 5], hdr[w, 4]))
+        print("  " + " ".join("%d/%d/%d" % (t[1] - t[0], t[2] - t[1], t[3] - t[2])
+                              for t in tl if t[3] > 0))
