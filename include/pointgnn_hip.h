@@ -12,7 +12,13 @@
  *     pointer past the call; scratch comes from a caller-provided workspace
  *     sized by the matching *_workspace_bytes() query;
  *   - every entry takes a hipStream_t (as void*) and is asynchronous with
- *     respect to the host: no hidden synchronisation, no global mutable state;
+ *     respect to the host: no hidden synchronisation.  The only process-wide
+ *     mutable state is the set of diagnostic knobs behind pgnn_set_tunable /
+ *     pgnn_set_debug_buffer (end of this header): launch-shape and ablation
+ *     switches for benchmarks and tests whose defaults never need changing.
+ *     They are plain words read once per call; change them only while no
+ *     other thread is inside the library.  Everything else is re-entrant
+ *     across streams and threads;
  *   - return value: 0 = ok, negative = argument error (PGNN_E_*), positive =
  *     hipError_t of the failing runtime call.  pgnn_last_error() returns a
  *     thread-local message for the last non-zero return.  No C++ exception
@@ -494,6 +500,25 @@ int pgnn_kitti_cam_points_in_image(
     const uint8_t *image_bgr, int64_t image_rows, int64_t image_cols,
     void *workspace, size_t workspace_bytes, float *out_xyz, float *out_attr,
     int32_t attr_dim, int64_t capacity, int32_t *out_count, void *stream);
+
+/* ---- diagnostics (not part of the reference-facing surface) -------------- */
+/* Process-wide knobs for benchmarks and tests; see "Conventions".  Keys:
+ *   launch shape   scatter_rows_per_wave, scatter_nt, mlp_blocks_per_cu,
+ *                  edge_msub, pool_msub, mlp_pool_pct, wgrad_wg_target,
+ *                  ws_xcds, ws_prio, ws_pool_pct, ws_chunk
+ *   kernel choice  mlp_debug bits 2048 / 4096 (edge stage: LDS-tile kernel /
+ *                  weights-stationary kernel), 8192 / 16384 (pooling stage),
+ *                  1024 (pooling hidden layers through the LDS tile), 32 / 128
+ *                  (scatter-max epilogue forms), 512 (4-wave small-row kernel)
+ *   ablations      mlp_debug bits 1 / 2 / 4 (drop gather loads / last GEMM /
+ *                  epilogue: WRONG results, timing only), graph_debug bit 1
+ *                  (skip the kd-tree replica: 'center' ties in slot order)
+ * Every key except the ablations leaves results bit-identical (tested).
+ * Returns 0, or PGNN_E_INVALID for an unknown key / value out of range.     */
+int pgnn_set_tunable(const char *key, int value);
+/* Device buffer for per-tile cycle stamps of the fused kernels
+ * (tools/tile_timeline.py, tools/ws_timeline.py); NULL disables.           */
+int pgnn_set_debug_buffer(void *device_ptr);
 
 #ifdef __cplusplus
 }

@@ -44,6 +44,14 @@
 
 namespace pgnn {
 
+#ifndef PGNN_WS_SCHED
+// placement of a K group's fragment requests (ds_read_b128 of the NEXT group):
+// 1 = all in front of the group's MFMAs, 2 = one after every four MFMAs
+// (measured: 997 -> 980 us for the edge kernel; left alone hipcc sinks them
+// all behind the MFMAs and the next group starts on a cold lgkmcnt)
+#define PGNN_WS_SCHED 2
+#endif
+
 constexpr int kWsMaxGroups = 4;
 constexpr int kWsWaves = 8;
 constexpr int kWsMaxSlices = 8;
@@ -409,12 +417,20 @@ __device__ __forceinline__ void edge_ws_body(const EdgeWsArgs &a,
           for (int t = 0; t < NTG; ++t)
             acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(
                 w[q & 1][t][s], in[q][s], acc[t], 0, 0, 0);
-        // the next K-group's fragments are requested BEFORE this group's
-        // MFMAs (left alone, hipcc sinks the ds_reads below them and the next
-        // group starts on a cold lgkmcnt); one K-group of prefetch, no more
+        // one K group of fragment prefetch, no more; see PGNN_WS_SCHED
+#if PGNN_WS_SCHED == 2
+        // one fragment request after every four MFMAs
+#pragma unroll
+        for (int t = 0; t < NTG; ++t) {
+          __builtin_amdgcn_sched_group_barrier(0x8 /*MFMA*/, 4, 0);
+          if (q + 1 < KQ)
+            __builtin_amdgcn_sched_group_barrier(0x100 /*DS read*/, 1, 0);
+        }
+#else
         if (q + 1 < KQ)
           __builtin_amdgcn_sched_group_barrier(0x100 /*DS read*/, NTG, 0);
         __builtin_amdgcn_sched_group_barrier(0x8 /*MFMA*/, 4 * NTG, 0);
+#endif
         __builtin_amdgcn_sched_barrier(0);
       }
     }

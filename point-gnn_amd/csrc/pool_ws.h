@@ -69,9 +69,18 @@ __device__ __forceinline__ void pool_ws_block(const v4f *const (&wfrag)[3],
       for (int t = 0; t < NTB; ++t)
         acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[q & 1][t][s], h[q][s],
                                                       acc[t], 0, 0, 0);
+#if PGNN_WS_SCHED == 2
+#pragma unroll
+    for (int t = 0; t < NTB; ++t) {
+      __builtin_amdgcn_sched_group_barrier(0x8 /*MFMA*/, 4, 0);
+      if (q + 1 < KQ)
+        __builtin_amdgcn_sched_group_barrier(0x100 /*DS read*/, 1, 0);
+    }
+#else
     if (q + 1 < KQ)
       __builtin_amdgcn_sched_group_barrier(0x100 /*DS read*/, NTB, 0);
     __builtin_amdgcn_sched_group_barrier(0x8 /*MFMA*/, 4 * NTB, 0);
+#endif
     __builtin_amdgcn_sched_barrier(0);
   }
 }

@@ -67,7 +67,13 @@ def batch_data(batch_list):
             point_counter += n_coords[b][lvl].shape[0]
             center_counter += n_kps[b][lvl].shape[0]
         kp_out.append(cat(kps))
-        edge_out.append(cat(eds))
+        merged = cat(eds)
+        # frames keep their order and every frame's centres move up by the
+        # centres before it: sorted frames merge into a sorted list
+        if is_torch and all(getattr(n_edges[b][lvl], "_pgnn_sorted", 0) == 1
+                            for b in range(len(batch_list))):
+            merged._pgnn_sorted = 1
+        edge_out.append(merged)
     coords = [cat([n_coords[b][lvl] for b in range(len(batch_list))])
               for lvl in range(level_num)]
     return (cat(n_input_v), coords, kp_out, edge_out, cat(n_labels),
@@ -110,7 +116,17 @@ def fetch_data(dataset, frame_idx, config, train_config, aug_fn=None):
     """train.py:78-133 with every per-point step on the device: crop to the
     image, augmentations, training-mode graph, label assignment, box
     encoding.  Returns the 7-tuple `batch_data` / `Trainer.train_step` take
-    (device tensors)."""
+    (device tensors).
+
+    One deviation from the reference's order of casts: there the augmented
+    cloud stays float64 through graph generation, label assignment and box
+    encoding and is cast to float32 last (train.py:88-130); here it is rounded
+    to float32 right after the augmentations (`preprocess.finish`) because the
+    graph kernels take float32 points (as the inference path feeds them,
+    run.py:219-222).  Voxel / radius / in-box tests of a point within one
+    float32 ulp of a boundary can therefore fall on the other side than in the
+    reference; everything downstream of the rounded cloud is the reference's
+    arithmetic (float64 predicates on float32 coordinates)."""
     from . import box_encoding, graph_gen, preprocess
     from .run import _input_features
     points = dataset.get_cam_points_in_image_with_rgb(
@@ -242,6 +258,11 @@ class Trainer(object):
             'optimizer': 'sgd', 'unify_copies': True}
         if self.train_config.get('optimizer', 'sgd') != 'sgd':
             raise NotImplementedError("only the shipped 'sgd' optimizer")
+        if not self.train_config.get('unify_copies', True):
+            # train.py:264-288: without it every tower normalises by its OWN
+            # endpoint counts; the step below always uses the global ones
+            raise NotImplementedError(
+                "unify_copies=False (every shipped train config sets it True)")
         if not torch.cuda.is_available():
             raise _lib.PointGnnHipError("Trainer needs a GPU (no CPU fallback)")
         self.device = device or torch.device("cuda",
@@ -405,8 +426,9 @@ class Trainer(object):
                           device=self.device)
         _lib.check(self.lib.pgnn_scatter_max_f32(
             _lib.ptr(data), data.stride(0), _lib.ptr(dst), int(data.shape[0]),
-            int(data.shape[1]), k, _lib.ptr(out), out.stride(0), 1,
-            self._st()), "pgnn_scatter_max_f32")
+            int(data.shape[1]), k, _lib.ptr(out), out.stride(0),
+            int(getattr(dst, "_pgnn_sorted", 0)), self._st()),
+            "pgnn_scatter_max_f32")
         return out
 
     def _scatter_max_bwd(self, data, dst, out, gout):
@@ -417,12 +439,19 @@ class Trainer(object):
             _lib.ptr(data), data.stride(0), _lib.ptr(dst), int(data.shape[0]),
             cols, k, _lib.ptr(out), out.stride(0), _lib.ptr(gout),
             gout.stride(0), _lib.ptr(ties), _lib.ptr(gdata), gdata.stride(0),
-            1, self._st()), "pgnn_scatter_max_bwd_f32")
+            int(getattr(dst, "_pgnn_sorted", 0)), self._st()),
+            "pgnn_scatter_max_bwd_f32")
         return gdata
 
     @staticmethod
     def _sorted_dst(edges):
+        """dst column, tagged with whether the list is grouped by ascending
+        dst: graph_gen / batch_data lists are (tagged there), a foreign list is
+        checked once (gnn._edges_sorted_flag) and takes the all-atomic path of
+        the scatter-max kernels when it is not."""
+        from . import gnn
         d = edges[:, 1].contiguous()
+        d._pgnn_sorted = int(gnn._edges_sorted_flag(edges))
         return d
 
     # ---- forward with saved activations ------------------------------------------

@@ -93,6 +93,35 @@ for ntg in sorted(set(hdr[:, 5])):
     print("   MFMA issue floor per tile: %d cycles alone, %d sharing the SIMD"
           % (mf, 2 * mf))
 
+if "--balance" in sys.argv:
+    # where does the spread of wave end times come from?
+    blk = np.repeat(np.arange(GRID), WAVES)[live]
+    wv = np.tile(np.arange(WAVES), GRID)[live]
+    dur = t_end - t_begin
+    wg_mean = np.array([dur[blk == b].mean() for b in range(GRID)])
+    wg_std_in = np.array([dur[blk == b].std() for b in range(GRID)])
+    print("wave duration us: overall mean %.1f std %.1f; std of workgroup "
+          "means %.1f; mean std inside a workgroup %.1f" % (
+              dur.mean(), dur.std(), wg_mean.std(), wg_std_in.mean()))
+    sl = hdr[:, 6]
+    print("by XCD slice (mean us): " + " ".join(
+        "%d:%.0f" % (x, dur[sl == x].mean()) for x in sorted(set(sl))))
+    print("by wave slot in the workgroup: " + " ".join(
+        "%d:%.0f" % (w, dur[wv == w].mean()) for w in range(WAVES)))
+    for ntg in sorted(set(hdr[:, 5])):
+        m = hdr[:, 5] == ntg
+        tl = tiles[m]
+        ok = tl[:, :, 3] > 0
+        per_wave = np.array([
+            (t[o][:, 3] - t[o][:, 0]).mean() if o.any() else 0
+            for t, o in zip(tl, ok)])
+        nb = np.array([((t[o][:, 3] - t[o][:, 2]) > 5000).sum()
+                       for t, o in zip(tl, ok)])
+        print("group %d: corr(wave duration, slow scatter tiles among the "
+              "stamped) = %.2f; per-wave mean tile cycles p10 %.0f p50 %.0f "
+              "p90 %.0f" % (ntg, np.corrcoef(dur[m], nb)[0, 1],
+                            np.percentile(per_wave, 10), np.median(per_wave),
+                            np.percentile(per_wave, 90)))
 if "--dump" in sys.argv:
     for w in (0, 333, 1500):
         tl = tiles[w]
