@@ -44,6 +44,48 @@ __device__ __forceinline__ int cell_of(double v, double origin, double cell) {
   return (int)floor((v - origin) / cell);
 }
 
+// NumPy's floor_divide for floating point (npy_divmod in
+// numpy/core/src/npymath/npy_math_internal.h.src), divisor > 0: the exact
+// floor of a / b for the given operands -- fmod is exact, so unlike
+// floor(a / b) the result never jumps a cell when the rounded quotient lands
+// on an integer.
+__device__ __forceinline__ float npy_floor_divide_f32(float a, float b) {
+  float mod = fmodf(a, b);
+  float div = (a - mod) / b;
+  if (mod != 0.0f && mod < 0.0f) div -= 1.0f;  // sign of b (> 0) != sign of mod
+  if (div == 0.0f) return 0.0f;
+  float fl = floorf(div);
+  if (div - fl > 0.5f) fl += 1.0f;
+  return fl;
+}
+__device__ __forceinline__ double npy_floor_divide_f64(double a, double b) {
+  double mod = fmod(a, b);
+  double div = (a - mod) / b;
+  if (mod != 0.0 && mod < 0.0) div -= 1.0;
+  if (div == 0.0) return 0.0;
+  double fl = floor(div);
+  if (div - fl > 0.5) fl += 1.0;
+  return fl;
+}
+
+// Voxel index of coordinate v (a float32 value held as double) along axis ax
+// under the keypoint grid's rule (grid_origin_kernel writes the record):
+//   rule[0..2] origin, rule[3..5] jitter, rule[6..8] float32 minimum, rule[9] mode
+//   mode 0: floor((v - origin) / voxel) in float64       ('center': open3d 0.7)
+//   mode 1: graph_gen.py:123-124   (points - offset) // voxel, ALL float32:
+//           float32 subtraction, NumPy floor_divide with float32(voxel)
+//   mode 2: graph_gen.py:126-128   (points - offset + voxel * rnd) // voxel:
+//           the float32 difference is promoted, the rest is float64
+__device__ __forceinline__ int vox_cell(const double *__restrict__ rule, int ax,
+                                        double v, double voxel) {
+  const int mode = (int)rule[9];
+  if (mode == 0) return cell_of(v, rule[ax], voxel);
+  const float a = (float)v - (float)rule[6 + ax];
+  if (mode == 1) return (int)npy_floor_divide_f32(a, (float)voxel);
+  return (int)npy_floor_divide_f64((double)a + rule[3 + ax], voxel);
+}
+constexpr int kVoxRuleDoubles = 10;
+
 struct Scale3 {
   double x, y, z;
   int on;
@@ -71,15 +113,16 @@ __global__ void cell_keys_kernel(const float *__restrict__ pts, int64_t n,
                                  uint32_t *__restrict__ vals) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  if (origin_dev) {
-    ox = origin_dev[0];
-    oy = origin_dev[1];
-    oz = origin_dev[2];
-  }
   double x, y, z;
   load_point(pts, i, sc, x, y, z);
-  keys[i] = cell_hash(cell_of(x, ox, cell), cell_of(y, oy, cell),
-                      cell_of(z, oz, cell), mask);
+  if (origin_dev) {  // keypoint grid: the rule record of grid_origin_kernel
+    keys[i] = cell_hash(vox_cell(origin_dev, 0, x, cell),
+                        vox_cell(origin_dev, 1, y, cell),
+                        vox_cell(origin_dev, 2, z, cell), mask);
+  } else {
+    keys[i] = cell_hash(cell_of(x, ox, cell), cell_of(y, oy, cell),
+                        cell_of(z, oz, cell), mask);
+  }
   vals[i] = (uint32_t)i;
 }
 
@@ -266,13 +309,19 @@ __global__ void min_bound_kernel(const float *__restrict__ pts, int64_t n,
 // origin[0..2] = grid origin, from the float32 minimum:
 //   center mode (open3d 0.7): min - voxel/2
 //   random mode (graph_gen.py:108-128): min - jitter
+// mode: see vox_cell (0 center, 1 random, 2 random with jitter = sub_*)
 __global__ void grid_origin_kernel(const uint32_t *__restrict__ ordered_min,
                                    double sub_x, double sub_y, double sub_z,
-                                   double *__restrict__ origin) {
+                                   int mode, double *__restrict__ origin) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
-    origin[0] = (double)ordered_to_float(ordered_min[0]) - sub_x;
-    origin[1] = (double)ordered_to_float(ordered_min[1]) - sub_y;
-    origin[2] = (double)ordered_to_float(ordered_min[2]) - sub_z;
+    const double sub[3] = {sub_x, sub_y, sub_z};
+    for (int ax = 0; ax < 3; ++ax) {
+      const double mn = (double)ordered_to_float(ordered_min[ax]);
+      origin[ax] = mn - sub[ax];
+      origin[3 + ax] = sub[ax];
+      origin[6 + ax] = mn;
+    }
+    origin[9] = (double)mode;
   }
 }
 
@@ -290,17 +339,16 @@ __global__ void voxel_leader_kernel(const SortedPoint *__restrict__ sorted,
                                     int32_t *__restrict__ member_count) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const double ox = origin[0], oy = origin[1], oz = origin[2];
   const SortedPoint me = sorted[i];
-  const int vx = cell_of(me.x, ox, voxel), vy = cell_of(me.y, oy, voxel),
-            vz = cell_of(me.z, oz, voxel);
+  const int vx = vox_cell(origin, 0, me.x, voxel), vy = vox_cell(origin, 1, me.y, voxel),
+            vz = vox_cell(origin, 2, me.z, voxel);
   const uint32_t b = keys[i];
   const int s = cell_start[b], e = cell_end[b];
   bool leader = true;
   for (int j = s; j < (int)i; ++j) {
     const SortedPoint o = sorted[j];
-    if (cell_of(o.x, ox, voxel) == vx && cell_of(o.y, oy, voxel) == vy &&
-        cell_of(o.z, oz, voxel) == vz) {
+    if (vox_cell(origin, 0, o.x, voxel) == vx && vox_cell(origin, 1, o.y, voxel) == vy &&
+        vox_cell(origin, 2, o.z, voxel) == vz) {
       leader = false;
       break;
     }
@@ -311,8 +359,8 @@ __global__ void voxel_leader_kernel(const SortedPoint *__restrict__ sorted,
   int cnt = 0;
   for (int j = (int)i; j < e; ++j) {
     const SortedPoint o = sorted[j];
-    if (cell_of(o.x, ox, voxel) == vx && cell_of(o.y, oy, voxel) == vy &&
-        cell_of(o.z, oz, voxel) == vz) {
+    if (vox_cell(origin, 0, o.x, voxel) == vx && vox_cell(origin, 1, o.y, voxel) == vy &&
+        vox_cell(origin, 2, o.z, voxel) == vz) {
       sx += o.x;
       sy += o.y;
       sz += o.z;
@@ -399,10 +447,9 @@ __global__ void voxel_random_pick_kernel(
     float *__restrict__ kp_xyz) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n || !is_leader[i]) return;
-  const double ox = origin[0], oy = origin[1], oz = origin[2];
   const SortedPoint me = sorted[i];
-  const int vx = cell_of(me.x, ox, voxel), vy = cell_of(me.y, oy, voxel),
-            vz = cell_of(me.z, oz, voxel);
+  const int vx = vox_cell(origin, 0, me.x, voxel), vy = vox_cell(origin, 1, me.y, voxel),
+            vz = vox_cell(origin, 2, me.z, voxel);
   const int cnt = member_count[i];
   const uint64_t h = mix64(seed ^ mix64((uint64_t)me.idx + 0x632be59bd9b4e019ull));
   int target = (int)((h >> 11) * (1.0 / 9007199254740992.0) * (double)cnt);
@@ -411,8 +458,8 @@ __global__ void voxel_random_pick_kernel(
   int chosen = me.idx, seen = 0;
   for (int j = (int)i; j < e; ++j) {
     const SortedPoint o = sorted[j];
-    if (cell_of(o.x, ox, voxel) == vx && cell_of(o.y, oy, voxel) == vy &&
-        cell_of(o.z, oz, voxel) == vz) {
+    if (vox_cell(origin, 0, o.x, voxel) == vx && vox_cell(origin, 1, o.y, voxel) == vy &&
+        vox_cell(origin, 2, o.z, voxel) == vz) {
       if (seen == target) {
         chosen = o.idx;
         break;
@@ -650,7 +697,7 @@ extern "C" int pgnn_cap_neighbors_fill(const int32_t *offsets,
   PGNN_GUARD_END
 }
 
-// workspace layout (keypoints): [Grid | ordered_min[4] | origin[3] |
+// workspace layout (keypoints): [Grid | ordered_min[4] | voxel rule[10] |
 //   is_leader[n] | slot[n+1] | member_count[n] | centroid[3n] | scan scratch]
 extern "C" size_t pgnn_keypoints_workspace_bytes(int64_t n_points) {
   if (n_points < 0) return 0;
@@ -684,7 +731,7 @@ int keypoints_impl(const float *points, int64_t n, double voxel, bool center,
   int rc = grid_carve(a, n, g);
   if (rc) return rc;
   uint32_t *omin = a.take<uint32_t>(4);
-  double *origin = a.take<double>(3);
+  double *origin = a.take<double>(kVoxRuleDoubles);
   int32_t *is_leader = a.take<int32_t>((size_t)n + 1);
   int32_t *slot = a.take<int32_t>((size_t)n + 1);
   int32_t *members = a.take<int32_t>((size_t)n + 1);
@@ -743,7 +790,7 @@ int keypoints_impl(const float *points, int64_t n, double voxel, bool center,
     sz = jitter3 ? jitter3[2] : 0.0;
   }
   hipLaunchKernelGGL(grid_origin_kernel, dim3(1), dim3(64), 0, stream, omin, sx,
-                     sy, sz, origin);
+                     sy, sz, center ? 0 : (jitter3 ? 2 : 1), origin);
   Scale3 sc = make_scale(nullptr);
   rc = grid_build(points, n, sc, 0.0, 0.0, 0.0, origin, voxel, g, stream);
   if (rc) return rc;

@@ -250,12 +250,30 @@ def _short_successor(a):
     return a
 
 
-def save_checkpoint(ckpt_dir, variables, global_step=None, name="model"):
+def _read_state(ckpt_dir):
+    """all_model_checkpoint_paths of an existing `checkpoint` state file."""
+    paths = []
+    try:
+        with open(os.path.join(ckpt_dir, "checkpoint")) as f:
+            for line in f:
+                if line.startswith("all_model_checkpoint_paths:"):
+                    paths.append(line.split('"')[1])
+    except (IOError, OSError, IndexError):
+        pass
+    return paths
+
+
+def save_checkpoint(ckpt_dir, variables, global_step=None, name="model",
+                    max_to_keep=5):
     """Write `<ckpt_dir>/<name>-<global_step>.{index,data-00000-of-00001}` and
     the `checkpoint` state file (tf.train.Saver.save with one shard).
     variables: {TF variable name: ndarray}; when `global_step` is given it is
     also stored as the int32 scalar `Variable`, as the reference's graph does
-    (train.py:375).  Returns the checkpoint prefix."""
+    (train.py:375).  Like tf.train.Saver (default max_to_keep = 5, which
+    train.py:496 uses) the state file lists the checkpoints kept so far, oldest
+    first, and the ones beyond `max_to_keep` are deleted (None / 0 keeps
+    all), so `saver.recover_last_checkpoints` of the reference (train.py:516)
+    sees them.  Returns the checkpoint prefix."""
     os.makedirs(ckpt_dir, exist_ok=True)
     items = {k: np.ascontiguousarray(v) for k, v in variables.items()}
     if global_step is not None and "Variable" not in items:
@@ -307,7 +325,17 @@ def save_checkpoint(ckpt_dir, variables, global_step=None, name="model"):
         f.write(bytes(data))
     with open(prefix + ".index", "wb") as f:
         f.write(bytes(out))
+    kept = [p for p in _read_state(ckpt_dir) if p != base] + [base]
+    if max_to_keep:
+        for old in kept[:-max_to_keep]:
+            for suffix in (".index", ".data-00000-of-00001"):
+                try:
+                    os.remove(os.path.join(ckpt_dir, old + suffix))
+                except OSError:
+                    pass
+        kept = kept[-max_to_keep:]
     with open(os.path.join(ckpt_dir, "checkpoint"), "w") as f:
         f.write('model_checkpoint_path: "%s"\n' % base)
-        f.write('all_model_checkpoint_paths: "%s"\n' % base)
+        for p in kept:
+            f.write('all_model_checkpoint_paths: "%s"\n' % p)
     return prefix

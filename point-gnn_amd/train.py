@@ -328,8 +328,9 @@ class Trainer(object):
         under their TF names + the int32 step `Variable`) that the reference's
         run.py / train.py restore unchanged."""
         from . import tf_bundle
-        return tf_bundle.save_checkpoint(train_dir, self.state_dict(),
-                                         global_step=self.global_step)
+        return tf_bundle.save_checkpoint(
+            train_dir, self.state_dict(), global_step=self.global_step,
+            name=self.train_config.get('checkpoint_path', 'model'))
 
     def load_checkpoint(self, train_dir):
         """train.py:512-516: resume weights and step from `train_dir`."""

@@ -384,14 +384,54 @@ def test_random_keypoints_properties(dev):
         i = i.cpu().numpy()[:, 0]
         c = c.cpu().numpy()
         assert np.array_equal(c, xyz[i])
-        off = xyz.astype(np.float64).min(0) - (0 if jitter is None else jitter)
-        vox = np.floor((xyz.astype(np.float64) - off) / 0.8).astype(np.int64)
+        off = np.asarray([np.amin(xyz, axis=0)])   # graph_gen.py:108-110
+        if jitter is None:     # :123-124, float32 throughout
+            vox = ((xyz - off) // 0.8).astype(np.int64)
+        else:                  # :126-128, float64 once the jitter is added
+            vox = ((xyz - off + jitter[None, :]) // 0.8).astype(np.int64)
         occupied = {tuple(v) for v in vox}
         chosen = [tuple(v) for v in vox[i]]
         assert len(chosen) == len(set(chosen)) == len(occupied)
         assert set(chosen) == occupied
     c2, i2 = graph_gen.keypoints_device(p, 0.8, 'random', None, seed=4)
     assert not torch.equal(i2, graph_gen.keypoints_device(p, 0.8, 'random', None, seed=3)[1])
+
+
+@pytest.mark.parametrize("fixture", ["graph_tiny.npz", "graph_small.npz"])
+def test_random_keypoints_voxels_equal_reference(dev, fixture):
+    """graph_gen.py:123-131: the voxel a point falls into is decided by NumPy's
+    `//` -- in FLOAT32 without jitter (float32 points minus float32 offset,
+    floor-divided by float32(voxel)), in float64 once the float64 jitter is
+    added.  `ref_rand_kp_idx` / `ref_randjit_kp_idx` were written by the
+    reference's own multi_layer_downsampling_random (tests/golden/
+    make_golden.py); which member of a voxel it drew depends on Python's
+    `random`, so what is compared is the voxelisation: the device must produce
+    exactly one keypoint per reference voxel -- under the reference's
+    arithmetic, evaluated here with the same NumPy expressions."""
+    from pointgnn_amd import graph_gen
+    g = gold(fixture)
+    xyz = g["xyz"]
+    p = T(xyz, dev)
+    voxel = 0.8
+    off = np.asarray([np.amin(xyz, axis=0)])
+    np.random.seed(0)   # make_golden.py: the jitter is the first draw
+    jit = voxel * np.random.random((1, 3))
+    for key, jitter in (("ref_rand_kp_idx", None), ("ref_randjit_kp_idx", jit)):
+        if jitter is None:
+            vox = ((xyz - off) // voxel).astype(np.int32)   # float32 throughout
+            assert ((xyz - off) // voxel).dtype == np.float32
+        else:
+            vox = ((xyz - off + jitter) // voxel).astype(np.int32)
+        ref = g[key][:, 0]
+        ref_vox = {tuple(v) for v in vox[ref]}
+        assert len(ref_vox) == len(ref)     # the reference: one point per voxel
+        assert ref_vox == {tuple(v) for v in vox}
+        _, i = graph_gen.keypoints_device(
+            p, voxel, 'random', None if jitter is None else jitter[0], seed=5)
+        i = i.cpu().numpy()[:, 0]
+        got = [tuple(v) for v in vox[i]]
+        assert len(got) == len(set(got)) == len(ref_vox), key
+        assert set(got) == ref_vox, key
 
 
 def test_multi_level_graph_center_mode(dev):

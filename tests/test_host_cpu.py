@@ -304,3 +304,29 @@ def test_learning_rate_schedule_matches_tf_exponential_decay():
     assert learning_rate(tc, 1399999) == pytest.approx(0.125 * 0.1 ** 3)
     ped = configs.get_train_config("ped_cyl_auto_T3_trainval")
     assert learning_rate(ped, 800000) == pytest.approx(0.32 * 0.25 ** 2)
+
+
+def test_checkpoint_state_file_lists_and_prunes(tmp_path):
+    """tf.train.Saver bookkeeping (train.py:496,516,634-636): the `checkpoint`
+    state file lists the checkpoints kept so far, oldest first; beyond
+    max_to_keep (TF default 5) the oldest are deleted; the prefix comes from
+    train_config['checkpoint_path']."""
+    import numpy as np
+    from pointgnn_amd import tf_bundle
+    d = str(tmp_path)
+    var = {"layer1/w": np.arange(6, dtype=np.float32).reshape(2, 3)}
+    for step in range(1, 8):
+        tf_bundle.save_checkpoint(d, var, global_step=step, name="mymodel",
+                                  max_to_keep=3)
+    lines = open(os.path.join(d, "checkpoint")).read().splitlines()
+    assert lines == ['model_checkpoint_path: "mymodel-7"',
+                     'all_model_checkpoint_paths: "mymodel-5"',
+                     'all_model_checkpoint_paths: "mymodel-6"',
+                     'all_model_checkpoint_paths: "mymodel-7"']
+    files = sorted(f for f in os.listdir(d) if f.endswith(".index"))
+    assert files == ["mymodel-5.index", "mymodel-6.index", "mymodel-7.index"]
+    ck = tf_bundle.load_checkpoint(d)
+    assert int(ck["Variable"]) == 7 and np.array_equal(ck["layer1/w"], var["layer1/w"])
+    # saving the same step again does not duplicate its entry
+    tf_bundle.save_checkpoint(d, var, global_step=7, name="mymodel", max_to_keep=3)
+    assert open(os.path.join(d, "checkpoint")).read().count("mymodel-7") == 2
