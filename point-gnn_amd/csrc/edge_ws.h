@@ -370,8 +370,13 @@ __device__ __forceinline__ void edge_ws_body(const EdgeWsArgs &a,
       v4f pq[KQ];
 #pragma unroll
       for (int q = 0; q < KQ; ++q) {
+#ifdef PGNN_WS_ABL_NO_GATHER  // timing ablation (wrong results): one load pair
+        in[q] = pr[0];
+        pq[q] = qr[0];
+#else
         in[q] = pr[4 * q];
         pq[q] = qr[4 * q];
+#endif
       }
       // all 2*KQ loads in flight before the first use
       __builtin_amdgcn_sched_barrier(0);
@@ -405,11 +410,21 @@ __device__ __forceinline__ void edge_ws_body(const EdgeWsArgs &a,
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int q = 0; q < KQ; ++q) {
+        // this group's fragments were requested a K group ago: ONE wait for
+        // all of them here instead of hipcc's s_waitcnt in front of every
+        // fragment's first MFMA (120 -> 45 waits per tile; measured neutral,
+        // kept because the MFMA stream stays regular: 3 MFMAs, 1 request)
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+        __builtin_amdgcn_sched_barrier(0);
         if (q + 1 < KQ) {
 #pragma unroll
           for (int t = 0; t < NTG; ++t)
+#ifdef PGNN_WS_ABL_NO_LDS  // timing ablation (wrong results): no fragment reads
+            w[(q + 1) & 1][t] = w[q & 1][t];
+#else
             w[(q + 1) & 1][t] = wfrag[((q + 1) * NTG + t) >> 6]
                                      [(((q + 1) * NTG + t) & 63) * 64];
+#endif
         }
 #pragma unroll
         for (int s = 0; s < 4; ++s)
@@ -422,10 +437,13 @@ __device__ __forceinline__ void edge_ws_body(const EdgeWsArgs &a,
         // one fragment request after every four MFMAs
 #pragma unroll
         for (int t = 0; t < NTG; ++t) {
-          __builtin_amdgcn_sched_group_barrier(0x8 /*MFMA*/, 4, 0);
+          __builtin_amdgcn_sched_group_barrier(0x8 /*MFMA*/, 3, 0);
           if (q + 1 < KQ)
             __builtin_amdgcn_sched_group_barrier(0x100 /*DS read*/, 1, 0);
         }
+        // (three MFMAs per request: the last fragment is then requested a
+        // quarter of a group -- ~200 cycles -- before the group boundary's wait)
+        __builtin_amdgcn_sched_group_barrier(0x8 /*MFMA*/, NTG, 0);
 #else
         if (q + 1 < KQ)
           __builtin_amdgcn_sched_group_barrier(0x100 /*DS read*/, NTG, 0);

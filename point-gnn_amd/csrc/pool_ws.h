@@ -57,6 +57,8 @@ __device__ __forceinline__ void pool_ws_block(const v4f *const (&wfrag)[3],
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int q = 0; q < KQ; ++q) {
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): see edge_ws.h
+    __builtin_amdgcn_sched_barrier(0);
     if (q + 1 < KQ) {
 #pragma unroll
       for (int t = 0; t < NTB; ++t)
@@ -72,10 +74,13 @@ __device__ __forceinline__ void pool_ws_block(const v4f *const (&wfrag)[3],
 #if PGNN_WS_SCHED == 2
 #pragma unroll
     for (int t = 0; t < NTB; ++t) {
-      __builtin_amdgcn_sched_group_barrier(0x8 /*MFMA*/, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x8 /*MFMA*/, 3, 0);
       if (q + 1 < KQ)
         __builtin_amdgcn_sched_group_barrier(0x100 /*DS read*/, 1, 0);
     }
+    // (three MFMAs per request: the last fragment is then requested a
+    // quarter of a group -- ~200 cycles -- before the group boundary's wait)
+    __builtin_amdgcn_sched_group_barrier(0x8 /*MFMA*/, NTB, 0);
 #else
     if (q + 1 < KQ)
       __builtin_amdgcn_sched_group_barrier(0x100 /*DS read*/, NTB, 0);
