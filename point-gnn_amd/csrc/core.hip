@@ -57,6 +57,7 @@ extern int g_ws_xcds;
 extern int g_ws_prio;
 extern int g_ws_pool_pct;
 extern int g_ws_chunk;
+extern int g_ws_reserve;
 extern int g_mlp_debug;
 extern void *g_mlp_ts;
 extern int g_scatter_nt;
@@ -170,6 +171,11 @@ extern "C" int pgnn_set_tunable(const char *key, int value) {
   if (!strcmp(key, "ws_chunk")) {
     if (value < 1 || value > 64) return PGNN_E_INVALID;
     pgnn::g_ws_chunk = value;
+    return 0;
+  }
+  if (!strcmp(key, "ws_reserve")) {
+    if (value < 0 || value > 128 || value % 8) return PGNN_E_INVALID;
+    pgnn::g_ws_reserve = value;
     return 0;
   }
   if (!strcmp(key, "ws_prio")) {

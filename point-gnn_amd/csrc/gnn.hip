@@ -28,6 +28,8 @@ int g_ws_pool_pct = 0;    // edge_ws.h / pool_ws.h: share of the tiles handed ou
                           // range boundaries than it returns; kept as a tested
                           // option for streams that share the GPU)
 int g_ws_chunk = 2;       // edge_ws.h: pool chunk (16-row tiles)
+int g_ws_reserve = 0;     // CUs the weights-stationary kernels leave to the
+                          // kernels of other streams (multiple of 8)
 void *g_mlp_ts = nullptr;  // device buffer for per-tile timestamps (profiling)
 int g_mlp_debug = 0;  // ablation mask (benchmarks only): 1 = no gather loads,
                       // 2 = no last-layer GEMM, 4 = no epilogue, 16 = print
@@ -1056,7 +1058,8 @@ extern "C" int pgnn_point_set_pooling_fwd(
       pa.reg_hidden = 1;
   }
   {
-    const int cus = stream_cu_count(stream);
+    int cus = stream_cu_count(stream);
+    if (g_ws_reserve > 0 && cus - g_ws_reserve >= 64) cus -= g_ws_reserve;
     if (pool_ws_applies(p, n_edges, cus))
       return launch_pool_ws(p, pa, n_edges, sa, cus, sched_ws, stream);
   }
@@ -1101,7 +1104,8 @@ extern "C" int pgnn_edge_mlp_scatter_max_fwd(
   EdgeArgs ea = {P, Q, ld_pq, edges};
   SegArgs sa = {out, ld_out, num_vertices, edges_sorted & 1};
   {
-    const int cus = stream_cu_count(stream);
+    int cus = stream_cu_count(stream);
+    if (g_ws_reserve > 0 && cus - g_ws_reserve >= 64) cus -= g_ws_reserve;
     if (edge_ws_applies(p, n_edges, cus)) {
       if (p.chain.l[0].nt == 19)
         return launch_edge_ws<19, 7>(p.chain.l[0], ea, n_edges, sa, cus,
