@@ -109,6 +109,19 @@ def gen_disjointed_rnn_local_graph_v3(
 
 
 _AUX_STREAMS = {}
+_IDENTITY = {}
+
+
+def _identity_indices(n, dev):
+    """[n,1] int32 0..n-1 for the levels that keep their vertices
+    (graph_gen.py:76-81): a view of one cached ramp per device, so the frame
+    loop launches no torch kernel for it.  Read-only by contract."""
+    ramp = _IDENTITY.get(dev.index)
+    if ramp is None or ramp.shape[0] < n:
+        size = max(int(n), 1 << 16, 2 * (ramp.shape[0] if ramp is not None else 0))
+        ramp = torch.arange(size, dtype=torch.int32, device=dev)
+        _IDENTITY[dev.index] = ramp
+    return ramp[:n].reshape(-1, 1)
 
 
 def _aux_stream(dev):
@@ -196,8 +209,7 @@ def _multi_layer_downsampling(points_xyz, base_voxel_size, levels, add_rnd3d,
         if np.isclose(last_level, level):
             # same scale (a GNN level): same vertices, identity keypoints
             coords.append(base)
-            kp_list.append(torch.arange(base.shape[0], dtype=torch.int32,
-                                        device=base.device).reshape(-1, 1))
+            kp_list.append(_identity_indices(int(base.shape[0]), base.device))
         else:
             if len(coords) != 1:
                 raise NotImplementedError(
