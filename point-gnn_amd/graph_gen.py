@@ -89,6 +89,47 @@ def radius_graph_device(points, centers, radius, scale=None, num_neighbors=-1,
     return edges, offsets
 
 
+def radius_graphs_device(queries):
+    """Several independent radius graphs with ONE wait between them: every
+    count pass is enqueued first, then the edge totals are read (the first read
+    waits for all the count passes, the rest return at once), then every fill
+    pass.  queries: list of (points, centers, radius,
+    scale); returns the list of edge tensors (no fan-in cap).  Used by
+    gen_multi_level_local_graph_v3 for the levels of a frame (two host reads
+    per frame -- K, then (E0, E1) -- instead of three)."""
+    lib = _lib.load()
+    st = _lib.stream_ptr()
+    pend = []
+    for points, centers, radius, scale in queries:
+        dev = points.device
+        n_p, n_c = int(points.shape[0]), int(centers.shape[0])
+        ws_bytes = lib.pgnn_radius_graph_workspace_bytes(n_p, n_c)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        offsets = torch.empty(n_c + 1, dtype=torch.int32, device=dev)
+        keep, sp = _scale3(scale)
+        _lib.check(lib.pgnn_radius_graph_count(
+            _lib.ptr(points), n_p, _lib.ptr(centers), n_c, float(radius), sp,
+            _lib.ptr(ws), ws_bytes, _lib.ptr(offsets), st),
+            "pgnn_radius_graph_count")
+        pend.append((points, centers, radius, keep, sp, ws, ws_bytes, offsets))
+    # the host read: the first one waits for every count pass enqueued above,
+    # the others find their value already computed
+    totals = [int(q[7][-1].item()) for q in pend]
+    out = []
+    for (points, centers, radius, keep, sp, ws, ws_bytes, offsets), n_e in zip(
+            pend, totals):
+        n_p, n_c = int(points.shape[0]), int(centers.shape[0])
+        edges = torch.empty((int(n_e), 2), dtype=torch.int32,
+                            device=points.device)
+        _lib.check(lib.pgnn_radius_graph_fill(
+            _lib.ptr(points), n_p, _lib.ptr(centers), n_c, float(radius), sp,
+            _lib.ptr(ws), ws_bytes, _lib.ptr(offsets), _lib.ptr(edges),
+            int(n_e), st), "pgnn_radius_graph_fill")
+        edges._pgnn_sorted = 1
+        out.append(edges)
+    return out
+
+
 def gen_disjointed_rnn_local_graph_v3(
         points_xyz, center_xyz, radius, num_neighbors,
         neighbors_downsample_method='random', scale=None, seed=None):
@@ -269,11 +310,24 @@ def gen_multi_level_local_graph_v3(points_xyz, base_voxel_size, level_configs,
     coords, kps, was_np = _multi_layer_downsampling(
         points_xyz, base_voxel_size, scales, add_rnd3d, downsample_method)
     edges_list = []
-    for cfg in level_configs:
-        lvl = cfg['graph_level']
-        fn = get_graph_generate_fn(cfg['graph_gen_method'])
-        edges_list.append(fn(coords[lvl], coords[lvl + 1],
-                             **cfg['graph_gen_kwargs']))
+    batched = not was_np and all(
+        cfg['graph_gen_method'] == 'disjointed_rnn_local_graph_v3' and
+        cfg['graph_gen_kwargs'].get('num_neighbors', -1) <= 0
+        for cfg in level_configs)
+    if batched:
+        # inference kwargs (no fan-in cap), device tensors: the levels' radius
+        # graphs are independent once the keypoints exist
+        edges_list = radius_graphs_device([
+            (coords[cfg['graph_level']], coords[cfg['graph_level'] + 1],
+             cfg['graph_gen_kwargs']['radius'],
+             cfg['graph_gen_kwargs'].get('scale'))
+            for cfg in level_configs])
+    else:
+        for cfg in level_configs:
+            lvl = cfg['graph_level']
+            fn = get_graph_generate_fn(cfg['graph_gen_method'])
+            edges_list.append(fn(coords[lvl], coords[lvl + 1],
+                                 **cfg['graph_gen_kwargs']))
     if was_np:
         return ([c.cpu().numpy() for c in coords],
                 [k.cpu().numpy() for k in kps],
