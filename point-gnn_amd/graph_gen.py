@@ -185,7 +185,7 @@ def keypoints_device(points, voxel_size, method='center', jitter=None, seed=0):
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     kp_idx = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
     kp_xyz = torch.empty((max(n, 1), 3), dtype=torch.float32, device=dev)
-    num = torch.zeros(1, dtype=torch.int32, device=dev)
+    num = torch.empty(1, dtype=torch.int32, device=dev)  # always written
     st = _lib.stream_ptr()
     if method == 'center':
         _lib.check(lib.pgnn_voxel_keypoints_center(
