@@ -17,6 +17,9 @@
 // launch-bound, not bandwidth-bound (DESIGN.md "Graph kernels").
 #include <math.h>
 
+#include <mutex>
+#include <vector>
+
 #include "kdtree.h"
 #include "sort.h"
 
@@ -712,6 +715,36 @@ int g_graph_debug = 0;  // benchmarks only: 1 = skip the kd-tree replica (exact
                         // ties then go to idx_array-free slot order)
 }
 namespace {
+// The (fork, join) event pair of a (stream, aux stream) couple, created once
+// and re-recorded every call.  Creating and destroying two events per frame
+// is not free in the HIP runtime: destroying an event whose record is still
+// pending makes the host wait for it, i.e. for the whole kd-tree build, on
+// every frame.  (An internal cache like device_cu_count()'s; entries live as
+// long as the process.)
+int fork_join_events(hipStream_t stream, hipStream_t aux, hipEvent_t *fork,
+                     hipEvent_t *join) {
+  struct Pair {
+    hipStream_t s, a;
+    hipEvent_t f, j;
+  };
+  static std::mutex mu;
+  static std::vector<Pair> cache;
+  std::lock_guard<std::mutex> lock(mu);
+  for (const Pair &p : cache)
+    if (p.s == stream && p.a == aux) {
+      *fork = p.f;
+      *join = p.j;
+      return 0;
+    }
+  Pair p = {stream, aux, nullptr, nullptr};
+  PGNN_HIP(hipEventCreateWithFlags(&p.f, hipEventDisableTiming));
+  PGNN_HIP(hipEventCreateWithFlags(&p.j, hipEventDisableTiming));
+  cache.push_back(p);
+  *fork = p.f;
+  *join = p.j;
+  return 0;
+}
+
 int keypoints_impl(const float *points, int64_t n, double voxel, bool center,
                    const double *jitter3, uint64_t seed, void *workspace,
                    size_t workspace_bytes, int32_t *kp_idx, float *kp_xyz,
@@ -759,8 +792,8 @@ int keypoints_impl(const float *points, int64_t n, double voxel, bool center,
   if (use_kd) {
     hipStream_t kd_stream = stream;
     if (aux && aux != stream) {
-      PGNN_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-      PGNN_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+      int erc = fork_join_events(stream, aux, &ev_fork, &ev_join);
+      if (erc) return erc;
       PGNN_HIP(hipEventRecord(ev_fork, stream));
       PGNN_HIP(hipStreamWaitEvent(aux, ev_fork, 0));
       kd_stream = aux;
@@ -771,8 +804,6 @@ int keypoints_impl(const float *points, int64_t n, double voxel, bool center,
       // on aux that `stream`'s later work does not wait for
       hipEventRecord(ev_join, aux);
       hipStreamWaitEvent(stream, ev_join, 0);
-      hipEventDestroy(ev_fork);
-      hipEventDestroy(ev_join);
     }
     if (rc) return rc;
   }

@@ -175,7 +175,8 @@ def _aux_stream(dev):
     return s
 
 
-def keypoints_device(points, voxel_size, method='center', jitter=None, seed=0):
+def keypoints_device(points, voxel_size, method='center', jitter=None, seed=0,
+                     fork_kdtree=False):
     """One pooling level.  Returns (coords float32 [K,3], indices int32 [K,1])
     as device tensors.  One host sync (reading K)."""
     lib = _lib.load()
@@ -191,7 +192,13 @@ def keypoints_device(points, voxel_size, method='center', jitter=None, seed=0):
         _lib.check(lib.pgnn_voxel_keypoints_center(
             _lib.ptr(points), n, float(voxel_size), _lib.ptr(ws), ws_bytes,
             _lib.ptr(kp_idx), _lib.ptr(kp_xyz), _lib.ptr(num), st,
-            ctypes.c_void_p(_aux_stream(dev).cuda_stream)),
+            # aux stream = NULL: the kd-tree replica runs on this stream.
+            # Forking it onto a side stream (pgnn_voxel_keypoints_center's
+            # aux_stream, _aux_stream below) bought 0.1 ms of latency when the
+            # replica was slower; measured equal since (0.97 vs 1.00 ms, 284 vs
+            # 282 frames/s), so the simpler order is the default.
+            ctypes.c_void_p(_aux_stream(dev).cuda_stream if fork_kdtree
+                            else 0)),
             "pgnn_voxel_keypoints_center")
     elif method == 'random':
         jit = None

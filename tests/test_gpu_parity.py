@@ -372,6 +372,20 @@ def test_center_keypoints(dev, preset, seed, voxel):
     assert np.array_equal(kps[1][:, 0], np.arange(len(coords[1])))
 
 
+def test_center_keypoints_forked_kdtree_equal(dev):
+    """pgnn_voxel_keypoints_center with an aux stream (the kd-tree replica
+    forked beside the voxel hashing and joined before the nearest-neighbour
+    kernel) gives the keypoints of the single-stream order."""
+    import torch
+    from pointgnn_amd import graph_gen
+    xyz, _ = synthetic_cloud(seed=3, preset="small")
+    p = T(xyz, dev)
+    c0, i0 = graph_gen.keypoints_device(p, 0.4, 'center')
+    c1, i1 = graph_gen.keypoints_device(p, 0.4, 'center', fork_kdtree=True)
+    torch.cuda.synchronize()
+    assert torch.equal(i0, i1) and torch.equal(c0, c1)
+
+
 def test_random_keypoints_properties(dev):
     """graph_gen.py:92-153: exactly one real point per occupied voxel of the
     grid anchored at the cloud minimum (+ jitter)."""
