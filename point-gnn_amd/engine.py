@@ -87,8 +87,8 @@ class InferenceEngine(object):
                              lookahead=0):
         """Steady-state loop over independent frames on HIP streams: while a
         compute stream executes the GNN of frame i, stream G builds the graph
-        of frame i+1.  The graph builder needs three host reads per frame (K,
-        E0, E1 size its outputs); they synchronise stream G only, so the host
+        of frame i+1.  The graph builder needs two host waits per frame (K, then
+        E0 and E1, which size its outputs); they synchronise stream G only, so the host
         waits for them while the GPU is busy with frame i's message passing.
         With compute_streams = 2 consecutive frames alternate between two
         compute streams, so the under-filled per-vertex kernels and the tail
@@ -123,7 +123,7 @@ class InferenceEngine(object):
             return g, ev
 
         # lookahead > 0: graphs come from a builder thread that runs up to
-        # that many frames ahead, so the three count reads block only that
+        # that many frames ahead, so the count reads block only that
         # thread.  Measured: no gain over lookahead = 0 (the
         # calling thread builds graph i+1 right after enqueueing frame i; its
         # reads complete long before frame i's message passing does), so 0 is
