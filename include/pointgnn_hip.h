@@ -505,7 +505,7 @@ int pgnn_kitti_cam_points_in_image(
 /* Process-wide knobs for benchmarks and tests; see "Conventions".  Keys:
  *   launch shape   scatter_rows_per_wave, scatter_nt, mlp_blocks_per_cu,
  *                  edge_msub, pool_msub, mlp_pool_pct, wgrad_wg_target,
- *                  ws_xcds, ws_prio, ws_pool_pct, ws_chunk
+ *                  ws_xcds, ws_prio, ws_pool_pct, ws_chunk, ws_reserve
  *   kernel choice  mlp_debug bits 2048 / 4096 (edge stage: LDS-tile kernel /
  *                  weights-stationary kernel), 8192 / 16384 (pooling stage),
  *                  1024 (pooling hidden layers through the LDS tile), 32 / 128

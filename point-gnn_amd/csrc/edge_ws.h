@@ -310,21 +310,20 @@ __device__ __forceinline__ void edge_ws_body(const EdgeWsArgs &a,
   for (int64_t tile = tile_first;; ++tile) {
     const bool fin = tile >= tile_last;
     const int64_t e0 = tile * 16;
-    // The kernel sits at the 256-VGPR limit.  Left alone, hipcc keeps every
-    // loop-invariant per-lane value (g, n + 16, P + 16 g, Q + 16 g, the LDS
-    // fragment address ...) in registers across the tile loop and SPILLS two
-    // of them -- reloaded here with an s_waitcnt vmcnt(0) that serialises the
-    // index prefetch behind it with the gather (gather phase 5.3k -> 9.1k
-    // cycles, tools/ws_timeline.py).  An opaque copy of the lane id makes them
-    // cheap per-tile recomputations instead.
-    // Everything outside the MFMA loop runs at raised priority.  The two waves
-    // of a SIMD share its VALU issue by priority, then age: next to a partner
-    // that streams MFMAs at equal priority, this wave's VALU instructions get
-    // about one issue slot per MFMA (measured: ~85 cycles per instruction, a
-    // segment-closing tile took 60-90k cycles, tools/ws_timeline.py).  With
-    // priority they issue at the VALU rate and cost the partner a few cycles
-    // of issue each while its MFMA in flight keeps the matrix pipe busy.
+    // Everything outside the MFMA loop runs at raised priority: next to a
+    // partner wave that streams MFMAs this wave's VALU instructions get few
+    // issue slots (fp32 MFMA runs on the same FMA lanes; the fast-path
+    // epilogue takes 0.6k cycles on an idle SIMD and 12k beside the partner's
+    // MFMA phase, tools/ws_timeline.py).  Measured gain: ~1 % -- the two
+    // waves of a SIMD end up alternating whole MFMA phases either way.
     if (a.prio) __builtin_amdgcn_s_setprio(3);
+    // Left alone, hipcc keeps every loop-invariant per-lane value (g, n + 16,
+    // P + 16 g, Q + 16 g, the LDS fragment address ...) in registers across
+    // the tile loop, ran into the 256-VGPR limit and SPILLED two of them --
+    // reloaded here with an s_waitcnt vmcnt(0) that serialised the index
+    // prefetch behind it with the gather (gather phase 5.3k -> 9.1k cycles).
+    // An opaque copy of the lane id makes them cheap per-tile recomputations
+    // instead (256 -> ~200 VGPRs, no scratch).
     int lz;
     asm volatile("v_mov_b32 %0, %1" : "=v"(lz) : "v"(lane));
     const int g = lz >> 4;
