@@ -330,3 +330,16 @@ def test_checkpoint_state_file_lists_and_prunes(tmp_path):
     # saving the same step again does not duplicate its entry
     tf_bundle.save_checkpoint(d, var, global_step=7, name="mymodel", max_to_keep=3)
     assert open(os.path.join(d, "checkpoint")).read().count("mymodel-7") == 2
+
+
+def test_sched_ws_size_matches_header():
+    """The Python loader allocates the scheduling counters the header
+    promises (PGNN_SCHED_WS_INTS), and the kernels' own layout fits in them."""
+    from pointgnn_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "pointgnn_hip.h")).read()
+    m = re.search(r"#define\s+PGNN_SCHED_WS_INTS\s+(\d+)", hdr)
+    assert m and int(m.group(1)) == _lib.SCHED_WS_INTS
+    src = open(os.path.join(ROOT, "point-gnn_amd", "csrc", "edge_ws.h")).read()
+    slices = int(re.search(r"kWsMaxSlices\s*=\s*(\d+)", src).group(1))
+    groups = int(re.search(r"kWsMaxGroups\s*=\s*(\d+)", src).group(1))
+    assert 2 + slices * groups <= _lib.SCHED_WS_INTS
