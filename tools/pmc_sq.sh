@@ -22,6 +22,7 @@ for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_V
            "SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_RD SQ_INST_LEVEL_LDS SQ_INST_CYCLES_VMEM_RD SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL" \
            "SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA SQ_LEVEL_WAVES SQ_IFETCH_LEVEL"; do
   i=$((i+1))
+  [[ -n "${PMC_SETS:-}" && $i -gt $PMC_SETS ]] && break
   (cd /tmp && timeout 120 rocprofv3 --kernel-trace --pmc $set -d $OUT/p$i -o pmc -- \
       python $ROOT/tools/kernel_bench.py frame --reps 6 --preset $PRESET ${PGNN_TUNE:+--tune $PGNN_TUNE} > $OUT/p$i.log 2>&1)
   echo "set $i rc=$?: $set" >> $RES
@@ -29,7 +30,8 @@ for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_V
   python - "$db" >> $RES <<'EOF2'
 import sqlite3, sys
 db = sqlite3.connect(sys.argv[1])
-for pat, tag in (("edge_ws_kernel", "edgews"), ("fused_mlp_kernel<4, 2>", "edge"),
+for pat, tag in (("edge_ws_kernel", "edgews"), ("pool_ws_kernel", "poolws"),
+                 ("fused_mlp_kernel<4, 2>", "edge"),
                  ("fused_mlp_kernel<4, 1>", "pool"), ("fused_mlp_kernel<4, 3>", "pool")):
     rows = db.execute("select counter_name, count(*), avg(value) from counters_collection "
                       "where kernel_name like ? group by counter_name", ("%" + pat + "%",))
