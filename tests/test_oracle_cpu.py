@@ -192,3 +192,48 @@ def test_kdtree_shape_abi_matches_sklearn():
         assert lib.pgnn_kdtree_shape(n, ctypes.byref(lv), ctypes.byref(nodes)) == 0
         t = KDTree(rng.random((n, 3)), leaf_size=30)
         assert nodes.value == t.get_arrays()[2].shape[0], n
+
+
+def _kernel_floor_divide(a, b, dtype):
+    """csrc/graph.hip npy_floor_divide_f32 / _f64 restated with NumPy scalars
+    of the same precision (divisor > 0)."""
+    a = dtype(a)
+    b = dtype(b)
+    mod = np.fmod(a, b)
+    div = dtype((a - mod) / b)
+    if mod != 0 and mod < 0:
+        div = dtype(div - dtype(1))
+    if div == 0:
+        return dtype(0)
+    fl = np.floor(div)
+    if dtype(div - fl) > dtype(0.5):
+        fl = dtype(fl + dtype(1))
+    return fl
+
+
+def test_random_keypoint_voxel_rule_is_numpy_floor_divide():
+    """graph_gen.py:123-131 voxelises with NumPy's `//`.  The device code
+    (vox_cell in csrc/graph.hip) evaluates npy_divmod's fmod-based exact floor;
+    this pins that formula to NumPy itself on cell boundaries +- a few ulps,
+    where floor(a / b) in the same precision can land in the neighbouring
+    cell."""
+    rng = np.random.default_rng(0)
+    for dtype, voxel in ((np.float32, np.float32(0.8)), (np.float64, 0.8),
+                         (np.float32, np.float32(0.4)), (np.float64, 0.2)):
+        vals = []
+        for k in list(range(0, 130)) + [1000, 4095, 65535]:
+            x = dtype(k) * dtype(voxel)
+            for _ in range(4):
+                vals.append(x)
+                x = np.nextafter(x, dtype(np.inf), dtype=dtype)
+            x = dtype(k) * dtype(voxel)
+            for _ in range(4):
+                x = np.nextafter(x, dtype(-np.inf), dtype=dtype)
+                if x >= 0:
+                    vals.append(x)
+        vals += list(rng.uniform(0, 120, 4000).astype(dtype))
+        vals = np.array(vals, dtype=dtype)
+        ref = vals // dtype(voxel)
+        assert ref.dtype == dtype
+        got = np.array([_kernel_floor_divide(v, voxel, dtype) for v in vals])
+        assert np.array_equal(got, ref)
