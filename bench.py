@@ -293,7 +293,8 @@ def run_train(args, torch, dev, rank, world, dist):
     from pointgnn_amd import configs, graph_gen, train
     from pointgnn_amd.synthetic import synthetic_cloud
     cfg = configs.get_config(args.config)
-    pg = None
+    # the gradient all-reduce runs on the default group (RCCL over xGMI)
+    pg = dist.group.WORLD if dist is not None else None
     tr = train.Trainer(cfg, seed=0, device=dev, process_group=pg)
     fpg = args.frames_per_gpu
     n_steps = args.steps + args.warmup

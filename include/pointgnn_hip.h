@@ -112,6 +112,23 @@ int pgnn_radius_graph_fill(const float *points, int64_t n_points,
                            const int32_t *offsets /* from _count */,
                            int32_t *edges /* [capacity, 2] */,
                            int64_t capacity, void *stream);
+/* The same two phases on FLOAT64 points / centres: the training data path
+ * keeps the augmented cloud float64 through graph generation (train.py:88-90
+ * -> graph_gen.py:187-194; the cast to float32 is train.py:124), and sklearn
+ * searches float64 data as it is.  Same workspace query, same outputs. */
+int pgnn_radius_graph_count_f64(const double *points, int64_t n_points,
+                                const double *centers, int64_t n_centers,
+                                double radius, const double *scale3_host,
+                                void *workspace, size_t workspace_bytes,
+                                int32_t *offsets /* [n_centers + 1] */,
+                                void *stream);
+int pgnn_radius_graph_fill_f64(const double *points, int64_t n_points,
+                               const double *centers, int64_t n_centers,
+                               double radius, const double *scale3_host,
+                               void *workspace, size_t workspace_bytes,
+                               const int32_t *offsets /* from _count */,
+                               int32_t *edges /* [capacity, 2] */,
+                               int64_t capacity, void *stream);
 /* Training-time fan-in cap (graph_gen.py:210-214, num_neighbors > 0): keeps a
  * uniformly random subset (without replacement) of `max_neighbors` edges for
  * every centre whose fan-in exceeds it (counter-based RNG keyed by `seed`,
@@ -138,8 +155,17 @@ int pgnn_cap_neighbors_fill(const int32_t *offsets, const int32_t *edges,
  * uniformly chosen point per occupied voxel of the grid anchored at the
  * cloud minimum (+ `jitter3_host`, the reference's add_rnd3d origin shift,
  * in units of metres; NULL = none), RNG keyed by `seed`.
- * Capacity of both outputs is n_points rows; *num_keypoints (device) receives
- * K.                                                                       */
+ * Capacity of both outputs is n_points rows.  num_keypoints: device int32[2],
+ * [0] = K, [1] = tie-order status of the kd-tree replica ('center' only; 0 =
+ * the reference's order; 1 = libstdc++'s heap-select fallback of
+ * std::nth_element would have run on this cloud -- it is not replicated, exact
+ * 1-NN ties may then be broken differently from the reference; the Python
+ * mirror raises on it).
+ * Limits of 'center' mode: float32 points only (the replica's keys), at most
+ * 524 288 points (PGNN_E_UNSUPPORTED beyond: node records are kept in LDS).
+ * The tie rule replicated is scikit-learn >= 1.0's (std::nth_element in
+ * sklearn/neighbors/_partition_nodes.pyx); the reference pins no version and a
+ * 2020-era 0.22 partitions differently.                                     */
 /* Replica of scikit-learn's KDTree(points, leaf_size=30) node order -- what
  * decides which of several exactly equidistant points
  * NearestNeighbors(algorithm='kd_tree').kneighbors returns (graph_gen.py:84-88)
@@ -160,7 +186,7 @@ int pgnn_kdtree_replica(const float *points, int64_t n_points, void *workspace,
                         size_t workspace_bytes, int32_t *idx_array,
                         double *node_bounds, int32_t *status, void *stream);
 
-size_t pgnn_keypoints_workspace_bytes(int64_t n_points);
+size_t pgnn_keypoints_workspace_bytes(int64_t n_points);  /* either precision */
 /* aux_stream (nullable): a second caller-owned stream.  When given, the
  * kd-tree replica (a latency-bound chain of ~10 dependent launches that only
  * needs the points) is issued there, forked from and joined back into `stream`
@@ -178,6 +204,17 @@ int pgnn_voxel_keypoints_random(const float *points, int64_t n_points,
                                 size_t workspace_bytes,
                                 int32_t *keypoint_indices, float *keypoint_xyz,
                                 int32_t *num_keypoints, void *stream);
+
+/* 'random' mode on a FLOAT64 cloud (train.py:88-90): NumPy's float64 `//` on
+ * (points - min) [+ jitter] (graph_gen.py:123-128); keypoint_xyz is float64
+ * (the reference returns rows of its float64 array).  */
+int pgnn_voxel_keypoints_random_f64(const double *points, int64_t n_points,
+                                    double voxel_size,
+                                    const double *jitter3_host, uint64_t seed,
+                                    void *workspace, size_t workspace_bytes,
+                                    int32_t *keypoint_indices,
+                                    double *keypoint_xyz,
+                                    int32_t *num_keypoints, void *stream);
 
 /* ---- dense layers --------------------------------------------------------
  * A fully connected layer y = act(x @ W + b) (slim.fully_connected with
@@ -450,6 +487,13 @@ int pgnn_assign_box_labels(const float *xyz, int64_t n_points,
                            const double *label_records, int32_t n_records,
                            int32_t *cls_labels, double *boxes_3d,
                            float *valid_boxes, int32_t *owner, void *stream);
+/* Float64 vertices (train.py:100-118 passes the float64 vertex_coord_list of
+ * the augmented cloud): np.matmul(xyz_f64, normals.T) on the exact values. */
+int pgnn_assign_box_labels_f64(const double *xyz, int64_t n_points,
+                               const double *label_records, int32_t n_records,
+                               int32_t *cls_labels, double *boxes_3d,
+                               float *valid_boxes, int32_t *owner,
+                               void *stream);
 /* pgnn_box_encode_f32 evaluated in float64 on float64 boxes and a float64
  * class table, rounded to float32 once -- what train.py:120-130 computes
  * (`box_encoding_fn(cls_labels, xyz, boxes_3d_f64, label_map).astype(f32)`). */
@@ -457,6 +501,12 @@ int pgnn_box_encode_f64(const int32_t *cls_labels, const float *xyz,
                         const double *boxes, const double *class_table,
                         int32_t n_table, int64_t n_rows, int32_t boxes_per_row,
                         float *encoded, void *stream);
+/* ... with float64 vertices as well (train.py:120-122 in the training path). */
+int pgnn_box_encode_f64_xyz64(const int32_t *cls_labels, const double *xyz,
+                              const double *boxes, const double *class_table,
+                              int32_t n_table, int64_t n_rows,
+                              int32_t boxes_per_row, float *encoded,
+                              void *stream);
 
 /* Point-wise parts of the training augmentations (models/preprocess.py:44-78
  * random_rotation_all / random_flip_all, :239-326 random_box_shift) on a

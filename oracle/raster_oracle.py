@@ -219,11 +219,13 @@ def _fill_edge_collection(img, edges, color):
                 break
             if draw:
                 if not clipline:
+                    # the left end of a span is rounded UP, the right end
+                    # down: x1 = (x + XY_ONE - 1) >> XY_SHIFT, x2 = x >> XY_SHIFT
                     if keep_prelast.x > prelast.x:
-                        xa = prelast.x >> XY_SHIFT
+                        xa = (prelast.x + XY_ONE - 1) >> XY_SHIFT
                         xb = keep_prelast.x >> XY_SHIFT
                     else:
-                        xa = keep_prelast.x >> XY_SHIFT
+                        xa = (keep_prelast.x + XY_ONE - 1) >> XY_SHIFT
                         xb = prelast.x >> XY_SHIFT
                     if xa < width and xb >= 0:
                         xa = max(xa, 0)

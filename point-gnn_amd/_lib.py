@@ -50,6 +50,11 @@ _SIGNATURES = {
                                         c_vp, c_sz, c_vp, c_vp]),
     "pgnn_radius_graph_fill": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_f64, c_vp,
                                        c_vp, c_sz, c_vp, c_vp, c_i64, c_vp]),
+    "pgnn_radius_graph_count_f64": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_f64,
+                                            c_vp, c_vp, c_sz, c_vp, c_vp]),
+    "pgnn_radius_graph_fill_f64": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_f64,
+                                           c_vp, c_vp, c_sz, c_vp, c_vp, c_i64,
+                                           c_vp]),
     "pgnn_cap_neighbors_count": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp]),
     "pgnn_cap_neighbors_fill": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_u64, c_vp,
                                         c_vp, c_i64, c_vp]),
@@ -59,6 +64,9 @@ _SIGNATURES = {
     "pgnn_voxel_keypoints_random": (c_i32, [c_vp, c_i64, c_f64, c_vp, c_u64,
                                             c_vp, c_sz, c_vp, c_vp, c_vp,
                                             c_vp]),
+    "pgnn_voxel_keypoints_random_f64": (c_i32, [c_vp, c_i64, c_f64, c_vp, c_u64,
+                                                c_vp, c_sz, c_vp, c_vp, c_vp,
+                                                c_vp]),
     "pgnn_kdtree_shape": (c_i32, [c_i64, c_vp, c_vp]),
     "pgnn_kdtree_workspace_bytes": (c_sz, [c_i64]),
     "pgnn_kdtree_replica": (c_i32, [c_vp, c_i64, c_vp, c_sz, c_vp, c_vp, c_vp,
@@ -126,8 +134,12 @@ _SIGNATURES = {
     # training targets
     "pgnn_assign_box_labels": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_vp, c_vp,
                                        c_vp, c_vp, c_vp]),
+    "pgnn_assign_box_labels_f64": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_vp,
+                                           c_vp, c_vp, c_vp, c_vp]),
     "pgnn_box_encode_f64": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i64,
                                     c_i32, c_vp, c_vp]),
+    "pgnn_box_encode_f64_xyz64": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i64,
+                                          c_i32, c_vp, c_vp]),
     "pgnn_points_affine_f64": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "pgnn_points_in_box_f64": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp,
                                        c_vp]),

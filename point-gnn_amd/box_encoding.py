@@ -70,11 +70,16 @@ def _run(entry, cls_labels, points_xyz, boxes, label_map):
         b = to(boxes, torch.float64)
         rows, per_row = int(b.shape[0]), int(b.shape[1])
         lab = to(cls_labels, torch.int32).reshape(-1)
-        xyz = to(points_xyz, torch.float32)
+        # float64 vertices (the training path, train.py:120-122) are used
+        # as they are; float32 ones are widened inside the kernel
+        xyz64 = (np.asarray(points_xyz).dtype == np.float64) if not isinstance(
+            points_xyz, torch.Tensor) else points_xyz.dtype == torch.float64
+        xyz = to(points_xyz, torch.float64 if xyz64 else torch.float32)
         table = torch.from_numpy(class_table(label_map, np.float64)).to(dev)
         out = torch.empty(tuple(b.shape), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            _lib.check(lib.pgnn_box_encode_f64(
+            _lib.check((lib.pgnn_box_encode_f64_xyz64 if xyz64 else
+                        lib.pgnn_box_encode_f64)(
                 _lib.ptr(lab), _lib.ptr(xyz), _lib.ptr(b), _lib.ptr(table),
                 int(table.shape[0]), rows, per_row, _lib.ptr(out),
                 _lib.stream_ptr()), "pgnn_box_encode_f64")

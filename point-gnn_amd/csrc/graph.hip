@@ -71,18 +71,26 @@ __device__ __forceinline__ double npy_floor_divide_f64(double a, double b) {
   return fl;
 }
 
-// Voxel index of coordinate v (a float32 value held as double) along axis ax
-// under the keypoint grid's rule (grid_origin_kernel writes the record):
-//   rule[0..2] origin, rule[3..5] jitter, rule[6..8] float32 minimum, rule[9] mode
+// Voxel index of coordinate v along axis ax under the keypoint grid's rule
+// (grid_origin_kernel writes the record):
+//   rule[0..2] origin, rule[3..5] jitter, rule[6..8] cloud minimum, rule[9] mode
 //   mode 0: floor((v - origin) / voxel) in float64       ('center': open3d 0.7)
+//   float32 cloud (v is a float32 value held as double):
 //   mode 1: graph_gen.py:123-124   (points - offset) // voxel, ALL float32:
 //           float32 subtraction, NumPy floor_divide with float32(voxel)
 //   mode 2: graph_gen.py:126-128   (points - offset + voxel * rnd) // voxel:
 //           the float32 difference is promoted, the rest is float64
+//   float64 cloud (what train.py:88-90 passes after the augmentations):
+//   mode 3: graph_gen.py:123-124 in float64 throughout
+//   mode 4: graph_gen.py:126-128 in float64 throughout, (v - min) + jitter
 __device__ __forceinline__ int vox_cell(const double *__restrict__ rule, int ax,
                                         double v, double voxel) {
   const int mode = (int)rule[9];
   if (mode == 0) return cell_of(v, rule[ax], voxel);
+  if (mode >= 3) {
+    const double a = v - rule[6 + ax];
+    return (int)npy_floor_divide_f64(mode == 3 ? a : a + rule[3 + ax], voxel);
+  }
   const float a = (float)v - (float)rule[6 + ax];
   if (mode == 1) return (int)npy_floor_divide_f32(a, (float)voxel);
   return (int)npy_floor_divide_f64((double)a + rule[3 + ax], voxel);
@@ -94,7 +102,12 @@ struct Scale3 {
   int on;
 };
 
-__device__ __forceinline__ void load_point(const float *p, int64_t i,
+// T = float (run.py:219-222 feeds the float32 cloud) or double (the training
+// path: the augmented cloud stays float64 through graph generation,
+// train.py:88-90 -- every predicate below is float64 either way, only the
+// load differs)
+template <typename T>
+__device__ __forceinline__ void load_point(const T *p, int64_t i,
                                            const Scale3 &sc, double &x,
                                            double &y, double &z) {
   x = (double)p[3 * i];
@@ -108,20 +121,28 @@ __device__ __forceinline__ void load_point(const float *p, int64_t i,
 }
 
 // ---- build -------------------------------------------------------------------
-__global__ void cell_keys_kernel(const float *__restrict__ pts, int64_t n,
+template <typename T>
+__global__ void cell_keys_kernel(const T *__restrict__ pts, int64_t n,
                                  Scale3 sc, double ox, double oy, double oz,
                                  const double *__restrict__ origin_dev,
                                  double cell, uint32_t mask,
                                  uint32_t *__restrict__ keys,
-                                 uint32_t *__restrict__ vals) {
+                                 uint32_t *__restrict__ vals,
+                                 int32_t *__restrict__ vcell) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   double x, y, z;
   load_point(pts, i, sc, x, y, z);
   if (origin_dev) {  // keypoint grid: the rule record of grid_origin_kernel
-    keys[i] = cell_hash(vox_cell(origin_dev, 0, x, cell),
-                        vox_cell(origin_dev, 1, y, cell),
-                        vox_cell(origin_dev, 2, z, cell), mask);
+    // the voxel index is evaluated ONCE per point (NumPy's floor_divide is an
+    // fmod; the leader / pick kernels compare the stored integers)
+    const int vx = vox_cell(origin_dev, 0, x, cell),
+              vy = vox_cell(origin_dev, 1, y, cell),
+              vz = vox_cell(origin_dev, 2, z, cell);
+    keys[i] = cell_hash(vx, vy, vz, mask);
+    vcell[3 * i] = vx;
+    vcell[3 * i + 1] = vy;
+    vcell[3 * i + 2] = vz;
   } else {
     keys[i] = cell_hash(cell_of(x, ox, cell), cell_of(y, oy, cell),
                         cell_of(z, oz, cell), mask);
@@ -129,12 +150,15 @@ __global__ void cell_keys_kernel(const float *__restrict__ pts, int64_t n,
   vals[i] = (uint32_t)i;
 }
 
+template <typename T>
 __global__ void cell_bounds_kernel(const uint32_t *__restrict__ keys,
                                    const uint32_t *__restrict__ vals, int64_t n,
-                                   const float *__restrict__ pts, Scale3 sc,
+                                   const T *__restrict__ pts, Scale3 sc,
                                    int32_t *__restrict__ cell_start,
                                    int32_t *__restrict__ cell_end,
-                                   SortedPoint *__restrict__ sorted) {
+                                   SortedPoint *__restrict__ sorted,
+                                   const int32_t *__restrict__ vcell,
+                                   int32_t *__restrict__ vcell_sorted) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint32_t k = keys[i];
@@ -146,14 +170,19 @@ __global__ void cell_bounds_kernel(const uint32_t *__restrict__ keys,
   sp.idx = (int32_t)idx;
   sp.pad = 0;
   sorted[i] = sp;
+  if (vcell) {
+    vcell_sorted[3 * i] = vcell[3 * (int64_t)idx];
+    vcell_sorted[3 * i + 1] = vcell[3 * (int64_t)idx + 1];
+    vcell_sorted[3 * i + 2] = vcell[3 * (int64_t)idx + 2];
+  }
 }
 
 // ---- radius search -------------------------------------------------------------
 // One wave per centre.  FILL = false: write the neighbour count; FILL = true:
 // write (point, centre) rows at offsets[centre].
-template <bool FILL>
+template <bool FILL, typename T>
 __global__ __launch_bounds__(256) void radius_query_kernel(
-    const float *__restrict__ centers, int64_t n_centers, Scale3 sc, double r,
+    const T *__restrict__ centers, int64_t n_centers, Scale3 sc, double r,
     uint32_t mask, const int32_t *__restrict__ cell_start,
     const int32_t *__restrict__ cell_end,
     const SortedPoint *__restrict__ sorted, int32_t *__restrict__ counts,
@@ -279,28 +308,38 @@ __global__ __launch_bounds__(256) void cap_fill_kernel(
 }
 
 // ---- keypoints --------------------------------------------------------------------
-__device__ __forceinline__ uint32_t float_to_ordered(float f) {
-  uint32_t u = __float_as_uint(f);
-  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+// order-preserving map double -> uint64 (float32 inputs are widened first: the
+// widening is exact and monotone, so the minimum is the float32 minimum)
+__device__ __forceinline__ unsigned long long double_to_ordered(double f) {
+  unsigned long long u = (unsigned long long)__double_as_longlong(f);
+  return (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
 }
-__device__ __forceinline__ float ordered_to_float(uint32_t u) {
-  return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+__device__ __forceinline__ double ordered_to_double(unsigned long long u) {
+  return __longlong_as_double((long long)(
+      (u & 0x8000000000000000ull) ? (u & 0x7fffffffffffffffull) : ~u));
 }
 
-__global__ void min_bound_kernel(const float *__restrict__ pts, int64_t n,
-                                 uint32_t *__restrict__ ordered_min) {
-  uint32_t m0 = 0xffffffffu, m1 = 0xffffffffu, m2 = 0xffffffffu;
+template <typename T>
+__global__ void min_bound_kernel(const T *__restrict__ pts, int64_t n,
+                                 unsigned long long *__restrict__ ordered_min) {
+  unsigned long long m0 = ~0ull, m1 = ~0ull, m2 = ~0ull;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * blockDim.x) {
-    m0 = min(m0, float_to_ordered(pts[3 * i]));
-    m1 = min(m1, float_to_ordered(pts[3 * i + 1]));
-    m2 = min(m2, float_to_ordered(pts[3 * i + 2]));
+    const unsigned long long a = double_to_ordered((double)pts[3 * i]);
+    const unsigned long long b = double_to_ordered((double)pts[3 * i + 1]);
+    const unsigned long long c = double_to_ordered((double)pts[3 * i + 2]);
+    m0 = a < m0 ? a : m0;
+    m1 = b < m1 ? b : m1;
+    m2 = c < m2 ? c : m2;
   }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) {
-    m0 = min(m0, (uint32_t)__shfl_xor((int)m0, d));
-    m1 = min(m1, (uint32_t)__shfl_xor((int)m1, d));
-    m2 = min(m2, (uint32_t)__shfl_xor((int)m2, d));
+    const unsigned long long a = (unsigned long long)__shfl_xor((long long)m0, d);
+    const unsigned long long b = (unsigned long long)__shfl_xor((long long)m1, d);
+    const unsigned long long c = (unsigned long long)__shfl_xor((long long)m2, d);
+    m0 = a < m0 ? a : m0;
+    m1 = b < m1 ? b : m1;
+    m2 = c < m2 ? c : m2;
   }
   if ((threadIdx.x & 63) == 0) {
     atomicMin(&ordered_min[0], m0);
@@ -309,17 +348,17 @@ __global__ void min_bound_kernel(const float *__restrict__ pts, int64_t n,
   }
 }
 
-// origin[0..2] = grid origin, from the float32 minimum:
+// origin[0..2] = grid origin, from the cloud minimum:
 //   center mode (open3d 0.7): min - voxel/2
 //   random mode (graph_gen.py:108-128): min - jitter
-// mode: see vox_cell (0 center, 1 random, 2 random with jitter = sub_*)
-__global__ void grid_origin_kernel(const uint32_t *__restrict__ ordered_min,
-                                   double sub_x, double sub_y, double sub_z,
-                                   int mode, double *__restrict__ origin) {
+// mode: see vox_cell
+__global__ void grid_origin_kernel(
+    const unsigned long long *__restrict__ ordered_min, double sub_x,
+    double sub_y, double sub_z, int mode, double *__restrict__ origin) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     const double sub[3] = {sub_x, sub_y, sub_z};
     for (int ax = 0; ax < 3; ++ax) {
-      const double mn = (double)ordered_to_float(ordered_min[ax]);
+      const double mn = ordered_to_double(ordered_min[ax]);
       origin[ax] = mn - sub[ax];
       origin[3 + ax] = sub[ax];
       origin[6 + ax] = mn;
@@ -333,8 +372,7 @@ __global__ void grid_origin_kernel(const uint32_t *__restrict__ ordered_min,
 // this is open3d's accumulation order -- and stores the float64 mean.
 __global__ void voxel_leader_kernel(const SortedPoint *__restrict__ sorted,
                                     const uint32_t *__restrict__ keys, int64_t n,
-                                    const double *__restrict__ origin,
-                                    double voxel,
+                                    const int32_t *__restrict__ vc,
                                     const int32_t *__restrict__ cell_start,
                                     const int32_t *__restrict__ cell_end,
                                     int32_t *__restrict__ is_leader,
@@ -342,16 +380,12 @@ __global__ void voxel_leader_kernel(const SortedPoint *__restrict__ sorted,
                                     int32_t *__restrict__ member_count) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const SortedPoint me = sorted[i];
-  const int vx = vox_cell(origin, 0, me.x, voxel), vy = vox_cell(origin, 1, me.y, voxel),
-            vz = vox_cell(origin, 2, me.z, voxel);
+  const int vx = vc[3 * i], vy = vc[3 * i + 1], vz = vc[3 * i + 2];
   const uint32_t b = keys[i];
   const int s = cell_start[b], e = cell_end[b];
   bool leader = true;
   for (int j = s; j < (int)i; ++j) {
-    const SortedPoint o = sorted[j];
-    if (vox_cell(origin, 0, o.x, voxel) == vx && vox_cell(origin, 1, o.y, voxel) == vy &&
-        vox_cell(origin, 2, o.z, voxel) == vz) {
+    if (vc[3 * j] == vx && vc[3 * j + 1] == vy && vc[3 * j + 2] == vz) {
       leader = false;
       break;
     }
@@ -361,9 +395,8 @@ __global__ void voxel_leader_kernel(const SortedPoint *__restrict__ sorted,
   double sx = 0.0, sy = 0.0, sz = 0.0;
   int cnt = 0;
   for (int j = (int)i; j < e; ++j) {
-    const SortedPoint o = sorted[j];
-    if (vox_cell(origin, 0, o.x, voxel) == vx && vox_cell(origin, 1, o.y, voxel) == vy &&
-        vox_cell(origin, 2, o.z, voxel) == vz) {
+    if (vc[3 * j] == vx && vc[3 * j + 1] == vy && vc[3 * j + 2] == vz) {
+      const SortedPoint o = sorted[j];
       sx += o.x;
       sy += o.y;
       sz += o.z;
@@ -441,30 +474,28 @@ __global__ __launch_bounds__(256) void voxel_nn_kernel(
 }
 
 // random mode: the leader picks member floor(u * count) of its voxel
+template <typename T>
 __global__ void voxel_random_pick_kernel(
     const SortedPoint *__restrict__ sorted, const uint32_t *__restrict__ keys,
-    int64_t n, const double *__restrict__ origin, double voxel,
+    int64_t n, const int32_t *__restrict__ vc,
     const int32_t *__restrict__ cell_end, const int32_t *__restrict__ is_leader,
     const int32_t *__restrict__ slot, const int32_t *__restrict__ member_count,
-    uint64_t seed, const float *__restrict__ pts, int32_t *__restrict__ kp_idx,
-    float *__restrict__ kp_xyz) {
+    uint64_t seed, const T *__restrict__ pts, int32_t *__restrict__ kp_idx,
+    T *__restrict__ kp_xyz) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n || !is_leader[i]) return;
-  const SortedPoint me = sorted[i];
-  const int vx = vox_cell(origin, 0, me.x, voxel), vy = vox_cell(origin, 1, me.y, voxel),
-            vz = vox_cell(origin, 2, me.z, voxel);
+  const int my_idx = sorted[i].idx;
+  const int vx = vc[3 * i], vy = vc[3 * i + 1], vz = vc[3 * i + 2];
   const int cnt = member_count[i];
-  const uint64_t h = mix64(seed ^ mix64((uint64_t)me.idx + 0x632be59bd9b4e019ull));
+  const uint64_t h = mix64(seed ^ mix64((uint64_t)my_idx + 0x632be59bd9b4e019ull));
   int target = (int)((h >> 11) * (1.0 / 9007199254740992.0) * (double)cnt);
   if (target >= cnt) target = cnt - 1;
   const int e = cell_end[keys[i]];
-  int chosen = me.idx, seen = 0;
+  int chosen = my_idx, seen = 0;
   for (int j = (int)i; j < e; ++j) {
-    const SortedPoint o = sorted[j];
-    if (vox_cell(origin, 0, o.x, voxel) == vx && vox_cell(origin, 1, o.y, voxel) == vy &&
-        vox_cell(origin, 2, o.z, voxel) == vz) {
+    if (vc[3 * j] == vx && vc[3 * j + 1] == vy && vc[3 * j + 2] == vz) {
       if (seen == target) {
-        chosen = o.idx;
+        chosen = sorted[j].idx;
         break;
       }
       ++seen;
@@ -477,8 +508,16 @@ __global__ void voxel_random_pick_kernel(
   kp_xyz[3 * k + 2] = pts[3 * (int64_t)chosen + 2];
 }
 
-__global__ void copy_total_kernel(const int32_t *src, int32_t *dst) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) *dst = *src;
+// num[0] = K; num[1] = tie-order status of the kd-tree replica (0 = the
+// reference's order, 1 = libstdc++'s heap-select fallback would have run and
+// is not replicated: exact ties then follow a different, still deterministic
+// order); kd_status null (random mode / ablation): 0
+__global__ void copy_total_kernel(const int32_t *src,
+                                  const int32_t *kd_status, int32_t *num) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    num[0] = *src;
+    num[1] = kd_status ? *kd_status : 0;
+  }
 }
 
 // ---- host-side helpers ---------------------------------------------------------------
@@ -528,24 +567,26 @@ int grid_carve(Arena &a, int64_t n, Grid &g) {
   return 0;
 }
 
-int grid_build(const float *pts, int64_t n, const Scale3 &sc, double ox,
+template <typename T>
+int grid_build(const T *pts, int64_t n, const Scale3 &sc, double ox,
                double oy, double oz, const double *origin_dev, double cell,
-               Grid &g, hipStream_t stream) {
+               Grid &g, hipStream_t stream, int32_t *vcell = nullptr,
+               int32_t *vcell_sorted = nullptr) {
   const size_t nbuckets = (size_t)1 << g.bits;
   PGNN_HIP(hipMemsetAsync(g.cell_start, 0, nbuckets * 4, stream));
   PGNN_HIP(hipMemsetAsync(g.cell_end, 0, nbuckets * 4, stream));
   if (n <= 0) return 0;
   const unsigned blocks = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL(cell_keys_kernel, dim3(blocks), dim3(256), 0, stream, pts,
+  hipLaunchKernelGGL(cell_keys_kernel<T>, dim3(blocks), dim3(256), 0, stream, pts,
                      n, sc, ox, oy, oz, origin_dev, cell, g.mask, g.keys_a,
-                     g.vals_a);
+                     g.vals_a, vcell);
   int rc = radix_sort_pairs(g.keys_a, g.vals_a, g.keys_b, g.vals_b, n, g.bits,
                             g.sort_scratch, g.sort_scratch_bytes, &g.keys,
                             &g.vals, stream);
   if (rc) return rc;
-  hipLaunchKernelGGL(cell_bounds_kernel, dim3(blocks), dim3(256), 0, stream,
+  hipLaunchKernelGGL(cell_bounds_kernel<T>, dim3(blocks), dim3(256), 0, stream,
                      g.keys, g.vals, n, pts, sc, g.cell_start, g.cell_end,
-                     g.sorted);
+                     g.sorted, (const int32_t *)vcell, vcell_sorted);
   PGNN_HIP(hipGetLastError());
   return 0;
 }
@@ -597,13 +638,13 @@ int radius_carve(void *ws, size_t ws_bytes, int64_t n_points, int64_t n_centers,
 }
 }  // namespace
 
-extern "C" int pgnn_radius_graph_count(const float *points, int64_t n_points,
-                                       const float *centers, int64_t n_centers,
-                                       double radius, const double *scale3_host,
-                                       void *workspace, size_t workspace_bytes,
-                                       int32_t *offsets, void *stream_) {
-  PGNN_GUARD_BEGIN
-  hipStream_t stream = (hipStream_t)stream_;
+namespace {
+template <typename T>
+int radius_count_impl(const T *points, int64_t n_points, const T *centers,
+                      int64_t n_centers, double radius,
+                      const double *scale3_host, void *workspace,
+                      size_t workspace_bytes, int32_t *offsets,
+                      hipStream_t stream) {
   PGNN_REQUIRE(n_points >= 0 && n_centers >= 0 && radius > 0.0 &&
                    offsets != nullptr,
                PGNN_E_INVALID, "radius_graph_count: bad argument");
@@ -617,7 +658,7 @@ extern "C" int pgnn_radius_graph_count(const float *points, int64_t n_points,
                   stream);
   if (rc) return rc;
   if (n_centers > 0) {
-    hipLaunchKernelGGL(radius_query_kernel<false>,
+    hipLaunchKernelGGL((radius_query_kernel<false, T>),
                        dim3((unsigned)((n_centers + 3) / 4)), dim3(256), 0,
                        stream, centers, n_centers, sc, radius, w.g.mask,
                        w.g.cell_start, w.g.cell_end, w.g.sorted, w.counts,
@@ -627,6 +668,43 @@ extern "C" int pgnn_radius_graph_count(const float *points, int64_t n_points,
   }
   return exclusive_scan_i32(w.counts, offsets, n_centers, w.scan_scratch,
                             w.scan_bytes, stream);
+}
+
+template <typename T>
+int radius_fill_impl(const T *points, int64_t n_points, const T *centers,
+                     int64_t n_centers, double radius,
+                     const double *scale3_host, void *workspace,
+                     size_t workspace_bytes, const int32_t *offsets,
+                     int32_t *edges, int64_t capacity, hipStream_t stream) {
+  PGNN_REQUIRE(n_points >= 0 && n_centers >= 0 && radius > 0.0 && offsets &&
+                   capacity >= 0,
+               PGNN_E_INVALID, "radius_graph_fill: bad argument");
+  if (n_centers == 0 || capacity == 0) return 0;
+  PGNN_REQUIRE(edges && points && centers, PGNN_E_INVALID,
+               "radius_graph_fill: null pointer");
+  RadiusWs w;  // same carve as _count: the grid built there is reused
+  int rc = radius_carve(workspace, workspace_bytes, n_points, n_centers, w);
+  if (rc) return rc;
+  const Scale3 sc = make_scale(scale3_host);
+  hipLaunchKernelGGL((radius_query_kernel<true, T>),
+                     dim3((unsigned)((n_centers + 3) / 4)), dim3(256), 0, stream,
+                     centers, n_centers, sc, radius, w.g.mask, w.g.cell_start,
+                     w.g.cell_end, w.g.sorted, (int32_t *)nullptr, offsets,
+                     edges, capacity);
+  PGNN_HIP(hipGetLastError());
+  return 0;
+}
+}  // namespace
+
+extern "C" int pgnn_radius_graph_count(const float *points, int64_t n_points,
+                                       const float *centers, int64_t n_centers,
+                                       double radius, const double *scale3_host,
+                                       void *workspace, size_t workspace_bytes,
+                                       int32_t *offsets, void *stream_) {
+  PGNN_GUARD_BEGIN
+  return radius_count_impl(points, n_points, centers, n_centers, radius,
+                           scale3_host, workspace, workspace_bytes, offsets,
+                           (hipStream_t)stream_);
   PGNN_GUARD_END
 }
 
@@ -637,25 +715,32 @@ extern "C" int pgnn_radius_graph_fill(const float *points, int64_t n_points,
                                       const int32_t *offsets, int32_t *edges,
                                       int64_t capacity, void *stream_) {
   PGNN_GUARD_BEGIN
-  hipStream_t stream = (hipStream_t)stream_;
-  PGNN_REQUIRE(n_points >= 0 && n_centers >= 0 && radius > 0.0 && offsets &&
-                   capacity >= 0,
-               PGNN_E_INVALID, "radius_graph_fill: bad argument");
-  if (n_centers == 0 || capacity == 0) return 0;
-  PGNN_REQUIRE(edges && points && centers, PGNN_E_INVALID,
-               "radius_graph_fill: null pointer");
-  RadiusWs w;  // same carve as _count: the grid built there is reused
-  int rc = radius_carve(workspace, workspace_bytes, n_points, n_centers, w);
-  if (rc) return rc;
-  // keys/vals ping-pong: after an even number of passes the result is in *_a
-  const Scale3 sc = make_scale(scale3_host);
-  hipLaunchKernelGGL(radius_query_kernel<true>,
-                     dim3((unsigned)((n_centers + 3) / 4)), dim3(256), 0, stream,
-                     centers, n_centers, sc, radius, w.g.mask, w.g.cell_start,
-                     w.g.cell_end, w.g.sorted, (int32_t *)nullptr, offsets,
-                     edges, capacity);
-  PGNN_HIP(hipGetLastError());
-  return 0;
+  return radius_fill_impl(points, n_points, centers, n_centers, radius,
+                          scale3_host, workspace, workspace_bytes, offsets,
+                          edges, capacity, (hipStream_t)stream_);
+  PGNN_GUARD_END
+}
+
+extern "C" int pgnn_radius_graph_count_f64(
+    const double *points, int64_t n_points, const double *centers,
+    int64_t n_centers, double radius, const double *scale3_host,
+    void *workspace, size_t workspace_bytes, int32_t *offsets, void *stream_) {
+  PGNN_GUARD_BEGIN
+  return radius_count_impl(points, n_points, centers, n_centers, radius,
+                           scale3_host, workspace, workspace_bytes, offsets,
+                           (hipStream_t)stream_);
+  PGNN_GUARD_END
+}
+
+extern "C" int pgnn_radius_graph_fill_f64(
+    const double *points, int64_t n_points, const double *centers,
+    int64_t n_centers, double radius, const double *scale3_host,
+    void *workspace, size_t workspace_bytes, const int32_t *offsets,
+    int32_t *edges, int64_t capacity, void *stream_) {
+  PGNN_GUARD_BEGIN
+  return radius_fill_impl(points, n_points, centers, n_centers, radius,
+                          scale3_host, workspace, workspace_bytes, offsets,
+                          edges, capacity, (hipStream_t)stream_);
   PGNN_GUARD_END
 }
 
@@ -701,12 +786,14 @@ extern "C" int pgnn_cap_neighbors_fill(const int32_t *offsets,
 }
 
 // workspace layout (keypoints): [Grid | ordered_min[4] | voxel rule[10] |
-//   is_leader[n] | slot[n+1] | member_count[n] | centroid[3n] | scan scratch]
+//   is_leader[n] | slot[n+1] | member_count[n] | centroid[3n] | vcell[3n] x2 |
+//   scan scratch]
 extern "C" size_t pgnn_keypoints_workspace_bytes(int64_t n_points) {
   if (n_points < 0) return 0;
   const size_t n = (size_t)(n_points > 0 ? n_points : 1);
   return grid_bytes(n_points) + 256 + 256 + 3 * align_up((n + 1) * 4, 256) +
-         align_up(3 * n * 8, 256) + align_up(scan_scratch_bytes(n_points), 256) +
+         align_up(3 * n * 8, 256) + 2 * align_up(3 * n * 4, 256) +
+         align_up(scan_scratch_bytes(n_points), 256) +
          kd_workspace_bytes(n_points) + 2048;
 }
 
@@ -745,15 +832,39 @@ int fork_join_events(hipStream_t stream, hipStream_t aux, hipEvent_t *fork,
   return 0;
 }
 
-int keypoints_impl(const float *points, int64_t n, double voxel, bool center,
+inline int kd_build_any(const float *pts, int64_t n, Arena &a, KdBuild &kb,
+                        hipStream_t s) {
+  return kd_build(pts, n, a, kb, s);
+}
+inline int kd_build_any(const double *, int64_t, Arena &, KdBuild &,
+                        hipStream_t) {
+  return fail(PGNN_E_UNSUPPORTED, "keypoints: 'center' mode on float64 points");
+}
+inline void launch_voxel_nn(const Grid &g, int64_t n, const double *origin,
+                            double voxel, const int32_t *is_leader,
+                            const int32_t *slot, const double *centroid,
+                            const float *points, const KdView &kd,
+                            int32_t *kp_idx, float *kp_xyz, hipStream_t stream);
+inline void launch_voxel_nn(const Grid &, int64_t, const double *, double,
+                            const int32_t *, const int32_t *, const double *,
+                            const double *, const KdView &, int32_t *, double *,
+                            hipStream_t) {}
+
+template <typename T>
+int keypoints_impl(const T *points, int64_t n, double voxel, bool center,
                    const double *jitter3, uint64_t seed, void *workspace,
-                   size_t workspace_bytes, int32_t *kp_idx, float *kp_xyz,
+                   size_t workspace_bytes, int32_t *kp_idx, T *kp_xyz,
                    int32_t *num_kp, hipStream_t stream,
                    hipStream_t aux = nullptr) {
+  constexpr bool kF64 = sizeof(T) == 8;
   PGNN_REQUIRE(n >= 0 && voxel > 0.0 && kp_idx && kp_xyz && num_kp,
                PGNN_E_INVALID, "keypoints: bad argument");
+  // 'center' on a float64 cloud: the kd-tree replica keys are float32 and no
+  // shipped config asks for it (training uses 'random', run.py feeds float32)
+  PGNN_REQUIRE(!(center && kF64), PGNN_E_UNSUPPORTED,
+               "keypoints: 'center' mode takes float32 points");
   if (n == 0) {
-    PGNN_HIP(hipMemsetAsync(num_kp, 0, 4, stream));
+    PGNN_HIP(hipMemsetAsync(num_kp, 0, 8, stream));
     return 0;
   }
   PGNN_REQUIRE(points != nullptr, PGNN_E_INVALID, "keypoints: null points");
@@ -763,16 +874,18 @@ int keypoints_impl(const float *points, int64_t n, double voxel, bool center,
   Grid g;
   int rc = grid_carve(a, n, g);
   if (rc) return rc;
-  uint32_t *omin = a.take<uint32_t>(4);
+  unsigned long long *omin = a.take<unsigned long long>(4);
   double *origin = a.take<double>(kVoxRuleDoubles);
   int32_t *is_leader = a.take<int32_t>((size_t)n + 1);
   int32_t *slot = a.take<int32_t>((size_t)n + 1);
   int32_t *members = a.take<int32_t>((size_t)n + 1);
   double *centroid = a.take<double>(3 * (size_t)n);
+  int32_t *vcell = a.take<int32_t>(3 * (size_t)n);
+  int32_t *vcell_sorted = a.take<int32_t>(3 * (size_t)n);
   const size_t scan_bytes = scan_scratch_bytes(n);
   void *scan_scratch = a.take<char>(scan_bytes);
   PGNN_REQUIRE(omin && origin && is_leader && slot && members && centroid &&
-                   scan_scratch,
+                   vcell && vcell_sorted && scan_scratch,
                PGNN_E_WORKSPACE, "keypoints: workspace too small");
   // scikit-learn's kd-tree node order over the points decides exact ties
   // ('center' only).  It depends on nothing but the points: with an aux
@@ -782,6 +895,7 @@ int keypoints_impl(const float *points, int64_t n, double voxel, bool center,
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   kb.pos = nullptr;
   kb.bounds = nullptr;
+  kb.status = nullptr;
   kb.n_nodes = 0;
   const bool use_kd = center && !(g_graph_debug & 1);
   if (!use_kd && center) {  // ablation: a valid (all-zero) slot table
@@ -798,20 +912,20 @@ int keypoints_impl(const float *points, int64_t n, double voxel, bool center,
       PGNN_HIP(hipStreamWaitEvent(aux, ev_fork, 0));
       kd_stream = aux;
     }
-    rc = kd_build(points, n, a, kb, kd_stream);
+    rc = kd_build_any(points, n, a, kb, kd_stream);
     if (ev_join) {
       // join even when kd_build failed half-way: nothing may be left running
       // on aux that `stream`'s later work does not wait for
-      hipEventRecord(ev_join, aux);
-      hipStreamWaitEvent(stream, ev_join, 0);
+      (void)hipEventRecord(ev_join, aux);
+      (void)hipStreamWaitEvent(stream, ev_join, 0);
     }
     if (rc) return rc;
   }
-  PGNN_HIP(hipMemsetAsync(omin, 0xff, 16, stream));
+  PGNN_HIP(hipMemsetAsync(omin, 0xff, 32, stream));
   int mb = (int)((n + 255) / 256);
   if (mb > 1024) mb = 1024;
-  hipLaunchKernelGGL(min_bound_kernel, dim3(mb), dim3(256), 0, stream, points, n,
-                     omin);
+  hipLaunchKernelGGL(min_bound_kernel<T>, dim3(mb), dim3(256), 0, stream, points,
+                     n, omin);
   double sx, sy, sz;
   if (center) {
     sx = sy = sz = voxel * 0.5;  // open3d 0.7: origin = min_bound - voxel/2
@@ -820,36 +934,49 @@ int keypoints_impl(const float *points, int64_t n, double voxel, bool center,
     sy = jitter3 ? jitter3[1] : 0.0;
     sz = jitter3 ? jitter3[2] : 0.0;
   }
+  const int mode = center ? 0 : (kF64 ? (jitter3 ? 4 : 3) : (jitter3 ? 2 : 1));
   hipLaunchKernelGGL(grid_origin_kernel, dim3(1), dim3(64), 0, stream, omin, sx,
-                     sy, sz, center ? 0 : (jitter3 ? 2 : 1), origin);
+                     sy, sz, mode, origin);
   Scale3 sc = make_scale(nullptr);
-  rc = grid_build(points, n, sc, 0.0, 0.0, 0.0, origin, voxel, g, stream);
+  rc = grid_build(points, n, sc, 0.0, 0.0, 0.0, origin, voxel, g, stream, vcell,
+                  vcell_sorted);
   if (rc) return rc;
   const unsigned blocks = (unsigned)((n + 255) / 256);
   hipLaunchKernelGGL(voxel_leader_kernel, dim3(blocks), dim3(256), 0, stream,
-                     g.sorted, g.keys, n, origin, voxel, g.cell_start,
-                     g.cell_end, is_leader, centroid, members);
+                     g.sorted, g.keys, n, (const int32_t *)vcell_sorted,
+                     g.cell_start, g.cell_end, is_leader, centroid, members);
   rc = exclusive_scan_i32(is_leader, slot, n, scan_scratch, scan_bytes, stream);
   if (rc) return rc;
   hipLaunchKernelGGL(copy_total_kernel, dim3(1), dim3(64), 0, stream, slot + n,
-                     num_kp);
+                     (const int32_t *)kb.status, num_kp);
   if (center) {
     KdView kd;
     kd.pos = kb.pos;
     kd.bounds = kb.bounds;
     kd.n = (int32_t)n;
     kd.n_nodes = kb.n_nodes;
-    hipLaunchKernelGGL(voxel_nn_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256),
-                       0, stream, g.sorted, n, origin, voxel, g.mask,
-                       g.cell_start, g.cell_end, is_leader, slot, centroid,
-                       points, kd, kp_idx, kp_xyz);
+    launch_voxel_nn(g, n, origin, voxel, is_leader, slot, centroid, points, kd,
+                    kp_idx, kp_xyz, stream);
   } else {
-    hipLaunchKernelGGL(voxel_random_pick_kernel, dim3(blocks), dim3(256), 0,
-                       stream, g.sorted, g.keys, n, origin, voxel, g.cell_end,
-                       is_leader, slot, members, seed, points, kp_idx, kp_xyz);
+    hipLaunchKernelGGL(voxel_random_pick_kernel<T>, dim3(blocks), dim3(256), 0,
+                       stream, g.sorted, g.keys, n,
+                       (const int32_t *)vcell_sorted, g.cell_end, is_leader,
+                       slot, members, seed, points, kp_idx, kp_xyz);
   }
   PGNN_HIP(hipGetLastError());
   return 0;
+}
+
+inline void launch_voxel_nn(const Grid &g, int64_t n, const double *origin,
+                            double voxel, const int32_t *is_leader,
+                            const int32_t *slot, const double *centroid,
+                            const float *points, const KdView &kd,
+                            int32_t *kp_idx, float *kp_xyz,
+                            hipStream_t stream) {
+  hipLaunchKernelGGL(voxel_nn_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256),
+                     0, stream, g.sorted, n, origin, voxel, g.mask,
+                     g.cell_start, g.cell_end, is_leader, slot, centroid, points,
+                     kd, kp_idx, kp_xyz);
 }
 }  // namespace
 
@@ -872,6 +999,18 @@ extern "C" int pgnn_voxel_keypoints_random(
     const float *points, int64_t n_points, double voxel_size,
     const double *jitter3_host, uint64_t seed, void *workspace,
     size_t workspace_bytes, int32_t *keypoint_indices, float *keypoint_xyz,
+    int32_t *num_keypoints, void *stream) {
+  PGNN_GUARD_BEGIN
+  return keypoints_impl(points, n_points, voxel_size, false, jitter3_host, seed,
+                        workspace, workspace_bytes, keypoint_indices,
+                        keypoint_xyz, num_keypoints, (hipStream_t)stream);
+  PGNN_GUARD_END
+}
+
+extern "C" int pgnn_voxel_keypoints_random_f64(
+    const double *points, int64_t n_points, double voxel_size,
+    const double *jitter3_host, uint64_t seed, void *workspace,
+    size_t workspace_bytes, int32_t *keypoint_indices, double *keypoint_xyz,
     int32_t *num_keypoints, void *stream) {
   PGNN_GUARD_BEGIN
   return keypoints_impl(points, n_points, voxel_size, false, jitter3_host, seed,

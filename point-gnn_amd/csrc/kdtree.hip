@@ -600,8 +600,10 @@ size_t kd_workspace_bytes(int64_t n) {
 // carve + build on `stream`; arrays live in the caller's arena
 int kd_build(const float *pts, int64_t n, Arena &a, KdBuild &kd,
              hipStream_t stream) {
-  PGNN_REQUIRE(n >= 0 && n <= KD_MAX_POINTS, PGNN_E_INVALID,
-               "kdtree: more than 524288 points are not supported");
+  PGNN_REQUIRE(n >= 0, PGNN_E_INVALID, "kdtree: negative point count");
+  PGNN_REQUIRE(n <= KD_MAX_POINTS, PGNN_E_UNSUPPORTED,
+               "kdtree: more than 524288 points are not supported (the replica "
+               "of scikit-learn's KDTree keeps node records in LDS)");
   static_assert(KD_MAX_POINTS == 524288, "keep the message in step");
   kd_shape(n, &kd.n_levels, &kd.n_nodes);
   const size_t nn = (size_t)(n > 0 ? n : 1);

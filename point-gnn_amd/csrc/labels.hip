@@ -26,7 +26,10 @@ struct LabelRecord {
 };
 static_assert(sizeof(LabelRecord) == 24 * sizeof(double), "record layout");
 
-__global__ void assign_labels_kernel(const float *__restrict__ xyz, int64_t n,
+// T: float32 vertices (inference-side callers) or float64 (train.py:100-118
+// passes the float64 vertex_coord_list of the augmented cloud)
+template <typename T>
+__global__ void assign_labels_kernel(const T *__restrict__ xyz, int64_t n,
                                      const LabelRecord *__restrict__ rec,
                                      int n_rec, int32_t *__restrict__ cls,
                                      double *__restrict__ boxes,
@@ -70,8 +73,9 @@ __global__ void assign_labels_kernel(const float *__restrict__ xyz, int64_t n,
 // box_encoding.py:231-263 evaluated in float64 (float64 boxes, float32 points,
 // Python-float medians) and rounded to float32 once, as train.py:120-130 does
 // with `.astype(np.float32)`.  table64 rows = {l, h, w, yaw_offset, active}.
+template <typename T>
 __global__ void box_encode_f64_kernel(const int32_t *__restrict__ labels,
-                                      const float *__restrict__ xyz,
+                                      const T *__restrict__ xyz,
                                       const double *__restrict__ boxes,
                                       const double *__restrict__ table64,
                                       int n_table, int64_t rows, int per_row,
@@ -213,25 +217,65 @@ extern "C" int pgnn_points_in_box_f64(const double *xyz, int64_t n_points,
   PGNN_GUARD_END
 }
 
-extern "C" int pgnn_assign_box_labels(const float *xyz, int64_t n_points,
-                                      const double *label_records,
-                                      int32_t n_records, int32_t *cls_labels,
-                                      double *boxes_3d, float *valid_boxes,
-                                      int32_t *owner, void *stream_) {
-  PGNN_GUARD_BEGIN
-  hipStream_t stream = (hipStream_t)stream_;
+namespace {
+template <typename T>
+int assign_impl(const T *xyz, int64_t n_points, const double *label_records,
+                int32_t n_records, int32_t *cls_labels, double *boxes_3d,
+                float *valid_boxes, int32_t *owner, hipStream_t stream) {
   PGNN_REQUIRE(n_points >= 0 && n_records >= 0, PGNN_E_INVALID,
                "assign_box_labels: bad size");
   if (n_points == 0) return 0;
   PGNN_REQUIRE(xyz && (label_records || n_records == 0), PGNN_E_INVALID,
                "assign_box_labels: null pointer");
-  hipLaunchKernelGGL(assign_labels_kernel,
+  hipLaunchKernelGGL(assign_labels_kernel<T>,
                      dim3((unsigned)((n_points + 255) / 256)), dim3(256), 0,
                      stream, xyz, n_points,
                      reinterpret_cast<const LabelRecord *>(label_records),
                      n_records, cls_labels, boxes_3d, valid_boxes, owner);
   PGNN_HIP(hipGetLastError());
   return 0;
+}
+
+template <typename T>
+int encode64_impl(const int32_t *cls_labels, const T *xyz, const double *boxes,
+                  const double *class_table, int32_t n_table, int64_t n_rows,
+                  int32_t boxes_per_row, float *encoded, hipStream_t stream) {
+  PGNN_REQUIRE(n_rows >= 0 && boxes_per_row > 0 && n_table >= 0,
+               PGNN_E_INVALID, "box_encode_f64: bad size");
+  if (n_rows == 0) return 0;
+  PGNN_REQUIRE(cls_labels && xyz && boxes && encoded &&
+                   (class_table || n_table == 0),
+               PGNN_E_INVALID, "box_encode_f64: null pointer");
+  const int64_t total = n_rows * boxes_per_row;
+  hipLaunchKernelGGL(box_encode_f64_kernel<T>,
+                     dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     stream, cls_labels, xyz, boxes, class_table, n_table,
+                     n_rows, boxes_per_row, encoded);
+  PGNN_HIP(hipGetLastError());
+  return 0;
+}
+}  // namespace
+
+extern "C" int pgnn_assign_box_labels(const float *xyz, int64_t n_points,
+                                      const double *label_records,
+                                      int32_t n_records, int32_t *cls_labels,
+                                      double *boxes_3d, float *valid_boxes,
+                                      int32_t *owner, void *stream_) {
+  PGNN_GUARD_BEGIN
+  return assign_impl(xyz, n_points, label_records, n_records, cls_labels,
+                     boxes_3d, valid_boxes, owner, (hipStream_t)stream_);
+  PGNN_GUARD_END
+}
+
+extern "C" int pgnn_assign_box_labels_f64(const double *xyz, int64_t n_points,
+                                          const double *label_records,
+                                          int32_t n_records,
+                                          int32_t *cls_labels, double *boxes_3d,
+                                          float *valid_boxes, int32_t *owner,
+                                          void *stream_) {
+  PGNN_GUARD_BEGIN
+  return assign_impl(xyz, n_points, label_records, n_records, cls_labels,
+                     boxes_3d, valid_boxes, owner, (hipStream_t)stream_);
   PGNN_GUARD_END
 }
 
@@ -241,19 +285,19 @@ extern "C" int pgnn_box_encode_f64(const int32_t *cls_labels, const float *xyz,
                                    int64_t n_rows, int32_t boxes_per_row,
                                    float *encoded, void *stream_) {
   PGNN_GUARD_BEGIN
-  hipStream_t stream = (hipStream_t)stream_;
-  PGNN_REQUIRE(n_rows >= 0 && boxes_per_row > 0 && n_table >= 0,
-               PGNN_E_INVALID, "box_encode_f64: bad size");
-  if (n_rows == 0) return 0;
-  PGNN_REQUIRE(cls_labels && xyz && boxes && encoded &&
-                   (class_table || n_table == 0),
-               PGNN_E_INVALID, "box_encode_f64: null pointer");
-  const int64_t total = n_rows * boxes_per_row;
-  hipLaunchKernelGGL(box_encode_f64_kernel,
-                     dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                     stream, cls_labels, xyz, boxes, class_table, n_table,
-                     n_rows, boxes_per_row, encoded);
-  PGNN_HIP(hipGetLastError());
-  return 0;
+  return encode64_impl(cls_labels, xyz, boxes, class_table, n_table, n_rows,
+                       boxes_per_row, encoded, (hipStream_t)stream_);
+  PGNN_GUARD_END
+}
+
+extern "C" int pgnn_box_encode_f64_xyz64(const int32_t *cls_labels,
+                                         const double *xyz, const double *boxes,
+                                         const double *class_table,
+                                         int32_t n_table, int64_t n_rows,
+                                         int32_t boxes_per_row, float *encoded,
+                                         void *stream_) {
+  PGNN_GUARD_BEGIN
+  return encode64_impl(cls_labels, xyz, boxes, class_table, n_table, n_rows,
+                       boxes_per_row, encoded, (hipStream_t)stream_);
   PGNN_GUARD_END
 }

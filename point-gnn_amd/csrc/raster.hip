@@ -203,7 +203,9 @@ __device__ int row_intervals(const Poly &p, int w, int y, int (&lo)[6],
       }
     }
     for (int k = 0; k + 1 < na; k += 2) {
-      long long xa = act[k] >> kShift, xb = act[k + 1] >> kShift;
+      // FillEdgeCollection: left end rounded up, right end down
+      long long xa = (act[k] + ((1ll << kShift) - 1)) >> kShift,
+                xb = act[k + 1] >> kShift;
       if (xa < w && xb >= 0) {
         if (xa < 0) xa = 0;
         if (xb >= w) xb = w - 1;

@@ -20,6 +20,7 @@ int32; activations are kept zero-padded to a multiple of 16 columns
 """
 import contextlib
 import ctypes
+import threading
 from functools import partial
 
 import numpy as np
@@ -109,37 +110,48 @@ class Chain(object):
         self.n_out = int(layers[-1][0].shape[1])
 
 
-_state = {"store": None, "scope": []}
+class _State(threading.local):
+    """The bound ParamStore and the variable-scope stack, PER THREAD: two
+    Python threads driving operators (the frame pipeline's builder thread, a
+    serving front end) each see their own `parameters()` / `variable_scope()`
+    nesting, like tf.variable_scope's thread-local stack."""
+
+    def __init__(self):
+        self.store = None
+        self.scope = []
+
+
+_state = _State()
 
 
 @contextlib.contextmanager
 def parameters(store):
-    prev = _state["store"]
-    _state["store"] = store
+    prev = _state.store
+    _state.store = store
     try:
         yield store
     finally:
-        _state["store"] = prev
+        _state.store = prev
 
 
 @contextlib.contextmanager
 def variable_scope(name):
-    _state["scope"].append(name)
+    _state.scope.append(name)
     try:
         yield
     finally:
-        _state["scope"].pop()
+        _state.scope.pop()
 
 
 def _scope(*suffix):
-    return '/'.join(list(_state["scope"]) + list(suffix))
+    return '/'.join(list(_state.scope) + list(suffix))
 
 
 def _store():
-    if _state["store"] is None:
+    if _state.store is None:
         raise RuntimeError("no ParamStore bound: wrap the call in "
                            "`with pointgnn_amd.gnn.parameters(store):`")
-    return _state["store"]
+    return _state.store
 
 
 def _check_kinds(activation_type, normalization_type):

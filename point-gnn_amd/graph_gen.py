@@ -8,7 +8,10 @@ Same function names, keyword arguments and registry keys as the reference
 
 Array contract: NumPy in -> NumPy out (host round trip, drop-in); torch CUDA
 tensors in -> torch CUDA tensors out (device-resident fast path used by
-bench.py and the model).  Edges are int32 [E,2] rows (point_idx, centre_idx)
+bench.py and the model).  Coordinates keep their precision like in the
+reference: a float64 cloud (what train.py:88-90 passes after the
+augmentations) is voxelised and searched as float64 and its vertex lists come
+back float64; anything else is the float32 cloud run.py:219-222 feeds.  Edges are int32 [E,2] rows (point_idx, centre_idx)
 grouped by ascending centre -- the reference emits the same grouping
 (graph_gen.py:215-219) with an unspecified order inside a centre.  Keypoint
 order is ascending voxel-hash bucket (the reference's is open3d's hash-map
@@ -33,12 +36,39 @@ def _device():
     return torch.device("cuda", torch.cuda.current_device())
 
 
+def _to_dev(a):
+    """-> (contiguous CUDA tensor [n,3], was_numpy): float64 stays float64
+    (the reference's arithmetic on such a cloud is float64 throughout),
+    every other dtype becomes float32."""
+    if isinstance(a, torch.Tensor):
+        dt = torch.float64 if a.dtype == torch.float64 else torch.float32
+        return a.to(device=_device(), dtype=dt).contiguous(), False
+    arr = np.asarray(a)
+    dt = np.float64 if arr.dtype == np.float64 else np.float32
+    arr = np.ascontiguousarray(arr, dtype=dt)
+    return torch.from_numpy(arr).to(_device()), True
+
+
 def _to_dev_f32(a):
     """-> (contiguous float32 CUDA tensor [n,3], was_numpy)"""
-    if isinstance(a, torch.Tensor):
-        return a.to(device=_device(), dtype=torch.float32).contiguous(), False
-    arr = np.ascontiguousarray(np.asarray(a), dtype=np.float32)
-    return torch.from_numpy(arr).to(_device()), True
+    t, was_np = _to_dev(a)
+    return t.to(torch.float32), was_np
+
+
+def _same_precision(points, centers):
+    """Both operands of a radius query in one dtype: float64 as soon as one of
+    them is (widening float32 is exact, so this is what NumPy's promotion in
+    sklearn's float64 tree does), float32 otherwise."""
+    if points.dtype == torch.float64 or centers.dtype == torch.float64:
+        return (points.to(torch.float64).contiguous(),
+                centers.to(torch.float64).contiguous(), True)
+    return points, centers, False
+
+
+# what to do when the kd-tree replica reports that libstdc++'s heap-select
+# fallback would have run (pgnn_kdtree_replica `status`): exact 1-NN ties of
+# that frame may then be broken differently from the reference's sklearn call
+KD_STATUS_POLICY = 'raise'   # or 'warn'
 
 
 def _scale3(scale):
@@ -55,19 +85,24 @@ def radius_graph_device(points, centers, radius, scale=None, num_neighbors=-1,
     [Q+1]).  One host sync (reading E) per call, two when capping."""
     lib = _lib.load()
     dev = points.device
+    points, centers, wide = _same_precision(points, centers)
+    count_fn = lib.pgnn_radius_graph_count_f64 if wide else \
+        lib.pgnn_radius_graph_count
+    fill_fn = lib.pgnn_radius_graph_fill_f64 if wide else \
+        lib.pgnn_radius_graph_fill
     n_p, n_c = int(points.shape[0]), int(centers.shape[0])
     ws_bytes = lib.pgnn_radius_graph_workspace_bytes(n_p, n_c)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     offsets = torch.empty(n_c + 1, dtype=torch.int32, device=dev)
     keep, sp = _scale3(scale)
     st = _lib.stream_ptr()
-    _lib.check(lib.pgnn_radius_graph_count(
+    _lib.check(count_fn(
         _lib.ptr(points), n_p, _lib.ptr(centers), n_c, float(radius), sp,
         _lib.ptr(ws), ws_bytes, _lib.ptr(offsets), st),
         "pgnn_radius_graph_count")
     n_e = int(offsets[-1].item())  # the one host sync
     edges = torch.empty((n_e, 2), dtype=torch.int32, device=dev)
-    _lib.check(lib.pgnn_radius_graph_fill(
+    _lib.check(fill_fn(
         _lib.ptr(points), n_p, _lib.ptr(centers), n_c, float(radius), sp,
         _lib.ptr(ws), ws_bytes, _lib.ptr(offsets), _lib.ptr(edges), n_e, st),
         "pgnn_radius_graph_fill")
@@ -102,26 +137,30 @@ def radius_graphs_device(queries):
     pend = []
     for points, centers, radius, scale in queries:
         dev = points.device
+        points, centers, wide = _same_precision(points, centers)
         n_p, n_c = int(points.shape[0]), int(centers.shape[0])
         ws_bytes = lib.pgnn_radius_graph_workspace_bytes(n_p, n_c)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         offsets = torch.empty(n_c + 1, dtype=torch.int32, device=dev)
         keep, sp = _scale3(scale)
-        _lib.check(lib.pgnn_radius_graph_count(
+        _lib.check((lib.pgnn_radius_graph_count_f64 if wide else
+                    lib.pgnn_radius_graph_count)(
             _lib.ptr(points), n_p, _lib.ptr(centers), n_c, float(radius), sp,
             _lib.ptr(ws), ws_bytes, _lib.ptr(offsets), st),
             "pgnn_radius_graph_count")
-        pend.append((points, centers, radius, keep, sp, ws, ws_bytes, offsets))
+        pend.append((points, centers, radius, keep, sp, ws, ws_bytes, offsets,
+                     wide))
     # the host read: the first one waits for every count pass enqueued above,
     # the others find their value already computed
     totals = [int(q[7][-1].item()) for q in pend]
     out = []
-    for (points, centers, radius, keep, sp, ws, ws_bytes, offsets), n_e in zip(
-            pend, totals):
+    for (points, centers, radius, keep, sp, ws, ws_bytes, offsets,
+         wide), n_e in zip(pend, totals):
         n_p, n_c = int(points.shape[0]), int(centers.shape[0])
         edges = torch.empty((int(n_e), 2), dtype=torch.int32,
                             device=points.device)
-        _lib.check(lib.pgnn_radius_graph_fill(
+        _lib.check((lib.pgnn_radius_graph_fill_f64 if wide else
+                    lib.pgnn_radius_graph_fill)(
             _lib.ptr(points), n_p, _lib.ptr(centers), n_c, float(radius), sp,
             _lib.ptr(ws), ws_bytes, _lib.ptr(offsets), _lib.ptr(edges),
             int(n_e), st), "pgnn_radius_graph_fill")
@@ -138,8 +177,8 @@ def gen_disjointed_rnn_local_graph_v3(
     if num_neighbors > 0 and neighbors_downsample_method != 'random':
         # the reference silently skips the cap for any other method name
         num_neighbors = -1
-    p, was_np = _to_dev_f32(points_xyz)
-    c, _ = _to_dev_f32(center_xyz)
+    p, was_np = _to_dev(points_xyz)
+    c, _ = _to_dev(center_xyz)
     if seed is None and num_neighbors > 0:
         seed = int(np.random.randint(0, 2 ** 31 - 1))
     edges, _ = radius_graph_device(p, c, radius, scale, num_neighbors,
@@ -177,16 +216,31 @@ def _aux_stream(dev):
 
 def keypoints_device(points, voxel_size, method='center', jitter=None, seed=0,
                      fork_kdtree=False):
-    """One pooling level.  Returns (coords float32 [K,3], indices int32 [K,1])
-    as device tensors.  One host sync (reading K)."""
+    """One pooling level.  Returns (coords [K,3] in the dtype of `points`,
+    indices int32 [K,1]) as device tensors.  One host sync (reading K and the
+    tie-order status together)."""
     lib = _lib.load()
     dev = points.device
     n = int(points.shape[0])
+    wide = points.dtype == torch.float64
+    if wide and method == 'center':
+        # the kd-tree replica keys are float32; a float64 cloud whose values
+        # are float32-representable (a widened float32 cloud) is the same
+        # computation, anything else has no device path (no shipped config:
+        # training uses 'random', run.py feeds the float32 cloud)
+        narrow = points.to(torch.float32)
+        if not bool((narrow.to(torch.float64) == points).all().item()):
+            raise NotImplementedError(
+                "downsample_method='center' on a float64 cloud that is not "
+                "float32-representable")
+        c, i = keypoints_device(narrow, voxel_size, 'center', jitter, seed,
+                                fork_kdtree)
+        return c.to(torch.float64), i
     ws_bytes = lib.pgnn_keypoints_workspace_bytes(n)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     kp_idx = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
-    kp_xyz = torch.empty((max(n, 1), 3), dtype=torch.float32, device=dev)
-    num = torch.empty(1, dtype=torch.int32, device=dev)  # always written
+    kp_xyz = torch.empty((max(n, 1), 3), dtype=points.dtype, device=dev)
+    num = torch.empty(2, dtype=torch.int32, device=dev)  # always written
     st = _lib.stream_ptr()
     if method == 'center':
         _lib.check(lib.pgnn_voxel_keypoints_center(
@@ -206,14 +260,24 @@ def keypoints_device(points, voxel_size, method='center', jitter=None, seed=0,
         if jitter is not None:
             jit = np.ascontiguousarray(np.asarray(jitter, np.float64).reshape(3))
             jp = ctypes.c_void_p(jit.ctypes.data)
-        _lib.check(lib.pgnn_voxel_keypoints_random(
+        _lib.check((lib.pgnn_voxel_keypoints_random_f64 if wide else
+                    lib.pgnn_voxel_keypoints_random)(
             _lib.ptr(points), n, float(voxel_size), jp,
             int(seed) & 0xFFFFFFFFFFFFFFFF, _lib.ptr(ws), ws_bytes,
             _lib.ptr(kp_idx), _lib.ptr(kp_xyz), _lib.ptr(num), st),
             "pgnn_voxel_keypoints_random")
     else:
         raise ValueError("unknown downsample method %r" % (method,))
-    k = int(num.item())
+    k, status = num.tolist()   # the one host read
+    if status != 0:
+        msg = ("kd-tree replica: std::nth_element's heap-select fallback "
+               "would have run on this cloud (not replicated); exact "
+               "nearest-neighbour ties of 'center' keypoints may differ from "
+               "the reference's sklearn order")
+        if KD_STATUS_POLICY == 'raise':
+            raise _lib.PointGnnHipError(msg)
+        import warnings
+        warnings.warn(msg, RuntimeWarning)
     return kp_xyz[:k], kp_idx[:k].reshape(k, 1)
 
 
@@ -248,7 +312,7 @@ def kdtree_replica(points):
 
 def _multi_layer_downsampling(points_xyz, base_voxel_size, levels, add_rnd3d,
                               method):
-    p, was_np = _to_dev_f32(points_xyz)
+    p, was_np = _to_dev(points_xyz)
     coords = [p]
     kp_list = []
     last_level = 0

@@ -352,7 +352,13 @@ def _assign(xyz, rec, want_boxes=True):
     as_numpy = not isinstance(xyz, torch.Tensor)
     dev = xyz.device if not as_numpy and xyz.is_cuda else \
         torch.device("cuda", 0)
-    p = torch.as_tensor(xyz).to(device=dev, dtype=torch.float32).contiguous()
+    p = torch.as_tensor(xyz)
+    # float64 vertices stay float64 (train.py:100-118 passes the float64
+    # vertex_coord_list of the augmented cloud; np.matmul then runs in float64
+    # on the exact coordinates); everything else is the float32 cloud
+    wide = p.dtype == torch.float64
+    p = p.to(device=dev, dtype=torch.float64 if wide else torch.float32
+             ).contiguous()
     n = int(p.shape[0])
     r = torch.from_numpy(np.ascontiguousarray(rec)).to(dev)
     cls = torch.empty((n,), dtype=torch.int32, device=dev)
@@ -361,7 +367,9 @@ def _assign(xyz, rec, want_boxes=True):
     valid = torch.empty((n,), dtype=torch.float32, device=dev)
     owner = torch.empty((n,), dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
-        _lib.check(lib.pgnn_assign_box_labels(
+        entry = lib.pgnn_assign_box_labels_f64 if wide else \
+            lib.pgnn_assign_box_labels
+        _lib.check(entry(
             _lib.ptr(p), n, _lib.ptr(r), int(r.shape[0]), _lib.ptr(cls),
             _lib.ptr(boxes) if boxes is not None else None, _lib.ptr(valid),
             _lib.ptr(owner), _lib.stream_ptr()), "pgnn_assign_box_labels")

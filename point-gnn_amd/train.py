@@ -118,15 +118,11 @@ def fetch_data(dataset, frame_idx, config, train_config, aug_fn=None):
     encoding.  Returns the 7-tuple `batch_data` / `Trainer.train_step` take
     (device tensors).
 
-    One deviation from the reference's order of casts: there the augmented
-    cloud stays float64 through graph generation, label assignment and box
-    encoding and is cast to float32 last (train.py:88-130); here it is rounded
-    to float32 right after the augmentations (`preprocess.finish`) because the
-    graph kernels take float32 points (as the inference path feeds them,
-    run.py:219-222).  Voxel / radius / in-box tests of a point within one
-    float32 ulp of a boundary can therefore fall on the other side than in the
-    reference; everything downstream of the rounded cloud is the reference's
-    arithmetic (float64 predicates on float32 coordinates)."""
+    Order of casts = the reference's: the augmented cloud is float64 from its
+    first `xyz.dot(R.T)` on, and graph generation (voxel keys, radius
+    predicate), label assignment and box encoding all see those float64
+    coordinates (train.py:88-122); float32 / int32 happen last
+    (train.py:123-130)."""
     from . import box_encoding, graph_gen, preprocess
     from .run import _input_features
     points = dataset.get_cam_points_in_image_with_rgb(
@@ -138,7 +134,6 @@ def fetch_data(dataset, frame_idx, config, train_config, aug_fn=None):
         aug_fn = preprocess.get_data_aug(
             train_config.get('data_aug_configs', []))
     points, labels = aug_fn(points, labels)
-    points = preprocess.finish(points)
     fn = graph_gen.get_graph_generate_fn(config['graph_gen_method'])
     coords, kps, edges = fn(points.xyz, **config['graph_gen_kwargs'])
     input_v = _input_features(config, points).contiguous()
@@ -150,7 +145,10 @@ def fetch_data(dataset, frame_idx, config, train_config, aug_fn=None):
         expend_factor=train_config.get('expend_factor', (1.0, 1.0, 1.0)))
     encoded = box_encoding.get_box_encoding_fn(config['box_encoding_method'])(
         cls_labels, last_xyz, boxes_3d, label_map)
-    return (input_v, coords, kps, edges, cls_labels, encoded, valid)
+    # train.py:123-130
+    coords = [c.to(torch.float32) for c in coords]
+    return (input_v.to(torch.float32), coords, kps, edges, cls_labels, encoded,
+            valid)
 
 
 def train_epochs(dataset, config, train_config, trainer=None, max_epoch=None,
@@ -263,6 +261,16 @@ class Trainer(object):
             # endpoint counts; the step below always uses the global ones
             raise NotImplementedError(
                 "unify_copies=False (every shipped train config sets it True)")
+        if self.train_config.get('is_pseudo_batch', False):
+            # train.py:559-575: gradient accumulation over tower-sized
+            # sub-batches; no shipped train config sets it
+            raise NotImplementedError(
+                "is_pseudo_batch (train.py:559-575): no shipped config uses it")
+        if int(self.train_config.get('COPY_PER_GPU', 1)) != 1:
+            # train.py:174-182: several towers per GPU; here one process per
+            # GPU takes batch_size / world frames in one merged batch
+            raise NotImplementedError(
+                "COPY_PER_GPU != 1 (train.py:174-182): no shipped config sets it")
         if not torch.cuda.is_available():
             raise _lib.PointGnnHipError("Trainer needs a GPU (no CPU fallback)")
         self.device = device or torch.device("cuda",

@@ -1,0 +1,253 @@
+"""Golden fixture for the float64 training data path (train.py:88-130): the
+reference keeps the augmented cloud float64 through graph generation, so
+voxel membership and the radius predicate are decided on float64 coordinates.
+
+    python tests/golden/make_golden_f64.py        (build container only)
+
+graph_f64.npz holds
+  * `xyz`  -- a float64 cloud: the seeded `tiny` cloud after a float64 yaw
+    rotation (what preprocess.random_rotation_all leaves behind: coordinates
+    that are NOT float32-representable), plus constructed probes, all far
+    away from the scene so that every probe is alone in its voxel:
+      - voxel probes: pairs of points a few float64 ulps either side of a
+        voxel face of the grid anchored at the cloud minimum (with and without
+        the origin jitter of add_rnd3d) -- the two points of a pair lie in
+        DIFFERENT voxels in the reference's float64 arithmetic and collapse
+        onto one float32 value when rounded (`probe_pairs`, `probe_pairs_jit`);
+      - radius probes: a centre point and satellites a few ulps inside / on /
+        outside its 1.0 m and 4.0 m spheres.
+  * the outputs of the REFERENCE's real `models/graph_gen.py` on it (imported
+    under stubs, tests/_refimport.py), NumPy / Python RNGs seeded to 0:
+      - gen_multi_level_local_graph_v3(downsample_method='random') with and
+        without add_rnd3d: keypoint indices and the level-0 / level-1 edge
+        lists it returned (level 1 uncapped so that the set is defined);
+      - gen_disjointed_rnn_local_graph_v3 on (cloud, its keypoints) and
+        (keypoints, keypoints) -- the same calls, spelled out, for the test
+        that feeds the reference's keypoints to the radius kernel.
+"""
+import os
+import random
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from _refimport import reference_graph_gen  # noqa: E402
+import pointgnn_amd  # noqa: E402,F401
+from pointgnn_amd import configs  # noqa: E402
+from pointgnn_amd.synthetic import synthetic_cloud  # noqa: E402
+
+VOXEL = 0.8
+
+
+def ulp_walk(x, steps):
+    for _ in range(abs(steps)):
+        x = np.nextafter(x, np.inf if steps > 0 else -np.inf)
+    return x
+
+
+def straddle(a0, k, shift, voxel=VOXEL):
+    """Two float64 coordinates p_lo < p_hi, a few ulps (of the largest
+    intermediate) apart, with ((p - a0) + shift) // voxel == k - 1 and == k
+    under NumPy's arithmetic (shift = 0.0: the no-jitter expression has no
+    addition at all)."""
+    def cell(p):
+        d = np.float64(p) - np.float64(a0)
+        if shift != 0.0:
+            d = d + np.float64(shift)
+        return int(np.floor_divide(d, np.float64(voxel)))
+    p = np.float64(a0) + (np.float64(k) * voxel - np.float64(shift))
+    step = np.spacing(max(abs(p), abs(p - a0) + abs(shift), abs(a0)))
+    lo = hi = None
+    for s in range(-16, 17):
+        q = p + s * step
+        c = cell(q)
+        if c == k - 1:
+            lo = q
+        elif c == k and hi is None:
+            hi = q
+    assert lo is not None and hi is not None and lo < hi, (a0, k, shift)
+    assert hi - lo <= 4 * step
+    assert np.float32(lo) == np.float32(hi)     # float32 cannot tell them apart
+    return lo, hi
+
+
+def build_cloud():
+    xyz32, inten = synthetic_cloud(seed=2, preset="tiny")
+    yaw = 0.1234567
+    c, s = np.cos(yaw), np.sin(yaw)
+    rot = np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]])
+    xyz = xyz32.astype(np.float64).dot(rot.T)       # preprocess.py:55
+    assert not np.array_equal(xyz.astype(np.float32).astype(np.float64), xyz)
+    # the anchor fixes the cloud minimum (the reference's xyz_offset); every
+    # probe lives in the slab z in [a0z, a0z + 0.8), more than 5 m behind the
+    # nearest scene point, one probe group per y row (rows 1.6 m = 2 voxels
+    # apart), so that each probe point is alone in its voxel
+    a0 = np.floor(xyz.min(axis=0)) - np.array([6.0, 30.0, 6.0])
+    assert xyz[:, 2].min() - (a0[2] + VOXEL) > 4.5
+    extra = [a0.copy()]
+    # the jitter the reference will draw first after np.random.seed(0)
+    np.random.seed(0)
+    jit = VOXEL * np.random.random((1, 3))[0]
+    pairs, pairs_jit = [], []
+    pz = a0[2] + 0.3
+    row = [0]
+
+    def next_y():
+        row[0] += 1
+        return a0[1] + 0.3 + 1.6 * row[0]
+    for k in range(3, 11):
+        lo, hi = straddle(a0[0], k, 0.0)
+        i = len(xyz) + len(extra)
+        y = next_y()
+        extra += [np.array([lo, y, pz]), np.array([hi, y, pz])]
+        pairs.append((i, i + 1))
+    for k in range(14, 22):
+        lo, hi = straddle(a0[0], k, jit[0])
+        i = len(xyz) + len(extra)
+        y = next_y()
+        extra += [np.array([lo, y, pz]), np.array([hi, y, pz])]
+        pairs_jit.append((i, i + 1))
+    # radius probes: one (centre, satellite) couple per row, the satellite a
+    # few ulps inside / on / outside the centre's 1.0 m or 4.0 m sphere
+    centres = []
+    n = 0
+    for r in (1.0, 4.0):
+        for sgn in (1.0, -1.0):
+            for s in (-3, -1, 0, 1, 3):
+                n += 1
+                cx = a0[0] + 10.0 + 0.123456789 * n
+                y = next_y()
+                centres.append(len(xyz) + len(extra))
+                extra.append(np.array([cx, y, pz]))
+                extra.append(np.array(
+                    [ulp_walk(np.float64(cx) + sgn * r, s), y, pz]))
+    xyz = np.vstack([xyz] + [e[None, :] for e in extra])
+    assert np.array_equal(xyz.min(axis=0), a0)
+    return xyz, inten, np.array(pairs), np.array(pairs_jit), \
+        np.array(centres), jit
+
+
+def main():
+    gg = reference_graph_gen()
+    assert gg is not None, "needs /root/reference"
+    xyz, inten, pairs, pairs_jit, centres, jit = build_cloud()
+    cfg = configs.car_auto_config(3)
+    out = {"xyz": xyz, "probe_pairs": pairs, "probe_pairs_jit": pairs_jit,
+           "probe_centres": centres, "jitter": jit}
+    for tag, rnd in (("rand", False), ("randjit", True)):
+        np.random.seed(0)
+        random.seed(0)
+        kw = dict(cfg["graph_gen_kwargs"])
+        kw["add_rnd3d"] = rnd
+        # uncapped level 1: the capped edge list is a random subset
+        kw["level_configs"] = [dict(c) for c in kw["level_configs"]]
+        for c in kw["level_configs"]:
+            c["graph_gen_kwargs"] = dict(c["graph_gen_kwargs"],
+                                         num_neighbors=-1)
+        vc, ki, el = gg.gen_multi_level_local_graph_v3(xyz, **kw)
+        assert vc[1].dtype == np.float64
+        out["ref_%s_kp_idx" % tag] = ki[0].astype(np.int32)
+        out["ref_%s_edges0" % tag] = el[0].astype(np.int32)
+        out["ref_%s_edges1" % tag] = el[1].astype(np.int32)
+        kp = xyz[ki[0][:, 0]]
+        assert np.array_equal(kp, vc[1])
+        # the probes are alone in their voxels: both ends of every pair of
+        # this grid, and every radius-probe point, are keypoints
+        chosen = set(ki[0][:, 0].tolist())
+        mine = pairs_jit if rnd else pairs
+        assert all(a in chosen and b in chosen for a, b in mine), tag
+        assert all(c in chosen for c in centres), tag
+    # what float32 rounding of the cloud would have produced instead: the
+    # fixture is only worth something if it differs
+    x32 = xyz.astype(np.float32)
+    np.random.seed(0)
+    random.seed(0)
+    kw = dict(cfg["graph_gen_kwargs"])
+    kw["add_rnd3d"] = False
+    vc32, ki32, el32 = gg.gen_multi_level_local_graph_v3(x32, **kw)
+    out["f32_rand_num_kp"] = np.int32(len(ki32[0]))
+    assert len(ki32[0]) != len(out["ref_rand_kp_idx"]), \
+        "float32 rounding does not change the voxelisation of this fixture"
+    e64 = gg.gen_disjointed_rnn_local_graph_v3(
+        xyz, xyz[out["ref_rand_kp_idx"][:, 0]], radius=1.0, num_neighbors=-1)
+    e32 = gg.gen_disjointed_rnn_local_graph_v3(
+        x32, x32[out["ref_rand_kp_idx"][:, 0]], radius=1.0, num_neighbors=-1)
+    canon = lambda e: sorted(map(tuple, np.asarray(e).tolist()))
+    assert canon(e64) == canon(out["ref_rand_edges0"])
+    out["f32_rand_num_edges0"] = np.int32(len(e32))
+    assert len(e32) != len(e64), \
+        "float32 rounding does not change the level-0 edge set of this fixture"
+    np.savez_compressed(os.path.join(HERE, "graph_f64.npz"), **out)
+    print("graph_f64.npz", {k: np.shape(v) for k, v in out.items()},
+          "K64", len(out["ref_rand_kp_idx"]), "K32", len(ki32[0]),
+          "E0_64", len(e64), "E0_32", len(e32))
+
+
+def labels_main():
+    """labels_f64.npz: the reference's label assignment and box encoding on
+    FLOAT64 vertices (train.py:100-122 hands them the float64
+    vertex_coord_list): rotated seeded vertices plus, for ten boxes, vertices
+    within 1e-12 m of each of the six faces."""
+    import types
+    for name in ("open3d", "cv2"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.path.insert(0, "/root/reference")
+    try:
+        from dataset import kitti_dataset as kd
+        from models import box_encoding
+    finally:
+        sys.path.remove("/root/reference")
+    from oracle import labels_oracle as LO
+    x32 = LO.synthetic_vertices(0)
+    labels = LO.synthetic_labels(0, x32, n_boxes=60)
+    yaw = 0.05
+    c, s = np.cos(yaw), np.sin(yaw)
+    rot = np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]])
+    xyz = x32.astype(np.float64).dot(rot.T)
+    extra = []
+    face_sets = ([0, 1, 2, 3], [4, 5, 6, 7], [0, 1, 4, 5], [2, 3, 6, 7],
+                 [0, 3, 4, 7], [1, 2, 5, 6])
+    for lab in labels[:10]:
+        corners = kd.box3d_to_cam_points(lab).xyz
+        centre = corners.mean(axis=0)
+        for f in face_sets:
+            fc = corners[f].mean(axis=0)
+            # a point of the face, pulled 30 % towards the box axis so that it
+            # is well inside the other four faces
+            fc = fc + 0.0 * (centre - fc)
+            n = (fc - centre) / np.linalg.norm(fc - centre)
+            for k in (-3, -1, 0, 1, 3):
+                extra.append(fc + k * 1e-12 * n)
+    xyz = np.vstack([xyz, np.array(extra)])
+    out = {"xyz": xyz, "n_labels": np.array(len(labels))}
+    ds = object.__new__(kd.KittiDataset)
+    methods = {"yaw": (8, "assign_classaware_label_to_points"),
+               "Car": (4, "assign_classaware_car_label_to_points"),
+               "Pedestrian_and_Cyclist": (
+                   6, "assign_classaware_ped_and_cyc_label_to_points")}
+    x32r = xyz.astype(np.float32)
+    for method, (nc, fn) in methods.items():
+        ds.num_classes = nc
+        cls, boxes, valid, lm = getattr(ds, fn)(labels, xyz, (1.0, 1.0, 1.0))
+        enc = box_encoding.classaware_all_class_box_encoding(
+            cls, xyz, boxes, lm).astype(np.float32)
+        cls32 = getattr(ds, fn)(labels, x32r, (1.0, 1.0, 1.0))[0]
+        out[method + "_cls"] = cls
+        out[method + "_boxes"] = boxes
+        out[method + "_valid"] = valid
+        out[method + "_encoded"] = enc
+        out[method + "_n_diff_f32"] = np.array(int((cls32 != cls).sum()))
+        print(method, "labelled", int((cls > 0).sum()),
+              "labels that float32 vertices change:", int((cls32 != cls).sum()))
+    assert out["yaw_n_diff_f32"] > 0
+    np.savez_compressed(os.path.join(HERE, "labels_f64.npz"), **out)
+
+
+if __name__ == "__main__":
+    main()
+    labels_main()

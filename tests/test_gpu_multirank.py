@@ -1,0 +1,68 @@
+"""Two `Trainer`s under nccl (= RCCL): the gradient all-reduce of config 4 on
+real hardware (train.py:178-181, 264-288, 397-405; util/tf_util.py:3-43).
+
+Needs two visible GPUs: with one it SKIPS (the gloo world-2 run of the same
+helpers on oracle gradients is tests/test_sharding_cpu.py)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(t_config, backend):
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["PGNN_TEST_T"] = str(t_config)
+    env["PGNN_TEST_BACKEND"] = backend
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()),
+           os.path.join(HERE, "_multirank_worker.py")]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    rows = [json.loads(l.split("MULTIRANK ", 1)[1])
+            for l in p.stdout.splitlines() if "MULTIRANK " in l]
+    assert sorted(r["rank"] for r in rows) == [0, 1]
+    for r in rows:
+        assert r["backend"] == backend and r["world"] == 2
+        assert r["same_on_all"] and r["weights_same"]
+        # float32 sums in a different order (two partial gradients added by
+        # the collective vs one pass over the merged batch; the adjoint
+        # scatter kernels use float atomics): rounding-level agreement
+        assert r["rel_fro_err"] < 2e-5, r
+        for k in ("cls_loss", "loc_loss", "reg_loss"):
+            assert abs(r["loss"][k] - r["loss_ref"][k]) <= \
+                1e-5 * max(1.0, abs(r["loss_ref"][k])), (k, r)
+        assert r["loss"]["num_endpoint"] == r["loss_ref"]["num_endpoint"]
+        assert r["loss"]["num_valid_endpoint"] == \
+            r["loss_ref"]["num_valid_endpoint"]
+
+
+@pytest.mark.parametrize("t_config", [1, 3])
+def test_two_rank_nccl_gradient_equals_merged_batch(t_config):
+    import torch
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs (have %d)" % (
+            torch.cuda.device_count() if torch.cuda.is_available() else 0))
+    _run(t_config, "nccl")
+
+
+def test_two_ranks_on_one_gpu_gloo_dry_run():
+    """The same worker with both ranks on cuda:0 and gloo collectives: what a
+    one-GPU box can execute of the two-rank step (everything but RCCL)."""
+    _run(1, "gloo")

@@ -343,3 +343,32 @@ def test_sched_ws_size_matches_header():
     slices = int(re.search(r"kWsMaxSlices\s*=\s*(\d+)", src).group(1))
     groups = int(re.search(r"kWsMaxGroups\s*=\s*(\d+)", src).group(1))
     assert 2 + slices * groups <= _lib.SCHED_WS_INTS
+
+
+def test_variable_scope_is_thread_local():
+    """gnn.parameters / gnn.variable_scope mirror tf.variable_scope: the stack
+    belongs to the calling thread, so two threads driving operators do not see
+    (or corrupt) each other's scope."""
+    import threading
+    from pointgnn_amd import gnn
+    seen = {}
+    gate_a, gate_b = threading.Event(), threading.Event()
+
+    def worker():
+        seen["store_in_thread"] = gnn._state.store
+        with gnn.variable_scope("other"):
+            gate_a.set()
+            gate_b.wait(5)
+            seen["scope_in_thread"] = gnn._scope("x")
+
+    store = gnn.ParamStore({})
+    with gnn.parameters(store), gnn.variable_scope("layer1"):
+        t = threading.Thread(target=worker)
+        t.start()
+        assert gate_a.wait(5)
+        assert gnn._scope("w") == "layer1/w"       # untouched by the thread
+        gate_b.set()
+        t.join()
+    assert seen["store_in_thread"] is None
+    assert seen["scope_in_thread"] == "other/x"
+    assert gnn._state.scope == [] and gnn._state.store is None

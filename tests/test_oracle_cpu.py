@@ -237,3 +237,53 @@ def test_random_keypoint_voxel_rule_is_numpy_floor_divide():
         assert ref.dtype == dtype
         got = np.array([_kernel_floor_divide(v, voxel, dtype) for v in vals])
         assert np.array_equal(got, ref)
+
+
+# ---- float64 clouds (the training data path, train.py:88-130) ----------------
+@pytest.mark.parametrize("tag,rnd", [("rand", False), ("randjit", True)])
+def test_oracle_on_float64_cloud_equals_reference_golden(tag, rnd):
+    """graph_f64.npz (tests/golden/make_golden_f64.py): the reference's own
+    graph_gen.py on a float64 cloud with points a few ulps either side of voxel
+    faces and of the search spheres.  The oracle, seeded alike, reproduces the
+    keypoints and both edge lists; the tree-free C predicate gives the same
+    edge sets."""
+    g = gold("graph_f64.npz")
+    xyz = g["xyz"]
+    assert xyz.dtype == np.float64
+    kw = dict(configs.car_auto_config(3)["graph_gen_kwargs"])
+    kw["add_rnd3d"] = rnd
+    kw["level_configs"] = [dict(c, graph_gen_kwargs=dict(
+        c["graph_gen_kwargs"], num_neighbors=-1)) for c in kw["level_configs"]]
+    np.random.seed(0)
+    random.seed(0)
+    coords, kps, edges = go.multi_level_graph(xyz, **kw)
+    assert np.array_equal(kps[0], g["ref_%s_kp_idx" % tag])
+    assert np.array_equal(edges[0], g["ref_%s_edges0" % tag])
+    assert np.array_equal(edges[1], g["ref_%s_edges1" % tag])
+    kp = xyz[g["ref_%s_kp_idx" % tag][:, 0]]
+    assert np.array_equal(go.radius_graph_c(xyz, kp, 1.0),
+                          go.canonical_edges(g["ref_%s_edges0" % tag]))
+    assert np.array_equal(go.radius_graph_c(kp, kp, 4.0),
+                          go.canonical_edges(g["ref_%s_edges1" % tag]))
+    # the fixture is only worth something if float32 rounding changes it
+    if not rnd:
+        x32 = xyz.astype(np.float32)
+        assert len(go.radius_graph_c(x32, x32[g["ref_rand_kp_idx"][:, 0]],
+                                     1.0)) == int(g["f32_rand_num_edges0"]) \
+            != len(g["ref_rand_edges0"])
+
+
+def test_labels_oracle_on_float64_vertices_equals_reference_golden():
+    from oracle import labels_oracle as LO
+    fix = gold("labels_f64.npz")
+    labels = LO.synthetic_labels(0, LO.synthetic_vertices(0),
+                                 n_boxes=int(fix["n_labels"]))
+    for m in ("yaw", "Car", "Pedestrian_and_Cyclist"):
+        cls, boxes, valid, _ = LO.assign_labels(labels, fix["xyz"],
+                                                (1.0, 1.0, 1.0), m)
+        assert np.array_equal(cls, fix[m + "_cls"])
+        assert np.array_equal(boxes, fix[m + "_boxes"])
+        assert np.array_equal(valid, fix[m + "_valid"])
+        cls32 = LO.assign_labels(labels, fix["xyz"].astype(np.float32),
+                                 (1.0, 1.0, 1.0), m)[0]
+        assert int((cls32 != cls).sum()) == int(fix[m + "_n_diff_f32"]) > 0

@@ -112,6 +112,39 @@ def test_convex_fill_is_outline_plus_interior():
             assert img[y, x] == 1
 
 
+def test_span_fill_stays_between_the_outline_pixels():
+    """FillEdgeCollection rounds the left end of a span UP and the right end
+    DOWN (x1 = (x + XY_ONE - 1) >> XY_SHIFT, x2 = x >> XY_SHIFT), so on every
+    row of a convex polygon the filled pixels lie between the leftmost and the
+    rightmost outline pixel of that row; flooring the left end sets the pixel
+    OUTSIDE a slanted left side whenever the crossing's fraction is >= 0.5."""
+    rng = np.random.default_rng(11)
+    n_rows = 0
+    for t in range(200):
+        c = rng.uniform(12, 28, 2)
+        l, w = rng.uniform(4, 20, 2)
+        a = rng.uniform(0, np.pi)
+        rot = np.array([[np.cos(a), np.sin(a)], [-np.sin(a), np.cos(a)]])
+        p = (np.array([[l, w], [l, -w], [-l, -w], [-l, w]]) / 2 @ rot.T
+             + c).astype(np.int64)
+        img = _fill(p, 40, 40)
+        outline = np.zeros_like(img)
+        for i in range(4):
+            for (x, y) in RO.line_pixels(40, 40, tuple(p[i]),
+                                         tuple(p[(i + 1) % 4])):
+                outline[y, x] = 1
+        assert np.all(img[outline > 0] == 1)
+        for y in range(40):
+            xs = np.nonzero(img[y])[0]
+            if len(xs) == 0:
+                assert outline[y].sum() == 0
+                continue
+            ox = np.nonzero(outline[y])[0]
+            assert xs[0] == ox[0] and xs[-1] == ox[-1], (t, y)
+            n_rows += 1
+    assert n_rows > 2000
+
+
 def test_fixture_reproduces():
     fix = np.load(os.path.join(GOLD, "raster_overlap.npz"))
     for tag in ("a10", "a100", "quad"):
