@@ -83,7 +83,72 @@ def time_kernel(fn, reps, torch):
     return start.elapsed_time(stop) * 1e-3 / reps
 
 
-def roofline_scatter_max(torch, edges1, n_k, width, reps=30):
+def live_pmc_scatter(preset, timeout_s=150):
+    """HBM bytes of the standalone scatter-max measured in THIS run: two
+    child processes under `rocprofv3 --kernel-trace --pmc <counter>` (FETCH_SIZE
+    and WRITE_SIZE in separate passes, as MI355X_MICROARCH.md prescribes) each
+    replay tools/kernel_bench.py scatter on seed 0 of `preset` -- the frame
+    the roofline is timed on.  Returns the dict tools/pmc_scatter_json.py
+    builds, or None (rocprofv3 missing / failed / timed out)."""
+    import shutil
+    import subprocess
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import pmc_scatter_json as pj
+    finally:
+        sys.path.pop(0)
+    tmp = tempfile.mkdtemp(prefix="pgnn_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    vals, kernel, wl = {}, None, None
+    try:
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            out_dir = os.path.join(tmp, c)
+            p = subprocess.run(
+                [rocprof, "--kernel-trace", "--pmc", c, "-d", out_dir, "-o",
+                 "pmc", "--", sys.executable,
+                 os.path.join(ROOT, "tools", "kernel_bench.py"), "scatter",
+                 "--reps", "3", "--preset", preset],
+                cwd="/tmp", env=env, capture_output=True, text=True,
+                timeout=timeout_s)
+            for line in p.stdout.splitlines():
+                if line.startswith("{"):
+                    wl = json.loads(line).get("workload")
+            db = None
+            for root, _, files in os.walk(out_dir):
+                for f in files:
+                    if f.endswith(".db"):
+                        db = os.path.join(root, f)
+            if p.returncode != 0 or db is None:
+                return None
+            avg, n, kernel = pj.avg_counter(db, c)
+            if avg is None:
+                return None
+            vals[c], vals[c + "_n"] = avg, n
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return {
+        "kernel": pj.short_kernel_name(kernel), "workload": wl,
+        "FETCH_SIZE_KiB": vals["FETCH_SIZE"],
+        "WRITE_SIZE_KiB": vals["WRITE_SIZE"],
+        "launches_averaged": vals["FETCH_SIZE_n"],
+        "hbm_bytes_per_launch":
+            (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024,
+        "write_note": pj.WRITE_NOTE,
+        "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in "
+                  "separate child runs of tools/kernel_bench.py scatter taken "
+                  "by this bench.py invocation; bytes = (2*FETCH_SIZE + "
+                  "WRITE_SIZE)*1024: KiB units, and FETCH_SIZE counts half of "
+                  "a wide coalesced read on gfx950 (MI355X_MICROARCH.md, HBM)",
+    }
+
+
+def roofline_scatter_max(torch, edges1, n_k, width, reps=30, live_pmc=None):
     """Standalone scatter-max on an [E1, C] fp32 matrix resident in HBM, dst
     ids of the real level-1 graph (sorted).  Algorithmic bytes per launch =
     E*C*4 + E*4 + K*C*4."""
@@ -101,13 +166,19 @@ def roofline_scatter_max(torch, edges1, n_k, width, reps=30):
         state["i"] += 1
     dur = time_kernel(run, reps, torch)
     alg = n_e * width * 4 + n_e * 4 + n_k * width * 4
-    # HBM traffic cannot be read from inside this process; it comes from the
-    # committed PMC pass of this same kernel (tools/pmc_scatter.sh) when that
-    # pass was taken on exactly this workload, else it stays null.
+    # HBM traffic cannot be read from inside this process: `live_pmc` (two
+    # rocprofv3 --pmc child runs of this same kernel on this same workload,
+    # taken by the caller) supplies it; failing that, the committed PMC pass
+    # (tools/pmc_scatter.sh) when it was taken on exactly this workload; else
+    # it stays null.
     traffic, traffic_src = None, None
+    if live_pmc is not None and live_pmc.get("workload") == {
+            "E": n_e, "C": width, "K": n_k}:
+        traffic = live_pmc["hbm_bytes_per_launch"]
+        traffic_src = "live: " + live_pmc["method"]
     import glob
-    for side in sorted(glob.glob(os.path.join(
-            ROOT, "profiles", "r*pmc_scatter_max*.json")), reverse=True):
+    for side in ([] if traffic is not None else sorted(glob.glob(os.path.join(
+            ROOT, "profiles", "r*pmc_scatter_max*.json")), reverse=True)):
         with open(side) as fh:
             pm = json.load(fh)
         wl = pm.get("workload", {})
@@ -122,6 +193,10 @@ def roofline_scatter_max(torch, edges1, n_k, width, reps=30):
         "bound": "hbm", "achieved": alg / dur / 1e9, "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": alg / dur / 1e9 / HBM_PEAK_GBS,
         "traffic": traffic, "algorithmic_bytes": alg,
+        "traffic_detail": None if live_pmc is None else {
+            k: live_pmc[k] for k in ("kernel", "FETCH_SIZE_KiB",
+                                     "WRITE_SIZE_KiB", "launches_averaged",
+                                     "write_note")},
         "avg_launch_us": dur * 1e6,
         "note": "duration includes the 4*K*C-byte lowest() fill memset",
         "scope": "the kernel BASELINE.json's metric and SURVEY 8(d) name "
@@ -227,17 +302,56 @@ def roofline_pool_kernel(torch, engine, reps=10, frame=None):
     }
 
 
+def _host_description():
+    """CPU model, core count and BLAS backend of this host (SURVEY.md 8d asks
+    for them next to the CPU baseline)."""
+    model = None
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.lower().startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    blas, threads = None, os.cpu_count() or 1
+    try:
+        import threadpoolctl
+        infos = threadpoolctl.threadpool_info()
+        for p in infos:
+            if p.get("user_api") == "blas":
+                blas = "%s %s (%s)" % (p.get("internal_api"), p.get("version"),
+                                       p.get("threading_layer", "?"))
+        threads = max([p.get('num_threads', 1) for p in infos] + [1])
+    except Exception:
+        pass
+    import platform
+    return {"cpu_model": model or platform.processor() or platform.machine(),
+            "host_cpu_count": os.cpu_count(), "blas": blas,
+            "blas_threads": int(threads)}
+
+
 def cpu_baseline(cfg, params, xyz, inten, budget_s=20.0):
     """The oracle (CPU port of the reference path: scikit-learn ball tree as
-    the reference calls it + NumPy/BLAS GNN) timed on this host.  Bounded: the
-    GNN part runs on the sub-graph of the first K' keypoints, K' chosen from a
-    short GEMM probe so the whole leg takes ~budget_s; throughput is scaled by
-    the edge fraction."""
+    the reference calls it + NumPy/BLAS GNN) timed on this host with SURVEY
+    8d's protocol: third-party imports before the clock, one warm-up, median
+    of 5 for the graph build (single-threaded as the reference ships it,
+    graph_gen.py:85,208); the GNN part (BLAS on all cores) is bounded: it runs
+    on the sub-graph of the first K' keypoints, K' chosen from a short GEMM
+    probe so that the whole leg stays near budget_s, one warm-up + median of
+    3, scaled by the FLOP fraction."""
     from oracle import graph_oracle as go
     from oracle import gnn_oracle as gn
-    t0 = time.perf_counter()
-    coords, kps, edges = go.multi_level_graph(xyz, **cfg['runtime_graph_gen_kwargs'])
-    t_graph = time.perf_counter() - t0
+    import sklearn.neighbors  # noqa: F401  (imported before the clock starts)
+    host = _host_description()
+    kw = cfg['runtime_graph_gen_kwargs']
+    coords, kps, edges = go.multi_level_graph(xyz, **kw)      # warm-up
+    t_graphs = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        go.multi_level_graph(xyz, **kw)
+        t_graphs.append(time.perf_counter() - t0)
+    t_graph = float(np.median(t_graphs))
     n_k = coords[1].shape[0]
     e0, e1 = np.asarray(edges[0]), np.asarray(edges[1])
     # GEMM probe -> sustained GFLOP/s of this host's BLAS
@@ -250,7 +364,8 @@ def cpu_baseline(cfg, params, xyz, inten, budget_s=20.0):
     gflops = 5 * 2 * 4096 * 304 * 304 / (time.perf_counter() - t) / 1e9
     total = algorithmic_flops_per_frame(cfg, n_k, len(e0), len(e1))
     est = total / (gflops * 1e9) * 1.5
-    frac = min(1.0, max(0.02, (budget_s - t_graph) / max(est, 1e-9)))
+    # 1 warm-up + 3 timed runs of the GNN share the remaining budget
+    frac = min(1.0, max(0.02, (budget_s - 6 * t_graph) / 4.0 / max(est, 1e-9)))
     k_sub = max(16, int(n_k * frac))
     m0 = e0[:, 1] < k_sub
     # level-1 sub-graph induced by the first k_sub keypoints
@@ -258,56 +373,109 @@ def cpu_baseline(cfg, params, xyz, inten, budget_s=20.0):
     sub_coords = [coords[0], coords[1][:k_sub], coords[2][:k_sub]]
     sub_kps = [kps[0][:k_sub], kps[1][:k_sub]]
     sub_edges = [e0[m0], e1[m1]]
-    t = time.perf_counter()
-    gn.predict(params, cfg, inten, sub_coords, sub_kps, sub_edges)
-    t_gnn_sub = time.perf_counter() - t
+    gn.predict(params, cfg, inten, sub_coords, sub_kps, sub_edges)  # warm-up
+    t_gnns = []
+    for _ in range(3):
+        t = time.perf_counter()
+        gn.predict(params, cfg, inten, sub_coords, sub_kps, sub_edges)
+        t_gnns.append(time.perf_counter() - t)
+    t_gnn_sub = float(np.median(t_gnns))
     sub_flops = algorithmic_flops_per_frame(cfg, k_sub, int(m0.sum()),
                                             int(m1.sum()))
     t_gnn_full = t_gnn_sub * total / max(sub_flops, 1)
-    try:
-        import threadpoolctl
-        threads = max([p.get('num_threads', 1)
-                       for p in threadpoolctl.threadpool_info()] + [1])
-    except Exception:
-        threads = os.cpu_count() or 1
-    return {
+    threads = host["blas_threads"]
+    out = {
         "value": 1.0 / (t_graph + t_gnn_full), "unit": "frames/s",
         "cores": int(threads), "kind": "port",
-        "sample": "1 frame: full graph build with the reference's sklearn "
-                  "calls, single-threaded as shipped (%.2f s); GNN oracle "
-                  "(NumPy fp32, BLAS threads=%d, %.0f GFLOP/s probe) on the "
-                  "sub-graph of the first %d of %d keypoints (%.1f%% of the "
-                  "frame's FLOPs, %.2f s) scaled to the full frame (%.1f s)"
-                  % (t_graph, threads, gflops, k_sub, n_k,
-                     100.0 * sub_flops / total, t_gnn_sub, t_gnn_full),
+        "sample": "1 frame (%s seed of the headline pool): graph build with "
+                  "the reference's sklearn calls, single-threaded as shipped, "
+                  "1 warm-up + median of 5 (%.2f s; min %.2f, max %.2f); GNN "
+                  "oracle (NumPy fp32, BLAS threads=%d, %.0f GFLOP/s probe) on "
+                  "the sub-graph of the first %d of %d keypoints (%.1f%% of "
+                  "the frame's FLOPs), 1 warm-up + median of 3 (%.2f s), "
+                  "scaled to the full frame (%.1f s)"
+                  % ("first", t_graph, min(t_graphs), max(t_graphs), threads,
+                     gflops, k_sub, n_k, 100.0 * sub_flops / total, t_gnn_sub,
+                     t_gnn_full),
         "gen_graph_s": t_graph, "gnn_inference_s_scaled": t_gnn_full,
-        "host_cpu_count": os.cpu_count(),
     }
+    out.update(host)
+    return out
 
 
-def run_train(args, torch, dev, rank, world, dist):
-    """BASELINE config 4: car_auto_T3 training step -- per rank and step:
-    training-mode graph build (voxel 0.8 m, random keypoints + origin jitter,
-    level-1 fan-in capped at 256) for `frames_per_gpu` frames, frame merge,
-    forward, loss, backward, ONE all-reduce of the flat gradient, SGD."""
+def roofline_graph(torch, cfg, coords):
+    """Radius-graph kernels alone (count pass + scan + fill pass per level, no
+    host read in between: the capacity is known from the frame's own graph):
+    edges/s and algorithmic bytes 12(P+Q) + 8E over the launch time.  These
+    kernels are latency-bound (~7 MB per frame), so the fraction of
+    the HBM peak is small by construction; reported as the spec asks."""
+    from pointgnn_amd import _lib
+    lib = _lib.load()
+    out = []
+    for lc in cfg['runtime_graph_gen_kwargs']['level_configs']:
+        lvl = lc['graph_level']
+        r = float(lc['graph_gen_kwargs']['radius'])
+        pts, ctr = coords[lvl].contiguous(), coords[lvl + 1].contiguous()
+        n_p, n_c = int(pts.shape[0]), int(ctr.shape[0])
+        ws_bytes = lib.pgnn_radius_graph_workspace_bytes(n_p, n_c)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=pts.device)
+        off = torch.empty(n_c + 1, dtype=torch.int32, device=pts.device)
+
+        def count():
+            _lib.check(lib.pgnn_radius_graph_count(
+                _lib.ptr(pts), n_p, _lib.ptr(ctr), n_c, r, None, _lib.ptr(ws),
+                ws_bytes, _lib.ptr(off), _lib.stream_ptr()), "count")
+        count()
+        n_e = int(off[-1].item())
+        edges = torch.empty((n_e, 2), dtype=torch.int32, device=pts.device)
+
+        def both():
+            count()
+            _lib.check(lib.pgnn_radius_graph_fill(
+                _lib.ptr(pts), n_p, _lib.ptr(ctr), n_c, r, None, _lib.ptr(ws),
+                ws_bytes, _lib.ptr(off), _lib.ptr(edges), n_e,
+                _lib.stream_ptr()), "fill")
+        dur = time_kernel(both, 20, torch)
+        alg = 12 * (n_p + n_c) + 8 * n_e
+        out.append({"level": lvl, "radius": r, "P": n_p, "Q": n_c, "E": n_e,
+                    "us": dur * 1e6, "edges_per_s": n_e / dur,
+                    "algorithmic_bytes": alg, "GB_per_s": alg / dur / 1e9,
+                    "frac_of_hbm_peak": alg / dur / 1e9 / HBM_PEAK_GBS})
+    tot_e = sum(o["E"] for o in out)
+    tot_t = sum(o["us"] for o in out) * 1e-6
+    return {"kernel": "radius graph: cell keys + radix sort + bounds + "
+                      "radius_query<count> + scan + radius_query<fill> "
+                      "(csrc/graph.hip, csrc/sort.hip), keypoints excluded",
+            "bound": "latency (HBM-side bytes are ~MB)", "levels": out,
+            "edges_per_s": tot_e / tot_t, "us": tot_t * 1e6,
+            "GB_per_s": sum(o["algorithmic_bytes"] for o in out) / tot_t / 1e9}
+
+
+def train_measure(torch, dev, rank, world, dist, config_name, preset, steps,
+                  warmup, frames, fpg=2, pipeline=True):
+    """BASELINE config 4: `steps` timed training steps of `config_name` --
+    per rank and step: training-mode graph build (voxel 0.8 m, random
+    keypoints + origin jitter, level-1 fan-in capped at 256) for `fpg` frames,
+    frame merge, forward, loss, backward, ONE all-reduce of the flat gradient,
+    SGD.  Returns (elapsed max over ranks, all-reduce ms, trainer, per-step
+    shapes [(K, E0, E1)], last loss dict)."""
     from pointgnn_amd import configs, graph_gen, train
     from pointgnn_amd.synthetic import synthetic_cloud
-    cfg = configs.get_config(args.config)
+    cfg = configs.get_config(config_name)
     # the gradient all-reduce runs on the default group (RCCL over xGMI)
     pg = dist.group.WORLD if dist is not None else None
     tr = train.Trainer(cfg, seed=0, device=dev, process_group=pg)
-    fpg = args.frames_per_gpu
-    n_steps = args.steps + args.warmup
+    n_steps = steps + warmup
     pool = {}
-    for s in range(args.frames):
-        xyz, inten = synthetic_cloud(seed=s, preset=args.preset)
+    for s in range(frames):
+        xyz, inten = synthetic_cloud(seed=s, preset=preset)
         pool[s] = (torch.from_numpy(xyz).to(dev), torch.from_numpy(inten).to(dev))
     fn = graph_gen.get_graph_generate_fn(cfg['graph_gen_method'])
     gen = torch.Generator(device='cpu').manual_seed(1234 + rank)
     np.random.seed(99 + rank)
 
     def make_frame(i):
-        x, f = pool[i % args.frames]
+        x, f = pool[i % frames]
         coords, kps, edges = fn(x, **cfg['graph_gen_kwargs'])
         k = int(coords[1].shape[0])
         lab = (torch.rand(k, generator=gen) < 0.2).to(torch.int32) * \
@@ -317,7 +485,7 @@ def run_train(args, torch, dev, rank, world, dist):
         valid = (lab > 0).to(torch.float32).reshape(k, 1, 1)
         return (f, coords, kps, edges, lab, boxes, valid)
 
-    shapes = {}
+    shapes = []
     # The data side (graph build + frame merge of step i+1) runs on its own
     # stream while step i's forward/backward occupy the compute stream -- the
     # reference hides it behind 16 loader processes (train.py:430-440).
@@ -328,9 +496,9 @@ def run_train(args, torch, dev, rank, world, dist):
         with torch.cuda.stream(sg):
             # every rank walks the whole frame pool (offset by its rank): the
             # same mix of graph sizes per GPU at every N
-            frames = [make_frame((rank + i) * fpg + j) for j in range(fpg)]
-            batch = train.batch_data(frames)
-            nv = float(sum(float(fr[6].sum().item()) for fr in frames))
+            fr = [make_frame((rank + i) * fpg + j) for j in range(fpg)]
+            batch = train.batch_data(fr)
+            nv = float(sum(float(x[6].sum().item()) for x in fr))
         return batch, nv
 
     def use(batch):
@@ -339,9 +507,8 @@ def run_train(args, torch, dev, rank, world, dist):
                 list(batch[3]) + list(batch[4:]):
             if isinstance(t, torch.Tensor) and t.is_cuda:
                 t.record_stream(cur)
-        shapes['K'] = int(batch[1][1].shape[0])
-        shapes['E0'] = int(batch[3][0].shape[0])
-        shapes['E1'] = int(batch[3][1].shape[0])
+        shapes.append((int(batch[1][1].shape[0]), int(batch[3][0].shape[0]),
+                       int(batch[3][1].shape[0])))
 
     state = {}
 
@@ -350,36 +517,61 @@ def run_train(args, torch, dev, rank, world, dist):
             state['next'] = make_batch(i)
         batch, nv = state.pop('next')
         use(batch)
-        if args.no_pipeline:
-            out = tr.train_step(batch, num_valid=nv)
-        else:
-            out = tr.train_step(
-                batch, num_valid=nv,
-                after_enqueue=lambda: state.__setitem__('next',
-                                                        make_batch(i + 1)))
-        return out
+        if not pipeline:
+            return tr.train_step(batch, num_valid=nv)
+        return tr.train_step(
+            batch, num_valid=nv,
+            after_enqueue=lambda: state.__setitem__('next', make_batch(i + 1)))
 
-    for i in range(args.warmup):
+    for i in range(warmup):
         step(i)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
+    _sync(torch, dist)
+    del shapes[:]
     tr.allreduce_events = []
     t0 = time.perf_counter()
-    for i in range(args.warmup, n_steps):
+    for i in range(warmup, n_steps):
         out = step(i)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
+    _sync(torch, dist)
     elapsed = time.perf_counter() - t0
     ar_ms = (sum(a.elapsed_time(b) for a, b in tr.allreduce_events) /
              max(1, len(tr.allreduce_events)))
-    if dist is not None:
-        t = torch.tensor([elapsed, ar_ms], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, ar_ms = float(t[0].item()), float(t[1].item())
+    tr.allreduce_events = None
+    elapsed, ar_ms = _max_over_ranks(torch, dist, dev, [elapsed, ar_ms])
+    return elapsed, ar_ms, tr, cfg, list(shapes), out
+
+
+def train_roofline(cfg, shapes, fpg, elapsed, steps):
+    """Whole-step MFMA roofline of the training step.  Algorithmic FLOPs per
+    step = 3 x the forward's algorithmic FLOPs (SURVEY 8d's per-row figures;
+    backward = dX and dW GEMMs of every layer, each the forward's size) at the
+    mean (K, E0, E1) of the timed merged batches; the kernels execute fewer:
+    the first edge layer is evaluated per vertex."""
+    a = np.asarray(shapes, dtype=np.float64)
+    fwd = float(np.mean([algorithmic_flops_per_frame(cfg, *map(int, r))
+                         for r in a]))
+    exe = float(np.mean([executed_flops_per_frame(cfg, *map(int, r))
+                         for r in a]))
+    per_step = elapsed / steps
+    return {
+        "kernel": "whole training step (forward + loss + backward + SGD)",
+        "bound": "mfma", "achieved": 3 * fwd / per_step / 1e12,
+        "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+        "frac": 3 * fwd / per_step / 1e12 / FP32_MFMA_PEAK_TF,
+        "formula": "3 * algorithmic_forward_flops(K, E0, E1 of the merged "
+                   "%d-frame batch) / step time / 157.3 TFLOP/s" % fpg,
+        "algorithmic_forward_gflop": fwd / 1e9,
+        "dense_executed_forward_gflop": exe / 1e9,
+        "batch_shape_mean": {"K": float(a[:, 0].mean()),
+                             "E0": float(a[:, 1].mean()),
+                             "E1": float(a[:, 2].mean())},
+    }
+
+
+def run_train(args, torch, dev, rank, world, dist):
+    fpg = args.frames_per_gpu
+    elapsed, ar_ms, tr, cfg, shapes, out = train_measure(
+        torch, dev, rank, world, dist, args.config, args.preset, args.steps,
+        args.warmup, args.frames, fpg, not args.no_pipeline)
     if rank == 0:
         res = {
             "metric": "training frames/sec (%s, fwd+loss+bwd+allreduce+SGD, "
@@ -395,7 +587,7 @@ def run_train(args, torch, dev, rank, world, dist):
                             % (args.config, fpg, world * fpg,
                                "" if args.no_pipeline else
                                " (next batch built on a second stream)"),
-                "last_batch_shape": shapes,
+                "last_batch_shape": dict(zip(("K", "E0", "E1"), shapes[-1])),
                 "params": int(tr.flat.numel()),
                 "allreduce_bytes": int(tr.flat.numel()) * 4,
                 # device time between the events that bracket the gradient
@@ -407,6 +599,7 @@ def run_train(args, torch, dev, rank, world, dist):
                                                   'reg_loss')},
                 "parallelism": "dp%d (frames sharded, one flat gradient "
                                "all-reduce per step)" % world},
+            "roofline": train_roofline(cfg, shapes, fpg, elapsed, args.steps),
         }
         print(json.dumps(res), flush=True)
 
@@ -455,6 +648,10 @@ def parse_args(argv=None):
                     help="distinct synthetic frames in the pool")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="do not spawn the two rocprofv3 --pmc child runs "
+                         "that measure roofline.traffic (uses the committed "
+                         "PMC pass of the same workload instead, if any)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the extra `car`-preset measurement")
     ap.add_argument("--no-pipeline", action="store_true",
@@ -614,6 +811,72 @@ def run_stub(args, torch, dev, rank, world, dist):
                        "distributed": dist_info(dist, world)}}), flush=True)
 
 
+def secondary_ped(args, torch, dev, measure):
+    """BASELINE config 5 (`ped_cyl_auto_T3`, dense scan: ~50k points, small
+    radii, C = 256): >= 10 pipelined frames of preset `ped_dense` plus the MFMA
+    rooflines of its edge and pooling kernels on the pool's first frame."""
+    from pointgnn_amd import configs, weights
+    from pointgnn_amd.engine import InferenceEngine
+    cfg = configs.get_config("ped_cyl_auto_T3")
+    params = weights.init_params(cfg, seed=0, bias_scale=0.05)
+    eng = InferenceEngine(cfg, params, device=dev)
+    steps = max(10, min(16, args.steps // 2))
+    elapsed, shapes, pool = measure("ped_dense", steps, 3, engine=eng,
+                                    n_frames=4)
+    st = pool_statistics(cfg, shapes)
+    out = {
+        "workload": "ped_cyl_auto_T3 inference, preset 'ped_dense' (4 seeded "
+                    "frames cycled), 1 frame/step, same pipeline",
+        "steps": steps, "frames_per_sec": steps / elapsed,
+        "ms_per_frame": elapsed / steps * 1e3, "N": 50000,
+        "K": st["K"], "E0": st["E0"], "E1": st["E1"],
+        "algorithmic_gflop_per_frame": st["alg_flops_mean"] / 1e9,
+        "executed_gflop_per_frame": st["exe_flops_mean"] / 1e9,
+        "algorithmic_tflops": st["alg_flops_mean"] * steps / elapsed / 1e12,
+        "executed_frac_of_fp32_mfma_peak":
+            st["exe_flops_mean"] * steps / elapsed / 1e12 / FP32_MFMA_PEAK_TF,
+    }
+    if not args.no_roofline:
+        first = sorted(pool)[0]
+        x, f = pool[first][:2]
+        eng.run_frame(x, f)
+        coords, kps, edges = eng.last_graph
+        n_k = int(coords[1].shape[0])
+        mf = roofline_edge_kernel(torch, eng, edges[1], n_k, frame=(x, f))
+        if mf is not None:
+            mf["workload"] = {"frame_seed": first,
+                              "E": int(edges[1].shape[0]), "K": n_k}
+            out["roofline_mfma"] = mf
+        pl = roofline_pool_kernel(torch, eng, frame=(x, f))
+        if pl is not None:
+            out["roofline_pool"] = pl
+    return out
+
+
+def secondary_train(args, torch, dev):
+    """BASELINE config 4 on one GPU (`car_auto_T3` training step, 2 frames per
+    step, training graph kwargs): >= 10 timed steps and the whole-step MFMA
+    roofline.  The 8-GPU form is `bench.py --train --gpus 8`."""
+    steps = max(10, min(16, args.steps // 2))
+    fpg = 2
+    elapsed, ar_ms, tr, cfg, shapes, out = train_measure(
+        torch, dev, 0, 1, None, "car_auto_T3", "car", steps, 4, 4, fpg, True)
+    res = {
+        "workload": "car_auto_T3 training step, %d frames/step, training "
+                    "graph kwargs (voxel 0.8, random keypoints + jitter, "
+                    "fan-in cap 256), graph build included (next batch built "
+                    "on a second stream), synthetic labels, preset 'car'" % fpg,
+        "steps": steps, "ms_per_step": elapsed / steps * 1e3,
+        "training_frames_per_sec": fpg * steps / elapsed,
+        "params": int(tr.flat.numel()),
+        "last_loss": {k: out[k] for k in ('cls_loss', 'loc_loss', 'reg_loss')},
+        "roofline": train_roofline(cfg, shapes, fpg, elapsed, steps),
+    }
+    del tr
+    torch.cuda.empty_cache()
+    return res
+
+
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse_args(argv)
@@ -649,9 +912,10 @@ def main(argv=None):
     params = weights.init_params(cfg, seed=0, bias_scale=0.05)
     engine = InferenceEngine(cfg, params, device=dev)
 
-    def measure(preset, steps, warmup):
+    def measure(preset, steps, warmup, engine=engine, n_frames=None):
         """Time `steps` frames per rank of `preset`; returns (elapsed max over
         ranks, all ranks' per-frame shapes, this rank's pool, last output)."""
+        n_frames = n_frames or args.frames
         # frame stream: rank r owns frames r, r+W, ...
         my_ids = shard_frames(world * (steps + warmup), rank, world)
 
@@ -659,7 +923,7 @@ def main(argv=None):
             # every rank cycles through ALL pool frames (rank r starts at
             # frame r), so the per-GPU work is the same mix at every N (weak
             # scaling); with `id % frames` rank 0 of 8 would see frame 0 only
-            return (my_ids[i] // world + rank) % args.frames
+            return (my_ids[i] // world + rank) % n_frames
         pool = {}
         for s in sorted({seed_of(i) for i in range(len(my_ids))}):
             xyz, inten = synthetic_cloud(seed=s, preset=preset)
@@ -708,6 +972,15 @@ def main(argv=None):
             "K": st2["K"], "E0": st2["E0"], "E1": st2["E1"],
             "algorithmic_gflop_per_frame": st2["alg_flops_mean"] / 1e9,
             "algorithmic_tflops": st2["alg_flops_mean"] * s2 / e2 / 1e12}
+
+    # BASELINE configs 5 and 4 in the same line (single-GPU runs of the
+    # headline command only; `--config ped_cyl_auto_T3` / `--train` are the
+    # full-length forms): the ped_cyl dense-scan stress and the training step
+    ped = trn = None
+    if world == 1 and not args.no_secondary and args.preset == "car_600k" \
+            and args.config == "car_auto_T3":
+        ped = secondary_ped(args, torch, dev, measure)
+        trn = secondary_train(args, torch, dev)
 
     if rank == 0:
         # per-phase wall clock of the pool's first frame (outside the timed
@@ -796,11 +1069,20 @@ def main(argv=None):
         }
         if second is not None:
             res["config"]["secondary"] = second
+        if ped is not None:
+            res["config"]["secondary_ped"] = ped
+        if trn is not None:
+            res["config"]["secondary_train"] = trn
         if not args.no_roofline:
             width = cfg['model_kwargs']['layer_configs'][1]['kwargs'][
                 'edge_MLP_depth_list'][-1] if len(
                 cfg['model_kwargs']['layer_configs']) > 2 else 300
-            res["roofline"] = roofline_scatter_max(torch, edges[1], n_k, width)
+            live = None
+            if world == 1 and not args.no_live_pmc:
+                torch.cuda.synchronize()
+                live = live_pmc_scatter(args.preset)
+            res["roofline"] = roofline_scatter_max(torch, edges[1], n_k, width,
+                                                   live_pmc=live)
             res["roofline"]["workload"] = {
                 "frame_seed": first, "E": n_e1, "C": width, "K": n_k}
             mf = roofline_edge_kernel(torch, engine, edges[1], n_k,
@@ -811,6 +1093,7 @@ def main(argv=None):
             pl = roofline_pool_kernel(torch, engine, frame=(x, f))
             if pl is not None:
                 res["roofline_pool"] = pl
+            res["roofline_graph"] = roofline_graph(torch, cfg, coords)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, params, xyz_np, inten_np,
                                                args.cpu_budget)

@@ -560,10 +560,13 @@ int pgnn_kitti_cam_points_in_image(
  *                  weights-stationary kernel), 8192 / 16384 (pooling stage),
  *                  1024 (pooling hidden layers through the LDS tile), 32 / 128
  *                  (scatter-max epilogue forms), 512 (4-wave small-row kernel)
- *   ablations      mlp_debug bits 1 / 2 / 4 (drop gather loads / last GEMM /
- *                  epilogue: WRONG results, timing only), graph_debug bit 1
- *                  (skip the kd-tree replica: 'center' ties in slot order)
- * Every key except the ablations leaves results bit-identical (tested).
+ *   ablations      NOT in this library: mlp_debug bits 1 / 2 / 4 (drop gather
+ *                  loads / last GEMM / epilogue: wrong results, timing only)
+ *                  and graph_debug bit 1 (skip the kd-tree replica) exist only
+ *                  in diagnostic builds (-DPGNN_DIAG, tools/build_variant.py);
+ *                  the default build rejects them with PGNN_E_INVALID and
+ *                  compiles their code out
+ * Every key accepted here leaves results bit-identical (tested).
  * Returns 0, or PGNN_E_INVALID for an unknown key / value out of range.     */
 int pgnn_set_tunable(const char *key, int value);
 /* Device buffer for per-tile cycle stamps of the fused kernels

@@ -2,6 +2,7 @@
 #include <string.h>
 
 #include <mutex>
+#include <vector>
 
 #include "pgnn_common.h"
 
@@ -35,16 +36,68 @@ int device_cu_count() {
 int stream_cu_count(hipStream_t stream) {
   const int total = device_cu_count();
   if (stream == nullptr) return total;
+  // the mask of a stream never changes: ask the runtime once per handle (this
+  // sits on the launch path of every fused kernel)
+  struct Entry {
+    hipStream_t s;
+    int n;
+  };
+  static std::mutex mu;
+  static std::vector<Entry> cache;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    for (const Entry &e : cache)
+      if (e.s == stream) return e.n;
+  }
   uint32_t mask[32] = {0};
   const int words = (total + 31) / 32;
+  int n = 0;
   if (words > 32 ||
       hipExtStreamGetCUMask(stream, (uint32_t)words, mask) != hipSuccess) {
     (void)hipGetLastError();
-    return total;
+    n = total;
+  } else {
+    for (int i = 0; i < total; ++i) n += (mask[i >> 5] >> (i & 31)) & 1u;
+    if (n <= 0) n = total;
   }
-  int n = 0;
-  for (int i = 0; i < total; ++i) n += (mask[i >> 5] >> (i & 31)) & 1u;
-  return n > 0 ? n : total;
+  std::lock_guard<std::mutex> lock(mu);
+  if (cache.size() < 4096) cache.push_back({stream, n});
+  return n;
+}
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel and size
+// instead of once per launch; fails (error code) when the device cannot give
+// a workgroup that much LDS
+int ensure_dynamic_lds(const void *kernel, size_t bytes) {
+  struct Entry {
+    const void *k;
+    size_t b;
+  };
+  static std::mutex mu;
+  static std::vector<Entry> done;
+  std::lock_guard<std::mutex> lock(mu);
+  for (const Entry &e : done)
+    if (e.k == kernel && e.b >= bytes) return 0;
+  PGNN_HIP(hipFuncSetAttribute(kernel,
+                               hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)bytes));
+  done.push_back({kernel, bytes});
+  return 0;
+}
+
+// LDS a workgroup may allocate on the current device (160 KiB on gfx950)
+size_t device_max_lds() {
+  static size_t cached = 0;
+  if (cached) return cached;
+  int dev = 0, v = 0;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock,
+                            dev) != hipSuccess || v <= 0) {
+    (void)hipGetLastError();
+    return 64 * 1024;
+  }
+  cached = (size_t)v;
+  return cached;
 }
 
 extern int g_scatter_rows_per_wave;
@@ -150,6 +203,12 @@ extern "C" int pgnn_set_tunable(const char *key, int value) {
     return 0;
   }
   if (!strcmp(key, "mlp_debug")) {
+#ifndef PGNN_DIAG
+    if (value & 7)
+      return pgnn::fail(PGNN_E_INVALID,
+                        "mlp_debug bits 1/2/4 (timing ablations with wrong "
+                        "results) need a -DPGNN_DIAG build");
+#endif
     pgnn::g_mlp_debug = value;
     return 0;
   }
@@ -183,6 +242,12 @@ extern "C" int pgnn_set_tunable(const char *key, int value) {
     return 0;
   }
   if (!strcmp(key, "graph_debug")) {
+#ifndef PGNN_DIAG
+    if (value & 1)
+      return pgnn::fail(PGNN_E_INVALID,
+                        "graph_debug bit 1 (skip the kd-tree replica: "
+                        "non-reference tie order) needs a -DPGNN_DIAG build");
+#endif
     pgnn::g_graph_debug = value;
     return 0;
   }

@@ -229,6 +229,12 @@ __global__ __launch_bounds__(256, 2) void fused_mlp_kernel(
     int32_t *sched /* nullable: {next pool tile, finished workgroups}, zero */,
     int64_t n_static /* tiles below this index are partitioned statically */) {
   constexpr int ROWS = 16 * MSUB;
+#ifndef PGNN_DIAG
+  // the timing ablations (bits 1 / 2 / 4: drop the gather loads / the last
+  // GEMM / the epilogue -- WRONG results) exist only in -DPGNN_DIAG builds
+  // (tools/); here the bits are constant-folded away with their code
+  dbg &= ~7;
+#endif
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int *dst = reinterpret_cast<int *>(smem);
   // 16 * 3 floats behind dst[]: meeting point of the per-wave partial maxima of
@@ -746,9 +752,10 @@ int launch_fused(const Plan &p, int64_t n_rows, const RowsArgs &ra,
   PGNN_REQUIRE(lds <= 160 * 1024, PGNN_E_UNSUPPORTED,
                "mlp: layer too wide for the LDS tile");
   auto kern = fused_mlp_kernel<MSUB, PRO>;
-  PGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                               hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)lds));
+  {
+    const int lrc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
+    if (lrc) return lrc;
+  }
   const int64_t n_tiles = (n_rows + ROWS - 1) / ROWS;
   int per_cu = (int)((160 * 1024) / lds);
   if (per_cu > g_mlp_blocks_per_cu) per_cu = g_mlp_blocks_per_cu;
@@ -760,6 +767,7 @@ int launch_fused(const Plan &p, int64_t n_rows, const RowsArgs &ra,
   int64_t n_static = n_tiles;
   if (g_mlp_ts || g_mlp_pool_pct <= 0 || n_tiles < 6 * grid) sched = nullptr;
   if (sched) n_static = n_tiles - n_tiles * g_mlp_pool_pct / 100;
+  PGNN_HIP((hipError_t)arm_sched(sched, stream));
   const int stage_off = p.stage_cols ? ROWS * p.tile_floats_per_row : -1;
   if (g_mlp_debug & 16) {
     int nb = -1;
@@ -836,9 +844,10 @@ int launch_rows8(const Plan &p, int64_t n_rows, const RowsArgs &ra,
   PGNN_REQUIRE(lds <= 160 * 1024, PGNN_E_UNSUPPORTED,
                "mlp: layer too wide for the LDS tile");
   auto kern = rows_mlp_kernel;
-  PGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                               hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)lds));
+  {
+    const int lrc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
+    if (lrc) return lrc;
+  }
   const int64_t n_tiles = (n_rows + 15) / 16;
   const int stage_off = p.stage_cols ? 16 * p.tile_floats_per_row : -1;
   hipLaunchKernelGGL(kern, dim3((unsigned)n_tiles), dim3(64 * kRowsWaves), lds,
@@ -870,6 +879,7 @@ int launch_edge_ws(const LayerDev &L, const EdgeArgs &ea, int64_t n_edges,
   a.prio = g_ws_prio;
   a.ts = (long long *)g_mlp_ts;
   a.sched = (g_ws_pool_pct > 0 && a.xcds <= kWsMaxSlices) ? sched : nullptr;
+  PGNN_HIP((hipError_t)arm_sched(a.sched, stream));
   a.pool_pct = g_ws_pool_pct;
   a.chunk = g_ws_chunk;
   a.groups = (L.nt + NTMAX - 1) / NTMAX;
@@ -904,9 +914,10 @@ int launch_edge_ws(const LayerDev &L, const EdgeArgs &ea, int64_t n_edges,
   for (int g = 0; g < a.groups; ++g) a.wg0[g + 1] = a.wg0[g] + cnt[g];
   const size_t lds = (size_t)KQ * NTMAX * 1024 + 16 * NTMAX * sizeof(float);
   auto kern = edge_ws_kernel<KQ, NTMAX>;
-  PGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                               hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)lds));
+  {
+    const int lrc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
+    if (lrc) return lrc;
+  }
   hipLaunchKernelGGL(kern, dim3((unsigned)(per_slice * a.xcds)),
                      dim3(64 * kWsWaves), lds, stream, a);
   PGNN_HIP(hipGetLastError());
@@ -920,6 +931,12 @@ bool edge_ws_applies(const Plan &p, int64_t n_edges, int cus) {
   const LayerDev &L = p.chain.l[0];
   if (p.chain.n != 1 || L.kq != L.nt || (L.nt != 19 && L.nt != 16)) return false;
   if (cus < 64 || cus % 8 != 0) return false;
+  // one column group of the layer's fragments + bias must fit a workgroup's
+  // LDS (133 KiB / 128 KiB on gfx950's 160 KiB); a device with less takes the
+  // LDS-tile kernel
+  if ((size_t)L.kq * (L.nt == 19 ? 7 : 8) * 1024 + 16 * 8 * sizeof(float) >
+      device_max_lds())
+    return false;
   if (g_mlp_debug & 4096) return true;
   // below ~2 tiles per wave the fixed cost (133 KiB of weights per workgroup
   // into LDS) is not amortised
@@ -934,6 +951,8 @@ bool pool_ws_applies(const Plan &p, int64_t n_edges, int cus) {
       c.l[2].nt != 8 || c.l[3].kq != 8 || c.l[3].nt != 19)
     return false;
   if (cus < 8) return false;
+  if ((size_t)8 * 19 * 1024 + 16 * 19 * sizeof(float) > device_max_lds())
+    return false;
   if (g_mlp_debug & 16384) return true;
   return n_edges >= (int64_t)16 * 2 * kWsWaves * cus;
 }
@@ -962,13 +981,15 @@ int launch_pool_ws(const Plan &p, const PoolArgs &pa, int64_t n_edges,
   a.prio = g_ws_prio;
   a.ts = (long long *)g_mlp_ts;
   a.sched = g_ws_pool_pct > 0 ? sched : nullptr;
+  PGNN_HIP((hipError_t)arm_sched(a.sched, stream));
   a.pool_pct = g_ws_pool_pct;
   a.chunk = 1;
   const size_t lds = (size_t)8 * 19 * 1024 + 16 * 19 * sizeof(float);
   auto kern = pool_ws_kernel;
-  PGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                               hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)lds));
+  {
+    const int lrc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
+    if (lrc) return lrc;
+  }
   hipLaunchKernelGGL(kern, dim3((unsigned)cus), dim3(64 * kWsWaves), lds, stream,
                      a);
   PGNN_HIP(hipGetLastError());
@@ -1275,9 +1296,10 @@ extern "C" int pgnn_vertex_pre_edge_fwd(
   PGNN_REQUIRE(lds <= 160 * 1024, PGNN_E_UNSUPPORTED,
                "vertex_pre_edge: layer too wide for the LDS tile");
   auto kern = vertex_pre_edge_kernel;
-  PGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                               hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)lds));
+  {
+    const int lrc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
+    if (lrc) return lrc;
+  }
   hipLaunchKernelGGL(kern, dim3((unsigned)((n_vertices + 15) / 16)),
                      dim3(64 * kRowsWaves), lds, stream, off, pl, a);
   PGNN_HIP(hipGetLastError());

@@ -897,7 +897,11 @@ int keypoints_impl(const T *points, int64_t n, double voxel, bool center,
   kb.bounds = nullptr;
   kb.status = nullptr;
   kb.n_nodes = 0;
+#ifdef PGNN_DIAG  // ablation (non-reference tie order): diagnostic builds only
   const bool use_kd = center && !(g_graph_debug & 1);
+#else
+  const bool use_kd = center;
+#endif
   if (!use_kd && center) {  // ablation: a valid (all-zero) slot table
     kb.pos = a.take<int32_t>((size_t)n);
     PGNN_REQUIRE(kb.pos, PGNN_E_WORKSPACE, "keypoints: workspace too small");

@@ -81,5 +81,17 @@ __device__ __forceinline__ void atomic_max_f32(float *addr, float v) {
 
 int device_cu_count();
 int stream_cu_count(hipStream_t stream);
+int ensure_dynamic_lds(const void *kernel, size_t bytes);
+size_t device_max_lds();
+// The tile-pool counters of the fused kernels ({next tile, finished
+// workgroups}) must be zero when a launch starts.  The kernels hand them back
+// zeroed, but an aborted launch or a caller sharing one buffer between
+// streams would leave them poisoned and later launches would silently skip
+// pool tiles: re-arm them in stream order before every launch that uses them.
+inline int arm_sched(int32_t *sched, hipStream_t stream) {
+  if (!sched) return 0;
+  return (int)hipMemsetAsync(sched, 0, PGNN_SCHED_WS_INTS * sizeof(int32_t),
+                             stream);
+}
 
 }  // namespace pgnn

@@ -59,29 +59,54 @@ class InferenceEngine(object):
         graph_cus / 8 CUs of every XCD -- and the compute streams only the
         others (pgnn_stream_create_cu_mask); 0: ordinary streams sharing the
         whole device."""
-        key = int(graph_cus)
+        dev_index = torch.cuda.current_device()
+        key = (dev_index, int(graph_cus))
         cache = self.__dict__.setdefault("_stream_sets", {})
         if key in cache:
             return cache[key]
-        if key <= 0:
+        graph_cus = int(graph_cus)
+        if graph_cus <= 0:
             streams = [torch.cuda.Stream() for _ in range(5)]
             cache[key] = (streams[0], streams[1:])
             return cache[key]
         import ctypes
         from . import _lib
         lib = _lib.load()
-        dev = torch.device("cuda", torch.cuda.current_device())
+        dev = torch.device("cuda", dev_index)
+        owned = self.__dict__.setdefault("_owned_streams", [])
 
         def make(complement):
             p = ctypes.c_void_p()
             _lib.check(lib.pgnn_stream_create_cu_mask(
-                0, key, complement, ctypes.byref(p)),
+                0, graph_cus, complement, ctypes.byref(p)),
                 "pgnn_stream_create_cu_mask")
+            owned.append(p.value)     # destroyed by close()
             return torch.cuda.ExternalStream(p.value, device=dev)
         sg, aux = make(0), make(0)
         graph_gen._AUX_STREAMS[(dev.index, sg.cuda_stream)] = aux
         cache[key] = (sg, [make(1) for _ in range(4)])
         return cache[key]
+
+    def close(self):
+        """Destroy the CU-masked streams this engine created
+        (pgnn_stream_create_cu_mask); ordinary torch streams need nothing."""
+        owned = self.__dict__.pop("_owned_streams", [])
+        self.__dict__.pop("_stream_sets", None)
+        if owned:
+            from . import _lib
+            torch.cuda.synchronize()
+            lib = _lib.load()
+            for h in owned:
+                lib.pgnn_stream_destroy(h)
+            for k in [k for k, s in graph_gen._AUX_STREAMS.items()
+                      if s.cuda_stream in owned]:
+                del graph_gen._AUX_STREAMS[k]
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def run_frames_pipelined(self, frames, compute_streams=1, graph_cus=0,
                              lookahead=0):

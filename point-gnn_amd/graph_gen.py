@@ -200,6 +200,9 @@ def _identity_indices(n, dev):
     if ramp is None or ramp.shape[0] < n:
         size = max(int(n), 1 << 16, 2 * (ramp.shape[0] if ramp is not None else 0))
         ramp = torch.arange(size, dtype=torch.int32, device=dev)
+        # other streams read views of this ramp without an event: make sure
+        # the fill has run before anyone can (a rare, one-off wait)
+        torch.cuda.current_stream(dev).synchronize()
         _IDENTITY[dev.index] = ramp
     return ramp[:n].reshape(-1, 1)
 

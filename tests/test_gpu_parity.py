@@ -1088,3 +1088,37 @@ def test_pipelined_frames_equal_sequential(dev):
         assert len(pip) == len(seq)
         for (l0, b0), (l1, b1) in zip(seq, pip):
             assert torch.equal(l0, l1) and torch.equal(b0, b1)
+
+
+def test_poisoned_sched_ws_is_rearmed(dev):
+    """The tile-pool counters (sched_ws) are re-armed in stream order before
+    every launch that uses them: counters left non-zero (an aborted launch, a
+    buffer shared between streams) must not make a later launch skip pool
+    tiles -- results stay bit-identical.  Exercised with the pools switched on
+    in both kernel families (`ws_pool_pct`, the LDS-tile kernels' default
+    `mlp_pool_pct`)."""
+    import torch
+    from pointgnn_amd import _lib
+    from pointgnn_amd.engine import InferenceEngine
+    cfg = configs.car_auto_config(3)
+    params = weights.init_params(cfg, seed=2, bias_scale=0.05)
+    eng = InferenceEngine(cfg, params, device=dev)
+    xyz, inten = synthetic_cloud(seed=0, preset="car")
+    x, f = T(xyz, dev), T(inten, dev)
+    try:
+        for key, val in (("ws_pool_pct", 30), ("mlp_debug", 2048 | 8192)):
+            _lib.set_tunable(key, val)
+            ref = [t.clone() for t in eng.run_frame(x, f)]
+            torch.cuda.synchronize()
+            assert _lib._SCHED_WS, "no scheduling counters were handed out"
+            for t in _lib._SCHED_WS.values():
+                t.fill_(7)
+            got = eng.run_frame(x, f)
+            torch.cuda.synchronize()
+            assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+            for t in _lib._SCHED_WS.values():      # handed back zeroed
+                assert int(t.abs().sum().item()) == 0
+            _lib.set_tunable(key, 0)
+    finally:
+        _lib.set_tunable("ws_pool_pct", 0)
+        _lib.set_tunable("mlp_debug", 0)

@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Where the 'gen graph' phase goes (GPU box): wall time of the sequential
+"""[needs a diagnostic build: python tools/build_variant.py diag core.hip,gnn.hip,graph.hip -DPGNN_DIAG; PGNN_LIB=ab/libdiag.so]
+Where the 'gen graph' phase goes (GPU box): wall time of the sequential
 graph build of one frame, with / without the kd-tree replica, and the time
 the host alone spends inside the calls (measured by running the same calls
 while the stream is blocked behind a long-running kernel, so that no host

@@ -23,6 +23,33 @@ def avg_counter(db_path, counter):
     return row
 
 
+def short_kernel_name(name):
+    """'void (anonymous namespace)::scatter_max_kernel<4, 2, 8, true>(float
+    const*, ...)' -> 'scatter_max_kernel<4, 2, 8, true>'."""
+    name = (name or "").replace("(anonymous namespace)::", "")
+    name = name.replace("pgnn::", "")
+    if name.startswith("void "):
+        name = name[5:]
+    depth = 0
+    for i, ch in enumerate(name):      # cut at the argument list, not at '<..(..)..>'
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            return name[:i]
+    return name
+
+
+WRITE_NOTE = (
+    "WRITE_SIZE exceeds the 4*K*C-byte output because the two range-boundary "
+    "runs of every wave are flushed with float atomic-max (csrc/scatter_max.hip)"
+    ": E / rows_per_wave waves x 2 runs x C atomics, each counted by the TCC "
+    "as a partial-line write, on top of the plain stores of the complete "
+    "segments; the lowest() fill is a separate memset kernel and not in this "
+    "kernel's counters")
+
+
 def main(src, out):
     vals = {}
     kernel = None
@@ -38,11 +65,12 @@ def main(src, out):
             if line.startswith("{"):
                 wl = json.loads(line).get("workload")
     res = {
-        "kernel": kernel.split("(")[0].replace("void (anonymous namespace)::", ""),
+        "kernel": short_kernel_name(kernel),
         "workload": wl,
         "FETCH_SIZE_KiB": vals["FETCH_SIZE"],
         "WRITE_SIZE_KiB": vals["WRITE_SIZE"],
         "launches_averaged": vals["FETCH_SIZE_launches"],
+        "write_note": WRITE_NOTE,
         "hbm_bytes_per_launch": (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024,
         "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in "
                   "separate passes (tools/pmc_scatter.sh); bytes = (2*FETCH_SIZE "
