@@ -41,6 +41,54 @@ def _lt(data, d, a, b):
     return (va < vb) | ((va == vb) & (a < b))
 
 
+HEAP_SELECT_CALLS = [0]   # how often the fallback ran (tests look at it)
+
+
+def _adjust_heap(data, d, idx, first, hole, length, value):
+    """libstdc++ std::__adjust_heap (bits/stl_heap.h) followed by its
+    __push_heap, on the max-heap idx[first:first+length] under _lt."""
+    top = hole
+    child = hole
+    while child < (length - 1) // 2:
+        child = 2 * (child + 1)
+        if _lt(data, d, idx[first + child], idx[first + child - 1]):
+            child -= 1
+        idx[first + hole] = idx[first + child]
+        hole = child
+    if (length & 1) == 0 and child == (length - 2) // 2:
+        child = 2 * (child + 1)
+        idx[first + hole] = idx[first + child - 1]
+        hole = child - 1
+    parent = (hole - 1) // 2
+    while hole > top and _lt(data, d, idx[first + parent], value):
+        idx[first + hole] = idx[first + parent]
+        hole = parent
+        parent = (hole - 1) // 2
+    idx[first + hole] = value
+
+
+def heap_select(data, d, idx, first, middle, last):
+    """libstdc++ std::__heap_select(first, middle, last): what introselect
+    falls back to when its depth limit (2 * floor(log2 n) partition rounds) is
+    used up: a max-heap of [first, middle) swallows every later element that
+    is smaller than its top."""
+    HEAP_SELECT_CALLS[0] += 1
+    length = middle - first
+    if length >= 2:                      # __make_heap
+        parent = (length - 2) // 2
+        while True:
+            _adjust_heap(data, d, idx, first, parent, length,
+                         idx[first + parent])
+            if parent == 0:
+                break
+            parent -= 1
+    for i in range(middle, last):
+        if _lt(data, d, idx[i], idx[first]):      # __pop_heap(first, middle, i)
+            value = idx[i]
+            idx[i] = idx[first]
+            _adjust_heap(data, d, idx, first, 0, length, value)
+
+
 def nth_element(data, d, idx, first, nth, last):
     """libstdc++ std::nth_element on idx[first:last] (in place)."""
     n = last - first
@@ -49,7 +97,10 @@ def nth_element(data, d, idx, first, nth, last):
     depth = 2 * (int(n).bit_length() - 1)
     while last - first > 3:
         if depth == 0:
-            raise NotImplementedError("introselect depth limit (heap-select)")
+            # __introselect: heap-select, then the nth element to its place
+            heap_select(data, d, idx, first, nth + 1, last)
+            idx[first], idx[nth] = idx[nth], idx[first]
+            return
         depth -= 1
         mid = first + (last - first) // 2
         a, b, c = first + 1, mid, last - 1

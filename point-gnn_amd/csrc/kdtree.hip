@@ -120,6 +120,65 @@ __device__ __forceinline__ void kd_scan2(int a, int b, int &ea, int &eb,
   __syncthreads();  // sh[] is reused by the next call
 }
 
+// libstdc++ std::__adjust_heap + __push_heap (bits/stl_heap.h) on the max-heap
+// H[0 .. len) under kd_less; one thread.
+__device__ inline void kd_adjust_heap(Rec *H, int dim, int hole, int len,
+                                      const Rec value) {
+  const float vk = value.c[dim];
+  const int top = hole;
+  int child = hole;
+  while (child < (len - 1) / 2) {
+    child = 2 * (child + 1);
+    if (kd_less(H[child].c[dim], H[child].idx, H[child - 1].c[dim],
+                H[child - 1].idx))
+      --child;
+    H[hole] = H[child];
+    hole = child;
+  }
+  if ((len & 1) == 0 && child == (len - 2) / 2) {
+    child = 2 * (child + 1);
+    H[hole] = H[child - 1];
+    hole = child - 1;
+  }
+  int parent = (hole - 1) / 2;
+  while (hole > top && kd_less(H[parent].c[dim], H[parent].idx, vk, value.idx)) {
+    H[hole] = H[parent];
+    hole = parent;
+    parent = (hole - 1) / 2;
+  }
+  H[hole] = value;
+}
+
+// What __introselect does once its depth limit (2 * floor(log2 n) partition
+// rounds) is used up: std::__heap_select(first, nth + 1, last) -- a max-heap
+// of [first, nth] swallows every later element smaller than its top -- then
+// iter_swap(first, nth).  Rare (about one cloud in fifty has one such node)
+// and short (the range left over is a handful of elements), so ONE thread
+// replays libstdc++'s exact sequence of moves; the caller synchronises.
+__device__ inline void kd_heap_select(Rec *R, int off, int dim, int first,
+                                      int nth, int last) {
+  Rec *H = R + (first - off);
+  const int len = nth + 1 - first;
+  if (len >= 2) {  // __make_heap
+    int parent = (len - 2) / 2;
+    while (true) {
+      const Rec value = H[parent];
+      kd_adjust_heap(H, dim, parent, len, value);
+      if (parent == 0) break;
+      --parent;
+    }
+  }
+  for (int i = nth + 1; i < last; ++i) {
+    Rec *e = R + (i - off);
+    if (kd_less(e->c[dim], e->idx, H[0].c[dim], H[0].idx)) {  // __pop_heap
+      const Rec value = *e;
+      *e = H[0];
+      kd_adjust_heap(H, dim, 0, len, value);
+    }
+  }
+  rec_swap(&R[first - off], &R[nth - off]);
+}
+
 // libstdc++ __introselect iterations on slots [first, last) -- slot i lives at
 // R[i - off] (R: LDS or global) -- executed by G = (WAVE ? 64 : KD_NT) threads
 // with ids `tid`, until the range is <= max(3, stop_len) long.  lg/ls: swap
@@ -132,9 +191,10 @@ __device__ __forceinline__ void kd_introselect(Rec *R, int off, int dim,
                                                int32_t *status) {
   constexpr int G = WAVE ? 64 : KD_NT;
   while (last - first > 3 && last - first > stop_len) {
-    if (depth == 0) {  // libstdc++ switches to heap-select here: not replicated
-      if (tid == 0) atomicOr(status, 1);
-      last = first;  // nothing left for the caller to do
+    if (depth == 0) {  // libstdc++ switches to heap-select here
+      if (tid == 0) kd_heap_select(R, off, dim, first, nth, last);
+      kd_sync<WAVE>();
+      last = first;  // nothing left for the caller to do (no final sort)
       return;
     }
     --depth;
@@ -240,8 +300,9 @@ __device__ __forceinline__ void kd_introselect_wave(Rec *R, int off, int dim,
                                                     int32_t *ls,
                                                     int32_t *status) {
   while (last - first > 3) {
-    if (depth == 0) {  // libstdc++ switches to heap-select here: not replicated
-      if (lane == 0) atomicOr(status, 1);
+    if (depth == 0) {  // libstdc++ switches to heap-select here
+      if (lane == 0) kd_heap_select(R, off, dim, first, nth, last);
+      kd_sync<true>();
       last = first;
       return;
     }

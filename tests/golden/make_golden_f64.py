@@ -192,7 +192,7 @@ def labels_main():
     """labels_f64.npz: the reference's label assignment and box encoding on
     FLOAT64 vertices (train.py:100-122 hands them the float64
     vertex_coord_list): rotated seeded vertices plus, for ten boxes, vertices
-    within 1e-12 m of each of the six faces."""
+    1e-12 m and 3e-12 m either side of each of the six faces."""
     import types
     for name in ("open3d", "cv2"):
         sys.modules.setdefault(name, types.ModuleType(name))
@@ -221,7 +221,10 @@ def labels_main():
             # is well inside the other four faces
             fc = fc + 0.0 * (centre - fc)
             n = (fc - centre) / np.linalg.norm(fc - centre)
-            for k in (-3, -1, 0, 1, 3):
+            # no probe ON the face: there the reference's answer is the
+            # rounding of its BLAS dgemm kernel (FMA chain or not), i.e. a
+            # property of the host, not of the reference
+            for k in (-3, -1, 1, 3):
                 extra.append(fc + k * 1e-12 * n)
     xyz = np.vstack([xyz, np.array(extra)])
     out = {"xyz": xyz, "n_labels": np.array(len(labels))}

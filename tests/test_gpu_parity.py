@@ -325,18 +325,43 @@ def _kd_clouds():
     }
 
 
+def _heap_select_cloud(name):
+    """Clouds on which libstdc++'s introselect uses up its depth limit in one
+    node and falls back to std::__heap_select (found by scanning with
+    oracle/kdtree_oracle.py, whose restatement of the fallback equals the real
+    sklearn on each of them; tests/test_oracle_cpu.py)."""
+    if name == "hs_ped_dense1":
+        return synthetic_cloud(seed=1, preset="ped_dense")[0]
+    if name == "hs_small19":
+        return synthetic_cloud(seed=19, preset="small")[0]
+    rng = np.random.default_rng(0)
+    want = {"hs_rand7": 7, "hs_rand39": 39, "hs_rand90": 90}[name]
+    for t in range(want + 1):
+        n = int(rng.integers(200, 6000))
+        xyz = (rng.standard_normal((n, 3)) * np.array([20, 2, 30])).astype(
+            np.float32)
+    return xyz
+
+
 @pytest.mark.parametrize("name", ["n1", "n31", "n61", "n62", "n500",
                                   "duplicates", "lattice", "constant", "tiny",
-                                  "small", "car", "car_600k", "ped_dense"])
+                                  "small", "car", "car_600k", "ped_dense",
+                                  "hs_ped_dense1", "hs_small19", "hs_rand7",
+                                  "hs_rand39", "hs_rand90"])
 def test_kdtree_replica_equals_sklearn(dev, name):
     """csrc/kdtree.hip against the REAL scikit-learn: idx_array and node_bounds
     of KDTree(points, leaf_size=30).get_arrays(), bit for bit (the permutation
-    libstdc++'s std::nth_element leaves behind, node by node)."""
+    libstdc++'s std::nth_element leaves behind, node by node) -- including
+    clouds (hs_*) with a node where introselect hits its depth limit and
+    finishes with heap-select."""
     from sklearn.neighbors import KDTree
     from pointgnn_amd import graph_gen
     clouds = _kd_clouds()
-    xyz = clouds[name] if name in clouds else synthetic_cloud(
-        seed=0 if name != "tiny" else 1, preset=name)[0]
+    if name.startswith("hs_"):
+        xyz = _heap_select_cloud(name)
+    else:
+        xyz = clouds[name] if name in clouds else synthetic_cloud(
+            seed=0 if name != "tiny" else 1, preset=name)[0]
     idx, bounds, status = graph_gen.kdtree_replica(xyz)
     _, idx_ref, node_data, node_bounds = KDTree(
         xyz.astype(np.float64), leaf_size=30).get_arrays()

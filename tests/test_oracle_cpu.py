@@ -287,3 +287,29 @@ def test_labels_oracle_on_float64_vertices_equals_reference_golden():
         cls32 = LO.assign_labels(labels, fix["xyz"].astype(np.float32),
                                  (1.0, 1.0, 1.0), m)[0]
         assert int((cls32 != cls).sum()) == int(fix[m + "_n_diff_f32"]) > 0
+
+
+def test_kdtree_oracle_heap_select_fallback_equals_sklearn():
+    """libstdc++'s introselect gives up after 2*floor(log2 n) partition rounds
+    and finishes with std::__heap_select; about one cloud in fifty has such a
+    node.  The restatement (oracle/kdtree_oracle.py heap_select) against the
+    REAL scikit-learn KDTree on clouds where it runs."""
+    from sklearn.neighbors import KDTree
+    from oracle import kdtree_oracle as ko
+    from pointgnn_amd.synthetic import synthetic_cloud
+    clouds = [synthetic_cloud(seed=19, preset="small")[0]]
+    rng = np.random.default_rng(0)
+    for t in range(91):
+        n = int(rng.integers(200, 6000))
+        xyz = (rng.standard_normal((n, 3)) * np.array([20, 2, 30])).astype(
+            np.float32)
+        if t in (7, 39, 90):
+            clouds.append(xyz)
+    for xyz in clouds:
+        ko.HEAP_SELECT_CALLS[0] = 0
+        idx, _, bounds = ko.build(xyz)
+        assert ko.HEAP_SELECT_CALLS[0] >= 1
+        _, idx_ref, _, nb = KDTree(xyz.astype(np.float64),
+                                   leaf_size=30).get_arrays()
+        assert np.array_equal(idx, idx_ref)
+        assert np.array_equal(bounds[:, :3], nb[0])
