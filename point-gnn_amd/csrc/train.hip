@@ -218,6 +218,272 @@ __global__ void segmax_route4_kernel(const float *__restrict__ data, int64_t ld,
   }
 }
 
+// ---------------------------------------------------------------- packing, all layers at once
+// One launch re-packs every layer after an SGD step (the per-layer entry took
+// 155 launches of ~2 us each, ~0.8 ms of host-paced time per step).  `jobs`
+// is a device table built once (the flat parameter buffer never moves).
+struct PackJob {
+  const float *w;   // [k_in, n_out] row-major inside the flat buffer
+  const float *b;   // [n_out] or null
+  float *dst;
+  int32_t k_in, n_out;
+  int32_t kind;     // 0 fragment image, 1 fragment image of W^T (no bias),
+                    // 2 plain W^T [n_out rows][ld = 16*ceil(k_in/16)], zero pad
+  int32_t first_block;  // prefix sum of the jobs' block counts
+};
+static_assert(sizeof(PackJob) == 40, "PackJob layout (Python mirrors it)");
+
+__global__ __launch_bounds__(256) void pack_many_kernel(
+    const PackJob *__restrict__ jobs, int n_jobs) {
+  // binary search of the job this block belongs to
+  int lo = 0, hi = n_jobs - 1;
+  const int blk = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].first_block <= blk) lo = mid; else hi = mid - 1;
+  }
+  const PackJob j = jobs[lo];
+  const int64_t base = (int64_t)(blk - j.first_block) * 256 + threadIdx.x;
+  if (j.kind == 2) {
+    const int ld = (j.k_in + 15) / 16 * 16;
+    const int64_t total = (int64_t)j.n_out * ld;
+    if (base < total) {
+      const int n = (int)(base / ld), k = (int)(base - (int64_t)n * ld);
+      j.dst[base] = k < j.k_in ? j.w[(int64_t)k * j.n_out + n] : 0.0f;
+    }
+    return;
+  }
+  const int transpose = j.kind;
+  const int K = transpose ? j.n_out : j.k_in, N = transpose ? j.k_in : j.n_out;
+  const int kq = (K + 15) / 16, nt = (N + 15) / 16;
+  const int64_t total = (int64_t)kq * nt * 256;
+  const int64_t idx = base;
+  if (idx >= total + nt * 16) return;
+  if (idx >= total) {
+    const int n = (int)(idx - total);
+    j.dst[idx] = (!transpose && j.b && n < N) ? j.b[n] : 0.0f;
+    return;
+  }
+  const int sidx = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
+  const int64_t qt = idx >> 8;
+  const int t = (int)(qt % nt), q = (int)(qt / nt);
+  const int k = 16 * q + 4 * (lane >> 4) + sidx, n = 16 * t + (lane & 15);
+  float v = 0.0f;
+  if (k < K && n < N)
+    v = transpose ? j.w[(int64_t)n * j.n_out + k] : j.w[(int64_t)k * j.n_out + n];
+  j.dst[idx] = v;
+}
+
+// ---------------------------------------------------------------- sparse scatter-max adjoint
+// y = scatter_max(Y), Y = ReLU(X W + b)  (gnn.py:269-277 / 357-365).  The
+// gradient of the max reaches ONE row per (segment, column) (TF's tie rule
+// aside), so dZ = dY * [Y > 0] has ~K*C non-zeros among E*C entries (2-7 per
+// row).  The dense adjoint -- dX = dZ W^T and dW = X^T dZ, two E-row GEMMs per
+// layer, the largest kernels of the dense training step -- collapses to
+//   count_win : winners and tie counts per (segment, column)
+//   route     : dX[e,:] = sum over the row's winning columns g * W^T[c,:]
+//   wgrad     : dW[:,c] = sum over segments g * X[winner(s,c),:]  (row gathers)
+// with g = dY[s,c] / ties(s,c).  Ties between POSITIVE maxima (duplicate
+// points) are rare; they are routed exactly (route sees every tied row; a
+// separate pass adds their weight-gradient terms and runs only when the
+// count pass raised the tie flag).
+__global__ void segmax_count_win4_kernel(
+    const float *__restrict__ data, int64_t ld, const int32_t *__restrict__ seg,
+    int64_t rows, int cols4, int nseg, const float *__restrict__ out,
+    int64_t ldo, int32_t *__restrict__ cnt, int32_t *__restrict__ win,
+    int ldc, int32_t *__restrict__ tie_flag) {
+  const int64_t total = rows * cols4;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = idx / cols4;
+    const int c = 4 * (int)(idx - r * cols4);
+    const int s = seg[r];
+    if (s < 0 || s >= nseg) continue;
+    const v4f d = *reinterpret_cast<const v4f *>(data + r * ld + c);
+    const v4f o = *reinterpret_cast<const v4f *>(out + (int64_t)s * ldo + c);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (d[i] == o[i] && d[i] > 0.0f) {
+        const int slot = atomicAdd(&cnt[(int64_t)s * ldc + c + i], 1);
+        if (slot == 0)
+          win[(int64_t)s * ldc + c + i] = (int32_t)r;
+        else
+          *tie_flag = 1;
+      }
+  }
+}
+
+// one wave per row: lanes own columns c = lane + 64 j of Y and features
+// k = lane + 64 i of X / dX
+template <int J /* ceil(cols/64) */, int I /* ceil(ld_dx/64) */>
+__global__ __launch_bounds__(256) void segmax_route_sparse_kernel(
+    const float *__restrict__ data, int64_t ld, const int32_t *__restrict__ seg,
+    int64_t rows, int cols, int nseg, const float *__restrict__ out, int64_t ldo,
+    const float *__restrict__ gout, int64_t ldg, const int32_t *__restrict__ cnt,
+    int ldc, const float *__restrict__ WT, int64_t ldwt, int k_in,
+    const float *__restrict__ X, int64_t ldx, int mask_x,
+    float *__restrict__ dX, int64_t lddx, int wdx) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave; r < rows; r += n_waves) {
+    const int s = seg[r];
+    float acc[I];
+#pragma unroll
+    for (int i = 0; i < I; ++i) acc[i] = 0.0f;
+    if (s >= 0 && s < nseg) {
+      float g[J];
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const int c = lane + 64 * j;
+        g[j] = 0.0f;
+        if (c < cols) {
+          const float d = data[r * ld + c];
+          if (d > 0.0f && d == out[(int64_t)s * ldo + c])
+            g[j] = gout[(int64_t)s * ldg + c] /
+                   (float)cnt[(int64_t)s * ldc + c];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        // a winner whose incoming gradient is exactly 0 contributes nothing
+        unsigned long long m = __ballot(g[j] != 0.0f);
+        while (m) {
+          const int l = __builtin_ctzll(m);
+          m &= m - 1;
+          const float gv = __shfl(g[j], l);
+          const float *wrow = WT + (int64_t)(l + 64 * j) * ldwt;
+#pragma unroll
+          for (int i = 0; i < I; ++i) {
+            const int k = lane + 64 * i;
+            if (k < k_in) acc[i] += gv * wrow[k];
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < I; ++i) {
+      const int k = lane + 64 * i;
+      if (k < wdx) {
+        float v = acc[i];
+        if (mask_x && !(k < k_in && X[r * ldx + k] > 0.0f)) v = 0.0f;
+        dX[r * lddx + k] = v;
+      }
+    }
+  }
+}
+
+// grid (column, slice): dW^T partial [slice][c][k] and db partial [slice][c]
+// from the single winners (cnt == 1); tied maxima are left to the tie pass
+template <int I /* ceil(kin_p/64) */>
+__global__ __launch_bounds__(64) void segmax_wgrad_gather_kernel(
+    const float *__restrict__ gout, int64_t ldg, const int32_t *__restrict__ cnt,
+    const int32_t *__restrict__ win, int ldc, int nseg, int seg_per_slice,
+    const float *__restrict__ X, int64_t ldx, int k_in, int kin_p,
+    float *__restrict__ partial, float *__restrict__ partial_b, int cols) {
+  const int lane = threadIdx.x;
+  const int c = blockIdx.x, slice = blockIdx.y;
+  const int s0 = slice * seg_per_slice;
+  int s1 = s0 + seg_per_slice;
+  if (s1 > nseg) s1 = nseg;
+  float acc[I];
+#pragma unroll
+  for (int i = 0; i < I; ++i) acc[i] = 0.0f;
+  float bsum = 0.0f;
+  for (int sb = s0; sb < s1; sb += 64) {
+    const int s = sb + lane;
+    float g = 0.0f;
+    int e = 0;
+    if (s < s1 && cnt[(int64_t)s * ldc + c] == 1) {
+      g = gout[(int64_t)s * ldg + c];
+      e = win[(int64_t)s * ldc + c];
+    }
+    bsum += g;
+    const int nl = min(64, s1 - sb);
+    // rows are independent gathers: four in flight per wave
+    for (int l0 = 0; l0 < nl; l0 += 4) {
+      float gv[4];
+      const float *xr[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        gv[u] = __shfl(g, (l0 + u) & 63);
+        xr[u] = X + (int64_t)__shfl(e, (l0 + u) & 63) * ldx;
+      }
+      float xv[4][I];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int i = 0; i < I; ++i) {
+          const int k = lane + 64 * i;
+          xv[u][i] = (k < k_in) ? xr[u][k] : 0.0f;
+        }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int i = 0; i < I; ++i) acc[i] += gv[u] * xv[u][i];
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) bsum += __shfl_xor(bsum, d);
+  float *po = partial + ((int64_t)slice * cols + c) * kin_p;
+#pragma unroll
+  for (int i = 0; i < I; ++i) {
+    const int k = lane + 64 * i;
+    if (k < kin_p) po[k] = acc[i];
+  }
+  if (lane == 0) partial_b[(int64_t)slice * cols + c] = bsum;
+}
+
+// dW[k, c] += sum_slices partial[slice][c][k]; db[c] += sum_slices pb[slice][c]
+__global__ void segmax_wgrad_reduce_kernel(const float *__restrict__ partial,
+                                           const float *__restrict__ partial_b,
+                                           int slices, int cols, int k_in,
+                                           int kin_p, float *__restrict__ dW,
+                                           float *__restrict__ db) {
+  const int64_t total = (int64_t)(k_in + 1) * cols;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(idx / cols), c = (int)(idx - (int64_t)k * cols);
+    float s = 0.0f;
+    if (k < k_in) {
+      for (int sl = 0; sl < slices; ++sl)
+        s += partial[((int64_t)sl * cols + c) * kin_p + k];
+      dW[(int64_t)k * cols + c] += s;
+    } else if (db) {
+      for (int sl = 0; sl < slices; ++sl) s += partial_b[(int64_t)sl * cols + c];
+      db[c] += s;
+    }
+  }
+}
+
+// weight-gradient terms of tied positive maxima (cnt > 1); exits at once when
+// the count pass found none.  Rare: plain float atomics.
+__global__ void segmax_wgrad_ties_kernel(
+    const int32_t *__restrict__ tie_flag, const float *__restrict__ data,
+    int64_t ld, const int32_t *__restrict__ seg, int64_t rows, int cols,
+    int nseg, const float *__restrict__ out, int64_t ldo,
+    const float *__restrict__ gout, int64_t ldg, const int32_t *__restrict__ cnt,
+    int ldc, const float *__restrict__ X, int64_t ldx, int k_in,
+    float *__restrict__ dW, float *__restrict__ db) {
+  if (*tie_flag == 0) return;
+  const int64_t total = rows * cols;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = idx / cols;
+    const int c = (int)(idx - r * cols);
+    const int s = seg[r];
+    if (s < 0 || s >= nseg) continue;
+    const float d = data[r * ld + c];
+    if (!(d > 0.0f) || d != out[(int64_t)s * ldo + c]) continue;
+    const int n = cnt[(int64_t)s * ldc + c];
+    if (n <= 1) continue;
+    const float g = gout[(int64_t)s * ldg + c] / (float)n;
+    for (int k = 0; k < k_in; ++k)
+      atomicAdd(&dW[(int64_t)k * cols + c], g * X[r * ldx + k]);
+    if (db) atomicAdd(&db[c], g);
+  }
+}
+
 // ---------------------------------------------------------------- weight gradient
 // dW[i][j] = sum_r X[r][i] dZ[r][j], db[j] = sum_r dZ[r][j] (a constant-one
 // input column at index k_in produces db as an extra row of the same GEMM).

@@ -89,24 +89,26 @@ class InferenceEngine(object):
 
     def close(self):
         """Destroy the CU-masked streams this engine created
-        (pgnn_stream_create_cu_mask); ordinary torch streams need nothing."""
+        (pgnn_stream_create_cu_mask); ordinary torch streams need nothing.
+        Explicit only (never from __del__): torch's caching allocator keeps
+        blocks and recorded events keyed by the streams they were used on, so
+        the streams may go only after the device is idle and the cache has
+        been emptied -- and the caller must hold no tensor produced by a
+        pipelined run any more."""
         owned = self.__dict__.pop("_owned_streams", [])
         self.__dict__.pop("_stream_sets", None)
         if owned:
             from . import _lib
+            for k in [k for k, s in graph_gen._AUX_STREAMS.items()
+                      if s.cuda_stream in owned or k[1] in owned]:
+                del graph_gen._AUX_STREAMS[k]
+            for k in [k for k in _lib._SCHED_WS if k[1] in owned]:
+                del _lib._SCHED_WS[k]
             torch.cuda.synchronize()
+            torch.cuda.empty_cache()
             lib = _lib.load()
             for h in owned:
-                lib.pgnn_stream_destroy(h)
-            for k in [k for k, s in graph_gen._AUX_STREAMS.items()
-                      if s.cuda_stream in owned]:
-                del graph_gen._AUX_STREAMS[k]
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
+                _lib.check(lib.pgnn_stream_destroy(h), "pgnn_stream_destroy")
 
     def run_frames_pipelined(self, frames, compute_streams=1, graph_cus=0,
                              lookahead=0):

@@ -1141,8 +1141,11 @@ def test_poisoned_sched_ws_is_rearmed(dev):
             got = eng.run_frame(x, f)
             torch.cuda.synchronize()
             assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
-            for t in _lib._SCHED_WS.values():      # handed back zeroed
-                assert int(t.abs().sum().item()) == 0
+            # the counters of THIS stream were used and handed back zeroed
+            # (other streams' sets, poisoned above, were never launched on)
+            assert int(_lib.sched_ws(dev).abs().sum().item()) == 0
+            for t in _lib._SCHED_WS.values():
+                t.zero_()
             _lib.set_tunable(key, 0)
     finally:
         _lib.set_tunable("ws_pool_pct", 0)
