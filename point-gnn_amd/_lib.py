@@ -225,7 +225,7 @@ def sched_ws(device=None):
     back zeroed."""
     import torch
     dev = torch.device("cuda", torch.cuda.current_device()) \
-        if device is None else device
+        if device is None or device.index is None else device
     key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
     t = _SCHED_WS.get(key)
     if t is None:
