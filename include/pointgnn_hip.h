@@ -333,6 +333,18 @@ int pgnn_pack_fc_device(const float *w, const float *b, int32_t k_in,
                         int32_t n_out, int32_t transpose, float *packed,
                         void *stream);
 
+/* Every layer's device images refreshed in ONE launch (after pgnn_sgd_step):
+ * `jobs_device` is a device array of n_jobs records
+ *   struct { const float *w; const float *b; float *dst; int32_t k_in, n_out,
+ *            kind, first_block; }                         (40 bytes each)
+ * kind 0 = pgnn_pack_fc image of (w [k_in,n_out], b), 1 = image of w^T (no
+ * bias), 2 = plain w^T as [n_out][16*ceil(k_in/16)] rows (zero padded; what
+ * pgnn_segmax_fc_bwd_f32 reads).  A job covers ceil(elements / 256) blocks
+ * of the launch; first_block is the running sum, total_blocks the grand
+ * total.  The table is built once: the flat parameter buffer never moves.  */
+int pgnn_pack_fc_many(const void *jobs_device, int32_t n_jobs,
+                      int32_t total_blocks, void *stream);
+
 /* H1[e] = ReLU(P[src(e)] - Q[dst(e)]) materialised, [n_edges, ld_pq].       */
 int pgnn_edge_hidden_fwd(const float *P, const float *Q, int64_t ld_pq,
                          const int32_t *edges, int64_t n_edges, float *H1,
@@ -364,6 +376,32 @@ int pgnn_scatter_max_bwd_f32(const float *data, int64_t ld_data,
                              int32_t *tie_count_ws, float *grad_data,
                              int64_t ld_grad_data, int32_t relu_mask,
                              void *stream);
+/* Adjoint of  out = unsorted_segment_max(Y),  Y = ReLU(X W + b)  -- the last
+ * per-edge layer and the aggregation of PointSetPooling (gnn.py:269-277) and
+ * GraphNetAutoCenter (gnn.py:357-365) -- exploiting that the max passes its
+ * gradient to one row per (segment, column): ~num_segments*n_cols non-zeros
+ * among n_rows*n_cols, so neither dZ nor the two n_rows-sized GEMMs of the
+ * dense adjoint are formed.  Same result as pgnn_scatter_max_bwd_f32
+ * (relu_mask = 1: TF's tie rule, ReluGrad) followed by dX = dZ W^T (masked by
+ * X > 0 when mask_x != 0: the ReluGrad of the layer that produced X) and
+ * dW += X^T dZ, db += column sums of dZ, up to float32 summation order.
+ *   Y [n_rows, ld_y], out [num_segments, ld_out]: 16-byte aligned rows padded
+ *   to a multiple of 4 columns; X [n_rows, ld_x] (k_in features);
+ *   WT = W^T as [n_cols][ld_wt] (pgnn_pack_fc_many kind 2);
+ *   dX [n_rows, ld_dx] (nullable): dx_cols columns written (zeros beyond k_in);
+ *   dW [k_in, n_cols] and db [n_cols] (nullable) are ACCUMULATED into.       */
+size_t pgnn_segmax_fc_bwd_workspace_bytes(int64_t n_rows, int32_t n_cols,
+                                          int32_t num_segments, int32_t k_in);
+int pgnn_segmax_fc_bwd_f32(const float *Y, int64_t ld_y,
+                           const int32_t *seg_ids, int64_t n_rows,
+                           int32_t n_cols, int32_t num_segments,
+                           const float *out, int64_t ld_out,
+                           const float *grad_out, int64_t ld_go,
+                           const float *X, int64_t ld_x, int32_t k_in,
+                           const float *WT, int64_t ld_wt, float *dX,
+                           int64_t ld_dx, int32_t dx_cols, int32_t mask_x,
+                           float *dW, float *db, void *workspace,
+                           size_t workspace_bytes, void *stream);
 /* dW [k_in, n_out] (= X^T dZ) and db [n_out] (= column sums of dZ; may be
  * NULL) of y = x W + b, deterministic (fixed-order slice reduction).
  * accumulate != 0 adds to dW/db.                                             */

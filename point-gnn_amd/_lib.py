@@ -27,6 +27,12 @@ class FcLayer(ctypes.Structure):
                 ("relu_from", c_i32)]
 
 
+class PackJob(ctypes.Structure):
+    """One record of pgnn_pack_fc_many's job table."""
+    _fields_ = [("w", c_vp), ("b", c_vp), ("dst", c_vp), ("k_in", c_i32),
+                ("n_out", c_i32), ("kind", c_i32), ("first_block", c_i32)]
+
+
 class PointGnnHipError(RuntimeError):
     pass
 
@@ -95,6 +101,12 @@ _SIGNATURES = {
     # training step
     "pgnn_pack_fc_device": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp,
                                     c_vp]),
+    "pgnn_pack_fc_many": (c_i32, [c_vp, c_i32, c_i32, c_vp]),
+    "pgnn_segmax_fc_bwd_workspace_bytes": (c_sz, [c_i64, c_i32, c_i32, c_i32]),
+    "pgnn_segmax_fc_bwd_f32": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_i32,
+                                       c_vp, c_i64, c_vp, c_i64, c_vp, c_i64,
+                                       c_i32, c_vp, c_i64, c_vp, c_i64, c_i32,
+                                       c_i32, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "pgnn_edge_hidden_fwd": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp,
                                      c_vp]),
     "pgnn_edge_hidden_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_vp,

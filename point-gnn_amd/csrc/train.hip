@@ -314,8 +314,11 @@ __global__ void segmax_count_win4_kernel(
 }
 
 // one wave per row: lanes own columns c = lane + 64 j of Y and features
-// k = lane + 64 i of X / dX
-template <int J /* ceil(cols/64) */, int I /* ceil(ld_dx/64) */>
+// k = lane + 64 i of X / dX.  Branch-free on purpose: every load of a phase is
+// issued before the first use (clamped addresses + selects instead of
+// predicated loads -- with `if (c < cols) load` the compiler serialised the
+// loads behind exec-mask branches and a row cost ~30 us of latency).
+template <int J /* ceil(cols/64) */, int I /* ceil(dx_cols/64) */>
 __global__ __launch_bounds__(256) void segmax_route_sparse_kernel(
     const float *__restrict__ data, int64_t ld, const int32_t *__restrict__ seg,
     int64_t rows, int cols, int nseg, const float *__restrict__ out, int64_t ldo,
@@ -326,49 +329,65 @@ __global__ __launch_bounds__(256) void segmax_route_sparse_kernel(
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  int kc[I];  // clamped feature index of this lane (loads), validity by k < k_in
+#pragma unroll
+  for (int i = 0; i < I; ++i) kc[i] = min(lane + 64 * i, k_in - 1);
   for (int64_t r = wave; r < rows; r += n_waves) {
-    const int s = seg[r];
+    const int s_raw = seg[r];
+    const bool s_ok = s_raw >= 0 && s_raw < nseg;
+    const int s = s_ok ? s_raw : 0;
+    float d[J], o[J], go[J], xv[I];
+    int cn[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const int cc = min(lane + 64 * j, cols - 1);
+      d[j] = data[r * ld + cc];
+      o[j] = out[(int64_t)s * ldo + cc];
+      go[j] = gout[(int64_t)s * ldg + cc];
+      cn[j] = cnt[(int64_t)s * ldc + cc];
+    }
+#pragma unroll
+    for (int i = 0; i < I; ++i) xv[i] = X[r * ldx + kc[i]];
+    float g[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const bool w = s_ok && (lane + 64 * j) < cols && d[j] > 0.0f && d[j] == o[j];
+      g[j] = w ? go[j] / (float)max(cn[j], 1) : 0.0f;
+    }
     float acc[I];
 #pragma unroll
     for (int i = 0; i < I; ++i) acc[i] = 0.0f;
-    if (s >= 0 && s < nseg) {
-      float g[J];
 #pragma unroll
-      for (int j = 0; j < J; ++j) {
-        const int c = lane + 64 * j;
-        g[j] = 0.0f;
-        if (c < cols) {
-          const float d = data[r * ld + c];
-          if (d > 0.0f && d == out[(int64_t)s * ldo + c])
-            g[j] = gout[(int64_t)s * ldg + c] /
-                   (float)cnt[(int64_t)s * ldc + c];
+    for (int j = 0; j < J; ++j) {
+      // a winner whose incoming gradient is exactly 0 contributes nothing
+      unsigned long long m = __ballot(g[j] != 0.0f);
+      while (m) {  // two winners per round: their W^T rows load together
+        const int l0 = __builtin_ctzll(m);
+        m &= m - 1;
+        const int l1 = m ? __builtin_ctzll(m) : l0;
+        const float g0 = __shfl(g[j], l0);
+        const float g1 = m ? __shfl(g[j], l1) : 0.0f;
+        m &= m - 1;
+        const float *w0 = WT + (int64_t)(l0 + 64 * j) * ldwt;
+        const float *w1 = WT + (int64_t)(l1 + 64 * j) * ldwt;
+        float a0[I], a1[I];
+#pragma unroll
+        for (int i = 0; i < I; ++i) {
+          a0[i] = w0[kc[i]];
+          a1[i] = w1[kc[i]];
         }
-      }
 #pragma unroll
-      for (int j = 0; j < J; ++j) {
-        // a winner whose incoming gradient is exactly 0 contributes nothing
-        unsigned long long m = __ballot(g[j] != 0.0f);
-        while (m) {
-          const int l = __builtin_ctzll(m);
-          m &= m - 1;
-          const float gv = __shfl(g[j], l);
-          const float *wrow = WT + (int64_t)(l + 64 * j) * ldwt;
-#pragma unroll
-          for (int i = 0; i < I; ++i) {
-            const int k = lane + 64 * i;
-            if (k < k_in) acc[i] += gv * wrow[k];
-          }
+        for (int i = 0; i < I; ++i) {
+          acc[i] += g0 * a0[i];
+          acc[i] += g1 * a1[i];
         }
       }
     }
 #pragma unroll
     for (int i = 0; i < I; ++i) {
       const int k = lane + 64 * i;
-      if (k < wdx) {
-        float v = acc[i];
-        if (mask_x && !(k < k_in && X[r * ldx + k] > 0.0f)) v = 0.0f;
-        dX[r * lddx + k] = v;
-      }
+      const bool live = k < k_in && (!mask_x || xv[i] > 0.0f);
+      if (k < wdx) dX[r * lddx + k] = live ? acc[i] : 0.0f;
     }
   }
 }
@@ -727,6 +746,154 @@ extern "C" int pgnn_pack_fc_device(const float *w, const float *b, int32_t k_in,
   hipLaunchKernelGGL(pack_fc_device_kernel, dim3(grid_for((int64_t)total)),
                      dim3(256), 0, (hipStream_t)stream_, w, b, k_in, n_out,
                      transpose, packed);
+  PGNN_HIP(hipGetLastError());
+  return 0;
+  PGNN_GUARD_END
+}
+
+extern "C" int pgnn_pack_fc_many(const void *jobs_device, int32_t n_jobs,
+                                 int32_t total_blocks, void *stream_) {
+  PGNN_GUARD_BEGIN
+  if (n_jobs <= 0 || total_blocks <= 0) return 0;
+  PGNN_REQUIRE(jobs_device, PGNN_E_INVALID, "pack_fc_many: null job table");
+  hipLaunchKernelGGL(pack_many_kernel, dim3((unsigned)total_blocks), dim3(256), 0,
+                     (hipStream_t)stream_,
+                     reinterpret_cast<const PackJob *>(jobs_device), n_jobs);
+  PGNN_HIP(hipGetLastError());
+  return 0;
+  PGNN_GUARD_END
+}
+
+namespace {
+struct SegFcWs {
+  int32_t *cnt, *win, *tie;
+  float *partial, *partial_b;
+  int ldc, slices, seg_per_slice, kin_p;
+};
+int segfc_slices(int32_t num_segments, int32_t n_cols) {
+  // (columns x slices) waves: enough to fill the chip a few times over
+  int s = (8 * 256 * 4 + n_cols - 1) / n_cols;
+  const int max_s = (num_segments + 63) / 64;
+  if (s > max_s) s = max_s;
+  if (s < 1) s = 1;
+  return s;
+}
+size_t segfc_carve(void *ws, int64_t n_rows, int32_t n_cols,
+                   int32_t num_segments, int32_t k_in, SegFcWs *o) {
+  const int ldc = (n_cols + 3) / 4 * 4;
+  const int slices = segfc_slices(num_segments, n_cols);
+  const int kin_p = (k_in + 15) / 16 * 16;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    const size_t at = off;
+    off += (bytes + 255) / 256 * 256;
+    return at;
+  };
+  const size_t a_cnt = take((size_t)num_segments * ldc * 4 + 256);  // + tie flag
+  const size_t a_win = take((size_t)num_segments * ldc * 4);
+  const size_t a_par = take((size_t)slices * n_cols * kin_p * 4);
+  const size_t a_pb = take((size_t)slices * n_cols * 4);
+  if (o) {
+    char *b = (char *)ws;
+    o->cnt = (int32_t *)(b + a_cnt);
+    o->tie = o->cnt + (size_t)num_segments * ldc;  // zeroed with the counts
+    o->win = (int32_t *)(b + a_win);
+    o->partial = (float *)(b + a_par);
+    o->partial_b = (float *)(b + a_pb);
+    o->ldc = ldc;
+    o->slices = slices;
+    o->seg_per_slice = (num_segments + slices - 1) / slices;
+    o->kin_p = kin_p;
+  }
+  (void)n_rows;
+  return off + 256;
+}
+}  // namespace
+
+extern "C" size_t pgnn_segmax_fc_bwd_workspace_bytes(int64_t n_rows,
+                                                     int32_t n_cols,
+                                                     int32_t num_segments,
+                                                     int32_t k_in) {
+  if (n_rows < 0 || n_cols <= 0 || num_segments < 0 || k_in <= 0) return 0;
+  return segfc_carve(nullptr, n_rows, n_cols, num_segments, k_in, nullptr);
+}
+
+extern "C" int pgnn_segmax_fc_bwd_f32(
+    const float *Y, int64_t ld_y, const int32_t *seg_ids, int64_t n_rows,
+    int32_t n_cols, int32_t num_segments, const float *out, int64_t ld_out,
+    const float *grad_out, int64_t ld_go, const float *X, int64_t ld_x,
+    int32_t k_in, const float *WT, int64_t ld_wt, float *dX, int64_t ld_dx,
+    int32_t dx_cols, int32_t mask_x, float *dW, float *db, void *workspace,
+    size_t workspace_bytes, void *stream_) {
+  PGNN_GUARD_BEGIN
+  hipStream_t stream = (hipStream_t)stream_;
+  PGNN_REQUIRE(n_rows >= 0 && n_cols > 0 && n_cols <= 512 && num_segments >= 0 &&
+                   k_in > 0 && k_in <= 512,
+               PGNN_E_INVALID, "segmax_fc_bwd: bad sizes");
+  if (n_rows == 0 || num_segments == 0) return 0;
+  PGNN_REQUIRE(Y && seg_ids && out && grad_out && X && WT && dW, PGNN_E_INVALID,
+               "segmax_fc_bwd: null pointer");
+  PGNN_REQUIRE(ld_y % 4 == 0 && ld_out % 4 == 0 && (uintptr_t)Y % 16 == 0 &&
+                   (uintptr_t)out % 16 == 0 && ld_y >= (n_cols + 3) / 4 * 4 &&
+                   ld_out >= (n_cols + 3) / 4 * 4,
+               PGNN_E_INVALID,
+               "segmax_fc_bwd: Y / out rows must be 16-byte aligned and padded "
+               "to a multiple of 4 columns");
+  PGNN_REQUIRE(ld_x >= k_in && ld_wt >= k_in && ld_go >= n_cols, PGNN_E_INVALID,
+               "segmax_fc_bwd: bad leading dimension");
+  PGNN_REQUIRE(!dX || (dx_cols > 0 && dx_cols <= 512 && ld_dx >= dx_cols),
+               PGNN_E_INVALID, "segmax_fc_bwd: bad dX shape");
+  PGNN_REQUIRE(workspace && workspace_bytes >= pgnn_segmax_fc_bwd_workspace_bytes(
+                                                   n_rows, n_cols, num_segments,
+                                                   k_in),
+               PGNN_E_WORKSPACE, "segmax_fc_bwd: workspace too small");
+  SegFcWs w;
+  segfc_carve(workspace, n_rows, n_cols, num_segments, k_in, &w);
+  PGNN_HIP(hipMemsetAsync(w.cnt, 0, (size_t)num_segments * w.ldc * 4 + 4, stream));
+  const int cols4 = (n_cols + 3) / 4;
+  hipLaunchKernelGGL(segmax_count_win4_kernel,
+                     dim3(grid_for(n_rows * cols4, 8192)), dim3(256), 0, stream, Y,
+                     ld_y, seg_ids, n_rows, cols4, num_segments, out, ld_out,
+                     w.cnt, w.win, w.ldc, w.tie);
+  if (dX) {
+    const int J = (n_cols + 63) / 64, I = (dx_cols + 63) / 64;
+    const unsigned blocks = (unsigned)((n_rows + 3) / 4 < 8192 ? (n_rows + 3) / 4
+                                                             : 8192);
+#define PGNN_ROUTE(JV, IV)                                                     \
+  hipLaunchKernelGGL((segmax_route_sparse_kernel<JV, IV>), dim3(blocks),       \
+                     dim3(256), 0, stream, Y, ld_y, seg_ids, n_rows, n_cols,   \
+                     num_segments, out, ld_out, grad_out, ld_go, w.cnt, w.ldc,  \
+                     WT, ld_wt, k_in, X, ld_x, mask_x, dX, ld_dx, dx_cols)
+    if (J == 5 && I == 5) PGNN_ROUTE(5, 5);
+    else if (J == 5 && I == 2) PGNN_ROUTE(5, 2);
+    else if (J == 4 && I == 4) PGNN_ROUTE(4, 4);
+    else if (J == 8 && I == 4) PGNN_ROUTE(8, 4);
+    else PGNN_ROUTE(8, 8);
+#undef PGNN_ROUTE
+  }
+  {
+    dim3 grid((unsigned)n_cols, (unsigned)w.slices);
+    const int I = (w.kin_p + 63) / 64;
+#define PGNN_WG(IV)                                                            \
+  hipLaunchKernelGGL((segmax_wgrad_gather_kernel<IV>), grid, dim3(64), 0,      \
+                     stream, grad_out, ld_go, w.cnt, w.win, w.ldc, num_segments, \
+                     w.seg_per_slice, X, ld_x, k_in, w.kin_p, w.partial,        \
+                     w.partial_b, n_cols)
+    if (I <= 2) PGNN_WG(2);
+    else if (I <= 4) PGNN_WG(4);
+    else if (I == 5) PGNN_WG(5);
+    else PGNN_WG(8);
+#undef PGNN_WG
+    hipLaunchKernelGGL(segmax_wgrad_reduce_kernel,
+                       dim3(grid_for((int64_t)(k_in + 1) * n_cols)), dim3(256), 0,
+                       stream, w.partial, w.partial_b, w.slices, n_cols, k_in,
+                       w.kin_p, dW, db);
+    hipLaunchKernelGGL(segmax_wgrad_ties_kernel,
+                       dim3(grid_for(n_rows * n_cols, 2048)), dim3(256), 0,
+                       stream, w.tie, Y, ld_y, seg_ids, n_rows, n_cols,
+                       num_segments, out, ld_out, grad_out, ld_go, w.cnt, w.ldc,
+                       X, ld_x, k_in, dW, db);
+  }
   PGNN_HIP(hipGetLastError());
   return 0;
   PGNN_GUARD_END

@@ -245,6 +245,7 @@ class _Fc(object):
         self.w, self.b, self.gw, self.gb = w, b, gw, gb
         self.packed = None    # forward image  (k_in -> n_out, bias)
         self.packed_t = None  # backward image (n_out -> k_in, no bias)
+        self.wt = None        # plain W^T [n_out, pad16(k_in)] (sparse adjoint)
 
 
 class Trainer(object):
@@ -276,6 +277,10 @@ class Trainer(object):
         self.device = device or torch.device("cuda",
                                              torch.cuda.current_device())
         self.lib = _lib.load()
+        # the last per-edge layer + scatter-max of every stage is
+        # differentiated sparsely (pgnn_segmax_fc_bwd_f32); False = the dense
+        # adjoint primitives (tests compare the two)
+        self.sparse_adjoint = True
         self.box_len = box_encoding_len
         self.nc = config['num_classes']
         self.pg = process_group
@@ -319,6 +324,8 @@ class Trainer(object):
                                 self._view(self.grad, name),
                                 self._view(self.grad, base + '/biases'))
         self._ws = None
+        self._ws2 = None
+        self._pack_jobs = None
         self.repack()
 
     # ---- plumbing -----------------------------------------------------------
@@ -359,25 +366,87 @@ class Trainer(object):
     def _st(self):
         return _lib.stream_ptr()
 
-    def repack(self):
-        """Refresh the MFMA-fragment images of every layer (forward and
-        transposed) from the flat buffer -- after init and after every SGD
-        step."""
-        lib, st = self.lib, self._st()
+    def _sparse_layers(self):
+        """Names of the layers whose output feeds a scatter-max (the last
+        per-edge layer of every pooling / GNN stage): their adjoint runs
+        sparse (pgnn_segmax_fc_bwd_f32) and needs a plain W^T image."""
+        out = []
+        for lc in self.config['model_kwargs']['layer_configs'][:-1]:
+            kw = lc['kwargs']
+            if lc['type'] == 'scatter_max_point_set_pooling':
+                n = len(kw['point_MLP_depth_list'])
+            elif lc['type'] == 'scatter_max_graph_auto_center_net':
+                n = len(kw['edge_MLP_depth_list'])
+            else:
+                continue
+            if n >= 2:   # the layer needs a materialised input activation
+                out.append(mlp_names(
+                    lc['scope'] + '/extract_vertex_features', n)[-1])
+        return out
+
+    def _build_pack_jobs(self):
+        """Device table of pgnn_pack_fc_many: the fragment images (forward,
+        transposed) of every layer, the W^T rows of the Wx block of each first
+        edge layer (dx' = dQ Wx^T), plain W^T of the sparse-adjoint layers."""
+        lib = self.lib
+        sparse = set(self._sparse_layers())
+        jobs = []
+
+        def add(w_ptr, b_ptr, dst, k_in, n_out, kind):
+            if kind == 2:
+                elems = n_out * padded_width(k_in)
+            elif kind == 1:
+                elems = lib.pgnn_packed_fc_floats(n_out, k_in)
+            else:
+                elems = lib.pgnn_packed_fc_floats(k_in, n_out)
+            jobs.append((w_ptr, b_ptr, dst.data_ptr(), k_in, n_out, kind,
+                         (int(elems) + 255) // 256))
         for fc in self.fc.values():
-            if fc.packed is None:
-                fc.packed = torch.empty(
-                    lib.pgnn_packed_fc_floats(fc.k_in, fc.n_out),
-                    dtype=torch.float32, device=self.device)
-                fc.packed_t = torch.empty(
-                    lib.pgnn_packed_fc_floats(fc.n_out, fc.k_in),
-                    dtype=torch.float32, device=self.device)
-            _lib.check(lib.pgnn_pack_fc_device(
-                _lib.ptr(fc.w), _lib.ptr(fc.b), fc.k_in, fc.n_out, 0,
-                _lib.ptr(fc.packed), st), "pgnn_pack_fc_device")
-            _lib.check(lib.pgnn_pack_fc_device(
-                _lib.ptr(fc.w), None, fc.k_in, fc.n_out, 1,
-                _lib.ptr(fc.packed_t), st), "pgnn_pack_fc_device")
+            fc.packed = torch.empty(
+                lib.pgnn_packed_fc_floats(fc.k_in, fc.n_out),
+                dtype=torch.float32, device=self.device)
+            fc.packed_t = torch.empty(
+                lib.pgnn_packed_fc_floats(fc.n_out, fc.k_in),
+                dtype=torch.float32, device=self.device)
+            add(fc.w.data_ptr(), fc.b.data_ptr(), fc.packed, fc.k_in,
+                fc.n_out, 0)
+            add(fc.w.data_ptr(), 0, fc.packed_t, fc.k_in, fc.n_out, 1)
+            if fc.name in sparse:
+                fc.wt = torch.empty((fc.n_out, padded_width(fc.k_in)),
+                                    dtype=torch.float32, device=self.device)
+                add(fc.w.data_ptr(), 0, fc.wt, fc.k_in, fc.n_out, 2)
+        # Wx = rows c..c+2 of every first edge layer, transposed image
+        self.wx_packed_t = {}
+        for lc in self.config['model_kwargs']['layer_configs'][:-1]:
+            if lc['type'] != 'scatter_max_graph_auto_center_net':
+                continue
+            name = mlp_names(lc['scope'] + '/extract_vertex_features', 1)[0]
+            w1 = self.fc[name]
+            c = w1.k_in - 3
+            pk = torch.empty(lib.pgnn_packed_fc_floats(w1.n_out, 3),
+                             dtype=torch.float32, device=self.device)
+            add(w1.w.data_ptr() + 4 * c * w1.n_out, 0, pk, 3, w1.n_out, 1)
+            self.wx_packed_t[name] = pk
+        arr = (_lib.PackJob * len(jobs))()
+        first = 0
+        for i, (w, b, dst, k, n, kind, blocks) in enumerate(jobs):
+            arr[i].w, arr[i].b, arr[i].dst = w, b or None, dst
+            arr[i].k_in, arr[i].n_out, arr[i].kind = int(k), int(n), int(kind)
+            arr[i].first_block = first
+            first += blocks
+        raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
+        self._pack_jobs = torch.from_numpy(raw).to(self.device)
+        self._pack_n, self._pack_blocks = len(jobs), first
+
+    def repack(self):
+        """Refresh every device image derived from the flat buffer (MFMA
+        fragment images forward / transposed, plain W^T of the sparse-adjoint
+        layers) -- after init and after every SGD step: ONE launch."""
+        if getattr(self, '_pack_jobs', None) is None:
+            self._build_pack_jobs()
+        _lib.check(self.lib.pgnn_pack_fc_many(
+            _lib.ptr(self._pack_jobs), self._pack_n, self._pack_blocks,
+            self._st()), "pgnn_pack_fc_many")
 
     def _layer_array(self, packed, k_in, n_out, relu):
         arr = (_lib.FcLayer * 1)()
@@ -451,6 +520,33 @@ class Trainer(object):
             int(getattr(dst, "_pgnn_sorted", 0)), self._st()),
             "pgnn_scatter_max_bwd_f32")
         return gdata
+
+    def _segmax_fc_bwd(self, name, y, dst, out, gout, x, need_dx=True,
+                       mask_x=True):
+        """Adjoint of out = scatter_max(y), y = ReLU(x W + b) for layer `name`
+        (pgnn_segmax_fc_bwd_f32): accumulates dW / db, returns dX (masked by
+        x > 0) or None."""
+        fc = self.fc[name]
+        rows, k = int(y.shape[0]), int(out.shape[0])
+        need = self.lib.pgnn_segmax_fc_bwd_workspace_bytes(rows, fc.n_out, k,
+                                                           fc.k_in)
+        if self._ws2 is None or self._ws2.numel() < need:
+            self._ws2 = torch.empty(int(need), dtype=torch.uint8,
+                                    device=self.device)
+        dx = None
+        if need_dx:
+            dx = torch.empty((rows, int(x.shape[1])), dtype=torch.float32,
+                             device=self.device)
+        _lib.check(self.lib.pgnn_segmax_fc_bwd_f32(
+            _lib.ptr(y), y.stride(0), _lib.ptr(dst), rows, fc.n_out, k,
+            _lib.ptr(out), out.stride(0), _lib.ptr(gout), gout.stride(0),
+            _lib.ptr(x), x.stride(0), fc.k_in, _lib.ptr(fc.wt),
+            fc.wt.stride(0), _lib.ptr(dx),
+            dx.stride(0) if dx is not None else 0,
+            int(x.shape[1]) if dx is not None else 0, 1 if mask_x else 0,
+            _lib.ptr(fc.gw), _lib.ptr(fc.gb), _lib.ptr(self._ws2),
+            self._ws2.numel(), self._st()), "pgnn_segmax_fc_bwd_f32")
+        return dx
 
     @staticmethod
     def _sorted_dst(edges):
@@ -659,12 +755,16 @@ class Trainer(object):
                     d = self.fc_bwd(unames[i], uacts[i], uacts[i + 1], dcur,
                                     not last)
                 dagg = d
-                g = self._scatter_max_bwd(eacts[-1], dst, agg, dagg)
-                if getattr(self, 'debug', None) is not None:
-                    self.debug[enames[0] + '#z2'] = dict(
-                        gz2=g.clone(), h1=eacts[0].clone(), h2=eacts[-1].clone(),
-                        e=e.clone())
-                for i in range(len(enames) - 1, 0, -1):
+                if self.sparse_adjoint and self.fc[enames[-1]].wt is not None:
+                    # last edge layer + scatter-max: sparse adjoint (returns
+                    # the gradient w.r.t. its input, already ReLU-masked)
+                    g = self._segmax_fc_bwd(enames[-1], eacts[-1], dst, agg,
+                                            dagg, eacts[-2])
+                    dense_from = len(enames) - 2
+                else:
+                    g = self._scatter_max_bwd(eacts[-1], dst, agg, dagg)
+                    dense_from = len(enames) - 1
+                for i in range(dense_from, 0, -1):
                     # g is already masked by the ReLU of layer i (relu_mask)
                     g = self.fc_bwd(enames[i], eacts[i - 1], eacts[i], g,
                                     relu=False)
@@ -691,13 +791,9 @@ class Trainer(object):
                 gwx_ptr = ctypes.c_void_p(w1.gw.data_ptr() + 4 * c * w1.n_out)
                 self._weight_grad(xo, 3, 3, dq, w1.n_out, gwx_ptr, None)
                 if off_names is not None:
-                    pk = torch.empty(lib.pgnn_packed_fc_floats(w1.n_out, 3),
-                                     dtype=torch.float32, device=dev)
-                    wx_ptr = ctypes.c_void_p(w1.w.data_ptr() + 4 * c * w1.n_out)
-                    _lib.check(lib.pgnn_pack_fc_device(
-                        wx_ptr, None, 3, w1.n_out, 1, _lib.ptr(pk), st),
-                        "pgnn_pack_fc_device")
-                    d = self._mlp1(pk, w1.n_out, 3, False, dq, w1.n_out)
+                    # dx' = dQ Wx^T (image refreshed by repack())
+                    d = self._mlp1(self.wx_packed_t[enames[0]], w1.n_out, 3,
+                                   False, dq, w1.n_out)
                     for i in range(len(off_names) - 1, -1, -1):
                         d = self.fc_bwd(off_names[i], off_acts[i],
                                         off_acts[i + 1], d,
@@ -709,8 +805,14 @@ class Trainer(object):
                 d = dh
                 for i in range(len(onames) - 1, -1, -1):
                     d = self.fc_bwd(onames[i], oacts[i], oacts[i + 1], d, True)
-                g = self._scatter_max_bwd(acts[-1], dst, agg, d)
-                for i in range(len(names) - 1, -1, -1):
+                if self.sparse_adjoint and self.fc[names[-1]].wt is not None:
+                    g = self._segmax_fc_bwd(names[-1], acts[-1], dst, agg, d,
+                                            acts[-2])
+                    dense_from = len(names) - 2
+                else:
+                    g = self._scatter_max_bwd(acts[-1], dst, agg, d)
+                    dense_from = len(names) - 1
+                for i in range(dense_from, -1, -1):
                     g = self.fc_bwd(names[i], acts[i], acts[i + 1], g,
                                     relu=False, need_dx=i > 0)
                     if i > 0:

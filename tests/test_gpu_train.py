@@ -315,3 +315,93 @@ def test_two_frame_batch_equals_two_ranks(dev):
     for n, ref in g_ref.items():
         e_max, e_fro = _grad_errors(g_merged[n], ref)
         assert e_fro < 3e-3 and e_max < 3e-2, (n, e_max, e_fro)
+
+
+@pytest.mark.parametrize("rows,k_in,n_cols,nseg,ties", [
+    (4000, 300, 300, 90, False), (4000, 300, 300, 90, True),
+    (9000, 128, 300, 150, False), (3000, 256, 256, 40, True),
+    (2500, 256, 512, 60, False), (700, 40, 70, 9, True), (5, 16, 16, 3, False)])
+def test_segmax_fc_bwd_matches_dense_adjoint(dev, rows, k_in, n_cols, nseg,
+                                             ties):
+    """pgnn_segmax_fc_bwd_f32 (sparse adjoint of out = segment_max(ReLU(XW+b)))
+    against the dense chain in float64: dZ = TF's tie-sharing scatter-max
+    gradient * [Y > 0], dX = (dZ W^T) * [X > 0], dW = X^T dZ, db = sum dZ.
+    `ties`: duplicated X rows inside segments give equal POSITIVE maxima
+    (duplicate points of a cloud), which share the gradient equally."""
+    import torch
+    from pointgnn_amd import _lib, gnn
+    from pointgnn_amd.gnn import padded_width
+    lib = _lib.load()
+    rng = np.random.default_rng(rows + n_cols)
+    kp, cp = padded_width(k_in), padded_width(n_cols)
+    x = np.zeros((rows, kp), np.float32)
+    x[:, :k_in] = np.maximum(rng.standard_normal((rows, k_in)), 0)
+    seg = np.sort(rng.integers(0, nseg, rows)).astype(np.int32)
+    if nseg > 4:
+        seg[seg == 2] = 3                                # an empty segment
+    if ties and rows > 50:
+        for t in range(0, rows - 3, 7):                  # duplicate neighbours
+            if seg[t] == seg[t + 1]:
+                x[t + 1] = x[t]
+    w = (rng.standard_normal((k_in, n_cols)) / np.sqrt(k_in)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(n_cols)).astype(np.float32)
+    y = np.zeros((rows, cp), np.float32)
+    y[:, :n_cols] = np.maximum(x[:, :k_in] @ w + b, 0)
+    gout = np.zeros((nseg, cp), np.float32)
+    gout[:, :n_cols] = rng.standard_normal((nseg, n_cols))
+    wt = np.zeros((n_cols, kp), np.float32)
+    wt[:, :k_in] = w.T
+    yd, xd, sd, wtd, god = (T(y, dev), T(x, dev), T(seg, dev), T(wt, dev),
+                            T(gout, dev))
+    out = gnn.graph_scatter_max_fn(yd, sd, nseg, ids_sorted=True)
+    dx = torch.full((rows, kp), 7.0, dtype=torch.float32, device=dev)
+    dw = torch.full((k_in, n_cols), 0.25, dtype=torch.float32, device=dev)
+    db = torch.full((n_cols,), -0.5, dtype=torch.float32, device=dev)
+    ws = torch.empty(lib.pgnn_segmax_fc_bwd_workspace_bytes(rows, n_cols, nseg,
+                                                            k_in),
+                     dtype=torch.uint8, device=dev)
+    _lib.check(lib.pgnn_segmax_fc_bwd_f32(
+        _lib.ptr(yd), cp, _lib.ptr(sd), rows, n_cols, nseg, _lib.ptr(out),
+        out.stride(0), _lib.ptr(god), cp, _lib.ptr(xd), kp, k_in,
+        _lib.ptr(wtd), kp, _lib.ptr(dx), kp, kp, 1, _lib.ptr(dw), _lib.ptr(db),
+        _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "segmax_fc_bwd")
+    # float64 reference
+    y64 = y[:, :n_cols].astype(np.float64)
+    o64 = out.cpu().numpy()[:, :n_cols].astype(np.float64)
+    sel = (y64 == o64[seg]) & (y64 > 0)
+    cnt = np.zeros((nseg, n_cols))
+    np.add.at(cnt, seg, sel)
+    dz = np.where(sel, gout[seg][:, :n_cols] / np.maximum(cnt[seg], 1), 0.0)
+    if ties and rows > 50:
+        assert cnt.max() >= 2, "the case was meant to contain positive ties"
+    ref_dx = (dz @ w.astype(np.float64).T) * (x[:, :k_in] > 0)
+    ref_dw = x[:, :k_in].astype(np.float64).T @ dz + 0.25
+    ref_db = dz.sum(0) - 0.5
+    got_dx = dx.cpu().numpy()
+    np.testing.assert_allclose(got_dx[:, :k_in], ref_dx, atol=2e-5, rtol=1e-4)
+    assert np.all(got_dx[:, k_in:] == 0)
+    np.testing.assert_allclose(dw.cpu().numpy(), ref_dw, atol=5e-5, rtol=2e-4)
+    np.testing.assert_allclose(db.cpu().numpy(), ref_db, atol=5e-5, rtol=2e-4)
+
+
+@pytest.mark.parametrize("name", ["car_auto_T1", "car_auto_T3"])
+def test_sparse_and_dense_adjoint_give_the_same_gradient(dev, name):
+    """Trainer.sparse_adjoint switches the last per-edge layer + scatter-max of
+    every stage between pgnn_segmax_fc_bwd_f32 and the dense primitives
+    (pgnn_scatter_max_bwd_f32 + two GEMMs): same forward, same masks and
+    arg-max picks, so the gradients agree to float32 summation order."""
+    from pointgnn_amd import train
+    cfg = configs.get_config(name)
+    params = weights.init_params(cfg, seed=5, bias_scale=0.1)
+    batch = _tiny_batch(seed=3, num_classes=cfg["num_classes"])
+    grads = {}
+    for mode in (True, False):
+        tr = train.Trainer(cfg, params=params, device=dev)
+        tr.sparse_adjoint = mode
+        tr.train_step(batch, apply=False)
+        grads[mode] = tr.grad_dict()
+    for n in grads[True]:
+        a, b = grads[True][n].astype(np.float64), grads[False][n].astype(np.float64)
+        scale = max(np.abs(b).max(), 1e-12)
+        assert np.abs(a - b).max() <= 2e-5 * scale + 1e-9, (
+            n, np.abs(a - b).max(), scale)
