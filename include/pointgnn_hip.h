@@ -339,7 +339,8 @@ int pgnn_pack_fc_device(const float *w, const float *b, int32_t k_in,
  *            kind, first_block; }                         (40 bytes each)
  * kind 0 = pgnn_pack_fc image of (w [k_in,n_out], b), 1 = image of w^T (no
  * bias), 2 = plain w^T as [n_out][16*ceil(k_in/16)] rows (zero padded; what
- * pgnn_segmax_fc_bwd_f32 reads).  A job covers ceil(elements / 256) blocks
+ * pgnn_segmax_fc_bwd_f32 reads), 3 = plain w as [k_in][16*ceil(n_out/16)]
+ * rows (zero padded).  A job covers ceil(elements / 256) blocks
  * of the launch; first_block is the running sum, total_blocks the grand
  * total.  The table is built once: the flat parameter buffer never moves.  */
 int pgnn_pack_fc_many(const void *jobs_device, int32_t n_jobs,
@@ -433,6 +434,85 @@ int pgnn_sgd_step(float *params, const float *grads, const float *is_weight,
 /* *out (device double) = sum |params| over is_weight entries (reg_loss/scale). */
 int pgnn_l1_norm(const float *params, const float *is_weight, int64_t n,
                  double *out, void *stream);
+
+/* ---- native training step (config 4) ----------------------------------------
+ * What train.py builds with TF towers -- model.predict with saved
+ * activations, tf.gradients of model.loss (models.py:79-163, 170-311;
+ * train.py:225-297) -- as ONE object on the device: the whole forward and the
+ * whole backward are two calls, every kernel launch inside is issued from C++.
+ * (The Python mirror keeps a step composed of the primitives above; tests hold
+ * the two to the same gradients.)
+ *
+ * The model is described by where each fully connected layer lives in the
+ * caller's FLAT parameter buffer (reference variable order, [k_in, n_out]
+ * row-major weights, then biases): offsets in floats.  Gradients go to a flat
+ * buffer of the same layout and are ACCUMULATED (zero it per step).          */
+#define PGNN_TRAIN_MAX_FC 8
+#define PGNN_TRAIN_MAX_STAGES 8
+#define PGNN_TRAIN_MAX_CLASSES 16
+#define PGNN_TRAIN_MAX_LEVELS 4
+typedef struct pgnn_train_fc {
+  int64_t w_off, b_off; /* float offsets of weights / biases in the flat buffer */
+  int32_t k_in, n_out;
+} pgnn_train_fc;
+typedef struct pgnn_train_stage {
+  int32_t kind;        /* 0 = scatter_max_point_set_pooling (gnn.py:222-283),
+                          1 = scatter_max_graph_auto_center_net (gnn.py:298-373) */
+  int32_t graph_level; /* index into the batch's coords / keypoints / edges     */
+  int32_t n_a, n_b, n_c, reserved;
+  pgnn_train_fc a[PGNN_TRAIN_MAX_FC]; /* point MLP / edge MLP (all ReLU)        */
+  pgnn_train_fc b[PGNN_TRAIN_MAX_FC]; /* output MLP (ReLU) / update MLP (last
+                                         layer linear, + residual)             */
+  pgnn_train_fc c[PGNN_TRAIN_MAX_FC]; /* auto-offset MLP, last layer linear;
+                                         n_c = 0: auto_offset False            */
+} pgnn_train_stage;
+typedef struct pgnn_train_model {
+  int32_t n_stages, num_classes, box_len, reserved;
+  int64_t n_params;
+  pgnn_train_stage stages[PGNN_TRAIN_MAX_STAGES];
+  pgnn_train_fc cls[2];                          /* C -> 64 -> nc (gnn.py:145-152)  */
+  pgnn_train_fc loc[PGNN_TRAIN_MAX_CLASSES][3];  /* per class C -> 64 -> 64 -> L   */
+} pgnn_train_model;
+typedef struct pgnn_train_batch { /* device pointers; what train.py's batch_data
+                                     returns for this rank (train.py:135-171) */
+  const float *input_v;           /* [n_vertices[0], n_feat]                   */
+  int32_t n_feat, n_levels;
+  int64_t n_vertices[PGNN_TRAIN_MAX_LEVELS + 1];
+  const float *coords[PGNN_TRAIN_MAX_LEVELS + 1];   /* [n_vertices[l], 3]      */
+  const int32_t *keypoints[PGNN_TRAIN_MAX_LEVELS];  /* [n_vertices[l + 1]]     */
+  const int32_t *edges[PGNN_TRAIN_MAX_LEVELS];      /* [n_edges[l], 2]         */
+  int64_t n_edges[PGNN_TRAIN_MAX_LEVELS];
+  int32_t edges_sorted[PGNN_TRAIN_MAX_LEVELS];      /* grouped by ascending dst */
+} pgnn_train_batch;
+
+int pgnn_trainer_create(const pgnn_train_model *model_host, void **handle);
+int pgnn_trainer_destroy(void *handle);
+/* Device images of the weights (MFMA fragment order forward / transposed,
+ * plain W^T of the sparse-adjoint layers, fused prediction heads) + the job
+ * table that refreshes them: the caller allocates images_bytes once and binds
+ * the flat buffers (they must not move afterwards).  bind packs once;
+ * repack after every parameter update (one launch). */
+size_t pgnn_trainer_images_bytes(void *handle);
+int pgnn_trainer_bind(void *handle, float *params, float *grads, void *images,
+                      size_t images_bytes, void *stream);
+int pgnn_trainer_repack(void *handle, void *stream);
+/* Scratch of one forward + backward on a batch of these sizes (saved
+ * activations included). */
+size_t pgnn_trainer_workspace_bytes(void *handle, const pgnn_train_batch *batch);
+/* Forward with saved activations.  *logits / *pred_box point INTO the
+ * workspace (valid until the next forward on it): logits [K, *ld_logits]
+ * (num_classes columns used), pred_box [K, num_classes, box_len] contiguous. */
+int pgnn_trainer_forward(void *handle, const pgnn_train_batch *batch,
+                         void *workspace, size_t workspace_bytes,
+                         const float **logits, int64_t *ld_logits,
+                         const float **pred_box, void *stream);
+/* Backward of the forward last run on `workspace`: dlogits [K, num_classes]
+ * and dpred_box [K, num_classes, box_len] (what pgnn_loss_fwd_bwd wrote) ->
+ * gradients accumulated into the bound flat gradient buffer. */
+int pgnn_trainer_backward(void *handle, const pgnn_train_batch *batch,
+                          void *workspace, size_t workspace_bytes,
+                          const float *dlogits, const float *dpred_box,
+                          void *stream);
 
 /* ---- detection post-processing (the step right after
  * the path; run.py:264-326).  All arrays are device pointers.

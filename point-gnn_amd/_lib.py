@@ -33,6 +33,43 @@ class PackJob(ctypes.Structure):
                 ("n_out", c_i32), ("kind", c_i32), ("first_block", c_i32)]
 
 
+TRAIN_MAX_FC, TRAIN_MAX_STAGES, TRAIN_MAX_CLASSES, TRAIN_MAX_LEVELS = 8, 8, 16, 4
+
+
+class TrainFc(ctypes.Structure):
+    """struct pgnn_train_fc"""
+    _fields_ = [("w_off", c_i64), ("b_off", c_i64), ("k_in", c_i32),
+                ("n_out", c_i32)]
+
+
+class TrainStage(ctypes.Structure):
+    """struct pgnn_train_stage"""
+    _fields_ = [("kind", c_i32), ("graph_level", c_i32), ("n_a", c_i32),
+                ("n_b", c_i32), ("n_c", c_i32), ("reserved", c_i32),
+                ("a", TrainFc * TRAIN_MAX_FC), ("b", TrainFc * TRAIN_MAX_FC),
+                ("c", TrainFc * TRAIN_MAX_FC)]
+
+
+class TrainModel(ctypes.Structure):
+    """struct pgnn_train_model"""
+    _fields_ = [("n_stages", c_i32), ("num_classes", c_i32),
+                ("box_len", c_i32), ("reserved", c_i32), ("n_params", c_i64),
+                ("stages", TrainStage * TRAIN_MAX_STAGES),
+                ("cls", TrainFc * 2),
+                ("loc", (TrainFc * 3) * TRAIN_MAX_CLASSES)]
+
+
+class TrainBatch(ctypes.Structure):
+    """struct pgnn_train_batch"""
+    _fields_ = [("input_v", c_vp), ("n_feat", c_i32), ("n_levels", c_i32),
+                ("n_vertices", c_i64 * (TRAIN_MAX_LEVELS + 1)),
+                ("coords", c_vp * (TRAIN_MAX_LEVELS + 1)),
+                ("keypoints", c_vp * TRAIN_MAX_LEVELS),
+                ("edges", c_vp * TRAIN_MAX_LEVELS),
+                ("n_edges", c_i64 * TRAIN_MAX_LEVELS),
+                ("edges_sorted", c_i32 * TRAIN_MAX_LEVELS)]
+
+
 class PointGnnHipError(RuntimeError):
     pass
 
@@ -107,6 +144,19 @@ _SIGNATURES = {
                                        c_vp, c_i64, c_vp, c_i64, c_vp, c_i64,
                                        c_i32, c_vp, c_i64, c_vp, c_i64, c_i32,
                                        c_i32, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "pgnn_trainer_create": (c_i32, [ctypes.POINTER(TrainModel),
+                                    ctypes.POINTER(c_vp)]),
+    "pgnn_trainer_destroy": (c_i32, [c_vp]),
+    "pgnn_trainer_images_bytes": (c_sz, [c_vp]),
+    "pgnn_trainer_bind": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "pgnn_trainer_repack": (c_i32, [c_vp, c_vp]),
+    "pgnn_trainer_workspace_bytes": (c_sz, [c_vp, ctypes.POINTER(TrainBatch)]),
+    "pgnn_trainer_forward": (c_i32, [c_vp, ctypes.POINTER(TrainBatch), c_vp,
+                                     c_sz, ctypes.POINTER(c_vp),
+                                     ctypes.POINTER(c_i64),
+                                     ctypes.POINTER(c_vp), c_vp]),
+    "pgnn_trainer_backward": (c_i32, [c_vp, ctypes.POINTER(TrainBatch), c_vp,
+                                      c_sz, c_vp, c_vp, c_vp]),
     "pgnn_edge_hidden_fwd": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp,
                                      c_vp]),
     "pgnn_edge_hidden_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_vp,

@@ -229,6 +229,7 @@ struct PackJob {
   int32_t k_in, n_out;
   int32_t kind;     // 0 fragment image, 1 fragment image of W^T (no bias),
                     // 2 plain W^T [n_out rows][ld = 16*ceil(k_in/16)], zero pad
+                    // 3 plain W   [k_in rows][ld = 16*ceil(n_out/16)], zero pad
   int32_t first_block;  // prefix sum of the jobs' block counts
 };
 static_assert(sizeof(PackJob) == 40, "PackJob layout (Python mirrors it)");
@@ -244,6 +245,15 @@ __global__ __launch_bounds__(256) void pack_many_kernel(
   }
   const PackJob j = jobs[lo];
   const int64_t base = (int64_t)(blk - j.first_block) * 256 + threadIdx.x;
+  if (j.kind == 3) {
+    const int ld = (j.n_out + 15) / 16 * 16;
+    const int64_t total = (int64_t)j.k_in * ld;
+    if (base < total) {
+      const int k = (int)(base / ld), n = (int)(base - (int64_t)k * ld);
+      j.dst[base] = n < j.n_out ? j.w[(int64_t)k * j.n_out + n] : 0.0f;
+    }
+    return;
+  }
   if (j.kind == 2) {
     const int ld = (j.k_in + 15) / 16 * 16;
     const int64_t total = (int64_t)j.n_out * ld;

@@ -1,0 +1,959 @@
+// Native training step (config 4): the forward with saved activations and the
+// whole backward of MultiLayerFastLocalGraphModelV2 (models.py:79-163, 170-311
+// through tf.gradients in train.py:225-297) driven from C++ -- one call each.
+//
+// The arithmetic is the library's own primitives (pgnn_mlp_fwd one layer at a
+// time, pgnn_scatter_max_f32, pgnn_segmax_fc_bwd_f32, pgnn_weight_grad_f32,
+// ...): this file only sequences them, carves every saved activation and
+// temporary out of ONE caller-provided workspace (no allocation, no host
+// synchronisation) and keeps the device images of the weights fresh with one
+// pack launch per parameter update.  A Python-driven step issues the same
+// ~300 launches through ctypes at ~10 us each and another ~100 torch glue
+// kernels (concat, zero fill, slice add): host-paced.  The Python mirror
+// (pointgnn_amd/train.py, Trainer.forward / .backward) is kept as the readable
+// composition and the tests hold both to the same gradients.
+#include <string.h>
+
+#include <vector>
+
+#include "pgnn_common.h"
+
+namespace {
+using namespace pgnn;
+
+inline int pad16(int n) { return (n + 15) / 16 * 16; }
+
+// ---- glue kernels ---------------------------------------------------------------
+// dst[r, dc0 + c] (op)= src[r, sc0 + c], c < ncols; ADD: accumulate
+template <bool ADD>
+__global__ void block_copy_kernel(float *__restrict__ dst, int64_t ldd, int dc0,
+                                  const float *__restrict__ src, int64_t lds,
+                                  int sc0, int64_t rows, int ncols) {
+  const int64_t total = rows * ncols;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = idx / ncols;
+    const int c = (int)(idx - r * ncols);
+    const float v = src[r * lds + sc0 + c];
+    float *d = dst + r * ldd + dc0 + c;
+    *d = ADD ? *d + v : v;
+  }
+}
+
+// hx = [h[:, :c] | x | 0 ...] (gnn.py:350-352: the vertex part of the concat)
+__global__ void concat_hx_kernel(const float *__restrict__ h, int64_t ldh, int c,
+                                 const float *__restrict__ x, int64_t rows,
+                                 float *__restrict__ hx, int ldhx) {
+  const int64_t total = rows * ldhx;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = idx / ldhx;
+    const int k = (int)(idx - r * ldhx);
+    float v = 0.0f;
+    if (k < c) v = h[r * ldh + k];
+    else if (k < c + 3) v = x[3 * r + (k - c)];
+    hx[idx] = v;
+  }
+}
+
+// pred[r, j, :L] = y[r, :L]
+__global__ void pred_slice_kernel(const float *__restrict__ y, int64_t ldy,
+                                  int64_t rows, int L, int nc, int j,
+                                  float *__restrict__ pred) {
+  const int64_t total = rows * L;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = idx / L;
+    const int k = (int)(idx - r * L);
+    pred[(r * nc + j) * L + k] = y[r * ldy + k];
+  }
+}
+
+// dy[r, :] = [dpred[r, j, :L] | 0 ...] (ld = ldy)
+__global__ void dpred_slice_kernel(const float *__restrict__ dpred, int64_t rows,
+                                   int L, int nc, int j, float *__restrict__ dy,
+                                   int ldy) {
+  const int64_t total = rows * ldy;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = idx / ldy;
+    const int k = (int)(idx - r * ldy);
+    dy[idx] = k < L ? dpred[(r * nc + j) * L + k] : 0.0f;
+  }
+}
+
+__global__ void edge_dst_kernel(const int32_t *__restrict__ edges, int64_t n,
+                                int32_t *__restrict__ dst) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    dst[i] = edges[2 * i + 1];
+}
+
+inline unsigned blocks_for(int64_t total, int cap = 2048) {
+  int64_t b = (total + 255) / 256;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+// ---- the handle -------------------------------------------------------------------
+struct PackJobRec {  // = train.hip's PackJob (pgnn_pack_fc_many's record)
+  const float *w;
+  const float *b;
+  float *dst;
+  int32_t k_in, n_out, kind, first_block;
+};
+static_assert(sizeof(PackJobRec) == 40, "job record layout");
+
+struct FcDev {  // one layer: where it lives + its device images
+  pgnn_train_fc ref;
+  float *packed = nullptr, *packed_t = nullptr, *wt = nullptr;
+  size_t off_packed = 0, off_packed_t = 0, off_wt = 0;
+  bool want_wt = false;
+};
+
+struct StageDev {
+  int kind, level;
+  std::vector<FcDev> a, b, c;
+  // gnn: images of Wx = rows c..c+2 of a[0]
+  float *wx = nullptr, *wx_packed_t = nullptr;
+  size_t off_wx = 0, off_wx_packed_t = 0;
+};
+
+struct Trainer {
+  pgnn_train_model m;
+  std::vector<StageDev> stages;
+  FcDev cls[2];
+  std::vector<FcDev> loc;  // 3 per class
+  float *params = nullptr, *grads = nullptr;
+  char *images = nullptr;
+  size_t images_bytes = 0, off_jobs = 0;
+  int n_jobs = 0, total_blocks = 0;
+};
+
+size_t packed_floats(int k_in, int n_out) {
+  return pgnn_packed_fc_floats(k_in, n_out);
+}
+
+// lay out every image; returns the bytes needed (jobs table included)
+size_t layout_images(Trainer &t) {
+  size_t off = 0;
+  auto take = [&](size_t floats) {
+    const size_t at = off;
+    off += align_up(floats * 4, 256);
+    return at;
+  };
+  int jobs = 0;
+  auto lay = [&](FcDev &f) {
+    f.off_packed = take(packed_floats(f.ref.k_in, f.ref.n_out));
+    f.off_packed_t = take(packed_floats(f.ref.n_out, f.ref.k_in));
+    jobs += 2;
+    if (f.want_wt) {
+      f.off_wt = take((size_t)f.ref.n_out * pad16(f.ref.k_in));
+      ++jobs;
+    }
+  };
+  for (StageDev &s : t.stages) {
+    for (FcDev &f : s.a) lay(f);
+    for (FcDev &f : s.b) lay(f);
+    for (FcDev &f : s.c) lay(f);
+    if (s.kind == 1) {
+      const int n_out = s.a[0].ref.n_out;
+      s.off_wx = take((size_t)3 * pad16(n_out));
+      s.off_wx_packed_t = take(packed_floats(n_out, 3));
+      jobs += 2;
+    }
+  }
+  for (FcDev &f : t.cls) lay(f);
+  for (FcDev &f : t.loc) lay(f);
+  t.off_jobs = off;
+  t.n_jobs = jobs;
+  off += align_up((size_t)jobs * sizeof(PackJobRec), 256);
+  return off + 256;
+}
+
+// ---- workspace ------------------------------------------------------------------------
+// Bump allocator that also runs "dry" (null base) to size the workspace: the
+// forward and the backward replay the same allocation sequence.
+struct Bump {
+  char *base;
+  size_t off, cap, high;
+  Bump(void *p, size_t n) : base((char *)p), off(0), cap(n), high(0) {}
+  void *raw(size_t bytes) {
+    const size_t at = align_up(off, 256);
+    off = at + bytes;
+    if (off > high) high = off;
+    if (!base) return (void *)(uintptr_t)(at + 256);  // dry run: never used
+    if (off > cap) return nullptr;
+    return base + at;
+  }
+  float *f(int64_t rows, int64_t ld) { return (float *)raw((size_t)rows * ld * 4); }
+  int32_t *i32(int64_t n) { return (int32_t *)raw((size_t)n * 4); }
+};
+
+struct PoolSaved {
+  float *feat;                 // [E, 16]
+  float *act[PGNN_TRAIN_MAX_FC];   // outputs of the point MLP layers
+  int32_t *dst;
+  float *agg;                  // [K, pad(n_out of last a)]
+  float *oact[PGNN_TRAIN_MAX_FC];  // outputs of the output MLP layers
+};
+struct GnnSaved {
+  const float *h_in;           // [K, ld_h]
+  float *off_act[PGNN_TRAIN_MAX_FC];  // outputs of the offset MLP layers
+  float *xo, *q, *hx, *p;
+  float *eact[PGNN_TRAIN_MAX_FC];  // eact[0] = H1, eact[i] = output of a[i]
+  int32_t *dst;
+  float *agg;
+  float *uact[PGNN_TRAIN_MAX_FC];  // outputs of the update MLP layers
+};
+struct HeadsSaved {
+  float *c1, *logits;          // [K, 64], [K, pad(nc)]
+  float *l1[PGNN_TRAIN_MAX_CLASSES], *l2[PGNN_TRAIN_MAX_CLASSES],
+      *l3[PGNN_TRAIN_MAX_CLASSES];
+  float *pred;                 // [K, nc, L]
+};
+struct Saved {  // lives at the start of the workspace (host-visible copy kept
+                // in the handle would break re-entrancy: it is recomputed by
+                // replaying the allocation sequence in backward)
+  PoolSaved pool[PGNN_TRAIN_MAX_STAGES];
+  GnnSaved gnn[PGNN_TRAIN_MAX_STAGES];
+  HeadsSaved heads;
+  const float *h_final;
+  int ld_h_final;
+  int64_t k_final;
+  float *scratch;              // weight-grad / segmax workspace
+  size_t scratch_bytes;
+};
+
+struct Ctx {
+  Trainer &t;
+  const pgnn_train_batch &b;
+  Bump &ws;
+  hipStream_t stream;
+  bool dry;  // sizing run: allocate only
+};
+
+int check_batch(const Trainer &t, const pgnn_train_batch *b) {
+  PGNN_REQUIRE(b && b->n_levels >= 1 && b->n_levels <= PGNN_TRAIN_MAX_LEVELS &&
+                   b->n_feat >= 0 && b->n_feat <= 13,
+               PGNN_E_INVALID, "trainer: bad batch header");
+  for (int l = 0; l <= b->n_levels; ++l)
+    PGNN_REQUIRE(b->n_vertices[l] >= 0, PGNN_E_INVALID, "trainer: n_vertices < 0");
+  for (int l = 0; l < b->n_levels; ++l)
+    PGNN_REQUIRE(b->n_edges[l] >= 0, PGNN_E_INVALID, "trainer: n_edges < 0");
+  for (const StageDev &s : t.stages)
+    PGNN_REQUIRE(s.level >= 0 && s.level < b->n_levels, PGNN_E_INVALID,
+                 "trainer: stage graph_level outside the batch");
+  return 0;
+}
+
+// one FC layer forward on `rows` rows: y = act(x[:, :k_in] W + b) (+ residual)
+int fc_fwd(Ctx &c, const FcDev &f, const float *x, int64_t ldx, int64_t rows,
+           bool relu, const float *residual, int64_t ld_res, float *y) {
+  if (c.dry || rows == 0) return 0;
+  pgnn_fc_layer L;
+  L.packed = f.packed;
+  L.k_in = f.ref.k_in;
+  L.n_out = f.ref.n_out;
+  L.relu_from = relu ? 0 : f.ref.n_out;
+  return pgnn_mlp_fwd(x, ldx, f.ref.k_in, nullptr, 0, 0, rows, &L, 1, residual,
+                      ld_res, y, pad16(f.ref.n_out), c.stream);
+}
+
+// dX = dY W^T through the forward engine on the transposed image
+int fc_dx(Ctx &c, const FcDev &f, const float *dy, int64_t lddy, int64_t rows,
+          float *dx) {
+  if (c.dry || rows == 0) return 0;
+  pgnn_fc_layer L;
+  L.packed = f.packed_t;
+  L.k_in = f.ref.n_out;
+  L.n_out = f.ref.k_in;
+  L.relu_from = f.ref.k_in;  // linear
+  return pgnn_mlp_fwd(dy, lddy, f.ref.n_out, nullptr, 0, 0, rows, &L, 1, nullptr,
+                      0, dx, pad16(f.ref.k_in), c.stream);
+}
+
+int fc_wgrad(Ctx &c, Saved &sv, const FcDev &f, const float *x, int64_t ldx,
+             const float *dy, int64_t lddy, int64_t rows) {
+  if (c.dry || rows == 0) return 0;
+  return pgnn_weight_grad_f32(x, ldx, f.ref.k_in, dy, lddy, f.ref.n_out, rows,
+                              c.t.grads + f.ref.w_off, c.t.grads + f.ref.b_off, 1,
+                              sv.scratch, sv.scratch_bytes, c.stream);
+}
+
+// fc_bwd of the Python mirror: optional ReluGrad (in place on dy), dW/db, dX
+int fc_bwd(Ctx &c, Saved &sv, const FcDev &f, const float *x, int64_t ldx,
+           const float *y, float *dy, int64_t rows, bool relu, float *dx) {
+  if (c.dry || rows == 0) return 0;
+  const int ldy = pad16(f.ref.n_out);
+  int rc = 0;
+  if (relu) {
+    rc = pgnn_relu_mask_mul(dy, y, rows * ldy, c.stream);
+    if (rc) return rc;
+  }
+  rc = fc_wgrad(c, sv, f, x, ldx, dy, ldy, rows);
+  if (rc) return rc;
+  if (dx) rc = fc_dx(c, f, dy, ldy, rows, dx);
+  return rc;
+}
+
+size_t scratch_need(const Trainer &t, const pgnn_train_batch &b) {
+  size_t need = 256;
+  auto wg = [&](const FcDev &f, int64_t rows) {
+    const size_t n = pgnn_weight_grad_workspace_bytes(f.ref.k_in, f.ref.n_out, rows);
+    if (n > need) need = n;
+  };
+  for (const StageDev &s : t.stages) {
+    const int64_t E = b.n_edges[s.level], K = b.n_vertices[s.level + 1];
+    for (const FcDev &f : s.a) wg(f, s.kind == 0 ? E : (&f == &s.a[0] ? K : E));
+    for (const FcDev &f : s.b) wg(f, K);
+    for (const FcDev &f : s.c) wg(f, K);
+    const FcDev &last = s.a.back();
+    if (last.want_wt) {
+      const size_t n = pgnn_segmax_fc_bwd_workspace_bytes(E, last.ref.n_out,
+                                                          (int32_t)K, last.ref.k_in);
+      if (n > need) need = n;
+    }
+    if (s.kind == 1) {  // the Wx rows: k_in = 3
+      const size_t n = pgnn_weight_grad_workspace_bytes(3, s.a[0].ref.n_out, K);
+      if (n > need) need = n;
+    }
+  }
+  const int64_t K = b.n_vertices[b.n_levels];
+  for (const FcDev &f : t.cls) wg(f, K);
+  for (const FcDev &f : t.loc) wg(f, K);
+  return need;
+}
+
+// ---- forward ---------------------------------------------------------------------------
+// Allocation sequence of the forward (shared by the sizing run, the forward
+// and the backward, which re-derives the same pointers).
+int forward_impl(Ctx &c, Saved &sv) {
+  Trainer &t = c.t;
+  const pgnn_train_batch &b = c.b;
+  int rc = 0;
+  sv.scratch_bytes = scratch_need(t, b);
+  sv.scratch = (float *)c.ws.raw(sv.scratch_bytes);
+  const float *h = nullptr;
+  int ld_h = 0;
+  int64_t k_h = 0;
+  for (size_t si = 0; si < t.stages.size(); ++si) {
+    StageDev &s = t.stages[si];
+    const int lvl = s.level;
+    const int64_t E = b.n_edges[lvl], K = b.n_vertices[lvl + 1];
+    if (s.kind == 0) {
+      PoolSaved &p = sv.pool[si];
+      p.feat = c.ws.f(E, 16);
+      for (size_t i = 0; i < s.a.size(); ++i) p.act[i] = c.ws.f(E, pad16(s.a[i].ref.n_out));
+      p.dst = c.ws.i32(E > 0 ? E : 1);
+      const int wa = pad16(s.a.back().ref.n_out);
+      p.agg = c.ws.f(K, wa);
+      for (size_t i = 0; i < s.b.size(); ++i) p.oact[i] = c.ws.f(K, pad16(s.b[i].ref.n_out));
+      if (!c.dry) {
+        PGNN_REQUIRE(s.a[0].ref.k_in == b.n_feat + 3, PGNN_E_INVALID,
+                     "trainer: point MLP input width != n_feat + 3");
+        rc = pgnn_pool_features_fwd(b.input_v, b.n_feat, b.coords[lvl],
+                                    b.keypoints[lvl], b.edges[lvl], E, p.feat,
+                                    c.stream);
+        if (rc) return rc;
+        const float *x = p.feat;
+        int64_t ldx = 16;
+        for (size_t i = 0; i < s.a.size(); ++i) {
+          rc = fc_fwd(c, s.a[i], x, ldx, E, true, nullptr, 0, p.act[i]);
+          if (rc) return rc;
+          x = p.act[i];
+          ldx = pad16(s.a[i].ref.n_out);
+        }
+        if (E > 0)
+          hipLaunchKernelGGL(edge_dst_kernel, dim3(blocks_for(E)), dim3(256), 0,
+                             c.stream, b.edges[lvl], E, p.dst);
+        rc = pgnn_scatter_max_f32(x, ldx, p.dst, E, (int32_t)ldx, (int32_t)K,
+                                  p.agg, wa, b.edges_sorted[lvl] ? 1 : 0,
+                                  c.stream);
+        if (rc) return rc;
+        x = p.agg;
+        ldx = wa;
+        for (size_t i = 0; i < s.b.size(); ++i) {
+          rc = fc_fwd(c, s.b[i], x, ldx, K, true, nullptr, 0, p.oact[i]);
+          if (rc) return rc;
+          x = p.oact[i];
+          ldx = pad16(s.b[i].ref.n_out);
+        }
+      }
+      h = p.oact[s.b.size() - 1];
+      ld_h = pad16(s.b.back().ref.n_out);
+      k_h = K;
+    } else {
+      GnnSaved &g = sv.gnn[si];
+      PGNN_REQUIRE(h != nullptr || c.dry, PGNN_E_INVALID,
+                   "trainer: a GNN stage needs vertex features from a pooling stage");
+      PGNN_REQUIRE(c.dry || k_h == K, PGNN_E_INVALID,
+                   "trainer: GNN stage vertex count != feature rows");
+      const FcDev &w1 = s.a[0];
+      const int cc = w1.ref.k_in - 3;
+      const int wq = pad16(w1.ref.n_out);
+      g.h_in = h;
+      for (size_t i = 0; i < s.c.size(); ++i) g.off_act[i] = c.ws.f(K, pad16(s.c[i].ref.n_out));
+      g.xo = c.ws.f(K, 3);
+      g.q = c.ws.f(K, wq);
+      g.hx = c.ws.f(K, pad16(cc + 3));
+      g.p = c.ws.f(K, wq);
+      g.eact[0] = c.ws.f(E, wq);
+      for (size_t i = 1; i < s.a.size(); ++i) g.eact[i] = c.ws.f(E, pad16(s.a[i].ref.n_out));
+      g.dst = c.ws.i32(E > 0 ? E : 1);
+      const int wa = pad16(s.a.back().ref.n_out);
+      g.agg = c.ws.f(K, wa);
+      for (size_t i = 0; i < s.b.size(); ++i) g.uact[i] = c.ws.f(K, pad16(s.b[i].ref.n_out));
+      if (!c.dry) {
+        PGNN_REQUIRE(ld_h >= cc, PGNN_E_INVALID,
+                     "trainer: vertex features narrower than the edge MLP input");
+        PGNN_REQUIRE(s.b.back().ref.n_out == cc && ld_h >= pad16(cc), PGNN_E_INVALID,
+                     "trainer: update MLP must preserve the feature width");
+        const float *delta = nullptr;
+        int64_t ld_delta = 0;
+        const float *x = h;
+        int64_t ldx = ld_h;
+        for (size_t i = 0; i < s.c.size(); ++i) {
+          rc = fc_fwd(c, s.c[i], x, ldx, K, i + 1 < s.c.size(), nullptr, 0,
+                      g.off_act[i]);
+          if (rc) return rc;
+          x = g.off_act[i];
+          ldx = pad16(s.c[i].ref.n_out);
+        }
+        if (!s.c.empty()) {
+          PGNN_REQUIRE(s.c.back().ref.n_out == 3, PGNN_E_INVALID,
+                       "trainer: the offset MLP must end in 3 outputs");
+          delta = x;
+          ld_delta = ldx;
+        }
+        rc = pgnn_offset_apply(b.coords[lvl], delta, ld_delta, K, s.wx, g.xo, g.q,
+                               wq, c.stream);
+        if (rc) return rc;
+        if (K > 0)
+          hipLaunchKernelGGL(concat_hx_kernel, dim3(blocks_for(K * pad16(cc + 3))),
+                             dim3(256), 0, c.stream, h, (int64_t)ld_h, cc,
+                             b.coords[lvl], K, g.hx, pad16(cc + 3));
+        rc = fc_fwd(c, w1, g.hx, pad16(cc + 3), K, false, nullptr, 0, g.p);
+        if (rc) return rc;
+        rc = pgnn_edge_hidden_fwd(g.p, g.q, wq, b.edges[lvl], E, g.eact[0],
+                                  c.stream);
+        if (rc) return rc;
+        for (size_t i = 1; i < s.a.size(); ++i) {
+          rc = fc_fwd(c, s.a[i], g.eact[i - 1], pad16(s.a[i - 1].ref.n_out), E,
+                      true, nullptr, 0, g.eact[i]);
+          if (rc) return rc;
+        }
+        if (E > 0)
+          hipLaunchKernelGGL(edge_dst_kernel, dim3(blocks_for(E)), dim3(256), 0,
+                             c.stream, b.edges[lvl], E, g.dst);
+        rc = pgnn_scatter_max_f32(g.eact[s.a.size() - 1], wa, g.dst, E, wa,
+                                  (int32_t)K, g.agg, wa,
+                                  b.edges_sorted[lvl] ? 1 : 0, c.stream);
+        if (rc) return rc;
+        x = g.agg;
+        ldx = wa;
+        for (size_t i = 0; i < s.b.size(); ++i) {
+          const bool last = i + 1 == s.b.size();
+          rc = fc_fwd(c, s.b[i], x, ldx, K, !last, last ? h : nullptr,
+                      last ? ld_h : 0, g.uact[i]);
+          if (rc) return rc;
+          x = g.uact[i];
+          ldx = pad16(s.b[i].ref.n_out);
+        }
+      }
+      h = g.uact[s.b.size() - 1];
+      ld_h = pad16(s.b.back().ref.n_out);
+      k_h = K;
+    }
+  }
+  // prediction heads (gnn.py:133-163)
+  const int64_t K = b.n_vertices[b.n_levels];
+  const int nc = t.m.num_classes, L = t.m.box_len;
+  HeadsSaved &hs = sv.heads;
+  hs.c1 = c.ws.f(K, pad16(t.cls[0].ref.n_out));
+  hs.logits = c.ws.f(K, pad16(nc));
+  for (int j = 0; j < nc; ++j) {
+    hs.l1[j] = c.ws.f(K, pad16(t.loc[3 * j].ref.n_out));
+    hs.l2[j] = c.ws.f(K, pad16(t.loc[3 * j + 1].ref.n_out));
+    hs.l3[j] = c.ws.f(K, pad16(L));
+  }
+  hs.pred = c.ws.f(K, (int64_t)nc * L);
+  sv.h_final = h;
+  sv.ld_h_final = ld_h;
+  sv.k_final = K;
+  if (!c.dry) {
+    PGNN_REQUIRE(h != nullptr && k_h == K, PGNN_E_INVALID,
+                 "trainer: heads need the last level's vertex features");
+    rc = fc_fwd(c, t.cls[0], h, ld_h, K, true, nullptr, 0, hs.c1);
+    if (rc) return rc;
+    rc = fc_fwd(c, t.cls[1], hs.c1, pad16(t.cls[0].ref.n_out), K, false, nullptr,
+                0, hs.logits);
+    if (rc) return rc;
+    for (int j = 0; j < nc; ++j) {
+      rc = fc_fwd(c, t.loc[3 * j], h, ld_h, K, true, nullptr, 0, hs.l1[j]);
+      if (rc) return rc;
+      rc = fc_fwd(c, t.loc[3 * j + 1], hs.l1[j], pad16(t.loc[3 * j].ref.n_out), K,
+                  true, nullptr, 0, hs.l2[j]);
+      if (rc) return rc;
+      rc = fc_fwd(c, t.loc[3 * j + 2], hs.l2[j],
+                  pad16(t.loc[3 * j + 1].ref.n_out), K, false, nullptr, 0,
+                  hs.l3[j]);
+      if (rc) return rc;
+      if (K > 0)
+        hipLaunchKernelGGL(pred_slice_kernel, dim3(blocks_for(K * L)), dim3(256), 0,
+                           c.stream, hs.l3[j], (int64_t)pad16(L), K, L, nc, j,
+                           hs.pred);
+    }
+    PGNN_HIP(hipGetLastError());
+  }
+  return 0;
+}
+
+// ---- backward --------------------------------------------------------------------------
+int backward_impl(Ctx &c, Saved &sv, const float *dlogits, const float *dpred) {
+  Trainer &t = c.t;
+  const pgnn_train_batch &b = c.b;
+  const int64_t K = sv.k_final;
+  const int nc = t.m.num_classes, L = t.m.box_len;
+  const int hw = sv.ld_h_final;
+  const HeadsSaved &hs = sv.heads;
+  int rc = 0;
+  // gradient w.r.t. the current stage output; two buffers alternate
+  float *dh = c.ws.f(K, hw), *dh2 = c.ws.f(K, hw);
+  const int w64 = pad16(t.cls[0].ref.n_out);
+  int wh = w64;  // widest hidden layer of the heads
+  for (const FcDev &f : t.loc)
+    if (pad16(f.ref.n_out) > wh) wh = pad16(f.ref.n_out);
+  float *dy = c.ws.f(K, pad16(nc > L ? nc : L));
+  float *d1 = c.ws.f(K, wh), *d2 = c.ws.f(K, wh);
+  float *dxh = c.ws.f(K, hw);
+  const int cw = t.cls[0].ref.k_in;
+  if (!c.dry && K > 0) {
+    PGNN_HIP(hipMemsetAsync(dh, 0, (size_t)K * hw * 4, c.stream));
+    // class head
+    PGNN_HIP(hipMemsetAsync(dy, 0, (size_t)K * pad16(nc) * 4, c.stream));
+    hipLaunchKernelGGL(block_copy_kernel<false>, dim3(blocks_for(K * nc)),
+                       dim3(256), 0, c.stream, dy, (int64_t)pad16(nc), 0, dlogits,
+                       (int64_t)nc, 0, K, nc);
+    rc = fc_bwd(c, sv, t.cls[1], hs.c1, w64, hs.logits, dy, K, false, d1);
+    if (rc) return rc;
+    rc = fc_bwd(c, sv, t.cls[0], sv.h_final, hw, hs.c1, d1, K, true, dxh);
+    if (rc) return rc;
+    hipLaunchKernelGGL(block_copy_kernel<true>, dim3(blocks_for(K * cw)),
+                       dim3(256), 0, c.stream, dh, (int64_t)hw, 0, dxh,
+                       (int64_t)pad16(cw), 0, K, cw);
+    for (int j = 0; j < nc; ++j) {
+      hipLaunchKernelGGL(dpred_slice_kernel, dim3(blocks_for(K * pad16(L))),
+                         dim3(256), 0, c.stream, dpred, K, L, nc, j, dy,
+                         pad16(L));
+      rc = fc_bwd(c, sv, t.loc[3 * j + 2], hs.l2[j],
+                  pad16(t.loc[3 * j + 1].ref.n_out), hs.l3[j], dy, K, false, d2);
+      if (rc) return rc;
+      rc = fc_bwd(c, sv, t.loc[3 * j + 1], hs.l1[j],
+                  pad16(t.loc[3 * j].ref.n_out), hs.l2[j], d2, K, true, d1);
+      if (rc) return rc;
+      rc = fc_bwd(c, sv, t.loc[3 * j], sv.h_final, hw, hs.l1[j], d1, K, true, dxh);
+      if (rc) return rc;
+      hipLaunchKernelGGL(block_copy_kernel<true>, dim3(blocks_for(K * cw)),
+                         dim3(256), 0, c.stream, dh, (int64_t)hw, 0, dxh,
+                         (int64_t)pad16(cw), 0, K, cw);
+    }
+  }
+  // stages in reverse
+  for (int si = (int)t.stages.size() - 1; si >= 0; --si) {
+    StageDev &s = t.stages[si];
+    const int lvl = s.level;
+    const int64_t E = b.n_edges[lvl], Ks = b.n_vertices[lvl + 1];
+    const size_t mark = c.ws.off;  // stage temporaries are released at the end
+    if (s.kind == 1) {
+      GnnSaved &g = sv.gnn[si];
+      const FcDev &w1 = s.a[0];
+      const int cc = w1.ref.k_in - 3;
+      const int wq = pad16(w1.ref.n_out);
+      const int wa = pad16(s.a.back().ref.n_out);
+      const int ld_h = hw;
+      // temporaries
+      float *du[PGNN_TRAIN_MAX_FC + 1];
+      for (size_t i = 0; i < s.b.size(); ++i)
+        du[i] = c.ws.f(Ks, pad16(s.b[i].ref.k_in));
+      float *ge[PGNN_TRAIN_MAX_FC];
+      for (size_t i = 0; i + 1 < s.a.size(); ++i)
+        ge[i] = c.ws.f(E, pad16(s.a[i + 1].ref.k_in));  // grad w.r.t. eact[i]
+      float *gz = nullptr;  // dense fallback: grad w.r.t. the last edge layer
+      if (!s.a.back().want_wt) gz = c.ws.f(E, wa);
+      int32_t *ties = nullptr;
+      if (!s.a.back().want_wt) ties = c.ws.i32(Ks * wa > 0 ? Ks * wa : 1);
+      float *dp = c.ws.f(Ks, wq), *dq = c.ws.f(Ks, wq);
+      float *dhx = c.ws.f(Ks, pad16(cc + 3));
+      float *dxo = c.ws.f(Ks, 16);
+      float *doff[PGNN_TRAIN_MAX_FC];
+      for (size_t i = 0; i < s.c.size(); ++i)
+        doff[i] = c.ws.f(Ks, pad16(s.c[i].ref.k_in));
+      if (!c.dry && Ks > 0) {
+        // residual branch (gnn.py:372): dh_in starts as a copy of dh
+        PGNN_HIP(hipMemcpyAsync(dh2, dh, (size_t)Ks * ld_h * 4,
+                                hipMemcpyDeviceToDevice, c.stream));
+        // update MLP, last layer linear
+        float *d = dh;
+        for (int i = (int)s.b.size() - 1; i >= 0; --i) {
+          const bool last = i + 1 == (int)s.b.size();
+          const float *xin = i == 0 ? g.agg : g.uact[i - 1];
+          const int64_t ldx = i == 0 ? wa : pad16(s.b[i - 1].ref.n_out);
+          rc = fc_bwd(c, sv, s.b[i], xin, ldx, g.uact[i], d, Ks, !last, du[i]);
+          if (rc) return rc;
+          d = du[i];
+        }
+        const float *dagg = d;  // [Ks, pad(k_in of b[0])] = [Ks, wa]
+        const int na = (int)s.a.size();
+        float *gcur = nullptr;  // grad w.r.t. eact[i], ReLU-masked
+        int from;
+        if (s.a.back().want_wt) {
+          rc = pgnn_segmax_fc_bwd_f32(
+              g.eact[na - 1], wa, g.dst, E, s.a.back().ref.n_out, (int32_t)Ks,
+              g.agg, wa, dagg, wa, g.eact[na - 2], pad16(s.a.back().ref.k_in),
+              s.a.back().ref.k_in, s.a.back().wt, pad16(s.a.back().ref.k_in),
+              ge[na - 2], pad16(s.a.back().ref.k_in), pad16(s.a.back().ref.k_in),
+              1, t.grads + s.a.back().ref.w_off, t.grads + s.a.back().ref.b_off,
+              sv.scratch, sv.scratch_bytes, c.stream);
+          if (rc) return rc;
+          gcur = ge[na - 2];
+          from = na - 2;
+        } else {
+          rc = pgnn_scatter_max_bwd_f32(g.eact[na - 1], wa, g.dst, E, wa,
+                                        (int32_t)Ks, g.agg, wa, dagg, wa, ties,
+                                        gz, wa, 1, c.stream);
+          if (rc) return rc;
+          gcur = gz;
+          from = na - 1;
+        }
+        for (int i = from; i >= 1; --i) {  // dense middle edge layers
+          rc = fc_bwd(c, sv, s.a[i], g.eact[i - 1], pad16(s.a[i].ref.k_in),
+                      g.eact[i], gcur, E, false, ge[i - 1]);
+          if (rc) return rc;
+          rc = pgnn_relu_mask_mul(ge[i - 1], g.eact[i - 1],
+                                  E * pad16(s.a[i].ref.k_in), c.stream);
+          if (rc) return rc;
+          gcur = ge[i - 1];
+        }
+        rc = pgnn_edge_hidden_bwd(gcur, wq, b.edges[lvl], E, Ks, dp, dq, c.stream);
+        if (rc) return rc;
+        // P = [h, x] W1 + b1
+        rc = fc_bwd(c, sv, w1, g.hx, pad16(cc + 3), nullptr, dp, Ks, false, dhx);
+        if (rc) return rc;
+        hipLaunchKernelGGL(block_copy_kernel<true>, dim3(blocks_for(Ks * cc)),
+                           dim3(256), 0, c.stream, dh2, (int64_t)ld_h, 0, dhx,
+                           (int64_t)pad16(cc + 3), 0, Ks, cc);
+        // Q = x' Wx, Wx = rows cc..cc+2 of W1 (the minus sign is in dq)
+        rc = pgnn_weight_grad_f32(g.xo, 3, 3, dq, wq, w1.ref.n_out, Ks,
+                                  t.grads + w1.ref.w_off + (int64_t)cc * w1.ref.n_out,
+                                  nullptr, 1, sv.scratch, sv.scratch_bytes,
+                                  c.stream);
+        if (rc) return rc;
+        if (!s.c.empty()) {
+          pgnn_fc_layer Lx;  // dx' = dQ Wx^T
+          Lx.packed = s.wx_packed_t;
+          Lx.k_in = w1.ref.n_out;
+          Lx.n_out = 3;
+          Lx.relu_from = 3;
+          rc = pgnn_mlp_fwd(dq, wq, w1.ref.n_out, nullptr, 0, 0, Ks, &Lx, 1,
+                            nullptr, 0, dxo, 16, c.stream);
+          if (rc) return rc;
+          float *d = dxo;
+          for (int i = (int)s.c.size() - 1; i >= 0; --i) {
+            const float *xin = i == 0 ? g.h_in : g.off_act[i - 1];
+            const int64_t ldx = i == 0 ? ld_h : pad16(s.c[i - 1].ref.n_out);
+            rc = fc_bwd(c, sv, s.c[i], xin, ldx, g.off_act[i], d, Ks,
+                        i + 1 < (int)s.c.size(), doff[i]);
+            if (rc) return rc;
+            d = doff[i];
+          }
+          hipLaunchKernelGGL(block_copy_kernel<true>, dim3(blocks_for(Ks * cc)),
+                             dim3(256), 0, c.stream, dh2, (int64_t)ld_h, 0, d,
+                             (int64_t)pad16(s.c[0].ref.k_in), 0, Ks, cc);
+        }
+      }
+      float *tmp = dh;
+      dh = dh2;
+      dh2 = tmp;
+    } else {
+      PoolSaved &p = sv.pool[si];
+      const int wa = pad16(s.a.back().ref.n_out);
+      float *dob[PGNN_TRAIN_MAX_FC];
+      for (size_t i = 0; i < s.b.size(); ++i)
+        dob[i] = c.ws.f(Ks, pad16(s.b[i].ref.k_in));
+      float *ga[PGNN_TRAIN_MAX_FC];  // grad w.r.t. act[i] (input of layer i+1)
+      for (size_t i = 0; i + 1 < s.a.size(); ++i)
+        ga[i] = c.ws.f(E, pad16(s.a[i + 1].ref.k_in));
+      float *gz = nullptr;
+      int32_t *ties = nullptr;
+      if (!s.a.back().want_wt) {
+        gz = c.ws.f(E, wa);
+        ties = c.ws.i32(Ks * wa > 0 ? Ks * wa : 1);
+      }
+      if (!c.dry && Ks > 0) {
+        float *d = dh;
+        for (int i = (int)s.b.size() - 1; i >= 0; --i) {
+          const float *xin = i == 0 ? p.agg : p.oact[i - 1];
+          const int64_t ldx = i == 0 ? wa : pad16(s.b[i - 1].ref.n_out);
+          rc = fc_bwd(c, sv, s.b[i], xin, ldx, p.oact[i], d, Ks, true, dob[i]);
+          if (rc) return rc;
+          d = dob[i];
+        }
+        const int na = (int)s.a.size();
+        float *gcur;
+        int from;
+        if (s.a.back().want_wt) {
+          rc = pgnn_segmax_fc_bwd_f32(
+              p.act[na - 1], wa, p.dst, E, s.a.back().ref.n_out, (int32_t)Ks,
+              p.agg, wa, d, wa, p.act[na - 2], pad16(s.a.back().ref.k_in),
+              s.a.back().ref.k_in, s.a.back().wt, pad16(s.a.back().ref.k_in),
+              ga[na - 2], pad16(s.a.back().ref.k_in), pad16(s.a.back().ref.k_in),
+              1, t.grads + s.a.back().ref.w_off, t.grads + s.a.back().ref.b_off,
+              sv.scratch, sv.scratch_bytes, c.stream);
+          if (rc) return rc;
+          gcur = ga[na - 2];
+          from = na - 2;
+        } else {
+          rc = pgnn_scatter_max_bwd_f32(p.act[na - 1], wa, p.dst, E, wa,
+                                        (int32_t)Ks, p.agg, wa, d, wa, ties, gz,
+                                        wa, 1, c.stream);
+          if (rc) return rc;
+          gcur = gz;
+          from = na - 1;
+        }
+        for (int i = from; i >= 0; --i) {
+          const float *xin = i == 0 ? p.feat : p.act[i - 1];
+          const int64_t ldx = i == 0 ? 16 : pad16(s.a[i - 1].ref.n_out);
+          rc = fc_bwd(c, sv, s.a[i], xin, ldx, p.act[i], gcur, E, false,
+                      i > 0 ? ga[i - 1] : nullptr);
+          if (rc) return rc;
+          if (i > 0) {
+            rc = pgnn_relu_mask_mul(ga[i - 1], p.act[i - 1],
+                                    E * pad16(s.a[i].ref.k_in), c.stream);
+            if (rc) return rc;
+            gcur = ga[i - 1];
+          }
+        }
+      }
+    }
+    c.ws.off = mark;
+  }
+  if (!c.dry) PGNN_HIP(hipGetLastError());
+  return 0;
+}
+
+int make_fc(const pgnn_train_fc &r, int64_t n_params, FcDev &f) {
+  PGNN_REQUIRE(r.k_in > 0 && r.n_out > 0 && r.k_in <= 4096 && r.n_out <= 4096 &&
+                   r.w_off >= 0 && r.b_off >= 0 &&
+                   r.w_off + (int64_t)r.k_in * r.n_out <= n_params &&
+                   r.b_off + r.n_out <= n_params,
+               PGNN_E_INVALID, "trainer: layer outside the flat parameter buffer");
+  f.ref = r;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int pgnn_trainer_create(const pgnn_train_model *m, void **handle) {
+  PGNN_GUARD_BEGIN
+  PGNN_REQUIRE(m && handle, PGNN_E_INVALID, "trainer_create: null argument");
+  PGNN_REQUIRE(m->n_stages >= 1 && m->n_stages <= PGNN_TRAIN_MAX_STAGES &&
+                   m->num_classes >= 1 &&
+                   m->num_classes <= PGNN_TRAIN_MAX_CLASSES && m->box_len >= 1 &&
+                   m->box_len <= 16 && m->n_params > 0,
+               PGNN_E_INVALID, "trainer_create: bad model header");
+  Trainer *t = new Trainer();
+  t->m = *m;
+  int rc = 0;
+  for (int si = 0; si < m->n_stages && !rc; ++si) {
+    const pgnn_train_stage &s = m->stages[si];
+    StageDev d;
+    d.kind = s.kind;
+    d.level = s.graph_level;
+    if (!((s.kind == 0 || s.kind == 1) && s.n_a >= 1 && s.n_a <= PGNN_TRAIN_MAX_FC &&
+          s.n_b >= 1 && s.n_b <= PGNN_TRAIN_MAX_FC && s.n_c >= 0 &&
+          s.n_c <= PGNN_TRAIN_MAX_FC && (s.kind == 1 || s.n_c == 0) &&
+          (s.kind == 0 || s.n_a >= 2))) {
+      rc = fail(PGNN_E_INVALID, "trainer_create: bad stage description");
+      break;
+    }
+    d.a.resize(s.n_a);
+    d.b.resize(s.n_b);
+    d.c.resize(s.n_c);
+    for (int i = 0; i < s.n_a && !rc; ++i) rc = make_fc(s.a[i], m->n_params, d.a[i]);
+    for (int i = 0; i < s.n_b && !rc; ++i) rc = make_fc(s.b[i], m->n_params, d.b[i]);
+    for (int i = 0; i < s.n_c && !rc; ++i) rc = make_fc(s.c[i], m->n_params, d.c[i]);
+    // the last per-edge layer feeds the scatter-max: sparse adjoint when it
+    // has a materialised input activation (n_a >= 2) and fits the kernel
+    if (!rc && s.n_a >= 2 && d.a.back().ref.n_out <= 512 &&
+        d.a.back().ref.k_in <= 512)
+      d.a.back().want_wt = true;
+    t->stages.push_back(d);
+  }
+  for (int i = 0; i < 2 && !rc; ++i) rc = make_fc(m->cls[i], m->n_params, t->cls[i]);
+  t->loc.resize(3 * (size_t)m->num_classes);
+  for (int j = 0; j < m->num_classes && !rc; ++j)
+    for (int i = 0; i < 3 && !rc; ++i)
+      rc = make_fc(m->loc[j][i], m->n_params, t->loc[3 * j + i]);
+  if (rc) {
+    delete t;
+    return rc;
+  }
+  t->images_bytes = layout_images(*t);
+  *handle = t;
+  return 0;
+  PGNN_GUARD_END
+}
+
+extern "C" int pgnn_trainer_destroy(void *handle) {
+  PGNN_GUARD_BEGIN
+  delete (Trainer *)handle;
+  return 0;
+  PGNN_GUARD_END
+}
+
+extern "C" size_t pgnn_trainer_images_bytes(void *handle) {
+  return handle ? ((Trainer *)handle)->images_bytes : 0;
+}
+
+extern "C" int pgnn_trainer_bind(void *handle, float *params, float *grads,
+                                 void *images, size_t images_bytes,
+                                 void *stream_) {
+  PGNN_GUARD_BEGIN
+  Trainer *t = (Trainer *)handle;
+  PGNN_REQUIRE(t && params && grads && images, PGNN_E_INVALID,
+               "trainer_bind: null argument");
+  PGNN_REQUIRE(images_bytes >= t->images_bytes, PGNN_E_WORKSPACE,
+               "trainer_bind: images buffer too small");
+  t->params = params;
+  t->grads = grads;
+  t->images = (char *)images;
+  std::vector<PackJobRec> jobs;
+  int first = 0;
+  auto add = [&](const float *w, const float *b, float *dst, int k_in, int n_out,
+                 int kind, size_t elems) {
+    PackJobRec j;
+    j.w = w;
+    j.b = b;
+    j.dst = dst;
+    j.k_in = k_in;
+    j.n_out = n_out;
+    j.kind = kind;
+    j.first_block = first;
+    first += (int)((elems + 255) / 256);
+    jobs.push_back(j);
+  };
+  auto bind_fc = [&](FcDev &f) {
+    f.packed = (float *)(t->images + f.off_packed);
+    f.packed_t = (float *)(t->images + f.off_packed_t);
+    const float *w = params + f.ref.w_off, *bb = params + f.ref.b_off;
+    add(w, bb, f.packed, f.ref.k_in, f.ref.n_out, 0,
+        packed_floats(f.ref.k_in, f.ref.n_out));
+    add(w, nullptr, f.packed_t, f.ref.k_in, f.ref.n_out, 1,
+        packed_floats(f.ref.n_out, f.ref.k_in));
+    if (f.want_wt) {
+      f.wt = (float *)(t->images + f.off_wt);
+      add(w, nullptr, f.wt, f.ref.k_in, f.ref.n_out, 2,
+          (size_t)f.ref.n_out * pad16(f.ref.k_in));
+    }
+  };
+  for (StageDev &s : t->stages) {
+    for (FcDev &f : s.a) bind_fc(f);
+    for (FcDev &f : s.b) bind_fc(f);
+    for (FcDev &f : s.c) bind_fc(f);
+    if (s.kind == 1) {
+      const FcDev &w1 = s.a[0];
+      const int cc = w1.ref.k_in - 3, n_out = w1.ref.n_out;
+      const float *wx = params + w1.ref.w_off + (int64_t)cc * n_out;
+      s.wx = (float *)(t->images + s.off_wx);
+      s.wx_packed_t = (float *)(t->images + s.off_wx_packed_t);
+      add(wx, nullptr, s.wx, 3, n_out, 3, (size_t)3 * pad16(n_out));
+      add(wx, nullptr, s.wx_packed_t, 3, n_out, 1, packed_floats(n_out, 3));
+    }
+  }
+  for (FcDev &f : t->cls) bind_fc(f);
+  for (FcDev &f : t->loc) bind_fc(f);
+  PGNN_REQUIRE((int)jobs.size() == t->n_jobs, PGNN_E_INVALID,
+               "trainer_bind: job count mismatch");
+  t->total_blocks = first;
+  hipStream_t stream = (hipStream_t)stream_;
+  PGNN_HIP(hipMemcpyAsync(t->images + t->off_jobs, jobs.data(),
+                          jobs.size() * sizeof(PackJobRec), hipMemcpyHostToDevice,
+                          stream));
+  PGNN_HIP(hipStreamSynchronize(stream));  // `jobs` is a host temporary
+  return pgnn_pack_fc_many(t->images + t->off_jobs, t->n_jobs, t->total_blocks,
+                           stream_);
+  PGNN_GUARD_END
+}
+
+extern "C" int pgnn_trainer_repack(void *handle, void *stream_) {
+  PGNN_GUARD_BEGIN
+  Trainer *t = (Trainer *)handle;
+  PGNN_REQUIRE(t && t->images, PGNN_E_INVALID, "trainer_repack: not bound");
+  return pgnn_pack_fc_many(t->images + t->off_jobs, t->n_jobs, t->total_blocks,
+                           stream_);
+  PGNN_GUARD_END
+}
+
+extern "C" size_t pgnn_trainer_workspace_bytes(void *handle,
+                                               const pgnn_train_batch *batch) {
+  Trainer *t = (Trainer *)handle;
+  if (!t || !batch || check_batch(*t, batch)) return 0;
+  Bump ws(nullptr, 0);
+  Saved sv;
+  memset(&sv, 0, sizeof sv);
+  Ctx c{*t, *batch, ws, nullptr, true};
+  if (forward_impl(c, sv)) return 0;
+  if (backward_impl(c, sv, nullptr, nullptr)) return 0;
+  return ws.high + 4096;
+}
+
+extern "C" int pgnn_trainer_forward(void *handle, const pgnn_train_batch *batch,
+                                    void *workspace, size_t workspace_bytes,
+                                    const float **logits, int64_t *ld_logits,
+                                    const float **pred_box, void *stream_) {
+  PGNN_GUARD_BEGIN
+  Trainer *t = (Trainer *)handle;
+  PGNN_REQUIRE(t && t->images && workspace && logits && ld_logits && pred_box,
+               PGNN_E_INVALID, "trainer_forward: null argument / not bound");
+  int rc = check_batch(*t, batch);
+  if (rc) return rc;
+  PGNN_REQUIRE(workspace_bytes >= pgnn_trainer_workspace_bytes(handle, batch),
+               PGNN_E_WORKSPACE, "trainer_forward: workspace too small");
+  Bump ws(workspace, workspace_bytes);
+  Saved sv;
+  memset(&sv, 0, sizeof sv);
+  Ctx c{*t, *batch, ws, (hipStream_t)stream_, false};
+  rc = forward_impl(c, sv);
+  if (rc) return rc;
+  *logits = sv.heads.logits;
+  *ld_logits = pad16(t->m.num_classes);
+  *pred_box = sv.heads.pred;
+  return 0;
+  PGNN_GUARD_END
+}
+
+extern "C" int pgnn_trainer_backward(void *handle, const pgnn_train_batch *batch,
+                                     void *workspace, size_t workspace_bytes,
+                                     const float *dlogits, const float *dpred_box,
+                                     void *stream_) {
+  PGNN_GUARD_BEGIN
+  Trainer *t = (Trainer *)handle;
+  PGNN_REQUIRE(t && t->images && workspace && dlogits && dpred_box,
+               PGNN_E_INVALID, "trainer_backward: null argument / not bound");
+  int rc = check_batch(*t, batch);
+  if (rc) return rc;
+  PGNN_REQUIRE(workspace_bytes >= pgnn_trainer_workspace_bytes(handle, batch),
+               PGNN_E_WORKSPACE, "trainer_backward: workspace too small");
+  // re-derive the forward's pointers by replaying its allocation sequence
+  Bump ws(workspace, workspace_bytes);
+  Saved sv;
+  memset(&sv, 0, sizeof sv);
+  Ctx dryc{*t, *batch, ws, nullptr, true};
+  rc = forward_impl(dryc, sv);
+  if (rc) return rc;
+  Ctx c{*t, *batch, ws, (hipStream_t)stream_, false};
+  return backward_impl(c, sv, dlogits, dpred_box);
+  PGNN_GUARD_END
+}

@@ -326,6 +326,14 @@ class Trainer(object):
         self._ws = None
         self._ws2 = None
         self._pack_jobs = None
+        # The step runs natively by default (csrc/trainer.hip: forward and
+        # backward are one C call each, all launches issued from C++);
+        # native = False drives the same primitives from Python (the readable
+        # composition below; tests hold the two to the same gradients).
+        self.native = True
+        self._native = None
+        self._native_ws = None
+        self._py_images_stale = True
         self.repack()
 
     # ---- plumbing -----------------------------------------------------------
@@ -441,12 +449,26 @@ class Trainer(object):
     def repack(self):
         """Refresh every device image derived from the flat buffer (MFMA
         fragment images forward / transposed, plain W^T of the sparse-adjoint
-        layers) -- after init and after every SGD step: ONE launch."""
+        layers) -- after init and after every SGD step: ONE launch.  Only the
+        images of the path in use are refreshed (native step: the handle's;
+        Python-driven step: this object's, lazily)."""
+        if self.native and self.sparse_adjoint:
+            self._py_images_stale = True
+            if self._native is not None:
+                _lib.check(self.lib.pgnn_trainer_repack(self._native,
+                                                        self._st()),
+                           "pgnn_trainer_repack")
+            # (a handle created later packs in pgnn_trainer_bind)
+            return
+        self._repack_py()
+
+    def _repack_py(self):
         if getattr(self, '_pack_jobs', None) is None:
             self._build_pack_jobs()
         _lib.check(self.lib.pgnn_pack_fc_many(
             _lib.ptr(self._pack_jobs), self._pack_n, self._pack_blocks,
             self._st()), "pgnn_pack_fc_many")
+        self._py_images_stale = False
 
     def _layer_array(self, packed, k_in, n_out, relu):
         arr = (_lib.FcLayer * 1)()
@@ -559,10 +581,151 @@ class Trainer(object):
         d._pgnn_sorted = int(gnn._edges_sorted_flag(edges))
         return d
 
+    # ---- native step (csrc/trainer.hip) -----------------------------------------------
+    def _fc_ref(self, dst, name):
+        off_w, (k, n) = self.offsets[name + '/weights']
+        off_b, _ = self.offsets[name + '/biases']
+        dst.w_off, dst.b_off, dst.k_in, dst.n_out = off_w, off_b, int(k), int(n)
+
+    def _native_handle(self):
+        """pgnn_trainer_create + bind for this model (once)."""
+        if self._native is not None:
+            return self._native
+        lib = self.lib
+        m = _lib.TrainModel()
+        lcs = self.config['model_kwargs']['layer_configs']
+        m.n_stages = len(lcs) - 1
+        m.num_classes, m.box_len = self.nc, self.box_len
+        m.n_params = int(self.flat.numel())
+        for si, lc in enumerate(lcs[:-1]):
+            st, kw, scope = m.stages[si], lc['kwargs'], lc['scope']
+            st.graph_level = int(lc['graph_level'])
+            if lc['type'] == 'scatter_max_point_set_pooling':
+                st.kind = 0
+                a = mlp_names(scope + '/extract_vertex_features',
+                              len(kw['point_MLP_depth_list']))
+                b = mlp_names(scope + '/combined_features',
+                              len(kw['output_MLP_depth_list']))
+                c = []
+            elif lc['type'] == 'scatter_max_graph_auto_center_net':
+                st.kind = 1
+                a = mlp_names(scope + '/extract_vertex_features',
+                              len(kw['edge_MLP_depth_list']))
+                b = mlp_names(scope + '/combined_features',
+                              len(kw['update_MLP_depth_list']))
+                c = mlp_names(scope, len(kw['auto_offset_MLP_depth_list'])) \
+                    if kw['auto_offset'] else []
+            else:
+                raise NotImplementedError(lc['type'])
+            st.n_a, st.n_b, st.n_c = len(a), len(b), len(c)
+            for arr, names in ((st.a, a), (st.b, b), (st.c, c)):
+                for i, n in enumerate(names):
+                    self._fc_ref(arr[i], n)
+        pc = lcs[-1]
+        if pc['type'] != 'classaware_predictor':
+            raise NotImplementedError(pc['type'])
+        ps = pc['scope'] + '/predictor'
+        for i, n in enumerate(mlp_names(ps + '/cls', 2)):
+            self._fc_ref(m.cls[i], n)
+        for j in range(self.nc):
+            for i, n in enumerate(mlp_names(ps + '/loc/cls_%d' % j, 3)):
+                self._fc_ref(m.loc[j][i], n)
+        h = ctypes.c_void_p()
+        _lib.check(lib.pgnn_trainer_create(ctypes.byref(m), ctypes.byref(h)),
+                   "pgnn_trainer_create")
+        self._native_images = torch.empty(
+            int(lib.pgnn_trainer_images_bytes(h)), dtype=torch.uint8,
+            device=self.device)
+        _lib.check(lib.pgnn_trainer_bind(
+            h, _lib.ptr(self.flat), _lib.ptr(self.grad),
+            _lib.ptr(self._native_images), self._native_images.numel(),
+            self._st()), "pgnn_trainer_bind")
+        self._native = h
+        return h
+
+    def __del__(self):
+        h, self._native = getattr(self, '_native', None), None
+        if h is not None:
+            try:
+                self.lib.pgnn_trainer_destroy(h)
+            except Exception:
+                pass
+
+    def _native_batch(self, input_v, coords, kps, edges):
+        """pgnn_train_batch for these tensors (kept alive by the caller)."""
+        dev = self.device
+        f32 = lambda t: torch.as_tensor(t).to(
+            device=dev, dtype=torch.float32).contiguous()
+        i32 = lambda t: torch.as_tensor(t).to(
+            device=dev, dtype=torch.int32).contiguous()
+        input_v = f32(input_v)
+        coords = [f32(c) for c in coords]
+        kps = [i32(torch.as_tensor(k).reshape(-1)) for k in kps]
+        from . import gnn
+        flags = [int(gnn._edges_sorted_flag(torch.as_tensor(e)))
+                 for e in edges]
+        edges = [i32(e) for e in edges]
+        b = _lib.TrainBatch()
+        b.input_v, b.n_feat = input_v.data_ptr(), int(input_v.shape[1])
+        b.n_levels = len(edges)
+        for l, c in enumerate(coords):
+            b.n_vertices[l], b.coords[l] = int(c.shape[0]), c.data_ptr()
+        for l in range(len(edges)):
+            b.keypoints[l] = kps[l].data_ptr()
+            b.edges[l], b.n_edges[l] = edges[l].data_ptr(), int(edges[l].shape[0])
+            b.edges_sorted[l] = flags[l]
+        return b, (input_v, coords, kps, edges)
+
+    def _native_forward(self, input_v, coords, kps, edges):
+        lib = self.lib
+        h = self._native_handle()
+        batch, keep = self._native_batch(input_v, coords, kps, edges)
+        need = int(lib.pgnn_trainer_workspace_bytes(h, ctypes.byref(batch)))
+        if need == 0:
+            raise _lib.PointGnnHipError("pgnn_trainer_workspace_bytes: %s" % (
+                (lib.pgnn_last_error() or b'?').decode()))
+        if self._native_ws is None or self._native_ws.numel() < need:
+            self._native_ws = torch.empty(
+                (int(need * 1.25) + 255) // 256 * 256, dtype=torch.uint8,
+                device=self.device)
+        lg, ld, pb = ctypes.c_void_p(), ctypes.c_int64(), ctypes.c_void_p()
+        _lib.check(lib.pgnn_trainer_forward(
+            h, ctypes.byref(batch), _lib.ptr(self._native_ws),
+            self._native_ws.numel(), ctypes.byref(lg), ctypes.byref(ld),
+            ctypes.byref(pb), self._st()), "pgnn_trainer_forward")
+        k = int(batch.n_vertices[batch.n_levels])
+        # views INTO the workspace (valid until the next forward)
+        base = self._native_ws.data_ptr()
+        flat = self._native_ws.view(torch.float32)
+        o_lg = (lg.value - base) // 4
+        o_pb = (pb.value - base) // 4
+        logits = flat[o_lg:o_lg + k * ld.value].view(k, ld.value)
+        pred = flat[o_pb:o_pb + k * self.nc * self.box_len].view(
+            k, self.nc, self.box_len)
+        self._saved = ('native', batch, keep)
+        self._h_width = padded_width(self.fc[mlp_names(
+            self.config['model_kwargs']['layer_configs'][-1]['scope'] +
+            '/predictor/cls', 2)[0]].k_in)
+        return logits[:, :self.nc], pred
+
+    def _native_backward(self, dlogits, dpred):
+        _, batch, keep = self._saved
+        dl = dlogits.contiguous()
+        dp = dpred.contiguous()
+        _lib.check(self.lib.pgnn_trainer_backward(
+            self._native_handle(), ctypes.byref(batch),
+            _lib.ptr(self._native_ws), self._native_ws.numel(), _lib.ptr(dl),
+            _lib.ptr(dp), self._st()), "pgnn_trainer_backward")
+        self._saved = None
+
     # ---- forward with saved activations ------------------------------------------
     def forward(self, input_v, coords, kps, edges):
         """Returns (logits [K,nc], pred_box [K,nc,L]) and keeps what backward
         needs in self._saved."""
+        if self.native and self.sparse_adjoint:
+            return self._native_forward(input_v, coords, kps, edges)
+        if getattr(self, '_py_images_stale', True):
+            self._repack_py()
         lib, st = self.lib, self._st()
         dev = self.device
         f32 = lambda t: torch.as_tensor(t).to(
@@ -686,7 +849,7 @@ class Trainer(object):
         dlogits [K,nc], dpred [K,nc,L] for the globally normalised loss."""
         dev = self.device
         k = int(logits.shape[0])
-        lg = logits.contiguous()
+        lg = logits if logits.stride(1) == 1 else logits.contiguous()
         labels = labels.to(device=dev, dtype=torch.int32).reshape(-1).contiguous()
         gt = gt_box.to(device=dev, dtype=torch.float32).reshape(
             k, self.box_len).contiguous()
@@ -715,6 +878,8 @@ class Trainer(object):
 
     # ---- backward -----------------------------------------------------------------
     def backward(self, dlogits, dpred):
+        if self._saved and self._saved[0] == 'native':
+            return self._native_backward(dlogits, dpred)
         lib, st, dev = self.lib, self._st(), self.device
         saved = list(self._saved)
         kind, cls_names, cacts, loc = saved.pop()

@@ -384,24 +384,55 @@ def test_segmax_fc_bwd_matches_dense_adjoint(dev, rows, k_in, n_cols, nseg,
     np.testing.assert_allclose(db.cpu().numpy(), ref_db, atol=5e-5, rtol=2e-4)
 
 
-@pytest.mark.parametrize("name", ["car_auto_T1", "car_auto_T3"])
-def test_sparse_and_dense_adjoint_give_the_same_gradient(dev, name):
-    """Trainer.sparse_adjoint switches the last per-edge layer + scatter-max of
-    every stage between pgnn_segmax_fc_bwd_f32 and the dense primitives
-    (pgnn_scatter_max_bwd_f32 + two GEMMs): same forward, same masks and
-    arg-max picks, so the gradients agree to float32 summation order."""
+@pytest.mark.parametrize("name", ["car_auto_T1", "car_auto_T3",
+                                  "ped_cyl_auto_T3", "car_auto_T0"])
+def test_native_sparse_and_dense_steps_give_the_same_gradient(dev, name):
+    """Three ways to run one step on the same batch:
+      native  -- csrc/trainer.hip: forward and backward one C call each;
+      python  -- the same primitives driven from Trainer.forward/.backward
+                 (sparse adjoint of the last per-edge layer + scatter-max);
+      dense   -- pgnn_scatter_max_bwd_f32 + the two E-row GEMMs instead.
+    Same forward arithmetic, same masks and arg-max picks: the gradients agree
+    to float32 summation order, the losses exactly."""
     from pointgnn_amd import train
     cfg = configs.get_config(name)
     params = weights.init_params(cfg, seed=5, bias_scale=0.1)
     batch = _tiny_batch(seed=3, num_classes=cfg["num_classes"])
-    grads = {}
-    for mode in (True, False):
+    grads, losses = {}, {}
+    for mode, (native, sparse) in (("native", (True, True)),
+                                   ("python", (False, True)),
+                                   ("dense", (False, False))):
         tr = train.Trainer(cfg, params=params, device=dev)
-        tr.sparse_adjoint = mode
-        tr.train_step(batch, apply=False)
+        tr.native, tr.sparse_adjoint = native, sparse
+        out = tr.train_step(batch, apply=False)
+        assert (tr._native is not None) == (mode == "native")
         grads[mode] = tr.grad_dict()
-    for n in grads[True]:
-        a, b = grads[True][n].astype(np.float64), grads[False][n].astype(np.float64)
-        scale = max(np.abs(b).max(), 1e-12)
-        assert np.abs(a - b).max() <= 2e-5 * scale + 1e-9, (
-            n, np.abs(a - b).max(), scale)
+        losses[mode] = (out['cls_loss'], out['loc_loss'])
+    assert losses["native"] == losses["python"] == losses["dense"]
+    for mode in ("native", "python"):
+        for n in grads["dense"]:
+            a = grads[mode][n].astype(np.float64)
+            b = grads["dense"][n].astype(np.float64)
+            scale = max(np.abs(b).max(), 1e-12)
+            assert np.abs(a - b).max() <= 2e-5 * scale + 1e-9, (
+                mode, n, np.abs(a - b).max(), scale)
+
+
+def test_native_step_updates_like_the_python_step(dev):
+    """Three SGD steps (apply=True: repack after every update) native vs
+    Python-driven: the weights stay within float32 summation order of each
+    other, and a checkpoint round trip resumes the native step."""
+    from pointgnn_amd import train
+    cfg = configs.car_auto_config(3)
+    params = weights.init_params(cfg, seed=8, bias_scale=0.05)
+    batches = [_tiny_batch(seed=s) for s in (1, 2, 3)]
+    finals = {}
+    for native in (True, False):
+        tr = train.Trainer(cfg, params=params, device=dev)
+        tr.native = native
+        for b in batches:
+            tr.train_step(b)
+        finals[native] = tr.state_dict()
+    for n in finals[True]:
+        a, b = finals[True][n].astype(np.float64), finals[False][n].astype(np.float64)
+        assert np.abs(a - b).max() <= 1e-5 * max(np.abs(b).max(), 1e-6) + 1e-8, n
