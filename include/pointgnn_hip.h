@@ -336,11 +336,14 @@ int pgnn_pack_fc_device(const float *w, const float *b, int32_t k_in,
 /* Every layer's device images refreshed in ONE launch (after pgnn_sgd_step):
  * `jobs_device` is a device array of n_jobs records
  *   struct { const float *w; const float *b; float *dst; int32_t k_in, n_out,
- *            kind, first_block; }                         (40 bytes each)
+ *            kind, first_block, ld, reserved; }           (48 bytes each)
  * kind 0 = pgnn_pack_fc image of (w [k_in,n_out], b), 1 = image of w^T (no
  * bias), 2 = plain w^T as [n_out][16*ceil(k_in/16)] rows (zero padded; what
  * pgnn_segmax_fc_bwd_f32 reads), 3 = plain w as [k_in][16*ceil(n_out/16)]
- * rows (zero padded).  A job covers ceil(elements / 256) blocks
+ * rows (zero padded); 4 / 5 / 6 = strided block copy / block add / identity
+ * (how the native trainer assembles its fused prediction-head matrices from
+ * parameter blocks and hands their gradients back; `ld` = row stride of the
+ * strided side).  A job covers ceil(elements / 256) blocks
  * of the launch; first_block is the running sum, total_blocks the grand
  * total.  The table is built once: the flat parameter buffer never moves.  */
 int pgnn_pack_fc_many(const void *jobs_device, int32_t n_jobs,
@@ -403,6 +406,22 @@ int pgnn_segmax_fc_bwd_f32(const float *Y, int64_t ld_y,
                            int64_t ld_dx, int32_t dx_cols, int32_t mask_x,
                            float *dW, float *db, void *workspace,
                            size_t workspace_bytes, void *stream);
+/* The GraphNetAutoCenter form (gnn.py:348-365): X = H1 = ReLU(P[src] - Q[dst])
+ * [n_edges, ld_h1] feeds the layer, so the routed gradient is scattered
+ * straight into dP[src] += g, dQ[dst] -= g (both [num_vertices, ld_pq], zeroed
+ * by the call: pgnn_edge_hidden_bwd's outputs) and dH1 is never written.
+ * edges [n_edges, 2] = (src, dst) grouped by dst for the in-register dQ runs
+ * (any order is correct); dst_ids = its dst column, contiguous.            */
+int pgnn_edge_segmax_fc_bwd_f32(const float *Y, int64_t ld_y,
+                                const int32_t *edges, const int32_t *dst_ids,
+                                int64_t n_edges, int32_t n_cols,
+                                int32_t num_vertices, const float *out,
+                                int64_t ld_out, const float *grad_out,
+                                int64_t ld_go, const float *H1, int64_t ld_h1,
+                                int32_t k_in, const float *WT, int64_t ld_wt,
+                                float *dP, float *dQ, int64_t ld_pq, float *dW,
+                                float *db, void *workspace,
+                                size_t workspace_bytes, void *stream);
 /* dW [k_in, n_out] (= X^T dZ) and db [n_out] (= column sums of dZ; may be
  * NULL) of y = x W + b, deterministic (fixed-order slice reduction).
  * accumulate != 0 adds to dW/db.                                             */

@@ -30,7 +30,8 @@ class FcLayer(ctypes.Structure):
 class PackJob(ctypes.Structure):
     """One record of pgnn_pack_fc_many's job table."""
     _fields_ = [("w", c_vp), ("b", c_vp), ("dst", c_vp), ("k_in", c_i32),
-                ("n_out", c_i32), ("kind", c_i32), ("first_block", c_i32)]
+                ("n_out", c_i32), ("kind", c_i32), ("first_block", c_i32),
+                ("ld", c_i32), ("reserved", c_i32)]
 
 
 TRAIN_MAX_FC, TRAIN_MAX_STAGES, TRAIN_MAX_CLASSES, TRAIN_MAX_LEVELS = 8, 8, 16, 4
@@ -140,6 +141,11 @@ _SIGNATURES = {
                                     c_vp]),
     "pgnn_pack_fc_many": (c_i32, [c_vp, c_i32, c_i32, c_vp]),
     "pgnn_segmax_fc_bwd_workspace_bytes": (c_sz, [c_i64, c_i32, c_i32, c_i32]),
+    "pgnn_edge_segmax_fc_bwd_f32": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64,
+                                            c_i32, c_i32, c_vp, c_i64, c_vp,
+                                            c_i64, c_vp, c_i64, c_i32, c_vp,
+                                            c_i64, c_vp, c_vp, c_i64, c_vp,
+                                            c_vp, c_vp, c_sz, c_vp]),
     "pgnn_segmax_fc_bwd_f32": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_i32,
                                        c_vp, c_i64, c_vp, c_i64, c_vp, c_i64,
                                        c_i32, c_vp, c_i64, c_vp, c_i64, c_i32,

@@ -230,9 +230,16 @@ struct PackJob {
   int32_t kind;     // 0 fragment image, 1 fragment image of W^T (no bias),
                     // 2 plain W^T [n_out rows][ld = 16*ceil(k_in/16)], zero pad
                     // 3 plain W   [k_in rows][ld = 16*ceil(n_out/16)], zero pad
+                    // 4 block copy  dst[r*ld + c]  = w[r*n_out + c]
+                    // 5 block add   dst[r*n_out + c] += w[r*ld + c]
+                    //   (r < k_in, c < n_out; 4 assembles fused matrices from
+                    //   parameter blocks, 5 hands their gradients back)
+                    // 6 dst[i*ld + i] = 1, i < k_in
   int32_t first_block;  // prefix sum of the jobs' block counts
+  int32_t ld;           // kinds 4-6: row stride of the strided side
+  int32_t reserved;
 };
-static_assert(sizeof(PackJob) == 40, "PackJob layout (Python mirrors it)");
+static_assert(sizeof(PackJob) == 48, "PackJob layout (Python mirrors it)");
 
 __global__ __launch_bounds__(256) void pack_many_kernel(
     const PackJob *__restrict__ jobs, int n_jobs) {
@@ -245,6 +252,21 @@ __global__ __launch_bounds__(256) void pack_many_kernel(
   }
   const PackJob j = jobs[lo];
   const int64_t base = (int64_t)(blk - j.first_block) * 256 + threadIdx.x;
+  if (j.kind >= 4) {
+    const int64_t total = j.kind == 6 ? j.k_in : (int64_t)j.k_in * j.n_out;
+    if (base < total) {
+      if (j.kind == 6) {
+        j.dst[base * j.ld + base] = 1.0f;
+      } else {
+        const int r = (int)(base / j.n_out), c = (int)(base - (int64_t)r * j.n_out);
+        if (j.kind == 4)
+          j.dst[(int64_t)r * j.ld + c] = j.w[base];
+        else
+          j.dst[base] += j.w[(int64_t)r * j.ld + c];
+      }
+    }
+    return;
+  }
   if (j.kind == 3) {
     const int ld = (j.n_out + 15) / 16 * 16;
     const int64_t total = (int64_t)j.k_in * ld;
@@ -301,7 +323,8 @@ __global__ void segmax_count_win4_kernel(
     const float *__restrict__ data, int64_t ld, const int32_t *__restrict__ seg,
     int64_t rows, int cols4, int nseg, const float *__restrict__ out,
     int64_t ldo, int32_t *__restrict__ cnt, int32_t *__restrict__ win,
-    int ldc, int32_t *__restrict__ tie_flag) {
+    int ldc, int32_t *__restrict__ tie_count, int32_t *__restrict__ tie_list,
+    int tie_cap) {
   const int64_t total = rows * cols4;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
@@ -315,10 +338,15 @@ __global__ void segmax_count_win4_kernel(
     for (int i = 0; i < 4; ++i)
       if (d[i] == o[i] && d[i] > 0.0f) {
         const int slot = atomicAdd(&cnt[(int64_t)s * ldc + c + i], 1);
-        if (slot == 0)
+        if (slot == 0) {
           win[(int64_t)s * ldc + c + i] = (int32_t)r;
-        else
-          *tie_flag = 1;
+        } else {  // a further row holding the same positive maximum
+          const int p = atomicAdd(tie_count, 1);
+          if (p < tie_cap) {
+            tie_list[2 * p] = (int32_t)r;
+            tie_list[2 * p + 1] = c + i;
+          }
+        }
       }
   }
 }
@@ -402,8 +430,126 @@ __global__ __launch_bounds__(256) void segmax_route_sparse_kernel(
   }
 }
 
+// The edge stage's form of the same routing (gnn.py:348-356 adjoint): X = H1
+// = ReLU(P[src] - Q[dst]) feeds the layer, so the routed gradient goes
+// straight to dP[src] += g, dQ[dst] -= g (pgnn_edge_hidden_bwd) and the E x C
+// matrix dH1 is never written.  A wave owns kChunk consecutive rows: the list
+// is grouped by dst, so the dQ sum of a run stays in registers and is flushed
+// with one row of atomics per run instead of one per edge; dP rows are atomic
+// adds (src is unordered).
+constexpr int kScatterChunk = 16;
+template <int J, int I>
+__global__ __launch_bounds__(256) void segmax_route_scatter_kernel(
+    const float *__restrict__ data, int64_t ld, const int32_t *__restrict__ edges,
+    int64_t rows, int cols, int nseg, const float *__restrict__ out, int64_t ldo,
+    const float *__restrict__ gout, int64_t ldg, const int32_t *__restrict__ cnt,
+    int ldc, const float *__restrict__ WT, int64_t ldwt, int k_in,
+    const float *__restrict__ X, int64_t ldx, float *__restrict__ dP,
+    float *__restrict__ dQ, int64_t ldpq) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  int kc[I];
+#pragma unroll
+  for (int i = 0; i < I; ++i) kc[i] = min(lane + 64 * i, k_in - 1);
+  const int64_t n_chunks = (rows + kScatterChunk - 1) / kScatterChunk;
+  for (int64_t ch = wave; ch < n_chunks; ch += n_waves) {
+    const int64_t r0 = ch * kScatterChunk;
+    const int64_t r1 = min(r0 + (int64_t)kScatterChunk, rows);
+    float qacc[I];
+#pragma unroll
+    for (int i = 0; i < I; ++i) qacc[i] = 0.0f;
+    int q_dst = -1;
+    for (int64_t r = r0; r < r1; ++r) {
+      const int src = edges[2 * r], s_raw = edges[2 * r + 1];
+      const bool s_ok = s_raw >= 0 && s_raw < nseg && src >= 0 && src < nseg;
+      const int s = s_ok ? s_raw : 0;
+      float d[J], o[J], go[J], xv[I];
+      int cn[J];
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const int cc = min(lane + 64 * j, cols - 1);
+        d[j] = data[r * ld + cc];
+        o[j] = out[(int64_t)s * ldo + cc];
+        go[j] = gout[(int64_t)s * ldg + cc];
+        cn[j] = cnt[(int64_t)s * ldc + cc];
+      }
+#pragma unroll
+      for (int i = 0; i < I; ++i) xv[i] = X[r * ldx + kc[i]];
+      float g[J];
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const bool w = s_ok && (lane + 64 * j) < cols && d[j] > 0.0f && d[j] == o[j];
+        g[j] = w ? go[j] / (float)max(cn[j], 1) : 0.0f;
+      }
+      float acc[I];
+#pragma unroll
+      for (int i = 0; i < I; ++i) acc[i] = 0.0f;
+      bool any = false;
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        unsigned long long m = __ballot(g[j] != 0.0f);
+        any = any || m != 0ull;
+        while (m) {
+          const int l0 = __builtin_ctzll(m);
+          m &= m - 1;
+          const int l1 = m ? __builtin_ctzll(m) : l0;
+          const float g0 = __shfl(g[j], l0);
+          const float g1 = m ? __shfl(g[j], l1) : 0.0f;
+          m &= m - 1;
+          const float *w0 = WT + (int64_t)(l0 + 64 * j) * ldwt;
+          const float *w1 = WT + (int64_t)(l1 + 64 * j) * ldwt;
+          float a0[I], a1[I];
+#pragma unroll
+          for (int i = 0; i < I; ++i) {
+            a0[i] = w0[kc[i]];
+            a1[i] = w1[kc[i]];
+          }
+#pragma unroll
+          for (int i = 0; i < I; ++i) {
+            acc[i] += g0 * a0[i];
+            acc[i] += g1 * a1[i];
+          }
+        }
+      }
+      if (s != q_dst) {  // wave-uniform: the dst run ended
+        if (q_dst >= 0) {
+#pragma unroll
+          for (int i = 0; i < I; ++i) {
+            const int k = lane + 64 * i;
+            if (k < k_in && qacc[i] != 0.0f)
+              atomicAdd(&dQ[(int64_t)q_dst * ldpq + k], -qacc[i]);
+            qacc[i] = 0.0f;
+          }
+        }
+        q_dst = s;
+      }
+      if (any) {  // wave-uniform
+#pragma unroll
+        for (int i = 0; i < I; ++i) {
+          const int k = lane + 64 * i;
+          const float v = (k < k_in && xv[i] > 0.0f) ? acc[i] : 0.0f;
+          if (v != 0.0f) {
+            atomicAdd(&dP[(int64_t)src * ldpq + k], v);
+            qacc[i] += v;
+          }
+        }
+      }
+    }
+    if (q_dst >= 0) {
+#pragma unroll
+      for (int i = 0; i < I; ++i) {
+        const int k = lane + 64 * i;
+        if (k < k_in && qacc[i] != 0.0f)
+          atomicAdd(&dQ[(int64_t)q_dst * ldpq + k], -qacc[i]);
+      }
+    }
+  }
+}
+
 // grid (column, slice): dW^T partial [slice][c][k] and db partial [slice][c]
-// from the single winners (cnt == 1); tied maxima are left to the tie pass
+// from the recorded winner of every (segment, column); the other rows of a
+// tie are left to the tie passes
 template <int I /* ceil(kin_p/64) */>
 __global__ __launch_bounds__(64) void segmax_wgrad_gather_kernel(
     const float *__restrict__ gout, int64_t ldg, const int32_t *__restrict__ cnt,
@@ -423,9 +569,14 @@ __global__ __launch_bounds__(64) void segmax_wgrad_gather_kernel(
     const int s = sb + lane;
     float g = 0.0f;
     int e = 0;
-    if (s < s1 && cnt[(int64_t)s * ldc + c] == 1) {
-      g = gout[(int64_t)s * ldg + c];
-      e = win[(int64_t)s * ldc + c];
+    if (s < s1) {
+      // the recorded (first) winner takes its share here; further rows tied
+      // with it are on the tie list
+      const int n = cnt[(int64_t)s * ldc + c];
+      if (n >= 1) {
+        g = gout[(int64_t)s * ldg + c] / (float)n;
+        e = win[(int64_t)s * ldc + c];
+      }
     }
     bsum += g;
     const int nl = min(64, s1 - sb);
@@ -485,16 +636,40 @@ __global__ void segmax_wgrad_reduce_kernel(const float *__restrict__ partial,
   }
 }
 
-// weight-gradient terms of tied positive maxima (cnt > 1); exits at once when
-// the count pass found none.  Rare: plain float atomics.
+// weight-gradient terms of the further rows of tied positive maxima: one wave
+// per list entry (row r, column c).  Rare (duplicate points): float atomics.
+__global__ __launch_bounds__(256) void segmax_wgrad_tie_list_kernel(
+    const int32_t *__restrict__ tie_count, const int32_t *__restrict__ tie_list,
+    int tie_cap, const int32_t *__restrict__ seg, const float *__restrict__ gout,
+    int64_t ldg, const int32_t *__restrict__ cnt, int ldc,
+    const float *__restrict__ X, int64_t ldx, int k_in, int cols,
+    float *__restrict__ dW, float *__restrict__ db) {
+  int n = *tie_count;
+  if (n > tie_cap) return;  // overflow: the scan kernel below does them all
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int n_waves = (gridDim.x * blockDim.x) >> 6;
+  for (int t = wave; t < n; t += n_waves) {
+    const int r = tie_list[2 * t], c = tie_list[2 * t + 1];
+    const int s = seg[r];
+    const float g = gout[(int64_t)s * ldg + c] / (float)cnt[(int64_t)s * ldc + c];
+    for (int k = lane; k < k_in; k += 64)
+      atomicAdd(&dW[(int64_t)k * cols + c], g * X[(int64_t)r * ldx + k]);
+    if (db && lane == 0) atomicAdd(&db[c], g);
+  }
+}
+
+// the same by a full scan (every tied row except the recorded winner); runs
+// only when the tie list overflowed
 __global__ void segmax_wgrad_ties_kernel(
-    const int32_t *__restrict__ tie_flag, const float *__restrict__ data,
-    int64_t ld, const int32_t *__restrict__ seg, int64_t rows, int cols,
-    int nseg, const float *__restrict__ out, int64_t ldo,
-    const float *__restrict__ gout, int64_t ldg, const int32_t *__restrict__ cnt,
+    const int32_t *__restrict__ tie_count, int tie_cap,
+    const float *__restrict__ data, int64_t ld,
+    const int32_t *__restrict__ seg, int64_t rows, int cols, int nseg,
+    const float *__restrict__ out, int64_t ldo, const float *__restrict__ gout,
+    int64_t ldg, const int32_t *__restrict__ cnt, const int32_t *__restrict__ win,
     int ldc, const float *__restrict__ X, int64_t ldx, int k_in,
     float *__restrict__ dW, float *__restrict__ db) {
-  if (*tie_flag == 0) return;
+  if (*tie_count <= tie_cap) return;
   const int64_t total = rows * cols;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
@@ -505,7 +680,7 @@ __global__ void segmax_wgrad_ties_kernel(
     const float d = data[r * ld + c];
     if (!(d > 0.0f) || d != out[(int64_t)s * ldo + c]) continue;
     const int n = cnt[(int64_t)s * ldc + c];
-    if (n <= 1) continue;
+    if (n <= 1 || win[(int64_t)s * ldc + c] == (int32_t)r) continue;
     const float g = gout[(int64_t)s * ldg + c] / (float)n;
     for (int k = 0; k < k_in; ++k)
       atomicAdd(&dW[(int64_t)k * cols + c], g * X[r * ldx + k]);
@@ -775,8 +950,9 @@ extern "C" int pgnn_pack_fc_many(const void *jobs_device, int32_t n_jobs,
 }
 
 namespace {
+constexpr int kTieCap = 65536;
 struct SegFcWs {
-  int32_t *cnt, *win, *tie;
+  int32_t *cnt, *win, *tie, *tie_list;
   float *partial, *partial_b;
   int ldc, slices, seg_per_slice, kin_p;
 };
@@ -803,6 +979,7 @@ size_t segfc_carve(void *ws, int64_t n_rows, int32_t n_cols,
   const size_t a_win = take((size_t)num_segments * ldc * 4);
   const size_t a_par = take((size_t)slices * n_cols * kin_p * 4);
   const size_t a_pb = take((size_t)slices * n_cols * 4);
+  const size_t a_tl = take((size_t)kTieCap * 2 * 4);
   if (o) {
     char *b = (char *)ws;
     o->cnt = (int32_t *)(b + a_cnt);
@@ -810,6 +987,7 @@ size_t segfc_carve(void *ws, int64_t n_rows, int32_t n_cols,
     o->win = (int32_t *)(b + a_win);
     o->partial = (float *)(b + a_par);
     o->partial_b = (float *)(b + a_pb);
+    o->tie_list = (int32_t *)(b + a_tl);
     o->ldc = ldc;
     o->slices = slices;
     o->seg_per_slice = (num_segments + slices - 1) / slices;
@@ -828,18 +1006,26 @@ extern "C" size_t pgnn_segmax_fc_bwd_workspace_bytes(int64_t n_rows,
   return segfc_carve(nullptr, n_rows, n_cols, num_segments, k_in, nullptr);
 }
 
-extern "C" int pgnn_segmax_fc_bwd_f32(
-    const float *Y, int64_t ld_y, const int32_t *seg_ids, int64_t n_rows,
-    int32_t n_cols, int32_t num_segments, const float *out, int64_t ld_out,
-    const float *grad_out, int64_t ld_go, const float *X, int64_t ld_x,
-    int32_t k_in, const float *WT, int64_t ld_wt, float *dX, int64_t ld_dx,
-    int32_t dx_cols, int32_t mask_x, float *dW, float *db, void *workspace,
-    size_t workspace_bytes, void *stream_) {
-  PGNN_GUARD_BEGIN
-  hipStream_t stream = (hipStream_t)stream_;
+namespace {
+// shared body: edges != null selects the edge-stage form (dP / dQ scatter
+// instead of a materialised dX)
+int segfc_bwd_impl(const float *Y, int64_t ld_y, const int32_t *seg_ids,
+                   int64_t n_rows, int32_t n_cols, int32_t num_segments,
+                   const float *out, int64_t ld_out, const float *grad_out,
+                   int64_t ld_go, const float *X, int64_t ld_x, int32_t k_in,
+                   const float *WT, int64_t ld_wt, float *dX, int64_t ld_dx,
+                   int32_t dx_cols, int32_t mask_x, const int32_t *edges,
+                   float *dP, float *dQ, int64_t ld_pq, float *dW, float *db,
+                   void *workspace, size_t workspace_bytes, hipStream_t stream) {
   PGNN_REQUIRE(n_rows >= 0 && n_cols > 0 && n_cols <= 512 && num_segments >= 0 &&
                    k_in > 0 && k_in <= 512,
                PGNN_E_INVALID, "segmax_fc_bwd: bad sizes");
+  if (edges && num_segments > 0) {
+    PGNN_REQUIRE(dP && dQ && ld_pq >= k_in, PGNN_E_INVALID,
+                 "edge_segmax_fc_bwd: bad dP / dQ");
+    PGNN_HIP(hipMemsetAsync(dP, 0, (size_t)num_segments * ld_pq * 4, stream));
+    PGNN_HIP(hipMemsetAsync(dQ, 0, (size_t)num_segments * ld_pq * 4, stream));
+  }
   if (n_rows == 0 || num_segments == 0) return 0;
   PGNN_REQUIRE(Y && seg_ids && out && grad_out && X && WT && dW, PGNN_E_INVALID,
                "segmax_fc_bwd: null pointer");
@@ -864,8 +1050,22 @@ extern "C" int pgnn_segmax_fc_bwd_f32(
   hipLaunchKernelGGL(segmax_count_win4_kernel,
                      dim3(grid_for(n_rows * cols4, 8192)), dim3(256), 0, stream, Y,
                      ld_y, seg_ids, n_rows, cols4, num_segments, out, ld_out,
-                     w.cnt, w.win, w.ldc, w.tie);
-  if (dX) {
+                     w.cnt, w.win, w.ldc, w.tie, w.tie_list, kTieCap);
+  if (edges) {
+    const int J = (n_cols + 63) / 64, I = (k_in + 63) / 64;
+    const int64_t chunks = (n_rows + kScatterChunk - 1) / kScatterChunk;
+    const unsigned blocks =
+        (unsigned)((chunks + 3) / 4 < 8192 ? (chunks + 3) / 4 : 8192);
+#define PGNN_SCAT(JV, IV)                                                      \
+  hipLaunchKernelGGL((segmax_route_scatter_kernel<JV, IV>), dim3(blocks),      \
+                     dim3(256), 0, stream, Y, ld_y, edges, n_rows, n_cols,     \
+                     num_segments, out, ld_out, grad_out, ld_go, w.cnt, w.ldc,  \
+                     WT, ld_wt, k_in, X, ld_x, dP, dQ, ld_pq)
+    if (J == 5 && I == 5) PGNN_SCAT(5, 5);
+    else if (J == 4 && I == 4) PGNN_SCAT(4, 4);
+    else PGNN_SCAT(8, 8);
+#undef PGNN_SCAT
+  } else if (dX) {
     const int J = (n_cols + 63) / 64, I = (dx_cols + 63) / 64;
     const unsigned blocks = (unsigned)((n_rows + 3) / 4 < 8192 ? (n_rows + 3) / 4
                                                              : 8192);
@@ -898,14 +1098,51 @@ extern "C" int pgnn_segmax_fc_bwd_f32(
                        dim3(grid_for((int64_t)(k_in + 1) * n_cols)), dim3(256), 0,
                        stream, w.partial, w.partial_b, w.slices, n_cols, k_in,
                        w.kin_p, dW, db);
+    hipLaunchKernelGGL(segmax_wgrad_tie_list_kernel, dim3(64), dim3(256), 0,
+                       stream, w.tie, w.tie_list, kTieCap, seg_ids, grad_out,
+                       ld_go, w.cnt, w.ldc, X, ld_x, k_in, n_cols, dW, db);
     hipLaunchKernelGGL(segmax_wgrad_ties_kernel,
                        dim3(grid_for(n_rows * n_cols, 2048)), dim3(256), 0,
-                       stream, w.tie, Y, ld_y, seg_ids, n_rows, n_cols,
-                       num_segments, out, ld_out, grad_out, ld_go, w.cnt, w.ldc,
-                       X, ld_x, k_in, dW, db);
+                       stream, w.tie, kTieCap, Y, ld_y, seg_ids, n_rows, n_cols,
+                       num_segments, out, ld_out, grad_out, ld_go, w.cnt, w.win,
+                       w.ldc, X, ld_x, k_in, dW, db);
   }
   PGNN_HIP(hipGetLastError());
   return 0;
+}
+}  // namespace
+
+extern "C" int pgnn_segmax_fc_bwd_f32(
+    const float *Y, int64_t ld_y, const int32_t *seg_ids, int64_t n_rows,
+    int32_t n_cols, int32_t num_segments, const float *out, int64_t ld_out,
+    const float *grad_out, int64_t ld_go, const float *X, int64_t ld_x,
+    int32_t k_in, const float *WT, int64_t ld_wt, float *dX, int64_t ld_dx,
+    int32_t dx_cols, int32_t mask_x, float *dW, float *db, void *workspace,
+    size_t workspace_bytes, void *stream_) {
+  PGNN_GUARD_BEGIN
+  return segfc_bwd_impl(Y, ld_y, seg_ids, n_rows, n_cols, num_segments, out,
+                        ld_out, grad_out, ld_go, X, ld_x, k_in, WT, ld_wt, dX,
+                        ld_dx, dx_cols, mask_x, nullptr, nullptr, nullptr, 0, dW,
+                        db, workspace, workspace_bytes, (hipStream_t)stream_);
+  PGNN_GUARD_END
+}
+
+extern "C" int pgnn_edge_segmax_fc_bwd_f32(
+    const float *Y, int64_t ld_y, const int32_t *edges, const int32_t *dst_ids,
+    int64_t n_edges, int32_t n_cols, int32_t num_vertices, const float *out,
+    int64_t ld_out, const float *grad_out, int64_t ld_go, const float *H1,
+    int64_t ld_h1, int32_t k_in, const float *WT, int64_t ld_wt, float *dP,
+    float *dQ, int64_t ld_pq, float *dW, float *db, void *workspace,
+    size_t workspace_bytes, void *stream_) {
+  PGNN_GUARD_BEGIN
+  PGNN_REQUIRE(edges || n_edges == 0, PGNN_E_INVALID,
+               "edge_segmax_fc_bwd: null edges");
+  // a non-null marker keeps the edge form selected for n_edges == 0 as well
+  static const int32_t kNoEdges[2] = {0, 0};
+  return segfc_bwd_impl(Y, ld_y, dst_ids, n_edges, n_cols, num_vertices, out,
+                        ld_out, grad_out, ld_go, H1, ld_h1, k_in, WT, ld_wt,
+                        nullptr, 0, 0, 1, edges ? edges : kNoEdges, dP, dQ, ld_pq,
+                        dW, db, workspace, workspace_bytes, (hipStream_t)stream_);
   PGNN_GUARD_END
 }
 

@@ -101,15 +101,31 @@ struct PackJobRec {  // = train.hip's PackJob (pgnn_pack_fc_many's record)
   const float *w;
   const float *b;
   float *dst;
-  int32_t k_in, n_out, kind, first_block;
+  int32_t k_in, n_out, kind, first_block, ld, reserved;
 };
-static_assert(sizeof(PackJobRec) == 40, "job record layout");
+static_assert(sizeof(PackJobRec) == 48, "job record layout");
 
 struct FcDev {  // one layer: where it lives + its device images
-  pgnn_train_fc ref;
+  pgnn_train_fc ref;  // dims; offsets into the flat buffers (not for fused layers)
+  float *w = nullptr, *b = nullptr;    // weights / biases (flat buffer or fused)
+  float *gw = nullptr, *gb = nullptr;  // their gradients
   float *packed = nullptr, *packed_t = nullptr, *wt = nullptr;
   size_t off_packed = 0, off_packed_t = 0, off_wt = 0;
   bool want_wt = false;
+};
+
+// The prediction heads of one group as three fused layers (the block layout
+// of the inference path, pointgnn_amd/gnn.py ClassAwarePredictor): all first
+// layers side by side, block-diagonal second and third layers, the class
+// logits passed through the third layer by an identity block.  ~75 launches
+// of 64-wide layers per step become ~13.
+struct HeadGroup {
+  bool has_cls = false;
+  std::vector<int> lids;  // box heads in this group
+  int base = 0;           // columns reserved for the logits in layers 2 / 3
+  FcDev f[3];             // fused layers (weights / gradients live in `images`)
+  size_t off_w[3] = {0, 0, 0}, off_b[3] = {0, 0, 0}, off_gw[3] = {0, 0, 0},
+         off_gb[3] = {0, 0, 0};
 };
 
 struct StageDev {
@@ -125,17 +141,57 @@ struct Trainer {
   std::vector<StageDev> stages;
   FcDev cls[2];
   std::vector<FcDev> loc;  // 3 per class
+  std::vector<HeadGroup> groups;  // empty: heads run one by one
   float *params = nullptr, *grads = nullptr;
   char *images = nullptr;
-  size_t images_bytes = 0, off_jobs = 0;
-  int n_jobs = 0, total_blocks = 0;
+  size_t images_bytes = 0, off_jobs = 0, off_jobs_a = 0, off_jobs_u = 0;
+  size_t fused_lo = 0, fused_hi = 0;  // byte range of the fused matrices
+  int n_jobs = 0, total_blocks = 0;       // fragment / transpose images
+  int n_jobs_a = 0, total_blocks_a = 0;   // assemble fused matrices (before)
+  int n_jobs_u = 0, total_blocks_u = 0;   // hand fused gradients back (after)
 };
 
 size_t packed_floats(int k_in, int n_out) {
   return pgnn_packed_fc_floats(k_in, n_out);
 }
 
-// lay out every image; returns the bytes needed (jobs table included)
+// groups of heads as the inference path forms them (gnn.py of the package,
+// ClassAwarePredictor): returns false when the heads do not have the shipped
+// shape (C -> hw -> nc and C -> hw -> hw -> L with one hw, L <= 8)
+bool plan_head_groups(Trainer &t) {
+  const int nc = t.m.num_classes, L = t.m.box_len;
+  const int C = t.cls[0].ref.k_in, hw = t.cls[0].ref.n_out;
+  if (L > 8 || nc > 16 || t.cls[1].ref.k_in != hw || t.cls[1].ref.n_out != nc)
+    return false;
+  for (int j = 0; j < nc; ++j) {
+    const FcDev *f = &t.loc[3 * j];
+    if (f[0].ref.k_in != C || f[0].ref.n_out != hw || f[1].ref.k_in != hw ||
+        f[1].ref.n_out != hw || f[2].ref.k_in != hw || f[2].ref.n_out != L)
+      return false;
+  }
+  if (hw > 160) return false;
+  const int per_first = (320 / hw - 1) > 1 ? (320 / hw - 1) : 1;
+  const int per_rest = (320 / hw) > 1 ? (320 / hw) : 1;
+  int next = 0;
+  bool first = true;
+  while (first || next < nc) {
+    HeadGroup g;
+    g.has_cls = first;
+    g.base = first ? 16 : 0;
+    const int take = first ? per_first : per_rest;
+    for (int i = 0; i < take && next < nc; ++i) g.lids.push_back(next++);
+    const int nh = (int)g.lids.size() + (first ? 1 : 0);
+    const int nl = (int)g.lids.size();
+    g.f[0].ref = {0, 0, C, hw * nh};
+    g.f[1].ref = {0, 0, hw * nh, g.base + hw * nl};
+    g.f[2].ref = {0, 0, g.base + hw * nl, g.base + 8 * nl};
+    t.groups.push_back(g);
+    first = false;
+  }
+  return true;
+}
+
+// lay out every image; returns the bytes needed (job tables included)
 size_t layout_images(Trainer &t) {
   size_t off = 0;
   auto take = [&](size_t floats) {
@@ -164,11 +220,41 @@ size_t layout_images(Trainer &t) {
       jobs += 2;
     }
   }
-  for (FcDev &f : t.cls) lay(f);
-  for (FcDev &f : t.loc) lay(f);
+  int jobs_a = 0, jobs_u = 0;
+  if (t.groups.empty()) {
+    for (FcDev &f : t.cls) lay(f);
+    for (FcDev &f : t.loc) lay(f);
+  } else {
+    // fused weight / bias matrices (zeroed once, parameter blocks copied in
+    // before every pack) in one contiguous range
+    t.fused_lo = off;
+    for (HeadGroup &g : t.groups)
+      for (int i = 0; i < 3; ++i) {
+        g.off_w[i] = take((size_t)g.f[i].ref.k_in * g.f[i].ref.n_out);
+        g.off_b[i] = take((size_t)g.f[i].ref.n_out);
+      }
+    t.fused_hi = off;
+    for (HeadGroup &g : t.groups)
+      for (int i = 0; i < 3; ++i) {
+        g.off_gw[i] = take((size_t)g.f[i].ref.k_in * g.f[i].ref.n_out);
+        g.off_gb[i] = take((size_t)g.f[i].ref.n_out);
+        lay(g.f[i]);
+      }
+    for (HeadGroup &g : t.groups) {
+      const int blocks = (g.has_cls ? 2 : 0) + 3 * (int)g.lids.size();
+      jobs_a += 2 * blocks;  // weights + biases
+      jobs_u += 2 * blocks;
+    }
+  }
   t.off_jobs = off;
   t.n_jobs = jobs;
   off += align_up((size_t)jobs * sizeof(PackJobRec), 256);
+  t.off_jobs_a = off;
+  t.n_jobs_a = jobs_a;
+  off += align_up((size_t)(jobs_a + 1) * sizeof(PackJobRec), 256);
+  t.off_jobs_u = off;
+  t.n_jobs_u = jobs_u;
+  off += align_up((size_t)(jobs_u + 1) * sizeof(PackJobRec), 256);
   return off + 256;
 }
 
@@ -208,6 +294,7 @@ struct GnnSaved {
   float *uact[PGNN_TRAIN_MAX_FC];  // outputs of the update MLP layers
 };
 struct HeadsSaved {
+  float *y1[4], *y2[4], *y3[4];  // fused groups: outputs of the three layers
   float *c1, *logits;          // [K, 64], [K, pad(nc)]
   float *l1[PGNN_TRAIN_MAX_CLASSES], *l2[PGNN_TRAIN_MAX_CLASSES],
       *l3[PGNN_TRAIN_MAX_CLASSES];
@@ -248,17 +335,24 @@ int check_batch(const Trainer &t, const pgnn_train_batch *b) {
   return 0;
 }
 
-// one FC layer forward on `rows` rows: y = act(x[:, :k_in] W + b) (+ residual)
-int fc_fwd(Ctx &c, const FcDev &f, const float *x, int64_t ldx, int64_t rows,
-           bool relu, const float *residual, int64_t ld_res, float *y) {
+// one FC layer forward on `rows` rows: y = act(x[:, :k_in] W + b) (+ residual);
+// relu_from: ReLU on output columns >= relu_from (0 = all, n_out = linear)
+int fc_fwd_from(Ctx &c, const FcDev &f, const float *x, int64_t ldx,
+                int64_t rows, int relu_from, const float *residual,
+                int64_t ld_res, float *y) {
   if (c.dry || rows == 0) return 0;
   pgnn_fc_layer L;
   L.packed = f.packed;
   L.k_in = f.ref.k_in;
   L.n_out = f.ref.n_out;
-  L.relu_from = relu ? 0 : f.ref.n_out;
+  L.relu_from = relu_from;
   return pgnn_mlp_fwd(x, ldx, f.ref.k_in, nullptr, 0, 0, rows, &L, 1, residual,
                       ld_res, y, pad16(f.ref.n_out), c.stream);
+}
+int fc_fwd(Ctx &c, const FcDev &f, const float *x, int64_t ldx, int64_t rows,
+           bool relu, const float *residual, int64_t ld_res, float *y) {
+  return fc_fwd_from(c, f, x, ldx, rows, relu ? 0 : f.ref.n_out, residual,
+                     ld_res, y);
 }
 
 // dX = dY W^T through the forward engine on the transposed image
@@ -275,16 +369,17 @@ int fc_dx(Ctx &c, const FcDev &f, const float *dy, int64_t lddy, int64_t rows,
 }
 
 int fc_wgrad(Ctx &c, Saved &sv, const FcDev &f, const float *x, int64_t ldx,
-             const float *dy, int64_t lddy, int64_t rows) {
+             const float *dy, int64_t lddy, int64_t rows, bool accumulate = true) {
   if (c.dry || rows == 0) return 0;
   return pgnn_weight_grad_f32(x, ldx, f.ref.k_in, dy, lddy, f.ref.n_out, rows,
-                              c.t.grads + f.ref.w_off, c.t.grads + f.ref.b_off, 1,
-                              sv.scratch, sv.scratch_bytes, c.stream);
+                              f.gw, f.gb, accumulate ? 1 : 0, sv.scratch,
+                              sv.scratch_bytes, c.stream);
 }
 
 // fc_bwd of the Python mirror: optional ReluGrad (in place on dy), dW/db, dX
 int fc_bwd(Ctx &c, Saved &sv, const FcDev &f, const float *x, int64_t ldx,
-           const float *y, float *dy, int64_t rows, bool relu, float *dx) {
+           const float *y, float *dy, int64_t rows, bool relu, float *dx,
+           bool accumulate = true) {
   if (c.dry || rows == 0) return 0;
   const int ldy = pad16(f.ref.n_out);
   int rc = 0;
@@ -292,7 +387,7 @@ int fc_bwd(Ctx &c, Saved &sv, const FcDev &f, const float *x, int64_t ldx,
     rc = pgnn_relu_mask_mul(dy, y, rows * ldy, c.stream);
     if (rc) return rc;
   }
-  rc = fc_wgrad(c, sv, f, x, ldx, dy, ldy, rows);
+  rc = fc_wgrad(c, sv, f, x, ldx, dy, ldy, rows, accumulate);
   if (rc) return rc;
   if (dx) rc = fc_dx(c, f, dy, ldy, rows, dx);
   return rc;
@@ -323,6 +418,8 @@ size_t scratch_need(const Trainer &t, const pgnn_train_batch &b) {
   const int64_t K = b.n_vertices[b.n_levels];
   for (const FcDev &f : t.cls) wg(f, K);
   for (const FcDev &f : t.loc) wg(f, K);
+  for (const HeadGroup &g : t.groups)
+    for (int i = 0; i < 3; ++i) wg(g.f[i], K);
   return need;
 }
 
@@ -471,6 +568,51 @@ int forward_impl(Ctx &c, Saved &sv) {
   const int64_t K = b.n_vertices[b.n_levels];
   const int nc = t.m.num_classes, L = t.m.box_len;
   HeadsSaved &hs = sv.heads;
+  sv.h_final = h;
+  sv.ld_h_final = ld_h;
+  sv.k_final = K;
+  PGNN_REQUIRE(c.dry || (h != nullptr && k_h == K), PGNN_E_INVALID,
+               "trainer: heads need the last level's vertex features");
+  if (!t.groups.empty()) {
+    PGNN_REQUIRE(t.groups.size() <= 4, PGNN_E_UNSUPPORTED,
+                 "trainer: too many head groups");
+    for (size_t gi = 0; gi < t.groups.size(); ++gi) {
+      HeadGroup &g = t.groups[gi];
+      hs.y1[gi] = c.ws.f(K, pad16(g.f[0].ref.n_out));
+      hs.y2[gi] = c.ws.f(K, pad16(g.f[1].ref.n_out));
+      hs.y3[gi] = c.ws.f(K, pad16(g.f[2].ref.n_out));
+    }
+    hs.logits = c.ws.f(K, pad16(nc));
+    hs.pred = c.ws.f(K, (int64_t)nc * L);
+    if (!c.dry) {
+      for (size_t gi = 0; gi < t.groups.size(); ++gi) {
+        HeadGroup &g = t.groups[gi];
+        rc = fc_fwd(c, g.f[0], h, ld_h, K, true, nullptr, 0, hs.y1[gi]);
+        if (rc) return rc;
+        rc = fc_fwd_from(c, g.f[1], hs.y1[gi], pad16(g.f[0].ref.n_out), K, g.base,
+                         nullptr, 0, hs.y2[gi]);
+        if (rc) return rc;
+        rc = fc_fwd(c, g.f[2], hs.y2[gi], pad16(g.f[1].ref.n_out), K, false,
+                    nullptr, 0, hs.y3[gi]);
+        if (rc) return rc;
+        if (K > 0) {
+          const int ld3 = pad16(g.f[2].ref.n_out);
+          if (g.has_cls)
+            hipLaunchKernelGGL(block_copy_kernel<false>,
+                               dim3(blocks_for(K * pad16(nc))), dim3(256), 0,
+                               c.stream, hs.logits, (int64_t)pad16(nc), 0,
+                               hs.y3[gi], (int64_t)ld3, 0, K, pad16(nc));
+          for (size_t i = 0; i < g.lids.size(); ++i)
+            hipLaunchKernelGGL(pred_slice_kernel, dim3(blocks_for(K * L)),
+                               dim3(256), 0, c.stream,
+                               hs.y3[gi] + g.base + 8 * (int)i, (int64_t)ld3, K, L,
+                               nc, g.lids[i], hs.pred);
+        }
+      }
+      PGNN_HIP(hipGetLastError());
+    }
+    return 0;
+  }
   hs.c1 = c.ws.f(K, pad16(t.cls[0].ref.n_out));
   hs.logits = c.ws.f(K, pad16(nc));
   for (int j = 0; j < nc; ++j) {
@@ -479,12 +621,7 @@ int forward_impl(Ctx &c, Saved &sv) {
     hs.l3[j] = c.ws.f(K, pad16(L));
   }
   hs.pred = c.ws.f(K, (int64_t)nc * L);
-  sv.h_final = h;
-  sv.ld_h_final = ld_h;
-  sv.k_final = K;
   if (!c.dry) {
-    PGNN_REQUIRE(h != nullptr && k_h == K, PGNN_E_INVALID,
-                 "trainer: heads need the last level's vertex features");
     rc = fc_fwd(c, t.cls[0], h, ld_h, K, true, nullptr, 0, hs.c1);
     if (rc) return rc;
     rc = fc_fwd(c, t.cls[1], hs.c1, pad16(t.cls[0].ref.n_out), K, false, nullptr,
@@ -510,6 +647,41 @@ int forward_impl(Ctx &c, Saved &sv) {
   return 0;
 }
 
+// dy3 of a fused group: [dlogits | 0.. | dpred of the group's box heads | 0..]
+__global__ void fused_dy3_kernel(const float *__restrict__ dlogits,
+                                 const float *__restrict__ dpred, int64_t rows,
+                                 int nc, int L, int has_cls, int base, int n_loc,
+                                 int lid0, float *__restrict__ dy, int ld) {
+  const int64_t total = rows * ld;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = idx / ld;
+    const int k = (int)(idx - r * ld);
+    float v = 0.0f;
+    if (has_cls && k < nc) {
+      v = dlogits[r * nc + k];
+    } else if (k >= base && k < base + 8 * n_loc) {
+      const int i = (k - base) >> 3, q = (k - base) & 7;
+      if (q < L) v = dpred[(r * nc + lid0 + i) * L + q];
+    }
+    dy[idx] = v;
+  }
+}
+
+// dy[r, c] = 0 where y[r, c] <= 0, for columns c0 <= c < c1 only
+__global__ void relu_mask_cols_kernel(float *__restrict__ dy,
+                                      const float *__restrict__ y, int64_t rows,
+                                      int ld, int c0, int c1) {
+  const int w = c1 - c0;
+  const int64_t total = rows * w;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = idx / w;
+    const int c = c0 + (int)(idx - r * w);
+    if (!(y[r * ld + c] > 0.0f)) dy[r * ld + c] = 0.0f;
+  }
+}
+
 // ---- backward --------------------------------------------------------------------------
 int backward_impl(Ctx &c, Saved &sv, const float *dlogits, const float *dpred) {
   Trainer &t = c.t;
@@ -521,14 +693,59 @@ int backward_impl(Ctx &c, Saved &sv, const float *dlogits, const float *dpred) {
   int rc = 0;
   // gradient w.r.t. the current stage output; two buffers alternate
   float *dh = c.ws.f(K, hw), *dh2 = c.ws.f(K, hw);
+  float *dxh = c.ws.f(K, hw);
+  const int cw = t.cls[0].ref.k_in;
+  if (!t.groups.empty()) {
+    // fused heads: three layers per group
+    int w1 = 16, w2 = 16, w3 = 16;
+    for (const HeadGroup &g : t.groups) {
+      w1 = pad16(g.f[0].ref.n_out) > w1 ? pad16(g.f[0].ref.n_out) : w1;
+      w2 = pad16(g.f[1].ref.n_out) > w2 ? pad16(g.f[1].ref.n_out) : w2;
+      w3 = pad16(g.f[2].ref.n_out) > w3 ? pad16(g.f[2].ref.n_out) : w3;
+    }
+    float *dy3 = c.ws.f(K, w3), *dy2 = c.ws.f(K, w2), *dy1 = c.ws.f(K, w1);
+    if (!c.dry && K > 0) {
+      for (size_t gi = 0; gi < t.groups.size(); ++gi) {
+        HeadGroup &g = t.groups[gi];
+        const int ld1 = pad16(g.f[0].ref.n_out), ld2 = pad16(g.f[1].ref.n_out),
+                  ld3 = pad16(g.f[2].ref.n_out);
+        hipLaunchKernelGGL(fused_dy3_kernel, dim3(blocks_for(K * ld3)), dim3(256),
+                           0, c.stream, dlogits, dpred, K, nc, L,
+                           g.has_cls ? 1 : 0, g.base, (int)g.lids.size(),
+                           g.lids.empty() ? 0 : g.lids[0], dy3, ld3);
+        // the fused gradients are overwritten (accumulate = false) and handed
+        // to the flat buffer by the unpack jobs at the end
+        rc = fc_bwd(c, sv, g.f[2], sv.heads.y2[gi], ld2, nullptr, dy3, K, false,
+                    dy2, false);
+        if (rc) return rc;
+        // second layer: ReLU on the box-head columns only (logits are linear)
+        if (g.f[1].ref.n_out > g.base)
+          hipLaunchKernelGGL(relu_mask_cols_kernel,
+                             dim3(blocks_for(K * (g.f[1].ref.n_out - g.base))),
+                             dim3(256), 0, c.stream, dy2, sv.heads.y2[gi], K, ld2,
+                             g.base, g.f[1].ref.n_out);
+        rc = fc_bwd(c, sv, g.f[1], sv.heads.y1[gi], ld1, nullptr, dy2, K, false,
+                    dy1, false);
+        if (rc) return rc;
+        rc = fc_bwd(c, sv, g.f[0], sv.h_final, hw, sv.heads.y1[gi], dy1, K, true,
+                    gi == 0 ? dh : dxh, false);
+        if (rc) return rc;
+        if (gi > 0)
+          hipLaunchKernelGGL(block_copy_kernel<true>, dim3(blocks_for(K * cw)),
+                             dim3(256), 0, c.stream, dh, (int64_t)hw, 0, dxh,
+                             (int64_t)pad16(cw), 0, K, cw);
+      }
+      rc = pgnn_pack_fc_many(t.images + t.off_jobs_u, t.n_jobs_u, t.total_blocks_u,
+                             c.stream);
+      if (rc) return rc;
+    }
+  } else {
   const int w64 = pad16(t.cls[0].ref.n_out);
   int wh = w64;  // widest hidden layer of the heads
   for (const FcDev &f : t.loc)
     if (pad16(f.ref.n_out) > wh) wh = pad16(f.ref.n_out);
   float *dy = c.ws.f(K, pad16(nc > L ? nc : L));
   float *d1 = c.ws.f(K, wh), *d2 = c.ws.f(K, wh);
-  float *dxh = c.ws.f(K, hw);
-  const int cw = t.cls[0].ref.k_in;
   if (!c.dry && K > 0) {
     PGNN_HIP(hipMemsetAsync(dh, 0, (size_t)K * hw * 4, c.stream));
     // class head
@@ -560,6 +777,7 @@ int backward_impl(Ctx &c, Saved &sv, const float *dlogits, const float *dpred) {
                          (int64_t)pad16(cw), 0, K, cw);
     }
   }
+  }
   // stages in reverse
   for (int si = (int)t.stages.size() - 1; si >= 0; --si) {
     StageDev &s = t.stages[si];
@@ -577,9 +795,10 @@ int backward_impl(Ctx &c, Saved &sv, const float *dlogits, const float *dpred) {
       float *du[PGNN_TRAIN_MAX_FC + 1];
       for (size_t i = 0; i < s.b.size(); ++i)
         du[i] = c.ws.f(Ks, pad16(s.b[i].ref.k_in));
-      float *ge[PGNN_TRAIN_MAX_FC];
-      for (size_t i = 0; i + 1 < s.a.size(); ++i)
-        ge[i] = c.ws.f(E, pad16(s.a[i + 1].ref.k_in));  // grad w.r.t. eact[i]
+      float *ge[PGNN_TRAIN_MAX_FC] = {nullptr};
+      if (!(s.a.back().want_wt && s.a.size() == 2))
+        for (size_t i = 0; i + 1 < s.a.size(); ++i)
+          ge[i] = c.ws.f(E, pad16(s.a[i + 1].ref.k_in));  // grad w.r.t. eact[i]
       float *gz = nullptr;  // dense fallback: grad w.r.t. the last edge layer
       if (!s.a.back().want_wt) gz = c.ws.f(E, wa);
       int32_t *ties = nullptr;
@@ -608,14 +827,26 @@ int backward_impl(Ctx &c, Saved &sv, const float *dlogits, const float *dpred) {
         const int na = (int)s.a.size();
         float *gcur = nullptr;  // grad w.r.t. eact[i], ReLU-masked
         int from;
-        if (s.a.back().want_wt) {
+        bool scattered = false;
+        if (s.a.back().want_wt && na == 2) {
+          // last edge layer + scatter-max + the gather's adjoint in one
+          // routing pass: dP / dQ directly, dH1 is never written
+          rc = pgnn_edge_segmax_fc_bwd_f32(
+              g.eact[1], wa, b.edges[lvl], g.dst, E, s.a[1].ref.n_out,
+              (int32_t)Ks, g.agg, wa, dagg, wa, g.eact[0], wq, s.a[1].ref.k_in,
+              s.a[1].wt, pad16(s.a[1].ref.k_in), dp, dq, wq, s.a[1].gw,
+              s.a[1].gb, sv.scratch, sv.scratch_bytes, c.stream);
+          if (rc) return rc;
+          scattered = true;
+          from = 0;
+        } else if (s.a.back().want_wt) {
           rc = pgnn_segmax_fc_bwd_f32(
               g.eact[na - 1], wa, g.dst, E, s.a.back().ref.n_out, (int32_t)Ks,
               g.agg, wa, dagg, wa, g.eact[na - 2], pad16(s.a.back().ref.k_in),
               s.a.back().ref.k_in, s.a.back().wt, pad16(s.a.back().ref.k_in),
               ge[na - 2], pad16(s.a.back().ref.k_in), pad16(s.a.back().ref.k_in),
-              1, t.grads + s.a.back().ref.w_off, t.grads + s.a.back().ref.b_off,
-              sv.scratch, sv.scratch_bytes, c.stream);
+              1, s.a.back().gw, s.a.back().gb, sv.scratch, sv.scratch_bytes,
+              c.stream);
           if (rc) return rc;
           gcur = ge[na - 2];
           from = na - 2;
@@ -636,8 +867,11 @@ int backward_impl(Ctx &c, Saved &sv, const float *dlogits, const float *dpred) {
           if (rc) return rc;
           gcur = ge[i - 1];
         }
-        rc = pgnn_edge_hidden_bwd(gcur, wq, b.edges[lvl], E, Ks, dp, dq, c.stream);
-        if (rc) return rc;
+        if (!scattered) {
+          rc = pgnn_edge_hidden_bwd(gcur, wq, b.edges[lvl], E, Ks, dp, dq,
+                                    c.stream);
+          if (rc) return rc;
+        }
         // P = [h, x] W1 + b1
         rc = fc_bwd(c, sv, w1, g.hx, pad16(cc + 3), nullptr, dp, Ks, false, dhx);
         if (rc) return rc;
@@ -646,8 +880,8 @@ int backward_impl(Ctx &c, Saved &sv, const float *dlogits, const float *dpred) {
                            (int64_t)pad16(cc + 3), 0, Ks, cc);
         // Q = x' Wx, Wx = rows cc..cc+2 of W1 (the minus sign is in dq)
         rc = pgnn_weight_grad_f32(g.xo, 3, 3, dq, wq, w1.ref.n_out, Ks,
-                                  t.grads + w1.ref.w_off + (int64_t)cc * w1.ref.n_out,
-                                  nullptr, 1, sv.scratch, sv.scratch_bytes,
+                                  w1.gw + (int64_t)cc * w1.ref.n_out, nullptr, 1,
+                                  sv.scratch, sv.scratch_bytes,
                                   c.stream);
         if (rc) return rc;
         if (!s.c.empty()) {
@@ -709,8 +943,8 @@ int backward_impl(Ctx &c, Saved &sv, const float *dlogits, const float *dpred) {
               p.agg, wa, d, wa, p.act[na - 2], pad16(s.a.back().ref.k_in),
               s.a.back().ref.k_in, s.a.back().wt, pad16(s.a.back().ref.k_in),
               ga[na - 2], pad16(s.a.back().ref.k_in), pad16(s.a.back().ref.k_in),
-              1, t.grads + s.a.back().ref.w_off, t.grads + s.a.back().ref.b_off,
-              sv.scratch, sv.scratch_bytes, c.stream);
+              1, s.a.back().gw, s.a.back().gb, sv.scratch, sv.scratch_bytes,
+              c.stream);
           if (rc) return rc;
           gcur = ga[na - 2];
           from = na - 2;
@@ -800,6 +1034,7 @@ extern "C" int pgnn_trainer_create(const pgnn_train_model *m, void **handle) {
     delete t;
     return rc;
   }
+  if (!plan_head_groups(*t)) t->groups.clear();  // heads one by one
   t->images_bytes = layout_images(*t);
   *handle = t;
   return 0;
@@ -829,10 +1064,11 @@ extern "C" int pgnn_trainer_bind(void *handle, float *params, float *grads,
   t->params = params;
   t->grads = grads;
   t->images = (char *)images;
-  std::vector<PackJobRec> jobs;
-  int first = 0;
-  auto add = [&](const float *w, const float *b, float *dst, int k_in, int n_out,
-                 int kind, size_t elems) {
+  hipStream_t stream = (hipStream_t)stream_;
+  std::vector<PackJobRec> jobs, jobs_a, jobs_u;
+  auto add_to = [](std::vector<PackJobRec> &v, int &first, const float *w,
+                   const float *b, float *dst, int k_in, int n_out, int kind,
+                   size_t elems, int ld) {
     PackJobRec j;
     j.w = w;
     j.b = b;
@@ -841,22 +1077,38 @@ extern "C" int pgnn_trainer_bind(void *handle, float *params, float *grads,
     j.n_out = n_out;
     j.kind = kind;
     j.first_block = first;
+    j.ld = ld;
+    j.reserved = 0;
     first += (int)((elems + 255) / 256);
-    jobs.push_back(j);
+    v.push_back(j);
   };
-  auto bind_fc = [&](FcDev &f) {
+  int first = 0, first_a = 0, first_u = 0;
+  auto add = [&](const float *w, const float *b, float *dst, int k_in, int n_out,
+                 int kind, size_t elems) {
+    add_to(jobs, first, w, b, dst, k_in, n_out, kind, elems, 0);
+  };
+  auto images_of = [&](FcDev &f) {  // f.w / f.b are set
     f.packed = (float *)(t->images + f.off_packed);
     f.packed_t = (float *)(t->images + f.off_packed_t);
-    const float *w = params + f.ref.w_off, *bb = params + f.ref.b_off;
-    add(w, bb, f.packed, f.ref.k_in, f.ref.n_out, 0,
+    add(f.w, f.b, f.packed, f.ref.k_in, f.ref.n_out, 0,
         packed_floats(f.ref.k_in, f.ref.n_out));
-    add(w, nullptr, f.packed_t, f.ref.k_in, f.ref.n_out, 1,
+    add(f.w, nullptr, f.packed_t, f.ref.k_in, f.ref.n_out, 1,
         packed_floats(f.ref.n_out, f.ref.k_in));
     if (f.want_wt) {
       f.wt = (float *)(t->images + f.off_wt);
-      add(w, nullptr, f.wt, f.ref.k_in, f.ref.n_out, 2,
+      add(f.w, nullptr, f.wt, f.ref.k_in, f.ref.n_out, 2,
           (size_t)f.ref.n_out * pad16(f.ref.k_in));
     }
+  };
+  auto bind_flat = [&](FcDev &f) {
+    f.w = params + f.ref.w_off;
+    f.b = params + f.ref.b_off;
+    f.gw = grads + f.ref.w_off;
+    f.gb = grads + f.ref.b_off;
+  };
+  auto bind_fc = [&](FcDev &f) {
+    bind_flat(f);
+    images_of(f);
   };
   for (StageDev &s : t->stages) {
     for (FcDev &f : s.a) bind_fc(f);
@@ -865,25 +1117,102 @@ extern "C" int pgnn_trainer_bind(void *handle, float *params, float *grads,
     if (s.kind == 1) {
       const FcDev &w1 = s.a[0];
       const int cc = w1.ref.k_in - 3, n_out = w1.ref.n_out;
-      const float *wx = params + w1.ref.w_off + (int64_t)cc * n_out;
+      const float *wx = w1.w + (int64_t)cc * n_out;
       s.wx = (float *)(t->images + s.off_wx);
       s.wx_packed_t = (float *)(t->images + s.off_wx_packed_t);
       add(wx, nullptr, s.wx, 3, n_out, 3, (size_t)3 * pad16(n_out));
       add(wx, nullptr, s.wx_packed_t, 3, n_out, 1, packed_floats(n_out, 3));
     }
   }
-  for (FcDev &f : t->cls) bind_fc(f);
-  for (FcDev &f : t->loc) bind_fc(f);
-  PGNN_REQUIRE((int)jobs.size() == t->n_jobs, PGNN_E_INVALID,
-               "trainer_bind: job count mismatch");
+  for (FcDev &f : t->cls) bind_flat(f);
+  for (FcDev &f : t->loc) bind_flat(f);
+  if (t->groups.empty()) {
+    for (FcDev &f : t->cls) images_of(f);
+    for (FcDev &f : t->loc) images_of(f);
+  } else {
+    // fused matrices: zero once (the blocks outside the parameter blocks
+    // stay zero for good), identity pass-through of the logits once
+    PGNN_HIP(hipMemsetAsync(t->images + t->fused_lo, 0, t->fused_hi - t->fused_lo,
+                            stream));
+    std::vector<PackJobRec> once;
+    int first_o = 0;
+    const int nc = t->m.num_classes, L = t->m.box_len;
+    const int hw = t->cls[0].ref.n_out;
+    for (HeadGroup &g : t->groups) {
+      for (int i = 0; i < 3; ++i) {
+        g.f[i].w = (float *)(t->images + g.off_w[i]);
+        g.f[i].b = (float *)(t->images + g.off_b[i]);
+        g.f[i].gw = (float *)(t->images + g.off_gw[i]);
+        g.f[i].gb = (float *)(t->images + g.off_gb[i]);
+      }
+      const int n1 = g.f[0].ref.n_out, n2 = g.f[1].ref.n_out, n3 = g.f[2].ref.n_out;
+      // one parameter block <-> its place in a fused matrix (and back for the
+      // gradient): rows x cols at (r0, c0) of a matrix with row stride ld
+      auto block = [&](const FcDev &src, int layer, int r0, int c0) {
+        const FcDev &dst = g.f[layer];
+        const int ld = dst.ref.n_out;
+        const int rows = src.ref.k_in, cols = src.ref.n_out;
+        add_to(jobs_a, first_a, src.w, nullptr, dst.w + (int64_t)r0 * ld + c0, rows,
+               cols, 4, (size_t)rows * cols, ld);
+        add_to(jobs_a, first_a, src.b, nullptr, dst.b + c0, 1, cols, 4, (size_t)cols,
+               ld);
+        add_to(jobs_u, first_u, dst.gw + (int64_t)r0 * ld + c0, nullptr, src.gw, rows,
+               cols, 5, (size_t)rows * cols, ld);
+        add_to(jobs_u, first_u, dst.gb + c0, nullptr, src.gb, 1, cols, 5,
+               (size_t)cols, ld);
+      };
+      int slot = 0;
+      if (g.has_cls) {
+        block(t->cls[0], 0, 0, 0);
+        block(t->cls[1], 1, 0, 0);
+        // logits ride through the third layer
+        add_to(once, first_o, nullptr, nullptr, g.f[2].w, nc, nc, 6, (size_t)nc, n3);
+        slot = 1;
+      }
+      for (size_t i = 0; i < g.lids.size(); ++i) {
+        const int j = g.lids[i], sl = slot + (int)i;
+        block(t->loc[3 * j], 0, 0, hw * sl);
+        block(t->loc[3 * j + 1], 1, hw * sl, g.base + hw * (int)i);
+        block(t->loc[3 * j + 2], 2, g.base + hw * (int)i, g.base + 8 * (int)i);
+      }
+      (void)n1;
+      (void)n2;
+      (void)L;
+      for (int i = 0; i < 3; ++i) images_of(g.f[i]);
+    }
+    if (!once.empty()) {
+      // run the one-off jobs from the (not yet used) assemble table slot
+      PGNN_REQUIRE(once.size() <= (size_t)t->n_jobs_a + 1, PGNN_E_INVALID,
+                   "trainer_bind: one-off job table too large");
+      PGNN_HIP(hipMemcpyAsync(t->images + t->off_jobs_a, once.data(),
+                              once.size() * sizeof(PackJobRec),
+                              hipMemcpyHostToDevice, stream));
+      PGNN_HIP(hipStreamSynchronize(stream));
+      int rc1 = pgnn_pack_fc_many(t->images + t->off_jobs_a, (int)once.size(),
+                                  first_o, stream_);
+      if (rc1) return rc1;
+      PGNN_HIP(hipStreamSynchronize(stream));
+    }
+  }
+  PGNN_REQUIRE((int)jobs.size() == t->n_jobs && (int)jobs_a.size() == t->n_jobs_a &&
+                   (int)jobs_u.size() == t->n_jobs_u,
+               PGNN_E_INVALID, "trainer_bind: job count mismatch");
   t->total_blocks = first;
-  hipStream_t stream = (hipStream_t)stream_;
+  t->total_blocks_a = first_a;
+  t->total_blocks_u = first_u;
   PGNN_HIP(hipMemcpyAsync(t->images + t->off_jobs, jobs.data(),
                           jobs.size() * sizeof(PackJobRec), hipMemcpyHostToDevice,
                           stream));
-  PGNN_HIP(hipStreamSynchronize(stream));  // `jobs` is a host temporary
-  return pgnn_pack_fc_many(t->images + t->off_jobs, t->n_jobs, t->total_blocks,
-                           stream_);
+  if (!jobs_a.empty()) {
+    PGNN_HIP(hipMemcpyAsync(t->images + t->off_jobs_a, jobs_a.data(),
+                            jobs_a.size() * sizeof(PackJobRec),
+                            hipMemcpyHostToDevice, stream));
+    PGNN_HIP(hipMemcpyAsync(t->images + t->off_jobs_u, jobs_u.data(),
+                            jobs_u.size() * sizeof(PackJobRec),
+                            hipMemcpyHostToDevice, stream));
+  }
+  PGNN_HIP(hipStreamSynchronize(stream));  // the tables are host temporaries
+  return pgnn_trainer_repack(handle, stream_);
   PGNN_GUARD_END
 }
 
@@ -891,6 +1220,11 @@ extern "C" int pgnn_trainer_repack(void *handle, void *stream_) {
   PGNN_GUARD_BEGIN
   Trainer *t = (Trainer *)handle;
   PGNN_REQUIRE(t && t->images, PGNN_E_INVALID, "trainer_repack: not bound");
+  if (t->n_jobs_a > 0) {  // fused head matrices from their parameter blocks
+    int rc = pgnn_pack_fc_many(t->images + t->off_jobs_a, t->n_jobs_a,
+                               t->total_blocks_a, stream_);
+    if (rc) return rc;
+  }
   return pgnn_pack_fc_many(t->images + t->off_jobs, t->n_jobs, t->total_blocks,
                            stream_);
   PGNN_GUARD_END
