@@ -297,6 +297,23 @@ int pgnn_edge_mlp_scatter_max_fwd(const float *P, const float *Q,
                                   float *out, int64_t ld_out, int32_t *sched_ws,
                                   void *stream);
 
+/* Training forward of the same stage with ONE remaining edge layer: the fused
+ * kernel also writes that layer's per-edge output rows [n_edges, ld_rows]
+ * (the backward compares them with `out` to find the arg-max rows; rows and
+ * maxima come from the same accumulators, so the winner reproduces `out` bit
+ * for bit).  Returns PGNN_E_UNSUPPORTED -- having done nothing -- when the
+ * weights-stationary kernel does not apply (fewer than ~65k edges, layer
+ * shapes other than 300x300 / 256x256): the caller then runs
+ * pgnn_edge_hidden_fwd + pgnn_mlp_fwd + pgnn_scatter_max_f32.               */
+int pgnn_edge_mlp_scatter_max_rows_fwd(const float *P, const float *Q,
+                                       int64_t ld_pq, int32_t width,
+                                       const int32_t *edges, int64_t n_edges,
+                                       int32_t num_vertices,
+                                       const pgnn_fc_layer *layer_host,
+                                       int32_t edges_sorted, float *out,
+                                       int64_t ld_out, float *rows_out,
+                                       int64_t ld_rows, void *stream);
+
 /* x' = x + delta (gnn.py:346) and Q = x' @ Wx where Wx = the last 3 rows of
  * the first edge layer's weights (the rows that multiply the coordinate part
  * of the concat, gnn.py:350-352).  wx: device [3, ld_q] (zero padded).      */
@@ -411,14 +428,18 @@ int pgnn_segmax_fc_bwd_f32(const float *Y, int64_t ld_y,
  * straight into dP[src] += g, dQ[dst] -= g (both [num_vertices, ld_pq], zeroed
  * by the call: pgnn_edge_hidden_bwd's outputs) and dH1 is never written.
  * edges [n_edges, 2] = (src, dst) grouped by dst for the in-register dQ runs
- * (any order is correct); dst_ids = its dst column, contiguous.            */
+ * (any order is correct); dst_ids = its dst column, contiguous.  H1 may be
+ * NULL (the fused training forward pgnn_edge_mlp_scatter_max_rows_fwd never
+ * writes it): its rows are then recomputed from P and Q [num_vertices,
+ * ld_pq] as ReLU(P[src] - Q[dst]).                                          */
 int pgnn_edge_segmax_fc_bwd_f32(const float *Y, int64_t ld_y,
                                 const int32_t *edges, const int32_t *dst_ids,
                                 int64_t n_edges, int32_t n_cols,
                                 int32_t num_vertices, const float *out,
                                 int64_t ld_out, const float *grad_out,
                                 int64_t ld_go, const float *H1, int64_t ld_h1,
-                                int32_t k_in, const float *WT, int64_t ld_wt,
+                                const float *P, const float *Q, int32_t k_in,
+                                const float *WT, int64_t ld_wt,
                                 float *dP, float *dQ, int64_t ld_pq, float *dW,
                                 float *db, void *workspace,
                                 size_t workspace_bytes, void *stream);

@@ -129,6 +129,11 @@ _SIGNATURES = {
                                               ctypes.POINTER(FcLayer), c_i32,
                                               c_i32, c_vp, c_i64, c_vp,
                                               c_vp]),
+    "pgnn_edge_mlp_scatter_max_rows_fwd": (c_i32, [c_vp, c_vp, c_i64, c_i32,
+                                                   c_vp, c_i64, c_i32,
+                                                   ctypes.POINTER(FcLayer),
+                                                   c_i32, c_vp, c_i64, c_vp,
+                                                   c_i64, c_vp]),
     "pgnn_offset_apply": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp,
                                   c_i64, c_vp]),
     "pgnn_vertex_pre_edge_fwd": (c_i32, [c_vp, c_i64, c_i32, c_vp,
@@ -143,9 +148,10 @@ _SIGNATURES = {
     "pgnn_segmax_fc_bwd_workspace_bytes": (c_sz, [c_i64, c_i32, c_i32, c_i32]),
     "pgnn_edge_segmax_fc_bwd_f32": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64,
                                             c_i32, c_i32, c_vp, c_i64, c_vp,
-                                            c_i64, c_vp, c_i64, c_i32, c_vp,
-                                            c_i64, c_vp, c_vp, c_i64, c_vp,
-                                            c_vp, c_vp, c_sz, c_vp]),
+                                            c_i64, c_vp, c_i64, c_vp, c_vp,
+                                            c_i32, c_vp, c_i64, c_vp, c_vp,
+                                            c_i64, c_vp, c_vp, c_vp, c_sz,
+                                            c_vp]),
     "pgnn_segmax_fc_bwd_f32": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_i32,
                                        c_vp, c_i64, c_vp, c_i64, c_vp, c_i64,
                                        c_i32, c_vp, c_i64, c_vp, c_i64, c_i32,

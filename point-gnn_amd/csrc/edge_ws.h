@@ -82,6 +82,11 @@ struct EdgeWsArgs {
   int groups;                        // column groups
   int tile0[kWsMaxGroups + 1];       // group g owns column tiles [tile0[g], tile0[g+1])
   int wg0[kWsMaxGroups + 1];         // ... and local workgroups [wg0[g], wg0[g+1]) of a slice
+  // training forward (EMIT kernels only): the layer's per-edge output rows
+  // act(h W + b) are ALSO written, [n_edges, ld_rows] -- the backward finds the
+  // arg-max rows by comparing them with `out`
+  float *rows_out;
+  int64_t ld_rows;
 };
 
 // max(a, b) as ONE instruction: fmaxf() first canonicalises operands the
@@ -266,7 +271,7 @@ __device__ __forceinline__ void ws_epilogue(const ARGS &a, const float *bias_lds
 
 // tiles [tile_first, tile_last) of 16 edge rows, column tiles t0 .. t0+NTG-1
 // whose fragments sit in `wl` ([KQ][NTG][64] float4)
-template <int KQ, int NTG>
+template <int KQ, int NTG, bool EMIT>
 __device__ __forceinline__ void edge_ws_body(const EdgeWsArgs &a,
                                              const v4f *__restrict__ wl, int t0,
                                              const float *bias_lds,
@@ -456,6 +461,28 @@ __device__ __forceinline__ void edge_ws_body(const EdgeWsArgs &a,
       if (lane == 0) tst[2] = c;
       __builtin_amdgcn_sched_barrier(0);
     }
+    if constexpr (EMIT) {
+      // the rows themselves (training): the same accumulators the maxima are
+      // taken from, the same bias add and ReLU as in ws_flush -- the row that
+      // holds a segment's maximum reproduces `out` bit for bit.  Lane (g, n)
+      // holds features 16 t + 4 g .. + 3 of row n: one 16-byte store per tile.
+      const int64_t row = e0 + n;
+      if (row < E) {
+        float *dstp = a.rows_out + row * a.ld_rows + 16 * t0 + 4 * g;
+#pragma unroll
+        for (int t = 0; t < NTG; ++t) {
+          const v4f bb = *reinterpret_cast<const v4f *>(bias_lds + 16 * t + 4 * g);
+          v4f y;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float x = acc[t][r] + bb[r];
+            if (16 * (t0 + t) + 4 * g + r >= a.relu_from) x = x > 0.0f ? x : 0.0f;
+            y[r] = x;
+          }
+          *reinterpret_cast<v4f *>(dstp + 16 * t) = y;
+        }
+      }
+    }
     // ---- segmented max over the 16 rows ------------------------------------
     if (a.prio) __builtin_amdgcn_s_setprio(3);
     // bit r of `starts`: row r does not continue the run of the edge before it
@@ -480,7 +507,7 @@ __device__ __forceinline__ void edge_ws_body(const EdgeWsArgs &a,
 }
 
 
-template <int KQ, int NTMAX>
+template <int KQ, int NTMAX, bool EMIT = false>
 __global__ __launch_bounds__(64 * kWsWaves) void edge_ws_kernel(EdgeWsArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   v4f *wl = reinterpret_cast<v4f *>(smem);
@@ -539,11 +566,11 @@ __global__ __launch_bounds__(64 * kWsWaves) void edge_ws_kernel(EdgeWsArgs a) {
   int32_t *counter = a.sched ? a.sched + 2 + slice * kWsMaxGroups + grp : nullptr;
   for (;;) {
     if (ntg == NTMAX)
-      edge_ws_body<KQ, NTMAX>(a, wl, t0, bias_lds, tile_first, tile_last, lane,
-                              tsw, stamped);
+      edge_ws_body<KQ, NTMAX, EMIT>(a, wl, t0, bias_lds, tile_first, tile_last,
+                                    lane, tsw, stamped);
     else
-      edge_ws_body<KQ, NTMAX - 1>(a, wl, t0, bias_lds, tile_first, tile_last,
-                                  lane, tsw, stamped);
+      edge_ws_body<KQ, NTMAX - 1, EMIT>(a, wl, t0, bias_lds, tile_first,
+                                        tile_last, lane, tsw, stamped);
     if (pool == 0) break;
     int c = 0;
     if (lane == 0)

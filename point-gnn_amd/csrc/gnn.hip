@@ -861,8 +861,11 @@ int launch_rows8(const Plan &p, int64_t n_rows, const RowsArgs &ra,
 template <int KQ, int NTMAX>
 int launch_edge_ws(const LayerDev &L, const EdgeArgs &ea, int64_t n_edges,
                    const SegArgs &sa, int cus, int32_t *sched,
-                   hipStream_t stream) {
+                   hipStream_t stream, float *rows_out = nullptr,
+                   int64_t ld_rows = 0) {
   EdgeWsArgs a = {};
+  a.rows_out = rows_out;
+  a.ld_rows = ld_rows;
   a.P = ea.P;
   a.Q = ea.Q;
   a.ldv4 = (int)(ea.ldpq >> 2);
@@ -913,6 +916,15 @@ int launch_edge_ws(const LayerDev &L, const EdgeArgs &ea, int64_t n_edges,
   a.wg0[0] = 0;
   for (int g = 0; g < a.groups; ++g) a.wg0[g + 1] = a.wg0[g] + cnt[g];
   const size_t lds = (size_t)KQ * NTMAX * 1024 + 16 * NTMAX * sizeof(float);
+  if (rows_out) {  // training forward: the rows are written as well
+    auto kern = edge_ws_kernel<KQ, NTMAX, true>;
+    const int lrc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
+    if (lrc) return lrc;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(per_slice * a.xcds)),
+                       dim3(64 * kWsWaves), lds, stream, a);
+    PGNN_HIP(hipGetLastError());
+    return 0;
+  }
   auto kern = edge_ws_kernel<KQ, NTMAX>;
   {
     const int lrc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
@@ -1304,6 +1316,49 @@ extern "C" int pgnn_vertex_pre_edge_fwd(
                      dim3(64 * kRowsWaves), lds, stream, off, pl, a);
   PGNN_HIP(hipGetLastError());
   return 0;
+  PGNN_GUARD_END
+}
+
+// Training forward of the edge stage: pgnn_edge_mlp_scatter_max_fwd that also
+// writes the per-edge output rows (one fused kernel instead of materialising
+// H1, a rows GEMM and a standalone scatter-max).  Only the weights-stationary
+// kernel has the form; when it does not apply (few edges, other layer shapes)
+// the call returns PGNN_E_UNSUPPORTED and changes nothing: the caller runs
+// the three separate primitives.
+extern "C" int pgnn_edge_mlp_scatter_max_rows_fwd(
+    const float *P, const float *Q, int64_t ld_pq, int32_t width,
+    const int32_t *edges, int64_t n_edges, int32_t num_vertices,
+    const pgnn_fc_layer *layer, int32_t edges_sorted, float *out, int64_t ld_out,
+    float *rows_out, int64_t ld_rows, void *stream_) {
+  PGNN_GUARD_BEGIN
+  hipStream_t stream = (hipStream_t)stream_;
+  PGNN_REQUIRE(n_edges >= 0 && num_vertices >= 0 && width > 0 && layer,
+               PGNN_E_INVALID, "edge_mlp_rows: bad sizes");
+  Plan p;
+  int rc = make_plan(layer, 1, width, p);
+  if (rc) return rc;
+  PGNN_REQUIRE(ld_pq == 16 * p.chain.l[0].kq, PGNN_E_INVALID,
+               "edge_mlp_rows: ld_pq must equal the padded width");
+  const int out_cols = 16 * p.chain.l[0].nt;
+  PGNN_REQUIRE(out && ld_out >= out_cols && rows_out && ld_rows >= out_cols &&
+                   ld_rows % 4 == 0 && (uintptr_t)rows_out % 16 == 0,
+               PGNN_E_INVALID, "edge_mlp_rows: bad output");
+  int cus = stream_cu_count(stream);
+  if (g_ws_reserve > 0 && cus - g_ws_reserve >= 64) cus -= g_ws_reserve;
+  if (n_edges == 0 || num_vertices == 0 || !edge_ws_applies(p, n_edges, cus))
+    return PGNN_E_UNSUPPORTED;  // (no message: an expected answer)
+  PGNN_REQUIRE(P && Q && edges, PGNN_E_INVALID, "edge_mlp_rows: null input");
+  PGNN_REQUIRE(((uintptr_t)P % 16 == 0) && ((uintptr_t)Q % 16 == 0),
+               PGNN_E_INVALID, "edge_mlp_rows: P/Q must be 16-byte aligned");
+  rc = fill_lowest(out, (int64_t)num_vertices * ld_out, stream);
+  if (rc) return rc;
+  EdgeArgs ea = {P, Q, ld_pq, edges};
+  SegArgs sa = {out, ld_out, num_vertices, edges_sorted & 1};
+  if (p.chain.l[0].nt == 19)
+    return launch_edge_ws<19, 7>(p.chain.l[0], ea, n_edges, sa, cus, nullptr,
+                                 stream, rows_out, ld_rows);
+  return launch_edge_ws<16, 8>(p.chain.l[0], ea, n_edges, sa, cus, nullptr, stream,
+                               rows_out, ld_rows);
   PGNN_GUARD_END
 }
 

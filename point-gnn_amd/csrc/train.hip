@@ -430,6 +430,36 @@ __global__ __launch_bounds__(256) void segmax_route_sparse_kernel(
   }
 }
 
+// Where the layer's input rows X come from: a materialised [rows, ldx] matrix,
+// or -- the edge stage after the fused training forward, which never writes
+// H1 -- recomputed as ReLU(P[src] - Q[dst]) from the per-vertex tables.
+struct XSrc {
+  const float *X;
+  int64_t ldx;
+  const float *P, *Q;
+  int64_t ldpq;
+  const int32_t *edges;
+};
+struct XRow {  // row r resolved: x[k] = a[k] - (b ? b[k] : 0), ReLU when b
+  const float *a, *b;
+};
+__device__ __forceinline__ XRow xs_row(const XSrc &x, int64_t r) {
+  XRow o;
+  if (x.X) {
+    o.a = x.X + r * x.ldx;
+    o.b = nullptr;
+  } else {
+    o.a = x.P + (int64_t)x.edges[2 * r] * x.ldpq;
+    o.b = x.Q + (int64_t)x.edges[2 * r + 1] * x.ldpq;
+  }
+  return o;
+}
+__device__ __forceinline__ float xr_at(const XRow &r, int k) {
+  if (!r.b) return r.a[k];
+  const float t = r.a[k] - r.b[k];
+  return t > 0.0f ? t : 0.0f;
+}
+
 // The edge stage's form of the same routing (gnn.py:348-356 adjoint): X = H1
 // = ReLU(P[src] - Q[dst]) feeds the layer, so the routed gradient goes
 // straight to dP[src] += g, dQ[dst] -= g (pgnn_edge_hidden_bwd) and the E x C
@@ -443,9 +473,8 @@ __global__ __launch_bounds__(256) void segmax_route_scatter_kernel(
     const float *__restrict__ data, int64_t ld, const int32_t *__restrict__ edges,
     int64_t rows, int cols, int nseg, const float *__restrict__ out, int64_t ldo,
     const float *__restrict__ gout, int64_t ldg, const int32_t *__restrict__ cnt,
-    int ldc, const float *__restrict__ WT, int64_t ldwt, int k_in,
-    const float *__restrict__ X, int64_t ldx, float *__restrict__ dP,
-    float *__restrict__ dQ, int64_t ldpq) {
+    int ldc, const float *__restrict__ WT, int64_t ldwt, int k_in, XSrc xs,
+    float *__restrict__ dP, float *__restrict__ dQ, int64_t ldpq) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -474,8 +503,19 @@ __global__ __launch_bounds__(256) void segmax_route_scatter_kernel(
         go[j] = gout[(int64_t)s * ldg + cc];
         cn[j] = cnt[(int64_t)s * ldc + cc];
       }
+      {
+        // (src, dst are in hand: resolve the row without xs_row's index loads)
+        XRow xr;
+        if (xs.X) {
+          xr.a = xs.X + r * xs.ldx;
+          xr.b = nullptr;
+        } else {
+          xr.a = xs.P + (int64_t)(s_ok ? src : 0) * xs.ldpq;
+          xr.b = xs.Q + (int64_t)s * xs.ldpq;
+        }
 #pragma unroll
-      for (int i = 0; i < I; ++i) xv[i] = X[r * ldx + kc[i]];
+        for (int i = 0; i < I; ++i) xv[i] = xr_at(xr, kc[i]);
+      }
       float g[J];
 #pragma unroll
       for (int j = 0; j < J; ++j) {
@@ -554,8 +594,8 @@ template <int I /* ceil(kin_p/64) */>
 __global__ __launch_bounds__(64) void segmax_wgrad_gather_kernel(
     const float *__restrict__ gout, int64_t ldg, const int32_t *__restrict__ cnt,
     const int32_t *__restrict__ win, int ldc, int nseg, int seg_per_slice,
-    const float *__restrict__ X, int64_t ldx, int k_in, int kin_p,
-    float *__restrict__ partial, float *__restrict__ partial_b, int cols) {
+    XSrc xs, int k_in, int kin_p, float *__restrict__ partial,
+    float *__restrict__ partial_b, int cols) {
   const int lane = threadIdx.x;
   const int c = blockIdx.x, slice = blockIdx.y;
   const int s0 = slice * seg_per_slice;
@@ -583,11 +623,11 @@ __global__ __launch_bounds__(64) void segmax_wgrad_gather_kernel(
     // rows are independent gathers: four in flight per wave
     for (int l0 = 0; l0 < nl; l0 += 4) {
       float gv[4];
-      const float *xr[4];
+      XRow xr[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         gv[u] = __shfl(g, (l0 + u) & 63);
-        xr[u] = X + (int64_t)__shfl(e, (l0 + u) & 63) * ldx;
+        xr[u] = xs_row(xs, (int64_t)__shfl(e, (l0 + u) & 63));
       }
       float xv[4][I];
 #pragma unroll
@@ -595,8 +635,13 @@ __global__ __launch_bounds__(64) void segmax_wgrad_gather_kernel(
 #pragma unroll
         for (int i = 0; i < I; ++i) {
           const int k = lane + 64 * i;
-          xv[u][i] = (k < k_in) ? xr[u][k] : 0.0f;
+          xv[u][i] = xr_at(xr[u], min(k, k_in - 1));
         }
+#pragma unroll
+      for (int i = 0; i < I; ++i)
+        if (lane + 64 * i >= k_in)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) xv[u][i] = 0.0f;
 #pragma unroll
       for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -641,9 +686,8 @@ __global__ void segmax_wgrad_reduce_kernel(const float *__restrict__ partial,
 __global__ __launch_bounds__(256) void segmax_wgrad_tie_list_kernel(
     const int32_t *__restrict__ tie_count, const int32_t *__restrict__ tie_list,
     int tie_cap, const int32_t *__restrict__ seg, const float *__restrict__ gout,
-    int64_t ldg, const int32_t *__restrict__ cnt, int ldc,
-    const float *__restrict__ X, int64_t ldx, int k_in, int cols,
-    float *__restrict__ dW, float *__restrict__ db) {
+    int64_t ldg, const int32_t *__restrict__ cnt, int ldc, XSrc xs, int k_in,
+    int cols, float *__restrict__ dW, float *__restrict__ db) {
   int n = *tie_count;
   if (n > tie_cap) return;  // overflow: the scan kernel below does them all
   const int lane = threadIdx.x & 63;
@@ -653,8 +697,9 @@ __global__ __launch_bounds__(256) void segmax_wgrad_tie_list_kernel(
     const int r = tie_list[2 * t], c = tie_list[2 * t + 1];
     const int s = seg[r];
     const float g = gout[(int64_t)s * ldg + c] / (float)cnt[(int64_t)s * ldc + c];
+    const XRow xr = xs_row(xs, r);
     for (int k = lane; k < k_in; k += 64)
-      atomicAdd(&dW[(int64_t)k * cols + c], g * X[(int64_t)r * ldx + k]);
+      atomicAdd(&dW[(int64_t)k * cols + c], g * xr_at(xr, k));
     if (db && lane == 0) atomicAdd(&db[c], g);
   }
 }
@@ -667,8 +712,7 @@ __global__ void segmax_wgrad_ties_kernel(
     const int32_t *__restrict__ seg, int64_t rows, int cols, int nseg,
     const float *__restrict__ out, int64_t ldo, const float *__restrict__ gout,
     int64_t ldg, const int32_t *__restrict__ cnt, const int32_t *__restrict__ win,
-    int ldc, const float *__restrict__ X, int64_t ldx, int k_in,
-    float *__restrict__ dW, float *__restrict__ db) {
+    int ldc, XSrc xs, int k_in, float *__restrict__ dW, float *__restrict__ db) {
   if (*tie_count <= tie_cap) return;
   const int64_t total = rows * cols;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -682,8 +726,9 @@ __global__ void segmax_wgrad_ties_kernel(
     const int n = cnt[(int64_t)s * ldc + c];
     if (n <= 1 || win[(int64_t)s * ldc + c] == (int32_t)r) continue;
     const float g = gout[(int64_t)s * ldg + c] / (float)n;
+    const XRow xr = xs_row(xs, r);
     for (int k = 0; k < k_in; ++k)
-      atomicAdd(&dW[(int64_t)k * cols + c], g * X[r * ldx + k]);
+      atomicAdd(&dW[(int64_t)k * cols + c], g * xr_at(xr, k));
     if (db) atomicAdd(&db[c], g);
   }
 }
@@ -1016,7 +1061,9 @@ int segfc_bwd_impl(const float *Y, int64_t ld_y, const int32_t *seg_ids,
                    const float *WT, int64_t ld_wt, float *dX, int64_t ld_dx,
                    int32_t dx_cols, int32_t mask_x, const int32_t *edges,
                    float *dP, float *dQ, int64_t ld_pq, float *dW, float *db,
-                   void *workspace, size_t workspace_bytes, hipStream_t stream) {
+                   void *workspace, size_t workspace_bytes, hipStream_t stream,
+                   const float *P = nullptr, const float *Q = nullptr) {
+  XSrc xs = {X, ld_x, P, Q, ld_pq, edges};
   PGNN_REQUIRE(n_rows >= 0 && n_cols > 0 && n_cols <= 512 && num_segments >= 0 &&
                    k_in > 0 && k_in <= 512,
                PGNN_E_INVALID, "segmax_fc_bwd: bad sizes");
@@ -1027,16 +1074,17 @@ int segfc_bwd_impl(const float *Y, int64_t ld_y, const int32_t *seg_ids,
     PGNN_HIP(hipMemsetAsync(dQ, 0, (size_t)num_segments * ld_pq * 4, stream));
   }
   if (n_rows == 0 || num_segments == 0) return 0;
-  PGNN_REQUIRE(Y && seg_ids && out && grad_out && X && WT && dW, PGNN_E_INVALID,
-               "segmax_fc_bwd: null pointer");
+  PGNN_REQUIRE(Y && seg_ids && out && grad_out && WT && dW &&
+                   (X || (P && Q && edges)),
+               PGNN_E_INVALID, "segmax_fc_bwd: null pointer");
   PGNN_REQUIRE(ld_y % 4 == 0 && ld_out % 4 == 0 && (uintptr_t)Y % 16 == 0 &&
                    (uintptr_t)out % 16 == 0 && ld_y >= (n_cols + 3) / 4 * 4 &&
                    ld_out >= (n_cols + 3) / 4 * 4,
                PGNN_E_INVALID,
                "segmax_fc_bwd: Y / out rows must be 16-byte aligned and padded "
                "to a multiple of 4 columns");
-  PGNN_REQUIRE(ld_x >= k_in && ld_wt >= k_in && ld_go >= n_cols, PGNN_E_INVALID,
-               "segmax_fc_bwd: bad leading dimension");
+  PGNN_REQUIRE((!X || ld_x >= k_in) && ld_wt >= k_in && ld_go >= n_cols,
+               PGNN_E_INVALID, "segmax_fc_bwd: bad leading dimension");
   PGNN_REQUIRE(!dX || (dx_cols > 0 && dx_cols <= 512 && ld_dx >= dx_cols),
                PGNN_E_INVALID, "segmax_fc_bwd: bad dX shape");
   PGNN_REQUIRE(workspace && workspace_bytes >= pgnn_segmax_fc_bwd_workspace_bytes(
@@ -1060,7 +1108,7 @@ int segfc_bwd_impl(const float *Y, int64_t ld_y, const int32_t *seg_ids,
   hipLaunchKernelGGL((segmax_route_scatter_kernel<JV, IV>), dim3(blocks),      \
                      dim3(256), 0, stream, Y, ld_y, edges, n_rows, n_cols,     \
                      num_segments, out, ld_out, grad_out, ld_go, w.cnt, w.ldc,  \
-                     WT, ld_wt, k_in, X, ld_x, dP, dQ, ld_pq)
+                     WT, ld_wt, k_in, xs, dP, dQ, ld_pq)
     if (J == 5 && I == 5) PGNN_SCAT(5, 5);
     else if (J == 4 && I == 4) PGNN_SCAT(4, 4);
     else PGNN_SCAT(8, 8);
@@ -1087,7 +1135,7 @@ int segfc_bwd_impl(const float *Y, int64_t ld_y, const int32_t *seg_ids,
 #define PGNN_WG(IV)                                                            \
   hipLaunchKernelGGL((segmax_wgrad_gather_kernel<IV>), grid, dim3(64), 0,      \
                      stream, grad_out, ld_go, w.cnt, w.win, w.ldc, num_segments, \
-                     w.seg_per_slice, X, ld_x, k_in, w.kin_p, w.partial,        \
+                     w.seg_per_slice, xs, k_in, w.kin_p, w.partial,             \
                      w.partial_b, n_cols)
     if (I <= 2) PGNN_WG(2);
     else if (I <= 4) PGNN_WG(4);
@@ -1100,12 +1148,12 @@ int segfc_bwd_impl(const float *Y, int64_t ld_y, const int32_t *seg_ids,
                        w.kin_p, dW, db);
     hipLaunchKernelGGL(segmax_wgrad_tie_list_kernel, dim3(64), dim3(256), 0,
                        stream, w.tie, w.tie_list, kTieCap, seg_ids, grad_out,
-                       ld_go, w.cnt, w.ldc, X, ld_x, k_in, n_cols, dW, db);
+                       ld_go, w.cnt, w.ldc, xs, k_in, n_cols, dW, db);
     hipLaunchKernelGGL(segmax_wgrad_ties_kernel,
                        dim3(grid_for(n_rows * n_cols, 2048)), dim3(256), 0,
                        stream, w.tie, kTieCap, Y, ld_y, seg_ids, n_rows, n_cols,
                        num_segments, out, ld_out, grad_out, ld_go, w.cnt, w.win,
-                       w.ldc, X, ld_x, k_in, dW, db);
+                       w.ldc, xs, k_in, dW, db);
   }
   PGNN_HIP(hipGetLastError());
   return 0;
@@ -1131,18 +1179,21 @@ extern "C" int pgnn_edge_segmax_fc_bwd_f32(
     const float *Y, int64_t ld_y, const int32_t *edges, const int32_t *dst_ids,
     int64_t n_edges, int32_t n_cols, int32_t num_vertices, const float *out,
     int64_t ld_out, const float *grad_out, int64_t ld_go, const float *H1,
-    int64_t ld_h1, int32_t k_in, const float *WT, int64_t ld_wt, float *dP,
-    float *dQ, int64_t ld_pq, float *dW, float *db, void *workspace,
-    size_t workspace_bytes, void *stream_) {
+    int64_t ld_h1, const float *P, const float *Q, int32_t k_in, const float *WT,
+    int64_t ld_wt, float *dP, float *dQ, int64_t ld_pq, float *dW, float *db,
+    void *workspace, size_t workspace_bytes, void *stream_) {
   PGNN_GUARD_BEGIN
   PGNN_REQUIRE(edges || n_edges == 0, PGNN_E_INVALID,
                "edge_segmax_fc_bwd: null edges");
+  PGNN_REQUIRE(H1 || (P && Q) || n_edges == 0, PGNN_E_INVALID,
+               "edge_segmax_fc_bwd: H1 rows or the (P, Q) tables are needed");
   // a non-null marker keeps the edge form selected for n_edges == 0 as well
   static const int32_t kNoEdges[2] = {0, 0};
   return segfc_bwd_impl(Y, ld_y, dst_ids, n_edges, n_cols, num_vertices, out,
                         ld_out, grad_out, ld_go, H1, ld_h1, k_in, WT, ld_wt,
                         nullptr, 0, 0, 1, edges ? edges : kNoEdges, dP, dQ, ld_pq,
-                        dW, db, workspace, workspace_bytes, (hipStream_t)stream_);
+                        dW, db, workspace, workspace_bytes, (hipStream_t)stream_,
+                        H1 ? nullptr : P, H1 ? nullptr : Q);
   PGNN_GUARD_END
 }
 

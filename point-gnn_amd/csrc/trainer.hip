@@ -533,21 +533,39 @@ int forward_impl(Ctx &c, Saved &sv) {
                              b.coords[lvl], K, g.hx, pad16(cc + 3));
         rc = fc_fwd(c, w1, g.hx, pad16(cc + 3), K, false, nullptr, 0, g.p);
         if (rc) return rc;
-        rc = pgnn_edge_hidden_fwd(g.p, g.q, wq, b.edges[lvl], E, g.eact[0],
-                                  c.stream);
-        if (rc) return rc;
-        for (size_t i = 1; i < s.a.size(); ++i) {
-          rc = fc_fwd(c, s.a[i], g.eact[i - 1], pad16(s.a[i - 1].ref.n_out), E,
-                      true, nullptr, 0, g.eact[i]);
-          if (rc) return rc;
-        }
         if (E > 0)
           hipLaunchKernelGGL(edge_dst_kernel, dim3(blocks_for(E)), dim3(256), 0,
                              c.stream, b.edges[lvl], E, g.dst);
-        rc = pgnn_scatter_max_f32(g.eact[s.a.size() - 1], wa, g.dst, E, wa,
-                                  (int32_t)K, g.agg, wa,
-                                  b.edges_sorted[lvl] ? 1 : 0, c.stream);
-        if (rc) return rc;
+        bool fused = false;
+        if (s.a.size() == 2 && s.a[1].want_wt) {
+          // gather + last edge layer + scatter-max in ONE kernel that also
+          // writes the layer's rows (H1 is never materialised: the backward
+          // recomputes its rows from P and Q)
+          pgnn_fc_layer L2;
+          L2.packed = s.a[1].packed;
+          L2.k_in = s.a[1].ref.k_in;
+          L2.n_out = s.a[1].ref.n_out;
+          L2.relu_from = 0;
+          rc = pgnn_edge_mlp_scatter_max_rows_fwd(
+              g.p, g.q, wq, s.a[1].ref.k_in, b.edges[lvl], E, (int32_t)K, &L2,
+              b.edges_sorted[lvl] ? 1 : 0, g.agg, wa, g.eact[1], wa, c.stream);
+          if (rc == 0) fused = true;
+          else if (rc != PGNN_E_UNSUPPORTED) return rc;
+        }
+        if (!fused) {
+          rc = pgnn_edge_hidden_fwd(g.p, g.q, wq, b.edges[lvl], E, g.eact[0],
+                                    c.stream);
+          if (rc) return rc;
+          for (size_t i = 1; i < s.a.size(); ++i) {
+            rc = fc_fwd(c, s.a[i], g.eact[i - 1], pad16(s.a[i - 1].ref.n_out), E,
+                        true, nullptr, 0, g.eact[i]);
+            if (rc) return rc;
+          }
+          rc = pgnn_scatter_max_f32(g.eact[s.a.size() - 1], wa, g.dst, E, wa,
+                                    (int32_t)K, g.agg, wa,
+                                    b.edges_sorted[lvl] ? 1 : 0, c.stream);
+          if (rc) return rc;
+        }
         x = g.agg;
         ldx = wa;
         for (size_t i = 0; i < s.b.size(); ++i) {
@@ -831,11 +849,12 @@ int backward_impl(Ctx &c, Saved &sv, const float *dlogits, const float *dpred) {
         if (s.a.back().want_wt && na == 2) {
           // last edge layer + scatter-max + the gather's adjoint in one
           // routing pass: dP / dQ directly, dH1 is never written
+          // (H1 rows recomputed from P, Q: valid after either forward form)
           rc = pgnn_edge_segmax_fc_bwd_f32(
               g.eact[1], wa, b.edges[lvl], g.dst, E, s.a[1].ref.n_out,
-              (int32_t)Ks, g.agg, wa, dagg, wa, g.eact[0], wq, s.a[1].ref.k_in,
-              s.a[1].wt, pad16(s.a[1].ref.k_in), dp, dq, wq, s.a[1].gw,
-              s.a[1].gb, sv.scratch, sv.scratch_bytes, c.stream);
+              (int32_t)Ks, g.agg, wa, dagg, wa, nullptr, 0, g.p, g.q,
+              s.a[1].ref.k_in, s.a[1].wt, pad16(s.a[1].ref.k_in), dp, dq, wq,
+              s.a[1].gw, s.a[1].gb, sv.scratch, sv.scratch_bytes, c.stream);
           if (rc) return rc;
           scattered = true;
           from = 0;
