@@ -301,7 +301,9 @@ int pgnn_edge_mlp_scatter_max_fwd(const float *P, const float *Q,
  * kernel also writes that layer's per-edge output rows [n_edges, ld_rows]
  * (the backward compares them with `out` to find the arg-max rows; rows and
  * maxima come from the same accumulators, so the winner reproduces `out` bit
- * for bit).  Returns PGNN_E_UNSUPPORTED -- having done nothing -- when the
+ * for bit).  h1_out (nullable): the gathered hidden rows ReLU(P[src] -
+ * Q[dst]) [n_edges, ld_pq] are written as well (= pgnn_edge_hidden_fwd).
+ * Returns PGNN_E_UNSUPPORTED -- having done nothing -- when the
  * weights-stationary kernel does not apply (fewer than ~65k edges, layer
  * shapes other than 300x300 / 256x256): the caller then runs
  * pgnn_edge_hidden_fwd + pgnn_mlp_fwd + pgnn_scatter_max_f32.               */
@@ -312,7 +314,8 @@ int pgnn_edge_mlp_scatter_max_rows_fwd(const float *P, const float *Q,
                                        const pgnn_fc_layer *layer_host,
                                        int32_t edges_sorted, float *out,
                                        int64_t ld_out, float *rows_out,
-                                       int64_t ld_rows, void *stream);
+                                       int64_t ld_rows, float *h1_out,
+                                       void *stream);
 
 /* x' = x + delta (gnn.py:346) and Q = x' @ Wx where Wx = the last 3 rows of
  * the first edge layer's weights (the rows that multiply the coordinate part

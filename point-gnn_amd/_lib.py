@@ -133,7 +133,7 @@ _SIGNATURES = {
                                                    c_vp, c_i64, c_i32,
                                                    ctypes.POINTER(FcLayer),
                                                    c_i32, c_vp, c_i64, c_vp,
-                                                   c_i64, c_vp]),
+                                                   c_i64, c_vp, c_vp]),
     "pgnn_offset_apply": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp,
                                   c_i64, c_vp]),
     "pgnn_vertex_pre_edge_fwd": (c_i32, [c_vp, c_i64, c_i32, c_vp,

@@ -87,6 +87,10 @@ struct EdgeWsArgs {
   // arg-max rows by comparing them with `out`
   float *rows_out;
   int64_t ld_rows;
+  // ... and, optionally, the gathered hidden rows ReLU(P[src] - Q[dst])
+  // [n_edges, 4 * ldv4] (written by the workgroups of column group 0 only:
+  // every group gathers the same rows)
+  float *h1_out;
 };
 
 // max(a, b) as ONE instruction: fmaxf() first canonicalises operands the
@@ -394,6 +398,13 @@ __device__ __forceinline__ void edge_ws_body(const EdgeWsArgs &a,
         in[q][1] = max_nc(lo[1], 0.0f, inf);
         in[q][2] = max_nc(hi[0], 0.0f, inf);
         in[q][3] = max_nc(hi[1], 0.0f, inf);
+      }
+    }
+    if constexpr (EMIT) {
+      if (a.h1_out && t0 == 0 && e0 + n < E) {  // t0 == 0: column group 0
+        v4f *hrow = reinterpret_cast<v4f *>(a.h1_out) + (e0 + n) * a.ldv4 + g;
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) hrow[4 * q] = in[q];
       }
     }
     __builtin_amdgcn_sched_barrier(0);

@@ -862,10 +862,11 @@ template <int KQ, int NTMAX>
 int launch_edge_ws(const LayerDev &L, const EdgeArgs &ea, int64_t n_edges,
                    const SegArgs &sa, int cus, int32_t *sched,
                    hipStream_t stream, float *rows_out = nullptr,
-                   int64_t ld_rows = 0) {
+                   int64_t ld_rows = 0, float *h1_out = nullptr) {
   EdgeWsArgs a = {};
   a.rows_out = rows_out;
   a.ld_rows = ld_rows;
+  a.h1_out = h1_out;
   a.P = ea.P;
   a.Q = ea.Q;
   a.ldv4 = (int)(ea.ldpq >> 2);
@@ -1329,7 +1330,7 @@ extern "C" int pgnn_edge_mlp_scatter_max_rows_fwd(
     const float *P, const float *Q, int64_t ld_pq, int32_t width,
     const int32_t *edges, int64_t n_edges, int32_t num_vertices,
     const pgnn_fc_layer *layer, int32_t edges_sorted, float *out, int64_t ld_out,
-    float *rows_out, int64_t ld_rows, void *stream_) {
+    float *rows_out, int64_t ld_rows, float *h1_out, void *stream_) {
   PGNN_GUARD_BEGIN
   hipStream_t stream = (hipStream_t)stream_;
   PGNN_REQUIRE(n_edges >= 0 && num_vertices >= 0 && width > 0 && layer,
@@ -1348,17 +1349,18 @@ extern "C" int pgnn_edge_mlp_scatter_max_rows_fwd(
   if (n_edges == 0 || num_vertices == 0 || !edge_ws_applies(p, n_edges, cus))
     return PGNN_E_UNSUPPORTED;  // (no message: an expected answer)
   PGNN_REQUIRE(P && Q && edges, PGNN_E_INVALID, "edge_mlp_rows: null input");
-  PGNN_REQUIRE(((uintptr_t)P % 16 == 0) && ((uintptr_t)Q % 16 == 0),
-               PGNN_E_INVALID, "edge_mlp_rows: P/Q must be 16-byte aligned");
+  PGNN_REQUIRE(((uintptr_t)P % 16 == 0) && ((uintptr_t)Q % 16 == 0) &&
+                   ((uintptr_t)h1_out % 16 == 0),
+               PGNN_E_INVALID, "edge_mlp_rows: P/Q/H1 must be 16-byte aligned");
   rc = fill_lowest(out, (int64_t)num_vertices * ld_out, stream);
   if (rc) return rc;
   EdgeArgs ea = {P, Q, ld_pq, edges};
   SegArgs sa = {out, ld_out, num_vertices, edges_sorted & 1};
   if (p.chain.l[0].nt == 19)
     return launch_edge_ws<19, 7>(p.chain.l[0], ea, n_edges, sa, cus, nullptr,
-                                 stream, rows_out, ld_rows);
+                                 stream, rows_out, ld_rows, h1_out);
   return launch_edge_ws<16, 8>(p.chain.l[0], ea, n_edges, sa, cus, nullptr, stream,
-                               rows_out, ld_rows);
+                               rows_out, ld_rows, h1_out);
   PGNN_GUARD_END
 }
 

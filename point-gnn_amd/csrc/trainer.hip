@@ -539,8 +539,7 @@ int forward_impl(Ctx &c, Saved &sv) {
         bool fused = false;
         if (s.a.size() == 2 && s.a[1].want_wt) {
           // gather + last edge layer + scatter-max in ONE kernel that also
-          // writes the layer's rows (H1 is never materialised: the backward
-          // recomputes its rows from P and Q)
+          // writes the layer's rows and the gathered hidden rows H1
           pgnn_fc_layer L2;
           L2.packed = s.a[1].packed;
           L2.k_in = s.a[1].ref.k_in;
@@ -548,7 +547,8 @@ int forward_impl(Ctx &c, Saved &sv) {
           L2.relu_from = 0;
           rc = pgnn_edge_mlp_scatter_max_rows_fwd(
               g.p, g.q, wq, s.a[1].ref.k_in, b.edges[lvl], E, (int32_t)K, &L2,
-              b.edges_sorted[lvl] ? 1 : 0, g.agg, wa, g.eact[1], wa, c.stream);
+              b.edges_sorted[lvl] ? 1 : 0, g.agg, wa, g.eact[1], wa, g.eact[0],
+              c.stream);
           if (rc == 0) fused = true;
           else if (rc != PGNN_E_UNSUPPORTED) return rc;
         }
@@ -849,10 +849,9 @@ int backward_impl(Ctx &c, Saved &sv, const float *dlogits, const float *dpred) {
         if (s.a.back().want_wt && na == 2) {
           // last edge layer + scatter-max + the gather's adjoint in one
           // routing pass: dP / dQ directly, dH1 is never written
-          // (H1 rows recomputed from P, Q: valid after either forward form)
           rc = pgnn_edge_segmax_fc_bwd_f32(
               g.eact[1], wa, b.edges[lvl], g.dst, E, s.a[1].ref.n_out,
-              (int32_t)Ks, g.agg, wa, dagg, wa, nullptr, 0, g.p, g.q,
+              (int32_t)Ks, g.agg, wa, dagg, wa, g.eact[0], wq, g.p, g.q,
               s.a[1].ref.k_in, s.a[1].wt, pad16(s.a[1].ref.k_in), dp, dq, wq,
               s.a[1].gw, s.a[1].gb, sv.scratch, sv.scratch_bytes, c.stream);
           if (rc) return rc;
