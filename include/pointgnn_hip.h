@@ -279,6 +279,25 @@ int pgnn_point_set_pooling_fwd(const float *point_features, int32_t n_feat,
                                float *out, int64_t ld_out, int32_t *sched_ws,
                                void *stream);
 
+/* Training forward of the same: the fused kernel also writes the point MLP's
+ * activations -- acts_host[0..3] (a HOST array of four DEVICE pointers):
+ * [n_edges, 32], [n_edges, 64], [n_edges, 128] and [n_edges, ld_last] for the
+ * shipped car chain 4-32-64-128-300 -- which the backward needs (the last one
+ * against `out` gives the arg-max rows: rows and maxima come from the same
+ * accumulators).  PGNN_E_UNSUPPORTED, having done nothing, for other chains
+ * or fewer than ~65k edges: run pgnn_pool_features_fwd + pgnn_mlp_fwd per
+ * layer + pgnn_scatter_max_f32 instead.                                     */
+int pgnn_point_set_pooling_rows_fwd(const float *point_features, int32_t n_feat,
+                                    const float *point_xyz,
+                                    const int32_t *keypoint_indices,
+                                    const int32_t *edges, int64_t n_edges,
+                                    int32_t num_keypoints,
+                                    const pgnn_fc_layer *layers_host,
+                                    int32_t n_layers, int32_t edges_sorted,
+                                    float *out, int64_t ld_out,
+                                    float *const *acts_host, int64_t ld_last,
+                                    void *stream);
+
 /* Fused GraphNetAutoCenter edge stage (gnn.py:338-365).  The first edge layer
  * is linear before its ReLU, so with P = [h, x] @ W1 + b1 and Q = x' @ W1[C:]
  * (both per vertex, computed by pgnn_mlp_fwd / pgnn_offset_apply) the

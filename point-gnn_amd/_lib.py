@@ -129,6 +129,12 @@ _SIGNATURES = {
                                               ctypes.POINTER(FcLayer), c_i32,
                                               c_i32, c_vp, c_i64, c_vp,
                                               c_vp]),
+    "pgnn_point_set_pooling_rows_fwd": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp,
+                                                c_i64, c_i32,
+                                                ctypes.POINTER(FcLayer), c_i32,
+                                                c_i32, c_vp, c_i64,
+                                                ctypes.POINTER(c_vp), c_i64,
+                                                c_vp]),
     "pgnn_edge_mlp_scatter_max_rows_fwd": (c_i32, [c_vp, c_vp, c_i64, c_i32,
                                                    c_vp, c_i64, c_i32,
                                                    ctypes.POINTER(FcLayer),

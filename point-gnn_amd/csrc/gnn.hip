@@ -972,8 +972,16 @@ bool pool_ws_applies(const Plan &p, int64_t n_edges, int cus) {
 
 int launch_pool_ws(const Plan &p, const PoolArgs &pa, int64_t n_edges,
                    const SegArgs &sa, int cus, int32_t *sched,
-                   hipStream_t stream) {
+                   hipStream_t stream, float *const *acts = nullptr,
+                   int64_t ld4 = 0) {
   PoolWsArgs a = {};
+  if (acts) {
+    a.a1_out = acts[0];
+    a.a2_out = acts[1];
+    a.a3_out = acts[2];
+    a.a4_out = acts[3];
+    a.ld4 = ld4;
+  }
   a.feat = pa.feat;
   a.nfeat = pa.nfeat;
   a.xyz = pa.xyz;
@@ -998,7 +1006,16 @@ int launch_pool_ws(const Plan &p, const PoolArgs &pa, int64_t n_edges,
   a.pool_pct = g_ws_pool_pct;
   a.chunk = 1;
   const size_t lds = (size_t)8 * 19 * 1024 + 16 * 19 * sizeof(float);
-  auto kern = pool_ws_kernel;
+  if (acts) {  // training forward: the layers' activations are written too
+    auto kern = pool_ws_kernel<true>;
+    const int lrc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
+    if (lrc) return lrc;
+    hipLaunchKernelGGL(kern, dim3((unsigned)cus), dim3(64 * kWsWaves), lds,
+                       stream, a);
+    PGNN_HIP(hipGetLastError());
+    return 0;
+  }
+  auto kern = pool_ws_kernel<false>;
   {
     const int lrc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
     if (lrc) return lrc;
@@ -1317,6 +1334,46 @@ extern "C" int pgnn_vertex_pre_edge_fwd(
                      dim3(64 * kRowsWaves), lds, stream, off, pl, a);
   PGNN_HIP(hipGetLastError());
   return 0;
+  PGNN_GUARD_END
+}
+
+// Training forward of PointSetPooling: pgnn_point_set_pooling_fwd that also
+// writes the four layers' activations (car chain 4-32-64-128-300 on the
+// weights-stationary kernel only; PGNN_E_UNSUPPORTED otherwise, nothing done).
+extern "C" int pgnn_point_set_pooling_rows_fwd(
+    const float *point_features, int32_t n_feat, const float *point_xyz,
+    const int32_t *keypoint_indices, const int32_t *edges, int64_t n_edges,
+    int32_t num_keypoints, const pgnn_fc_layer *layers, int32_t n_layers,
+    int32_t edges_sorted, float *out, int64_t ld_out, float *const *acts_host,
+    int64_t ld_last, void *stream_) {
+  PGNN_GUARD_BEGIN
+  hipStream_t stream = (hipStream_t)stream_;
+  PGNN_REQUIRE(n_edges >= 0 && num_keypoints >= 0 && n_feat >= 0 && n_feat <= 13 &&
+                   layers && acts_host,
+               PGNN_E_INVALID, "point_set_pooling_rows: bad sizes");
+  if (n_layers != 4) return PGNN_E_UNSUPPORTED;
+  Plan p;
+  int rc = make_plan(layers, n_layers, n_feat + 3, p);
+  if (rc) return rc;
+  const int out_cols = 16 * p.chain.l[n_layers - 1].nt;
+  PGNN_REQUIRE(out && ld_out >= out_cols && ld_last >= out_cols && ld_last % 4 == 0,
+               PGNN_E_INVALID, "point_set_pooling_rows: bad output");
+  int cus = stream_cu_count(stream);
+  if (g_ws_reserve > 0 && cus - g_ws_reserve >= 64) cus -= g_ws_reserve;
+  if (n_edges == 0 || num_keypoints == 0 || !pool_ws_applies(p, n_edges, cus))
+    return PGNN_E_UNSUPPORTED;
+  PGNN_REQUIRE(point_xyz && keypoint_indices && edges && (n_feat == 0 || point_features),
+               PGNN_E_INVALID, "point_set_pooling_rows: null input");
+  for (int i = 0; i < 4; ++i)
+    PGNN_REQUIRE(acts_host[i] && (uintptr_t)acts_host[i] % 16 == 0, PGNN_E_INVALID,
+                 "point_set_pooling_rows: activation buffers must be 16-byte "
+                 "aligned");
+  rc = fill_lowest(out, (int64_t)num_keypoints * ld_out, stream);
+  if (rc) return rc;
+  PoolArgs pa = {point_features, n_feat, point_xyz, keypoint_indices, edges};
+  SegArgs sa = {out, ld_out, num_keypoints, edges_sorted & 1};
+  return launch_pool_ws(p, pa, n_edges, sa, cus, nullptr, stream, acts_host,
+                        ld_last);
   PGNN_GUARD_END
 }
 

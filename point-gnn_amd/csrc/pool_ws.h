@@ -41,6 +41,12 @@ struct PoolWsArgs {
   int32_t *sched;
   int pool_pct;
   int chunk;
+  // training forward (EMIT kernel only): the activations of the four layers
+  // are ALSO written -- a1 [E,32], a2 [E,64], a3 [E,128], a4 [E, ld4] -- for
+  // the backward (a4 against `out` gives the arg-max rows; rows and maxima
+  // come from the same accumulators)
+  float *a1_out, *a2_out, *a3_out, *a4_out;
+  int64_t ld4;
 };
 
 // acc[t] = sum_q W[q][tb + t]^T h[q]  for the NTB column tiles from tb on
@@ -92,6 +98,7 @@ __device__ __forceinline__ void pool_ws_block(const v4f *const (&wfrag)[3],
 
 // tiles [tile_first, tile_last) of 16 edge rows; last layer = 8 K groups x 19
 // column tiles in LDS
+template <bool EMIT>
 __device__ __forceinline__ void pool_ws_body(const PoolWsArgs &a,
                                              const v4f *__restrict__ wl,
                                              const float *bias_lds,
@@ -193,6 +200,22 @@ __device__ __forceinline__ void pool_ws_body(const PoolWsArgs &a,
       reg_layer<1, 2>(a.l0, lane, x, h1);
       reg_layer<2, 4>(a.l1, lane, h1, h2);
       reg_layer<4, 8>(a.l2, lane, h2, h3);
+      if constexpr (EMIT) {
+        // hidden activations: lane (g, n) holds features 16 q + 4 g .. + 3 of
+        // row n -- one 16-byte store per K group
+        if (e0 + n < E) {
+          const int64_t row = e0 + n;
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+            *reinterpret_cast<v4f *>(a.a1_out + row * 32 + 16 * q + 4 * g) = h1[q];
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<v4f *>(a.a2_out + row * 64 + 16 * q + 4 * g) = h2[q];
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+            *reinterpret_cast<v4f *>(a.a3_out + row * 128 + 16 * q + 4 * g) = h3[q];
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);
       // second level of the next tile's index chain (its pair has landed)
       {
@@ -212,6 +235,25 @@ __device__ __forceinline__ void pool_ws_body(const PoolWsArgs &a,
       v4f acc[NTB];                                                            \
       if (!fin) {                                                              \
         pool_ws_block<KQ, NT, NTB>(wfrag, TB, h3, acc);                        \
+        if constexpr (EMIT) { /* the rows: same accumulators, bias, ReLU */    \
+          if (e0 + n < E) {                                                    \
+            float *dstp = a.a4_out + (e0 + n) * a.ld4 + 16 * (TB) + 4 * g;     \
+            _Pragma("unroll")                                                  \
+            for (int t = 0; t < NTB; ++t) {                                    \
+              const v4f bb = *reinterpret_cast<const v4f *>(                   \
+                  bias_lds + 16 * ((TB) + t) + 4 * g);                         \
+              v4f y;                                                           \
+              _Pragma("unroll")                                                \
+              for (int r = 0; r < 4; ++r) {                                    \
+                float xx = acc[t][r] + bb[r];                                  \
+                if (16 * ((TB) + t) + 4 * g + r >= a.relu_from)                \
+                  xx = xx > 0.0f ? xx : 0.0f;                                  \
+                y[r] = xx;                                                     \
+              }                                                                \
+              *reinterpret_cast<v4f *>(dstp + 16 * t) = y;                     \
+            }                                                                  \
+          }                                                                    \
+        }                                                                      \
       } else { /* defined on both paths: an undef phi would keep every */      \
         _Pragma("unroll") /* block's accumulators live round the loop */       \
         for (int t = 0; t < NTB; ++t) acc[t] = (v4f){0.f, 0.f, 0.f, 0.f};      \
@@ -239,6 +281,7 @@ __device__ __forceinline__ void pool_ws_body(const PoolWsArgs &a,
   __builtin_amdgcn_s_setprio(0);
 }
 
+template <bool EMIT = false>
 __global__ __launch_bounds__(64 * kWsWaves) void pool_ws_kernel(PoolWsArgs a) {
   constexpr int KQ = 8, NT = 19;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -280,7 +323,8 @@ __global__ __launch_bounds__(64 * kWsWaves) void pool_ws_kernel(PoolWsArgs a) {
   }
   int stamped = 0;
   for (;;) {
-    pool_ws_body(a, wl, bias_lds, tile_first, tile_last, lane, tsw, stamped);
+    pool_ws_body<EMIT>(a, wl, bias_lds, tile_first, tile_last, lane, tsw,
+                       stamped);
     if (pool == 0) break;
     int c = 0;
     if (lane == 0)

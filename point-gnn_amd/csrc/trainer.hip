@@ -454,21 +454,44 @@ int forward_impl(Ctx &c, Saved &sv) {
                                     b.keypoints[lvl], b.edges[lvl], E, p.feat,
                                     c.stream);
         if (rc) return rc;
-        const float *x = p.feat;
-        int64_t ldx = 16;
-        for (size_t i = 0; i < s.a.size(); ++i) {
-          rc = fc_fwd(c, s.a[i], x, ldx, E, true, nullptr, 0, p.act[i]);
-          if (rc) return rc;
-          x = p.act[i];
-          ldx = pad16(s.a[i].ref.n_out);
-        }
         if (E > 0)
           hipLaunchKernelGGL(edge_dst_kernel, dim3(blocks_for(E)), dim3(256), 0,
                              c.stream, b.edges[lvl], E, p.dst);
-        rc = pgnn_scatter_max_f32(x, ldx, p.dst, E, (int32_t)ldx, (int32_t)K,
-                                  p.agg, wa, b.edges_sorted[lvl] ? 1 : 0,
-                                  c.stream);
-        if (rc) return rc;
+        const float *x = p.feat;
+        int64_t ldx = 16;
+        bool fused = false;
+        if (s.a.size() == 4 && s.a.back().want_wt &&
+            pad16(s.a[0].ref.n_out) == 32 && pad16(s.a[1].ref.n_out) == 64 &&
+            pad16(s.a[2].ref.n_out) == 128) {
+          // gather + the whole point MLP + scatter-max in ONE kernel that
+          // also writes the four layers' activations
+          pgnn_fc_layer Ls[4];
+          for (int i = 0; i < 4; ++i) {
+            Ls[i].packed = s.a[i].packed;
+            Ls[i].k_in = s.a[i].ref.k_in;
+            Ls[i].n_out = s.a[i].ref.n_out;
+            Ls[i].relu_from = 0;
+          }
+          float *acts[4] = {p.act[0], p.act[1], p.act[2], p.act[3]};
+          rc = pgnn_point_set_pooling_rows_fwd(
+              b.input_v, b.n_feat, b.coords[lvl], b.keypoints[lvl], b.edges[lvl],
+              E, (int32_t)K, Ls, 4, b.edges_sorted[lvl] ? 1 : 0, p.agg, wa, acts,
+              wa, c.stream);
+          if (rc == 0) fused = true;
+          else if (rc != PGNN_E_UNSUPPORTED) return rc;
+        }
+        if (!fused) {
+          for (size_t i = 0; i < s.a.size(); ++i) {
+            rc = fc_fwd(c, s.a[i], x, ldx, E, true, nullptr, 0, p.act[i]);
+            if (rc) return rc;
+            x = p.act[i];
+            ldx = pad16(s.a[i].ref.n_out);
+          }
+          rc = pgnn_scatter_max_f32(x, ldx, p.dst, E, (int32_t)ldx, (int32_t)K,
+                                    p.agg, wa, b.edges_sorted[lvl] ? 1 : 0,
+                                    c.stream);
+          if (rc) return rc;
+        }
         x = p.agg;
         ldx = wa;
         for (size_t i = 0; i < s.b.size(); ++i) {

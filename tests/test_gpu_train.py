@@ -505,3 +505,63 @@ def test_edge_rows_forward_reproduces_its_maxima(dev, c, fixture):
         _lib.ptr(pd), _lib.ptr(qd), wq, c, _lib.ptr(ed), 5000, k, chain.array,
         1, _lib.ptr(out), wq, _lib.ptr(rows), wq, None, _lib.stream_ptr())
     assert rc == -3 and bool((rows == 7.0).all())
+
+
+def test_pool_rows_forward_reproduces_its_maxima(dev):
+    """pgnn_point_set_pooling_rows_fwd (training forward of PointSetPooling on
+    the weights-stationary kernel): `out` is bit for bit the inference
+    kernel's and the exact segment maximum of the emitted last-layer rows; the
+    four activation matrices equal the layers applied one by one to the
+    materialised edge features."""
+    import ctypes
+    import torch
+    from pointgnn_amd import _lib, gnn
+    lib = _lib.load()
+    g = gold("graph_small.npz")
+    edges = g["ref_edges0"].astype(np.int32)
+    kp = g["kp_idx"].astype(np.int32).reshape(-1)
+    k = len(kp)
+    assert len(edges) >= 70000
+    rng = np.random.default_rng(9)
+    dims = [4, 32, 64, 128, 300]
+    layers = [((rng.standard_normal((a, b)) / np.sqrt(a)).astype(np.float32),
+               (0.1 * rng.standard_normal(b)).astype(np.float32), 0)
+              for a, b in zip(dims[:-1], dims[1:])]
+    store = gnn.ParamStore({}, device=dev)
+    chain = gnn.Chain(store, layers)
+    xyz, inten = T(g["xyz"], dev), T(g["intensity"], dev)
+    ed, kd = T(edges, dev), T(kp, dev)
+    n_e = len(edges)
+    out = torch.empty((k, 304), dtype=torch.float32, device=dev)
+    acts = [torch.full((n_e, w), 7.0, dtype=torch.float32, device=dev)
+            for w in (32, 64, 128, 304)]
+    ptrs = (ctypes.c_void_p * 4)(*[a.data_ptr() for a in acts])
+    _lib.check(lib.pgnn_point_set_pooling_rows_fwd(
+        _lib.ptr(inten), 1, _lib.ptr(xyz), _lib.ptr(kd), _lib.ptr(ed), n_e, k,
+        chain.array, 4, 1, _lib.ptr(out), 304, ptrs, 304, _lib.stream_ptr()),
+        "pgnn_point_set_pooling_rows_fwd")
+    ref = torch.empty_like(out)
+    _lib.check(lib.pgnn_point_set_pooling_fwd(
+        _lib.ptr(inten), 1, _lib.ptr(xyz), _lib.ptr(kd), _lib.ptr(ed), n_e, k,
+        chain.array, 4, 1, _lib.ptr(ref), 304, _lib.ptr(_lib.sched_ws(dev)),
+        _lib.stream_ptr()), "pgnn_point_set_pooling_fwd")
+    assert torch.equal(out, ref)
+    seg = gnn.graph_scatter_max_fn(acts[3], ed[:, 1].contiguous(), k,
+                                   ids_sorted=True)
+    assert torch.equal(seg, out)
+    feat = torch.empty((n_e, 16), dtype=torch.float32, device=dev)
+    _lib.check(lib.pgnn_pool_features_fwd(
+        _lib.ptr(inten), 1, _lib.ptr(xyz), _lib.ptr(kd), _lib.ptr(ed), n_e,
+        _lib.ptr(feat), _lib.stream_ptr()), "pgnn_pool_features_fwd")
+    x, nx = feat, 4
+    for i, (w, b, _) in enumerate(layers):
+        one = gnn.Chain(store, [(w, b, 0)])
+        x = gnn.mlp_forward(one, x, nx)
+        nx = w.shape[1]
+        assert torch.equal(x, acts[i]), "layer %d" % i
+    # too few edges: declined, nothing written
+    acts[0].fill_(7.0)
+    rc = lib.pgnn_point_set_pooling_rows_fwd(
+        _lib.ptr(inten), 1, _lib.ptr(xyz), _lib.ptr(kd), _lib.ptr(ed), 3000, k,
+        chain.array, 4, 1, _lib.ptr(out), 304, ptrs, 304, _lib.stream_ptr())
+    assert rc == -3 and bool((acts[0] == 7.0).all())
