@@ -383,11 +383,21 @@ __global__ void voxel_leader_kernel(const SortedPoint *__restrict__ sorted,
   const int vx = vc[3 * i], vy = vc[3 * i + 1], vz = vc[3 * i + 2];
   const uint32_t b = keys[i];
   const int s = cell_start[b], e = cell_end[b];
-  bool leader = true;
-  for (int j = s; j < (int)i; ++j) {
-    if (vc[3 * j] == vx && vc[3 * j + 1] == vy && vc[3 * j + 2] == vz) {
-      leader = false;
-      break;
+  // Leader = the first slot of this voxel in its bucket.  A bucket nearly
+  // always holds ONE voxel (>= 2 buckets per point): a slot whose voxel is the
+  // bucket's first voxel is a leader iff it is the first slot -- no search;
+  // only the members of a colliding second voxel walk the slots before them
+  // (the walk made this kernel O(members^2) per voxel: 300 us at voxel 0.8 m)
+  bool leader;
+  if (vc[3 * s] == vx && vc[3 * s + 1] == vy && vc[3 * s + 2] == vz) {
+    leader = (int)i == s;
+  } else {
+    leader = true;
+    for (int j = s; j < (int)i; ++j) {
+      if (vc[3 * j] == vx && vc[3 * j + 1] == vy && vc[3 * j + 2] == vz) {
+        leader = false;
+        break;
+      }
     }
   }
   is_leader[i] = leader ? 1 : 0;

@@ -953,7 +953,13 @@ __global__ void l1_norm_kernel(const float *__restrict__ w,
     if (is_weight[i] != 0.0f) s += (double)fabsf(w[i]);
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
-  if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+  // one fp64 atomic per workgroup (one per wave serialised 23k of them on a
+  // single address: 56 us for 1.5 M parameters)
+  __shared__ double part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    atomicAdd(out, (part[0] + part[1]) + (part[2] + part[3]));
 }
 
 inline unsigned grid_for(int64_t total, int cap = 4096) {
