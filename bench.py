@@ -489,7 +489,9 @@ def train_measure(torch, dev, rank, world, dist, config_name, preset, steps,
     # The data side (graph build + frame merge of step i+1) runs on its own
     # stream while step i's forward/backward occupy the compute stream -- the
     # reference hides it behind 16 loader processes (train.py:430-440).
-    sg = torch.cuda.Stream()
+    # (a stream on a hardware queue of its own: see engine.concurrent_streams)
+    from pointgnn_amd.engine import concurrent_streams
+    sg = concurrent_streams(1, dev)[0]
     cur = torch.cuda.current_stream()
 
     def make_batch(i):
@@ -857,10 +859,12 @@ def secondary_train(args, torch, dev):
     """BASELINE config 4 on one GPU (`car_auto_T3` training step, 2 frames per
     step, training graph kwargs): >= 10 timed steps and the whole-step MFMA
     roofline.  The 8-GPU form is `bench.py --train --gpus 8`."""
-    steps = max(10, min(16, args.steps // 2))
+    steps = max(16, min(24, args.steps))
     fpg = 2
+    # (8 warm-up steps: the first few size the trainer's workspace and the
+    # allocator's pools for the graph tensors)
     elapsed, ar_ms, tr, cfg, shapes, out = train_measure(
-        torch, dev, 0, 1, None, "car_auto_T3", "car", steps, 4, 4, fpg, True)
+        torch, dev, 0, 1, None, "car_auto_T3", "car", steps, 8, 4, fpg, True)
     res = {
         "workload": "car_auto_T3 training step, %d frames/step, training "
                     "graph kwargs (voxel 0.8, random keypoints + jitter, "
