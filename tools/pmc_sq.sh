@@ -23,8 +23,10 @@ for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_V
            "SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA SQ_LEVEL_WAVES SQ_IFETCH_LEVEL"; do
   i=$((i+1))
   [[ -n "${PMC_SETS:-}" && $i -gt $PMC_SETS ]] && break
-  (cd /tmp && timeout 120 rocprofv3 --kernel-trace --pmc $set -d $OUT/p$i -o pmc -- \
-      python $ROOT/tools/kernel_bench.py frame --reps 6 --preset $PRESET ${PGNN_TUNE:+--tune $PGNN_TUNE} > $OUT/p$i.log 2>&1)
+  # PMC_CMD overrides the profiled command (e.g. the training bench)
+  CMD=${PMC_CMD:-"python $ROOT/tools/kernel_bench.py frame --reps 6 --preset $PRESET ${PGNN_TUNE:+--tune $PGNN_TUNE}"}
+  (cd /tmp && timeout 180 rocprofv3 --kernel-trace --pmc $set -d $OUT/p$i -o pmc -- \
+      $CMD > $OUT/p$i.log 2>&1)
   echo "set $i rc=$?: $set" >> $RES
   db=$(find $OUT/p$i -name "*.db" | head -1)
   python - "$db" >> $RES <<'EOF2'
@@ -32,7 +34,10 @@ import sqlite3, sys
 db = sqlite3.connect(sys.argv[1])
 for pat, tag in (("edge_ws_kernel", "edgews"), ("pool_ws_kernel", "poolws"),
                  ("fused_mlp_kernel<4, 2>", "edge"),
-                 ("fused_mlp_kernel<4, 1>", "pool"), ("fused_mlp_kernel<4, 3>", "pool")):
+                 ("fused_mlp_kernel<4, 1>", "pool"), ("fused_mlp_kernel<4, 3>", "pool"),
+                 ("weight_grad_kernel<5>", "wgrad5"), ("weight_grad_kernel<2>", "wgrad2"),
+                 ("segmax_route_scatter_kernel", "route"),
+                 ("fused_mlp_kernel<4, 0>", "rowsE")):
     rows = db.execute("select counter_name, count(*), avg(value) from counters_collection "
                       "where kernel_name like ? group by counter_name", ("%" + pat + "%",))
     n = db.execute("select count(distinct dispatch_id) from counters_collection where "
