@@ -658,12 +658,18 @@ def parse_args(argv=None):
                     help="skip the extra `car`-preset measurement")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run frames strictly sequentially on one stream")
+    ap.add_argument("--host-sized", action="store_true",
+                    help="build the graphs with host-read sizes (two host "
+                         "waits per frame) instead of the capacity form")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--train", action="store_true",
                     help="BASELINE config 4: training step instead of inference")
     ap.add_argument("--frames-per-gpu", type=int, default=2)
-    ap.add_argument("--compute-streams", type=int, default=2,
+    ap.add_argument("--compute-streams", type=int, default=1,
                     help="GNN streams of the frame pipeline (1 or 2)")
+    ap.add_argument("--graph-streams", type=int, default=2,
+                    help="streams the graphs of consecutive frames are built "
+                         "on (capacity form only; 1 = a single builder)")
     ap.add_argument("--lookahead", type=int, default=0,
                     help="frames the graph-builder thread may run ahead of the "
                          "GNN (0 = build inline on the calling thread)")
@@ -939,14 +945,19 @@ def main(argv=None):
             pipeline on HIP streams (graph build of frame i+1 overlaps the GNN
             of frame i); --no-pipeline runs them strictly one after the other."""
             fr = [pool[seed_of(i)][:2] for i in range(lo, hi)]
+            deferred = not args.host_sized
             if args.no_pipeline:
+                if deferred:
+                    outs = [engine.run_frame_deferred(x, f) for x, f in fr]
+                    return [d.result() for d in outs][-1]
                 out = None
                 for x, f in fr:
                     out = engine.run_frame(x, f)
                 return out
             return engine.run_frames_pipelined(
                 fr, compute_streams=args.compute_streams,
-                graph_cus=args.graph_cus, lookahead=args.lookahead)[-1]
+                graph_cus=args.graph_cus, lookahead=args.lookahead,
+                deferred=deferred, graph_streams=args.graph_streams)[-1]
 
         if warmup:
             run(0, warmup)
@@ -999,6 +1010,24 @@ def main(argv=None):
         n_k = int(coords[1].shape[0])
         n_e1 = int(edges[1].shape[0])
         frames = engine.time_dict['frames']
+        # one frame alone, enqueue to results on the host: host-sized graph
+        # (the builder waits twice for sizes) vs capacity form (one read, at
+        # the end)
+        lat = {"host-sized": [], "capacity form": []}
+        for _ in range(7):
+            for key in lat:
+                torch.cuda.synchronize()
+                tp = time.perf_counter()
+                if key == "host-sized":
+                    engine.run_frame(x, f)
+                    torch.cuda.synchronize()
+                else:
+                    engine.run_frame_deferred(x, f).result()
+                    torch.cuda.synchronize()
+                lat[key].append((time.perf_counter() - tp) * 1e3)
+        lat = {k_: float(np.median(v[2:])) for k_, v in lat.items()}
+        engine.run_frame(x, f)   # last_graph back to the host-sized form
+        coords, kps, edges = engine.last_graph
         # run.py's last two phases ("decode box", "nms", run.py:264-326) on
         # this frame's outputs -- reported beside the metric, not part of it
         # (the metric excludes NMS)
@@ -1022,6 +1051,8 @@ def main(argv=None):
                         "case for the NMS"}
         st = pool_statistics(cfg, shapes)
         assert st["frames"] == world * args.steps
+        n_builders = 1 if (args.host_sized or args.graph_cus > 0) else \
+            max(1, args.graph_streams)
         fps = world * args.steps / elapsed
         n_pts = int(x.shape[0])
         res = {
@@ -1042,13 +1073,16 @@ def main(argv=None):
                 "N": n_pts, "K": st["K"], "E0": st["E0"], "E1": st["E1"],
                 "frames_timed": st["frames"],
                 "frames_per_gpu_per_step": 1,
+                "sizes": "host-read (two waits per frame in the graph "
+                         "builder)" if args.host_sized else
+                         "capacity form: K, E0, E1 stay on the device, one "
+                         "host read per batch of frames (results)",
                 "schedule": "sequential, 1 stream" if args.no_pipeline else
-                            "%d HIP streams: graph build of frame i+1 overlaps "
-                            "the GNN of frame i%s" % (
-                                1 + args.compute_streams,
-                                ("; consecutive frames alternate between two "
-                                 "GNN streams" if args.compute_streams > 1
-                                 else "") +
+                            "%d HIP streams: the graphs of frames i+1 .. i+%d "
+                            "are built on %d builder stream(s) while %d GNN "
+                            "stream(s) run frame i%s" % (
+                                args.compute_streams + n_builders,
+                                n_builders, n_builders, args.compute_streams,
                                 ("; graph stream on %d reserved CUs, GNN "
                                  "streams on the other CUs (CU-masked "
                                  "streams)" % args.graph_cus
@@ -1068,6 +1102,8 @@ def main(argv=None):
                     "gnn inference":
                         engine.time_dict['gnn inference'] / frames * 1e3,
                     "decode box + nms": post["ms"]},
+                "latency_ms_frame_seed%d" % first: lat,
+                "capacity_overflow_rebuilds": engine.deferred_overflows,
                 "postprocess": post,
             },
         }

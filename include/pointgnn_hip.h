@@ -129,6 +129,36 @@ int pgnn_radius_graph_fill_f64(const double *points, int64_t n_points,
                                const int32_t *offsets /* from _count */,
                                int32_t *edges /* [capacity, 2] */,
                                int64_t capacity, void *stream);
+/* Capacity form of the same builder -- count, scan and fill in ONE call with
+ * no size leaving the device (graph_gen.py:155-220 never waits for one: its
+ * NumPy arrays carry their sizes; a device pipeline that reads K or E back
+ * stalls the host once per level).  `points_cap` / `centers_cap` size the
+ * launches and the workspace; when `n_points_dev` / `n_centers_dev` (device
+ * int32, nullable) are given, min(*n_dev, cap) rows are valid -- this is how a
+ * level takes the keypoints of pgnn_voxel_keypoints_* (whose count is
+ * num_keypoints[0] on the device) as its points and centres.  Rows are written
+ * up to `edge_capacity`; n_edges_dev[0] = rows written = min(E, capacity),
+ * n_edges_dev[1] = E, the size required: the caller compares the two when it
+ * reads the frame's results and re-runs with a larger buffer if they differ.
+ * Same rows, same order as _count + _fill. */
+size_t pgnn_radius_graph_dyn_workspace_bytes(int64_t points_cap,
+                                             int64_t centers_cap);
+int pgnn_radius_graph_dyn(const float *points, int64_t points_cap,
+                          const int32_t *n_points_dev, const float *centers,
+                          int64_t centers_cap, const int32_t *n_centers_dev,
+                          double radius, const double *scale3_host,
+                          void *workspace, size_t workspace_bytes,
+                          int32_t *edges /* [edge_capacity, 2] */,
+                          int64_t edge_capacity,
+                          int32_t *n_edges_dev /* [2], device */, void *stream);
+int pgnn_radius_graph_dyn_f64(const double *points, int64_t points_cap,
+                              const int32_t *n_points_dev,
+                              const double *centers, int64_t centers_cap,
+                              const int32_t *n_centers_dev, double radius,
+                              const double *scale3_host, void *workspace,
+                              size_t workspace_bytes, int32_t *edges,
+                              int64_t edge_capacity, int32_t *n_edges_dev,
+                              void *stream);
 /* Training-time fan-in cap (graph_gen.py:210-214, num_neighbors > 0): keeps a
  * uniformly random subset (without replacement) of `max_neighbors` edges for
  * every centre whose fan-in exceeds it (counter-based RNG keyed by `seed`,
@@ -239,6 +269,25 @@ typedef struct pgnn_fc_layer {
 
 #define PGNN_MAX_LAYERS 8
 
+/* ---- capacity form of the per-frame operators ------------------------------
+ * The reference's graph builder hands NumPy arrays to the model
+ * (run.py:219-222 -> 245-260): sizes travel with the arrays and nobody waits
+ * for them.  On the device the keypoint count K and the edge counts exist
+ * only after the builder's kernels ran; reading them back to size the next
+ * launch stalls the host twice per frame.  The *_dyn entries below are the
+ * operators of this section with every such count taken from DEVICE memory:
+ * the ordinary size argument becomes the capacity (it sizes buffers and
+ * grids), `dev` points at the int32 count (min(*dev, capacity) rows are
+ * processed; the rows behind it are neither read nor written), and `hint` is
+ * the count the host expects (e.g. the previous frame's): it only chooses
+ * between kernels that give bit-identical results (weights-stationary vs
+ * LDS-tile, 8-wave vs 4-wave rows kernel) and sizes strided grids, so a wrong
+ * hint costs time, never correctness.  hint <= 0 means the capacity. */
+typedef struct pgnn_dyn_count {
+  const int32_t *dev; /* device int32: the actual count                     */
+  int64_t hint;       /* expected value (host), <= 0: unknown               */
+} pgnn_dyn_count;
+
 /* Per-row MLP chain: y = MLP(concat(x[:, :nx], x2[:, :nx2])) (+ residual).
  * Covers multi_layer_neural_network_fn / multi_layer_fc_fn on per-vertex
  * inputs: PointSetPooling's output MLP (gnn.py:279-282), the auto-offset MLP
@@ -251,6 +300,11 @@ int pgnn_mlp_fwd(const float *x, int64_t ld_x, int32_t nx, const float *x2,
                  const pgnn_fc_layer *layers_host, int32_t n_layers,
                  const float *residual, int64_t ld_res, float *y, int64_t ld_y,
                  void *stream);
+int pgnn_mlp_fwd_dyn(const float *x, int64_t ld_x, int32_t nx, const float *x2,
+                     int64_t ld_x2, int32_t nx2, int64_t rows_cap,
+                     const pgnn_fc_layer *layers_host, int32_t n_layers,
+                     const float *residual, int64_t ld_res, float *y,
+                     int64_t ld_y, const pgnn_dyn_count *n_rows, void *stream);
 
 /* Fused PointSetPooling front half (gnn.py:256-277): for every edge
  * (point, keypoint) build [features(point), xyz(point) - xyz(keypoint)], run
@@ -278,6 +332,18 @@ int pgnn_point_set_pooling_fwd(const float *point_features, int32_t n_feat,
                                int32_t n_layers, int32_t edges_sorted,
                                float *out, int64_t ld_out, int32_t *sched_ws,
                                void *stream);
+int pgnn_point_set_pooling_fwd_dyn(const float *point_features, int32_t n_feat,
+                                   const float *point_xyz,
+                                   const int32_t *keypoint_indices,
+                                   const int32_t *edges, int64_t edges_cap,
+                                   int32_t keypoints_cap,
+                                   const pgnn_fc_layer *layers_host,
+                                   int32_t n_layers, int32_t edges_sorted,
+                                   float *out, int64_t ld_out,
+                                   int32_t *sched_ws,
+                                   const pgnn_dyn_count *n_edges,
+                                   const pgnn_dyn_count *num_keypoints,
+                                   void *stream);
 
 /* Training forward of the same: the fused kernel also writes the point MLP's
  * activations -- acts_host[0..3] (a HOST array of four DEVICE pointers):
@@ -315,6 +381,17 @@ int pgnn_edge_mlp_scatter_max_fwd(const float *P, const float *Q,
                                   int32_t n_layers, int32_t edges_sorted,
                                   float *out, int64_t ld_out, int32_t *sched_ws,
                                   void *stream);
+int pgnn_edge_mlp_scatter_max_fwd_dyn(const float *P, const float *Q,
+                                      int64_t ld_pq, int32_t width,
+                                      const int32_t *edges, int64_t edges_cap,
+                                      int32_t vertices_cap,
+                                      const pgnn_fc_layer *layers_host,
+                                      int32_t n_layers, int32_t edges_sorted,
+                                      float *out, int64_t ld_out,
+                                      int32_t *sched_ws,
+                                      const pgnn_dyn_count *n_edges,
+                                      const pgnn_dyn_count *num_vertices,
+                                      void *stream);
 
 /* Training forward of the same stage with ONE remaining edge layer: the fused
  * kernel also writes that layer's per-edge output rows [n_edges, ld_rows]
@@ -359,6 +436,16 @@ int pgnn_vertex_pre_edge_fwd(const float *h, int64_t ld_h, int32_t c,
                              int64_t n_vertices, float *P, float *Q,
                              int64_t ld_pq, float *agg, int64_t ld_agg,
                              void *stream);
+int pgnn_vertex_pre_edge_fwd_dyn(const float *h, int64_t ld_h, int32_t c,
+                                 const float *xyz,
+                                 const pgnn_fc_layer *offset_layers_host,
+                                 int32_t n_offset_layers,
+                                 const pgnn_fc_layer *p_layer_host,
+                                 const float *wx, int64_t vertices_cap,
+                                 float *P, float *Q, int64_t ld_pq, float *agg,
+                                 int64_t ld_agg,
+                                 const pgnn_dyn_count *n_vertices,
+                                 void *stream);
 
 /* ---- training step (config 4: models.py:170-311, train.py:135-171,264-297,
  * 375-405, util/tf_util.py:3-43) ------------------------------------------

@@ -27,6 +27,12 @@ class FcLayer(ctypes.Structure):
                 ("relu_from", c_i32)]
 
 
+class DynCount(ctypes.Structure):
+    """struct pgnn_dyn_count: a size that lives in device memory (`dev`, an
+    int32) plus the value the host expects (`hint`)."""
+    _fields_ = [("dev", c_vp), ("hint", c_i64)]
+
+
 class PackJob(ctypes.Structure):
     """One record of pgnn_pack_fc_many's job table."""
     _fields_ = [("w", c_vp), ("b", c_vp), ("dst", c_vp), ("k_in", c_i32),
@@ -99,6 +105,13 @@ _SIGNATURES = {
     "pgnn_radius_graph_fill_f64": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_f64,
                                            c_vp, c_vp, c_sz, c_vp, c_vp, c_i64,
                                            c_vp]),
+    "pgnn_radius_graph_dyn_workspace_bytes": (c_sz, [c_i64, c_i64]),
+    "pgnn_radius_graph_dyn": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp,
+                                      c_f64, c_vp, c_vp, c_sz, c_vp, c_i64,
+                                      c_vp, c_vp]),
+    "pgnn_radius_graph_dyn_f64": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp,
+                                          c_f64, c_vp, c_vp, c_sz, c_vp, c_i64,
+                                          c_vp, c_vp]),
     "pgnn_cap_neighbors_count": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp]),
     "pgnn_cap_neighbors_fill": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_u64, c_vp,
                                         c_vp, c_i64, c_vp]),
@@ -120,6 +133,30 @@ _SIGNATURES = {
     "pgnn_mlp_fwd": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_i64,
                              ctypes.POINTER(FcLayer), c_i32, c_vp, c_i64, c_vp,
                              c_i64, c_vp]),
+    "pgnn_mlp_fwd_dyn": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_i64,
+                                 ctypes.POINTER(FcLayer), c_i32, c_vp, c_i64,
+                                 c_vp, c_i64, ctypes.POINTER(DynCount), c_vp]),
+    "pgnn_point_set_pooling_fwd_dyn": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp,
+                                               c_i64, c_i32,
+                                               ctypes.POINTER(FcLayer), c_i32,
+                                               c_i32, c_vp, c_i64, c_vp,
+                                               ctypes.POINTER(DynCount),
+                                               ctypes.POINTER(DynCount),
+                                               c_vp]),
+    "pgnn_edge_mlp_scatter_max_fwd_dyn": (c_i32, [c_vp, c_vp, c_i64, c_i32,
+                                                  c_vp, c_i64, c_i32,
+                                                  ctypes.POINTER(FcLayer),
+                                                  c_i32, c_i32, c_vp, c_i64,
+                                                  c_vp,
+                                                  ctypes.POINTER(DynCount),
+                                                  ctypes.POINTER(DynCount),
+                                                  c_vp]),
+    "pgnn_vertex_pre_edge_fwd_dyn": (c_i32, [c_vp, c_i64, c_i32, c_vp,
+                                             ctypes.POINTER(FcLayer), c_i32,
+                                             ctypes.POINTER(FcLayer), c_vp,
+                                             c_i64, c_vp, c_vp, c_i64, c_vp,
+                                             c_i64, ctypes.POINTER(DynCount),
+                                             c_vp]),
     "pgnn_point_set_pooling_fwd": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp,
                                            c_i64, c_i32,
                                            ctypes.POINTER(FcLayer), c_i32,
@@ -282,6 +319,13 @@ def load():
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    # PGNN_TUNE="key=value,key=value": tunables applied when the library is
+    # loaded (pgnn_set_tunable) -- runs a whole test session under, e.g., the
+    # frame pipeline's capped builder grids
+    for kv in filter(None, os.environ.get("PGNN_TUNE", "").split(",")):
+        k, v = kv.split("=")
+        check(lib.pgnn_set_tunable(k.strip().encode(), int(v)),
+              "PGNN_TUNE " + kv)
     return lib
 
 
@@ -324,6 +368,36 @@ def ptr(t):
     if t is None:
         return ctypes.c_void_p(0)
     return ctypes.c_void_p(t.data_ptr())
+
+
+class DeviceCount(object):
+    """A size that exists only in device memory (capacity form, struct
+    pgnn_dyn_count): `dev` is a 1-element int32 CUDA tensor, `hint` the value
+    the host expects (it chooses between kernels with identical results and
+    sizes strided grids, nothing else), `frame` the FrameCounts record it
+    belongs to.  Tensors whose leading dimension is a capacity carry one as
+    `t._pgnn_count` (tag_count / count_of)."""
+    __slots__ = ("dev", "hint", "frame")
+
+    def __init__(self, dev, hint=0, frame=None):
+        self.dev = dev
+        self.hint = int(hint)
+        self.frame = frame
+
+    def arg(self):
+        """ctypes pgnn_dyn_count* for a *_dyn entry (valid during the call)."""
+        return ctypes.byref(DynCount(self.dev.data_ptr(), self.hint))
+
+
+def tag_count(t, count):
+    """Mark tensor `t` as capacity-form: only the first `count` rows exist."""
+    if count is not None:
+        t._pgnn_count = count
+    return t
+
+
+def count_of(t):
+    return getattr(t, "_pgnn_count", None) if t is not None else None
 
 
 def set_tunable(key, value):

@@ -13,6 +13,9 @@ std::string &last_error() {
   return err;
 }
 
+int g_graph_lds_pad = 0;
+int g_graph_max_wgs = 0;
+
 int device_cu_count() {
   // per-device cache; the value never changes for a given ordinal
   static int cached[64] = {0};
@@ -235,6 +238,16 @@ extern "C" int pgnn_set_tunable(const char *key, int value) {
   if (!strcmp(key, "ws_reserve")) {
     if (value < 0 || value > 128 || value % 8) return PGNN_E_INVALID;
     pgnn::g_ws_reserve = value;
+    return 0;
+  }
+  if (!strcmp(key, "graph_lds_pad")) {
+    if (value < 0 || value > 60 * 1024) return PGNN_E_INVALID;
+    pgnn::g_graph_lds_pad = value;
+    return 0;
+  }
+  if (!strcmp(key, "graph_max_wgs")) {
+    if (value < 0 || value > 65535) return PGNN_E_INVALID;
+    pgnn::g_graph_max_wgs = value;
     return 0;
   }
   if (!strcmp(key, "ws_prio")) {

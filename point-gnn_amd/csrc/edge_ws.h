@@ -66,6 +66,9 @@ struct EdgeWsArgs {
   int ldv4;
   const int32_t *edges;  // [n_edges, 2] rows (src, dst)
   int64_t n_edges;
+  // capacity form (nullable): the edge count lives on the device and n_edges
+  // is its upper bound -- min(*n_dev, n_edges) rows are processed
+  const int32_t *n_dev;
   const float *wp;  // packed weights (pgnn_pack_fc), bias follows
   int nt;           // column tiles of the layer (= its K groups)
   int relu_from;
@@ -281,10 +284,10 @@ __device__ __forceinline__ void edge_ws_body(const EdgeWsArgs &a,
                                              const float *bias_lds,
                                              int64_t tile_first,
                                              int64_t tile_last, int lane,
-                                             long long *tsw, int &stamped) {
+                                             long long *tsw, int &stamped,
+                                             const int64_t E) {
   if (tile_first >= tile_last) return;
   const int n = lane & 15;
-  const int64_t E = a.n_edges;
   const int64_t e_first = tile_first * 16;
   const int64_t e_end = tile_last * 16 < E ? tile_last * 16 : E;
   const v4f *__restrict__ P4 = reinterpret_cast<const v4f *>(a.P);
@@ -550,7 +553,12 @@ __global__ __launch_bounds__(64 * kWsWaves) void edge_ws_kernel(EdgeWsArgs a) {
   // waves take `chunk` tiles at a time when their own range is done -- slack
   // for waves that hit more segment boundaries, slower CUs, or a late start
   // behind another stream's kernels.  A pool chunk is a range of its own.
-  const int64_t n_wt = (a.n_edges + 15) / 16;
+  int64_t n_edges = a.n_edges;
+  if (a.n_dev) {
+    const int64_t nd = *a.n_dev;
+    n_edges = nd < n_edges ? nd : n_edges;
+  }
+  const int64_t n_wt = (n_edges + 15) / 16;
   const int64_t s_first = n_wt * slice / a.xcds;
   const int64_t s_last = n_wt * (slice + 1) / a.xcds;
   const int64_t nw = (int64_t)(a.wg0[grp + 1] - a.wg0[grp]) * kWsWaves;
@@ -578,10 +586,10 @@ __global__ __launch_bounds__(64 * kWsWaves) void edge_ws_kernel(EdgeWsArgs a) {
   for (;;) {
     if (ntg == NTMAX)
       edge_ws_body<KQ, NTMAX, EMIT>(a, wl, t0, bias_lds, tile_first, tile_last,
-                                    lane, tsw, stamped);
+                                    lane, tsw, stamped, n_edges);
     else
       edge_ws_body<KQ, NTMAX - 1, EMIT>(a, wl, t0, bias_lds, tile_first,
-                                        tile_last, lane, tsw, stamped);
+                                        tile_last, lane, tsw, stamped, n_edges);
     if (pool == 0) break;
     int c = 0;
     if (lane == 0)

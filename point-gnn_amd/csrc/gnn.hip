@@ -227,8 +227,15 @@ __global__ __launch_bounds__(256, 2) void fused_mlp_kernel(
     SegArgs sa, int stage_off /* floats from tile base; < 0: in place */,
     int dbg, long long *ts /* optional per-tile timestamps (profiling) */,
     int32_t *sched /* nullable: {next pool tile, finished workgroups}, zero */,
-    int64_t n_static /* tiles below this index are partitioned statically */) {
+    int64_t n_static /* tiles below this index are partitioned statically */,
+    const int32_t *n_dev /* nullable, capacity form: the row count lives on
+                            the device, n_rows is its upper bound */,
+    int dyn_pool_pct /* with n_dev: the pool's share of the tiles */) {
   constexpr int ROWS = 16 * MSUB;
+  if (n_dev) {
+    const int64_t nd = *n_dev;
+    n_rows = nd < n_rows ? nd : n_rows;
+  }
 #ifndef PGNN_DIAG
   // the timing ablations (bits 1 / 2 / 4: drop the gather loads / the last
   // GEMM / the epilogue -- WRONG results) exist only in -DPGNN_DIAG builds
@@ -261,6 +268,12 @@ __global__ __launch_bounds__(256, 2) void fused_mlp_kernel(
   // with a pool the others pick up the difference, a tile (~30 us) at a time.
   // A pool tile is a range of its own: nothing carried in or out, boundary
   // runs flushed atomically.  sched == nullptr: everything static.
+  if (n_dev) {  // the host could not size the pool: launch_fused's rule, here
+    if (sched && n_tiles >= 6 * (int64_t)gridDim.x)
+      n_static = n_tiles - n_tiles * dyn_pool_pct / 100;
+    else
+      sched = nullptr;
+  }
   if (!sched) n_static = n_tiles;
   const int64_t tq = n_static / gridDim.x, trem = n_static % gridDim.x;
   const int64_t tile_first =
@@ -746,7 +759,9 @@ size_t plan_lds_bytes(const Plan &p, int rows) {
 template <int MSUB, int PRO>
 int launch_fused(const Plan &p, int64_t n_rows, const RowsArgs &ra,
                  const PoolArgs &pa, const EdgeArgs &ea, const SegArgs &sa,
-                 hipStream_t stream, int32_t *sched = nullptr) {
+                 hipStream_t stream, int32_t *sched = nullptr,
+                 const int32_t *n_dev = nullptr) {
+  // n_dev: capacity form -- n_rows sizes the grid, the kernel reads the count
   constexpr int ROWS = 16 * MSUB;
   const size_t lds = plan_lds_bytes(p, ROWS);
   PGNN_REQUIRE(lds <= 160 * 1024, PGNN_E_UNSUPPORTED,
@@ -765,7 +780,8 @@ int launch_fused(const Plan &p, int64_t n_rows, const RowsArgs &ra,
   // tile pool (see the kernel): g_mlp_pool_pct % of the tiles, when every
   // workgroup still keeps a static range of a few tiles
   int64_t n_static = n_tiles;
-  if (g_mlp_ts || g_mlp_pool_pct <= 0 || n_tiles < 6 * grid) sched = nullptr;
+  if (g_mlp_ts || g_mlp_pool_pct <= 0 || (!n_dev && n_tiles < 6 * grid))
+    sched = nullptr;
   if (sched) n_static = n_tiles - n_tiles * g_mlp_pool_pct / 100;
   PGNN_HIP((hipError_t)arm_sched(sched, stream));
   const int stage_off = p.stage_cols ? ROWS * p.tile_floats_per_row : -1;
@@ -778,7 +794,8 @@ int launch_fused(const Plan &p, int64_t n_rows, const RowsArgs &ra,
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, stream, p.chain,
                      n_rows, ra, pa, ea, sa, stage_off, g_mlp_debug,
-                     (long long *)g_mlp_ts, sched, n_static);
+                     (long long *)g_mlp_ts, sched, n_static, n_dev,
+                     g_mlp_pool_pct);
   PGNN_HIP(hipGetLastError());
   return 0;
 }
@@ -792,8 +809,13 @@ int launch_fused(const Plan &p, int64_t n_rows, const RowsArgs &ra,
 constexpr int kRowsWaves = 8;  // (16 waves: 128 VGPRs, spills, 13 % slower)
 
 __global__ __launch_bounds__(64 * kRowsWaves) void rows_mlp_kernel(
-    ChainDev chain, int64_t n_rows, RowsArgs ra, int stage_off) {
+    ChainDev chain, int64_t n_rows, RowsArgs ra, int stage_off,
+    const int32_t *n_dev /* nullable: capacity form, see fused_mlp_kernel */) {
   constexpr int ROWS = 16, NW = kRowsWaves;
+  if (n_dev) {
+    const int64_t nd = *n_dev;
+    n_rows = nd < n_rows ? nd : n_rows;
+  }
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float *tile = reinterpret_cast<float *>(smem);
   float *stage = stage_off >= 0 ? tile + stage_off : tile;
@@ -839,7 +861,9 @@ __global__ __launch_bounds__(64 * kRowsWaves) void rows_mlp_kernel(
 }
 
 int launch_rows8(const Plan &p, int64_t n_rows, const RowsArgs &ra,
-                 hipStream_t stream) {
+                 hipStream_t stream, const int32_t *n_dev = nullptr,
+                 int64_t grid_tiles = 0 /* capacity form: workgroups to
+                     launch (the kernel strides over the tiles) */) {
   const size_t lds = plan_lds_bytes(p, 16);
   PGNN_REQUIRE(lds <= 160 * 1024, PGNN_E_UNSUPPORTED,
                "mlp: layer too wide for the LDS tile");
@@ -850,8 +874,9 @@ int launch_rows8(const Plan &p, int64_t n_rows, const RowsArgs &ra,
   }
   const int64_t n_tiles = (n_rows + 15) / 16;
   const int stage_off = p.stage_cols ? 16 * p.tile_floats_per_row : -1;
-  hipLaunchKernelGGL(kern, dim3((unsigned)n_tiles), dim3(64 * kRowsWaves), lds,
-                     stream, p.chain, n_rows, ra, stage_off);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(grid_tiles > 0 ? grid_tiles : n_tiles)),
+                     dim3(64 * kRowsWaves), lds,
+                     stream, p.chain, n_rows, ra, stage_off, n_dev);
   PGNN_HIP(hipGetLastError());
   return 0;
 }
@@ -862,8 +887,10 @@ template <int KQ, int NTMAX>
 int launch_edge_ws(const LayerDev &L, const EdgeArgs &ea, int64_t n_edges,
                    const SegArgs &sa, int cus, int32_t *sched,
                    hipStream_t stream, float *rows_out = nullptr,
-                   int64_t ld_rows = 0, float *h1_out = nullptr) {
+                   int64_t ld_rows = 0, float *h1_out = nullptr,
+                   const int32_t *n_dev = nullptr) {
   EdgeWsArgs a = {};
+  a.n_dev = n_dev;
   a.rows_out = rows_out;
   a.ld_rows = ld_rows;
   a.h1_out = h1_out;
@@ -973,8 +1000,9 @@ bool pool_ws_applies(const Plan &p, int64_t n_edges, int cus) {
 int launch_pool_ws(const Plan &p, const PoolArgs &pa, int64_t n_edges,
                    const SegArgs &sa, int cus, int32_t *sched,
                    hipStream_t stream, float *const *acts = nullptr,
-                   int64_t ld4 = 0) {
+                   int64_t ld4 = 0, const int32_t *n_dev = nullptr) {
   PoolWsArgs a = {};
+  a.n_dev = n_dev;
   if (acts) {
     a.a1_out = acts[0];
     a.a2_out = acts[1];
@@ -1032,16 +1060,67 @@ int fill_lowest(float *out, int64_t count, hipStream_t stream) {
   return 0;
 }
 
+// Capacity form (include/pointgnn_hip.h, pgnn_dyn_count): the count an
+// operator works on lives in device memory; the ordinary size argument is
+// its capacity (grids, buffers) and `hint` the expected value, which only
+// chooses between kernels whose results are identical.
+struct Dyn {
+  const int32_t *dev;
+  int64_t hint;
+};
+inline Dyn dyn_of(const pgnn_dyn_count *c) {
+  Dyn d = {nullptr, 0};
+  if (c) {
+    d.dev = c->dev;
+    d.hint = c->hint;
+  }
+  return d;
+}
+// the size the host-side choices are made for
+inline int64_t expected(const Dyn &d, int64_t cap) {
+  return (d.dev && d.hint > 0 && d.hint < cap) ? d.hint : cap;
+}
+
+__global__ void fill_rows_dyn_kernel(float *__restrict__ out, int64_t ld,
+                                     int64_t cap_rows,
+                                     const int32_t *__restrict__ n_dev) {
+  const int64_t nd = *n_dev;
+  const int64_t total = (nd < cap_rows ? nd : cap_rows) * ld;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = kFloatLowest;
+}
+int fill_lowest_rows(float *out, int64_t ld, int64_t rows, const Dyn &d,
+                     hipStream_t stream) {
+  if (!d.dev) return fill_lowest(out, rows * ld, stream);
+  int64_t blocks = (expected(d, rows) * ld + 1023) / 1024;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(fill_rows_dyn_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     stream, out, ld, rows, d.dev);
+  PGNN_HIP(hipGetLastError());
+  return 0;
+}
+
 }  // namespace
 
-extern "C" int pgnn_mlp_fwd(const float *x, int64_t ld_x, int32_t nx,
-                            const float *x2, int64_t ld_x2, int32_t nx2,
-                            int64_t n_rows, const pgnn_fc_layer *layers,
-                            int32_t n_layers, const float *residual,
-                            int64_t ld_res, float *y, int64_t ld_y,
-                            void *stream_) {
-  PGNN_GUARD_BEGIN
-  hipStream_t stream = (hipStream_t)stream_;
+namespace {
+// workgroups for a capacity-form launch of a 16-row-tile kernel that strides
+// over its tiles: the expected tiles plus a quarter (a larger count is still
+// covered by the stride), never more than the capacity needs
+int64_t dyn_grid_tiles(const Dyn &d, int64_t cap_rows) {
+  const int64_t cap_tiles = (cap_rows + 15) / 16;
+  if (!d.dev) return cap_tiles;
+  int64_t t = (expected(d, cap_rows) + 15) / 16;
+  t += t / 4 + 8;
+  return t < cap_tiles ? t : cap_tiles;
+}
+
+int mlp_fwd_impl(const float *x, int64_t ld_x, int32_t nx, const float *x2,
+                 int64_t ld_x2, int32_t nx2, int64_t n_rows,
+                 const pgnn_fc_layer *layers, int32_t n_layers,
+                 const float *residual, int64_t ld_res, float *y, int64_t ld_y,
+                 hipStream_t stream, const Dyn &rows) {
   PGNN_REQUIRE(n_rows >= 0 && nx > 0 && nx2 >= 0, PGNN_E_INVALID,
                "mlp_fwd: bad sizes");
   if (n_rows == 0) return 0;
@@ -1058,23 +1137,57 @@ extern "C" int pgnn_mlp_fwd(const float *x, int64_t ld_x, int32_t nx,
   EdgeArgs ea = {};
   SegArgs sa = {};
   // fewer 16-row tiles than ~2 per CU: the 8-wave kernel (latency bound);
-  // small row counts: 16-row tiles keep all CUs busy; large: 64-row tiles
-  if (n_rows <= 32 * (int64_t)device_cu_count() && !(g_mlp_debug & 512))
-    return launch_rows8(p, n_rows, ra, stream);
-  if (n_rows <= 64 * (int64_t)device_cu_count())
-    return launch_fused<1, PRO_ROWS>(p, n_rows, ra, pa, ea, sa, stream);
-  return launch_fused<4, PRO_ROWS>(p, n_rows, ra, pa, ea, sa, stream);
+  // small row counts: 16-row tiles keep all CUs busy; large: 64-row tiles.
+  // (Every output element is the same MFMA sequence over k in all three, so
+  // the choice -- made on the expected count in the capacity form -- does not
+  // change a bit of the result.)
+  const int64_t n_sel = expected(rows, n_rows);
+  if (n_sel <= 32 * (int64_t)device_cu_count() && !(g_mlp_debug & 512))
+    return launch_rows8(p, n_rows, ra, stream, rows.dev,
+                        rows.dev ? dyn_grid_tiles(rows, n_rows) : 0);
+  if (n_sel <= 64 * (int64_t)device_cu_count())
+    return launch_fused<1, PRO_ROWS>(p, n_rows, ra, pa, ea, sa, stream, nullptr,
+                                     rows.dev);
+  return launch_fused<4, PRO_ROWS>(p, n_rows, ra, pa, ea, sa, stream, nullptr,
+                                   rows.dev);
+}
+}  // namespace
+
+extern "C" int pgnn_mlp_fwd(const float *x, int64_t ld_x, int32_t nx,
+                            const float *x2, int64_t ld_x2, int32_t nx2,
+                            int64_t n_rows, const pgnn_fc_layer *layers,
+                            int32_t n_layers, const float *residual,
+                            int64_t ld_res, float *y, int64_t ld_y,
+                            void *stream_) {
+  PGNN_GUARD_BEGIN
+  return mlp_fwd_impl(x, ld_x, nx, x2, ld_x2, nx2, n_rows, layers, n_layers,
+                      residual, ld_res, y, ld_y, (hipStream_t)stream_,
+                      dyn_of(nullptr));
   PGNN_GUARD_END
 }
 
-extern "C" int pgnn_point_set_pooling_fwd(
-    const float *point_features, int32_t n_feat, const float *point_xyz,
-    const int32_t *keypoint_indices, const int32_t *edges, int64_t n_edges,
-    int32_t num_keypoints, const pgnn_fc_layer *layers, int32_t n_layers,
-    int32_t edges_sorted, float *out, int64_t ld_out, int32_t *sched_ws,
-    void *stream_) {
+extern "C" int pgnn_mlp_fwd_dyn(const float *x, int64_t ld_x, int32_t nx,
+                                const float *x2, int64_t ld_x2, int32_t nx2,
+                                int64_t rows_cap, const pgnn_fc_layer *layers,
+                                int32_t n_layers, const float *residual,
+                                int64_t ld_res, float *y, int64_t ld_y,
+                                const pgnn_dyn_count *rows, void *stream_) {
   PGNN_GUARD_BEGIN
-  hipStream_t stream = (hipStream_t)stream_;
+  PGNN_REQUIRE(rows && rows->dev, PGNN_E_INVALID, "mlp_fwd_dyn: null count");
+  return mlp_fwd_impl(x, ld_x, nx, x2, ld_x2, nx2, rows_cap, layers, n_layers,
+                      residual, ld_res, y, ld_y, (hipStream_t)stream_,
+                      dyn_of(rows));
+  PGNN_GUARD_END
+}
+
+namespace {
+int pooling_fwd_impl(const float *point_features, int32_t n_feat,
+                     const float *point_xyz, const int32_t *keypoint_indices,
+                     const int32_t *edges, int64_t n_edges,
+                     int32_t num_keypoints, const pgnn_fc_layer *layers,
+                     int32_t n_layers, int32_t edges_sorted, float *out,
+                     int64_t ld_out, int32_t *sched_ws, hipStream_t stream,
+                     const Dyn &de, const Dyn &dk) {
   PGNN_REQUIRE(n_edges >= 0 && num_keypoints >= 0 && n_feat >= 0 && n_feat <= 13,
                PGNN_E_INVALID, "pooling: bad sizes (n_feat <= 13)");
   Plan p;
@@ -1086,7 +1199,7 @@ extern "C" int pgnn_point_set_pooling_fwd(
   PGNN_REQUIRE(out && ld_out >= out_cols, PGNN_E_INVALID,
                "pooling: ld_out < padded output width");
   if (num_keypoints == 0) return 0;
-  rc = fill_lowest(out, (int64_t)num_keypoints * ld_out, stream);
+  rc = fill_lowest_rows(out, ld_out, num_keypoints, dk, stream);
   if (rc) return rc;
   if (n_edges == 0) return 0;
   PGNN_REQUIRE((n_feat == 0 || point_features) && point_xyz &&
@@ -1111,26 +1224,28 @@ extern "C" int pgnn_point_set_pooling_fwd(
   {
     int cus = stream_cu_count(stream);
     if (g_ws_reserve > 0 && cus - g_ws_reserve >= 64) cus -= g_ws_reserve;
-    if (pool_ws_applies(p, n_edges, cus))
-      return launch_pool_ws(p, pa, n_edges, sa, cus, sched_ws, stream);
+    // (capacity form: chosen on the expected count; the two kernels give
+    // bit-identical maxima, tests/test_gpu_parity.py)
+    if (pool_ws_applies(p, expected(de, n_edges), cus))
+      return launch_pool_ws(p, pa, n_edges, sa, cus, sched_ws, stream, nullptr,
+                            0, de.dev);
   }
   if (msub == 4 && pa.reg_hidden == 1)
     return launch_fused<4, PRO_POOL_R3>(p, n_edges, ra, pa, ea, sa, stream,
-                                        sched_ws);
+                                        sched_ws, de.dev);
   if (msub == 4)
     return launch_fused<4, PRO_POOL>(p, n_edges, ra, pa, ea, sa, stream,
-                                     sched_ws);
-  return launch_fused<2, PRO_POOL>(p, n_edges, ra, pa, ea, sa, stream, sched_ws);
-  PGNN_GUARD_END
+                                     sched_ws, de.dev);
+  return launch_fused<2, PRO_POOL>(p, n_edges, ra, pa, ea, sa, stream, sched_ws,
+                                   de.dev);
 }
 
-extern "C" int pgnn_edge_mlp_scatter_max_fwd(
-    const float *P, const float *Q, int64_t ld_pq, int32_t width,
-    const int32_t *edges, int64_t n_edges, int32_t num_vertices,
-    const pgnn_fc_layer *layers, int32_t n_layers, int32_t edges_sorted,
-    float *out, int64_t ld_out, int32_t *sched_ws, void *stream_) {
-  PGNN_GUARD_BEGIN
-  hipStream_t stream = (hipStream_t)stream_;
+int edge_fwd_impl(const float *P, const float *Q, int64_t ld_pq, int32_t width,
+                  const int32_t *edges, int64_t n_edges, int32_t num_vertices,
+                  const pgnn_fc_layer *layers, int32_t n_layers,
+                  int32_t edges_sorted, float *out, int64_t ld_out,
+                  int32_t *sched_ws, hipStream_t stream, const Dyn &de,
+                  const Dyn &dk) {
   PGNN_REQUIRE(n_edges >= 0 && num_vertices >= 0 && width > 0, PGNN_E_INVALID,
                "edge_mlp: bad sizes");
   Plan p;
@@ -1143,7 +1258,7 @@ extern "C" int pgnn_edge_mlp_scatter_max_fwd(
                "edge_mlp: ld_out < padded output width");
   if (num_vertices == 0) return 0;
   if (!(edges_sorted & 2)) {  // bit 1: caller already filled `out` with lowest()
-    rc = fill_lowest(out, (int64_t)num_vertices * ld_out, stream);
+    rc = fill_lowest_rows(out, ld_out, num_vertices, dk, stream);
     if (rc) return rc;
   }
   if (n_edges == 0) return 0;
@@ -1157,12 +1272,13 @@ extern "C" int pgnn_edge_mlp_scatter_max_fwd(
   {
     int cus = stream_cu_count(stream);
     if (g_ws_reserve > 0 && cus - g_ws_reserve >= 64) cus -= g_ws_reserve;
-    if (edge_ws_applies(p, n_edges, cus)) {
+    if (edge_ws_applies(p, expected(de, n_edges), cus)) {
       if (p.chain.l[0].nt == 19)
         return launch_edge_ws<19, 7>(p.chain.l[0], ea, n_edges, sa, cus,
-                                     sched_ws, stream);
+                                     sched_ws, stream, nullptr, 0, nullptr,
+                                     de.dev);
       return launch_edge_ws<16, 8>(p.chain.l[0], ea, n_edges, sa, cus, sched_ws,
-                                   stream);
+                                   stream, nullptr, 0, nullptr, de.dev);
     }
   }
   int msub = g_edge_msub;
@@ -1171,8 +1287,71 @@ extern "C" int pgnn_edge_mlp_scatter_max_fwd(
             plan_lds_bytes(p, 32) > 80 * 1024) ? 4 : 2;
   if (msub == 4)
     return launch_fused<4, PRO_EDGE>(p, n_edges, ra, pa, ea, sa, stream,
-                                     sched_ws);
-  return launch_fused<2, PRO_EDGE>(p, n_edges, ra, pa, ea, sa, stream, sched_ws);
+                                     sched_ws, de.dev);
+  return launch_fused<2, PRO_EDGE>(p, n_edges, ra, pa, ea, sa, stream, sched_ws,
+                                   de.dev);
+}
+}  // namespace
+
+extern "C" int pgnn_point_set_pooling_fwd(
+    const float *point_features, int32_t n_feat, const float *point_xyz,
+    const int32_t *keypoint_indices, const int32_t *edges, int64_t n_edges,
+    int32_t num_keypoints, const pgnn_fc_layer *layers, int32_t n_layers,
+    int32_t edges_sorted, float *out, int64_t ld_out, int32_t *sched_ws,
+    void *stream_) {
+  PGNN_GUARD_BEGIN
+  return pooling_fwd_impl(point_features, n_feat, point_xyz, keypoint_indices,
+                          edges, n_edges, num_keypoints, layers, n_layers,
+                          edges_sorted, out, ld_out, sched_ws,
+                          (hipStream_t)stream_, dyn_of(nullptr),
+                          dyn_of(nullptr));
+  PGNN_GUARD_END
+}
+
+extern "C" int pgnn_point_set_pooling_fwd_dyn(
+    const float *point_features, int32_t n_feat, const float *point_xyz,
+    const int32_t *keypoint_indices, const int32_t *edges, int64_t edges_cap,
+    int32_t keypoints_cap, const pgnn_fc_layer *layers, int32_t n_layers,
+    int32_t edges_sorted, float *out, int64_t ld_out, int32_t *sched_ws,
+    const pgnn_dyn_count *n_edges, const pgnn_dyn_count *num_keypoints,
+    void *stream_) {
+  PGNN_GUARD_BEGIN
+  PGNN_REQUIRE(n_edges && n_edges->dev && num_keypoints && num_keypoints->dev,
+               PGNN_E_INVALID, "pooling_dyn: null count");
+  return pooling_fwd_impl(point_features, n_feat, point_xyz, keypoint_indices,
+                          edges, edges_cap, keypoints_cap, layers, n_layers,
+                          edges_sorted, out, ld_out, sched_ws,
+                          (hipStream_t)stream_, dyn_of(n_edges),
+                          dyn_of(num_keypoints));
+  PGNN_GUARD_END
+}
+
+extern "C" int pgnn_edge_mlp_scatter_max_fwd(
+    const float *P, const float *Q, int64_t ld_pq, int32_t width,
+    const int32_t *edges, int64_t n_edges, int32_t num_vertices,
+    const pgnn_fc_layer *layers, int32_t n_layers, int32_t edges_sorted,
+    float *out, int64_t ld_out, int32_t *sched_ws, void *stream_) {
+  PGNN_GUARD_BEGIN
+  return edge_fwd_impl(P, Q, ld_pq, width, edges, n_edges, num_vertices, layers,
+                       n_layers, edges_sorted, out, ld_out, sched_ws,
+                       (hipStream_t)stream_, dyn_of(nullptr), dyn_of(nullptr));
+  PGNN_GUARD_END
+}
+
+extern "C" int pgnn_edge_mlp_scatter_max_fwd_dyn(
+    const float *P, const float *Q, int64_t ld_pq, int32_t width,
+    const int32_t *edges, int64_t edges_cap, int32_t vertices_cap,
+    const pgnn_fc_layer *layers, int32_t n_layers, int32_t edges_sorted,
+    float *out, int64_t ld_out, int32_t *sched_ws,
+    const pgnn_dyn_count *n_edges, const pgnn_dyn_count *num_vertices,
+    void *stream_) {
+  PGNN_GUARD_BEGIN
+  PGNN_REQUIRE(n_edges && n_edges->dev && num_vertices && num_vertices->dev,
+               PGNN_E_INVALID, "edge_mlp_dyn: null count");
+  return edge_fwd_impl(P, Q, ld_pq, width, edges, edges_cap, vertices_cap,
+                       layers, n_layers, edges_sorted, out, ld_out, sched_ws,
+                       (hipStream_t)stream_, dyn_of(n_edges),
+                       dyn_of(num_vertices));
   PGNN_GUARD_END
 }
 
@@ -1192,6 +1371,7 @@ struct PreEdgeArgs {
   const float *xyz;
   const float *wx;
   int64_t n;
+  const int32_t *n_dev;  // nullable: capacity form (the count is on the device)
   float *P, *Q;
   int64_t ld_pq;
   float *agg;
@@ -1199,6 +1379,7 @@ struct PreEdgeArgs {
   int ld_tile, ld_scratch;  // LDS leading dimensions
 };
 
+template <bool STRIDE>
 __global__ __launch_bounds__(64 * kRowsWaves) void vertex_pre_edge_kernel(
     ChainDev off, LayerDev pl, PreEdgeArgs a) {
   constexpr int ROWS = 16;
@@ -1208,9 +1389,18 @@ __global__ __launch_bounds__(64 * kRowsWaves) void vertex_pre_edge_kernel(
   float *stage = scratch + ROWS * a.ld_scratch;       // P before it leaves
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t row0 = (int64_t)blockIdx.x * ROWS;
+  int64_t n_rows = a.n;
+  if (a.n_dev) {
+    const int64_t nd = *a.n_dev;
+    n_rows = nd < n_rows ? nd : n_rows;
+  }
+  // one tile per workgroup when the host knows the count (STRIDE = false: the
+  // loop below runs once and folds away); the capacity form launches for the
+  // expected count and strides
+  for (int64_t row0 = (int64_t)blockIdx.x * ROWS; row0 < n_rows;
+       row0 += STRIDE ? (int64_t)gridDim.x * ROWS : n_rows) {
   const int rows_valid =
-      (int)((a.n - row0 < ROWS) ? (a.n - row0) : ROWS);
+      (int)((n_rows - row0 < ROWS) ? (n_rows - row0) : ROWS);
   const int kc = 16 * pl.kq;
   for (int idx = threadIdx.x; idx < ROWS * kc; idx += 64 * kRowsWaves) {
     const int r = idx / kc, c = idx - r * kc;
@@ -1263,17 +1453,19 @@ __global__ __launch_bounds__(64 * kRowsWaves) void vertex_pre_edge_kernel(
   ra.y = a.P;
   ra.ldy = a.ld_pq;
   consume_rows<ROWS>(stage, ld_st, row0, rows_valid, 0, 16 * pl.nt, ra);
+  if (STRIDE) __syncthreads();  // the next tile overwrites tile / scratch / stage
+  }
 }
 
 }  // namespace
 
-extern "C" int pgnn_vertex_pre_edge_fwd(
+namespace {
+int pre_edge_impl(
     const float *h, int64_t ld_h, int32_t c, const float *xyz,
     const pgnn_fc_layer *offset_layers, int32_t n_offset_layers,
     const pgnn_fc_layer *p_layer, const float *wx, int64_t n_vertices, float *P,
-    float *Q, int64_t ld_pq, float *agg, int64_t ld_agg, void *stream_) {
-  PGNN_GUARD_BEGIN
-  hipStream_t stream = (hipStream_t)stream_;
+    float *Q, int64_t ld_pq, float *agg, int64_t ld_agg, hipStream_t stream,
+    const Dyn &dk) {
   PGNN_REQUIRE(n_vertices >= 0 && c > 0 && ld_h >= c && n_offset_layers >= 0 &&
                    n_offset_layers <= PGNN_MAX_LAYERS && p_layer,
                PGNN_E_INVALID, "vertex_pre_edge: bad argument");
@@ -1314,6 +1506,7 @@ extern "C" int pgnn_vertex_pre_edge_fwd(
   a.xyz = xyz;
   a.wx = wx;
   a.n = n_vertices;
+  a.n_dev = dk.dev;
   a.P = P;
   a.Q = Q;
   a.ld_pq = ld_pq;
@@ -1325,15 +1518,42 @@ extern "C" int pgnn_vertex_pre_edge_fwd(
       (size_t)16 * (a.ld_tile + a.ld_scratch + lds_ld(16 * pl.nt)) * 4;
   PGNN_REQUIRE(lds <= 160 * 1024, PGNN_E_UNSUPPORTED,
                "vertex_pre_edge: layer too wide for the LDS tile");
-  auto kern = vertex_pre_edge_kernel;
+  auto kern = dk.dev ? vertex_pre_edge_kernel<true> : vertex_pre_edge_kernel<false>;
   {
     const int lrc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
     if (lrc) return lrc;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)((n_vertices + 15) / 16)),
+  hipLaunchKernelGGL(kern, dim3((unsigned)dyn_grid_tiles(dk, n_vertices)),
                      dim3(64 * kRowsWaves), lds, stream, off, pl, a);
   PGNN_HIP(hipGetLastError());
   return 0;
+}
+}  // namespace
+
+extern "C" int pgnn_vertex_pre_edge_fwd(
+    const float *h, int64_t ld_h, int32_t c, const float *xyz,
+    const pgnn_fc_layer *offset_layers, int32_t n_offset_layers,
+    const pgnn_fc_layer *p_layer, const float *wx, int64_t n_vertices, float *P,
+    float *Q, int64_t ld_pq, float *agg, int64_t ld_agg, void *stream_) {
+  PGNN_GUARD_BEGIN
+  return pre_edge_impl(h, ld_h, c, xyz, offset_layers, n_offset_layers, p_layer,
+                       wx, n_vertices, P, Q, ld_pq, agg, ld_agg,
+                       (hipStream_t)stream_, dyn_of(nullptr));
+  PGNN_GUARD_END
+}
+
+extern "C" int pgnn_vertex_pre_edge_fwd_dyn(
+    const float *h, int64_t ld_h, int32_t c, const float *xyz,
+    const pgnn_fc_layer *offset_layers, int32_t n_offset_layers,
+    const pgnn_fc_layer *p_layer, const float *wx, int64_t vertices_cap,
+    float *P, float *Q, int64_t ld_pq, float *agg, int64_t ld_agg,
+    const pgnn_dyn_count *n_vertices, void *stream_) {
+  PGNN_GUARD_BEGIN
+  PGNN_REQUIRE(n_vertices && n_vertices->dev, PGNN_E_INVALID,
+               "vertex_pre_edge_dyn: null count");
+  return pre_edge_impl(h, ld_h, c, xyz, offset_layers, n_offset_layers, p_layer,
+                       wx, vertices_cap, P, Q, ld_pq, agg, ld_agg,
+                       (hipStream_t)stream_, dyn_of(n_vertices));
   PGNN_GUARD_END
 }
 

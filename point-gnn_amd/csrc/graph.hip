@@ -128,26 +128,32 @@ __global__ void cell_keys_kernel(const T *__restrict__ pts, int64_t n,
                                  double cell, uint32_t mask,
                                  uint32_t *__restrict__ keys,
                                  uint32_t *__restrict__ vals,
-                                 int32_t *__restrict__ vcell) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  double x, y, z;
-  load_point(pts, i, sc, x, y, z);
-  if (origin_dev) {  // keypoint grid: the rule record of grid_origin_kernel
-    // the voxel index is evaluated ONCE per point (NumPy's floor_divide is an
-    // fmod; the leader / pick kernels compare the stored integers)
-    const int vx = vox_cell(origin_dev, 0, x, cell),
-              vy = vox_cell(origin_dev, 1, y, cell),
-              vz = vox_cell(origin_dev, 2, z, cell);
-    keys[i] = cell_hash(vx, vy, vz, mask);
-    vcell[3 * i] = vx;
-    vcell[3 * i + 1] = vy;
-    vcell[3 * i + 2] = vz;
-  } else {
-    keys[i] = cell_hash(cell_of(x, ox, cell), cell_of(y, oy, cell),
-                        cell_of(z, oz, cell), mask);
+                                 int32_t *__restrict__ vcell,
+                                 const int32_t *__restrict__ n_dev) {
+  graph_prio();
+  // n_dev (nullable): the point count when only the device knows it (the
+  // keypoints of this frame); n is then the capacity the grid is sized for
+  if (n_dev) n = *n_dev < n ? *n_dev : n;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    double x, y, z;
+    load_point(pts, i, sc, x, y, z);
+    if (origin_dev) {  // keypoint grid: the rule record of grid_origin_kernel
+      // the voxel index is evaluated ONCE per point (NumPy's floor_divide is
+      // an fmod; the leader / pick kernels compare the stored integers)
+      const int vx = vox_cell(origin_dev, 0, x, cell),
+                vy = vox_cell(origin_dev, 1, y, cell),
+                vz = vox_cell(origin_dev, 2, z, cell);
+      keys[i] = cell_hash(vx, vy, vz, mask);
+      vcell[3 * i] = vx;
+      vcell[3 * i + 1] = vy;
+      vcell[3 * i + 2] = vz;
+    } else {
+      keys[i] = cell_hash(cell_of(x, ox, cell), cell_of(y, oy, cell),
+                          cell_of(z, oz, cell), mask);
+    }
+    vals[i] = (uint32_t)i;
   }
-  vals[i] = (uint32_t)i;
 }
 
 template <typename T>
@@ -158,86 +164,146 @@ __global__ void cell_bounds_kernel(const uint32_t *__restrict__ keys,
                                    int32_t *__restrict__ cell_end,
                                    SortedPoint *__restrict__ sorted,
                                    const int32_t *__restrict__ vcell,
-                                   int32_t *__restrict__ vcell_sorted) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t k = keys[i];
-  if (i == 0 || keys[i - 1] != k) cell_start[k] = (int32_t)i;
-  if (i == n - 1 || keys[i + 1] != k) cell_end[k] = (int32_t)(i + 1);
-  SortedPoint sp;
-  const uint32_t idx = vals[i];
-  load_point(pts, idx, sc, sp.x, sp.y, sp.z);
-  sp.idx = (int32_t)idx;
-  sp.pad = 0;
-  sorted[i] = sp;
-  if (vcell) {
-    vcell_sorted[3 * i] = vcell[3 * (int64_t)idx];
-    vcell_sorted[3 * i + 1] = vcell[3 * (int64_t)idx + 1];
-    vcell_sorted[3 * i + 2] = vcell[3 * (int64_t)idx + 2];
+                                   int32_t *__restrict__ vcell_sorted,
+                                   const int32_t *__restrict__ n_dev) {
+  graph_prio();
+  if (n_dev) n = *n_dev < n ? *n_dev : n;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t k = keys[i];
+    if (i == 0 || keys[i - 1] != k) cell_start[k] = (int32_t)i;
+    if (i == n - 1 || keys[i + 1] != k) cell_end[k] = (int32_t)(i + 1);
+    SortedPoint sp;
+    const uint32_t idx = vals[i];
+    load_point(pts, idx, sc, sp.x, sp.y, sp.z);
+    sp.idx = (int32_t)idx;
+    sp.pad = 0;
+    sorted[i] = sp;
+    if (vcell) {
+      vcell_sorted[3 * i] = vcell[3 * (int64_t)idx];
+      vcell_sorted[3 * i + 1] = vcell[3 * (int64_t)idx + 1];
+      vcell_sorted[3 * i + 2] = vcell[3 * (int64_t)idx + 2];
+    }
   }
 }
 
 // ---- radius search -------------------------------------------------------------
-// One wave per centre.  FILL = false: write the neighbour count; FILL = true:
-// write (point, centre) rows at offsets[centre].
+// One wave per centre (a wave takes centres wave_id, + total waves, ...).
+// FILL = false: write the neighbour count; FILL = true: write (point, centre)
+// rows at offsets[centre].
+//
+// The cells that can hold a neighbour are a box of at most 4 x 4 x 4 cells of
+// edge r around the centre (3 per axis, 4 when the centre sits within 1e-9 r of
+// a cell face).  Lane c looks up cell c's bucket -- all (start, end) pairs in
+// ONE round of loads -- and a wave scan turns the bucket sizes into offsets of
+// one concatenated candidate list, which the wave then walks 64 candidates at
+// a time (cell order z, y, x and slot order inside a bucket: the order of the
+// nested loops this replaces, so rows come out in the same order).  The
+// nested form made ~2 dependent memory round trips per cell, 54+ per centre;
+// this one makes 2 plus one per 64 candidates -- the kernel is a chain of such
+// round trips, and beside the message passing of another frame each of them
+// takes several times longer.
 template <bool FILL, typename T>
-__global__ __launch_bounds__(256) void radius_query_kernel(
+__global__ __launch_bounds__(1024) void radius_query_kernel(
     const T *__restrict__ centers, int64_t n_centers, Scale3 sc, double r,
     uint32_t mask, const int32_t *__restrict__ cell_start,
     const int32_t *__restrict__ cell_end,
     const SortedPoint *__restrict__ sorted, int32_t *__restrict__ counts,
     const int32_t *__restrict__ offsets, int32_t *__restrict__ edges,
-    int64_t capacity) {
+    int64_t capacity, const int32_t *__restrict__ n_centers_dev) {
+  graph_prio();
   const int lane = threadIdx.x & 63;
-  const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (q >= n_centers) return;
-  double cx, cy, cz;
-  load_point(centers, q, sc, cx, cy, cz);
+  const int wpb = blockDim.x >> 6;
+  const int64_t wave0 = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6);
+  const int64_t n_waves = (int64_t)gridDim.x * wpb;
+  const int64_t cap = n_centers;
+  if (n_centers_dev)
+    // capacity form: n_centers is the capacity, the count is on the device
+    n_centers = *n_centers_dev < cap ? *n_centers_dev : cap;
   const double r2 = r * r;
   // cells that can hold a point within r: widen by a relative 1e-9 so that
   // rounding in (v - origin) / cell can never exclude a true neighbour
   const double rr = r * (1.0 + 1e-9) + 1e-300;
-  const int x0 = cell_of(cx - rr, 0.0, r), x1 = cell_of(cx + rr, 0.0, r);
-  const int y0 = cell_of(cy - rr, 0.0, r), y1 = cell_of(cy + rr, 0.0, r);
-  const int z0 = cell_of(cz - rr, 0.0, r), z1 = cell_of(cz + rr, 0.0, r);
-  int64_t out_pos = FILL ? (int64_t)offsets[q] : 0;
-  int total = 0;
-  for (int iz = z0; iz <= z1; ++iz)
-    for (int iy = y0; iy <= y1; ++iy)
-      for (int ix = x0; ix <= x1; ++ix) {
-        const uint32_t b = cell_hash(ix, iy, iz, mask);
-        const int s = cell_start[b], e = cell_end[b];
-        for (int i0 = s; i0 < e; i0 += 64) {
-          const int i = i0 + lane;
-          bool hit = false;
-          int pidx = 0;
-          if (i < e) {
-            const SortedPoint sp = sorted[i];
-            pidx = sp.idx;
-            if (cell_of(sp.x, 0.0, r) == ix && cell_of(sp.y, 0.0, r) == iy &&
-                cell_of(sp.z, 0.0, r) == iz) {
-              const double dx = sp.x - cx, dy = sp.y - cy, dz = sp.z - cz;
-              const double d2 = (dx * dx + dy * dy) + dz * dz;
-              hit = d2 <= r2;
-            }
-          }
-          const unsigned long long m = __ballot(hit);
-          if (FILL) {
-            if (hit) {
-              const int64_t pos =
-                  out_pos + __popcll(m & ((1ull << lane) - 1ull));
-              if (pos < capacity) {
-                edges[2 * pos] = pidx;
-                edges[2 * pos + 1] = (int32_t)q;
-              }
-            }
-            out_pos += __popcll(m);
-          } else {
-            total += __popcll(m);
-          }
+  for (int64_t q = wave0; q < cap; q += n_waves) {
+    if (q >= n_centers) {
+      // the slots behind the count get a zero so that the scan over the whole
+      // capacity leaves the edge total in its last entry
+      if (!FILL && lane == 0) counts[q] = 0;
+      continue;
+    }
+    double cx, cy, cz;
+    load_point(centers, q, sc, cx, cy, cz);
+    const int x0 = cell_of(cx - rr, 0.0, r), x1 = cell_of(cx + rr, 0.0, r);
+    const int y0 = cell_of(cy - rr, 0.0, r), y1 = cell_of(cy + rr, 0.0, r);
+    const int z0 = cell_of(cz - rr, 0.0, r), z1 = cell_of(cz + rr, 0.0, r);
+    const int nx = x1 - x0 + 1, ny = y1 - y0 + 1, nz = z1 - z0 + 1;
+    const int n_cells = nx * ny * nz;  // <= 64 (see above)
+    // lane c: cell c of the box in (z, y, x) order
+    int my_s = 0, my_cnt = 0, my_ix = 0, my_iy = 0, my_iz = 0;
+    if (lane < n_cells) {
+      my_ix = x0 + lane % nx;
+      my_iy = y0 + (lane / nx) % ny;
+      my_iz = z0 + lane / (nx * ny);
+      const uint32_t b = cell_hash(my_ix, my_iy, my_iz, mask);
+      my_s = cell_start[b];
+      my_cnt = cell_end[b] - my_s;
+    }
+    int incl = my_cnt;  // inclusive scan of the bucket sizes over the lanes
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(incl, d);
+      if (lane >= d) incl += t;
+    }
+    const int total_cand = __shfl(incl, 63);
+    int64_t out_pos = FILL ? (int64_t)offsets[q] : 0;
+    int total = 0;
+    for (int j0 = 0; j0 < total_cand; j0 += 64) {
+      // every lane runs the search and the shuffles (a shuffle may only read
+      // lanes that execute it); lanes past the end repeat the last candidate
+      // and skip the load
+      const bool valid = j0 + lane < total_cand;
+      const int j = valid ? j0 + lane : total_cand - 1;
+      // the cell whose candidate range holds j: first lane with incl > j
+      int lo = 0, hi = n_cells - 1;
+#pragma unroll
+      for (int step = 0; step < 6; ++step) {
+        const int mid = (lo + hi) >> 1;
+        const int v = __shfl(incl, mid);
+        if (v > j) hi = mid; else lo = mid + 1;
+      }
+      const int c = lo < n_cells ? lo : n_cells - 1;
+      const int c_incl = __shfl(incl, c), c_cnt = __shfl(my_cnt, c);
+      const int c_s = __shfl(my_s, c);
+      const int ix = __shfl(my_ix, c), iy = __shfl(my_iy, c),
+                iz = __shfl(my_iz, c);
+      bool hit = false;
+      int pidx = 0;
+      if (valid) {
+        const SortedPoint sp = sorted[c_s + (j - (c_incl - c_cnt))];
+        pidx = sp.idx;
+        if (cell_of(sp.x, 0.0, r) == ix && cell_of(sp.y, 0.0, r) == iy &&
+            cell_of(sp.z, 0.0, r) == iz) {
+          const double dx = sp.x - cx, dy = sp.y - cy, dz = sp.z - cz;
+          const double d2 = (dx * dx + dy * dy) + dz * dz;
+          hit = d2 <= r2;
         }
       }
-  if (!FILL && lane == 0) counts[q] = total;
+      const unsigned long long m = __ballot(hit);
+      if (FILL) {
+        if (hit) {
+          const int64_t pos = out_pos + __popcll(m & ((1ull << lane) - 1ull));
+          if (pos < capacity) {
+            edges[2 * pos] = pidx;
+            edges[2 * pos + 1] = (int32_t)q;
+          }
+        }
+        out_pos += __popcll(m);
+      } else {
+        total += __popcll(m);
+      }
+    }
+    if (!FILL && lane == 0) counts[q] = total;
+  }
 }
 
 // ---- neighbour cap (training) ---------------------------------------------------
@@ -253,6 +319,7 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
 __global__ void cap_counts_kernel(const int32_t *__restrict__ offsets,
                                   int64_t n, int32_t cap,
                                   int32_t *__restrict__ counts) {
+  graph_prio();
   int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= n) return;
   int c = offsets[q + 1] - offsets[q];
@@ -268,6 +335,7 @@ __global__ __launch_bounds__(256) void cap_fill_kernel(
     int64_t n, int32_t cap, uint64_t seed,
     const int32_t *__restrict__ new_offsets, int32_t *__restrict__ new_edges,
     int64_t capacity) {
+  graph_prio();
   const int lane = threadIdx.x & 63;
   const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q >= n) return;
@@ -322,6 +390,7 @@ __device__ __forceinline__ double ordered_to_double(unsigned long long u) {
 template <typename T>
 __global__ void min_bound_kernel(const T *__restrict__ pts, int64_t n,
                                  unsigned long long *__restrict__ ordered_min) {
+  graph_prio();
   unsigned long long m0 = ~0ull, m1 = ~0ull, m2 = ~0ull;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * blockDim.x) {
@@ -355,6 +424,7 @@ __global__ void min_bound_kernel(const T *__restrict__ pts, int64_t n,
 __global__ void grid_origin_kernel(
     const unsigned long long *__restrict__ ordered_min, double sub_x,
     double sub_y, double sub_z, int mode, double *__restrict__ origin) {
+  graph_prio();
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     const double sub[3] = {sub_x, sub_y, sub_z};
     for (int ax = 0; ax < 3; ++ax) {
@@ -378,78 +448,122 @@ __global__ void voxel_leader_kernel(const SortedPoint *__restrict__ sorted,
                                     int32_t *__restrict__ is_leader,
                                     double *__restrict__ centroid,
                                     int32_t *__restrict__ member_count) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int vx = vc[3 * i], vy = vc[3 * i + 1], vz = vc[3 * i + 2];
-  const uint32_t b = keys[i];
-  const int s = cell_start[b], e = cell_end[b];
-  // Leader = the first slot of this voxel in its bucket.  A bucket nearly
-  // always holds ONE voxel (>= 2 buckets per point): a slot whose voxel is the
-  // bucket's first voxel is a leader iff it is the first slot -- no search;
-  // only the members of a colliding second voxel walk the slots before them
-  // (the walk made this kernel O(members^2) per voxel: 300 us at voxel 0.8 m)
-  bool leader;
-  if (vc[3 * s] == vx && vc[3 * s + 1] == vy && vc[3 * s + 2] == vz) {
-    leader = (int)i == s;
-  } else {
-    leader = true;
-    for (int j = s; j < (int)i; ++j) {
-      if (vc[3 * j] == vx && vc[3 * j + 1] == vy && vc[3 * j + 2] == vz) {
-        leader = false;
-        break;
+  graph_prio();
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int vx = vc[3 * i], vy = vc[3 * i + 1], vz = vc[3 * i + 2];
+    const uint32_t b = keys[i];
+    const int s = cell_start[b], e = cell_end[b];
+    // Leader = the first slot of this voxel in its bucket.  A bucket nearly
+    // always holds ONE voxel (>= 2 buckets per point): a slot whose voxel is
+    // the bucket's first voxel is a leader iff it is the first slot -- no
+    // search; only the members of a colliding second voxel walk the slots
+    // before them (the walk made this kernel O(members^2) per voxel: 300 us at
+    // voxel 0.8 m)
+    bool leader;
+    if (vc[3 * s] == vx && vc[3 * s + 1] == vy && vc[3 * s + 2] == vz) {
+      leader = (int)i == s;
+    } else {
+      leader = true;
+      for (int j = s; j < (int)i; ++j) {
+        if (vc[3 * j] == vx && vc[3 * j + 1] == vy && vc[3 * j + 2] == vz) {
+          leader = false;
+          break;
+        }
       }
     }
-  }
-  is_leader[i] = leader ? 1 : 0;
-  if (!leader) return;
-  double sx = 0.0, sy = 0.0, sz = 0.0;
-  int cnt = 0;
-  for (int j = (int)i; j < e; ++j) {
-    if (vc[3 * j] == vx && vc[3 * j + 1] == vy && vc[3 * j + 2] == vz) {
-      const SortedPoint o = sorted[j];
-      sx += o.x;
-      sy += o.y;
-      sz += o.z;
-      ++cnt;
+    is_leader[i] = leader ? 1 : 0;
+    if (!leader) continue;
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+    int cnt = 0;
+    for (int j = (int)i; j < e; ++j) {
+      if (vc[3 * j] == vx && vc[3 * j + 1] == vy && vc[3 * j + 2] == vz) {
+        const SortedPoint o = sorted[j];
+        sx += o.x;
+        sy += o.y;
+        sz += o.z;
+        ++cnt;
+      }
     }
+    centroid[3 * i] = sx / (double)cnt;
+    centroid[3 * i + 1] = sy / (double)cnt;
+    centroid[3 * i + 2] = sz / (double)cnt;
+    member_count[i] = cnt;
   }
-  centroid[3 * i] = sx / (double)cnt;
-  centroid[3 * i + 1] = sy / (double)cnt;
-  centroid[3 * i + 2] = sz / (double)cnt;
-  member_count[i] = cnt;
 }
 
-// One wave per sorted slot that is a leader: exact float64 1-NN of the voxel
-// centroid among all points (graph_gen.py:84-88).  The nearest point is closer
-// than 0.87 voxel edges (it is at most the RMS spread of the voxel's own
-// points away), so the 27 surrounding voxels suffice.  Exact distance ties
-// (every 2-point voxel) go to the point scikit-learn's kd-tree query meets
-// first (kdtree.h), which is the reference's pick.
-__global__ __launch_bounds__(256) void voxel_nn_kernel(
+// Exact float64 1-NN of every voxel centroid among all points
+// (graph_gen.py:84-88).  The nearest point is closer than 0.87 voxel edges (it
+// is at most the RMS spread of the voxel's own points away), so the 27
+// surrounding voxels suffice.  Exact distance ties (every 2-point voxel) go to
+// the point scikit-learn's kd-tree query meets first (kdtree.h), which is the
+// reference's pick.
+// A wave takes `spw` sorted slots at a time (4 when the grid may be as large as
+// it likes -- about one leader per wave --, 64 when the frame pipeline caps the
+// grid) and serves the leaders among them one after the other: lane c looks up bucket c of the leader's 27 voxels in ONE
+// round of loads, a scan concatenates the buckets, and the wave walks the
+// candidates 64 at a time (see radius_query_kernel).  The winner does not
+// depend on the order candidates are met in: the (distance, kd order) relation
+// is a strict total order.
+__global__ __launch_bounds__(1024) void voxel_nn_kernel(
     const SortedPoint *__restrict__ sorted, int64_t n,
     const double *__restrict__ origin, double voxel, uint32_t mask,
     const int32_t *__restrict__ cell_start, const int32_t *__restrict__ cell_end,
     const int32_t *__restrict__ is_leader, const int32_t *__restrict__ slot,
     const double *__restrict__ centroid, const float *__restrict__ pts,
-    KdView kd, int32_t *__restrict__ kp_idx, float *__restrict__ kp_xyz) {
+    KdView kd, int32_t *__restrict__ kp_idx, float *__restrict__ kp_xyz,
+    int spw /* sorted slots a wave takes at a time, <= 64 */) {
+  graph_prio();
   const int lane = threadIdx.x & 63;
-  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (i >= n || !is_leader[i]) return;
+  const int wpb = blockDim.x >> 6;
+  const int64_t n_waves = (int64_t)gridDim.x * wpb;
   const double ox = origin[0], oy = origin[1], oz = origin[2];
-  const double cx = centroid[3 * i], cy = centroid[3 * i + 1],
-               cz = centroid[3 * i + 2];
-  const int vx = cell_of(cx, ox, voxel), vy = cell_of(cy, oy, voxel),
-            vz = cell_of(cz, oz, voxel);
-  double best = 1.0e300;
-  int best_idx = 0x7fffffff;
-  for (int dz = -1; dz <= 1; ++dz)
-    for (int dy = -1; dy <= 1; ++dy)
-      for (int dx = -1; dx <= 1; ++dx) {
-        const int ix = vx + dx, iy = vy + dy, iz = vz + dz;
-        const uint32_t b = cell_hash(ix, iy, iz, mask);
-        const int s = cell_start[b], e = cell_end[b];
-        for (int j = s + lane; j < e; j += 64) {
-          const SortedPoint o = sorted[j];
+  for (int64_t base = ((int64_t)blockIdx.x * wpb + (threadIdx.x >> 6)) * spw;
+       base < n; base += n_waves * spw) {
+    unsigned long long leaders = __ballot(
+        lane < spw && base + lane < n && is_leader[base + lane] != 0);
+    while (leaders) {
+      const int64_t i = base + __builtin_ctzll(leaders);
+      leaders &= leaders - 1;
+      const double cx = centroid[3 * i], cy = centroid[3 * i + 1],
+                   cz = centroid[3 * i + 2];
+      const int vx = cell_of(cx, ox, voxel), vy = cell_of(cy, oy, voxel),
+                vz = cell_of(cz, oz, voxel);
+      int my_s = 0, my_cnt = 0, my_ix = 0, my_iy = 0, my_iz = 0;
+      if (lane < 27) {  // (dz, dy, dx) order
+        my_ix = vx - 1 + lane % 3;
+        my_iy = vy - 1 + (lane / 3) % 3;
+        my_iz = vz - 1 + lane / 9;
+        const uint32_t b = cell_hash(my_ix, my_iy, my_iz, mask);
+        my_s = cell_start[b];
+        my_cnt = cell_end[b] - my_s;
+      }
+      int incl = my_cnt;
+#pragma unroll
+      for (int d = 1; d < 32; d <<= 1) {
+        const int t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+      }
+      const int total_cand = __shfl(incl, 26);
+      double best = 1.0e300;
+      int best_idx = 0x7fffffff;
+      for (int j0 = 0; j0 < total_cand; j0 += 64) {
+        const bool valid = j0 + lane < total_cand;
+        const int j = valid ? j0 + lane : total_cand - 1;
+        int lo = 0, hi = 26;
+#pragma unroll
+        for (int step = 0; step < 5; ++step) {
+          const int mid = (lo + hi) >> 1;
+          const int v = __shfl(incl, mid);
+          if (v > j) hi = mid; else lo = mid + 1;
+        }
+        const int c = lo < 27 ? lo : 26;
+        const int c_incl = __shfl(incl, c), c_cnt = __shfl(my_cnt, c);
+        const int c_s = __shfl(my_s, c);
+        const int ix = __shfl(my_ix, c), iy = __shfl(my_iy, c),
+                  iz = __shfl(my_iz, c);
+        if (valid) {
+          const SortedPoint o = sorted[c_s + (j - (c_incl - c_cnt))];
           if (cell_of(o.x, ox, voxel) == ix && cell_of(o.y, oy, voxel) == iy &&
               cell_of(o.z, oz, voxel) == iz) {
             const double ex = o.x - cx, ey = o.y - cy, ez = o.z - cz;
@@ -464,22 +578,24 @@ __global__ __launch_bounds__(256) void voxel_nn_kernel(
         }
       }
 #pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) {
-    const double ob = __shfl_xor(best, d);
-    const int oi = __shfl_xor(best_idx, d);
-    if (ob < best ||
-        (ob == best && oi != best_idx && oi != 0x7fffffff &&
-         kd_met_before(kd, kd.pos[oi], kd.pos[best_idx], cx, cy, cz))) {
-      best = ob;
-      best_idx = oi;
+      for (int d = 32; d >= 1; d >>= 1) {
+        const double ob = __shfl_xor(best, d);
+        const int oi = __shfl_xor(best_idx, d);
+        if (ob < best ||
+            (ob == best && oi != best_idx && oi != 0x7fffffff &&
+             kd_met_before(kd, kd.pos[oi], kd.pos[best_idx], cx, cy, cz))) {
+          best = ob;
+          best_idx = oi;
+        }
+      }
+      if (lane == 0) {
+        const int k = slot[i];
+        kp_idx[k] = best_idx;
+        kp_xyz[3 * k] = pts[3 * (int64_t)best_idx];
+        kp_xyz[3 * k + 1] = pts[3 * (int64_t)best_idx + 1];
+        kp_xyz[3 * k + 2] = pts[3 * (int64_t)best_idx + 2];
+      }
     }
-  }
-  if (lane == 0) {
-    const int k = slot[i];
-    kp_idx[k] = best_idx;
-    kp_xyz[3 * k] = pts[3 * (int64_t)best_idx];
-    kp_xyz[3 * k + 1] = pts[3 * (int64_t)best_idx + 1];
-    kp_xyz[3 * k + 2] = pts[3 * (int64_t)best_idx + 2];
   }
 }
 
@@ -492,30 +608,34 @@ __global__ void voxel_random_pick_kernel(
     const int32_t *__restrict__ slot, const int32_t *__restrict__ member_count,
     uint64_t seed, const T *__restrict__ pts, int32_t *__restrict__ kp_idx,
     T *__restrict__ kp_xyz) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n || !is_leader[i]) return;
-  const int my_idx = sorted[i].idx;
-  const int vx = vc[3 * i], vy = vc[3 * i + 1], vz = vc[3 * i + 2];
-  const int cnt = member_count[i];
-  const uint64_t h = mix64(seed ^ mix64((uint64_t)my_idx + 0x632be59bd9b4e019ull));
-  int target = (int)((h >> 11) * (1.0 / 9007199254740992.0) * (double)cnt);
-  if (target >= cnt) target = cnt - 1;
-  const int e = cell_end[keys[i]];
-  int chosen = my_idx, seen = 0;
-  for (int j = (int)i; j < e; ++j) {
-    if (vc[3 * j] == vx && vc[3 * j + 1] == vy && vc[3 * j + 2] == vz) {
-      if (seen == target) {
-        chosen = sorted[j].idx;
-        break;
+  graph_prio();
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    if (!is_leader[i]) continue;
+    const int my_idx = sorted[i].idx;
+    const int vx = vc[3 * i], vy = vc[3 * i + 1], vz = vc[3 * i + 2];
+    const int cnt = member_count[i];
+    const uint64_t h =
+        mix64(seed ^ mix64((uint64_t)my_idx + 0x632be59bd9b4e019ull));
+    int target = (int)((h >> 11) * (1.0 / 9007199254740992.0) * (double)cnt);
+    if (target >= cnt) target = cnt - 1;
+    const int e = cell_end[keys[i]];
+    int chosen = my_idx, seen = 0;
+    for (int j = (int)i; j < e; ++j) {
+      if (vc[3 * j] == vx && vc[3 * j + 1] == vy && vc[3 * j + 2] == vz) {
+        if (seen == target) {
+          chosen = sorted[j].idx;
+          break;
+        }
+        ++seen;
       }
-      ++seen;
     }
+    const int k = slot[i];
+    kp_idx[k] = chosen;
+    kp_xyz[3 * k] = pts[3 * (int64_t)chosen];
+    kp_xyz[3 * k + 1] = pts[3 * (int64_t)chosen + 1];
+    kp_xyz[3 * k + 2] = pts[3 * (int64_t)chosen + 2];
   }
-  const int k = slot[i];
-  kp_idx[k] = chosen;
-  kp_xyz[3 * k] = pts[3 * (int64_t)chosen];
-  kp_xyz[3 * k + 1] = pts[3 * (int64_t)chosen + 1];
-  kp_xyz[3 * k + 2] = pts[3 * (int64_t)chosen + 2];
 }
 
 // num[0] = K; num[1] = tie-order status of the kd-tree replica (0 = the
@@ -524,10 +644,28 @@ __global__ void voxel_random_pick_kernel(
 // order); kd_status null (random mode / ablation): 0
 __global__ void copy_total_kernel(const int32_t *src,
                                   const int32_t *kd_status, int32_t *num) {
+  graph_prio();
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     num[0] = *src;
     num[1] = kd_status ? *kd_status : 0;
   }
+}
+
+// hipMemsetAsync for the builder: the runtime's fill kernel picks its own grid,
+// which the frame pipeline cannot cap (graph_max_wgs)
+__global__ void graph_fill32_kernel(uint32_t *__restrict__ p, uint32_t v,
+                                    int64_t count) {
+  graph_prio();
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+       i += (int64_t)gridDim.x * blockDim.x)
+    p[i] = v;
+}
+inline int graph_fill32(void *p, uint32_t v, int64_t count, hipStream_t stream) {
+  if (count <= 0) return 0;
+  hipLaunchKernelGGL(graph_fill32_kernel, dim3(graph_grid((count + 1023) / 1024)),
+                     dim3(1024), graph_lds_pad(), stream, (uint32_t *)p, v,
+                     count);
+  return (int)hipGetLastError();
 }
 
 // ---- host-side helpers ---------------------------------------------------------------
@@ -581,22 +719,26 @@ template <typename T>
 int grid_build(const T *pts, int64_t n, const Scale3 &sc, double ox,
                double oy, double oz, const double *origin_dev, double cell,
                Grid &g, hipStream_t stream, int32_t *vcell = nullptr,
-               int32_t *vcell_sorted = nullptr) {
+               int32_t *vcell_sorted = nullptr,
+               const int32_t *n_dev = nullptr) {
   const size_t nbuckets = (size_t)1 << g.bits;
-  PGNN_HIP(hipMemsetAsync(g.cell_start, 0, nbuckets * 4, stream));
-  PGNN_HIP(hipMemsetAsync(g.cell_end, 0, nbuckets * 4, stream));
+  // cell_start and cell_end are carved back to back (grid_carve): one fill
+  PGNN_REQUIRE(g.cell_end == g.cell_start + nbuckets, PGNN_E_INVALID,
+               "graph: bucket tables are not contiguous");
+  PGNN_HIP((hipError_t)graph_fill32(g.cell_start, 0u, 2 * (int64_t)nbuckets,
+                                    stream));
   if (n <= 0) return 0;
   const unsigned blocks = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL(cell_keys_kernel<T>, dim3(blocks), dim3(256), 0, stream, pts,
+  hipLaunchKernelGGL(cell_keys_kernel<T>, dim3(graph_grid(blocks)), dim3(256), graph_lds_pad(), stream, pts,
                      n, sc, ox, oy, oz, origin_dev, cell, g.mask, g.keys_a,
-                     g.vals_a, vcell);
+                     g.vals_a, vcell, n_dev);
   int rc = radix_sort_pairs(g.keys_a, g.vals_a, g.keys_b, g.vals_b, n, g.bits,
                             g.sort_scratch, g.sort_scratch_bytes, &g.keys,
-                            &g.vals, stream);
+                            &g.vals, stream, n_dev);
   if (rc) return rc;
-  hipLaunchKernelGGL(cell_bounds_kernel<T>, dim3(blocks), dim3(256), 0, stream,
+  hipLaunchKernelGGL(cell_bounds_kernel<T>, dim3(graph_grid(blocks)), dim3(256), graph_lds_pad(), stream,
                      g.keys, g.vals, n, pts, sc, g.cell_start, g.cell_end,
-                     g.sorted, (const int32_t *)vcell, vcell_sorted);
+                     g.sorted, (const int32_t *)vcell, vcell_sorted, n_dev);
   PGNN_HIP(hipGetLastError());
   return 0;
 }
@@ -669,11 +811,13 @@ int radius_count_impl(const T *points, int64_t n_points, const T *centers,
   if (rc) return rc;
   if (n_centers > 0) {
     hipLaunchKernelGGL((radius_query_kernel<false, T>),
-                       dim3((unsigned)((n_centers + 3) / 4)), dim3(256), 0,
+                       dim3(graph_grid((n_centers + (graph_wide_block() >> 6) - 1) /
+                                       (graph_wide_block() >> 6))),
+                       dim3(graph_wide_block()), graph_lds_pad(),
                        stream, centers, n_centers, sc, radius, w.g.mask,
                        w.g.cell_start, w.g.cell_end, w.g.sorted, w.counts,
                        (const int32_t *)nullptr, (int32_t *)nullptr,
-                       (int64_t)0);
+                       (int64_t)0, (const int32_t *)nullptr);
     PGNN_HIP(hipGetLastError());
   }
   return exclusive_scan_i32(w.counts, offsets, n_centers, w.scan_scratch,
@@ -697,10 +841,12 @@ int radius_fill_impl(const T *points, int64_t n_points, const T *centers,
   if (rc) return rc;
   const Scale3 sc = make_scale(scale3_host);
   hipLaunchKernelGGL((radius_query_kernel<true, T>),
-                     dim3((unsigned)((n_centers + 3) / 4)), dim3(256), 0, stream,
+                     dim3(graph_grid((n_centers + (graph_wide_block() >> 6) - 1) /
+                                       (graph_wide_block() >> 6))),
+                       dim3(graph_wide_block()), graph_lds_pad(), stream,
                      centers, n_centers, sc, radius, w.g.mask, w.g.cell_start,
                      w.g.cell_end, w.g.sorted, (int32_t *)nullptr, offsets,
-                     edges, capacity);
+                     edges, capacity, (const int32_t *)nullptr);
   PGNN_HIP(hipGetLastError());
   return 0;
 }
@@ -754,6 +900,117 @@ extern "C" int pgnn_radius_graph_fill_f64(
   PGNN_GUARD_END
 }
 
+// ---- capacity form: no count leaves the device --------------------------------
+// graph_gen.py:155-220 never waits for a size (NumPy arrays carry their own);
+// here the keypoint count K and the edge counts live in device memory and the
+// outputs are sized by a capacity.  One call = grid + count + scan + fill.
+namespace {
+__global__ void edge_total_kernel(const int32_t *__restrict__ total,
+                                  int64_t capacity, int32_t *__restrict__ n_out) {
+  graph_prio();
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const int32_t e = *total;
+    n_out[0] = (int64_t)e < capacity ? e : (int32_t)capacity;  // rows written
+    n_out[1] = e;                                              // rows required
+  }
+}
+
+template <typename T>
+int radius_dyn_impl(const T *points, int64_t points_cap,
+                    const int32_t *n_points_dev, const T *centers,
+                    int64_t centers_cap, const int32_t *n_centers_dev,
+                    double radius, const double *scale3_host, void *workspace,
+                    size_t workspace_bytes, int32_t *edges,
+                    int64_t edge_capacity, int32_t *n_edges_dev,
+                    hipStream_t stream) {
+  PGNN_REQUIRE(points_cap >= 0 && centers_cap >= 0 && radius > 0.0 &&
+                   edge_capacity >= 0 && edge_capacity <= 0x7fffffff &&
+                   n_edges_dev,
+               PGNN_E_INVALID, "radius_graph_dyn: bad argument");
+  PGNN_REQUIRE((points_cap == 0 || points) && (centers_cap == 0 || centers) &&
+                   (edge_capacity == 0 || edges),
+               PGNN_E_INVALID, "radius_graph_dyn: null pointer");
+  PGNN_REQUIRE(workspace &&
+                   workspace_bytes >= pgnn_radius_graph_dyn_workspace_bytes(
+                                          points_cap, centers_cap),
+               PGNN_E_WORKSPACE, "radius_graph_dyn: workspace too small");
+  RadiusWs w;
+  int rc = radius_carve(workspace, workspace_bytes, points_cap, centers_cap, w);
+  if (rc) return rc;
+  int32_t *offsets = reinterpret_cast<int32_t *>(
+      (char *)workspace +
+      pgnn_radius_graph_workspace_bytes(points_cap, centers_cap));
+  const Scale3 sc = make_scale(scale3_host);
+  rc = grid_build(points, points_cap, sc, 0.0, 0.0, 0.0, nullptr, radius, w.g,
+                  stream, nullptr, nullptr, n_points_dev);
+  if (rc) return rc;
+  if (centers_cap > 0) {
+    hipLaunchKernelGGL((radius_query_kernel<false, T>),
+                       dim3(graph_grid((centers_cap + (graph_wide_block() >> 6) - 1) /
+                                       (graph_wide_block() >> 6))),
+                       dim3(graph_wide_block()), graph_lds_pad(),
+                       stream, centers, centers_cap, sc, radius, w.g.mask,
+                       w.g.cell_start, w.g.cell_end, w.g.sorted, w.counts,
+                       (const int32_t *)nullptr, (int32_t *)nullptr,
+                       (int64_t)0, n_centers_dev);
+    PGNN_HIP(hipGetLastError());
+  }
+  rc = exclusive_scan_i32(w.counts, offsets, centers_cap, w.scan_scratch,
+                          w.scan_bytes, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(edge_total_kernel, dim3(1), dim3(64), graph_lds_pad(), stream,
+                     (const int32_t *)(offsets + centers_cap), edge_capacity,
+                     n_edges_dev);
+  if (centers_cap > 0 && edge_capacity > 0) {
+    hipLaunchKernelGGL((radius_query_kernel<true, T>),
+                       dim3(graph_grid((centers_cap + (graph_wide_block() >> 6) - 1) /
+                                       (graph_wide_block() >> 6))),
+                       dim3(graph_wide_block()), graph_lds_pad(),
+                       stream, centers, centers_cap, sc, radius, w.g.mask,
+                       w.g.cell_start, w.g.cell_end, w.g.sorted,
+                       (int32_t *)nullptr, (const int32_t *)offsets, edges,
+                       edge_capacity, n_centers_dev);
+  }
+  PGNN_HIP(hipGetLastError());
+  return 0;
+}
+}  // namespace
+
+extern "C" size_t pgnn_radius_graph_dyn_workspace_bytes(int64_t points_cap,
+                                                        int64_t centers_cap) {
+  if (points_cap < 0 || centers_cap < 0) return 0;
+  return pgnn_radius_graph_workspace_bytes(points_cap, centers_cap) +
+         align_up((size_t)(centers_cap + 1) * 4, 256);
+}
+
+extern "C" int pgnn_radius_graph_dyn(
+    const float *points, int64_t points_cap, const int32_t *n_points_dev,
+    const float *centers, int64_t centers_cap, const int32_t *n_centers_dev,
+    double radius, const double *scale3_host, void *workspace,
+    size_t workspace_bytes, int32_t *edges, int64_t edge_capacity,
+    int32_t *n_edges_dev, void *stream_) {
+  PGNN_GUARD_BEGIN
+  return radius_dyn_impl(points, points_cap, n_points_dev, centers, centers_cap,
+                         n_centers_dev, radius, scale3_host, workspace,
+                         workspace_bytes, edges, edge_capacity, n_edges_dev,
+                         (hipStream_t)stream_);
+  PGNN_GUARD_END
+}
+
+extern "C" int pgnn_radius_graph_dyn_f64(
+    const double *points, int64_t points_cap, const int32_t *n_points_dev,
+    const double *centers, int64_t centers_cap, const int32_t *n_centers_dev,
+    double radius, const double *scale3_host, void *workspace,
+    size_t workspace_bytes, int32_t *edges, int64_t edge_capacity,
+    int32_t *n_edges_dev, void *stream_) {
+  PGNN_GUARD_BEGIN
+  return radius_dyn_impl(points, points_cap, n_points_dev, centers, centers_cap,
+                         n_centers_dev, radius, scale3_host, workspace,
+                         workspace_bytes, edges, edge_capacity, n_edges_dev,
+                         (hipStream_t)stream_);
+  PGNN_GUARD_END
+}
+
 extern "C" int pgnn_cap_neighbors_count(const int32_t *offsets,
                                         int64_t n_centers,
                                         int32_t max_neighbors,
@@ -765,7 +1022,7 @@ extern "C" int pgnn_cap_neighbors_count(const int32_t *offsets,
   PGNN_HIP(hipMemsetAsync(new_offsets + n_centers, 0, 4, stream));
   if (n_centers == 0) return 0;
   hipLaunchKernelGGL(cap_counts_kernel,
-                     dim3((unsigned)((n_centers + 255) / 256)), dim3(256), 0,
+                     dim3((unsigned)((n_centers + 255) / 256)), dim3(256), graph_lds_pad(),
                      stream, offsets, n_centers, max_neighbors, new_offsets);
   PGNN_HIP(hipGetLastError());
   // exclusive scan over n_centers + 1 entries leaves the total in the last one
@@ -788,7 +1045,7 @@ extern "C" int pgnn_cap_neighbors_fill(const int32_t *offsets,
   PGNN_REQUIRE(edges && new_edges, PGNN_E_INVALID,
                "cap_neighbors_fill: null edges");
   hipLaunchKernelGGL(cap_fill_kernel, dim3((unsigned)((n_centers + 3) / 4)),
-                     dim3(256), 0, stream, offsets, edges, n_centers,
+                     dim3(256), graph_lds_pad(), stream, offsets, edges, n_centers,
                      max_neighbors, seed, new_offsets, new_edges, new_capacity);
   PGNN_HIP(hipGetLastError());
   return 0;
@@ -935,10 +1192,10 @@ int keypoints_impl(const T *points, int64_t n, double voxel, bool center,
     }
     if (rc) return rc;
   }
-  PGNN_HIP(hipMemsetAsync(omin, 0xff, 32, stream));
+  PGNN_HIP((hipError_t)graph_fill32(omin, 0xffffffffu, 8, stream));
   int mb = (int)((n + 255) / 256);
   if (mb > 1024) mb = 1024;
-  hipLaunchKernelGGL(min_bound_kernel<T>, dim3(mb), dim3(256), 0, stream, points,
+  hipLaunchKernelGGL(min_bound_kernel<T>, dim3(graph_grid(mb)), dim3(256), graph_lds_pad(), stream, points,
                      n, omin);
   double sx, sy, sz;
   if (center) {
@@ -949,19 +1206,19 @@ int keypoints_impl(const T *points, int64_t n, double voxel, bool center,
     sz = jitter3 ? jitter3[2] : 0.0;
   }
   const int mode = center ? 0 : (kF64 ? (jitter3 ? 4 : 3) : (jitter3 ? 2 : 1));
-  hipLaunchKernelGGL(grid_origin_kernel, dim3(1), dim3(64), 0, stream, omin, sx,
+  hipLaunchKernelGGL(grid_origin_kernel, dim3(1), dim3(64), graph_lds_pad(), stream, omin, sx,
                      sy, sz, mode, origin);
   Scale3 sc = make_scale(nullptr);
   rc = grid_build(points, n, sc, 0.0, 0.0, 0.0, origin, voxel, g, stream, vcell,
                   vcell_sorted);
   if (rc) return rc;
   const unsigned blocks = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL(voxel_leader_kernel, dim3(blocks), dim3(256), 0, stream,
+  hipLaunchKernelGGL(voxel_leader_kernel, dim3(graph_grid(blocks)), dim3(256), graph_lds_pad(), stream,
                      g.sorted, g.keys, n, (const int32_t *)vcell_sorted,
                      g.cell_start, g.cell_end, is_leader, centroid, members);
   rc = exclusive_scan_i32(is_leader, slot, n, scan_scratch, scan_bytes, stream);
   if (rc) return rc;
-  hipLaunchKernelGGL(copy_total_kernel, dim3(1), dim3(64), 0, stream, slot + n,
+  hipLaunchKernelGGL(copy_total_kernel, dim3(1), dim3(64), graph_lds_pad(), stream, slot + n,
                      (const int32_t *)kb.status, num_kp);
   if (center) {
     KdView kd;
@@ -972,7 +1229,7 @@ int keypoints_impl(const T *points, int64_t n, double voxel, bool center,
     launch_voxel_nn(g, n, origin, voxel, is_leader, slot, centroid, points, kd,
                     kp_idx, kp_xyz, stream);
   } else {
-    hipLaunchKernelGGL(voxel_random_pick_kernel<T>, dim3(blocks), dim3(256), 0,
+    hipLaunchKernelGGL(voxel_random_pick_kernel<T>, dim3(graph_grid(blocks)), dim3(256), graph_lds_pad(),
                        stream, g.sorted, g.keys, n,
                        (const int32_t *)vcell_sorted, g.cell_end, is_leader,
                        slot, members, seed, points, kp_idx, kp_xyz);
@@ -987,10 +1244,13 @@ inline void launch_voxel_nn(const Grid &g, int64_t n, const double *origin,
                             const float *points, const KdView &kd,
                             int32_t *kp_idx, float *kp_xyz,
                             hipStream_t stream) {
-  hipLaunchKernelGGL(voxel_nn_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256),
-                     0, stream, g.sorted, n, origin, voxel, g.mask,
+  const int64_t wb = graph_wide_block();
+  const int spw = g_graph_max_wgs > 0 ? 64 : 4;
+  const int64_t per_wg = (wb >> 6) * spw;
+  hipLaunchKernelGGL(voxel_nn_kernel, dim3(graph_grid((n + per_wg - 1) / per_wg)),
+                     dim3((unsigned)wb), graph_lds_pad(), stream, g.sorted, n, origin, voxel, g.mask,
                      g.cell_start, g.cell_end, is_leader, slot, centroid, points,
-                     kd, kp_idx, kp_xyz);
+                     kd, kp_idx, kp_xyz, spw);
 }
 }  // namespace
 

@@ -30,10 +30,19 @@ struct __attribute__((aligned(16))) Rec {
 };
 typedef float kd_v4 __attribute__((ext_vector_type(4)));
 
-constexpr int KD_NT = 1024;        // threads per workgroup
+#ifndef PGNN_KD_NT
+#define PGNN_KD_NT 1024
+#endif
+#ifndef PGNN_KD_LDS_CAP
+#define PGNN_KD_LDS_CAP 5120
+#endif
+#ifndef PGNN_KD_BATCH
+#define PGNN_KD_BATCH 2048
+#endif
+constexpr int KD_NT = PGNN_KD_NT;  // threads per workgroup
 constexpr int KD_NW = KD_NT / 64;
-constexpr int KD_LDS_CAP = 5120;   // records a workgroup keeps in LDS (80 KB)
-constexpr int KD_BATCH = 2048;     // swap-list entries per batch, block mode
+constexpr int KD_LDS_CAP = PGNN_KD_LDS_CAP;  // records a workgroup keeps in LDS (80 KB)
+constexpr int KD_BATCH = PGNN_KD_BATCH;  // swap-list entries per batch, block mode
 constexpr int KD_WBATCH = 256;     // ... per wave, wave mode (same storage)
 #ifndef PGNN_KD_WAVE_TAIL
 #define PGNN_KD_WAVE_TAIL 512
@@ -434,8 +443,9 @@ __device__ __forceinline__ int kd_split_dim(const float (&lo)[3],
 
 __global__ void kd_init_kernel(const float *__restrict__ pts, int n,
                                Rec *__restrict__ rec, int32_t *status) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) {
+  graph_prio();
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += gridDim.x * blockDim.x) {
     Rec r;
     r.c[0] = pts[3 * (size_t)i];
     r.c[1] = pts[3 * (size_t)i + 1];
@@ -443,7 +453,7 @@ __global__ void kd_init_kernel(const float *__restrict__ pts, int n,
     r.idx = i;
     rec[i] = r;
   }
-  if (i == 0) *status = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *status = 0;
 }
 
 // One workgroup per node of `level`, nodes longer than KD_LDS_CAP: the first
@@ -452,17 +462,22 @@ __global__ void kd_init_kernel(const float *__restrict__ pts, int n,
 __global__ __launch_bounds__(KD_NT) void kd_top_kernel(
     Rec *rec, int n, int level, int n_nodes, double *__restrict__ bounds,
     int32_t *__restrict__ status) {
+  graph_prio();
   __shared__ float red[6][KD_NW];
   __shared__ int sh[2 * KD_NW];
   __shared__ int32_t lg[KD_BATCH], ls[KD_BATCH];
   extern __shared__ __attribute__((aligned(16))) char kd_dyn[];
   Rec *L = reinterpret_cast<Rec *>(kd_dyn);
-  const int node = (1 << level) - 1 + blockIdx.x;
-  if (node >= n_nodes) return;
-  int s, e;
-  kd_node_range(n, level, blockIdx.x, s, e);
-  const int len = e - s;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // a workgroup takes the level's nodes blockIdx.x, + gridDim.x, ... (the
+  // frame pipeline caps the builder's grids, graph_max_wgs)
+  for (int jn = blockIdx.x; jn < (1 << level); jn += gridDim.x) {
+  __syncthreads();  // LDS of the previous node is free
+  const int node = (1 << level) - 1 + jn;
+  if (node >= n_nodes) continue;
+  int s, e;
+  kd_node_range(n, level, jn, s, e);
+  const int len = e - s;
   float lo[3] = {INFINITY, INFINITY, INFINITY};
   float hi[3] = {-INFINITY, -INFINITY, -INFINITY};
   for (int i = s + threadIdx.x; i < e; i += KD_NT) {
@@ -504,7 +519,7 @@ __global__ __launch_bounds__(KD_NT) void kd_top_kernel(
       bounds[6 * (size_t)node + 3 + j] = (double)hi[j];
     }
   }
-  if (2 * node + 1 >= n_nodes || len < 2) return;  // leaf
+  if (2 * node + 1 >= n_nodes || len < 2) continue;  // leaf
   const int dim = kd_split_dim(lo, hi);
   // ---- std::nth_element(idx + s, idx + s + len/2, idx + e)
   int first = s, last = e;
@@ -529,6 +544,7 @@ __global__ __launch_bounds__(KD_NT) void kd_top_kernel(
   for (int i = f0 + threadIdx.x; i < l0; i += KD_NT)
     *reinterpret_cast<kd_v4 *>(&rec[i]) =
         *reinterpret_cast<const kd_v4 *>(&L[i - f0]);
+  }
 }
 
 // One workgroup per node of `level0` (<= KD_LDS_CAP records): the whole
@@ -538,6 +554,7 @@ __global__ __launch_bounds__(KD_NT) void kd_subtree_kernel(
     const Rec *__restrict__ rec, int n, int level0, int n_levels, int n_nodes,
     double *__restrict__ bounds, int32_t *__restrict__ idx_out,
     int32_t *__restrict__ pos_out, int32_t *__restrict__ status) {
+  graph_prio();
   __shared__ int32_t lists[KD_NW][2][KD_WBATCH];  // 32 KB >= 2 * KD_BATCH ints
   __shared__ float red[6][KD_NW];
   __shared__ int sh[2 * KD_NW];
@@ -546,9 +563,12 @@ __global__ __launch_bounds__(KD_NT) void kd_subtree_kernel(
                 "wave-mode ranges");
   extern __shared__ __attribute__((aligned(16))) char kd_dyn[];
   Rec *L = reinterpret_cast<Rec *>(kd_dyn);
-  int s0, e0;
-  kd_node_range(n, level0, blockIdx.x, s0, e0);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // a workgroup takes the subtrees blockIdx.x, + gridDim.x, ...
+  for (int jb = blockIdx.x; jb < (1 << level0); jb += gridDim.x) {
+  __syncthreads();  // LDS of the previous subtree is free
+  int s0, e0;
+  kd_node_range(n, level0, jb, s0, e0);
   for (int i = s0 + threadIdx.x; i < e0; i += KD_NT)
     *reinterpret_cast<kd_v4 *>(&L[i - s0]) =
         *reinterpret_cast<const kd_v4 *>(&rec[i]);
@@ -560,7 +580,7 @@ __global__ __launch_bounds__(KD_NT) void kd_subtree_kernel(
     // (block mode); many short nodes: one wave each
     const bool block_mode = ((e0 - s0 + cnt - 1) >> dl) > KD_WAVE_NODE;
     for (int j = block_mode ? 0 : wave; j < cnt; j += block_mode ? 1 : KD_NW) {
-      const int jl = (blockIdx.x << dl) + j;  // index within level lv
+      const int jl = (jb << dl) + j;  // index within level lv
       const int node = (1 << lv) - 1 + jl;
       if (node >= n_nodes) continue;
       int s, e;
@@ -643,6 +663,7 @@ __global__ __launch_bounds__(KD_NT) void kd_subtree_kernel(
     idx_out[i] = p;
     pos_out[p] = i;
   }
+  }
 }
 
 }  // namespace
@@ -665,7 +686,8 @@ int kd_build(const float *pts, int64_t n, Arena &a, KdBuild &kd,
   PGNN_REQUIRE(n <= KD_MAX_POINTS, PGNN_E_UNSUPPORTED,
                "kdtree: more than 524288 points are not supported (the replica "
                "of scikit-learn's KDTree keeps node records in LDS)");
-  static_assert(KD_MAX_POINTS == 524288, "keep the message in step");
+  static_assert(KD_MAX_POINTS == 524288 || KD_NT != 1024,
+                "keep the message in step");
   kd_shape(n, &kd.n_levels, &kd.n_nodes);
   const size_t nn = (size_t)(n > 0 ? n : 1);
   kd.idx = a.take<int32_t>(nn);
@@ -690,20 +712,20 @@ int kd_build(const float *pts, int64_t n, Arena &a, KdBuild &kd,
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
     attr_set = true;
   }
-  hipLaunchKernelGGL(kd_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256),
-                     0, stream, pts, (int)n, rec, kd.status);
+  hipLaunchKernelGGL(kd_init_kernel, dim3(graph_grid((n + 255) / 256)), dim3(256),
+                     graph_lds_pad(), stream, pts, (int)n, rec, kd.status);
   // levels whose nodes can exceed the LDS capacity: one launch each
   int level0 = 0;
   while (level0 < kd.n_levels - 1 &&
          ((n + ((int64_t)1 << level0) - 1) >> level0) > KD_TOP_LEN) {
-    hipLaunchKernelGGL(kd_top_kernel, dim3(1u << level0), dim3(KD_NT), dyn,
+    hipLaunchKernelGGL(kd_top_kernel, dim3(graph_grid(1 << level0)), dim3(KD_NT), dyn,
                        stream, rec, (int)n, level0, kd.n_nodes, kd.bounds,
                        kd.status);
     ++level0;
   }
   PGNN_REQUIRE(((n + ((int64_t)1 << level0) - 1) >> level0) <= KD_LDS_CAP,
                PGNN_E_INVALID, "kdtree: leaf larger than the LDS capacity");
-  hipLaunchKernelGGL(kd_subtree_kernel, dim3(1u << level0), dim3(KD_NT), dyn,
+  hipLaunchKernelGGL(kd_subtree_kernel, dim3(graph_grid(1 << level0)), dim3(KD_NT), dyn,
                      stream, rec, (int)n, level0, kd.n_levels, kd.n_nodes,
                      kd.bounds, kd.idx, kd.pos, kd.status);
   PGNN_HIP(hipGetLastError());

@@ -79,6 +79,52 @@ __device__ __forceinline__ void atomic_max_f32(float *addr, float v) {
   }
 }
 
+// The graph-build kernels are chains of short dependent steps (a load, a
+// ballot, a barrier ...).  In the frame pipeline they share CUs with the
+// persistent MFMA kernels of the previous frame's message passing, whose
+// older, always-ready waves win every issue arbitration at equal priority:
+// measured, the builder's kernels then run 3-7x slower (radix_scatter 8.5 ->
+// 57 us, kd_top 59 -> 297 us) and the build of frame i+1 approaches the
+// length of frame i.  They issue few instructions, so letting them go first
+// costs the MFMA kernels next to nothing.
+#ifndef PGNN_GRAPH_PRIO
+#define PGNN_GRAPH_PRIO 3
+#endif
+__device__ __forceinline__ void graph_prio() {
+#if PGNN_GRAPH_PRIO > 0
+  __builtin_amdgcn_s_setprio(PGNN_GRAPH_PRIO);
+#endif
+}
+
+// Dynamic LDS every graph-build launch asks for on top of what it uses
+// (tunable `graph_lds_pad`, bytes, default 0).  The frame pipeline sets it to
+// 32 KiB together with `ws_reserve`: a workgroup of the weights-stationary
+// kernels holds 133-153 KiB of a CU's 160 KiB, so a padded builder workgroup
+// cannot be placed beside one -- it lands on the CUs those kernels leave free
+// (ws_reserve) and runs there at full speed, instead of on a CU whose SIMDs
+// are saturated with MFMAs, where every dependent step of the builder's
+// chains takes 5-9x longer (tools/corun_probe.py).
+extern int g_graph_lds_pad;
+inline size_t graph_lds_pad() { return (size_t)g_graph_lds_pad; }
+// ... and the cap on the workgroups of one builder launch (tunable
+// `graph_max_wgs`, default 0 = none): every builder kernel strides over its
+// work, so a grid of 8 covers any size.  With 8 CUs left free (one per XCD),
+// launches of at most 8 workgroups are placed on them at once; the
+// dispatcher does not route the later workgroups of a larger grid around
+// CUs that lack the LDS -- they wait for the persistent kernel to end
+// (tools/hog_probe.py) -- and a persistent kernel of (CUs - 8) workgroups
+// starts at once beside up to 8 resident builder workgroups, not beside more
+// (tools/hog_probe2.py).
+extern int g_graph_max_wgs;
+inline unsigned graph_grid(int64_t natural) {
+  if (natural < 1) natural = 1;
+  if (g_graph_max_wgs > 0 && natural > g_graph_max_wgs) natural = g_graph_max_wgs;
+  return (unsigned)natural;
+}
+// threads per workgroup of the wave-per-item kernels: 4 waves normally, 16
+// when the grid is capped (the few workgroups then carry all the parallelism)
+inline unsigned graph_wide_block() { return g_graph_max_wgs > 0 ? 1024u : 256u; }
+
 int device_cu_count();
 int stream_cu_count(hipStream_t stream);
 int ensure_dynamic_lds(const void *kernel, size_t bytes);

@@ -28,6 +28,7 @@ struct PoolWsArgs {
   const int32_t *kp;      // [num_segments] point index of each keypoint
   const int32_t *edges;   // [n_edges, 2] rows (point, keypoint)
   int64_t n_edges;
+  const int32_t *n_dev;   // capacity form (nullable), see EdgeWsArgs
   LayerDev l0, l1, l2;    // hidden layers (packed weights in global memory)
   const float *wp;        // last layer: packed weights, bias follows
   int kq, nt;             // ... its K groups (8) and column tiles (19)
@@ -104,11 +105,11 @@ __device__ __forceinline__ void pool_ws_body(const PoolWsArgs &a,
                                              const float *bias_lds,
                                              int64_t tile_first,
                                              int64_t tile_last, int lane,
-                                             long long *tsw, int &stamped) {
+                                             long long *tsw, int &stamped,
+                                             const int64_t E) {
   constexpr int KQ = 8, NT = 19;
   if (tile_first >= tile_last) return;
   const int n = lane & 15;
-  const int64_t E = a.n_edges;
   const int64_t e_first = tile_first * 16;
   const int64_t e_end = tile_last * 16 < E ? tile_last * 16 : E;
   const int2 *__restrict__ e2 = reinterpret_cast<const int2 *>(a.edges);
@@ -300,7 +301,12 @@ __global__ __launch_bounds__(64 * kWsWaves) void pool_ws_kernel(PoolWsArgs a) {
   // static ranges for (100 - pool_pct) % of the 16-row tiles, the rest in
   // chunks from a pool (edge_ws.h); ~10 tiles per wave at E0 = 350k, so the
   // pool works in single tiles
-  const int64_t n_wt = (a.n_edges + 15) / 16;
+  int64_t n_edges = a.n_edges;
+  if (a.n_dev) {
+    const int64_t nd = *a.n_dev;
+    n_edges = nd < n_edges ? nd : n_edges;
+  }
+  const int64_t n_wt = (n_edges + 15) / 16;
   const int64_t nw = (int64_t)gridDim.x * kWsWaves;
   const int64_t wi = (int64_t)blockIdx.x * kWsWaves + wave;
   int64_t span = n_wt;
@@ -324,7 +330,7 @@ __global__ __launch_bounds__(64 * kWsWaves) void pool_ws_kernel(PoolWsArgs a) {
   int stamped = 0;
   for (;;) {
     pool_ws_body<EMIT>(a, wl, bias_lds, tile_first, tile_last, lane, tsw,
-                       stamped);
+                       stamped, n_edges);
     if (pool == 0) break;
     int c = 0;
     if (lane == 0)

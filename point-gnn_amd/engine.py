@@ -15,7 +15,8 @@ import torch
 
 from . import graph_gen, models
 
-__all__ = ["InferenceEngine", "shard_frames", "concurrent_streams"]
+__all__ = ["InferenceEngine", "DeferredFrame", "shard_frames",
+           "concurrent_streams"]
 
 _CONCURRENT = {}
 
@@ -86,6 +87,42 @@ def shard_frames(num_frames, rank, world_size):
     return list(range(rank, num_frames, world_size))
 
 
+class DeferredFrame(object):
+    """A frame enqueued in capacity form (InferenceEngine.run_frame_deferred):
+    the graph builder and the model ran without the host reading K or an edge
+    count.  `result()` is the frame's one host read: it waits for the frame,
+    learns (K, E0, E1, ...), and returns (logits [K, nc], box_encodings
+    [K, nc, len]) -- views of the capacity-sized outputs."""
+
+    def __init__(self, engine, xyz, intensity, logits, boxes, counts):
+        self.engine = engine
+        self.xyz, self.intensity = xyz, intensity
+        self.logits, self.boxes = logits, boxes
+        self.counts = counts
+        self._out = None
+
+    def result(self, host_counts=None):
+        if self._out is not None:
+            return self._out
+        if host_counts is not None:
+            self.counts._host = [int(v) for v in host_counts]
+        c = self.counts
+        eng = self.engine
+        graph_gen.check_kd_status(c.kd_status)
+        k, edges = c.k, c.edges
+        eng._hints = (eng._hints or graph_gen.CountHints()).update(k, edges)
+        if c.overflowed:
+            # an edge list did not fit the capacity the hints gave it (the
+            # hints now hold 2 x this frame's sizes): rebuild the frame
+            # with host-read sizes
+            eng.deferred_overflows += 1
+            self._out = eng.run_frame(self.xyz, self.intensity)
+        else:
+            eng.frame_shapes.append((k,) + tuple(edges))
+            self._out = (self.logits[:k], self.boxes[:k])
+        return self._out
+
+
 class InferenceEngine(object):
     def __init__(self, config, params, box_encoding_len=7, device=None):
         self.config = config
@@ -102,11 +139,45 @@ class InferenceEngine(object):
         # (K, E0, E1, ...) of every frame processed since the caller last
         # cleared it: the sizes are host-known as soon as the graph is built
         self.frame_shapes = []
+        # capacity form (run_frame_deferred): what the next frame's sizes
+        # are expected to be, learnt from the frames finished so far
+        self._hints = None
+        self.deferred_overflows = 0
 
     def _note_shape(self, graph):
         coords, _, edges = graph
-        self.frame_shapes.append(
-            (int(coords[1].shape[0]),) + tuple(int(e.shape[0]) for e in edges))
+        shape = (int(coords[1].shape[0]),) + tuple(int(e.shape[0])
+                                                   for e in edges)
+        self.frame_shapes.append(shape)
+        self._hints = (self._hints or graph_gen.CountHints()).update(
+            shape[0], shape[1:])
+
+    def build_graph_deferred(self, xyz):
+        """build_graph in capacity form: no size is read back (graph_gen's
+        `deferred_counts`).  Needs the sizes of an earlier frame as hints; the
+        first frame of an engine therefore goes through run_frame."""
+        if self._hints is None:
+            raise RuntimeError("no size hints yet: run one frame through "
+                               "run_frame() first")
+        return self.graph_fn(xyz, deferred_counts=self._hints,
+                             **self.graph_kwargs)
+
+    def run_frame_deferred(self, xyz, intensity):
+        """run_frame without a host wait: graph build and model are enqueued
+        back to back, sizes stay on the device.  Returns a DeferredFrame; its
+        .result() gives (logits, box_encodings)."""
+        if self._hints is None:
+            out = self.run_frame(xyz, intensity)
+            f = DeferredFrame(self, xyz, intensity, None, None, None)
+            f._out = out
+            return f
+        graph = self.build_graph_deferred(xyz)
+        coords, kps, edges = graph
+        logits, boxes = self.model.predict(intensity, coords, kps, edges,
+                                           is_training=False)
+        self.last_graph = graph
+        return DeferredFrame(self, xyz, intensity, logits, boxes,
+                             edges[0]._pgnn_count.frame)
 
     def build_graph(self, xyz):
         """(vertex_coord_list, keypoint_indices_list, edges_list) on the
@@ -175,8 +246,23 @@ class InferenceEngine(object):
             for h in owned:
                 _lib.check(lib.pgnn_stream_destroy(h), "pgnn_stream_destroy")
 
+    def _builder_streams(self, n, compute):
+        """`n` streams for graph builds that share no hardware queue with each
+        other or with the `compute` streams in use, as far as the device has
+        queues (concurrent_streams probes them; HIP gives a process 4 by
+        default, GPU_MAX_HW_QUEUES raises that); the first one is the
+        pipeline's graph stream."""
+        sg, _ = self._pipeline_streams(0)
+        out = [sg]
+        for s in concurrent_streams(1 + len(compute) + n):
+            if len(out) >= n:
+                break
+            if s is not sg and all(s is not c for c in compute):
+                out.append(s)
+        return out
+
     def run_frames_pipelined(self, frames, compute_streams=1, graph_cus=0,
-                             lookahead=0):
+                             lookahead=0, deferred=False, graph_streams=1):
         """Steady-state loop over independent frames on HIP streams: while a
         compute stream executes the GNN of frame i, stream G builds the graph
         of frame i+1.  The graph builder needs two host waits per frame (K, then
@@ -187,6 +273,16 @@ class InferenceEngine(object):
         of one frame's edge kernel overlap the next frame's work.
         graph_cus > 0 gives stream G that many CUs of its own and keeps the
         compute streams off them (see _pipeline_streams).
+        deferred=True builds the graphs in capacity form (no host wait at
+        all while frames are enqueued; sizes are read once, for all frames,
+        at the end -- that read waits for the device).  Only then can
+        graph_streams > 1 be used: consecutive frames' graphs are built on
+        alternating streams, each build running that many frames ahead of its
+        GNN.  Beside the persistent MFMA kernels a build takes about as long
+        as a frame's message passing (its big-LDS kernels wait for kernel
+        boundaries, the others run several times slower than alone: DESIGN
+        7), so ONE builder stream is the pipeline's bottleneck on most
+        frames; two are not.
         frames: iterable of (xyz, intensity) CUDA tensors.  Returns the list of
         (logits, box_encodings); outputs are complete after
         torch.cuda.synchronize() (or a wait on the compute streams)."""
@@ -203,15 +299,20 @@ class InferenceEngine(object):
             self._warm = True
         sg, scs = self._pipeline_streams(graph_cus)
         scs = scs[:max(1, min(4, int(compute_streams)))]
+        sgs = [sg]
+        if deferred and graph_cus <= 0 and int(graph_streams) > 1:
+            sgs = self._builder_streams(int(graph_streams), scs)
         cur = torch.cuda.current_stream()
-        for s in (sg,) + tuple(scs):
+        for s in tuple(sgs) + tuple(scs):
             s.wait_stream(cur)
 
         def build(i):
-            with torch.cuda.stream(sg):
-                g = self.build_graph(frames[i][0])
+            s_build = sgs[i % len(sgs)]
+            with torch.cuda.stream(s_build):
+                g = self.build_graph_deferred(frames[i][0]) if deferred \
+                    else self.build_graph(frames[i][0])
                 ev = torch.cuda.Event()
-                ev.record(sg)
+                ev.record(s_build)
             return g, ev
 
         # lookahead > 0: graphs come from a builder thread that runs up to
@@ -238,9 +339,16 @@ class InferenceEngine(object):
             worker = threading.Thread(target=produce, daemon=True)
             worker.start()
 
+        # builds are enqueued `ahead` frames before their GNN: one per
+        # builder stream
+        ahead = len(sgs)
+        queued = []
+
         def next_graph(i):
             if ready is None:
-                return build(i)
+                while len(queued) < ahead and i + len(queued) < len(frames):
+                    queued.append(build(i + len(queued)))
+                return queued.pop(0)
             item = ready.get()
             if isinstance(item, BaseException):
                 raise item
@@ -256,10 +364,17 @@ class InferenceEngine(object):
                     coords, kps, edges = graph
                     for t in list(coords) + list(kps) + list(edges):
                         t.record_stream(sc)  # allocated on G, consumed on C
-                    outs.append(self.model.predict(frames[i][1], coords, kps,
-                                                   edges, is_training=False))
+                    if deferred:
+                        counts = edges[0]._pgnn_count.frame
+                        counts.tensor.record_stream(sc)
+                    out = self.model.predict(frames[i][1], coords, kps,
+                                             edges, is_training=False)
+                    outs.append(DeferredFrame(self, frames[i][0], frames[i][1],
+                                              out[0], out[1], counts)
+                                if deferred else out)
                 self.last_graph = graph
-                self._note_shape(graph)
+                if not deferred:
+                    self._note_shape(graph)
                 if i + 1 < len(frames):
                     graph, ev = next_graph(i + 1)
         finally:
@@ -274,6 +389,10 @@ class InferenceEngine(object):
                 worker.join()
         for s in scs:
             cur.wait_stream(s)
+        if deferred:
+            # the one host read, for all frames together (waits for them)
+            host = torch.stack([f.counts.tensor for f in outs]).tolist()
+            outs = [f.result(h) for f, h in zip(outs, host)]
         return outs
 
     def run_frame(self, xyz, intensity, timed=False):

@@ -191,10 +191,14 @@ def _as_i32(t):
     return t
 
 
-def mlp_forward(chain, x, nx, x2=None, nx2=0, residual=None):
+def mlp_forward(chain, x, nx, x2=None, nx2=0, residual=None, count=None):
     """y = chain(concat(x[:, :nx], x2[:, :nx2])) (+ residual); returns a
-    [rows, padded_width(n_out)] tensor (pad columns are zero)."""
+    [rows, padded_width(n_out)] tensor (pad columns are zero).  `count` (a
+    _lib.DeviceCount; default: the one `x` is tagged with): capacity form --
+    x has capacity rows, the count is on the device, the result is tagged."""
     lib = _lib.load()
+    if count is None:
+        count = _lib.count_of(x)
     x = _as_f32(x)
     rows = int(x.shape[0])
     out_w = padded_width(chain.n_out)
@@ -204,13 +208,17 @@ def mlp_forward(chain, x, nx, x2=None, nx2=0, residual=None):
     if residual is not None:
         residual = _as_f32(residual)
         assert residual.shape[1] >= out_w
-    _lib.check(lib.pgnn_mlp_fwd(
-        _lib.ptr(x), x.stride(0), int(nx), _lib.ptr(x2),
-        x2.stride(0) if x2 is not None else 0, int(nx2), rows, chain.array,
-        chain.n, _lib.ptr(residual),
-        residual.stride(0) if residual is not None else 0, _lib.ptr(y),
-        y.stride(0), _lib.stream_ptr()), "pgnn_mlp_fwd")
-    return y
+    args = (_lib.ptr(x), x.stride(0), int(nx), _lib.ptr(x2),
+            x2.stride(0) if x2 is not None else 0, int(nx2), rows, chain.array,
+            chain.n, _lib.ptr(residual),
+            residual.stride(0) if residual is not None else 0, _lib.ptr(y),
+            y.stride(0))
+    if count is None:
+        _lib.check(lib.pgnn_mlp_fwd(*args, _lib.stream_ptr()), "pgnn_mlp_fwd")
+        return y
+    _lib.check(lib.pgnn_mlp_fwd_dyn(*args, count.arg(), _lib.stream_ptr()),
+               "pgnn_mlp_fwd_dyn")
+    return _lib.tag_count(y, count)
 
 
 # --------------------------------------------------------------------------
@@ -315,6 +323,16 @@ def mark_sorted(edges, flag=1):
     return edges
 
 
+def _both_counts(cnt_a, n_a, cnt_b, n_b, device):
+    """A *_dyn entry takes both of its sizes from the device: the one the
+    host does know becomes a one-element device constant."""
+    def const(n):
+        t = torch.full((1,), int(n), dtype=torch.int32, device=device)
+        return _lib.DeviceCount(t, int(n))
+    return (cnt_a if cnt_a is not None else const(n_a),
+            cnt_b if cnt_b is not None else const(n_b))
+
+
 # --------------------------------------------------------------------------
 # layers
 # --------------------------------------------------------------------------
@@ -349,6 +367,10 @@ class PointSetPooling(object):
                                       list(point_MLP_depth_list), False)
         feats = _as_f32(point_features)
         xyz = _as_f32(point_coordinates)
+        # capacity form (graph_gen's deferred_counts): K and the edge count
+        # are device-side, the tensors' leading dimensions are capacities
+        cnt_k = _lib.count_of(keypoint_indices)
+        cnt_e = _lib.count_of(set_indices)
         kp = _as_i32(keypoint_indices.reshape(-1))
         edges = _as_i32(set_indices)
         n_feat = int(feats.shape[1])
@@ -357,16 +379,23 @@ class PointSetPooling(object):
         k = int(kp.shape[0])
         agg = torch.empty((k, padded_width(point_chain.n_out)),
                           dtype=torch.float32, device=xyz.device)
-        _lib.check(lib.pgnn_point_set_pooling_fwd(
-            _lib.ptr(feats), n_feat, _lib.ptr(xyz), _lib.ptr(kp),
-            _lib.ptr(edges), int(edges.shape[0]), k, point_chain.array,
-            point_chain.n, _edges_sorted_flag(set_indices), _lib.ptr(agg),
-            agg.stride(0), _lib.ptr(_lib.sched_ws(xyz.device)),
-            _lib.stream_ptr()), "pgnn_point_set_pooling_fwd")
+        args = (_lib.ptr(feats), n_feat, _lib.ptr(xyz), _lib.ptr(kp),
+                _lib.ptr(edges), int(edges.shape[0]), k, point_chain.array,
+                point_chain.n, _edges_sorted_flag(set_indices), _lib.ptr(agg),
+                agg.stride(0), _lib.ptr(_lib.sched_ws(xyz.device)))
+        if cnt_k is None and cnt_e is None:
+            _lib.check(lib.pgnn_point_set_pooling_fwd(
+                *args, _lib.stream_ptr()), "pgnn_point_set_pooling_fwd")
+        else:
+            cnt_k, cnt_e = _both_counts(cnt_k, k, cnt_e, int(edges.shape[0]),
+                                        xyz.device)
+            _lib.check(lib.pgnn_point_set_pooling_fwd_dyn(
+                *args, cnt_e.arg(), cnt_k.arg(), _lib.stream_ptr()),
+                "pgnn_point_set_pooling_fwd_dyn")
         with variable_scope('combined_features'):
             out_chain = _relu_chain(store, _scope(),
                                     list(output_MLP_depth_list), False)
-        return mlp_forward(out_chain, agg, point_chain.n_out)
+        return mlp_forward(out_chain, agg, point_chain.n_out, count=cnt_k)
 
 
 # when set to a list, every GraphNetAutoCenter call appends its (P, Q) per-vertex
@@ -406,10 +435,17 @@ class GraphNetAutoCenter(object):
         store = _store()
         scope = _scope()
         st = _lib.stream_ptr()
+        cnt_k = _lib.count_of(input_vertex_features)
+        if cnt_k is None:
+            cnt_k = _lib.count_of(input_vertex_coordinates)
+        cnt_e = _lib.count_of(edges)
         h = _as_f32(input_vertex_features)
         x = _as_f32(input_vertex_coordinates)
         e = _as_i32(edges)
         k = int(h.shape[0])
+        if cnt_k is not None or cnt_e is not None:   # capacity form
+            cnt_k, cnt_e = _both_counts(cnt_k, k, cnt_e, int(e.shape[0]),
+                                        h.device)
 
         edge_widths = list(edge_MLP_depth_list)
         edge_scope = scope + '/extract_vertex_features'
@@ -450,21 +486,31 @@ class GraphNetAutoCenter(object):
         p = torch.empty((k, wq), dtype=torch.float32, device=h.device)
         agg = torch.empty((k, padded_width(rest.n_out)), dtype=torch.float32,
                           device=h.device)
-        _lib.check(lib.pgnn_vertex_pre_edge_fwd(
-            _lib.ptr(h), h.stride(0), c, _lib.ptr(x),
-            off_chain.array if off_chain is not None else None,
-            off_chain.n if off_chain is not None else 0, p_chain.array,
-            _lib.ptr(wx_dev), k, _lib.ptr(p), _lib.ptr(q), wq, _lib.ptr(agg),
-            agg.stride(0), st), "pgnn_vertex_pre_edge_fwd")
+        pre_args = (_lib.ptr(h), h.stride(0), c, _lib.ptr(x),
+                    off_chain.array if off_chain is not None else None,
+                    off_chain.n if off_chain is not None else 0, p_chain.array,
+                    _lib.ptr(wx_dev), k, _lib.ptr(p), _lib.ptr(q), wq,
+                    _lib.ptr(agg), agg.stride(0))
+        if cnt_k is None:
+            _lib.check(lib.pgnn_vertex_pre_edge_fwd(*pre_args, st),
+                       "pgnn_vertex_pre_edge_fwd")
+        else:
+            _lib.check(lib.pgnn_vertex_pre_edge_fwd_dyn(
+                *pre_args, cnt_k.arg(), st), "pgnn_vertex_pre_edge_fwd_dyn")
         if EDGE_INPUT_TAP is not None:   # measurement hook (bench.py)
             EDGE_INPUT_TAP.append((p, q))
         # per-edge: ReLU(P[src] - Q[dst]) -> remaining edge layers -> max
-        _lib.check(lib.pgnn_edge_mlp_scatter_max_fwd(
-            _lib.ptr(p), _lib.ptr(q), wq, int(rest.k_in), _lib.ptr(e),
-            int(e.shape[0]), k, rest.array, rest.n,
-            _edges_sorted_flag(edges) | 2, _lib.ptr(agg), agg.stride(0),
-            _lib.ptr(_lib.sched_ws(h.device)), st),
-            "pgnn_edge_mlp_scatter_max_fwd")
+        edge_args = (_lib.ptr(p), _lib.ptr(q), wq, int(rest.k_in), _lib.ptr(e),
+                     int(e.shape[0]), k, rest.array, rest.n,
+                     _edges_sorted_flag(edges) | 2, _lib.ptr(agg),
+                     agg.stride(0), _lib.ptr(_lib.sched_ws(h.device)))
+        if cnt_k is None:
+            _lib.check(lib.pgnn_edge_mlp_scatter_max_fwd(*edge_args, st),
+                       "pgnn_edge_mlp_scatter_max_fwd")
+        else:
+            _lib.check(lib.pgnn_edge_mlp_scatter_max_fwd_dyn(
+                *edge_args, cnt_e.arg(), cnt_k.arg(), st),
+                "pgnn_edge_mlp_scatter_max_fwd_dyn")
         # update + residual, gnn.py:367-372
         upd_chain = _relu_chain(store, scope + '/combined_features',
                                 list(update_MLP_depth_list), True)
@@ -474,7 +520,8 @@ class GraphNetAutoCenter(object):
                              device=h.device)
             hp[:, :h.shape[1]] = h
             h = hp
-        return mlp_forward(upd_chain, agg, rest.n_out, residual=h)
+        return mlp_forward(upd_chain, agg, rest.n_out, residual=h,
+                           count=cnt_k)
 
 
 class ClassAwarePredictor(object):
@@ -555,16 +602,17 @@ class ClassAwarePredictor(object):
                 chains.append((has_cls, lids, base, chain))
             return c, chains
         c, chains = store.cached(('heads', scope, nc, bl, hw), build)
-        logits = None
+        cnt = _lib.count_of(features)   # capacity form: rows behind the
+        logits = None                   # count are undefined in the outputs
         boxes = torch.empty((f.shape[0], nc, bl), dtype=torch.float32,
                             device=f.device)
         for has_cls, lids, base, chain in chains:
-            y = mlp_forward(chain, f, c)
+            y = mlp_forward(chain, f, c, count=cnt)
             if has_cls:
                 logits = y[:, :nc]
             blk = y[:, base:base + 8 * len(lids)].reshape(-1, len(lids), 8)
             boxes[:, lids[0]:lids[0] + len(lids), :] = blk[:, :, :bl]
-        return logits, boxes
+        return _lib.tag_count(logits, cnt), _lib.tag_count(boxes, cnt)
 
 
 class ClassAwareSeparatedPredictor(object):

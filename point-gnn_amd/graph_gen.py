@@ -26,7 +26,81 @@ from . import _lib
 
 __all__ = ["gen_disjointed_rnn_local_graph_v3",
            "gen_multi_level_local_graph_v3", "get_graph_generate_fn",
-           "multi_layer_downsampling_select", "multi_layer_downsampling_random"]
+           "multi_layer_downsampling_select", "multi_layer_downsampling_random",
+           "CountHints", "FrameCounts"]
+
+
+class CountHints(object):
+    """What the host expects a frame's sizes to be, for the capacity form
+    (`gen_multi_level_local_graph_v3(..., deferred_counts=hints)`): `k` the
+    keypoint count, `edges[l]` the edge count of level l -- both only steer
+    kernel choice and grid sizes -- and `edge_caps[l]` the rows allocated for
+    level l's edge list (a frame that needs more reports it, see FrameCounts).
+    `update(k, edges)` folds a finished frame's sizes in: hints follow the
+    last frame, capacities keep 2 x the largest list seen (8 bytes a row)."""
+
+    MIN_EDGE_CAP = 1 << 16
+
+    def __init__(self, k=0, edges=(), edge_caps=()):
+        self.k = int(k)
+        self.edges = [int(e) for e in edges]
+        self.edge_caps = [int(c) for c in edge_caps]
+
+    def update(self, k, edges):
+        self.k = int(k)
+        self.edges = [int(e) for e in edges]
+        caps = list(self.edge_caps) + [0] * (len(edges) - len(self.edge_caps))
+        self.edge_caps = [max(c, self.MIN_EDGE_CAP, 2 * int(e) + 1024)
+                          for c, e in zip(caps, edges)]
+        return self
+
+    def cap(self, level):
+        if level < len(self.edge_caps) and self.edge_caps[level] > 0:
+            return self.edge_caps[level]
+        return self.MIN_EDGE_CAP
+
+    def edge_hint(self, level):
+        return self.edges[level] if level < len(self.edges) else 0
+
+
+class FrameCounts(object):
+    """The sizes of one capacity-form frame, in device memory until `read()`:
+    tensor = int32 [2 + 2 L]: K, kd-tree tie-order status, then per level
+    (rows written, rows required).  `read()` is the frame's ONE host read (it
+    waits for the stream that built the graph); the caller does it when it
+    takes the frame's results, not before the model runs."""
+
+    def __init__(self, tensor, edge_caps):
+        self.tensor = tensor
+        self.edge_caps = list(edge_caps)
+        self._host = None
+
+    def read(self):
+        if self._host is None:
+            self._host = [int(v) for v in self.tensor.tolist()]
+        return self._host
+
+    @property
+    def k(self):
+        return self.read()[0]
+
+    @property
+    def kd_status(self):
+        return self.read()[1]
+
+    @property
+    def edges(self):
+        """Edge rows each level needs (== rows written unless overflowed)."""
+        v = self.read()
+        return [v[3 + 2 * l] for l in range(len(self.edge_caps))]
+
+    @property
+    def overflowed(self):
+        """Levels whose edge list did not fit its capacity (their tail was
+        dropped: the frame has to be rebuilt with a larger capacity)."""
+        v = self.read()
+        return [l for l in range(len(self.edge_caps))
+                if v[3 + 2 * l] > v[2 + 2 * l]]
 
 
 def _device():
@@ -169,6 +243,34 @@ def radius_graphs_device(queries):
     return out
 
 
+def radius_graph_dyn_device(points, centers, radius, scale, edge_cap,
+                            n_edges_out, edge_hint=0):
+    """Capacity form (pgnn_radius_graph_dyn): no host read.  `points` /
+    `centers` may be capacity-form tensors (tagged with a DeviceCount);
+    `n_edges_out` is the int32 [2] device slice that receives (rows written,
+    rows required).  Returns the [edge_cap, 2] edge tensor tagged with its
+    count."""
+    lib = _lib.load()
+    dev = points.device
+    cp, cc = _lib.count_of(points), _lib.count_of(centers)
+    points, centers, wide = _same_precision(points, centers)
+    n_p, n_c = int(points.shape[0]), int(centers.shape[0])
+    ws_bytes = lib.pgnn_radius_graph_dyn_workspace_bytes(n_p, n_c)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    edges = torch.empty((int(edge_cap), 2), dtype=torch.int32, device=dev)
+    keep, sp = _scale3(scale)
+    _lib.check((lib.pgnn_radius_graph_dyn_f64 if wide else
+                lib.pgnn_radius_graph_dyn)(
+        _lib.ptr(points), n_p, _lib.ptr(cp.dev if cp else None),
+        _lib.ptr(centers), n_c, _lib.ptr(cc.dev if cc else None),
+        float(radius), sp, _lib.ptr(ws), ws_bytes, _lib.ptr(edges),
+        int(edge_cap), _lib.ptr(n_edges_out), _lib.stream_ptr()),
+        "pgnn_radius_graph_dyn")
+    del keep
+    edges._pgnn_sorted = 1
+    return _lib.tag_count(edges, _lib.DeviceCount(n_edges_out[0:1], edge_hint))
+
+
 def gen_disjointed_rnn_local_graph_v3(
         points_xyz, center_xyz, radius, num_neighbors,
         neighbors_downsample_method='random', scale=None, seed=None):
@@ -218,10 +320,13 @@ def _aux_stream(dev):
 
 
 def keypoints_device(points, voxel_size, method='center', jitter=None, seed=0,
-                     fork_kdtree=False):
+                     fork_kdtree=False, num_out=None, k_hint=0):
     """One pooling level.  Returns (coords [K,3] in the dtype of `points`,
     indices int32 [K,1]) as device tensors.  One host sync (reading K and the
-    tie-order status together)."""
+    tie-order status together) -- unless `num_out` (an int32 [2] device
+    tensor) is given: then K and the status stay there, nothing is read, and
+    the two arrays come back in capacity form ([n,3] / [n,1], tagged with the
+    DeviceCount of K)."""
     lib = _lib.load()
     dev = points.device
     n = int(points.shape[0])
@@ -237,13 +342,14 @@ def keypoints_device(points, voxel_size, method='center', jitter=None, seed=0,
                 "downsample_method='center' on a float64 cloud that is not "
                 "float32-representable")
         c, i = keypoints_device(narrow, voxel_size, 'center', jitter, seed,
-                                fork_kdtree)
-        return c.to(torch.float64), i
+                                fork_kdtree, num_out, k_hint)
+        return _lib.tag_count(c.to(torch.float64), _lib.count_of(c)), i
     ws_bytes = lib.pgnn_keypoints_workspace_bytes(n)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     kp_idx = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
     kp_xyz = torch.empty((max(n, 1), 3), dtype=points.dtype, device=dev)
-    num = torch.empty(2, dtype=torch.int32, device=dev)  # always written
+    num = num_out if num_out is not None else \
+        torch.empty(2, dtype=torch.int32, device=dev)  # always written
     st = _lib.stream_ptr()
     if method == 'center':
         _lib.check(lib.pgnn_voxel_keypoints_center(
@@ -271,17 +377,29 @@ def keypoints_device(points, voxel_size, method='center', jitter=None, seed=0,
             "pgnn_voxel_keypoints_random")
     else:
         raise ValueError("unknown downsample method %r" % (method,))
+    if num_out is not None:   # capacity form: K stays on the device
+        cnt = _lib.DeviceCount(num[0:1], k_hint)
+        return (_lib.tag_count(kp_xyz, cnt),
+                _lib.tag_count(kp_idx.reshape(-1, 1), cnt))
     k, status = num.tolist()   # the one host read
+    check_kd_status(status)
+    return kp_xyz[:k], kp_idx[:k].reshape(k, 1)
+
+
+def check_kd_status(status):
+    """The tie-order status of the 'center' keypoints' kd-tree replica
+    (num_keypoints[1] of pgnn_voxel_keypoints_center): non-zero means the
+    frame's exact nearest-neighbour ties may be broken differently from the
+    reference's sklearn call."""
     if status != 0:
-        msg = ("kd-tree replica: std::nth_element's heap-select fallback "
-               "would have run on this cloud (not replicated); exact "
-               "nearest-neighbour ties of 'center' keypoints may differ from "
-               "the reference's sklearn order")
+        msg = ("kd-tree replica: the cloud is outside what the replica "
+               "reproduces (status %d); exact nearest-neighbour ties of "
+               "'center' keypoints may differ from the reference's sklearn "
+               "order" % status)
         if KD_STATUS_POLICY == 'raise':
             raise _lib.PointGnnHipError(msg)
         import warnings
         warnings.warn(msg, RuntimeWarning)
-    return kp_xyz[:k], kp_idx[:k].reshape(k, 1)
 
 
 def kdtree_replica(points):
@@ -314,7 +432,7 @@ def kdtree_replica(points):
 
 
 def _multi_layer_downsampling(points_xyz, base_voxel_size, levels, add_rnd3d,
-                              method):
+                              method, num_out=None, k_hint=0):
     p, was_np = _to_dev(points_xyz)
     coords = [p]
     kp_list = []
@@ -324,7 +442,9 @@ def _multi_layer_downsampling(points_xyz, base_voxel_size, levels, add_rnd3d,
         if np.isclose(last_level, level):
             # same scale (a GNN level): same vertices, identity keypoints
             coords.append(base)
-            kp_list.append(_identity_indices(int(base.shape[0]), base.device))
+            kp_list.append(_lib.tag_count(
+                _identity_indices(int(base.shape[0]), base.device),
+                _lib.count_of(base)))
         else:
             if len(coords) != 1:
                 raise NotImplementedError(
@@ -337,13 +457,15 @@ def _multi_layer_downsampling(points_xyz, base_voxel_size, levels, add_rnd3d,
                 if add_rnd3d:
                     raise NotImplementedError(
                         "add_rnd3d with downsample_method='center'")
-                c, i = keypoints_device(base, voxel, 'center')
+                c, i = keypoints_device(base, voxel, 'center',
+                                        num_out=num_out, k_hint=k_hint)
             else:
                 jitter = None
                 if add_rnd3d:  # graph_gen.py:126-128
                     jitter = voxel * np.random.random(3)
                 seed = int(np.random.randint(0, 2 ** 31 - 1))
-                c, i = keypoints_device(base, voxel, 'random', jitter, seed)
+                c, i = keypoints_device(base, voxel, 'random', jitter, seed,
+                                        num_out=num_out, k_hint=k_hint)
             coords.append(c)
             kp_list.append(i)
         last_level = level
@@ -373,14 +495,28 @@ def multi_layer_downsampling_random(points_xyz, base_voxel_size, levels=[1],
 
 
 def gen_multi_level_local_graph_v3(points_xyz, base_voxel_size, level_configs,
-                                   add_rnd3d=False, downsample_method='center'):
+                                   add_rnd3d=False, downsample_method='center',
+                                   deferred_counts=None):
     """graph_gen.py:155-195.  Returns (vertex_coord_list,
-    keypoint_indices_list, edges_list)."""
+    keypoint_indices_list, edges_list).
+
+    `deferred_counts` (extension; a CountHints, device tensors only): the
+    capacity form.  Nothing is read back while the graph is built -- the
+    reference's builder never waits for a size either (NumPy arrays carry
+    theirs) -- so the call returns as soon as the kernels are enqueued.  The
+    lists then hold capacity-sized tensors tagged with their device-side
+    counts (`_lib.count_of`), which the operators of pointgnn_amd.gnn accept
+    as they are; `edges_list[0]._pgnn_count.frame` is the FrameCounts record
+    the caller reads (once) when it takes the frame's results."""
     if isinstance(base_voxel_size, list):
         base_voxel_size = np.array(base_voxel_size)
     scales = [cfg['graph_scale'] for cfg in level_configs]
     if downsample_method not in ('center', 'random'):
         raise ValueError("unknown downsample_method %r" % (downsample_method,))
+    if deferred_counts is not None:
+        return _multi_level_graph_deferred(
+            points_xyz, base_voxel_size, level_configs, scales, add_rnd3d,
+            downsample_method, deferred_counts)
     coords, kps, was_np = _multi_layer_downsampling(
         points_xyz, base_voxel_size, scales, add_rnd3d, downsample_method)
     edges_list = []
@@ -406,6 +542,41 @@ def gen_multi_level_local_graph_v3(points_xyz, base_voxel_size, level_configs,
         return ([c.cpu().numpy() for c in coords],
                 [k.cpu().numpy() for k in kps],
                 [e.cpu().numpy() for e in edges_list])
+    return coords, kps, edges_list
+
+
+def _multi_level_graph_deferred(points_xyz, base_voxel_size, level_configs,
+                                scales, add_rnd3d, downsample_method, hints):
+    if not isinstance(points_xyz, torch.Tensor):
+        raise ValueError("deferred_counts needs device tensors (a NumPy "
+                         "result has to know its size)")
+    for cfg in level_configs:
+        if cfg['graph_gen_method'] != 'disjointed_rnn_local_graph_v3' or \
+                cfg['graph_gen_kwargs'].get('num_neighbors', -1) > 0:
+            raise NotImplementedError(
+                "deferred_counts: levels with a fan-in cap (training kwargs) "
+                "or another generator have no capacity form")
+    n_levels = len(level_configs)
+    dev = _device()
+    counts = torch.zeros(2 + 2 * n_levels, dtype=torch.int32, device=dev)
+    caps = [hints.cap(l) for l in range(n_levels)]
+    frame = FrameCounts(counts, caps)
+    coords, kps, _ = _multi_layer_downsampling(
+        points_xyz, base_voxel_size, scales, add_rnd3d, downsample_method,
+        num_out=counts[0:2], k_hint=hints.k)
+    for t in list(coords) + list(kps):
+        c = _lib.count_of(t)
+        if c is not None:
+            c.frame = frame
+    edges_list = []
+    for l, cfg in enumerate(level_configs):
+        lvl = cfg['graph_level']
+        e = radius_graph_dyn_device(
+            coords[lvl], coords[lvl + 1], cfg['graph_gen_kwargs']['radius'],
+            cfg['graph_gen_kwargs'].get('scale'), caps[l],
+            counts[2 + 2 * l:4 + 2 * l], hints.edge_hint(l))
+        _lib.count_of(e).frame = frame
+        edges_list.append(e)
     return coords, kps, edges_list
 
 

@@ -1,0 +1,221 @@
+"""Capacity form of the per-frame path: graph build and model with every size
+(K, E0, E1) left in device memory (graph_gen `deferred_counts`, the *_dyn
+entries of include/pointgnn_hip.h).  The reference's builder never waits for a
+size (graph_gen.py:155-220 hands NumPy arrays on); the bar here is that taking
+the host reads out changes nothing: keypoints, edge rows (order included),
+logits and box encodings are BIT-identical to the host-sized path, whatever
+the hints and capacities are."""
+import numpy as np
+import pytest
+
+import pointgnn_amd  # noqa: F401
+from pointgnn_amd import configs, weights
+from pointgnn_amd.synthetic import synthetic_cloud
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import torch
+    assert torch.cuda.is_available()
+    from pointgnn_amd import _lib
+    _lib.load()
+    return torch.device("cuda")
+
+
+def T(a, dev):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _graph_kwargs(cfg):
+    return cfg['runtime_graph_gen_kwargs']
+
+
+@pytest.mark.parametrize("wide", [False, True])
+def test_radius_graph_dyn_equals_count_fill(dev, wide):
+    """pgnn_radius_graph_dyn on capacity-form points / centres (valid rows
+    followed by garbage, counts on the device) == pgnn_radius_graph_count +
+    _fill on the exact arrays, row for row."""
+    import torch
+    from pointgnn_amd import _lib, graph_gen as G
+    rng = np.random.default_rng(5)
+    dt = np.float64 if wide else np.float32
+    pts = (rng.random((6000, 3)) * [40, 3, 40]).astype(dt)
+    ctr = pts[rng.permutation(6000)[:900]].copy()
+    ctr[::7] += 0.01
+    for r, scale in ((1.0, None), (2.5, (1.0, 2.0, 1.0))):
+        want, _ = G.radius_graph_device(T(pts, dev), T(ctr, dev), r, scale)
+        # capacity form: 30 % more rows of garbage behind the valid ones
+        pcap = np.concatenate([pts, rng.random((1800, 3)).astype(dt) * 40])
+        ccap = np.concatenate([ctr, rng.random((300, 3)).astype(dt) * 40])
+        counts = torch.tensor([6000, 900, 0, 0], dtype=torch.int32, device=dev)
+        p = _lib.tag_count(T(pcap, dev), _lib.DeviceCount(counts[0:1], 6000))
+        c = _lib.tag_count(T(ccap, dev), _lib.DeviceCount(counts[1:2], 900))
+        cap = int(want.shape[0]) + 1000
+        got = G.radius_graph_dyn_device(p, c, r, scale, cap, counts[2:4])
+        n_written, n_required = counts[2:4].tolist()
+        assert n_written == n_required == int(want.shape[0])
+        assert torch.equal(got[:n_written], want)
+        # too small a buffer: the prefix is written, the required size reported
+        small = int(want.shape[0]) // 2
+        got = G.radius_graph_dyn_device(p, c, r, scale, small, counts[2:4])
+        assert counts[2:4].tolist() == [small, int(want.shape[0])]
+        assert torch.equal(got, want[:small])
+
+
+def test_radius_graph_dyn_empty_and_zero_counts(dev):
+    import torch
+    from pointgnn_amd import _lib, graph_gen as G
+    pts = T(np.random.default_rng(0).random((500, 3)).astype(np.float32), dev)
+    counts = torch.tensor([0, 0, 7, 7], dtype=torch.int32, device=dev)
+    p = _lib.tag_count(pts, _lib.DeviceCount(counts[0:1], 0))
+    c = _lib.tag_count(pts.clone(), _lib.DeviceCount(counts[1:2], 0))
+    G.radius_graph_dyn_device(p, c, 0.5, None, 4096, counts[2:4])
+    assert counts[2:4].tolist() == [0, 0]
+    counts[0] = 500          # points, but no centre
+    G.radius_graph_dyn_device(p, c, 0.5, None, 4096, counts[2:4])
+    assert counts[2:4].tolist() == [0, 0]
+    counts[0], counts[1] = 0, 500   # centres, but no point
+    G.radius_graph_dyn_device(p, c, 0.5, None, 4096, counts[2:4])
+    assert counts[2:4].tolist() == [0, 0]
+
+
+@pytest.mark.parametrize("cfg_name,preset", [
+    ("car", "small"), ("car", "car"), ("ped", "small")])
+def test_deferred_graph_equals_host_sized_graph(dev, cfg_name, preset):
+    """gen_multi_level_local_graph_v3(deferred_counts=...) == the host-sized
+    call: same keypoints in the same order, same edge rows in the same
+    order."""
+    import torch
+    from pointgnn_amd import _lib, graph_gen as G
+    cfg = configs.car_auto_config(3) if cfg_name == "car" else \
+        configs.ped_cyl_auto_config(3)
+    xyz, _ = synthetic_cloud(seed=3, preset=preset)
+    x = T(xyz, dev)
+    kw = _graph_kwargs(cfg)
+    coords, kps, edges = G.gen_multi_level_local_graph_v3(x, **kw)
+    k = int(coords[1].shape[0])
+    hints = G.CountHints().update(k, [int(e.shape[0]) for e in edges])
+    for trial in range(3):
+        if trial == 1:      # hints far off: only speed may change
+            hints.k, hints.edges = 7, [11, 13]
+        if trial == 2:
+            hints.k, hints.edges = 10 * k, [10 ** 8, 10 ** 8]
+        c2, k2, e2 = G.gen_multi_level_local_graph_v3(
+            x, deferred_counts=hints, **kw)
+        frame = _lib.count_of(e2[0]).frame
+        assert frame.k == k and frame.kd_status == 0
+        assert frame.edges == [int(e.shape[0]) for e in edges]
+        assert not frame.overflowed
+        assert int(c2[1].shape[0]) == int(x.shape[0])      # capacity = N
+        for a, b in zip(coords, c2):
+            n = int(a.shape[0])
+            assert torch.equal(a, b[:n])
+        for a, b in zip(kps, k2):
+            assert torch.equal(a, b[:int(a.shape[0])])
+        for a, b in zip(edges, e2):
+            assert torch.equal(a, b[:int(a.shape[0])])
+
+
+@pytest.mark.parametrize("cfg_name,preset,hint_scale", [
+    ("car", "car", 1.0), ("car", "car", 0.01), ("car", "car", 50.0),
+    ("car", "small", 1.0), ("car", "small", 100.0),
+    ("ped", "small", 1.0), ("ped", "car", 1.0), ("ped", "car", 0.01)])
+def test_deferred_frame_is_bit_identical(dev, cfg_name, preset, hint_scale):
+    """Graph build + model in capacity form == the host-sized frame, bit for
+    bit, also when the hints point at the other kernel of a pair (8-wave vs
+    4-wave rows kernel, weights-stationary vs LDS-tile edge / pooling
+    kernels): the choice is made on the hint and may not change a result."""
+    import torch
+    from pointgnn_amd import graph_gen as G
+    from pointgnn_amd.engine import InferenceEngine
+    cfg = configs.car_auto_config(3) if cfg_name == "car" else \
+        configs.ped_cyl_auto_config(3)
+    params = weights.init_params(cfg, seed=4, bias_scale=0.05)
+    eng = InferenceEngine(cfg, params, device=dev)
+    xyz, inten = synthetic_cloud(seed=1, preset=preset)
+    x, f = T(xyz, dev), T(inten, dev)
+    lg, bx = eng.run_frame(x, f)
+    k, e0, e1 = eng.frame_shapes[-1]
+    eng._hints = G.CountHints(
+        max(1, int(k * hint_scale)),
+        [max(1, int(e0 * hint_scale)), max(1, int(e1 * hint_scale))],
+        [e0 + 4096, e1 + 4096])
+    d = eng.run_frame_deferred(x, f)
+    assert d.counts._host is None          # nothing was read while enqueuing
+    lg2, bx2 = d.result()
+    assert eng.deferred_overflows == 0
+    assert eng.frame_shapes[-1] == (k, e0, e1)
+    assert lg2.shape == lg.shape and bx2.shape == bx.shape
+    assert torch.isfinite(lg2).all()
+    assert torch.equal(lg, lg2) and torch.equal(bx, bx2)
+
+
+def test_deferred_overflow_is_detected_and_rebuilt(dev):
+    """An edge list larger than its capacity: the frame reports it (required
+    > written) and the engine rebuilds it with host-read sizes; the next
+    frame's capacity covers it."""
+    import torch
+    from pointgnn_amd import graph_gen as G
+    from pointgnn_amd.engine import InferenceEngine
+    cfg = configs.car_auto_config(2)
+    params = weights.init_params(cfg, seed=6, bias_scale=0.05)
+    eng = InferenceEngine(cfg, params, device=dev)
+    xyz, inten = synthetic_cloud(seed=2, preset="car")
+    x, f = T(xyz, dev), T(inten, dev)
+    lg, bx = eng.run_frame(x, f)
+    k, e0, e1 = eng.frame_shapes[-1]
+    eng._hints = G.CountHints(k, [e0, e1], [e0 // 2, e1 + 10])
+    d = eng.run_frame_deferred(x, f)
+    assert d.counts.overflowed == [0]
+    lg2, bx2 = d.result()
+    assert eng.deferred_overflows == 1
+    assert torch.equal(lg, lg2) and torch.equal(bx, bx2)
+    assert eng._hints.cap(0) >= e0 and eng._hints.cap(1) >= e1
+    d = eng.run_frame_deferred(x, f)
+    lg3, bx3 = d.result()
+    assert eng.deferred_overflows == 1 and not d.counts.overflowed
+    assert torch.equal(lg, lg3) and torch.equal(bx, bx3)
+
+
+def test_deferred_pipeline_equals_sequential(dev):
+    """run_frames_pipelined(deferred=True): frames of different sizes through
+    the multi-stream schedule without a host wait == frame-at-a-time."""
+    import torch
+    from pointgnn_amd.engine import InferenceEngine
+    cfg = configs.car_auto_config(2)
+    params = weights.init_params(cfg, seed=9, bias_scale=0.05)
+    eng = InferenceEngine(cfg, params, device=dev)
+    frames = []
+    for s in range(6):
+        xyz, inten = synthetic_cloud(
+            seed=s, preset=("small", "tiny", "car")[s % 3])
+        frames.append((T(xyz, dev), T(inten, dev)))
+    seq = [eng.run_frame(x, f) for x, f in frames]
+    shapes = list(eng.frame_shapes)
+    torch.cuda.synchronize()
+    for rep in range(6):
+        eng.frame_shapes = []
+        # reps 2..5: the graphs of consecutive frames on two / three builder
+        # streams, each build running that many frames ahead of its GNN
+        pip = eng.run_frames_pipelined(frames, compute_streams=1 + rep % 2,
+                                       deferred=True,
+                                       graph_streams=1 + rep // 2)
+        torch.cuda.synchronize()
+        assert eng.frame_shapes == shapes[-len(frames):]
+        for (l0, b0), (l1, b1) in zip(seq, pip):
+            assert torch.equal(l0, l1) and torch.equal(b0, b1)
+
+
+def test_deferred_reports_kd_status(dev):
+    """The kd-tree replica's tie-order status travels with the counts: a
+    cloud outside what the replica reproduces raises when the frame's result
+    is taken, like the host-sized path does when it reads K."""
+    from pointgnn_amd import _lib, graph_gen as G
+    c = G.FrameCounts(None, [10, 10])
+    c._host = [5, 1, 3, 3, 4, 4]
+    assert c.kd_status == 1 and c.k == 5 and c.edges == [3, 4]
+    with pytest.raises(_lib.PointGnnHipError):
+        G.check_kd_status(c.kd_status)
