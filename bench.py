@@ -636,6 +636,21 @@ def pool_statistics(cfg, shapes):
             "exe_flops_mean": float(np.mean(exe))}
 
 
+# frame schedule per inference config (A/B on one MI355X): whole
+# frames on 3 streams for car_auto_T3 (307 vs 300 frames/s with the split);
+# one GNN stream + two builder streams for ped_cyl_auto_T3 (135 vs 130: its
+# LDS-tile pooling kernel and the C = 256 edge kernel of different frames
+# start on each other's tails when GNN streams overlap)
+SCHEDULES = {"car_auto_T3": 3, "car_auto_T2": 3, "car_auto_T1": 3,
+             "car_auto_T0": 3, "ped_cyl_auto_T3": 0}
+
+
+def frame_streams_for(args, config_name):
+    if args.frame_streams >= 0:
+        return args.frame_streams
+    return SCHEDULES.get(config_name, 3)
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -667,6 +682,12 @@ def parse_args(argv=None):
     ap.add_argument("--frames-per-gpu", type=int, default=2)
     ap.add_argument("--compute-streams", type=int, default=1,
                     help="GNN streams of the frame pipeline (1 or 2)")
+    ap.add_argument("--frame-streams", type=int, default=-1,
+                    help="capacity form: streams that take whole frames "
+                         "(build + GNN) round-robin; 0 = the builder / "
+                         "compute split (--graph-streams, --compute-streams); "
+                         "-1 = the schedule measured best for the config "
+                         "(SCHEDULES)")
     ap.add_argument("--graph-streams", type=int, default=2,
                     help="streams the graphs of consecutive frames are built "
                          "on (capacity form only; 1 = a single builder)")
@@ -828,13 +849,21 @@ def secondary_ped(args, torch, dev, measure):
     cfg = configs.get_config("ped_cyl_auto_T3")
     params = weights.init_params(cfg, seed=0, bias_scale=0.05)
     eng = InferenceEngine(cfg, params, device=dev)
+    eng.config_name = "ped_cyl_auto_T3"
     steps = max(10, min(16, args.steps // 2))
     elapsed, shapes, pool = measure("ped_dense", steps, 3, engine=eng,
                                     n_frames=4)
     st = pool_statistics(cfg, shapes)
     out = {
         "workload": "ped_cyl_auto_T3 inference, preset 'ped_dense' (4 seeded "
-                    "frames cycled), 1 frame/step, same pipeline",
+                    "frames cycled), 1 frame/step; schedule: %s" % (
+                        "%d whole-frame streams" % frame_streams_for(
+                            args, "ped_cyl_auto_T3")
+                        if frame_streams_for(args, "ped_cyl_auto_T3") > 0 and
+                        not args.host_sized else
+                        "%d GNN + %d builder stream(s)" % (
+                            args.compute_streams,
+                            1 if args.host_sized else args.graph_streams)),
         "steps": steps, "frames_per_sec": steps / elapsed,
         "ms_per_frame": elapsed / steps * 1e3, "N": 50000,
         "K": st["K"], "E0": st["E0"], "E1": st["E1"],
@@ -921,6 +950,7 @@ def main(argv=None):
     cfg = configs.get_config(args.config)
     params = weights.init_params(cfg, seed=0, bias_scale=0.05)
     engine = InferenceEngine(cfg, params, device=dev)
+    engine.config_name = args.config
 
     def measure(preset, steps, warmup, engine=engine, n_frames=None):
         """Time `steps` frames per rank of `preset`; returns (elapsed max over
@@ -954,6 +984,9 @@ def main(argv=None):
                 for x, f in fr:
                     out = engine.run_frame(x, f)
                 return out
+            n_fs = frame_streams_for(args, engine.config_name)
+            if deferred and n_fs > 0 and args.graph_cus <= 0:
+                return engine.run_frames_on_streams(fr, n_fs)[-1]
             return engine.run_frames_pipelined(
                 fr, compute_streams=args.compute_streams,
                 graph_cus=args.graph_cus, lookahead=args.lookahead,
@@ -1053,6 +1086,9 @@ def main(argv=None):
         assert st["frames"] == world * args.steps
         n_builders = 1 if (args.host_sized or args.graph_cus > 0) else \
             max(1, args.graph_streams)
+        n_fs = frame_streams_for(args, args.config)
+        frame_sched = (not args.host_sized and n_fs > 0 and
+                       args.graph_cus <= 0)
         fps = world * args.steps / elapsed
         n_pts = int(x.shape[0])
         res = {
@@ -1078,15 +1114,19 @@ def main(argv=None):
                          "capacity form: K, E0, E1 stay on the device, one "
                          "host read per batch of frames (results)",
                 "schedule": "sequential, 1 stream" if args.no_pipeline else
-                            "%d HIP streams: the graphs of frames i+1 .. i+%d "
-                            "are built on %d builder stream(s) while %d GNN "
-                            "stream(s) run frame i%s" % (
-                                args.compute_streams + n_builders,
-                                n_builders, n_builders, args.compute_streams,
-                                ("; graph stream on %d reserved CUs, GNN "
-                                 "streams on the other CUs (CU-masked "
-                                 "streams)" % args.graph_cus
-                                 if args.graph_cus > 0 else "")),
+                            ("%d HIP streams, frame i (graph build + GNN) "
+                             "wholly on stream i %% %d; sizes are read once "
+                             "per batch of frames" % (n_fs, n_fs)
+                             if frame_sched else
+                             "%d HIP streams: the graphs of frames i+1 .. i+%d "
+                             "are built on %d builder stream(s) while %d GNN "
+                             "stream(s) run frame i%s" % (
+                                 args.compute_streams + n_builders,
+                                 n_builders, n_builders, args.compute_streams,
+                                 ("; graph stream on %d reserved CUs, GNN "
+                                  "streams on the other CUs (CU-masked "
+                                  "streams)" % args.graph_cus
+                                  if args.graph_cus > 0 else ""))),
                 "parallelism": "frame-parallel x%d (no collective)" % world,
                 "distributed": dist_info(dist, world),
                 "frames_per_sec_per_gpu": fps / world,

@@ -79,16 +79,18 @@ __device__ __forceinline__ void atomic_max_f32(float *addr, float v) {
   }
 }
 
-// The graph-build kernels are chains of short dependent steps (a load, a
-// ballot, a barrier ...).  In the frame pipeline they share CUs with the
-// persistent MFMA kernels of the previous frame's message passing, whose
-// older, always-ready waves win every issue arbitration at equal priority:
-// measured, the builder's kernels then run 3-7x slower (radix_scatter 8.5 ->
-// 57 us, kd_top 59 -> 297 us) and the build of frame i+1 approaches the
-// length of frame i.  They issue few instructions, so letting them go first
-// costs the MFMA kernels next to nothing.
+// Wave priority of the graph-build kernels (s_setprio), compile-time, default 0.
+// These kernels are chains of short dependent steps (a load, a ballot, a
+// barrier ...); in the frame pipeline they share CUs with the persistent MFMA
+// kernels of another frame's message passing and every step then takes 5-9x
+// longer (tools/corun_probe.py: VALU chain 14 -> 69 ns per step, L2 pointer
+// chase 117 -> 1018 ns, barrier 66 -> 511 ns).  Raising their priority does
+// NOT change that (same table, priority 3: 67 / 1018 / 444 ns) -- the waves
+// are not losing an arbitration they could win, the SIMD and the memory path
+// are simply busy -- and it costs the MFMA kernels ~0.5 % once the pipeline
+// is bound by them (-DPGNN_GRAPH_PRIO=3: 298.8 vs 300.3 frames/s).
 #ifndef PGNN_GRAPH_PRIO
-#define PGNN_GRAPH_PRIO 3
+#define PGNN_GRAPH_PRIO 0
 #endif
 __device__ __forceinline__ void graph_prio() {
 #if PGNN_GRAPH_PRIO > 0

@@ -209,6 +209,32 @@ def test_deferred_pipeline_equals_sequential(dev):
             assert torch.equal(l0, l1) and torch.equal(b0, b1)
 
 
+def test_frames_on_streams_equal_sequential(dev):
+    """run_frames_on_streams: whole frames (graph build + GNN, capacity form)
+    round-robin on 1..4 streams == frame-at-a-time execution, bit for bit,
+    for frames of different sizes and for both shipped inference configs."""
+    import torch
+    from pointgnn_amd.engine import InferenceEngine
+    for cfg in (configs.car_auto_config(2), configs.ped_cyl_auto_config(1)):
+        params = weights.init_params(cfg, seed=11, bias_scale=0.05)
+        eng = InferenceEngine(cfg, params, device=dev)
+        frames = []
+        for s in range(7):
+            xyz, inten = synthetic_cloud(
+                seed=s, preset=("small", "car", "tiny")[s % 3])
+            frames.append((T(xyz, dev), T(inten, dev)))
+        seq = [eng.run_frame(x, f) for x, f in frames]
+        shapes = list(eng.frame_shapes)
+        torch.cuda.synchronize()
+        for n in (1, 2, 3, 4):
+            eng.frame_shapes = []
+            got = eng.run_frames_on_streams(frames, n)
+            assert eng.frame_shapes == shapes
+            for (l0, b0), (l1, b1) in zip(seq, got):
+                assert torch.equal(l0, l1) and torch.equal(b0, b1)
+        assert eng.deferred_overflows == 0
+
+
 def test_deferred_reports_kd_status(dev):
     """The kd-tree replica's tie-order status travels with the counts: a
     cloud outside what the replica reproduces raises when the frame's result
