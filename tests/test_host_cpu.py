@@ -213,6 +213,52 @@ def test_error_reporting_without_gpu():
     assert lib.pgnn_metrics_compute(None, 4, 200, None, None) == -1
 
 
+def test_capacity_form_host_logic():
+    """The host side of the capacity form (graph_gen deferred_counts): size
+    hints and capacities, the FrameCounts record, the pgnn_dyn_count struct
+    and the *_dyn entries' argument checks -- no GPU involved."""
+    import ctypes
+    from pointgnn_amd import graph_gen as G
+    L, lib = _lib()
+    # struct pgnn_dyn_count {const int32_t *dev; int64_t hint;}
+    assert ctypes.sizeof(L.DynCount) == 16
+    assert L.DynCount.dev.offset == 0 and L.DynCount.hint.offset == 8
+    h = G.CountHints()
+    assert h.cap(0) == G.CountHints.MIN_EDGE_CAP and h.edge_hint(1) == 0
+    h.update(3000, [350000, 600000])
+    assert h.k == 3000 and h.edges == [350000, 600000]
+    assert h.cap(0) >= 2 * 350000 and h.cap(1) >= 2 * 600000
+    caps = list(h.edge_caps)
+    h.update(2500, [10, 20])                  # hints follow, capacities stay
+    assert h.k == 2500 and h.edges == [10, 20] and h.edge_caps == caps
+    h.update(2500, [900000, 20])              # ... and only ever grow
+    assert h.cap(0) >= 1800000 and h.cap(1) == caps[1]
+    c = G.FrameCounts(None, [100, 50])
+    c._host = [7, 0, 100, 130, 40, 40]        # level 0 needed 130 rows, had 100
+    assert (c.k, c.kd_status, c.edges, c.overflowed) == (7, 0, [130, 40], [0])
+    c._host = [7, 0, 90, 90, 40, 40]
+    assert c.overflowed == []
+    # the capacity-form entries validate before any HIP call
+    assert lib.pgnn_radius_graph_dyn_workspace_bytes(-1, 5) == 0
+    assert lib.pgnn_radius_graph_dyn_workspace_bytes(20000, 20000) > \
+        lib.pgnn_radius_graph_workspace_bytes(20000, 20000)
+    assert lib.pgnn_radius_graph_dyn(None, 10, None, None, 10, None, 1.0, None,
+                                     None, 0, None, 100, None, None) == -1
+    assert lib.pgnn_mlp_fwd_dyn(None, 0, 4, None, 0, 0, 16, None, 1, None, 0,
+                                None, 0, None, None) == -1   # null count
+    assert b"count" in lib.pgnn_last_error()
+    assert lib.pgnn_vertex_pre_edge_fwd_dyn(None, 0, 0, None, None, 0, None,
+                                            None, 5, None, None, 0, None, 0,
+                                            None, None) == -1
+    # builder tunables of the frame pipeline exist and are range-checked
+    for key, ok, bad in (("graph_max_wgs", 8, -1), ("graph_lds_pad", 32768,
+                                                    1 << 20),
+                         ("ws_reserve", 8, 3)):
+        assert lib.pgnn_set_tunable(key.encode(), ok) == 0
+        assert lib.pgnn_set_tunable(key.encode(), bad) != 0
+        assert lib.pgnn_set_tunable(key.encode(), 0) == 0
+
+
 def _emulate_mfma_layer(x, packed, k_in, n_out):
     """NumPy model of mlp_engine.h: A fragment = x[row][16q + 4g + s], B
     fragment = packed[q][t][lane][s]; v_mfma_f32_16x16x4 sums the four k-slots
