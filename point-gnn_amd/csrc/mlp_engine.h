@@ -26,6 +26,9 @@ namespace pgnn {
 #ifndef PGNN_PF4
 #define PGNN_PF4 2  // register stages of the K-group pipeline for 64-row tiles
 #endif
+#ifndef PGNN_PF1
+#define PGNN_PF1 4  // ... for 16-row tiles (the K-row kernels)
+#endif
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
@@ -73,7 +76,7 @@ __device__ __forceinline__ void gemm_tile(const float *__restrict__ tile, int ld
   // (MSUB = 1: 20 MFMAs ~ 640 cycles per group, far less than an L2 round
   // trip) get 4.  The prefetch index is clamped, so the tail re-reads a valid
   // group instead of branching around loads.
-  constexpr int PF = MSUB >= 4 ? PGNN_PF4 : (MSUB == 2 ? 3 : 4);
+  constexpr int PF = MSUB >= 4 ? PGNN_PF4 : (MSUB == 2 ? 3 : PGNN_PF1);
   v4f a[PF][MSUB], b[PF][NT];
   auto fetch = [&](int q, v4f (&fa)[MSUB], v4f (&fb)[NT]) {
     if (q > kq - 1) q = kq - 1;
