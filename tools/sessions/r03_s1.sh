@@ -2,7 +2,7 @@
 # Round-3 GPU session 1: GPU suite on the float64 / raster / sched changes,
 # the new default bench line, and a per-launch trace of the training step.
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/s1
 rm -rf $OUT; mkdir -p $OUT

@@ -1,7 +1,7 @@
 #!/bin/bash
 # capped builder grids: parity in both modes, then graph build alone / beside
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/s13
 rm -rf $OUT; mkdir -p $OUT
@@ -13,4 +13,4 @@ tail -3 $OUT/pytest_capped.log
 echo "== corun default"; timeout 300 python tools/corun.py 2>&1 | grep -v amdgpu.ids
 echo "== corun capped"; timeout 300 python tools/corun.py --tune graph_max_wgs=8 --tune graph_lds_pad=32768 --tune ws_reserve=8 2>&1 | grep -v amdgpu.ids
 echo "== corun capped 16"; timeout 300 python tools/corun.py --tune graph_max_wgs=16 --tune graph_lds_pad=32768 --tune ws_reserve=16 2>&1 | grep -v amdgpu.ids
-bash tools/r03_s8.sh "" "--compute-streams 1 --tune graph_max_wgs=8 --tune graph_lds_pad=32768 --tune ws_reserve=8" "--compute-streams 2 --tune graph_max_wgs=8 --tune graph_lds_pad=32768 --tune ws_reserve=8" "--compute-streams 1 --tune graph_max_wgs=16 --tune graph_lds_pad=32768 --tune ws_reserve=16"
+bash tools/sessions/r03_s8.sh "" "--compute-streams 1 --tune graph_max_wgs=8 --tune graph_lds_pad=32768 --tune ws_reserve=8" "--compute-streams 2 --tune graph_max_wgs=8 --tune graph_lds_pad=32768 --tune ws_reserve=8" "--compute-streams 1 --tune graph_max_wgs=16 --tune graph_lds_pad=32768 --tune ws_reserve=16"

@@ -1,7 +1,7 @@
 #!/bin/bash
 # per-kernel durations of one sequential frame (no overlap)
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/s15
 rm -rf $OUT; mkdir -p $OUT

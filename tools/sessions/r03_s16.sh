@@ -1,7 +1,7 @@
 #!/bin/bash
 # full GPU suite (default and capped-builder modes for the graph tests) + the default bench line
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/s16
 rm -rf $OUT; mkdir -p $OUT

@@ -1,7 +1,7 @@
 #!/bin/bash
 # per-vertex kernel durations (sequential frame, rocprof) and bench fps per library variant
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/s19
 mkdir -p $OUT

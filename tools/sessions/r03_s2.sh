@@ -2,7 +2,7 @@
 # Round-3 GPU session 2: training-step work -- the training tests, the
 # training bench line, a per-launch trace of one step.
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/s2
 rm -rf $OUT; mkdir -p $OUT

@@ -2,7 +2,7 @@
 # Round-3 GPU session 3: capacity form (no host read in graph build / model):
 # its tests, then the bench line with and without it on the same box.
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/s3
 rm -rf $OUT; mkdir -p $OUT

@@ -2,7 +2,7 @@
 # Round-3 GPU session 4: graph-build kernels beside the persistent MFMA kernels
 # (wave priority, small-footprint kd-tree build): same-box A/B of the bench.
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/s4
 rm -rf $OUT; mkdir -p $OUT

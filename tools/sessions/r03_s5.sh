@@ -2,7 +2,7 @@
 # Round-3 GPU session 5: kernel trace of the steady-state frame pipeline.
 # usage: r03_s5.sh <tag> [pipe_run.py arguments]
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/s5
 mkdir -p $OUT

@@ -1,7 +1,7 @@
 #!/bin/bash
 # graph build alone / beside the GNN kernels, per library variant and CU split
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/s6
 mkdir -p $OUT

@@ -2,7 +2,7 @@
 # bench A/B over extra bench arguments (one quoted string per run; a leading
 # ENV=VALUE word is exported for that run)
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/s8
 mkdir -p $OUT
