@@ -823,6 +823,13 @@ int pgnn_kitti_cam_points_in_image(
  *   launch shape   scatter_rows_per_wave, scatter_nt, mlp_blocks_per_cu,
  *                  edge_msub, pool_msub, mlp_pool_pct, wgrad_wg_target,
  *                  ws_xcds, ws_prio, ws_pool_pct, ws_chunk, ws_reserve
+ *   graph builder  graph_max_wgs (cap on the workgroups of one builder launch;
+ *                  every builder kernel strides over its work), graph_lds_pad
+ *                  (bytes of dynamic LDS every builder launch asks for without
+ *                  using them: such a workgroup cannot be placed beside one of
+ *                  the weights-stationary kernels); with ws_reserve they put
+ *                  the builder on CUs the fused kernels leave free (measured:
+ *                  no net gain; default 0 = off)
  *   kernel choice  mlp_debug bits 2048 / 4096 (edge stage: LDS-tile kernel /
  *                  weights-stationary kernel), 8192 / 16384 (pooling stage),
  *                  1024 (pooling hidden layers through the LDS tile), 32 / 128
