@@ -6,7 +6,10 @@
 
 namespace pgnn {
 
-constexpr int kSortTile = 2048;  // keys per block per pass
+#ifndef PGNN_SORT_TILE
+#define PGNN_SORT_TILE 2048
+#endif
+constexpr int kSortTile = PGNN_SORT_TILE;  // keys per block per pass
 
 // bytes of scratch radix_sort_pairs needs for n pairs (excluding the ping-pong
 // key/value buffers, which the caller provides)

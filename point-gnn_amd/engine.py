@@ -292,8 +292,12 @@ class InferenceEngine(object):
                 pending.append(self.run_frame_deferred(xyz, intensity))
         for s in streams:
             cur.wait_stream(s)
-        host = torch.stack([f.counts.tensor for f in pending]).tolist()
-        outs = [f.result(h) for f, h in zip(pending, host)]
+        live = [f for f in pending if f.counts is not None]
+        host = torch.stack([f.counts.tensor for f in live]).tolist() \
+            if live else []
+        for f, h in zip(live, host):
+            f.result(h)
+        outs = [f.result() for f in pending]
         for lg, bx in outs:     # allocated on a side stream, used by the caller
             lg.record_stream(cur)
             bx.record_stream(cur)
@@ -431,6 +435,9 @@ class InferenceEngine(object):
             # the one host read, for all frames together (waits for them)
             host = torch.stack([f.counts.tensor for f in outs]).tolist()
             outs = [f.result(h) for f, h in zip(outs, host)]
+            for lg, bx in outs:
+                lg.record_stream(cur)
+                bx.record_stream(cur)
         return outs
 
     def run_frame(self, xyz, intensity, timed=False):

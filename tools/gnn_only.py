@@ -26,9 +26,9 @@ def main():
         eng.run_frame(x, f)
         pool.append((f, eng.last_graph))
     torch.cuda.synchronize()
-    streams = concurrent_streams(3)
+    streams = concurrent_streams(5)
     n = 64
-    for ns in (1, 2):
+    for ns in (1, 2, 3, 4):
         for rep in range(2):
             cur = torch.cuda.current_stream()
             for s in streams:
