@@ -15,7 +15,7 @@ import torch
 
 from . import graph_gen, models
 
-__all__ = ["InferenceEngine", "DeferredFrame", "shard_frames",
+__all__ = ["InferenceEngine", "DeferredFrame", "CapturedFrame", "shard_frames",
            "concurrent_streams"]
 
 _CONCURRENT = {}
@@ -121,6 +121,41 @@ class DeferredFrame(object):
             eng.frame_shapes.append((k,) + tuple(edges))
             self._out = (self.logits[:k], self.boxes[:k])
         return self._out
+
+
+class CapturedFrame(object):
+    """One frame -- graph build and message passing, ~110 launches through the
+    C ABI -- captured into ONE hipGraph (InferenceEngine.capture_frame).  That
+    is possible because the capacity form leaves every data-dependent size (K,
+    E0, E1) on the device: the launch sequence depends only on the number of
+    points N, the capacities and the size hints, so the same graph serves every
+    cloud of N points (a frame that overflows a capacity is detected as usual
+    and rebuilt eagerly).  `replay(xyz, intensity)` copies the cloud into the
+    graph's input buffers, launches the graph and returns a DeferredFrame."""
+
+    def __init__(self, engine, graph, stream, xyz, intensity, frame):
+        self.engine, self.graph, self.stream = engine, graph, stream
+        self.xyz, self.intensity, self.frame = xyz, intensity, frame
+
+    def replay(self, xyz, intensity):
+        if tuple(xyz.shape) != tuple(self.xyz.shape) or \
+                tuple(intensity.shape) != tuple(self.intensity.shape):
+            raise ValueError(
+                "captured for clouds of %d points, got %d: the point count "
+                "shapes the kd-tree launches, capture one graph per count"
+                % (self.xyz.shape[0], xyz.shape[0]))
+        cur = torch.cuda.current_stream()
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            self.xyz.copy_(xyz, non_blocking=True)
+            self.intensity.copy_(intensity, non_blocking=True)
+            self.graph.replay()
+        cur.wait_stream(self.stream)
+        f = self.frame
+        out = DeferredFrame(self.engine, xyz, intensity, f.logits, f.boxes,
+                            graph_gen.FrameCounts(f.counts.tensor,
+                                                  f.counts.edge_caps))
+        return out
 
 
 class InferenceEngine(object):
@@ -260,6 +295,32 @@ class InferenceEngine(object):
             if s is not sg and all(s is not c for c in compute):
                 out.append(s)
         return out
+
+    def capture_frame(self, xyz, intensity):
+        """Capture run_frame_deferred for clouds shaped like `xyz` /
+        `intensity` into a hipGraph (see CapturedFrame).  The outputs of a
+        replay live in the graph's own buffers: take `.result()` (or copy)
+        before the next replay.  Size hints and capacities are those of the
+        engine at capture time."""
+        if self._hints is None:
+            self.run_frame(xyz, intensity)
+            self.frame_shapes.pop()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            # every lazily built thing (weight images, LDS attributes, CU
+            # counts, counters) must exist before the capture starts
+            for _ in range(2):
+                self.run_frame_deferred(xyz, intensity).result()
+                self.frame_shapes.pop()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        xs, fs = xyz.clone(), intensity.clone()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            frame = self.run_frame_deferred(xs, fs)
+        torch.cuda.synchronize()
+        return CapturedFrame(self, graph, side, xs, fs, frame)
 
     def run_frames_on_streams(self, frames, n_streams=3):
         """Steady-state loop in capacity form: frame i -- graph build AND

@@ -235,6 +235,35 @@ def test_frames_on_streams_equal_sequential(dev):
         assert eng.deferred_overflows == 0
 
 
+def test_captured_frame_replays_bit_identically(dev):
+    """A whole frame in ONE hipGraph (engine.capture_frame): replays give the
+    eager results bit for bit, for the captured cloud and for other clouds of
+    the same point count (K and the edge counts differ: they live on the
+    device); another point count is refused."""
+    import torch
+    from pointgnn_amd.engine import InferenceEngine
+    cfg = configs.car_auto_config(3)
+    params = weights.init_params(cfg, seed=5, bias_scale=0.05)
+    eng = InferenceEngine(cfg, params, device=dev)
+    clouds = []
+    for s in (0, 1, 2):
+        xyz, inten = synthetic_cloud(seed=s, preset="car")
+        clouds.append((T(xyz, dev), T(inten, dev)))
+    eager = [eng.run_frame(x, f) for x, f in clouds]
+    shapes = list(eng.frame_shapes)
+    assert len({sh[0] for sh in shapes}) > 1       # different K per cloud
+    cap = eng.capture_frame(*clouds[0])
+    for rep in range(2):
+        for (x, f), (lg, bx), sh in zip(clouds, eager, shapes):
+            out = cap.replay(x, f)
+            lg2, bx2 = out.result()
+            assert eng.frame_shapes[-1] == sh
+            assert torch.equal(lg, lg2) and torch.equal(bx, bx2)
+    small = synthetic_cloud(seed=0, preset="small")
+    with pytest.raises(ValueError):
+        cap.replay(T(small[0], dev), T(small[1], dev))
+
+
 def test_deferred_reports_kd_status(dev):
     """The kd-tree replica's tie-order status travels with the counts: a
     cloud outside what the replica reproduces raises when the frame's result
