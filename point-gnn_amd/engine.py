@@ -3,7 +3,13 @@ between "fetch input" and "decode box" (run.py:219-263), device-resident.
 
     engine = InferenceEngine(config, params)
     logits, boxes = engine.run_frame(xyz_cuda, intensity_cuda)
+    outs = engine.run_frames_on_streams(frames, 3)   # steady state: whole
+                                                     # frames on three streams
 
+`run_frame` sizes its arrays on the host (two reads per frame in the graph
+builder).  `run_frame_deferred`, `run_frames_on_streams` and `capture_frame`
+use the capacity form (graph_gen `deferred_counts`): K and the edge counts
+stay on the device and are read once, with the frame's results.
 Phase names follow run.py's `time_dict` keys ("gen graph", "gnn inference").
 `shard_frames` is the multi-GPU decomposition: frames are independent units,
 rank r takes frames r, r+W, ... -- inference needs no collective

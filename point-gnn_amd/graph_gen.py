@@ -16,6 +16,11 @@ grouped by ascending centre -- the reference emits the same grouping
 (graph_gen.py:215-219) with an unspecified order inside a centre.  Keypoint
 order is ascending voxel-hash bucket (the reference's is open3d's hash-map
 order / dict order: only the *set* is defined).
+
+Device tensors are sized on the host by default (two reads per frame: K, then
+the edge totals).  `gen_multi_level_local_graph_v3(..., deferred_counts=hints)`
+is the capacity form: no read at all, capacity-sized outputs tagged with their
+device-side counts (CountHints, FrameCounts, _lib.DeviceCount).
 """
 import ctypes
 
