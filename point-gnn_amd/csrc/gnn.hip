@@ -1196,9 +1196,10 @@ int pooling_fwd_impl(const float *point_features, int32_t n_feat,
   PGNN_REQUIRE(p.chain.l[0].kq == 1, PGNN_E_UNSUPPORTED,
                "pooling: first layer k_in must be <= 16");
   const int out_cols = 16 * p.chain.l[n_layers - 1].nt;
-  PGNN_REQUIRE(out && ld_out >= out_cols, PGNN_E_INVALID,
+  PGNN_REQUIRE(ld_out >= out_cols, PGNN_E_INVALID,
                "pooling: ld_out < padded output width");
-  if (num_keypoints == 0) return 0;
+  if (num_keypoints == 0) return 0;  // (an empty output has no buffer)
+  PGNN_REQUIRE(out != nullptr, PGNN_E_INVALID, "pooling: null output");
   rc = fill_lowest_rows(out, ld_out, num_keypoints, dk, stream);
   if (rc) return rc;
   if (n_edges == 0) return 0;
@@ -1254,9 +1255,10 @@ int edge_fwd_impl(const float *P, const float *Q, int64_t ld_pq, int32_t width,
   PGNN_REQUIRE(ld_pq == 16 * p.chain.l[0].kq, PGNN_E_INVALID,
                "edge_mlp: ld_pq must equal the padded width 16*ceil(width/16)");
   const int out_cols = 16 * p.chain.l[n_layers - 1].nt;
-  PGNN_REQUIRE(out && ld_out >= out_cols, PGNN_E_INVALID,
+  PGNN_REQUIRE(ld_out >= out_cols, PGNN_E_INVALID,
                "edge_mlp: ld_out < padded output width");
   if (num_vertices == 0) return 0;
+  PGNN_REQUIRE(out != nullptr, PGNN_E_INVALID, "edge_mlp: null output");
   if (!(edges_sorted & 2)) {  // bit 1: caller already filled `out` with lowest()
     rc = fill_lowest_rows(out, ld_out, num_vertices, dk, stream);
     if (rc) return rc;

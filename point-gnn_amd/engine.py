@@ -207,7 +207,9 @@ class InferenceEngine(object):
         """run_frame without a host wait: graph build and model are enqueued
         back to back, sizes stay on the device.  Returns a DeferredFrame; its
         .result() gives (logits, box_encodings)."""
-        if self._hints is None:
+        if self._hints is None or int(xyz.shape[0]) == 0:
+            # no size hints yet, or an empty cloud (host-known: nothing to
+            # defer, and empty tensors have no device pointers to hand over)
             out = self.run_frame(xyz, intensity)
             f = DeferredFrame(self, xyz, intensity, None, None, None)
             f._out = out

@@ -235,6 +235,34 @@ def test_frames_on_streams_equal_sequential(dev):
         assert eng.deferred_overflows == 0
 
 
+@pytest.mark.parametrize("n_points", [0, 1, 2, 37])
+def test_deferred_frame_on_degenerate_clouds(dev, n_points):
+    """Empty, single-point and tiny clouds through the capacity form: the same
+    (possibly empty) outputs as the host-sized frame, no overflow, no
+    out-of-range access (capacities a few rows above the need)."""
+    import torch
+    from pointgnn_amd import graph_gen as G
+    from pointgnn_amd.engine import InferenceEngine
+    cfg = configs.car_auto_config(1)
+    params = weights.init_params(cfg, seed=3, bias_scale=0.05)
+    eng = InferenceEngine(cfg, params, device=dev)
+    rng = np.random.default_rng(n_points)
+    xyz = (rng.random((n_points, 3)) * [3.0, 1.0, 3.0]).astype(np.float32)
+    inten = rng.random((n_points, 1)).astype(np.float32)
+    x, f = T(xyz, dev), T(inten, dev)
+    lg, bx = eng.run_frame(x, f)
+    shape = eng.frame_shapes[-1]
+    eng._hints = G.CountHints(shape[0], shape[1:],
+                              [shape[1] + 8, shape[2] + 8])
+    d = eng.run_frame_deferred(x, f)
+    assert (d.counts is None) == (n_points == 0)   # an empty cloud is host-known
+    lg2, bx2 = d.result()
+    torch.cuda.synchronize()
+    assert eng.deferred_overflows == 0 and eng.frame_shapes[-1] == shape
+    assert lg2.shape == lg.shape and bx2.shape == bx.shape
+    assert torch.equal(lg, lg2) and torch.equal(bx, bx2)
+
+
 def test_captured_frame_replays_bit_identically(dev):
     """A whole frame in ONE hipGraph (engine.capture_frame): replays give the
     eager results bit for bit, for the captured cloud and for other clouds of
