@@ -104,32 +104,30 @@ class MultiLayerFastLocalGraphModelV2(object):
         keep = getattr(self, 'keep_features', False)
         self.feature_list = []
         with gnn.parameters(self._store):
-            tfeatures = t_initial_vertex_features
-            for idx in range(len(self._layer_configs) - 1):
-                layer_config = self._layer_configs[idx]
-                graph_level = layer_config['graph_level']
-                with gnn.variable_scope(layer_config['scope']):
-                    flgn = self._default_layers_type[layer_config['type']]
-                    tfeatures = flgn.apply_regular(
-                        tfeatures,
-                        t_vertex_coord_list[graph_level],
-                        t_keypoint_indices_list[graph_level],
-                        t_edges_list[graph_level],
-                        **layer_config['kwargs'])
+            feats = t_initial_vertex_features
+            *body, head = self._layer_configs
+            for cfg in body:
+                level = cfg['graph_level']
+                op = self._default_layers_type[cfg['type']]
+                with gnn.variable_scope(cfg['scope']):
+                    feats = op.apply_regular(
+                        feats, t_vertex_coord_list[level],
+                        t_keypoint_indices_list[level], t_edges_list[level],
+                        **cfg['kwargs'])
                 if keep:
-                    self.feature_list.append(tfeatures)
-            predictor_config = self._layer_configs[-1]
-            assert (predictor_config['type'] == 'classaware_predictor' or
-                    predictor_config['type'] == 'classaware_predictor_128' or
-                    predictor_config['type'] ==
-                    'classaware_separated_predictor')
-            predictor = self._default_layers_type[predictor_config['type']]
-            with gnn.variable_scope(predictor_config['scope']):
-                logits, box_encodings = predictor.apply_regular(
-                    tfeatures, num_classes=self.num_classes,
-                    box_encoding_len=self.box_encoding_len,
-                    **predictor_config['kwargs'])
-        self.last_features = tfeatures
+                    self.feature_list.append(feats)
+            if head['type'] not in ('classaware_predictor',
+                                    'classaware_predictor_128',
+                                    'classaware_separated_predictor'):
+                raise AssertionError("last layer must be a predictor, got %r"
+                                     % (head['type'],))
+            with gnn.variable_scope(head['scope']):
+                logits, box_encodings = \
+                    self._default_layers_type[head['type']].apply_regular(
+                        feats, num_classes=self.num_classes,
+                        box_encoding_len=self.box_encoding_len,
+                        **head['kwargs'])
+        self.last_features = feats
         if was_np:
             return logits.cpu().numpy(), box_encodings.cpu().numpy()
         return logits, box_encodings
