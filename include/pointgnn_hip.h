@@ -562,6 +562,30 @@ int pgnn_weight_grad_f32(const float *X, int64_t ld_x, int32_t k_in,
                          int64_t n_rows, float *dW, float *db,
                          int32_t accumulate, void *workspace,
                          size_t workspace_bytes, void *stream);
+/* The same for MANY small layers in one launch pair (train.py:264-297 asks
+ * tf.gradients for every variable at once; here the K-row layers of a step --
+ * ~25 GEMMs of [k_in x K] x [K x n_out], K ~ 2 000 vertices -- would each be a
+ * latency-bound launch plus a reduce: 0.7 ms of a 4.7 ms step).  jobs: a HOST
+ * array; 1 <= n_out <= 320 per job; dW is [k_in, n_out] contiguous; the
+ * outputs of different jobs must not overlap (they are written by one launch).  Fixed
+ * slice partition and reduction order: deterministic, not bit-equal to
+ * pgnn_weight_grad_f32 (other slice boundaries).                           */
+typedef struct pgnn_wgrad_job {
+  const float *X;   /* [n_rows, ld_x] layer input                           */
+  int64_t ld_x;
+  const float *dZ;  /* [n_rows, ld_dz] gradient w.r.t. the pre-activation    */
+  int64_t ld_dz;
+  int64_t n_rows;
+  float *dW;        /* [k_in, n_out]                                         */
+  float *db;        /* [n_out] or NULL                                       */
+  int32_t k_in, n_out;
+  int32_t accumulate, reserved;
+} pgnn_wgrad_job;
+size_t pgnn_weight_grad_many_workspace_bytes(const pgnn_wgrad_job *jobs_host,
+                                             int32_t n_jobs);
+int pgnn_weight_grad_many_f32(const pgnn_wgrad_job *jobs_host, int32_t n_jobs,
+                              void *workspace, size_t workspace_bytes,
+                              void *stream);
 /* models.py:212-255 (cls 'softmax', loc 'huber_loss', delta 1):
  * sums4 (device, 4 doubles) = {sum_v CE_v, sum_v mean_7 huber_v*valid_v,
  * n_vertices, sum valid}; dlogits [n, nc] / dpred_box [n, nc, box_len]

@@ -33,6 +33,13 @@ class DynCount(ctypes.Structure):
     _fields_ = [("dev", c_vp), ("hint", c_i64)]
 
 
+class WgradJob(ctypes.Structure):
+    """struct pgnn_wgrad_job (pgnn_weight_grad_many_f32)"""
+    _fields_ = [("X", c_vp), ("ld_x", c_i64), ("dZ", c_vp), ("ld_dz", c_i64),
+                ("n_rows", c_i64), ("dW", c_vp), ("db", c_vp), ("k_in", c_i32),
+                ("n_out", c_i32), ("accumulate", c_i32), ("reserved", c_i32)]
+
+
 class PackJob(ctypes.Structure):
     """One record of pgnn_pack_fc_many's job table."""
     _fields_ = [("w", c_vp), ("b", c_vp), ("dst", c_vp), ("k_in", c_i32),
@@ -226,6 +233,11 @@ _SIGNATURES = {
     "pgnn_weight_grad_f32": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32,
                                      c_i64, c_vp, c_vp, c_i32, c_vp, c_sz,
                                      c_vp]),
+    "pgnn_weight_grad_many_workspace_bytes": (c_sz,
+                                              [ctypes.POINTER(WgradJob),
+                                               c_i32]),
+    "pgnn_weight_grad_many_f32": (c_i32, [ctypes.POINTER(WgradJob), c_i32,
+                                          c_vp, c_sz, c_vp]),
     "pgnn_loss_fwd_bwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i32, c_vp, c_vp,
                                   c_i64, c_i32, ctypes.c_float, ctypes.c_float,
                                   c_vp, c_vp, c_vp, c_vp]),

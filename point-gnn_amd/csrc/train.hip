@@ -743,17 +743,17 @@ __global__ void segmax_wgrad_ties_kernel(
 constexpr int kWgRows = 32;  // data rows staged per step
 
 template <int NT>
-__global__ __launch_bounds__(256) void weight_grad_kernel(
+__device__ __forceinline__ void weight_grad_body(
     const float *__restrict__ X, int64_t ldx, int k_in,
     const float *__restrict__ dZ, int64_t ldz, int n_out, int64_t rows,
-    int64_t rows_per_slice, int nt, float *__restrict__ partial) {
+    int64_t rows_per_slice, int nt, float *__restrict__ partial, int ib,
+    int slice, int n_in_blocks) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int ldxs = 68, ldzs = 16 * nt + 4;
   float *Xs = reinterpret_cast<float *>(smem);
   float *Zs = Xs + kWgRows * ldxs;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int ib = blockIdx.x, slice = blockIdx.y;
   const int in0 = 64 * ib;
   const int64_t r_begin = (int64_t)slice * rows_per_slice;
   int64_t r_end = r_begin + rows_per_slice;
@@ -812,7 +812,7 @@ __global__ __launch_bounds__(256) void weight_grad_kernel(
     }
   }
   // partial[slice][in][out], in padded to 64*gridDim.x, out padded to 16*nt
-  const int64_t kin_p = 64 * (int64_t)gridDim.x, nout_p = 16 * nt;
+  const int64_t kin_p = 64 * (int64_t)n_in_blocks, nout_p = 16 * nt;
   float *po = partial + (int64_t)slice * kin_p * nout_p;
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
@@ -826,6 +826,87 @@ __global__ __launch_bounds__(256) void weight_grad_kernel(
           po[(int64_t)i * nout_p + 16 * t + (lane & 15)] = acc[m][j][r];
         }
     }
+  }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void weight_grad_kernel(
+    const float *__restrict__ X, int64_t ldx, int k_in,
+    const float *__restrict__ dZ, int64_t ldz, int n_out, int64_t rows,
+    int64_t rows_per_slice, int nt, float *__restrict__ partial) {
+  weight_grad_body<NT>(X, ldx, k_in, dZ, ldz, n_out, rows, rows_per_slice, nt,
+                       partial, (int)blockIdx.x, (int)blockIdx.y,
+                       (int)gridDim.x);
+}
+
+// ---- many small weight gradients in ONE launch -------------------------------
+// The K-row layers of a training step (update / offset / P layers of every
+// iteration, the pooling output layer, the heads: ~25 GEMMs of
+// [300 x 2000] x [2000 x 300]) each fill the chip for ~25 us plus a ~12 us
+// reduce when launched one by one -- 0.7 ms of a 4.7 ms step in latency-bound
+// launches.  None of them is on the backward's critical path (only dX is), so
+// the trainer records them and runs them together at the end: one launch whose
+// workgroups are (job, input block, row slice) triples, one reduce launch.
+constexpr int kWgManyJobs = 24;  // jobs per launch (kernel-argument size)
+struct WgJobDev {
+  const float *X, *dZ;
+  float *dW, *db;
+  int64_t ldx, ldz, rows, rps, part_off /* floats */, out0 /* first output */;
+  int k_in, n_out, nt, in_blocks, slices, wg0, accumulate, pad;
+};
+struct WgJobsDev {
+  int n, total_wgs;
+  int64_t total_out;
+  WgJobDev j[kWgManyJobs];
+};
+
+__global__ __launch_bounds__(256) void weight_grad_many_kernel(
+    WgJobsDev js, float *__restrict__ partial) {
+  int ji = 0;
+  while (ji + 1 < js.n && (int)blockIdx.x >= js.j[ji + 1].wg0) ++ji;
+  const WgJobDev &J = js.j[ji];
+  const int local = (int)blockIdx.x - J.wg0;
+  const int ib = local % J.in_blocks, slice = local / J.in_blocks;
+  weight_grad_body<5>(J.X, J.ldx, J.k_in, J.dZ, J.ldz, J.n_out, J.rows, J.rps,
+                      J.nt, partial + J.part_off, ib, slice, J.in_blocks);
+}
+
+// the reduce of weight_grad_reduce_kernel over the outputs of all jobs
+__global__ __launch_bounds__(256) void weight_grad_reduce_many_kernel(
+    WgJobsDev js, const float *__restrict__ partial) {
+  __shared__ float part[4][64];
+  const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+  for (int64_t base = (int64_t)blockIdx.x * 64; base < js.total_out;
+       base += (int64_t)gridDim.x * 64) {
+    const int64_t gidx = base + o;
+    int ji = 0;
+    while (ji + 1 < js.n && gidx >= js.j[ji + 1].out0) ++ji;
+    const WgJobDev &J = js.j[ji];
+    const int64_t idx = gidx - J.out0;
+    const int64_t total = (int64_t)(J.k_in + 1) * J.n_out;
+    const bool ok = gidx < js.total_out && idx < total;
+    const int64_t i = ok ? idx / J.n_out : 0;
+    const int j = ok ? (int)(idx - i * J.n_out) : 0;
+    float s = 0.0f;
+    if (ok) {
+      const int64_t kin_p = 64 * (int64_t)J.in_blocks;
+      const int nout_p = 16 * J.nt;
+      const float *pj = partial + J.part_off;
+      for (int sl = g; sl < J.slices; sl += 4)
+        s += pj[((int64_t)sl * kin_p + i) * nout_p + j];
+    }
+    part[g][o] = s;
+    __syncthreads();
+    if (g == 0 && ok) {
+      s = ((part[0][o] + part[1][o]) + part[2][o]) + part[3][o];
+      if (i < J.k_in) {
+        float *w = J.dW + i * J.n_out + j;
+        *w = J.accumulate ? *w + s : s;
+      } else if (J.db) {
+        J.db[j] = J.accumulate ? J.db[j] + s : s;
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -1389,6 +1470,130 @@ extern "C" int pgnn_weight_grad_f32(const float *X, int64_t ld_x, int32_t k_in,
                        stream, partial, slices, (int64_t)in_blocks * 64,
                        nt * 16, k_in, nc, (int64_t)n_out, dW + c0,
                        db ? db + c0 : nullptr, accumulate);
+  }
+  PGNN_HIP(hipGetLastError());
+  return 0;
+  PGNN_GUARD_END
+}
+
+namespace {
+// rows per slice / slices of one job when `wgs_per_in_block` workgroups are
+// available per input block
+void wg_many_split(int64_t rows, int target_slices, int64_t &rps, int &slices) {
+  int64_t s = target_slices < 1 ? 1 : target_slices;
+  const int64_t max_s = (rows + kWgRows - 1) / kWgRows;
+  if (s > max_s) s = max_s;
+  if (s < 1) s = 1;
+  rps = (rows + s - 1) / s;
+  rps = (rps + kWgRows - 1) / kWgRows * kWgRows;
+  if (rps < kWgRows) rps = kWgRows;
+  slices = (int)((rows + rps - 1) / rps);
+  if (slices < 1) slices = 1;
+}
+int wg_many_target_slices(const pgnn_wgrad_job *jobs, int32_t n_jobs) {
+  int64_t in_blocks = 0;
+  for (int i = 0; i < n_jobs; ++i)
+    in_blocks += ((int64_t)jobs[i].k_in + 1 + 63) / 64;
+  if (in_blocks < 1) in_blocks = 1;
+  // ~4 workgroups per CU over the whole batch of jobs
+  int t = (int)((int64_t)4 * device_cu_count() / in_blocks);
+  return t < 1 ? 1 : t;
+}
+}  // namespace
+
+extern "C" size_t pgnn_weight_grad_many_workspace_bytes(
+    const pgnn_wgrad_job *jobs, int32_t n_jobs) {
+  if (!jobs || n_jobs <= 0) return 0;
+  const int target = wg_many_target_slices(jobs, n_jobs);
+  size_t floats = 0;
+  for (int i = 0; i < n_jobs; ++i) {
+    const pgnn_wgrad_job &j = jobs[i];
+    if (j.k_in <= 0 || j.n_out <= 0 || j.n_rows <= 0) continue;
+    int64_t rps;
+    int slices;
+    wg_many_split(j.n_rows, target, rps, slices);
+    const size_t in_blocks = ((size_t)j.k_in + 1 + 63) / 64;
+    const size_t nt = ((size_t)j.n_out + 15) / 16;
+    floats += (size_t)slices * in_blocks * 64 * nt * 16;
+  }
+  return floats * 4 + 256;
+}
+
+extern "C" int pgnn_weight_grad_many_f32(const pgnn_wgrad_job *jobs,
+                                         int32_t n_jobs, void *workspace,
+                                         size_t workspace_bytes,
+                                         void *stream_) {
+  PGNN_GUARD_BEGIN
+  hipStream_t stream = (hipStream_t)stream_;
+  PGNN_REQUIRE(n_jobs >= 0 && (n_jobs == 0 || jobs), PGNN_E_INVALID,
+               "weight_grad_many: bad argument");
+  if (n_jobs == 0) return 0;
+  PGNN_REQUIRE(workspace && workspace_bytes >=
+                                pgnn_weight_grad_many_workspace_bytes(jobs, n_jobs),
+               PGNN_E_WORKSPACE, "weight_grad_many: workspace too small");
+  for (int i = 0; i < n_jobs; ++i) {
+    const pgnn_wgrad_job &j = jobs[i];
+    PGNN_REQUIRE(j.k_in > 0 && j.n_out > 0 && j.n_out <= 320 && j.n_rows >= 0 &&
+                     j.dW,
+                 PGNN_E_INVALID,
+                 "weight_grad_many: bad job (1 <= n_out <= 320, dW required)");
+    PGNN_REQUIRE(j.n_rows == 0 ||
+                     (j.X && j.dZ && j.ld_x >= j.k_in && j.ld_dz >= j.n_out),
+                 PGNN_E_INVALID, "weight_grad_many: bad job input");
+  }
+  const int target = wg_many_target_slices(jobs, n_jobs);
+  float *partial = (float *)workspace;
+  int64_t part_off = 0;
+  const size_t lds = (size_t)kWgRows * (68 + 16 * 20 + 4) * 4;
+  {
+    const int lrc = ensure_dynamic_lds(
+        reinterpret_cast<const void *>(weight_grad_many_kernel), lds);
+    if (lrc) return lrc;
+  }
+  for (int first = 0; first < n_jobs; first += kWgManyJobs) {
+    WgJobsDev js = {};
+    int wg = 0;
+    int64_t out0 = 0;
+    for (int i = first; i < n_jobs && js.n < kWgManyJobs; ++i) {
+      const pgnn_wgrad_job &j = jobs[i];
+      WgJobDev &d = js.j[js.n];
+      if (j.n_rows <= 0) {
+        // no rows: dW / db stay (accumulate) or become zero
+        if (!j.accumulate) {
+          PGNN_HIP(hipMemsetAsync(j.dW, 0, (size_t)j.k_in * j.n_out * 4, stream));
+          if (j.db) PGNN_HIP(hipMemsetAsync(j.db, 0, (size_t)j.n_out * 4, stream));
+        }
+        continue;
+      }
+      d.X = j.X;
+      d.dZ = j.dZ;
+      d.dW = j.dW;
+      d.db = j.db;
+      d.ldx = j.ld_x;
+      d.ldz = j.ld_dz;
+      d.rows = j.n_rows;
+      d.k_in = j.k_in;
+      d.n_out = j.n_out;
+      d.nt = (j.n_out + 15) / 16;
+      d.in_blocks = (j.k_in + 1 + 63) / 64;
+      wg_many_split(j.n_rows, target, d.rps, d.slices);
+      d.wg0 = wg;
+      d.accumulate = j.accumulate ? 1 : 0;
+      d.part_off = part_off;
+      d.out0 = out0;
+      wg += d.in_blocks * d.slices;
+      out0 += (int64_t)(j.k_in + 1) * j.n_out;
+      part_off += (int64_t)d.slices * d.in_blocks * 64 * d.nt * 16;
+      ++js.n;
+    }
+    if (js.n == 0) continue;
+    js.total_wgs = wg;
+    js.total_out = out0;
+    hipLaunchKernelGGL(weight_grad_many_kernel, dim3((unsigned)wg), dim3(256),
+                       lds, stream, js, partial);
+    hipLaunchKernelGGL(weight_grad_reduce_many_kernel,
+                       dim3(grid_for(out0 * 4)), dim3(256), 0, stream, js,
+                       (const float *)partial);
   }
   PGNN_HIP(hipGetLastError());
   return 0;

@@ -319,6 +319,11 @@ struct Ctx {
   Bump &ws;
   hipStream_t stream;
   bool dry;  // sizing run: allocate only
+  // weight gradients of the K-row layers, recorded by the backward and run in
+  // ONE launch pair at its end (pgnn_weight_grad_many_f32): only dX is on the
+  // backward's critical path.  Recorded in the sizing run too (the partial
+  // buffer comes out of the same workspace).
+  std::vector<pgnn_wgrad_job> wjobs;
 };
 
 int check_batch(const Trainer &t, const pgnn_train_batch *b) {
@@ -368,28 +373,89 @@ int fc_dx(Ctx &c, const FcDev &f, const float *dy, int64_t lddy, int64_t rows,
                       0, dx, pad16(f.ref.k_in), c.stream);
 }
 
+// record dW/db = (x^T dy, column sums) for the end of the backward; x and dy
+// must stay untouched until then
+void defer_wgrad(Ctx &c, const float *x, int64_t ldx, int k_in, const float *dy,
+                 int64_t lddy, int n_out, int64_t rows, float *gw, float *gb,
+                 bool accumulate) {
+  pgnn_wgrad_job j = {};
+  j.X = x;
+  j.ld_x = ldx;
+  j.dZ = dy;
+  j.ld_dz = lddy;
+  j.n_rows = rows;
+  j.dW = gw;
+  j.db = gb;
+  j.k_in = k_in;
+  j.n_out = n_out;
+  j.accumulate = accumulate ? 1 : 0;
+  c.wjobs.push_back(j);
+}
+
 int fc_wgrad(Ctx &c, Saved &sv, const FcDev &f, const float *x, int64_t ldx,
-             const float *dy, int64_t lddy, int64_t rows, bool accumulate = true) {
-  if (c.dry || rows == 0) return 0;
+             const float *dy, int64_t lddy, int64_t rows, bool accumulate = true,
+             bool defer = false) {
+  if (rows == 0) return 0;
+  if (defer && f.ref.n_out <= 320) {
+    defer_wgrad(c, x, ldx, f.ref.k_in, dy, lddy, f.ref.n_out, rows, f.gw, f.gb,
+                accumulate);
+    return 0;
+  }
+  if (c.dry) return 0;
   return pgnn_weight_grad_f32(x, ldx, f.ref.k_in, dy, lddy, f.ref.n_out, rows,
                               f.gw, f.gb, accumulate ? 1 : 0, sv.scratch,
                               sv.scratch_bytes, c.stream);
 }
 
-// fc_bwd of the Python mirror: optional ReluGrad (in place on dy), dW/db, dX
+// fc_bwd of the Python mirror: optional ReluGrad (in place on dy), dW/db, dX.
+// defer: the weight gradient is recorded for the end of the backward -- the
+// caller guarantees that x and dy are not written again before that.
 int fc_bwd(Ctx &c, Saved &sv, const FcDev &f, const float *x, int64_t ldx,
            const float *y, float *dy, int64_t rows, bool relu, float *dx,
-           bool accumulate = true) {
-  if (c.dry || rows == 0) return 0;
+           bool accumulate = true, bool defer = false) {
+  if (rows == 0) return 0;
   const int ldy = pad16(f.ref.n_out);
   int rc = 0;
-  if (relu) {
+  if (relu && !c.dry) {
     rc = pgnn_relu_mask_mul(dy, y, rows * ldy, c.stream);
     if (rc) return rc;
   }
-  rc = fc_wgrad(c, sv, f, x, ldx, dy, ldy, rows, accumulate);
+  rc = fc_wgrad(c, sv, f, x, ldx, dy, ldy, rows, accumulate, defer);
   if (rc) return rc;
-  if (dx) rc = fc_dx(c, f, dy, ldy, rows, dx);
+  if (dx && !c.dry) rc = fc_dx(c, f, dy, ldy, rows, dx);
+  return rc;
+}
+
+// run the recorded weight gradients (one launch pair).  Their partial sums
+// take a fixed slice of the workspace (the sizing run records no jobs: it
+// does not walk the launch code): pgnn_weight_grad_many_f32 aims for 4
+// workgroups per CU over all jobs, each writing a [64 x <= 320] block.
+size_t wgrad_many_bound() {
+  return ((size_t)4 * device_cu_count() + 8 * 64) * 64 * 320 * 4 + 256;
+}
+int flush_wgrads(Ctx &c, Saved &sv) {
+  const size_t bound = wgrad_many_bound();
+  void *part = c.ws.raw(bound);
+  if (c.dry || c.wjobs.empty()) {
+    c.wjobs.clear();
+    return 0;
+  }
+  PGNN_REQUIRE(part != nullptr, PGNN_E_WORKSPACE, "trainer: workspace too small");
+  int rc = 0;
+  const size_t bytes = pgnn_weight_grad_many_workspace_bytes(
+      c.wjobs.data(), (int32_t)c.wjobs.size());
+  if (bytes <= bound) {
+    rc = pgnn_weight_grad_many_f32(c.wjobs.data(), (int32_t)c.wjobs.size(), part,
+                                   bound, c.stream);
+  } else {  // (more jobs than the bound foresees: one by one)
+    for (const pgnn_wgrad_job &j : c.wjobs) {
+      rc = pgnn_weight_grad_f32(j.X, j.ld_x, j.k_in, j.dZ, j.ld_dz, j.n_out,
+                                j.n_rows, j.dW, j.db, j.accumulate, sv.scratch,
+                                sv.scratch_bytes, c.stream);
+      if (rc) break;
+    }
+  }
+  c.wjobs.clear();
   return rc;
 }
 
@@ -732,8 +798,13 @@ int backward_impl(Ctx &c, Saved &sv, const float *dlogits, const float *dpred) {
   const int hw = sv.ld_h_final;
   const HeadsSaved &hs = sv.heads;
   int rc = 0;
-  // gradient w.r.t. the current stage output; two buffers alternate
-  float *dh = c.ws.f(K, hw), *dh2 = c.ws.f(K, hw);
+  // gradient w.r.t. the output of stage i: dhs[i + 1] (dhs[n] = w.r.t. the
+  // input of the heads).  One buffer per boundary: each is also the dY of a
+  // deferred weight gradient and must survive until the end of the backward.
+  const int n_stages = (int)t.stages.size();
+  std::vector<float *> dhs((size_t)n_stages + 1);
+  for (int i = 0; i <= n_stages; ++i) dhs[(size_t)i] = c.ws.f(K, hw);
+  float *dh = dhs[(size_t)n_stages];
   float *dxh = c.ws.f(K, hw);
   const int cw = t.cls[0].ref.k_in;
   if (!t.groups.empty()) {
@@ -744,10 +815,17 @@ int backward_impl(Ctx &c, Saved &sv, const float *dlogits, const float *dpred) {
       w2 = pad16(g.f[1].ref.n_out) > w2 ? pad16(g.f[1].ref.n_out) : w2;
       w3 = pad16(g.f[2].ref.n_out) > w3 ? pad16(g.f[2].ref.n_out) : w3;
     }
-    float *dy3 = c.ws.f(K, w3), *dy2 = c.ws.f(K, w2), *dy1 = c.ws.f(K, w1);
+    // (one set per group: the buffers are the dY of deferred weight gradients)
+    std::vector<float *> dy3s, dy2s, dy1s;
+    for (size_t gi = 0; gi < t.groups.size(); ++gi) {
+      dy3s.push_back(c.ws.f(K, w3));
+      dy2s.push_back(c.ws.f(K, w2));
+      dy1s.push_back(c.ws.f(K, w1));
+    }
     if (!c.dry && K > 0) {
       for (size_t gi = 0; gi < t.groups.size(); ++gi) {
         HeadGroup &g = t.groups[gi];
+        float *dy3 = dy3s[gi], *dy2 = dy2s[gi], *dy1 = dy1s[gi];
         const int ld1 = pad16(g.f[0].ref.n_out), ld2 = pad16(g.f[1].ref.n_out),
                   ld3 = pad16(g.f[2].ref.n_out);
         hipLaunchKernelGGL(fused_dy3_kernel, dim3(blocks_for(K * ld3)), dim3(256),
@@ -757,7 +835,7 @@ int backward_impl(Ctx &c, Saved &sv, const float *dlogits, const float *dpred) {
         // the fused gradients are overwritten (accumulate = false) and handed
         // to the flat buffer by the unpack jobs at the end
         rc = fc_bwd(c, sv, g.f[2], sv.heads.y2[gi], ld2, nullptr, dy3, K, false,
-                    dy2, false);
+                    dy2, false, true);
         if (rc) return rc;
         // second layer: ReLU on the box-head columns only (logits are linear)
         if (g.f[1].ref.n_out > g.base)
@@ -766,19 +844,18 @@ int backward_impl(Ctx &c, Saved &sv, const float *dlogits, const float *dpred) {
                              dim3(256), 0, c.stream, dy2, sv.heads.y2[gi], K, ld2,
                              g.base, g.f[1].ref.n_out);
         rc = fc_bwd(c, sv, g.f[1], sv.heads.y1[gi], ld1, nullptr, dy2, K, false,
-                    dy1, false);
+                    dy1, false, true);
         if (rc) return rc;
         rc = fc_bwd(c, sv, g.f[0], sv.h_final, hw, sv.heads.y1[gi], dy1, K, true,
-                    gi == 0 ? dh : dxh, false);
+                    gi == 0 ? dh : dxh, false, true);
         if (rc) return rc;
         if (gi > 0)
           hipLaunchKernelGGL(block_copy_kernel<true>, dim3(blocks_for(K * cw)),
                              dim3(256), 0, c.stream, dh, (int64_t)hw, 0, dxh,
                              (int64_t)pad16(cw), 0, K, cw);
       }
-      rc = pgnn_pack_fc_many(t.images + t.off_jobs_u, t.n_jobs_u, t.total_blocks_u,
-                             c.stream);
-      if (rc) return rc;
+      // (the unpack of the fused gradients follows the deferred weight
+      // gradients at the end of the backward)
     }
   } else {
   const int w64 = pad16(t.cls[0].ref.n_out);
@@ -824,7 +901,8 @@ int backward_impl(Ctx &c, Saved &sv, const float *dlogits, const float *dpred) {
     StageDev &s = t.stages[si];
     const int lvl = s.level;
     const int64_t E = b.n_edges[lvl], Ks = b.n_vertices[lvl + 1];
-    const size_t mark = c.ws.off;  // stage temporaries are released at the end
+    // gradient w.r.t. this stage's output / input
+    float *dh = dhs[(size_t)si + 1], *dh2 = dhs[(size_t)si];
     if (s.kind == 1) {
       GnnSaved &g = sv.gnn[si];
       const FcDev &w1 = s.a[0];
@@ -832,10 +910,19 @@ int backward_impl(Ctx &c, Saved &sv, const float *dlogits, const float *dpred) {
       const int wq = pad16(w1.ref.n_out);
       const int wa = pad16(s.a.back().ref.n_out);
       const int ld_h = hw;
-      // temporaries
+      // K-row buffers first: they are the dY of deferred weight gradients and
+      // stay until the end of the backward; the E-row temporaries behind the
+      // mark are released with the stage
       float *du[PGNN_TRAIN_MAX_FC + 1];
       for (size_t i = 0; i < s.b.size(); ++i)
         du[i] = c.ws.f(Ks, pad16(s.b[i].ref.k_in));
+      float *dp = c.ws.f(Ks, wq), *dq = c.ws.f(Ks, wq);
+      float *dhx = c.ws.f(Ks, pad16(cc + 3));
+      float *dxo = c.ws.f(Ks, 16);
+      float *doff[PGNN_TRAIN_MAX_FC];
+      for (size_t i = 0; i < s.c.size(); ++i)
+        doff[i] = c.ws.f(Ks, pad16(s.c[i].ref.k_in));
+      const size_t mark = c.ws.off;
       float *ge[PGNN_TRAIN_MAX_FC] = {nullptr};
       if (!(s.a.back().want_wt && s.a.size() == 2))
         for (size_t i = 0; i + 1 < s.a.size(); ++i)
@@ -844,12 +931,6 @@ int backward_impl(Ctx &c, Saved &sv, const float *dlogits, const float *dpred) {
       if (!s.a.back().want_wt) gz = c.ws.f(E, wa);
       int32_t *ties = nullptr;
       if (!s.a.back().want_wt) ties = c.ws.i32(Ks * wa > 0 ? Ks * wa : 1);
-      float *dp = c.ws.f(Ks, wq), *dq = c.ws.f(Ks, wq);
-      float *dhx = c.ws.f(Ks, pad16(cc + 3));
-      float *dxo = c.ws.f(Ks, 16);
-      float *doff[PGNN_TRAIN_MAX_FC];
-      for (size_t i = 0; i < s.c.size(); ++i)
-        doff[i] = c.ws.f(Ks, pad16(s.c[i].ref.k_in));
       if (!c.dry && Ks > 0) {
         // residual branch (gnn.py:372): dh_in starts as a copy of dh
         PGNN_HIP(hipMemcpyAsync(dh2, dh, (size_t)Ks * ld_h * 4,
@@ -860,7 +941,8 @@ int backward_impl(Ctx &c, Saved &sv, const float *dlogits, const float *dpred) {
           const bool last = i + 1 == (int)s.b.size();
           const float *xin = i == 0 ? g.agg : g.uact[i - 1];
           const int64_t ldx = i == 0 ? wa : pad16(s.b[i - 1].ref.n_out);
-          rc = fc_bwd(c, sv, s.b[i], xin, ldx, g.uact[i], d, Ks, !last, du[i]);
+          rc = fc_bwd(c, sv, s.b[i], xin, ldx, g.uact[i], d, Ks, !last, du[i],
+                      true, true);
           if (rc) return rc;
           d = du[i];
         }
@@ -914,16 +996,18 @@ int backward_impl(Ctx &c, Saved &sv, const float *dlogits, const float *dpred) {
           if (rc) return rc;
         }
         // P = [h, x] W1 + b1
-        rc = fc_bwd(c, sv, w1, g.hx, pad16(cc + 3), nullptr, dp, Ks, false, dhx);
+        rc = fc_bwd(c, sv, w1, g.hx, pad16(cc + 3), nullptr, dp, Ks, false, dhx,
+                    true, true);
         if (rc) return rc;
         hipLaunchKernelGGL(block_copy_kernel<true>, dim3(blocks_for(Ks * cc)),
                            dim3(256), 0, c.stream, dh2, (int64_t)ld_h, 0, dhx,
                            (int64_t)pad16(cc + 3), 0, Ks, cc);
         // Q = x' Wx, Wx = rows cc..cc+2 of W1 (the minus sign is in dq)
+        // (not deferred: it adds into rows of the same dW as the deferred
+        // job of w1 above, and jobs of one batch must not share outputs)
         rc = pgnn_weight_grad_f32(g.xo, 3, 3, dq, wq, w1.ref.n_out, Ks,
                                   w1.gw + (int64_t)cc * w1.ref.n_out, nullptr, 1,
-                                  sv.scratch, sv.scratch_bytes,
-                                  c.stream);
+                                  sv.scratch, sv.scratch_bytes, c.stream);
         if (rc) return rc;
         if (!s.c.empty()) {
           pgnn_fc_layer Lx;  // dx' = dQ Wx^T
@@ -939,7 +1023,7 @@ int backward_impl(Ctx &c, Saved &sv, const float *dlogits, const float *dpred) {
             const float *xin = i == 0 ? g.h_in : g.off_act[i - 1];
             const int64_t ldx = i == 0 ? ld_h : pad16(s.c[i - 1].ref.n_out);
             rc = fc_bwd(c, sv, s.c[i], xin, ldx, g.off_act[i], d, Ks,
-                        i + 1 < (int)s.c.size(), doff[i]);
+                        i + 1 < (int)s.c.size(), doff[i], true, true);
             if (rc) return rc;
             d = doff[i];
           }
@@ -948,15 +1032,14 @@ int backward_impl(Ctx &c, Saved &sv, const float *dlogits, const float *dpred) {
                              (int64_t)pad16(s.c[0].ref.k_in), 0, Ks, cc);
         }
       }
-      float *tmp = dh;
-      dh = dh2;
-      dh2 = tmp;
+      c.ws.off = mark;
     } else {
       PoolSaved &p = sv.pool[si];
       const int wa = pad16(s.a.back().ref.n_out);
-      float *dob[PGNN_TRAIN_MAX_FC];
+      float *dob[PGNN_TRAIN_MAX_FC];  // K-row: kept (deferred weight gradients)
       for (size_t i = 0; i < s.b.size(); ++i)
         dob[i] = c.ws.f(Ks, pad16(s.b[i].ref.k_in));
+      const size_t mark = c.ws.off;
       float *ga[PGNN_TRAIN_MAX_FC];  // grad w.r.t. act[i] (input of layer i+1)
       for (size_t i = 0; i + 1 < s.a.size(); ++i)
         ga[i] = c.ws.f(E, pad16(s.a[i + 1].ref.k_in));
@@ -971,7 +1054,8 @@ int backward_impl(Ctx &c, Saved &sv, const float *dlogits, const float *dpred) {
         for (int i = (int)s.b.size() - 1; i >= 0; --i) {
           const float *xin = i == 0 ? p.agg : p.oact[i - 1];
           const int64_t ldx = i == 0 ? wa : pad16(s.b[i - 1].ref.n_out);
-          rc = fc_bwd(c, sv, s.b[i], xin, ldx, p.oact[i], d, Ks, true, dob[i]);
+          rc = fc_bwd(c, sv, s.b[i], xin, ldx, p.oact[i], d, Ks, true, dob[i],
+                      true, true);
           if (rc) return rc;
           d = dob[i];
         }
@@ -1011,8 +1095,17 @@ int backward_impl(Ctx &c, Saved &sv, const float *dlogits, const float *dpred) {
           }
         }
       }
+      c.ws.off = mark;
     }
-    c.ws.off = mark;
+  }
+  // every K-row weight gradient of the step, in one launch pair; then the
+  // fused heads' gradients go to the flat buffer
+  rc = flush_wgrads(c, sv);
+  if (rc) return rc;
+  if (!c.dry && K > 0 && !t.groups.empty()) {
+    rc = pgnn_pack_fc_many(t.images + t.off_jobs_u, t.n_jobs_u, t.total_blocks_u,
+                           c.stream);
+    if (rc) return rc;
   }
   if (!c.dry) PGNN_HIP(hipGetLastError());
   return 0;

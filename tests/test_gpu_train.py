@@ -105,6 +105,64 @@ def test_weight_grad_matches_numpy(dev, rows, k_in, n_out):
     assert torch.equal(dw2, dw3)
 
 
+@pytest.mark.parametrize("n_jobs,rows", [(1, 700), (7, 2013), (30, 1500),
+                                         (3, 1), (5, 40000)])
+def test_weight_grad_many_matches_numpy(dev, n_jobs, rows):
+    """pgnn_weight_grad_many_f32: many small layers in one launch pair == X^T dZ
+    and column sums per job (float64 NumPy), accumulate on and off, jobs with
+    no rows, more jobs than fit one launch; deterministic."""
+    import torch
+    from pointgnn_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(n_jobs * 1000 + rows)
+    shapes = [(300, 300), (303, 300), (3, 300), (300, 64), (64, 3), (300, 256),
+              (256, 208), (208, 24), (16, 16), (65, 320)]
+    jobs = (_lib.WgradJob * n_jobs)()
+    keep, refs = [], []
+    for i in range(n_jobs):
+        k_in, n_out = shapes[i % len(shapes)]
+        r = 0 if (n_jobs > 3 and i == 2) else rows
+        x = rng.standard_normal((r, k_in + 4)).astype(np.float32)
+        dz = rng.standard_normal((r, n_out + 2)).astype(np.float32)
+        acc = i % 2
+        dw = torch.full((k_in, n_out), 0.25, dtype=torch.float32, device=dev)
+        db = torch.full((n_out,), -2.0, dtype=torch.float32, device=dev) \
+            if i % 3 else None
+        xd, dzd = T(x, dev), T(dz, dev)
+        keep.append((xd, dzd, dw, db))
+        j = jobs[i]
+        j.X, j.ld_x = xd.data_ptr(), k_in + 4
+        j.dZ, j.ld_dz = dzd.data_ptr(), n_out + 2
+        j.n_rows = r
+        j.dW = dw.data_ptr()
+        j.db = db.data_ptr() if db is not None else None
+        j.k_in, j.n_out, j.accumulate = k_in, n_out, acc
+        rw = x[:, :k_in].astype(np.float64).T @ dz[:, :n_out].astype(np.float64)
+        rb = dz[:, :n_out].astype(np.float64).sum(0)
+        refs.append((rw + 0.25 * acc, rb - 2.0 * acc))
+    ws = torch.empty(lib.pgnn_weight_grad_many_workspace_bytes(jobs, n_jobs),
+                     dtype=torch.uint8, device=dev)
+    _lib.check(lib.pgnn_weight_grad_many_f32(jobs, n_jobs, _lib.ptr(ws),
+                                             ws.numel(), _lib.stream_ptr()))
+    tol = 2e-5 * np.sqrt(max(rows, 1)) + 1e-5
+    first = []
+    for (xd, dzd, dw, db), (rw, rb) in zip(keep, refs):
+        np.testing.assert_allclose(dw.cpu().numpy(), rw, atol=tol, rtol=1e-4)
+        if db is not None:
+            np.testing.assert_allclose(db.cpu().numpy(), rb, atol=tol, rtol=1e-4)
+        first.append(dw.clone())
+    # deterministic: overwrite jobs give the same bits again
+    for i in range(n_jobs):
+        jobs[i].accumulate = 0
+    outs = []
+    for rep in range(2):
+        _lib.check(lib.pgnn_weight_grad_many_f32(jobs, n_jobs, _lib.ptr(ws),
+                                                 ws.numel(), _lib.stream_ptr()))
+        outs.append([k[2].clone() for k in keep])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 def test_scatter_max_bwd_tie_rule(dev):
     import torch
     from pointgnn_amd import _lib, gnn
