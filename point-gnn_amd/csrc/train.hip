@@ -772,24 +772,48 @@ __device__ __forceinline__ void weight_grad_body(
   }
   for (int64_t r0 = r_begin; r0 < r_end; r0 += kWgRows) {
     __syncthreads();
-    for (int idx = threadIdx.x; idx < kWgRows * 64; idx += 256) {
-      const int r = idx >> 6, c = idx & 63;
-      const int64_t row = r0 + r;
-      float v = 0.0f;
-      if (row < r_end) {
-        const int col = in0 + c;
-        if (col < k_in)
-          v = X[row * ldx + col];
-        else if (col == k_in)
-          v = 1.0f;  // bias "input"
+    // Staging.  Every load is UNCONDITIONAL (clamped row / column) and the
+    // validity select happens on the loaded value: a load under an `if` (or a
+    // select the compiler turns into one) is waited for on the spot, and the
+    // tile's 40-odd loads per thread then go out one round trip at a time.
+    {  // X tile: thread -> input column (t & 63), rows (t >> 6) + 4 i
+      const int c = threadIdx.x & 63, col = in0 + c;
+      const int colc = col < k_in ? col : 0;
+      float xv[kWgRows / 4];
+#pragma unroll
+      for (int i = 0; i < kWgRows / 4; ++i) {
+        const int64_t row = r0 + (threadIdx.x >> 6) + 4 * i;
+        xv[i] = X[(row < r_end ? row : r_end - 1) * ldx + colc];
       }
-      Xs[r * ldxs + c] = v;
+#pragma unroll
+      for (int i = 0; i < kWgRows / 4; ++i) {
+        const int r = (threadIdx.x >> 6) + 4 * i;
+        const bool ok = r0 + r < r_end;
+        // column k_in is the bias "input": a constant one
+        Xs[r * ldxs + c] = !ok ? 0.0f : (col < k_in ? xv[i] : (col == k_in ? 1.0f : 0.0f));
+      }
     }
+    // dZ tile: thread (t >> 6, t & 63) takes rows (t >> 6) + 4 i and columns
+    // (t & 63) + 64 j -- 64 consecutive floats of a row per wave, every thread
+    // the same number of independent loads
     const int zc = 16 * nt;
-    for (int idx = threadIdx.x; idx < kWgRows * zc; idx += 256) {
-      const int r = idx / zc, c = idx - r * zc;
-      const int64_t row = r0 + r;
-      Zs[r * ldzs + c] = (row < r_end && c < n_out) ? dZ[row * ldz + c] : 0.0f;
+    {
+      const int cl = threadIdx.x & 63, rs = threadIdx.x >> 6;
+      for (int c = cl; c < zc; c += 64) {
+        const bool in_range = c < n_out;
+        const int cc = in_range ? c : 0;
+        float zv[kWgRows / 4];
+#pragma unroll
+        for (int i = 0; i < kWgRows / 4; ++i) {
+          const int64_t row = r0 + rs + 4 * i;
+          zv[i] = dZ[(row < r_end ? row : r_end - 1) * ldz + cc];
+        }
+#pragma unroll
+        for (int i = 0; i < kWgRows / 4; ++i) {
+          const int r = rs + 4 * i;
+          Zs[r * ldzs + c] = (in_range && r0 + r < r_end) ? zv[i] : 0.0f;
+        }
+      }
     }
     __syncthreads();
 #pragma unroll
@@ -1495,8 +1519,9 @@ int wg_many_target_slices(const pgnn_wgrad_job *jobs, int32_t n_jobs) {
   for (int i = 0; i < n_jobs; ++i)
     in_blocks += ((int64_t)jobs[i].k_in + 1 + 63) / 64;
   if (in_blocks < 1) in_blocks = 1;
-  // ~4 workgroups per CU over the whole batch of jobs
-  int t = (int)((int64_t)4 * device_cu_count() / in_blocks);
+  // one full wave of workgroups over the whole batch of jobs: 3 per CU (48 KB
+  // of LDS each); a fourth per CU would start a second, quarter-filled round
+  int t = (int)((int64_t)3 * device_cu_count() / in_blocks);
   return t < 1 ? 1 : t;
 }
 }  // namespace
