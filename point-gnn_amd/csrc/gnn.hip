@@ -828,6 +828,30 @@ __global__ __launch_bounds__(64 * kRowsWaves) void rows_mlp_kernel(
     const int rows_valid =
         (int)((n_rows - row0 < ROWS) ? (n_rows - row0) : ROWS);
     const int kc = 16 * chain.l[0].kq;
+    if (ra.nx2 == 0) {
+      // 32 threads per row, columns c0, c0 + 32, ...: every load is
+      // UNCONDITIONAL (clamped row / column, select on the value) -- a load
+      // under a predicate is waited for on the spot and the tile's loads
+      // would go out one round trip at a time
+      static_assert(64 * NW == 32 * ROWS, "one 32-thread group per row");
+      const int r = threadIdx.x >> 5, c0 = threadIdx.x & 31;
+      const float *xr =
+          ra.x + (row0 + (r < rows_valid ? r : rows_valid - 1)) * ra.ldx;
+      for (int cb = 0; cb < kc; cb += 32 * 4) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int c = cb + c0 + 32 * j;
+          v[j] = xr[c < ra.nx ? c : ra.nx - 1];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int c = cb + c0 + 32 * j;
+          if (c < kc)
+            tile[r * ld0 + c] = (r < rows_valid && c < ra.nx) ? v[j] : 0.0f;
+        }
+      }
+    } else {
     for (int idx = threadIdx.x; idx < ROWS * kc; idx += 64 * NW) {
       const int r = idx / kc, c = idx - r * kc;
       float v = 0.0f;
@@ -838,6 +862,7 @@ __global__ __launch_bounds__(64 * kRowsWaves) void rows_mlp_kernel(
           v = ra.x2[(row0 + r) * ra.ldx2 + (c - ra.nx)];
       }
       tile[r * ld0 + c] = v;
+    }
     }
     __syncthreads();
     for (int li = 0; li + 1 < chain.n; ++li) {
@@ -1404,16 +1429,33 @@ __global__ __launch_bounds__(64 * kRowsWaves) void vertex_pre_edge_kernel(
   const int rows_valid =
       (int)((n_rows - row0 < ROWS) ? (n_rows - row0) : ROWS);
   const int kc = 16 * pl.kq;
-  for (int idx = threadIdx.x; idx < ROWS * kc; idx += 64 * kRowsWaves) {
-    const int r = idx / kc, c = idx - r * kc;
-    float v = 0.0f;
-    if (r < rows_valid) {
-      if (c < a.c)
-        v = a.h[(row0 + r) * a.ld_h + c];
-      else if (c < a.c + 3)
-        v = a.xyz[(row0 + r) * 3 + (c - a.c)];
+  {
+    // 32 threads per row; unconditional clamped loads, select on the value
+    // (see rows_mlp_kernel)
+    static_assert(64 * kRowsWaves == 32 * ROWS, "one 32-thread group per row");
+    const int r = threadIdx.x >> 5, c0 = threadIdx.x & 31;
+    const int64_t rowc = row0 + (r < rows_valid ? r : rows_valid - 1);
+    const float *hr = a.h + rowc * a.ld_h;
+    const float *xr = a.xyz + rowc * 3;
+    for (int cb = 0; cb < kc; cb += 32 * 4) {
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = cb + c0 + 32 * j;
+        const int d = c - a.c;
+        // the three coordinate columns follow the features
+        const float hv = hr[c < a.c ? c : a.c - 1];
+        const float xv = xr[d < 0 ? 0 : (d > 2 ? 2 : d)];
+        v[j] = c < a.c ? hv : xv;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = cb + c0 + 32 * j;
+        if (c < kc)
+          tile[r * a.ld_tile + c] =
+              (r < rows_valid && c < a.c + 3) ? v[j] : 0.0f;
+      }
     }
-    tile[r * a.ld_tile + c] = v;
   }
   // lowest() rows of the aggregation buffer the edge kernel maxes into
   if (a.agg) {
