@@ -673,6 +673,8 @@ def parse_args(argv=None):
                     help="skip the extra `car`-preset measurement")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run frames strictly sequentially on one stream")
+    ap.add_argument("--no-capture", action="store_true",
+                    help="skip the hipGraph capture / replay latency entry")
     ap.add_argument("--host-sized", action="store_true",
                     help="build the graphs with host-read sizes (two host "
                          "waits per frame) instead of the capacity form")
@@ -1046,9 +1048,11 @@ def main(argv=None):
         # one frame alone, enqueue to results on the host: host-sized graph
         # (the builder waits twice for sizes) vs capacity form (one read, at
         # the end)
-        lat = {"host-sized": [], "capacity form": [],
-               "capacity form, one hipGraph": []}
-        captured = engine.capture_frame(x, f)
+        lat = {"host-sized": [], "capacity form": []}
+        captured = None
+        if not args.no_capture:
+            lat["capacity form, one hipGraph"] = []
+            captured = engine.capture_frame(x, f)
         for _ in range(7):
             for key in lat:
                 torch.cuda.synchronize()

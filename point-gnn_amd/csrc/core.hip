@@ -13,6 +13,19 @@ std::string &last_error() {
   return err;
 }
 
+namespace {
+__global__ void sched_zero_kernel(int32_t *sched) {
+  if (threadIdx.x < PGNN_SCHED_WS_INTS) sched[threadIdx.x] = 0;
+}
+}  // namespace
+
+int arm_sched(int32_t *sched, hipStream_t stream) {
+  if (!sched) return 0;
+  static_assert(PGNN_SCHED_WS_INTS <= 64, "one wave zeroes the counters");
+  hipLaunchKernelGGL(sched_zero_kernel, dim3(1), dim3(64), 0, stream, sched);
+  return (int)hipGetLastError();
+}
+
 int g_graph_lds_pad = 0;
 int g_graph_max_wgs = 0;
 

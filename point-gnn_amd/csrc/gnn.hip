@@ -319,6 +319,29 @@ __global__ __launch_bounds__(256, 2) void fused_mlp_kernel(
     if (!(dbg & 64)) __builtin_amdgcn_s_setprio(3);
     if constexpr (PRO == PRO_ROWS) {
       const int kc = 16 * chain.l[0].kq;
+      if (ra.nx2 == 0) {
+        // 32 threads per row (8 rows per sweep), columns c0, c0 + 32, ...;
+        // unconditional clamped loads, select on the value (rows_mlp_kernel)
+        const int c0 = threadIdx.x & 31;
+        for (int r = threadIdx.x >> 5; r < ROWS; r += 8) {
+          const float *xr =
+              ra.x + (row0 + (r < rows_valid ? r : rows_valid - 1)) * ra.ldx;
+          for (int cb = 0; cb < kc; cb += 32 * 4) {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int c = cb + c0 + 32 * j;
+              v[j] = xr[c < ra.nx ? c : ra.nx - 1];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int c = cb + c0 + 32 * j;
+              if (c < kc)
+                tile[r * ld0 + c] = (r < rows_valid && c < ra.nx) ? v[j] : 0.0f;
+            }
+          }
+        }
+      } else {
       for (int idx = threadIdx.x; idx < ROWS * kc; idx += 256) {
         const int r = idx / kc, c = idx - r * kc;
         float v = 0.0f;
@@ -329,6 +352,7 @@ __global__ __launch_bounds__(256, 2) void fused_mlp_kernel(
             v = ra.x2[(row0 + r) * ra.ldx2 + (c - ra.nx)];
         }
         tile[r * ld0 + c] = v;
+      }
       }
     } else if constexpr (is_pool_reg(PRO)) {
       // wave w owns rows 16w .. 16w+15; lane (g, n) holds input features

@@ -136,10 +136,9 @@ size_t device_max_lds();
 // zeroed, but an aborted launch or a caller sharing one buffer between
 // streams would leave them poisoned and later launches would silently skip
 // pool tiles: re-arm them in stream order before every launch that uses them.
-inline int arm_sched(int32_t *sched, hipStream_t stream) {
-  if (!sched) return 0;
-  return (int)hipMemsetAsync(sched, 0, PGNN_SCHED_WS_INTS * sizeof(int32_t),
-                             stream);
-}
+// (a kernel, not hipMemsetAsync: inside a captured hipGraph the memset node
+// did not take effect on replays after the first -- the pooling kernel of a
+// replayed ped_cyl frame then skipped pool tiles, tools/ped_check.py)
+int arm_sched(int32_t *sched, hipStream_t stream);
 
 }  // namespace pgnn

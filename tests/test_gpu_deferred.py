@@ -263,14 +263,18 @@ def test_deferred_frame_on_degenerate_clouds(dev, n_points):
     assert torch.equal(lg, lg2) and torch.equal(bx, bx2)
 
 
-def test_captured_frame_replays_bit_identically(dev):
+@pytest.mark.parametrize("cfg_name", ["car", "ped"])
+def test_captured_frame_replays_bit_identically(dev, cfg_name):
     """A whole frame in ONE hipGraph (engine.capture_frame): replays give the
     eager results bit for bit, for the captured cloud and for other clouds of
     the same point count (K and the edge counts differ: they live on the
-    device); another point count is refused."""
+    device), replay after replay (ped_cyl: the LDS-tile pooling kernel's tile
+    pool counters are re-armed by a kernel -- a hipMemsetAsync node did not
+    take effect on later replays); another point count is refused."""
     import torch
     from pointgnn_amd.engine import InferenceEngine
-    cfg = configs.car_auto_config(3)
+    cfg = configs.car_auto_config(3) if cfg_name == "car" else \
+        configs.ped_cyl_auto_config(3)
     params = weights.init_params(cfg, seed=5, bias_scale=0.05)
     eng = InferenceEngine(cfg, params, device=dev)
     clouds = []
@@ -281,7 +285,7 @@ def test_captured_frame_replays_bit_identically(dev):
     shapes = list(eng.frame_shapes)
     assert len({sh[0] for sh in shapes}) > 1       # different K per cloud
     cap = eng.capture_frame(*clouds[0])
-    for rep in range(2):
+    for rep in range(3):
         for (x, f), (lg, bx), sh in zip(clouds, eager, shapes):
             out = cap.replay(x, f)
             lg2, bx2 = out.result()

@@ -17,13 +17,20 @@ from pointgnn_amd.synthetic import synthetic_cloud  # noqa: E402
 
 
 def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="car_auto_T3")
+    ap.add_argument("--preset", default="car_600k")
+    ap.add_argument("--reps", type=int, default=9)
+    args = ap.parse_args()
     dev = torch.device("cuda")
-    cfg = configs.get_config("car_auto_T3")
+    cfg = configs.get_config(args.config)
     eng = InferenceEngine(cfg, weights.init_params(cfg, seed=0, bias_scale=0.05),
                           device=dev)
-    xyz, inten = synthetic_cloud(seed=0, preset="car_600k")
+    xyz, inten = synthetic_cloud(seed=0, preset=args.preset)
     x, f = torch.from_numpy(xyz).to(dev), torch.from_numpy(inten).to(dev)
     lg0, bx0 = eng.run_frame(x, f)
+    print("shapes", eng.frame_shapes[-1], flush=True)
     k = lg0.shape[0]
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
@@ -37,9 +44,9 @@ def main():
     with torch.cuda.graph(g, stream=side):
         d = eng.run_frame_deferred(xs, fs)
     torch.cuda.synchronize()
-    print("captured")
+    print("captured", flush=True)
     lat = {"eager": [], "replay": []}
-    for rep in range(9):
+    for rep in range(args.reps):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         eng.run_frame_deferred(x, f).result()
@@ -51,13 +58,15 @@ def main():
         counts = d.counts.tensor.tolist()
         torch.cuda.synchronize()
         lat["replay"].append((time.perf_counter() - t0) * 1e3)
+        print("rep", rep, "ok", counts[:2], flush=True)
     print("K", counts[0], "status", counts[1], "edges", counts[2:])
     print("latency ms: eager %.3f  replay %.3f" % (
-        sorted(lat["eager"])[4], sorted(lat["replay"])[4]))
+        sorted(lat["eager"])[len(lat["eager"]) // 2],
+        sorted(lat["replay"])[len(lat["replay"]) // 2]))
     print("replay == eager:", torch.equal(d.logits[:k], lg0),
           torch.equal(d.boxes[:k], bx0))
     # another cloud of the same size through the same graph
-    xyz2, inten2 = synthetic_cloud(seed=3, preset="car_600k")
+    xyz2, inten2 = synthetic_cloud(seed=3, preset=args.preset)
     lg2, bx2 = eng.run_frame(torch.from_numpy(xyz2).to(dev),
                              torch.from_numpy(inten2).to(dev))
     xs.copy_(torch.from_numpy(xyz2).to(dev))

@@ -1,4 +1,6 @@
 #!/bin/bash
 cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out/s21
-timeout 300 python tools/graph_capture_probe.py 2>&1 | grep -v amdgpu.ids | tail -25 | tee gpurun_out/s21/capture.log
+for i in 1 2 3; do
+timeout 300 python tools/graph_capture_probe.py "$@" 2>&1 | grep -v amdgpu.ids | tail -6
+done
