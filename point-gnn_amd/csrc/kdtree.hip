@@ -351,14 +351,16 @@ __device__ __forceinline__ void kd_introselect_wave(Rec *R, int off, int dim,
     const int nj = (rlen + 63) >> 6;  // <= KD_WCHUNK
     unsigned mask = 0;  // bit j: my element of row j is smaller than the pivot
     int c_less = 0;
+    // (unconditional loads from a clamped slot, the range test on the value:
+    // a load under `if (i < last)` is waited for on the spot and the rows of a
+    // pass would be read one LDS round trip after the other)
 #pragma unroll 4
     for (int j = 0; j < nj; ++j) {
       const int i = r0 + 64 * j + lane;
-      bool less = false;
-      if (i < last) {
-        const float k = R[i - off].c[dim];
-        less = (k == pk) ? (R[i - off].idx < pi) : (k < pk);
-      }
+      const Rec &e = R[(i < last ? i : last - 1) - off];
+      const float k = e.c[dim];
+      const int ei = e.idx;
+      const bool less = i < last && ((k == pk) ? (ei < pi) : (k < pk));
       mask |= less ? (1u << j) : 0u;
       c_less += __popcll(__ballot(less));
     }
