@@ -747,7 +747,11 @@ __device__ __forceinline__ void weight_grad_body(
     const float *__restrict__ X, int64_t ldx, int k_in,
     const float *__restrict__ dZ, int64_t ldz, int n_out, int64_t rows,
     int64_t rows_per_slice, int nt, float *__restrict__ partial, int ib,
-    int slice, int n_in_blocks) {
+    int slice, int n_in_blocks,
+    float *__restrict__ bias_partial = nullptr /* [slices][16 nt]: when given,
+        db is summed here by input block 0 from the staged dZ tile instead of
+        riding as input column k_in -- for k_in % 64 == 0 that column would
+        be an input block of its own re-reading all of dZ */) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int ldxs = 68, ldzs = 16 * nt + 4;
   float *Xs = reinterpret_cast<float *>(smem);
@@ -770,6 +774,7 @@ __device__ __forceinline__ void weight_grad_body(
     if (t > nt - 1) t = nt - 1;
     toff[j] = 16 * t + (lane & 15);
   }
+  float bsum[2] = {0.0f, 0.0f};
   for (int64_t r0 = r_begin; r0 < r_end; r0 += kWgRows) {
     __syncthreads();
     // Staging.  Every load is UNCONDITIONAL (clamped row / column) and the
@@ -790,7 +795,10 @@ __device__ __forceinline__ void weight_grad_body(
         const int r = (threadIdx.x >> 6) + 4 * i;
         const bool ok = r0 + r < r_end;
         // column k_in is the bias "input": a constant one
-        Xs[r * ldxs + c] = !ok ? 0.0f : (col < k_in ? xv[i] : (col == k_in ? 1.0f : 0.0f));
+        Xs[r * ldxs + c] =
+            !ok ? 0.0f
+                : (col < k_in ? xv[i]
+                              : ((col == k_in && !bias_partial) ? 1.0f : 0.0f));
       }
     }
     // dZ tile: thread (t >> 6, t & 63) takes rows (t >> 6) + 4 i and columns
@@ -816,6 +824,19 @@ __device__ __forceinline__ void weight_grad_body(
       }
     }
     __syncthreads();
+    if (bias_partial && ib == 0) {
+      // column sums of the staged dZ tile (rows past the end are zero)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int c = threadIdx.x + 256 * h;
+        if (c < 16 * nt) {
+          float sum = 0.0f;
+#pragma unroll 8
+          for (int r = 0; r < kWgRows; ++r) sum += Zs[r * ldzs + c];
+          bsum[h] += sum;
+        }
+      }
+    }
 #pragma unroll
     for (int q = 0; q < kWgRows / 16; ++q) {
 #pragma unroll
@@ -833,6 +854,13 @@ __device__ __forceinline__ void weight_grad_body(
             acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[j],
                                                              acc[m][j], 0, 0, 0);
       }
+    }
+  }
+  if (bias_partial && ib == 0) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int c = threadIdx.x + 256 * h;
+      if (c < 16 * nt) bias_partial[(int64_t)slice * 16 * nt + c] = bsum[h];
     }
   }
   // partial[slice][in][out], in padded to 64*gridDim.x, out padded to 16*nt
@@ -857,10 +885,11 @@ template <int NT>
 __global__ __launch_bounds__(256) void weight_grad_kernel(
     const float *__restrict__ X, int64_t ldx, int k_in,
     const float *__restrict__ dZ, int64_t ldz, int n_out, int64_t rows,
-    int64_t rows_per_slice, int nt, float *__restrict__ partial) {
+    int64_t rows_per_slice, int nt, float *__restrict__ partial,
+    float *__restrict__ bias_partial) {
   weight_grad_body<NT>(X, ldx, k_in, dZ, ldz, n_out, rows, rows_per_slice, nt,
                        partial, (int)blockIdx.x, (int)blockIdx.y,
-                       (int)gridDim.x);
+                       (int)gridDim.x, bias_partial);
 }
 
 // ---- many small weight gradients in ONE launch -------------------------------
@@ -941,7 +970,8 @@ __global__ __launch_bounds__(256) void weight_grad_reduce_many_kernel(
 __global__ __launch_bounds__(256) void weight_grad_reduce_kernel(
     const float *__restrict__ partial, int slices, int64_t kin_p, int nout_p,
     int k_in, int n_out, int64_t ld_dw, float *__restrict__ dW,
-    float *__restrict__ db, int accumulate) {
+    float *__restrict__ db, int accumulate,
+    const float *__restrict__ bias_partial /* nullable, see the kernel */) {
   __shared__ float part[4][64];
   const int64_t total = (int64_t)(k_in + 1) * n_out;
   const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
@@ -951,9 +981,15 @@ __global__ __launch_bounds__(256) void weight_grad_reduce_kernel(
     const int64_t i = idx / n_out;
     const int j = (int)(idx - i * n_out);
     float s = 0.0f;
-    if (idx < total)
-      for (int sl = g; sl < slices; sl += 4)
-        s += partial[((int64_t)sl * kin_p + i) * nout_p + j];
+    if (idx < total) {
+      if (bias_partial && i == k_in) {
+        for (int sl = g; sl < slices; sl += 4)
+          s += bias_partial[(int64_t)sl * nout_p + j];
+      } else {
+        for (int sl = g; sl < slices; sl += 4)
+          s += partial[((int64_t)sl * kin_p + i) * nout_p + j];
+      }
+    }
     part[g][o] = s;
     __syncthreads();
     if (g == 0 && idx < total) {
@@ -1444,7 +1480,9 @@ extern "C" size_t pgnn_weight_grad_workspace_bytes(int32_t k_in, int32_t n_out,
   if (k_in <= 0 || n_out <= 0 || n_rows < 0) return 0;
   const size_t in_blocks = ((size_t)k_in + 1 + 63) / 64;
   const size_t nt = ((size_t)n_out + 15) / 16;
-  return (size_t)wg_slices(n_rows, k_in) * in_blocks * 64 * nt * 16 * 4 + 256;
+  // (+ one [slices][16 nt] block for the separately summed bias, k_in % 64 == 0)
+  return (size_t)wg_slices(n_rows, k_in) * (in_blocks * 64 + 1) * nt * 16 * 4 +
+         256;
 }
 
 extern "C" int pgnn_weight_grad_f32(const float *X, int64_t ld_x, int32_t k_in,
@@ -1462,7 +1500,11 @@ extern "C" int pgnn_weight_grad_f32(const float *X, int64_t ld_x, int32_t k_in,
                PGNN_E_WORKSPACE, "weight_grad: workspace too small");
   PGNN_REQUIRE(n_rows == 0 || (X && dZ && ld_x >= k_in && ld_dz >= n_out),
                PGNN_E_INVALID, "weight_grad: bad input");
-  const int in_blocks = (k_in + 1 + 63) / 64;
+  // k_in a multiple of 64: the bias "input column" would be a block of its
+  // own that re-reads all of dZ for one row of dW; block 0 sums db from the
+  // tile it has staged anyway
+  const bool split_bias = db != nullptr && k_in % 64 == 0;
+  const int in_blocks = split_bias ? k_in / 64 : (k_in + 1 + 63) / 64;
   const int slices = wg_slices(n_rows, k_in);
   int64_t rps = (n_rows + slices - 1) / slices;
   rps = (rps + kWgRows - 1) / kWgRows * kWgRows;
@@ -1477,10 +1519,13 @@ extern "C" int pgnn_weight_grad_f32(const float *X, int64_t ld_x, int32_t k_in,
     const size_t lds = (size_t)kWgRows * (68 + 16 * nt + 4) * 4;
     const int ntw = (nt + 3) / 4;
     dim3 grid(in_blocks, slices);
+    // the pass's bias partials sit right behind its main block
+    float *bias_partial =
+        split_bias ? partial + (size_t)slices * in_blocks * 64 * nt * 16 : nullptr;
 #define PGNN_WG(NTV)                                                          \
   hipLaunchKernelGGL((weight_grad_kernel<NTV>), grid, dim3(256), lds, stream,  \
                      X, ld_x, k_in, dZ + c0, ld_dz, nc, n_rows, rps, nt,       \
-                     partial)
+                     partial, bias_partial)
     switch (ntw) {
       case 1: PGNN_WG(1); break;
       case 2: PGNN_WG(2); break;
@@ -1493,7 +1538,8 @@ extern "C" int pgnn_weight_grad_f32(const float *X, int64_t ld_x, int32_t k_in,
                        dim3(grid_for((int64_t)(k_in + 1) * nc * 4)), dim3(256), 0,
                        stream, partial, slices, (int64_t)in_blocks * 64,
                        nt * 16, k_in, nc, (int64_t)n_out, dW + c0,
-                       db ? db + c0 : nullptr, accumulate);
+                       db ? db + c0 : nullptr, accumulate,
+                       (const float *)bias_partial);
   }
   PGNN_HIP(hipGetLastError());
   return 0;
