@@ -562,6 +562,23 @@ int pgnn_weight_grad_f32(const float *X, int64_t ld_x, int32_t k_in,
                          int64_t n_rows, float *dW, float *db,
                          int32_t accumulate, void *workspace,
                          size_t workspace_bytes, void *stream);
+/* Fused backward of PointSetPooling's narrow point-MLP layers for the shipped
+ * car chain feat -> 32 -> 64 -> 128 (gnn.py:256-277 under tf.gradients): given
+ * the gradient w.r.t. the third layer's pre-activation (what
+ * pgnn_segmax_fc_bwd_f32 hands over for the 128 -> 300 layer), the weight and
+ * bias gradients of all three layers in one pass over the E rows -- the two dX
+ * products and ReLU masks in between happen in LDS.  feat [E,16] (k_in0 <= 15
+ * columns used), act0 [E,32], act1 [E,64], dz2 [E,128]: contiguous rows;
+ * w2t_packed / w1t_packed: the TRANSPOSED images (pgnn_pack_fc_many kind 1) of
+ * the 64 -> 128 and 32 -> 64 layers.  Deterministic (fixed slice order).     */
+size_t pgnn_pool_narrow_bwd_workspace_bytes(int64_t n_rows);
+int pgnn_pool_narrow_bwd_f32(const float *feat, const float *act0,
+                             const float *act1, const float *dz2,
+                             int64_t n_rows, const float *w2t_packed,
+                             const float *w1t_packed, int32_t k_in0, float *dW0,
+                             float *db0, float *dW1, float *db1, float *dW2,
+                             float *db2, int32_t accumulate, void *workspace,
+                             size_t workspace_bytes, void *stream);
 /* The same for MANY small layers in one launch pair (train.py:264-297 asks
  * tf.gradients for every variable at once; here the K-row layers of a step --
  * ~25 GEMMs of [k_in x K] x [K x n_out], K ~ 2 000 vertices -- would each be a

@@ -238,6 +238,10 @@ _SIGNATURES = {
                                                c_i32]),
     "pgnn_weight_grad_many_f32": (c_i32, [ctypes.POINTER(WgradJob), c_i32,
                                           c_vp, c_sz, c_vp]),
+    "pgnn_pool_narrow_bwd_workspace_bytes": (c_sz, [c_i64]),
+    "pgnn_pool_narrow_bwd_f32": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp,
+                                         c_vp, c_i32, c_vp, c_vp, c_vp, c_vp,
+                                         c_vp, c_vp, c_i32, c_vp, c_sz, c_vp]),
     "pgnn_loss_fwd_bwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i32, c_vp, c_vp,
                                   c_i64, c_i32, ctypes.c_float, ctypes.c_float,
                                   c_vp, c_vp, c_vp, c_vp]),

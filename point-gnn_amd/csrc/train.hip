@@ -1546,6 +1546,190 @@ extern "C" int pgnn_weight_grad_f32(const float *X, int64_t ld_x, int32_t k_in,
   PGNN_GUARD_END
 }
 
+// ---- fused backward of PointSetPooling's narrow point-MLP layers ---------------
+// car chain: feat [E,16 (4 used)] -> 32 -> 64 -> 128 (-> 300, whose adjoint is the
+// sparse segment-max kernel above and hands over dZ2, the gradient w.r.t. the
+// third layer's pre-activation).  Layer by layer this was three E-row weight
+// gradients, two E-row dX GEMMs and two mask passes -- 0.4 ms of a 4 ms step,
+// every one re-reading [E, 32..128] arrays and writing its dX back (gnn.py:256-277
+// under tf.gradients).  Here a workgroup walks a slice of the rows in 32-row
+// tiles: the four tiles (feat, act0, act1, dZ2) are staged once, and
+//     dW2 += act1^T dZ2        dA1 = dZ2 W2^T    dZ1 = dA1 * (act1 > 0)
+//     dW1 += act0^T dZ1        dA0 = dZ1 W1^T    dZ0 = dA0 * (act0 > 0)
+//     dW0 += feat^T dZ0        db_l += column sums of dZ_l
+// run from LDS: the dX products through the forward engine's layer pass on the
+// transposed weight images (what fc_dx does per layer), the weight gradients
+// with the MFMA loop of weight_grad_body, accumulated in registers over the
+// slice.  Partials per slice, summed in a fixed order by weight_grad_reduce_kernel.
+constexpr int kPnRows = 32;
+struct PoolNarrowArgs {
+  const float *feat, *act0, *act1, *dz2;
+  int64_t rows, rps;
+  LayerDev t2, t1;  // transposed images: 128 -> 64, 64 -> 32 (zero bias)
+  float *pw2, *pb2, *pw1, *pb1, *pw0, *pb0;  // partials [slices][...]
+};
+
+// tile[r][c] <- src[(r0 + r) * ld + c] for 32 rows x W columns (W = 16..128),
+// zero for rows past r_end; unconditional clamped loads
+template <int W>
+__device__ __forceinline__ void pn_stage(float *tile, int ldt, const float *src,
+                                         int64_t r0, int64_t r_end) {
+  constexpr int TPR = W < 64 ? W : 64;     // threads per row
+  constexpr int RPS = 256 / TPR;            // rows per sweep
+  const int c0 = threadIdx.x % TPR, rs = threadIdx.x / TPR;
+#pragma unroll
+  for (int cb = 0; cb < W; cb += TPR) {
+    float v[kPnRows / RPS];
+#pragma unroll
+    for (int i = 0; i < kPnRows / RPS; ++i) {
+      const int64_t row = r0 + rs + RPS * i;
+      v[i] = src[(row < r_end ? row : r_end - 1) * W + cb + c0];
+    }
+#pragma unroll
+    for (int i = 0; i < kPnRows / RPS; ++i) {
+      const int r = rs + RPS * i;
+      tile[r * ldt + cb + c0] = (r0 + r < r_end) ? v[i] : 0.0f;
+    }
+  }
+}
+
+// acc[m][j] += X^T Z over the tile's 32 rows: X [32][ldx] (MT input tiles of
+// 16), Z [32][ldz], column tiles t_j = wave + 4 j (clamped to nt - 1)
+template <int MT, int NT>
+__device__ __forceinline__ void pn_wgrad(const float *Xs, int ldx, const float *Zs,
+                                         int ldz, int nt, int wave, int lane,
+                                         v4f (&acc)[MT][NT]) {
+  int toff[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    int t = wave + 4 * j;
+    if (t > nt - 1) t = nt - 1;
+    toff[j] = 16 * t + (lane & 15);
+  }
+#pragma unroll
+  for (int q = 0; q < kPnRows / 16; ++q) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int r = 16 * q + 4 * (lane >> 4) + s;
+      float a[MT], b[NT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) a[m] = Xs[r * ldx + 16 * m + (lane & 15)];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) b[j] = Zs[r * ldz + toff[j]];
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[j], acc[m][j],
+                                                           0, 0, 0);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void pool_narrow_bwd_kernel(PoolNarrowArgs a) {
+  constexpr int LZ2 = 128 + 8, LA1 = 64 + 8, LA0 = 32 + 8, LF = 16 + 8;
+  __shared__ __attribute__((aligned(16))) float Z2[kPnRows * LZ2];
+  __shared__ __attribute__((aligned(16))) float A1[kPnRows * LA1];
+  __shared__ __attribute__((aligned(16))) float A0[kPnRows * LA0];
+  __shared__ __attribute__((aligned(16))) float F[kPnRows * LF];
+  __shared__ __attribute__((aligned(16))) float D1[kPnRows * LA1];
+  __shared__ __attribute__((aligned(16))) float D0[kPnRows * LA0];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int slice = blockIdx.x;
+  const int64_t r_begin = (int64_t)slice * a.rps;
+  int64_t r_end = r_begin + a.rps;
+  if (r_end > a.rows) r_end = a.rows;
+  v4f w2[4][2], w1[2][1], w0[1][1];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) w2[m][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int m = 0; m < 2; ++m) w1[m][0] = (v4f){0.f, 0.f, 0.f, 0.f};
+  w0[0][0] = (v4f){0.f, 0.f, 0.f, 0.f};
+  float b2 = 0.0f, b1 = 0.0f, b0 = 0.0f;  // thread t: column t of db2 / db1 / db0
+  for (int64_t r0 = r_begin; r0 < r_end; r0 += kPnRows) {
+    __syncthreads();  // the previous tile's buffers are free
+    pn_stage<16>(F, LF, a.feat, r0, r_end);
+    pn_stage<32>(A0, LA0, a.act0, r0, r_end);
+    pn_stage<64>(A1, LA1, a.act1, r0, r_end);
+    pn_stage<128>(Z2, LZ2, a.dz2, r0, r_end);
+    __syncthreads();
+    // layer 2 (64 -> 128)
+    pn_wgrad<4, 2>(A1, LA1, Z2, LZ2, 8, wave, lane, w2);
+    if (threadIdx.x < 128) {
+      float sum = 0.0f;
+#pragma unroll 8
+      for (int r = 0; r < kPnRows; ++r) sum += Z2[r * LZ2 + threadIdx.x];
+      b2 += sum;
+    }
+    layer_pass_dispatch<2, false, 4>(Z2, LZ2, D1, LA1, a.t2, 0, wave, lane);
+    for (int idx = threadIdx.x; idx < kPnRows * 64; idx += 256) {
+      const int r = idx >> 6, c = idx & 63;
+      if (!(A1[r * LA1 + c] > 0.0f)) D1[r * LA1 + c] = 0.0f;
+    }
+    __syncthreads();
+    // layer 1 (32 -> 64)
+    pn_wgrad<2, 1>(A0, LA0, D1, LA1, 4, wave, lane, w1);
+    if (threadIdx.x < 64) {
+      float sum = 0.0f;
+#pragma unroll 8
+      for (int r = 0; r < kPnRows; ++r) sum += D1[r * LA1 + threadIdx.x];
+      b1 += sum;
+    }
+    layer_pass_dispatch<2, false, 4>(D1, LA1, D0, LA0, a.t1, 0, wave, lane);
+    for (int idx = threadIdx.x; idx < kPnRows * 32; idx += 256) {
+      const int r = idx >> 5, c = idx & 31;
+      if (!(A0[r * LA0 + c] > 0.0f)) D0[r * LA0 + c] = 0.0f;
+    }
+    __syncthreads();
+    // layer 0 (16 -> 32)
+    pn_wgrad<1, 1>(F, LF, D0, LA0, 2, wave, lane, w0);
+    if (threadIdx.x < 32) {
+      float sum = 0.0f;
+#pragma unroll 8
+      for (int r = 0; r < kPnRows; ++r) sum += D0[r * LA0 + threadIdx.x];
+      b0 += sum;
+    }
+  }
+  // partials: register rr of tile (m, t) <-> dW[16 m + 4 (lane >> 4) + rr][16 t +
+  // (lane & 15)]
+  {
+    float *p = a.pw2 + (int64_t)slice * 64 * 128;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int t = wave + 4 * j;
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+          p[(16 * m + 4 * (lane >> 4) + rr) * 128 + 16 * t + (lane & 15)] =
+              w2[m][j][rr];
+    }
+    if (threadIdx.x < 128) a.pb2[(int64_t)slice * 128 + threadIdx.x] = b2;
+  }
+  {
+    float *p = a.pw1 + (int64_t)slice * 32 * 64;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
+        p[(16 * m + 4 * (lane >> 4) + rr) * 64 + 16 * wave + (lane & 15)] =
+            w1[m][0][rr];
+    if (threadIdx.x < 64) a.pb1[(int64_t)slice * 64 + threadIdx.x] = b1;
+  }
+  {
+    float *p = a.pw0 + (int64_t)slice * 16 * 32;
+    if (wave < 2) {
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
+        p[(4 * (lane >> 4) + rr) * 32 + 16 * wave + (lane & 15)] = w0[0][0][rr];
+    }
+    if (threadIdx.x < 32) a.pb0[(int64_t)slice * 32 + threadIdx.x] = b0;
+  }
+}
+
 namespace {
 // rows per slice / slices of one job when `wgs_per_in_block` workgroups are
 // available per input block
@@ -1666,6 +1850,105 @@ extern "C" int pgnn_weight_grad_many_f32(const pgnn_wgrad_job *jobs,
                        dim3(grid_for(out0 * 4)), dim3(256), 0, stream, js,
                        (const float *)partial);
   }
+  PGNN_HIP(hipGetLastError());
+  return 0;
+  PGNN_GUARD_END
+}
+
+namespace {
+void pn_split(int64_t rows, int64_t &rps, int &slices) {
+  // one wave of workgroups (3 per CU at 48 KB of LDS)
+  int64_t s = (int64_t)3 * device_cu_count();
+  const int64_t max_s = (rows + kPnRows - 1) / kPnRows;
+  if (s > max_s) s = max_s;
+  if (s < 1) s = 1;
+  rps = (rows + s - 1) / s;
+  rps = (rps + kPnRows - 1) / kPnRows * kPnRows;
+  slices = (int)((rows + rps - 1) / rps);
+  if (slices < 1) slices = 1;
+}
+constexpr size_t kPnSliceFloats = 64 * 128 + 128 + 32 * 64 + 64 + 16 * 32 + 32;
+}  // namespace
+
+extern "C" size_t pgnn_pool_narrow_bwd_workspace_bytes(int64_t n_rows) {
+  if (n_rows < 0) return 0;
+  int64_t rps;
+  int slices;
+  pn_split(n_rows > 0 ? n_rows : 1, rps, slices);
+  return (size_t)slices * kPnSliceFloats * 4 + 1024;
+}
+
+extern "C" int pgnn_pool_narrow_bwd_f32(
+    const float *feat, const float *act0, const float *act1, const float *dz2,
+    int64_t n_rows, const float *w2t_packed, const float *w1t_packed,
+    int32_t k_in0, float *dW0, float *db0, float *dW1, float *db1, float *dW2,
+    float *db2, int32_t accumulate, void *workspace, size_t workspace_bytes,
+    void *stream_) {
+  PGNN_GUARD_BEGIN
+  hipStream_t stream = (hipStream_t)stream_;
+  PGNN_REQUIRE(n_rows >= 0 && k_in0 >= 1 && k_in0 <= 15 && dW0 && dW1 && dW2 &&
+                   db0 && db1 && db2 && w2t_packed && w1t_packed,
+               PGNN_E_INVALID, "pool_narrow_bwd: bad argument");
+  if (n_rows == 0) {
+    if (!accumulate) {
+      PGNN_HIP(hipMemsetAsync(dW0, 0, (size_t)k_in0 * 32 * 4, stream));
+      PGNN_HIP(hipMemsetAsync(dW1, 0, (size_t)32 * 64 * 4, stream));
+      PGNN_HIP(hipMemsetAsync(dW2, 0, (size_t)64 * 128 * 4, stream));
+      PGNN_HIP(hipMemsetAsync(db0, 0, 32 * 4, stream));
+      PGNN_HIP(hipMemsetAsync(db1, 0, 64 * 4, stream));
+      PGNN_HIP(hipMemsetAsync(db2, 0, 128 * 4, stream));
+    }
+    return 0;
+  }
+  PGNN_REQUIRE(feat && act0 && act1 && dz2, PGNN_E_INVALID,
+               "pool_narrow_bwd: null input");
+  PGNN_REQUIRE(workspace &&
+                   workspace_bytes >= pgnn_pool_narrow_bwd_workspace_bytes(n_rows),
+               PGNN_E_WORKSPACE, "pool_narrow_bwd: workspace too small");
+  PoolNarrowArgs a;
+  a.feat = feat;
+  a.act0 = act0;
+  a.act1 = act1;
+  a.dz2 = dz2;
+  a.rows = n_rows;
+  int slices;
+  pn_split(n_rows, a.rps, slices);
+  a.t2.wp = w2t_packed;
+  a.t2.kq = 8;
+  a.t2.nt = 4;
+  a.t2.relu_from = 64;  // linear
+  a.t1.wp = w1t_packed;
+  a.t1.kq = 4;
+  a.t1.nt = 2;
+  a.t1.relu_from = 32;
+  float *w = (float *)workspace;
+  a.pw2 = w;
+  w += (size_t)slices * 64 * 128;
+  a.pb2 = w;
+  w += (size_t)slices * 128;
+  a.pw1 = w;
+  w += (size_t)slices * 32 * 64;
+  a.pb1 = w;
+  w += (size_t)slices * 64;
+  a.pw0 = w;
+  w += (size_t)slices * 16 * 32;
+  a.pb0 = w;
+  hipLaunchKernelGGL(pool_narrow_bwd_kernel, dim3((unsigned)slices), dim3(256), 0,
+                     stream, a);
+  const int acc = accumulate ? 1 : 0;
+  hipLaunchKernelGGL(weight_grad_reduce_kernel, dim3(grid_for((int64_t)65 * 128 * 4)),
+                     dim3(256), 0, stream, (const float *)a.pw2, slices,
+                     (int64_t)64, 128, 64, 128, (int64_t)128, dW2, db2, acc,
+                     (const float *)a.pb2);
+  hipLaunchKernelGGL(weight_grad_reduce_kernel, dim3(grid_for((int64_t)33 * 64 * 4)),
+                     dim3(256), 0, stream, (const float *)a.pw1, slices,
+                     (int64_t)32, 64, 32, 64, (int64_t)64, dW1, db1, acc,
+                     (const float *)a.pb1);
+  hipLaunchKernelGGL(weight_grad_reduce_kernel,
+                     dim3(grid_for((int64_t)(k_in0 + 1) * 32 * 4)), dim3(256), 0,
+                     stream, (const float *)a.pw0, slices, (int64_t)16, 32,
+                     (int)k_in0, 32, (int64_t)32, dW0, db0, acc,
+                     (const float *)a.pb0);
   PGNN_HIP(hipGetLastError());
   return 0;
   PGNN_GUARD_END

@@ -479,6 +479,9 @@ size_t scratch_need(const Trainer &t, const pgnn_train_batch &b) {
     if (s.kind == 1) {  // the Wx rows: k_in = 3
       const size_t n = pgnn_weight_grad_workspace_bytes(3, s.a[0].ref.n_out, K);
       if (n > need) need = n;
+    } else {  // the fused backward of the narrow pooling layers
+      const size_t n = pgnn_pool_narrow_bwd_workspace_bytes(E);
+      if (n > need) need = n;
     }
   }
   const int64_t K = b.n_vertices[b.n_levels];
@@ -1080,6 +1083,24 @@ int backward_impl(Ctx &c, Saved &sv, const float *dlogits, const float *dpred) {
           if (rc) return rc;
           gcur = gz;
           from = na - 1;
+        }
+        // the shipped car chain's three narrow layers (feat -> 32 -> 64 -> 128
+        // below the sparse 128 -> 300 layer): one fused pass over the E rows
+        const bool narrow =
+            s.a.back().want_wt && na == 4 && from == 2 &&
+            s.a[0].ref.k_in <= 15 && s.a[0].ref.n_out == 32 &&
+            s.a[1].ref.k_in == 32 && s.a[1].ref.n_out == 64 &&
+            s.a[2].ref.k_in == 64 && s.a[2].ref.n_out == 128 &&
+            s.a[1].packed_t && s.a[2].packed_t &&
+            sv.scratch_bytes >= pgnn_pool_narrow_bwd_workspace_bytes(E);
+        if (narrow) {
+          rc = pgnn_pool_narrow_bwd_f32(
+              p.feat, p.act[0], p.act[1], gcur, E, s.a[2].packed_t,
+              s.a[1].packed_t, s.a[0].ref.k_in, s.a[0].gw, s.a[0].gb, s.a[1].gw,
+              s.a[1].gb, s.a[2].gw, s.a[2].gb, 1, sv.scratch, sv.scratch_bytes,
+              c.stream);
+          if (rc) return rc;
+          from = -1;  // done
         }
         for (int i = from; i >= 0; --i) {
           const float *xin = i == 0 ? p.feat : p.act[i - 1];
