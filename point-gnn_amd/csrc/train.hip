@@ -1857,8 +1857,9 @@ extern "C" int pgnn_weight_grad_many_f32(const pgnn_wgrad_job *jobs,
 
 namespace {
 void pn_split(int64_t rows, int64_t &rps, int &slices) {
-  // one wave of workgroups (3 per CU at 48 KB of LDS)
-  int64_t s = (int64_t)3 * device_cu_count();
+  // one wave of workgroups (3 per CU at 48 KB of LDS; tunable with the
+  // weight-gradient kernels' `wgrad_wg_target`)
+  int64_t s = g_wgrad_wg_target;
   const int64_t max_s = (rows + kPnRows - 1) / kPnRows;
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;
