@@ -95,7 +95,12 @@ def main():
            "loss_ref": {k: out_ref[k] for k in ("cls_loss", "loc_loss",
                                                 "reg_loss", "num_endpoint",
                                                 "num_valid_endpoint")}}
-    print("MULTIRANK " + json.dumps(res), flush=True)
+    # one write per record, ranks in turn, so the records do not interleave
+    for r in range(world):
+        if r == rank:
+            sys.stdout.write("MULTIRANK " + json.dumps(res) + "\n")
+            sys.stdout.flush()
+        dist.barrier()
     dist.barrier()
     dist.destroy_process_group()
 
