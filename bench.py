@@ -675,6 +675,9 @@ def parse_args(argv=None):
                     help="run frames strictly sequentially on one stream")
     ap.add_argument("--no-capture", action="store_true",
                     help="skip the hipGraph capture / replay latency entry")
+    ap.add_argument("--no-capture-overlap", action="store_true",
+                    help="skip the capture of the frame with the overlapped "
+                         "graph build (side streams inside the hipGraph)")
     ap.add_argument("--host-sized", action="store_true",
                     help="build the graphs with host-read sizes (two host "
                          "waits per frame) instead of the capacity form")
@@ -1048,12 +1051,16 @@ def main(argv=None):
         # one frame alone, enqueue to results on the host: host-sized graph
         # (the builder waits twice for sizes) vs capacity form (one read, at
         # the end)
-        lat = {"host-sized": [], "capacity form": []}
-        captured = None
+        lat = {"host-sized": [], "capacity form": [],
+               "capacity form, overlapped build": []}
+        captured = captured_ov = None
         if not args.no_capture:
             lat["capacity form, one hipGraph"] = []
             captured = engine.capture_frame(x, f)
-        for _ in range(7):
+            if not args.no_capture_overlap:
+                lat["capacity form, overlapped build, one hipGraph"] = []
+                captured_ov = engine.capture_frame(x, f, overlap_build=True)
+        for _ in range(9):
             for key in lat:
                 torch.cuda.synchronize()
                 tp = time.perf_counter()
@@ -1061,12 +1068,30 @@ def main(argv=None):
                     engine.run_frame(x, f)
                 elif key == "capacity form":
                     engine.run_frame_deferred(x, f).result()
-                else:
+                elif key == "capacity form, overlapped build":
+                    engine.run_frame_deferred(x, f,
+                                              overlap_build=True).result()
+                elif key == "capacity form, one hipGraph":
                     captured.replay(x, f).result()
+                else:
+                    captured_ov.replay(x, f).result()
                 torch.cuda.synchronize()
                 lat[key].append((time.perf_counter() - tp) * 1e3)
-        del captured
+        del captured, captured_ov
         lat = {k_: float(np.median(v[2:])) for k_, v in lat.items()}
+        # the graph build alone in capacity form (enqueue to idle device):
+        # in order on one stream vs its independent parts on side streams
+        build = {"capacity form": [], "capacity form, overlapped build": []}
+        for _ in range(9):
+            for key in build:
+                torch.cuda.synchronize()
+                tp = time.perf_counter()
+                g_ = engine.build_graph_deferred(
+                    x, overlap=key.endswith("overlapped build"))
+                torch.cuda.synchronize()
+                build[key].append((time.perf_counter() - tp) * 1e3)
+                del g_
+        build = {k_: float(np.median(v[2:])) for k_, v in build.items()}
         engine.run_frame(x, f)   # last_graph back to the host-sized form
         coords, kps, edges = engine.last_graph
         # run.py's last two phases ("decode box", "nms", run.py:264-326) on
@@ -1151,6 +1176,7 @@ def main(argv=None):
                         engine.time_dict['gnn inference'] / frames * 1e3,
                     "decode box + nms": post["ms"]},
                 "latency_ms_frame_seed%d" % first: lat,
+                "graph_build_ms_frame_seed%d" % first: build,
                 "capacity_overflow_rebuilds": engine.deferred_overflows,
                 "postprocess": post,
             },

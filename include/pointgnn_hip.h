@@ -159,6 +159,39 @@ int pgnn_radius_graph_dyn_f64(const double *points, int64_t points_cap,
                               size_t workspace_bytes, int32_t *edges,
                               int64_t edge_capacity, int32_t *n_edges_dev,
                               void *stream);
+/* The same builder in its two stages, for a caller that overlaps them with
+ * other work: _grid needs the points only (cell keys, radix sort, bucket
+ * bounds), _query the centres as well (count, scan, fill).  A frame's level-0
+ * graph has the raw cloud as its points and the keypoints as its centres, so
+ * its grid stage can run on a second stream BESIDE the keypoint selection and
+ * only the query stage has to wait for it (the caller orders the two with its
+ * own stream / event calls; both stages take the SAME workspace, capacities,
+ * radius and scale).  _grid then _query on one stream is pgnn_radius_graph_dyn
+ * exactly. */
+int pgnn_radius_graph_dyn_grid(const float *points, int64_t points_cap,
+                               const int32_t *n_points_dev, int64_t centers_cap,
+                               double radius, const double *scale3_host,
+                               void *workspace, size_t workspace_bytes,
+                               void *stream);
+int pgnn_radius_graph_dyn_grid_f64(const double *points, int64_t points_cap,
+                                   const int32_t *n_points_dev,
+                                   int64_t centers_cap, double radius,
+                                   const double *scale3_host, void *workspace,
+                                   size_t workspace_bytes, void *stream);
+int pgnn_radius_graph_dyn_query(const float *points, int64_t points_cap,
+                                const float *centers, int64_t centers_cap,
+                                const int32_t *n_centers_dev, double radius,
+                                const double *scale3_host, void *workspace,
+                                size_t workspace_bytes, int32_t *edges,
+                                int64_t edge_capacity, int32_t *n_edges_dev,
+                                void *stream);
+int pgnn_radius_graph_dyn_query_f64(const double *points, int64_t points_cap,
+                                    const double *centers, int64_t centers_cap,
+                                    const int32_t *n_centers_dev, double radius,
+                                    const double *scale3_host, void *workspace,
+                                    size_t workspace_bytes, int32_t *edges,
+                                    int64_t edge_capacity, int32_t *n_edges_dev,
+                                    void *stream);
 /* Training-time fan-in cap (graph_gen.py:210-214, num_neighbors > 0): keeps a
  * uniformly random subset (without replacement) of `max_neighbors` edges for
  * every centre whose fan-in exceeds it (counter-based RNG keyed by `seed`,

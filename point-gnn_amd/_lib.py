@@ -119,6 +119,16 @@ _SIGNATURES = {
     "pgnn_radius_graph_dyn_f64": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp,
                                           c_f64, c_vp, c_vp, c_sz, c_vp, c_i64,
                                           c_vp, c_vp]),
+    "pgnn_radius_graph_dyn_grid": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_f64,
+                                           c_vp, c_vp, c_sz, c_vp]),
+    "pgnn_radius_graph_dyn_grid_f64": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_f64,
+                                               c_vp, c_vp, c_sz, c_vp]),
+    "pgnn_radius_graph_dyn_query": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp,
+                                            c_f64, c_vp, c_vp, c_sz, c_vp,
+                                            c_i64, c_vp, c_vp]),
+    "pgnn_radius_graph_dyn_query_f64": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp,
+                                                c_f64, c_vp, c_vp, c_sz, c_vp,
+                                                c_i64, c_vp, c_vp]),
     "pgnn_cap_neighbors_count": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp]),
     "pgnn_cap_neighbors_fill": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_u64, c_vp,
                                         c_vp, c_i64, c_vp]),

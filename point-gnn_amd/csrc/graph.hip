@@ -915,35 +915,63 @@ __global__ void edge_total_kernel(const int32_t *__restrict__ total,
   }
 }
 
+// The capacity-form builder in its two stages: the cell grid needs the POINTS
+// only, the queries additionally the centres -- a caller whose centres are
+// still being computed (the keypoints) can issue the grid stage beside that.
 template <typename T>
-int radius_dyn_impl(const T *points, int64_t points_cap,
-                    const int32_t *n_points_dev, const T *centers,
-                    int64_t centers_cap, const int32_t *n_centers_dev,
-                    double radius, const double *scale3_host, void *workspace,
-                    size_t workspace_bytes, int32_t *edges,
-                    int64_t edge_capacity, int32_t *n_edges_dev,
-                    hipStream_t stream) {
-  PGNN_REQUIRE(points_cap >= 0 && centers_cap >= 0 && radius > 0.0 &&
-                   edge_capacity >= 0 && edge_capacity <= 0x7fffffff &&
-                   n_edges_dev,
+int radius_dyn_carve(const T *points, int64_t points_cap, int64_t centers_cap,
+                     double radius, void *workspace, size_t workspace_bytes,
+                     RadiusWs &w, int32_t **offsets) {
+  PGNN_REQUIRE(points_cap >= 0 && centers_cap >= 0 && radius > 0.0,
                PGNN_E_INVALID, "radius_graph_dyn: bad argument");
-  PGNN_REQUIRE((points_cap == 0 || points) && (centers_cap == 0 || centers) &&
-                   (edge_capacity == 0 || edges),
-               PGNN_E_INVALID, "radius_graph_dyn: null pointer");
+  PGNN_REQUIRE(points_cap == 0 || points, PGNN_E_INVALID,
+               "radius_graph_dyn: null pointer");
   PGNN_REQUIRE(workspace &&
                    workspace_bytes >= pgnn_radius_graph_dyn_workspace_bytes(
                                           points_cap, centers_cap),
                PGNN_E_WORKSPACE, "radius_graph_dyn: workspace too small");
-  RadiusWs w;
   int rc = radius_carve(workspace, workspace_bytes, points_cap, centers_cap, w);
   if (rc) return rc;
-  int32_t *offsets = reinterpret_cast<int32_t *>(
+  *offsets = reinterpret_cast<int32_t *>(
       (char *)workspace +
       pgnn_radius_graph_workspace_bytes(points_cap, centers_cap));
-  const Scale3 sc = make_scale(scale3_host);
-  rc = grid_build(points, points_cap, sc, 0.0, 0.0, 0.0, nullptr, radius, w.g,
-                  stream, nullptr, nullptr, n_points_dev);
+  return 0;
+}
+
+template <typename T>
+int radius_dyn_grid(const T *points, int64_t points_cap,
+                    const int32_t *n_points_dev, int64_t centers_cap,
+                    double radius, const double *scale3_host, void *workspace,
+                    size_t workspace_bytes, hipStream_t stream) {
+  RadiusWs w;
+  int32_t *offsets;
+  int rc = radius_dyn_carve(points, points_cap, centers_cap, radius, workspace,
+                            workspace_bytes, w, &offsets);
   if (rc) return rc;
+  return grid_build(points, points_cap, make_scale(scale3_host), 0.0, 0.0, 0.0,
+                    nullptr, radius, w.g, stream, nullptr, nullptr,
+                    n_points_dev);
+}
+
+template <typename T>
+int radius_dyn_query(const T *points, int64_t points_cap, const T *centers,
+                     int64_t centers_cap, const int32_t *n_centers_dev,
+                     double radius, const double *scale3_host, void *workspace,
+                     size_t workspace_bytes, int32_t *edges,
+                     int64_t edge_capacity, int32_t *n_edges_dev,
+                     hipStream_t stream) {
+  PGNN_REQUIRE(edge_capacity >= 0 && edge_capacity <= 0x7fffffff && n_edges_dev,
+               PGNN_E_INVALID, "radius_graph_dyn: bad argument");
+  PGNN_REQUIRE((centers_cap == 0 || centers) && (edge_capacity == 0 || edges),
+               PGNN_E_INVALID, "radius_graph_dyn: null pointer");
+  RadiusWs w;
+  int32_t *offsets;
+  int rc = radius_dyn_carve(points, points_cap, centers_cap, radius, workspace,
+                            workspace_bytes, w, &offsets);
+  if (rc) return rc;
+  // (the tables the grid stage filled sit where the carve puts them: their
+  // layout is a function of the workspace and the two capacities alone)
+  const Scale3 sc = make_scale(scale3_host);
   if (centers_cap > 0) {
     hipLaunchKernelGGL((radius_query_kernel<false, T>),
                        dim3(graph_grid((centers_cap + (graph_wide_block() >> 6) - 1) /
@@ -983,6 +1011,85 @@ extern "C" size_t pgnn_radius_graph_dyn_workspace_bytes(int64_t points_cap,
          align_up((size_t)(centers_cap + 1) * 4, 256);
 }
 
+extern "C" int pgnn_radius_graph_dyn_grid(
+    const float *points, int64_t points_cap, const int32_t *n_points_dev,
+    int64_t centers_cap, double radius, const double *scale3_host,
+    void *workspace, size_t workspace_bytes, void *stream_) {
+  PGNN_GUARD_BEGIN
+  return radius_dyn_grid(points, points_cap, n_points_dev, centers_cap, radius,
+                         scale3_host, workspace, workspace_bytes,
+                         (hipStream_t)stream_);
+  PGNN_GUARD_END
+}
+
+extern "C" int pgnn_radius_graph_dyn_grid_f64(
+    const double *points, int64_t points_cap, const int32_t *n_points_dev,
+    int64_t centers_cap, double radius, const double *scale3_host,
+    void *workspace, size_t workspace_bytes, void *stream_) {
+  PGNN_GUARD_BEGIN
+  return radius_dyn_grid(points, points_cap, n_points_dev, centers_cap, radius,
+                         scale3_host, workspace, workspace_bytes,
+                         (hipStream_t)stream_);
+  PGNN_GUARD_END
+}
+
+extern "C" int pgnn_radius_graph_dyn_query(
+    const float *points, int64_t points_cap, const float *centers,
+    int64_t centers_cap, const int32_t *n_centers_dev, double radius,
+    const double *scale3_host, void *workspace, size_t workspace_bytes,
+    int32_t *edges, int64_t edge_capacity, int32_t *n_edges_dev,
+    void *stream_) {
+  PGNN_GUARD_BEGIN
+  return radius_dyn_query(points, points_cap, centers, centers_cap,
+                          n_centers_dev, radius, scale3_host, workspace,
+                          workspace_bytes, edges, edge_capacity, n_edges_dev,
+                          (hipStream_t)stream_);
+  PGNN_GUARD_END
+}
+
+extern "C" int pgnn_radius_graph_dyn_query_f64(
+    const double *points, int64_t points_cap, const double *centers,
+    int64_t centers_cap, const int32_t *n_centers_dev, double radius,
+    const double *scale3_host, void *workspace, size_t workspace_bytes,
+    int32_t *edges, int64_t edge_capacity, int32_t *n_edges_dev,
+    void *stream_) {
+  PGNN_GUARD_BEGIN
+  return radius_dyn_query(points, points_cap, centers, centers_cap,
+                          n_centers_dev, radius, scale3_host, workspace,
+                          workspace_bytes, edges, edge_capacity, n_edges_dev,
+                          (hipStream_t)stream_);
+  PGNN_GUARD_END
+}
+
+namespace {
+// Both stages in order on one stream.  The arguments are checked for BOTH
+// stages before anything is enqueued.
+template <typename T>
+int radius_dyn_both(const T *points, int64_t points_cap,
+                    const int32_t *n_points_dev, const T *centers,
+                    int64_t centers_cap, const int32_t *n_centers_dev,
+                    double radius, const double *scale3_host, void *workspace,
+                    size_t workspace_bytes, int32_t *edges,
+                    int64_t edge_capacity, int32_t *n_edges_dev,
+                    hipStream_t stream) {
+  PGNN_REQUIRE(points_cap >= 0 && centers_cap >= 0 && radius > 0.0 &&
+                   edge_capacity >= 0 && edge_capacity <= 0x7fffffff &&
+                   n_edges_dev,
+               PGNN_E_INVALID, "radius_graph_dyn: bad argument");
+  PGNN_REQUIRE((points_cap == 0 || points) && (centers_cap == 0 || centers) &&
+                   (edge_capacity == 0 || edges),
+               PGNN_E_INVALID, "radius_graph_dyn: null pointer");
+  int rc = radius_dyn_grid(points, points_cap, n_points_dev, centers_cap,
+                           radius, scale3_host, workspace, workspace_bytes,
+                           stream);
+  if (rc) return rc;
+  return radius_dyn_query(points, points_cap, centers, centers_cap,
+                          n_centers_dev, radius, scale3_host, workspace,
+                          workspace_bytes, edges, edge_capacity, n_edges_dev,
+                          stream);
+}
+}  // namespace
+
 extern "C" int pgnn_radius_graph_dyn(
     const float *points, int64_t points_cap, const int32_t *n_points_dev,
     const float *centers, int64_t centers_cap, const int32_t *n_centers_dev,
@@ -990,7 +1097,7 @@ extern "C" int pgnn_radius_graph_dyn(
     size_t workspace_bytes, int32_t *edges, int64_t edge_capacity,
     int32_t *n_edges_dev, void *stream_) {
   PGNN_GUARD_BEGIN
-  return radius_dyn_impl(points, points_cap, n_points_dev, centers, centers_cap,
+  return radius_dyn_both(points, points_cap, n_points_dev, centers, centers_cap,
                          n_centers_dev, radius, scale3_host, workspace,
                          workspace_bytes, edges, edge_capacity, n_edges_dev,
                          (hipStream_t)stream_);
@@ -1004,7 +1111,7 @@ extern "C" int pgnn_radius_graph_dyn_f64(
     size_t workspace_bytes, int32_t *edges, int64_t edge_capacity,
     int32_t *n_edges_dev, void *stream_) {
   PGNN_GUARD_BEGIN
-  return radius_dyn_impl(points, points_cap, n_points_dev, centers, centers_cap,
+  return radius_dyn_both(points, points_cap, n_points_dev, centers, centers_cap,
                          n_centers_dev, radius, scale3_host, workspace,
                          workspace_bytes, edges, edge_capacity, n_edges_dev,
                          (hipStream_t)stream_);
@@ -1160,6 +1267,20 @@ int keypoints_impl(const T *points, int64_t n, double voxel, bool center,
   // nearest-neighbour kernel).
   KdBuild kb;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // The join is enqueued in front of the first kernel that reads the tree
+  // (copy_total_kernel: its status word), i.e. BEHIND the voxel hashing --
+  // and on every other way out of this function: nothing may be left running
+  // on aux that `stream`'s later work does not wait for.
+  struct Joiner {
+    hipStream_t s = nullptr;
+    hipEvent_t e = nullptr;
+    void arm(hipStream_t s_, hipEvent_t e_) { s = s_; e = e_; }
+    void join() {
+      if (e) (void)hipStreamWaitEvent(s, e, 0);
+      e = nullptr;
+    }
+    ~Joiner() { join(); }
+  } joiner;
   kb.pos = nullptr;
   kb.bounds = nullptr;
   kb.status = nullptr;
@@ -1184,12 +1305,8 @@ int keypoints_impl(const T *points, int64_t n, double voxel, bool center,
       kd_stream = aux;
     }
     rc = kd_build_any(points, n, a, kb, kd_stream);
-    if (ev_join) {
-      // join even when kd_build failed half-way: nothing may be left running
-      // on aux that `stream`'s later work does not wait for
-      (void)hipEventRecord(ev_join, aux);
-      (void)hipStreamWaitEvent(stream, ev_join, 0);
-    }
+    if (ev_join) (void)hipEventRecord(ev_join, aux);
+    joiner.arm(stream, ev_join);
     if (rc) return rc;
   }
   PGNN_HIP((hipError_t)graph_fill32(omin, 0xffffffffu, 8, stream));
@@ -1218,6 +1335,7 @@ int keypoints_impl(const T *points, int64_t n, double voxel, bool center,
                      g.cell_start, g.cell_end, is_leader, centroid, members);
   rc = exclusive_scan_i32(is_leader, slot, n, scan_scratch, scan_bytes, stream);
   if (rc) return rc;
+  joiner.join();
   hipLaunchKernelGGL(copy_total_kernel, dim3(1), dim3(64), graph_lds_pad(), stream, slot + n,
                      (const int32_t *)kb.status, num_kp);
   if (center) {

@@ -193,17 +193,20 @@ class InferenceEngine(object):
         self._hints = (self._hints or graph_gen.CountHints()).update(
             shape[0], shape[1:])
 
-    def build_graph_deferred(self, xyz):
+    def build_graph_deferred(self, xyz, overlap=False):
         """build_graph in capacity form: no size is read back (graph_gen's
         `deferred_counts`).  Needs the sizes of an earlier frame as hints; the
-        first frame of an engine therefore goes through run_frame."""
+        first frame of an engine therefore goes through run_frame.
+        `overlap`: graph_gen's `overlap_build` (independent parts of the build
+        on side streams: a shorter critical path for ONE frame; a pipeline of
+        frames keeps the chip busy without it)."""
         if self._hints is None:
             raise RuntimeError("no size hints yet: run one frame through "
                                "run_frame() first")
         return self.graph_fn(xyz, deferred_counts=self._hints,
-                             **self.graph_kwargs)
+                             overlap_build=overlap, **self.graph_kwargs)
 
-    def run_frame_deferred(self, xyz, intensity):
+    def run_frame_deferred(self, xyz, intensity, overlap_build=False):
         """run_frame without a host wait: graph build and model are enqueued
         back to back, sizes stay on the device.  Returns a DeferredFrame; its
         .result() gives (logits, box_encodings)."""
@@ -214,7 +217,7 @@ class InferenceEngine(object):
             f = DeferredFrame(self, xyz, intensity, None, None, None)
             f._out = out
             return f
-        graph = self.build_graph_deferred(xyz)
+        graph = self.build_graph_deferred(xyz, overlap_build)
         coords, kps, edges = graph
         logits, boxes = self.model.predict(intensity, coords, kps, edges,
                                            is_training=False)
@@ -304,7 +307,7 @@ class InferenceEngine(object):
                 out.append(s)
         return out
 
-    def capture_frame(self, xyz, intensity):
+    def capture_frame(self, xyz, intensity, overlap_build=False):
         """Capture run_frame_deferred for clouds shaped like `xyz` /
         `intensity` into a hipGraph (see CapturedFrame).  The outputs of a
         replay live in the graph's own buffers: take `.result()` (or copy)
@@ -319,14 +322,15 @@ class InferenceEngine(object):
             # every lazily built thing (weight images, LDS attributes, CU
             # counts, counters) must exist before the capture starts
             for _ in range(2):
-                self.run_frame_deferred(xyz, intensity).result()
+                self.run_frame_deferred(xyz, intensity,
+                                        overlap_build).result()
                 self.frame_shapes.pop()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         xs, fs = xyz.clone(), intensity.clone()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=side):
-            frame = self.run_frame_deferred(xs, fs)
+            frame = self.run_frame_deferred(xs, fs, overlap_build)
         torch.cuda.synchronize()
         return CapturedFrame(self, graph, side, xs, fs, frame)
 

@@ -255,25 +255,65 @@ def radius_graph_dyn_device(points, centers, radius, scale, edge_cap,
     `n_edges_out` is the int32 [2] device slice that receives (rows written,
     rows required).  Returns the [edge_cap, 2] edge tensor tagged with its
     count."""
-    lib = _lib.load()
-    dev = points.device
     cp, cc = _lib.count_of(points), _lib.count_of(centers)
-    points, centers, wide = _same_precision(points, centers)
-    n_p, n_c = int(points.shape[0]), int(centers.shape[0])
-    ws_bytes = lib.pgnn_radius_graph_dyn_workspace_bytes(n_p, n_c)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    edges = torch.empty((int(edge_cap), 2), dtype=torch.int32, device=dev)
-    keep, sp = _scale3(scale)
-    _lib.check((lib.pgnn_radius_graph_dyn_f64 if wide else
-                lib.pgnn_radius_graph_dyn)(
-        _lib.ptr(points), n_p, _lib.ptr(cp.dev if cp else None),
-        _lib.ptr(centers), n_c, _lib.ptr(cc.dev if cc else None),
-        float(radius), sp, _lib.ptr(ws), ws_bytes, _lib.ptr(edges),
-        int(edge_cap), _lib.ptr(n_edges_out), _lib.stream_ptr()),
-        "pgnn_radius_graph_dyn")
-    del keep
-    edges._pgnn_sorted = 1
-    return _lib.tag_count(edges, _lib.DeviceCount(n_edges_out[0:1], edge_hint))
+    points, centers, _ = _same_precision(points, centers)
+    job = _RadiusDynJob(points, cp, int(centers.shape[0]), radius, scale,
+                        edge_cap, n_edges_out, edge_hint)
+    job.grid()
+    return job.query(centers, cc)
+
+
+class _RadiusDynJob(object):
+    """One capacity-form radius graph in its two stages
+    (pgnn_radius_graph_dyn_grid / _query).  Every buffer is allocated here, on
+    the stream current at construction; grid() and query() enqueue on the
+    stream current at THEIR call, so a caller can put the grid stage -- which
+    needs the points only -- on a side stream while the centres are still
+    being computed.  `points` and the later `centers` must have one dtype."""
+
+    def __init__(self, points, points_count, centers_cap, radius, scale,
+                 edge_cap, n_edges_out, edge_hint=0):
+        self.lib = _lib.load()
+        self.points, self.cp = points, points_count
+        self.wide = points.dtype == torch.float64
+        self.n_p = int(points.shape[0])
+        self.n_c = int(centers_cap)
+        self.radius = float(radius)
+        self.keep, self.sp = _scale3(scale)
+        dev = points.device
+        self.ws_bytes = self.lib.pgnn_radius_graph_dyn_workspace_bytes(
+            self.n_p, self.n_c)
+        self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
+        self.edge_cap = int(edge_cap)
+        self.edges = torch.empty((self.edge_cap, 2), dtype=torch.int32,
+                                 device=dev)
+        self.n_edges_out = n_edges_out
+        self.edge_hint = edge_hint
+
+    def grid(self):
+        _lib.check((self.lib.pgnn_radius_graph_dyn_grid_f64 if self.wide else
+                    self.lib.pgnn_radius_graph_dyn_grid)(
+            _lib.ptr(self.points), self.n_p,
+            _lib.ptr(self.cp.dev if self.cp else None), self.n_c, self.radius,
+            self.sp, _lib.ptr(self.ws), self.ws_bytes, _lib.stream_ptr()),
+            "pgnn_radius_graph_dyn_grid")
+
+    def query(self, centers, centers_count):
+        if centers.dtype != self.points.dtype or \
+                int(centers.shape[0]) != self.n_c:
+            raise ValueError("radius graph: centres do not match the job")
+        _lib.check((self.lib.pgnn_radius_graph_dyn_query_f64 if self.wide else
+                    self.lib.pgnn_radius_graph_dyn_query)(
+            _lib.ptr(self.points), self.n_p, _lib.ptr(centers), self.n_c,
+            _lib.ptr(centers_count.dev if centers_count else None),
+            self.radius, self.sp, _lib.ptr(self.ws), self.ws_bytes,
+            _lib.ptr(self.edges), self.edge_cap, _lib.ptr(self.n_edges_out),
+            _lib.stream_ptr()),
+            "pgnn_radius_graph_dyn_query")
+        self.edges._pgnn_sorted = 1
+        return _lib.tag_count(
+            self.edges,
+            _lib.DeviceCount(self.n_edges_out[0:1], self.edge_hint))
 
 
 def gen_disjointed_rnn_local_graph_v3(
@@ -312,6 +352,32 @@ def _identity_indices(n, dev):
         torch.cuda.current_stream(dev).synchronize()
         _IDENTITY[dev.index] = ramp
     return ramp[:n].reshape(-1, 1)
+
+
+_OVERLAP = {}
+
+
+class _OverlapSet(object):
+    """The side stream and the four events of an overlapped graph build, per
+    (device, main stream): made once, re-recorded every frame (creating and
+    destroying events per frame is not free in the HIP runtime)."""
+
+    def __init__(self, dev):
+        # streams on hardware queues of their own: two streams that HIP put
+        # on one queue run strictly in turn (engine.concurrent_streams probes
+        # for that once per main stream)
+        from .engine import concurrent_streams
+        self.side, self.aux = concurrent_streams(2, dev)
+        self.fork, self.grid, self.kp, self.join = (
+            torch.cuda.Event() for _ in range(4))
+
+
+def _overlap_set(dev):
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    o = _OVERLAP.get(key)
+    if o is None:
+        o = _OVERLAP[key] = _OverlapSet(dev)
+    return o
 
 
 def _aux_stream(dev):
@@ -365,8 +431,10 @@ def keypoints_device(points, voxel_size, method='center', jitter=None, seed=0,
             # aux_stream, _aux_stream below) bought 0.1 ms of latency when the
             # replica was slower; measured equal since (0.97 vs 1.00 ms, 284 vs
             # 282 frames/s), so the simpler order is the default.
-            ctypes.c_void_p(_aux_stream(dev).cuda_stream if fork_kdtree
-                            else 0)),
+            ctypes.c_void_p(0 if not fork_kdtree else
+                            fork_kdtree.cuda_stream
+                            if isinstance(fork_kdtree, torch.cuda.Stream)
+                            else _aux_stream(dev).cuda_stream)),
             "pgnn_voxel_keypoints_center")
     elif method == 'random':
         jit = None
@@ -437,7 +505,8 @@ def kdtree_replica(points):
 
 
 def _multi_layer_downsampling(points_xyz, base_voxel_size, levels, add_rnd3d,
-                              method, num_out=None, k_hint=0):
+                              method, num_out=None, k_hint=0,
+                              fork_kdtree=False):
     p, was_np = _to_dev(points_xyz)
     coords = [p]
     kp_list = []
@@ -463,6 +532,7 @@ def _multi_layer_downsampling(points_xyz, base_voxel_size, levels, add_rnd3d,
                     raise NotImplementedError(
                         "add_rnd3d with downsample_method='center'")
                 c, i = keypoints_device(base, voxel, 'center',
+                                        fork_kdtree=fork_kdtree,
                                         num_out=num_out, k_hint=k_hint)
             else:
                 jitter = None
@@ -501,7 +571,7 @@ def multi_layer_downsampling_random(points_xyz, base_voxel_size, levels=[1],
 
 def gen_multi_level_local_graph_v3(points_xyz, base_voxel_size, level_configs,
                                    add_rnd3d=False, downsample_method='center',
-                                   deferred_counts=None):
+                                   deferred_counts=None, overlap_build=False):
     """graph_gen.py:155-195.  Returns (vertex_coord_list,
     keypoint_indices_list, edges_list).
 
@@ -512,7 +582,12 @@ def gen_multi_level_local_graph_v3(points_xyz, base_voxel_size, level_configs,
     lists then hold capacity-sized tensors tagged with their device-side
     counts (`_lib.count_of`), which the operators of pointgnn_amd.gnn accept
     as they are; `edges_list[0]._pgnn_count.frame` is the FrameCounts record
-    the caller reads (once) when it takes the frame's results."""
+    the caller reads (once) when it takes the frame's results.
+    `overlap_build` (with deferred_counts): issue the parts of the build that
+    do not depend on each other on side streams (level-0 cell grid and kd-tree
+    replica beside the voxel hash, level-0 queries beside the level-1 graph),
+    joined back into the current stream before returning -- the same kernels
+    and results, a shorter critical path for a single frame."""
     if isinstance(base_voxel_size, list):
         base_voxel_size = np.array(base_voxel_size)
     scales = [cfg['graph_scale'] for cfg in level_configs]
@@ -521,7 +596,7 @@ def gen_multi_level_local_graph_v3(points_xyz, base_voxel_size, level_configs,
     if deferred_counts is not None:
         return _multi_level_graph_deferred(
             points_xyz, base_voxel_size, level_configs, scales, add_rnd3d,
-            downsample_method, deferred_counts)
+            downsample_method, deferred_counts, overlap_build)
     coords, kps, was_np = _multi_layer_downsampling(
         points_xyz, base_voxel_size, scales, add_rnd3d, downsample_method)
     edges_list = []
@@ -551,7 +626,8 @@ def gen_multi_level_local_graph_v3(points_xyz, base_voxel_size, level_configs,
 
 
 def _multi_level_graph_deferred(points_xyz, base_voxel_size, level_configs,
-                                scales, add_rnd3d, downsample_method, hints):
+                                scales, add_rnd3d, downsample_method, hints,
+                                overlap=False):
     if not isinstance(points_xyz, torch.Tensor):
         raise ValueError("deferred_counts needs device tensors (a NumPy "
                          "result has to know its size)")
@@ -566,22 +642,72 @@ def _multi_level_graph_deferred(points_xyz, base_voxel_size, level_configs,
     counts = torch.zeros(2 + 2 * n_levels, dtype=torch.int32, device=dev)
     caps = [hints.cap(l) for l in range(n_levels)]
     frame = FrameCounts(counts, caps)
+
+    def level_job(l, points, centers_cap):
+        kw = level_configs[l]['graph_gen_kwargs']
+        return _RadiusDynJob(points, _lib.count_of(points), centers_cap,
+                             kw['radius'], kw.get('scale'), caps[l],
+                             counts[2 + 2 * l:4 + 2 * l], hints.edge_hint(l))
+
+    # Overlapped build (single-frame latency): the level-0 cell grid needs
+    # the cloud only, so it runs on a side stream BESIDE the keypoint
+    # selection (whose kd-tree replica forks onto a third stream); afterwards
+    # level 0's queries (this stream) run beside the whole level-1 graph (side
+    # stream).  Same kernels, same buffers, same results; every buffer is
+    # allocated on this stream and the side stream is joined back before the
+    # function returns, so the caching allocator's stream rule holds.
+    p = _to_dev(points_xyz)[0]
+    n = int(p.shape[0])
+    overlap = bool(overlap) and n > 0 and p.dtype == torch.float32 and \
+        n_levels >= 1 and level_configs[0]['graph_level'] == 0 and \
+        not np.isclose(scales[0], 0)
+    job0 = ov = None
+    if overlap:
+        ov = _overlap_set(dev)
+        job0 = level_job(0, p, n)      # keypoint capacity = n rows
+        ov.fork.record()
+    # (the keypoint call comes first: its kd-tree replica is the longest
+    # chain of the build and should be the first thing the device sees)
     coords, kps, _ = _multi_layer_downsampling(
-        points_xyz, base_voxel_size, scales, add_rnd3d, downsample_method,
-        num_out=counts[0:2], k_hint=hints.k)
+        p, base_voxel_size, scales, add_rnd3d, downsample_method,
+        num_out=counts[0:2], k_hint=hints.k,
+        fork_kdtree=ov.aux if overlap else False)
+    if overlap:
+        ov.side.wait_event(ov.fork)
+        with torch.cuda.stream(ov.side):
+            job0.grid()
+            ov.grid.record()
     for t in list(coords) + list(kps):
         c = _lib.count_of(t)
         if c is not None:
             c.frame = frame
-    edges_list = []
-    for l, cfg in enumerate(level_configs):
-        lvl = cfg['graph_level']
-        e = radius_graph_dyn_device(
-            coords[lvl], coords[lvl + 1], cfg['graph_gen_kwargs']['radius'],
-            cfg['graph_gen_kwargs'].get('scale'), caps[l],
-            counts[2 + 2 * l:4 + 2 * l], hints.edge_hint(l))
+    edges_list = [None] * n_levels
+    side_jobs = []
+    if overlap:
+        ov.kp.record()
+        for l in range(1, n_levels):   # allocate on this stream ...
+            lvl = level_configs[l]['graph_level']
+            pts, ctr = coords[lvl], coords[lvl + 1]
+            side_jobs.append((l, level_job(l, pts, int(ctr.shape[0])), ctr))
+        ov.side.wait_event(ov.kp)
+        with torch.cuda.stream(ov.side):   # ... enqueue on the side stream
+            for l, job, ctr in side_jobs:
+                job.grid()
+                edges_list[l] = job.query(ctr, _lib.count_of(ctr))
+            ov.join.record()
+        torch.cuda.current_stream(dev).wait_event(ov.grid)
+        edges_list[0] = job0.query(coords[1], _lib.count_of(coords[1]))
+        torch.cuda.current_stream(dev).wait_event(ov.join)
+    else:
+        for l, cfg in enumerate(level_configs):
+            lvl = cfg['graph_level']
+            edges_list[l] = radius_graph_dyn_device(
+                coords[lvl], coords[lvl + 1], cfg['graph_gen_kwargs']['radius'],
+                cfg['graph_gen_kwargs'].get('scale'), caps[l],
+                counts[2 + 2 * l:4 + 2 * l], hints.edge_hint(l))
+    for e in edges_list:
         _lib.count_of(e).frame = frame
-        edges_list.append(e)
+    # job0 / side_jobs (their workspaces) die here: after the join was enqueued
     return coords, kps, edges_list
 
 

@@ -82,12 +82,15 @@ def test_radius_graph_dyn_empty_and_zero_counts(dev):
     assert counts[2:4].tolist() == [0, 0]
 
 
+@pytest.mark.parametrize("overlap", [False, True])
 @pytest.mark.parametrize("cfg_name,preset", [
     ("car", "small"), ("car", "car"), ("ped", "small")])
-def test_deferred_graph_equals_host_sized_graph(dev, cfg_name, preset):
+def test_deferred_graph_equals_host_sized_graph(dev, cfg_name, preset,
+                                                overlap):
     """gen_multi_level_local_graph_v3(deferred_counts=...) == the host-sized
     call: same keypoints in the same order, same edge rows in the same
-    order."""
+    order -- also with the independent parts of the build on side streams
+    (overlap_build)."""
     import torch
     from pointgnn_amd import _lib, graph_gen as G
     cfg = configs.car_auto_config(3) if cfg_name == "car" else \
@@ -104,7 +107,7 @@ def test_deferred_graph_equals_host_sized_graph(dev, cfg_name, preset):
         if trial == 2:
             hints.k, hints.edges = 10 * k, [10 ** 8, 10 ** 8]
         c2, k2, e2 = G.gen_multi_level_local_graph_v3(
-            x, deferred_counts=hints, **kw)
+            x, deferred_counts=hints, overlap_build=overlap, **kw)
         frame = _lib.count_of(e2[0]).frame
         assert frame.k == k and frame.kd_status == 0
         assert frame.edges == [int(e.shape[0]) for e in edges]
@@ -151,6 +154,79 @@ def test_deferred_frame_is_bit_identical(dev, cfg_name, preset, hint_scale):
     assert lg2.shape == lg.shape and bx2.shape == bx.shape
     assert torch.isfinite(lg2).all()
     assert torch.equal(lg, lg2) and torch.equal(bx, bx2)
+
+
+@pytest.mark.parametrize("cfg_name,preset", [
+    ("car", "car"), ("ped", "car"), ("car", "small")])
+def test_overlapped_build_frames_are_bit_identical(dev, cfg_name, preset):
+    """run_frame_deferred(overlap_build=True): several frames enqueued back to
+    back on a non-default stream with nothing waited for in between (the side
+    streams, their events and the allocator's blocks are reused from frame to
+    frame) give the host-sized frames' logits and boxes, bit for bit; an
+    overflowing level is still detected and rebuilt."""
+    import torch
+    from pointgnn_amd import graph_gen as G
+    from pointgnn_amd.engine import InferenceEngine
+    cfg = configs.car_auto_config(3) if cfg_name == "car" else \
+        configs.ped_cyl_auto_config(3)
+    params = weights.init_params(cfg, seed=4, bias_scale=0.05)
+    eng = InferenceEngine(cfg, params, device=dev)
+    clouds = []
+    for seed in (1, 2, 3, 4):
+        xyz, inten = synthetic_cloud(seed=seed, preset=preset)
+        clouds.append((T(xyz, dev), T(inten, dev)))
+    want = [eng.run_frame(x, f) for x, f in clouds]
+    shapes = list(eng.frame_shapes[-4:])
+    torch.cuda.synchronize()
+    stream = torch.cuda.Stream()
+    stream.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(stream):
+        for rep in range(2):
+            frames = [eng.run_frame_deferred(x, f, overlap_build=True)
+                      for x, f in clouds]
+            assert all(d.counts._host is None for d in frames)
+            got = [d.result() for d in frames]
+            for (lg, bx), (lg2, bx2) in zip(want, got):
+                assert torch.equal(lg, lg2) and torch.equal(bx, bx2)
+        assert eng.deferred_overflows == 0
+        k, e0, e1 = shapes[0]
+        eng._hints = G.CountHints(k, [e0, e1], [e0 // 2, e1 + 10])
+        d = eng.run_frame_deferred(*clouds[0], overlap_build=True)
+        assert d.counts.overflowed == [0]
+        lg2, bx2 = d.result()
+        assert eng.deferred_overflows == 1
+        assert torch.equal(want[0][0], lg2) and torch.equal(want[0][1], bx2)
+    torch.cuda.synchronize()
+
+
+def test_radius_graph_stages_on_two_streams(dev):
+    """pgnn_radius_graph_dyn_grid on one stream while the centres are still
+    being produced on another, _query after both: the rows of
+    pgnn_radius_graph_dyn."""
+    import torch
+    from pointgnn_amd import graph_gen as G
+    rng = np.random.RandomState(5)
+    pts = T((rng.rand(6000, 3) * 20).astype(np.float32), dev)
+    src = T((rng.rand(900, 3) * 20).astype(np.float32), dev)
+    counts = torch.zeros(4, dtype=torch.int32, device=dev)
+    want = G.radius_graph_dyn_device(pts, src * 1.0, 1.5, None, 200000,
+                                     counts[0:2])
+    n_want = int(counts[0].item())
+    assert 0 < n_want < 200000
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    ev = torch.cuda.Event()
+    job = G._RadiusDynJob(pts, None, 900, 1.5, None, 200000, counts[2:4])
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        job.grid()
+        ev.record()
+    ctr = src * 1.0                      # produced on the main stream
+    torch.cuda.current_stream().wait_event(ev)
+    got = job.query(ctr, None)
+    torch.cuda.synchronize()
+    assert counts.tolist() == [n_want, n_want, n_want, n_want]
+    assert torch.equal(want[:n_want], got[:n_want])
 
 
 def test_deferred_overflow_is_detected_and_rebuilt(dev):

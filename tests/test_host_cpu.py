@@ -244,6 +244,14 @@ def test_capacity_form_host_logic():
         lib.pgnn_radius_graph_workspace_bytes(20000, 20000)
     assert lib.pgnn_radius_graph_dyn(None, 10, None, None, 10, None, 1.0, None,
                                      None, 0, None, 100, None, None) == -1
+    # ... and so do its two stages (grid: points only; query: centres too)
+    assert lib.pgnn_radius_graph_dyn_grid(None, 10, None, 10, 1.0, None, None,
+                                          0, None) == -1
+    assert lib.pgnn_radius_graph_dyn_grid(None, 0, None, 0, -1.0, None, None,
+                                          0, None) == -1
+    assert lib.pgnn_radius_graph_dyn_query(None, 0, None, 10, None, 1.0, None,
+                                           None, 0, None, 100, None,
+                                           None) == -1
     assert lib.pgnn_mlp_fwd_dyn(None, 0, 4, None, 0, 0, 16, None, 1, None, 0,
                                 None, 0, None, None) == -1   # null count
     assert b"count" in lib.pgnn_last_error()
