@@ -47,6 +47,17 @@ __device__ __forceinline__ int cell_of(double v, double origin, double cell) {
   return (int)floor((v - origin) / cell);
 }
 
+// The radius graphs' own cell grid (anchored at 0, edge = r): the cell of a
+// coordinate is floor(v * (1 / r)).  Which cell a point near a face lands in
+// is immaterial -- candidates are accepted by the exact float64 distance --
+// as long as the build and the queries use this one function (a candidate of
+// another cell sharing the bucket is told apart by it) and it is monotone in
+// v (every point of [c - rr, c + rr] then lies in the box the query scans);
+// a multiplication is both, and costs a tenth of the float64 division.
+__device__ __forceinline__ int rcell_of(double v, double inv_cell) {
+  return (int)floor(v * inv_cell);
+}
+
 // NumPy's floor_divide for floating point (npy_divmod in
 // numpy/core/src/npymath/npy_math_internal.h.src), divisor > 0: the exact
 // floor of a / b for the given operands -- fmod is exact, so unlike
@@ -134,6 +145,7 @@ __global__ void cell_keys_kernel(const T *__restrict__ pts, int64_t n,
   // n_dev (nullable): the point count when only the device knows it (the
   // keypoints of this frame); n is then the capacity the grid is sized for
   if (n_dev) n = *n_dev < n ? *n_dev : n;
+  const double inv_cell = 1.0 / cell;  // radius grids (rcell_of)
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * blockDim.x) {
     double x, y, z;
@@ -149,8 +161,8 @@ __global__ void cell_keys_kernel(const T *__restrict__ pts, int64_t n,
       vcell[3 * i + 1] = vy;
       vcell[3 * i + 2] = vz;
     } else {
-      keys[i] = cell_hash(cell_of(x, ox, cell), cell_of(y, oy, cell),
-                          cell_of(z, oz, cell), mask);
+      keys[i] = cell_hash(rcell_of(x - ox, inv_cell), rcell_of(y - oy, inv_cell),
+                          rcell_of(z - oz, inv_cell), mask);
     }
     vals[i] = (uint32_t)i;
   }
@@ -221,8 +233,9 @@ __global__ __launch_bounds__(1024) void radius_query_kernel(
     // capacity form: n_centers is the capacity, the count is on the device
     n_centers = *n_centers_dev < cap ? *n_centers_dev : cap;
   const double r2 = r * r;
+  const double inv_r = 1.0 / r;  // as in cell_keys_kernel
   // cells that can hold a point within r: widen by a relative 1e-9 so that
-  // rounding in (v - origin) / cell can never exclude a true neighbour
+  // rounding in c -/+ r can never exclude a true neighbour
   const double rr = r * (1.0 + 1e-9) + 1e-300;
   for (int64_t q = wave0; q < cap; q += n_waves) {
     if (q >= n_centers) {
@@ -233,9 +246,9 @@ __global__ __launch_bounds__(1024) void radius_query_kernel(
     }
     double cx, cy, cz;
     load_point(centers, q, sc, cx, cy, cz);
-    const int x0 = cell_of(cx - rr, 0.0, r), x1 = cell_of(cx + rr, 0.0, r);
-    const int y0 = cell_of(cy - rr, 0.0, r), y1 = cell_of(cy + rr, 0.0, r);
-    const int z0 = cell_of(cz - rr, 0.0, r), z1 = cell_of(cz + rr, 0.0, r);
+    const int x0 = rcell_of(cx - rr, inv_r), x1 = rcell_of(cx + rr, inv_r);
+    const int y0 = rcell_of(cy - rr, inv_r), y1 = rcell_of(cy + rr, inv_r);
+    const int z0 = rcell_of(cz - rr, inv_r), z1 = rcell_of(cz + rr, inv_r);
     const int nx = x1 - x0 + 1, ny = y1 - y0 + 1, nz = z1 - z0 + 1;
     const int n_cells = nx * ny * nz;  // <= 64 (see above)
     // lane c: cell c of the box in (z, y, x) order
@@ -257,49 +270,71 @@ __global__ __launch_bounds__(1024) void radius_query_kernel(
     const int total_cand = __shfl(incl, 63);
     int64_t out_pos = FILL ? (int64_t)offsets[q] : 0;
     int total = 0;
-    for (int j0 = 0; j0 < total_cand; j0 += 64) {
-      // every lane runs the search and the shuffles (a shuffle may only read
-      // lanes that execute it); lanes past the end repeat the last candidate
-      // and skip the load
-      const bool valid = j0 + lane < total_cand;
-      const int j = valid ? j0 + lane : total_cand - 1;
-      // the cell whose candidate range holds j: first lane with incl > j
-      int lo = 0, hi = n_cells - 1;
+    // Two chunks of 64 candidates per round: their searches and loads are
+    // independent, so the second point load is in flight while the first is
+    // being waited for (the round is one memory round trip either way, and a
+    // centre next to the sensor has 20-30 chunks).  The loads carry no
+    // predicate: a lane past the end re-reads the last candidate (always a
+    // real one) and is masked at `hit` -- a load under a predicate is waited
+    // for on the spot.  Rows leave in candidate order as before.
+    for (int j0 = 0; j0 < total_cand; j0 += 128) {
+      const bool two = j0 + 64 < total_cand;  // wave-uniform
+      bool valid[2];
+      int ix[2], iy[2], iz[2];
+      SortedPoint sp[2];
 #pragma unroll
-      for (int step = 0; step < 6; ++step) {
-        const int mid = (lo + hi) >> 1;
-        const int v = __shfl(incl, mid);
-        if (v > j) hi = mid; else lo = mid + 1;
+      for (int u = 0; u < 2; ++u) {
+        if (u == 1 && !two) break;
+        // every lane runs the search and the shuffles (a shuffle may only
+        // read lanes that execute it)
+        valid[u] = j0 + 64 * u + lane < total_cand;
+        const int j = valid[u] ? j0 + 64 * u + lane : total_cand - 1;
+        // the cell whose candidate range holds j: first lane with incl > j
+        int lo = 0, hi = n_cells - 1;
+#pragma unroll
+        for (int step = 0; step < 6; ++step) {
+          const int mid = (lo + hi) >> 1;
+          const int v = __shfl(incl, mid);
+          if (v > j) hi = mid; else lo = mid + 1;
+        }
+        const int c = lo < n_cells ? lo : n_cells - 1;
+        const int c_incl = __shfl(incl, c), c_cnt = __shfl(my_cnt, c);
+        const int c_s = __shfl(my_s, c);
+        ix[u] = __shfl(my_ix, c);
+        iy[u] = __shfl(my_iy, c);
+        iz[u] = __shfl(my_iz, c);
+        sp[u] = sorted[c_s + (j - (c_incl - c_cnt))];
       }
-      const int c = lo < n_cells ? lo : n_cells - 1;
-      const int c_incl = __shfl(incl, c), c_cnt = __shfl(my_cnt, c);
-      const int c_s = __shfl(my_s, c);
-      const int ix = __shfl(my_ix, c), iy = __shfl(my_iy, c),
-                iz = __shfl(my_iz, c);
-      bool hit = false;
-      int pidx = 0;
-      if (valid) {
-        const SortedPoint sp = sorted[c_s + (j - (c_incl - c_cnt))];
-        pidx = sp.idx;
-        if (cell_of(sp.x, 0.0, r) == ix && cell_of(sp.y, 0.0, r) == iy &&
-            cell_of(sp.z, 0.0, r) == iz) {
-          const double dx = sp.x - cx, dy = sp.y - cy, dz = sp.z - cz;
+      unsigned long long m[2] = {0ull, 0ull};
+      bool hit[2] = {false, false};
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (u == 1 && !two) break;
+        if (valid[u] && rcell_of(sp[u].x, inv_r) == ix[u] &&
+            rcell_of(sp[u].y, inv_r) == iy[u] &&
+            rcell_of(sp[u].z, inv_r) == iz[u]) {
+          const double dx = sp[u].x - cx, dy = sp[u].y - cy,
+                       dz = sp[u].z - cz;
           const double d2 = (dx * dx + dy * dy) + dz * dz;
-          hit = d2 <= r2;
+          hit[u] = d2 <= r2;
         }
+        m[u] = __ballot(hit[u]);
       }
-      const unsigned long long m = __ballot(hit);
       if (FILL) {
-        if (hit) {
-          const int64_t pos = out_pos + __popcll(m & ((1ull << lane) - 1ull));
-          if (pos < capacity) {
-            edges[2 * pos] = pidx;
-            edges[2 * pos + 1] = (int32_t)q;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          if (hit[u]) {
+            const int64_t pos =
+                out_pos + __popcll(m[u] & ((1ull << lane) - 1ull));
+            if (pos < capacity) {
+              edges[2 * pos] = sp[u].idx;
+              edges[2 * pos + 1] = (int32_t)q;
+            }
           }
+          out_pos += __popcll(m[u]);
         }
-        out_pos += __popcll(m);
       } else {
-        total += __popcll(m);
+        total += __popcll(m[0]) + __popcll(m[1]);
       }
     }
     if (!FILL && lane == 0) counts[q] = total;
