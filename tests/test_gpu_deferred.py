@@ -339,9 +339,11 @@ def test_deferred_frame_on_degenerate_clouds(dev, n_points):
     assert torch.equal(lg, lg2) and torch.equal(bx, bx2)
 
 
-@pytest.mark.parametrize("cfg_name", ["car", "ped"])
-def test_captured_frame_replays_bit_identically(dev, cfg_name):
-    """A whole frame in ONE hipGraph (engine.capture_frame): replays give the
+@pytest.mark.parametrize("cfg_name,overlap", [
+    ("car", False), ("ped", False), ("car", True)])
+def test_captured_frame_replays_bit_identically(dev, cfg_name, overlap):
+    """A whole frame in ONE hipGraph (engine.capture_frame; `overlap`: with the
+    graph build's side streams as branches of the graph): replays give the
     eager results bit for bit, for the captured cloud and for other clouds of
     the same point count (K and the edge counts differ: they live on the
     device), replay after replay (ped_cyl: the LDS-tile pooling kernel's tile
@@ -360,7 +362,7 @@ def test_captured_frame_replays_bit_identically(dev, cfg_name):
     eager = [eng.run_frame(x, f) for x, f in clouds]
     shapes = list(eng.frame_shapes)
     assert len({sh[0] for sh in shapes}) > 1       # different K per cloud
-    cap = eng.capture_frame(*clouds[0])
+    cap = eng.capture_frame(*clouds[0], overlap_build=overlap)
     for rep in range(3):
         for (x, f), (lg, bx), sh in zip(clouds, eager, shapes):
             out = cap.replay(x, f)
