@@ -509,16 +509,42 @@ __global__ void voxel_leader_kernel(const SortedPoint *__restrict__ sorted,
     }
     is_leader[i] = leader ? 1 : 0;
     if (!leader) continue;
+    // The sum must run in slot order (open3d's accumulation order), but the
+    // loads need not wait for each other: four slots' voxel indices and
+    // records are requested together, without a predicate (every j < e is a
+    // real slot), and a slot of another voxel is dropped by a select.  The
+    // launch lasts as long as its fullest voxel (next to the sensor: 50-100
+    // members), which used to be two dependent round trips per member.
     double sx = 0.0, sy = 0.0, sz = 0.0;
     int cnt = 0;
-    for (int j = (int)i; j < e; ++j) {
-      if (vc[3 * j] == vx && vc[3 * j + 1] == vy && vc[3 * j + 2] == vz) {
-        const SortedPoint o = sorted[j];
-        sx += o.x;
-        sy += o.y;
-        sz += o.z;
-        ++cnt;
+    int j = (int)i;
+    for (; j + 4 <= e; j += 4) {
+      int ax[4], ay[4], az[4];
+      SortedPoint o[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        ax[u] = vc[3 * (j + u)];
+        ay[u] = vc[3 * (j + u) + 1];
+        az[u] = vc[3 * (j + u) + 2];
+        o[u] = sorted[j + u];
       }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool m = ax[u] == vx && ay[u] == vy && az[u] == vz;
+        sx = m ? sx + o[u].x : sx;
+        sy = m ? sy + o[u].y : sy;
+        sz = m ? sz + o[u].z : sz;
+        cnt += m ? 1 : 0;
+      }
+    }
+    for (; j < e; ++j) {
+      const int ax = vc[3 * j], ay = vc[3 * j + 1], az = vc[3 * j + 2];
+      const SortedPoint o = sorted[j];
+      const bool m = ax == vx && ay == vy && az == vz;
+      sx = m ? sx + o.x : sx;
+      sy = m ? sy + o.y : sy;
+      sz = m ? sz + o.z : sz;
+      cnt += m ? 1 : 0;
     }
     centroid[3 * i] = sx / (double)cnt;
     centroid[3 * i + 1] = sy / (double)cnt;
@@ -655,16 +681,39 @@ __global__ void voxel_random_pick_kernel(
     int target = (int)((h >> 11) * (1.0 / 9007199254740992.0) * (double)cnt);
     if (target >= cnt) target = cnt - 1;
     const int e = cell_end[keys[i]];
-    int chosen = my_idx, seen = 0;
-    for (int j = (int)i; j < e; ++j) {
+    // the target-th member of the voxel in slot order; four slots' voxel
+    // indices per round trip (see voxel_leader_kernel)
+    int chosen_slot = (int)i, seen = 0;
+    bool found = false;
+    int j = (int)i;
+    for (; !found && j + 4 <= e; j += 4) {
+      int ax[4], ay[4], az[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        ax[u] = vc[3 * (j + u)];
+        ay[u] = vc[3 * (j + u) + 1];
+        az[u] = vc[3 * (j + u) + 2];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool m = !found && ax[u] == vx && ay[u] == vy && az[u] == vz;
+        if (m && seen == target) {
+          chosen_slot = j + u;
+          found = true;
+        }
+        seen += m ? 1 : 0;
+      }
+    }
+    for (; !found && j < e; ++j) {
       if (vc[3 * j] == vx && vc[3 * j + 1] == vy && vc[3 * j + 2] == vz) {
         if (seen == target) {
-          chosen = sorted[j].idx;
-          break;
+          chosen_slot = j;
+          found = true;
         }
         ++seen;
       }
     }
+    const int chosen = found ? sorted[chosen_slot].idx : my_idx;
     const int k = slot[i];
     kp_idx[k] = chosen;
     kp_xyz[3 * k] = pts[3 * (int64_t)chosen];
