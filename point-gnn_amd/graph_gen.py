@@ -427,10 +427,11 @@ def keypoints_device(points, voxel_size, method='center', jitter=None, seed=0,
             _lib.ptr(points), n, float(voxel_size), _lib.ptr(ws), ws_bytes,
             _lib.ptr(kp_idx), _lib.ptr(kp_xyz), _lib.ptr(num), st,
             # aux stream = NULL: the kd-tree replica runs on this stream.
-            # Forking it onto a side stream (pgnn_voxel_keypoints_center's
-            # aux_stream, _aux_stream below) bought 0.1 ms of latency when the
-            # replica was slower; measured equal since (0.97 vs 1.00 ms, 284 vs
-            # 282 frames/s), so the simpler order is the default.
+            # With an aux stream (fork_kdtree: True or a stream) it runs
+            # beside the voxel hashing -- 0.15 ms off a single frame's build,
+            # nothing for a pipeline of frames, whose other streams keep the
+            # chip busy anyway; the overlapped build (overlap_build) passes a
+            # stream on a hardware queue of its own.
             ctypes.c_void_p(0 if not fork_kdtree else
                             fork_kdtree.cuda_stream
                             if isinstance(fork_kdtree, torch.cuda.Stream)
