@@ -675,6 +675,10 @@ def parse_args(argv=None):
                     help="run frames strictly sequentially on one stream")
     ap.add_argument("--no-capture", action="store_true",
                     help="skip the hipGraph capture / replay latency entry")
+    ap.add_argument("--gnn-priority", type=int, default=0,
+                    help="experiment: +1 = message passing of the frame "
+                         "streams on high-priority partner streams, -1 = the "
+                         "graph builds on them")
     ap.add_argument("--no-capture-overlap", action="store_true",
                     help="skip the capture of the frame with the overlapped "
                          "graph build (side streams inside the hipGraph)")
@@ -991,7 +995,8 @@ def main(argv=None):
                 return out
             n_fs = frame_streams_for(args, engine.config_name)
             if deferred and n_fs > 0 and args.graph_cus <= 0:
-                return engine.run_frames_on_streams(fr, n_fs)[-1]
+                return engine.run_frames_on_streams(
+                    fr, n_fs, gnn_priority=args.gnn_priority)[-1]
             return engine.run_frames_pipelined(
                 fr, compute_streams=args.compute_streams,
                 graph_cus=args.graph_cus, lookahead=args.lookahead,

@@ -334,7 +334,7 @@ class InferenceEngine(object):
         torch.cuda.synchronize()
         return CapturedFrame(self, graph, side, xs, fs, frame)
 
-    def run_frames_on_streams(self, frames, n_streams=3):
+    def run_frames_on_streams(self, frames, n_streams=3, gnn_priority=False):
         """Steady-state loop in capacity form: frame i -- graph build AND
         message passing -- runs wholly on stream i % n_streams, and nothing
         is read back until every frame is enqueued.  Frames are independent
@@ -360,9 +360,46 @@ class InferenceEngine(object):
         for s in streams:
             s.wait_stream(cur)
         pending = []
-        for i, (xyz, intensity) in enumerate(frames):
-            with torch.cuda.stream(streams[i % len(streams)]):
-                pending.append(self.run_frame_deferred(xyz, intensity))
+        if gnn_priority:
+            # tested negative (tools/sessions/r03_s33.sh): frame i's
+            # graph build on stream i % n as before, its message passing on a
+            # HIGH-priority partner stream (gnn_priority < 0: the other way
+            # round).  -13 % either way: HIP's priority -1 streams share a
+            # smaller pool of hardware queues and run in turn.
+            hi = self._priority_streams(len(streams))
+            for h in hi:
+                h.wait_stream(cur)
+            for i, (xyz, intensity) in enumerate(frames):
+                b, h = streams[i % len(streams)], hi[i % len(streams)]
+                if int(gnn_priority) < 0:    # the BUILD on the high-priority one
+                    b, h = h, b
+                if self._hints is None or int(xyz.shape[0]) == 0:
+                    with torch.cuda.stream(b):
+                        pending.append(self.run_frame_deferred(xyz, intensity))
+                    continue
+                with torch.cuda.stream(b):
+                    graph = self.build_graph_deferred(xyz)
+                h.wait_stream(b)
+                coords, kps, edges = graph
+                with torch.cuda.stream(h):
+                    for t in list(coords) + list(kps) + list(edges):
+                        t.record_stream(h)     # allocated on b, read on h
+                    frame = edges[0]._pgnn_count.frame
+                    frame.tensor.record_stream(h)
+                    logits, boxes = self.model.predict(
+                        intensity, coords, kps, edges, is_training=False)
+                    # the next build on b may not overtake this frame's GNN by
+                    # more than one frame (bounded memory, as before)
+                b.wait_stream(h)
+                self.last_graph = graph
+                pending.append(DeferredFrame(self, xyz, intensity, logits,
+                                             boxes, frame))
+            for h in hi:
+                cur.wait_stream(h)
+        else:
+            for i, (xyz, intensity) in enumerate(frames):
+                with torch.cuda.stream(streams[i % len(streams)]):
+                    pending.append(self.run_frame_deferred(xyz, intensity))
         for s in streams:
             cur.wait_stream(s)
         live = [f for f in pending if f.counts is not None]
@@ -375,6 +412,16 @@ class InferenceEngine(object):
             lg.record_stream(cur)
             bx.record_stream(cur)
         return outs
+
+    def _priority_streams(self, n):
+        """n high-priority streams (HIP keeps a pool of hardware queues per
+        priority level), made once per device."""
+        key = ("hi", torch.cuda.current_device())
+        cache = self.__dict__.setdefault("_stream_sets", {})
+        have = cache.setdefault(key, [])
+        while len(have) < n:
+            have.append(torch.cuda.Stream(priority=-1))
+        return have[:n]
 
     def run_frames_pipelined(self, frames, compute_streams=1, graph_cus=0,
                              lookahead=0, deferred=False, graph_streams=1):
