@@ -11,18 +11,82 @@ reference ships no gradient fixtures).  Documented TF semantics restated:
   * gradient of tf.math.unsorted_segment_max: split equally among the rows that
     equal the segment max (torch's scatter_reduce 'amax' has the same rule);
   * slim.l1_regularizer(scale)(W) = scale * sum|W| on FC weights only.
+
+MASK-MATCHED EVALUATION (round 4).  The loss is piecewise smooth: which side
+of zero a pre-activation falls on (ReLU) and which edge row wins a segment
+maximum are DECISIONS; a float32 and a float64 forward can take a handful of
+them differently, and then single gradient entries legitimately differ.  To
+separate that from a wrong formula, `forward` / `step_gradients` take a
+`Decisions` object: in record mode it notes every decision the float64 forward
+takes; in replay mode it applies decisions supplied from outside (the
+device's: y > 0 of its saved activations, row == segment max of its saved
+rows) -- ReLU becomes a multiplication by the given 0/1 mask and segment-max
+the mean of the given winner rows (TF's equal split among ties) -- so the
+float64 gradient is that of the SAME smooth piece the device differentiated.
+Decision order: the order `forward` reaches them (per stage: [auto-offset
+ReLUs], per-edge MLP ReLUs, the segment max, update/output MLP ReLUs; then
+cls head, then each loc head).
 Only tests/ may import this module.
 """
 import numpy as np
 import torch
 
 
-def _mlp(x, params, scope, n_layers, is_logits):
+class Decisions(object):
+    """Recorder / replayer of the forward's non-smooth choices (see header).
+    `supplied`: list of boolean arrays in decision order, or None to record.
+    After a forward: `.taken` = the list of masks used, `.own` = the masks the
+    float64 values themselves would have chosen (for counting flips)."""
+
+    def __init__(self, supplied=None):
+        self.supplied = list(supplied) if supplied is not None else None
+        self.pos = 0
+        self.taken, self.own = [], []
+
+    def _next(self, own):
+        own = np.asarray(own)
+        self.own.append(own)
+        if self.supplied is None:
+            self.taken.append(own)
+            return None
+        m = np.asarray(self.supplied[self.pos]).astype(bool)
+        assert m.shape == own.shape, "decision %d: mask %s, site %s" % (
+            self.pos, m.shape, own.shape)
+        self.pos += 1
+        self.taken.append(m)
+        return m
+
+    def relu(self, x):
+        m = self._next((x.detach() > 0).numpy())
+        if m is None:
+            return torch.relu(x)
+        return x * torch.as_tensor(m, dtype=x.dtype)
+
+    def segment_max(self, data, seg, num):
+        plain = _segment_max(data, seg, num)
+        m = self._next((data.detach() == plain.detach()[seg]).numpy())
+        if m is None:
+            return plain
+        w = torch.as_tensor(m, dtype=data.dtype)
+        idx = seg.reshape(-1, 1).expand(-1, data.shape[1])
+        cnt = torch.zeros((num, data.shape[1]), dtype=data.dtype)
+        cnt = cnt.scatter_add(0, idx, w)
+        tot = torch.zeros((num, data.shape[1]), dtype=data.dtype)
+        tot = tot.scatter_add(0, idx, data * w)
+        return tot / torch.clamp(cnt, min=1.0)
+
+    def flips(self):
+        """Per decision site: number of entries where the float64 forward's
+        own choice differs from the one applied."""
+        return [int((a != b).sum()) for a, b in zip(self.own, self.taken)]
+
+
+def _mlp(x, params, scope, n_layers, is_logits, dec=None):
     for i in range(n_layers):
         name = scope + '/fully_connected' + ('' if i == 0 else '_%d' % i)
         x = x @ params[name + '/weights'] + params[name + '/biases']
         if not (is_logits and i == n_layers - 1):
-            x = torch.relu(x)
+            x = torch.relu(x) if dec is None else dec.relu(x)
     return x
 
 
@@ -32,8 +96,11 @@ def _segment_max(data, seg, num):
     return out.scatter_reduce(0, idx, data, 'amax', include_self=True)
 
 
-def forward(params, config, input_v, coords, kps, edges, dtype=torch.float64):
+def forward(params, config, input_v, coords, kps, edges, dtype=torch.float64,
+            decisions=None):
     """params: {name: torch float64 tensor (requires_grad)}."""
+    dec = decisions
+    smax = _segment_max if dec is None else dec.segment_max
     t64 = lambda a: torch.as_tensor(np.asarray(a), dtype=dtype)
     i64 = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.int64)
     feats = t64(input_v)
@@ -47,26 +114,27 @@ def forward(params, config, input_v, coords, kps, edges, dtype=torch.float64):
             x = coords[lvl]
             f = torch.cat([feats[src], x[src] - x[kp[dst]]], dim=1)
             f = _mlp(f, params, scope + '/extract_vertex_features',
-                     len(kw['point_MLP_depth_list']), False)
-            agg = _segment_max(f, dst, kp.shape[0])
+                     len(kw['point_MLP_depth_list']), False, dec)
+            agg = smax(f, dst, kp.shape[0])
             feats = _mlp(agg, params, scope + '/combined_features',
-                         len(kw['output_MLP_depth_list']), False)
+                         len(kw['output_MLP_depth_list']), False, dec)
         else:
             x = coords[lvl]
             h = feats
             s_h, s_x = h[src], x[src]
             if kw['auto_offset']:
                 x = x + _mlp(h, params, scope,
-                             len(kw['auto_offset_MLP_depth_list']), True)
+                             len(kw['auto_offset_MLP_depth_list']), True, dec)
             ef = torch.cat([s_h, s_x - x[dst]], dim=1)
             ef = _mlp(ef, params, scope + '/extract_vertex_features',
-                      len(kw['edge_MLP_depth_list']), False)
-            agg = _segment_max(ef, dst, h.shape[0])
+                      len(kw['edge_MLP_depth_list']), False, dec)
+            agg = smax(ef, dst, h.shape[0])
             feats = _mlp(agg, params, scope + '/combined_features',
-                         len(kw['update_MLP_depth_list']), True) + h
+                         len(kw['update_MLP_depth_list']), True, dec) + h
     ps = config['model_kwargs']['layer_configs'][-1]['scope'] + '/predictor'
-    logits = _mlp(feats, params, ps + '/cls', 2, True)
-    boxes = [_mlp(feats, params, ps + '/loc/cls_%d' % j, 3, True)[:, None, :]
+    logits = _mlp(feats, params, ps + '/cls', 2, True, dec)
+    boxes = [_mlp(feats, params, ps + '/loc/cls_%d' % j, 3, True,
+                  dec)[:, None, :]
              for j in range(config['num_classes'])]
     return logits, torch.cat(boxes, dim=1)
 
@@ -88,20 +156,24 @@ def loss_terms(config, logits, pred_box, labels, gt_box, valid,
     return ce.sum(), loc.sum(), float(len(lab)), float(va.sum())
 
 
-def step_gradients(np_params, config, rank_batches, dtype=torch.float64):
+def step_gradients(np_params, config, rank_batches, dtype=torch.float64,
+                   decisions=None):
     """Global loss and gradients for a list of per-rank batches, following
     train.py:264-297 + util/tf_util.py:3-43: every tower's cls/loc loss is
     re-weighted by its share of (valid) endpoints and the tower gradients are
     averaged -- which equals the gradient of the global per-vertex means.
-    Returns (loss dict, {name: ndarray grad of cls+loc}, {name: grad of reg})."""
+    Returns (loss dict, {name: ndarray grad of cls+loc}, {name: grad of reg}).
+    decisions: one `Decisions` per batch (see the module header) or None."""
     params = {k: torch.tensor(np.asarray(v), dtype=dtype, requires_grad=True)
               for k, v in np_params.items()}
     cls_w = config['loss']['cls_loss_weight']
     loc_w = config['loss']['loc_loss_weight']
     terms = []
-    for (input_v, coords, kps, edges, labels, boxes, valid) in rank_batches:
+    for bi, (input_v, coords, kps, edges, labels, boxes,
+             valid) in enumerate(rank_batches):
         logits, pred = forward(params, config, input_v, coords, kps, edges,
-                               dtype)
+                               dtype, None if decisions is None
+                               else decisions[bi])
         terms.append(loss_terms(config, logits, pred, labels, boxes, valid,
                                 dtype))
     n_tot = sum(t[2] for t in terms)

@@ -334,6 +334,7 @@ class Trainer(object):
         self._native = None
         self._native_ws = None
         self._py_images_stale = True
+        self._native_images_stale = False
         self.repack()
 
     # ---- plumbing -----------------------------------------------------------
@@ -459,7 +460,11 @@ class Trainer(object):
                                                         self._st()),
                            "pgnn_trainer_repack")
             # (a handle created later packs in pgnn_trainer_bind)
+            self._native_images_stale = False
             return
+        # Python-driven step: the native handle's images (if one exists) are
+        # now behind the flat buffer; _native_forward repacks before reuse
+        self._native_images_stale = self._native is not None
         self._repack_py()
 
     def _repack_py(self):
@@ -679,6 +684,12 @@ class Trainer(object):
     def _native_forward(self, input_v, coords, kps, edges):
         lib = self.lib
         h = self._native_handle()
+        if self._native_images_stale:
+            # weights were updated while native = False (repack() refreshed
+            # only the Python-side images then)
+            _lib.check(lib.pgnn_trainer_repack(h, self._st()),
+                       "pgnn_trainer_repack")
+            self._native_images_stale = False
         batch, keep = self._native_batch(input_v, coords, kps, edges)
         need = int(lib.pgnn_trainer_workspace_bytes(h, ctypes.byref(batch)))
         if need == 0:

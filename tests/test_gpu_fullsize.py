@@ -1,0 +1,153 @@
+"""BASELINE sizes against the REFERENCE'S OWN outputs (tests/golden/
+fullsize_*.npz, written by tests/golden/make_golden_fullsize.py in the build
+container):
+
+  * the edge lists of the 20 000-point `car` / `car_600k` and 50 000-point
+    `ped_dense` frames are compared -- by (E, sha256) of the (dst,src)-sorted
+    int32 rows -- with what /root/reference/models/graph_gen.py:197-220 itself
+    returned, once with the fixture's keypoints fed in and once for the
+    device's own end-to-end build (keypoint-numbering-free form);
+  * BASELINE config 2 (`car_auto_T1`) and config 1's model (`car_auto_T0`) with
+    the TRAINED weights of checkpoints/car_auto_T{0,1}_train on those whole
+    frames, against the logits / box encodings of the reference's serialized
+    TF graph (model-1400000.meta, run.py:199-201,252-260) and against the
+    float64 oracle with per-layer deltas.
+"""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import pointgnn_amd  # noqa: F401
+from pointgnn_amd import configs
+from pointgnn_amd.synthetic import synthetic_cloud
+from oracle import gnn_oracle as gn
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+FP_TOL = 2e-4   # north-star tolerance is 1e-3
+
+FRAMES = {"car": "car_auto_T3", "car_600k": "car_auto_T3",
+          "ped_dense": "ped_cyl_auto_T3"}
+
+
+def gold(name):
+    return dict(np.load(os.path.join(GOLD, name)))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import torch
+    assert torch.cuda.is_available()
+    from pointgnn_amd import _lib
+    _lib.load()            # raises if the HIP extension is missing
+    return torch.device("cuda")
+
+
+def T(a, dev):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def edge_digest(src, dst):
+    """Same definition as tests/golden/make_golden_fullsize.py."""
+    src = np.asarray(src, np.int64)
+    dst = np.asarray(dst, np.int64)
+    order = np.lexsort((src, dst))
+    rows = np.stack([src[order], dst[order]], axis=1).astype("<i4")
+    return hashlib.sha256(np.ascontiguousarray(rows).tobytes()).hexdigest()
+
+
+def _frame(preset):
+    g = gold("fullsize_%s.npz" % preset)
+    xyz, inten = synthetic_cloud(seed=0, preset=preset)
+    assert hashlib.sha256(np.ascontiguousarray(
+        xyz.astype("<f4")).tobytes()).hexdigest() == str(g["xyz_sha"]), \
+        "the synthetic generator no longer reproduces the fixture's cloud"
+    return g, xyz, inten
+
+
+@pytest.mark.parametrize("preset", sorted(FRAMES))
+def test_full_size_edges_equal_reference_digest(dev, preset):
+    """graph_gen.py:197-220 at BASELINE size, both levels, bit-exact."""
+    from pointgnn_amd import graph_gen
+    g, xyz, _ = _frame(preset)
+    cfg = configs.get_config(FRAMES[preset])
+    r0, r1 = (float(r) for r in g["radii"])
+    # (i) the reference's keypoints fed in: same numbering, plain digest
+    kp = g["kp_idx"][:, 0].astype(np.int64)
+    kp_xyz = xyz[kp]
+    e0 = graph_gen.gen_disjointed_rnn_local_graph_v3(
+        T(xyz, dev), T(kp_xyz, dev), r0, -1).cpu().numpy()
+    e1 = graph_gen.gen_disjointed_rnn_local_graph_v3(
+        T(kp_xyz, dev), T(kp_xyz, dev), r1, -1).cpu().numpy()
+    assert (len(e0), len(e1)) == (int(g["E0"]), int(g["E1"]))
+    assert edge_digest(e0[:, 0], e0[:, 1]) == str(g["edges0_sha"])
+    assert edge_digest(e1[:, 0], e1[:, 1]) == str(g["edges1_sha"])
+    # (ii) the device's own build (its keypoints, its numbering)
+    fn = graph_gen.get_graph_generate_fn(cfg["graph_gen_method"])
+    coords, kps, edges = fn(T(xyz, dev), **cfg["runtime_graph_gen_kwargs"])
+    dk = kps[0].cpu().numpy()[:, 0].astype(np.int64)
+    d0 = edges[0].cpu().numpy()
+    d1 = edges[1].cpu().numpy()
+    assert np.array_equal(np.sort(dk), np.sort(kp))
+    assert (len(d0), len(d1)) == (int(g["E0"]), int(g["E1"]))
+    assert edge_digest(d0[:, 0], dk[d0[:, 1]]) == str(g["edges0_pt_sha"])
+    assert edge_digest(dk[d1[:, 0]], dk[d1[:, 1]]) == str(g["edges1_pt_sha"])
+    print("%s: K %d E0 %d E1 %d equal the reference's lists" % (
+        preset, len(kp), len(e0), len(e1)))
+
+
+@pytest.mark.parametrize("preset", ["car", "car_600k"])
+@pytest.mark.parametrize("t", [0, 1])
+def test_predict_real_weights_full_size(dev, preset, t):
+    """BASELINE config 2 at its own size: trained weights x whole frame."""
+    from pointgnn_amd import graph_gen, models
+    g, xyz, inten = _frame(preset)
+    cfg = configs.car_auto_config(t)
+    w = gold("weights_car_auto_T%d.npz" % t)
+    kp_idx = g["kp_idx"].astype(np.int32)
+    kp_xyz = xyz[kp_idx[:, 0]]
+    k = len(kp_idx)
+    r0, r1 = (float(r) for r in g["radii"])
+    e0 = graph_gen.gen_disjointed_rnn_local_graph_v3(T(xyz, dev),
+                                                     T(kp_xyz, dev), r0, -1)
+    e1 = graph_gen.gen_disjointed_rnn_local_graph_v3(T(kp_xyz, dev),
+                                                     T(kp_xyz, dev), r1, -1)
+    coords = [T(xyz, dev), T(kp_xyz, dev), T(kp_xyz, dev)]
+    kps = [T(kp_idx, dev),
+           T(np.arange(k, dtype=np.int32).reshape(-1, 1), dev)]
+    model = models.get_model(cfg["model_name"])(
+        num_classes=cfg["num_classes"], box_encoding_len=7, mode="test",
+        **cfg["model_kwargs"])
+    model.load_state_dict(w)
+    model.keep_features = True
+    logits, boxes = model.predict(T(inten, dev), coords, kps, [e0, e1], False)
+    logits = logits.cpu().numpy()
+    boxes = boxes.cpu().numpy()
+    ref_l, ref_b = g["T%d_logits" % t], g["T%d_box_encodings" % t]
+    assert logits.shape == ref_l.shape and boxes.shape == ref_b.shape
+    # float64 oracle on the same (device-built, digest-checked) graph
+    c_np = [xyz, kp_xyz, kp_xyz]
+    k_np = [kp_idx, np.arange(k, dtype=np.int32).reshape(-1, 1)]
+    e_np = [e0.cpu().numpy(), e1.cpu().numpy()]
+    lg, bx, feats = gn.predict(w, cfg, inten, c_np, k_np, e_np,
+                               dtype=np.float64, return_features=True)
+    report = []
+    for i, (got, ref) in enumerate(zip(model.feature_list, feats[1:])):
+        got = got.cpu().numpy()[:, :ref.shape[1]]
+        report.append("layer%d %.2g (|h|max %.3g)" % (
+            i + 1, np.abs(got - ref).max(), np.abs(ref).max()))
+        np.testing.assert_allclose(got, ref, atol=FP_TOL, rtol=1e-4)
+    print("car_auto_T%d/%s trained weights, K %d E1 %d: max|dlogit| %.3g "
+          "max|dbox| %.3g vs the reference TF graph; %.3g / %.3g vs the "
+          "float64 oracle (|logit|max %.3g); %s" % (
+              t, preset, k, len(e_np[1]), np.abs(logits - ref_l).max(),
+              np.abs(boxes - ref_b).max(), np.abs(logits - lg).max(),
+              np.abs(boxes - bx).max(), np.abs(ref_l).max(),
+              ", ".join(report)))
+    np.testing.assert_allclose(logits, ref_l, atol=FP_TOL, rtol=0)
+    np.testing.assert_allclose(boxes, ref_b, atol=FP_TOL, rtol=0)
+    np.testing.assert_allclose(logits, lg, atol=FP_TOL, rtol=0)
+    np.testing.assert_allclose(boxes, bx, atol=FP_TOL, rtol=0)

@@ -301,6 +301,92 @@ def test_full_gradient_matches_oracle(dev, name):
         worst_max, worst_fro))
 
 
+def _device_decisions(tr, cfg):
+    """The non-smooth choices the DEVICE's forward took (ReLU masks, segment-
+    max winners), read from the activations the Python-driven step keeps for
+    its backward (`Trainer._saved`), in oracle/train_oracle.Decisions order."""
+    out = []
+    fc = tr.fc
+
+    def relu_masks(names, acts, skip_last):
+        n = len(names) - (1 if skip_last else 0)
+        for i in range(n):
+            w = fc[names[i]].n_out
+            out.append((acts[i + 1][:, :w] > 0).cpu().numpy())
+
+    def winners(rows, dst, agg, width):
+        idx = dst.long()
+        out.append((rows[:, :width] == agg[idx][:, :width]).cpu().numpy())
+
+    for item in tr._saved:
+        if item[0] == 'pool':
+            _, names, acts, dst, agg, onames, oacts = item
+            relu_masks(names, acts, False)
+            winners(acts[-1], dst, agg, fc[names[-1]].n_out)
+            relu_masks(onames, oacts, False)
+        elif item[0] == 'gnn':
+            (_, enames, hx, xo, e, eacts, dst, agg, unames, uacts, off_names,
+             off_acts, c) = item
+            if off_names is not None:
+                relu_masks(off_names, off_acts, True)
+            for i, n in enumerate(enames):      # eacts[0] = ReLU(P - Q)
+                out.append((eacts[i][:, :fc[n].n_out] > 0).cpu().numpy())
+            winners(eacts[-1], dst, agg, fc[enames[-1]].n_out)
+            relu_masks(unames, uacts, True)
+        else:
+            _, cls_names, cacts, loc = item
+            relu_masks(cls_names, cacts, True)
+            for names, a in loc:
+                relu_masks(names, a, True)
+    return out
+
+
+@pytest.mark.parametrize("name", ["car_auto_T1", "car_auto_T3", "car_fixed_T3",
+                                  "ped_cyl_auto_T3"])
+def test_full_gradient_matches_mask_matched_oracle(dev, name):
+    """The demonstration the docstring above only asserted: with the device's
+    own ReLU masks and arg-max winners held fixed in the float64 oracle
+    (oracle/train_oracle.Decisions), EVERY gradient entry of every variable
+    agrees to float32 summation noise -- all three ways of running the step
+    (native, Python-driven sparse adjoint, dense adjoint).  The decisions the
+    float64 forward would have taken differently are counted and printed: they
+    are what the loose bars of test_full_gradient_matches_oracle pay for."""
+    from pointgnn_amd import train
+    cfg = configs.get_config(name)
+    params = weights.init_params(cfg, seed=5, bias_scale=0.1)
+    batch = _tiny_batch(seed=3, num_classes=cfg["num_classes"])
+    tr = train.Trainer(cfg, params=params, device=dev)
+    tr.native = False
+    tr.forward(*batch[:4])
+    masks = _device_decisions(tr, cfg)
+    dec = to.Decisions(masks)
+    loss, g_ref, _ = to.step_gradients(params, cfg, [batch], decisions=[dec])
+    assert dec.pos == len(masks)
+    flips = dec.flips()
+    n_dec = sum(m.size for m in masks)
+    worst = {}
+    for mode, (native, sparse) in (("native", (True, True)),
+                                   ("python", (False, True)),
+                                   ("dense", (False, False))):
+        t2 = train.Trainer(cfg, params=params, device=dev)
+        t2.native, t2.sparse_adjoint = native, sparse
+        out = t2.train_step(batch, apply=False)
+        assert abs(out['cls_loss'] - loss['cls_loss']) < 1e-5 * max(1, loss['cls_loss'])
+        assert abs(out['loc_loss'] - loss['loc_loss']) < 1e-5 * max(1, loss['loc_loss'])
+        got = t2.grad_dict()
+        w = 0.0
+        for n, ref in g_ref.items():
+            e_max, _ = _grad_errors(got[n], ref)
+            w = max(w, e_max)
+            assert e_max < 2e-5, "%s %s: max-entry rel err %.3g" % (mode, n,
+                                                                     e_max)
+        worst[mode] = w
+    print("%s: %d of %d decisions differ between the float32 device forward "
+          "and a float64 one (per site: %s); mask-matched worst entry error "
+          "%s" % (name, sum(flips), n_dec, [f for f in flips if f],
+                  {k: "%.2g" % v for k, v in worst.items()}))
+
+
 def test_sgd_step_and_loss_decrease(dev):
     from pointgnn_amd import train
     cfg = configs.car_auto_config(1)
@@ -503,6 +589,32 @@ def test_native_step_updates_like_the_python_step(dev):
     for n in finals[True]:
         a, b = finals[True][n].astype(np.float64), finals[False][n].astype(np.float64)
         assert np.abs(a - b).max() <= 3e-3 * max(np.abs(b).max(), 1e-6) + 1e-7, n
+
+
+def test_switching_step_paths_never_runs_on_stale_weight_images(dev):
+    """A native handle exists, the caller switches to the Python-driven step,
+    updates the weights there, then switches back: the native forward must
+    see the NEW weights (its fragment images are repacked on re-entry) -- the
+    logits equal, bit for bit, those of a fresh Trainer built from the updated
+    state.  Same the other way round (Python images after native updates)."""
+    import torch
+    from pointgnn_amd import train
+    cfg = configs.car_auto_config(3)
+    params = weights.init_params(cfg, seed=8, bias_scale=0.05)
+    b1, b2, b3 = (_tiny_batch(seed=s) for s in (1, 2, 3))
+    for first in (True, False):
+        tr = train.Trainer(cfg, params=params, device=dev)
+        tr.native = first
+        tr.train_step(b1)                 # creates the images of `first`
+        tr.native = not first
+        tr.train_step(b2)                 # updates weights on the other path
+        tr.native = first
+        lg, pb = tr.forward(*b3[:4])
+        lg, pb = lg.clone(), pb.clone()
+        fresh = train.Trainer(cfg, params=tr.state_dict(), device=dev)
+        fresh.native = first
+        lg2, pb2 = fresh.forward(*b3[:4])
+        assert torch.equal(lg, lg2) and torch.equal(pb, pb2), first
 
 
 @pytest.mark.parametrize("c,fixture", [(300, "graph_small.npz"),

@@ -10,6 +10,7 @@ import pytest
 
 import pointgnn_amd  # noqa: F401
 from pointgnn_amd import configs
+from pointgnn_amd.synthetic import synthetic_cloud
 from oracle import graph_oracle as go
 from oracle import gnn_oracle as gn
 from _refimport import reference_graph_gen
@@ -313,3 +314,54 @@ def test_kdtree_oracle_heap_select_fallback_equals_sklearn():
                                    leaf_size=30).get_arrays()
         assert np.array_equal(idx, idx_ref)
         assert np.array_equal(bounds[:, :3], nb[0])
+
+
+# ------------------------------------------------- BASELINE sizes (round 4)
+def _fullsize_digest(src, dst):
+    import hashlib
+    src = np.asarray(src, np.int64)
+    dst = np.asarray(dst, np.int64)
+    order = np.lexsort((src, dst))
+    rows = np.stack([src[order], dst[order]], axis=1).astype("<i4")
+    return hashlib.sha256(np.ascontiguousarray(rows).tobytes()).hexdigest()
+
+
+@pytest.mark.parametrize("preset", ["car", "car_600k", "ped_dense"])
+def test_c_restatement_equals_reference_full_size_digest(preset):
+    """oracle/radius_bruteforce.c (the full-size checker of the GPU tests)
+    against the digests of the lists the reference's own
+    gen_disjointed_rnn_local_graph_v3 wrote at BASELINE size
+    (tests/golden/make_golden_fullsize.py)."""
+    g = dict(np.load(os.path.join(GOLD, "fullsize_%s.npz" % preset)))
+    xyz, _ = synthetic_cloud(seed=0, preset=preset)
+    kp_xyz = xyz[g["kp_idx"][:, 0]]
+    r0, r1 = (float(r) for r in g["radii"])
+    e0 = go.radius_graph_c(xyz, kp_xyz, r0)
+    e1 = go.radius_graph_c(kp_xyz, kp_xyz, r1)
+    assert (len(e0), len(e1)) == (int(g["E0"]), int(g["E1"]))
+    assert _fullsize_digest(e0[:, 0], e0[:, 1]) == str(g["edges0_sha"])
+    assert _fullsize_digest(e1[:, 0], e1[:, 1]) == str(g["edges1_sha"])
+
+
+def test_gnn_oracle_equals_reference_tf_graph_full_size():
+    """BASELINE config 2 at its own size: oracle/gnn_oracle.predict with the
+    TRAINED car_auto_T1 weights on the whole 20 000-point `car` frame against
+    the reference's serialized TF graph (fixture T1_logits)."""
+    g = dict(np.load(os.path.join(GOLD, "fullsize_car.npz")))
+    w = dict(np.load(os.path.join(GOLD, "weights_car_auto_T1.npz")))
+    xyz, inten = synthetic_cloud(seed=0, preset="car")
+    kp_idx = g["kp_idx"].astype(np.int32)
+    kp_xyz = xyz[kp_idx[:, 0]]
+    k = len(kp_idx)
+    r0, r1 = (float(r) for r in g["radii"])
+    edges = [go.radius_graph_c(xyz, kp_xyz, r0),
+             go.radius_graph_c(kp_xyz, kp_xyz, r1)]
+    lg, bx = gn.predict(w, configs.car_auto_config(1), inten,
+                        [xyz, kp_xyz, kp_xyz],
+                        [kp_idx, np.arange(k, dtype=np.int32).reshape(-1, 1)],
+                        edges, dtype=np.float32)
+    print("max|dlogit| %.3g max|dbox| %.3g" % (
+        np.abs(lg - g["T1_logits"]).max(),
+        np.abs(bx - g["T1_box_encodings"]).max()))
+    np.testing.assert_allclose(lg, g["T1_logits"], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(bx, g["T1_box_encodings"], atol=1e-4, rtol=0)

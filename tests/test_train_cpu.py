@@ -1,4 +1,6 @@
 """Host-side pieces of the training step that need no GPU."""
+import os
+
 import numpy as np
 
 import pointgnn_amd  # noqa: F401
@@ -45,3 +47,46 @@ def test_learning_rate_schedule():
     assert learning_rate(tc, 399999) == 0.125
     assert abs(learning_rate(tc, 400000) - 0.0125) < 1e-12
     assert abs(learning_rate(tc, 1399999) - 0.125e-3) < 1e-12
+
+
+def test_mask_matched_oracle_replays_its_own_decisions():
+    """oracle/train_oracle.Decisions: replaying the decisions a forward
+    recorded reproduces its loss and gradients exactly; replaying a float32
+    forward's decisions in float64 brings the two gradients to float32 noise
+    (the mechanism behind tests/test_gpu_train.py::
+    test_full_gradient_matches_mask_matched_oracle)."""
+    import torch
+    from oracle import train_oracle as to
+    from pointgnn_amd import configs, weights
+    g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                                  "golden", "graph_tiny.npz")))
+    k = g["kp_xyz"].shape[0]
+    cfg = configs.get_config("car_auto_T3")
+    rng = np.random.default_rng(3)
+    labels = rng.integers(0, 4, (k, 1)).astype(np.int32)
+    labels[rng.random((k, 1)) < 0.5] = 0
+    boxes = (rng.standard_normal((k, 1, 7)) * 1.5).astype(np.float32)
+    valid = (labels > 0).astype(np.float32).reshape(k, 1, 1)
+    batch = (g["intensity"], [g["xyz"], g["kp_xyz"], g["kp_xyz"]],
+             [g["kp_idx"], np.arange(k, dtype=np.int32).reshape(-1, 1)],
+             [g["ref_edges0"], g["ref_edges1"]], labels, boxes, valid)
+    params = weights.init_params(cfg, seed=5, bias_scale=0.1)
+    l0, g0, _ = to.step_gradients(params, cfg, [batch])
+    rec = to.Decisions()
+    l1, g1, _ = to.step_gradients(params, cfg, [batch], decisions=[rec])
+    assert l0 == l1 and sum(rec.flips()) == 0
+    rep = to.Decisions(rec.taken)
+    l2, g2, _ = to.step_gradients(params, cfg, [batch], decisions=[rep])
+    assert l0 == l2 and rep.pos == len(rec.taken)
+    for n in g0:
+        assert np.array_equal(g0[n], g1[n])
+        np.testing.assert_allclose(g2[n], g0[n], rtol=0,
+                                   atol=1e-12 * (np.abs(g0[n]).max() + 1e-30))
+    rec32 = to.Decisions()
+    _, g32, _ = to.step_gradients(params, cfg, [batch], dtype=torch.float32,
+                                  decisions=[rec32])
+    rep64 = to.Decisions(rec32.taken)
+    _, g64, _ = to.step_gradients(params, cfg, [batch], decisions=[rep64])
+    for n in g0:
+        scale = np.abs(g64[n]).max() + 1e-30
+        assert np.abs(g32[n] - g64[n]).max() <= 1e-5 * scale, n
