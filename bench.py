@@ -663,6 +663,19 @@ def parse_args(argv=None):
                          "for ped_cyl configs)")
     ap.add_argument("--frames", type=int, default=8,
                     help="distinct synthetic frames in the pool")
+    ap.add_argument("--frames-per-step", type=int, default=8,
+                    help="inference: frames every GPU processes per step "
+                         "(the same at every N: weak scaling).  8 makes the "
+                         "timed region of a 20-step run ~0.5 s per rank, so "
+                         "a few ms of rank skew at the closing barrier is "
+                         "<1 %% of it")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="barrier-bracketed timed regions of exactly --steps "
+                         "steps; the FIRST is the headline `value`, the "
+                         "spread of all of them is reported beside it")
+    ap.add_argument("--no-bind", action="store_true",
+                    help="do not pin this rank to the CPUs of its GPU's "
+                         "NUMA node")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-live-pmc", action="store_true",
@@ -732,7 +745,7 @@ def self_launch(args, argv):
     if not STUB:
         import torch
         have = torch.cuda.device_count() if torch.cuda.is_available() else 0
-        if have < args.gpus:
+        if have < args.gpus and not (ONE_GPU and have >= 1):
             raise SystemExit(
                 "bench.py: --gpus %d but only %d GPU(s) visible; refusing to "
                 "report an n_gpus it did not run on" % (args.gpus, have))
@@ -749,6 +762,10 @@ def self_launch(args, argv):
 # CPU with gloo and a sleep in place of the engine (tests/test_sharding_cpu.py).
 # The line it prints says "data": "stub" and carries no rates.
 STUB = os.environ.get("PGNN_BENCH_STUB") == "1"
+# PGNN_BENCH_ONE_GPU=1 (tests/test_gpu_multirank.py on a one-GPU box): every
+# rank runs the REAL engine on cuda:0 and the rank plumbing uses gloo.  The
+# line says so in "data"; its value is not a multi-GPU measurement.
+ONE_GPU = os.environ.get("PGNN_BENCH_ONE_GPU") == "1"
 
 
 class _StubEngine(object):
@@ -759,6 +776,73 @@ class _StubEngine(object):
         for f in frames:
             time.sleep(0.002)
             self.frame_shapes.append((100 + f, 1000 + f, 2000 + f))
+
+
+def _parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def bind_rank_to_numa(torch, local_rank, local_world):
+    """Pin this process to the CPUs next to its GPU: the cpulist of the NUMA
+    node /sys reports for the GPU's PCI function; when the platform reports
+    no node (-1: one-socket hosts, VMs) the allowed CPUs are split evenly by
+    local rank instead, so 8 ranks' enqueue threads (~110 launches per frame
+    each) never share cores.  Returns what was done, for the JSON line."""
+    info = {"bound": False}
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        node = -1
+        bus = None
+        try:
+            pr = torch.cuda.get_device_properties(local_rank)
+            bus = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id,
+                                        pr.pci_device_id)
+            with open("/sys/bus/pci/devices/%s/numa_node" % bus) as fh:
+                node = int(fh.read().strip())
+        except Exception:
+            pass
+        info["pci"] = bus
+        info["numa_node"] = node
+        cpus = None
+        if node >= 0:
+            with open("/sys/devices/system/node/node%d/cpulist" % node) as fh:
+                cpus = sorted(_parse_cpulist(fh.read()) & set(allowed))
+            # ranks whose GPUs share the node split its CPUs
+            peers = []
+            for r in range(local_world):
+                try:
+                    q = torch.cuda.get_device_properties(r)
+                    with open("/sys/bus/pci/devices/%04x:%02x:%02x.0/numa_node"
+                              % (q.pci_domain_id, q.pci_bus_id,
+                                 q.pci_device_id)) as fh:
+                        if int(fh.read().strip()) == node:
+                            peers.append(r)
+                except Exception:
+                    pass
+            if local_rank in peers and len(peers) > 1 and \
+                    len(cpus) >= len(peers):
+                i, n = peers.index(local_rank), len(peers)
+                cpus = cpus[i * len(cpus) // n:(i + 1) * len(cpus) // n]
+            info["policy"] = "cpulist of the GPU's NUMA node / ranks on it"
+        if not cpus:
+            n = max(1, local_world)
+            cpus = allowed[local_rank * len(allowed) // n:
+                           (local_rank + 1) * len(allowed) // n]
+            info["policy"] = "no NUMA node reported: allowed CPUs split " \
+                             "evenly by local rank"
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+            info.update(bound=True, n_cpus=len(cpus), first_cpu=cpus[0],
+                        last_cpu=cpus[-1])
+    except Exception as exc:      # never fatal to the measurement
+        info["error"] = repr(exc)
+    return info
 
 
 def init_ranks(args, torch):
@@ -777,12 +861,21 @@ def init_ranks(args, torch):
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU (the hot path has no CPU "
                              "fallback)")
-        torch.cuda.set_device(local_rank)
-        dev = torch.device("cuda", local_rank)
-        backend = "nccl"
+        if ONE_GPU:
+            local_rank_dev = 0
+            backend = "gloo"
+        else:
+            local_rank_dev = local_rank
+            backend = "nccl"
+        torch.cuda.set_device(local_rank_dev)
+        dev = torch.device("cuda", local_rank_dev)
+        args.cpu_affinity = {"bound": False, "policy": "--no-bind"} \
+            if args.no_bind else bind_rank_to_numa(
+                torch, local_rank,
+                int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     if world > 1:
         import torch.distributed as dist
-        if STUB:
+        if STUB or ONE_GPU:
             dist.init_process_group(backend)
         else:
             dist.init_process_group(backend, device_id=dev)
@@ -802,7 +895,8 @@ def _sync(torch, dist):
 def _max_over_ranks(torch, dist, dev, values):
     if dist is None:
         return values
-    t = torch.tensor(values, dtype=torch.float64, device=dev)
+    t = torch.tensor(values, dtype=torch.float64,
+                     device="cpu" if ONE_GPU else dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return [float(v) for v in t.tolist()]
 
@@ -810,7 +904,8 @@ def _max_over_ranks(torch, dist, dev, values):
 def _gather_shapes(torch, dist, dev, shapes, world):
     """All ranks' per-frame (K, E0, E1) rows on rank 0 (sizes only, after the
     timed region)."""
-    a = torch.tensor(shapes, dtype=torch.int64, device=dev).reshape(-1, 3)
+    a = torch.tensor(shapes, dtype=torch.int64,
+                     device="cpu" if ONE_GPU else dev).reshape(-1, 3)
     if dist is None:
         return a.tolist()
     out = [torch.zeros_like(a) for _ in range(world)]
@@ -828,24 +923,41 @@ def dist_info(dist, world):
 
 def run_stub(args, torch, dev, rank, world, dist):
     eng = _StubEngine()
-    ids = list(range(rank, world * (args.steps + args.warmup), world))
-    eng.run_frames(ids[:args.warmup])
-    eng.frame_shapes = []
-    _sync(torch, dist)
-    t0 = time.perf_counter()
-    eng.run_frames(ids[args.warmup:])
-    _sync(torch, dist)
-    elapsed, = _max_over_ranks(torch, dist, dev, [time.perf_counter() - t0])
-    shapes = _gather_shapes(torch, dist, dev, eng.frame_shapes, world)
+    fps = max(1, args.frames_per_step)
+    reps = max(1, args.repeats)
+    per_region = args.steps * fps
+    ids = list(range(rank, world * (args.warmup * fps + reps * per_region),
+                     world))
+    eng.run_frames(ids[:args.warmup * fps])
+    regions, shapes = [], None
+    for r in range(reps):
+        lo = args.warmup * fps + r * per_region
+        eng.frame_shapes = []
+        _sync(torch, dist)
+        t0 = time.perf_counter()
+        eng.run_frames(ids[lo:lo + per_region])
+        _sync(torch, dist)
+        el, = _max_over_ranks(torch, dist, dev, [time.perf_counter() - t0])
+        regions.append(el)
+        if r == 0:
+            shapes = _gather_shapes(torch, dist, dev, eng.frame_shapes, world)
+    elapsed = regions[0]
+    rep_ms = [r / args.steps * 1e3 for r in regions]
     if rank == 0:
         print(json.dumps({
             "metric": "stub frames/sec (launcher self-test, no kernels)",
-            "value": world * args.steps / elapsed, "unit": "frames/s",
+            "value": world * per_region / elapsed, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "none", "data": "stub",
             "config": {"workload": "stub", "frames_timed": len(shapes),
+                       "frames_per_gpu_per_step": fps,
+                       "timed_region_s": elapsed,
+                       "repeat_ms_per_step": {
+                           "n": len(rep_ms), "min": min(rep_ms),
+                           "median": float(np.median(rep_ms)),
+                           "max": max(rep_ms), "all": rep_ms},
                        "distributed": dist_info(dist, world)}}), flush=True)
 
 
@@ -961,12 +1073,17 @@ def main(argv=None):
     engine = InferenceEngine(cfg, params, device=dev)
     engine.config_name = args.config
 
-    def measure(preset, steps, warmup, engine=engine, n_frames=None):
-        """Time `steps` frames per rank of `preset`; returns (elapsed max over
-        ranks, all ranks' per-frame shapes, this rank's pool, last output)."""
+    def measure(preset, steps, warmup, engine=engine, n_frames=None, fps=1,
+                repeats=1):
+        """Time `steps` steps of `fps` frames per rank of `preset`, `repeats`
+        times (each region bracketed by barrier + synchronize); returns
+        (elapsed of the FIRST region, max over ranks; all ranks' per-frame
+        shapes of that region; this rank's pool; every region's elapsed)."""
         n_frames = n_frames or args.frames
+        per_region = steps * fps
+        total = warmup * fps + repeats * per_region
         # frame stream: rank r owns frames r, r+W, ...
-        my_ids = shard_frames(world * (steps + warmup), rank, world)
+        my_ids = shard_frames(world * total, rank, world)
 
         def seed_of(i):
             # every rank cycles through ALL pool frames (rank r starts at
@@ -1003,21 +1120,47 @@ def main(argv=None):
                 deferred=deferred, graph_streams=args.graph_streams)[-1]
 
         if warmup:
-            run(0, warmup)
-        engine.frame_shapes = []
-        _sync(torch, dist)
-        t0 = time.perf_counter()
-        out = run(warmup, warmup + steps)
-        _sync(torch, dist)
-        elapsed, = _max_over_ranks(torch, dist, dev,
-                                   [time.perf_counter() - t0])
-        assert torch.isfinite(out[0]).all()
-        assert len(engine.frame_shapes) == steps
-        shapes = _gather_shapes(torch, dist, dev,
-                                [s[:3] for s in engine.frame_shapes], world)
-        return elapsed, shapes, pool
+            run(0, warmup * fps)
+        regions, shapes = [], None
+        for r in range(repeats):
+            lo = warmup * fps + r * per_region
+            engine.frame_shapes = []
+            _sync(torch, dist)
+            t0 = time.perf_counter()
+            out = run(lo, lo + per_region)
+            _sync(torch, dist)
+            el, = _max_over_ranks(torch, dist, dev,
+                                  [time.perf_counter() - t0])
+            regions.append(el)
+            assert torch.isfinite(out[0]).all()
+            assert len(engine.frame_shapes) == per_region
+            if r == 0:
+                shapes = _gather_shapes(
+                    torch, dist, dev, [s[:3] for s in engine.frame_shapes],
+                    world)
+        measure.regions = regions
+        # Python time to ENQUEUE one frame (~110 ctypes launches: graph build
+        # + GNN), nothing read back: 16 frames onto an idle device -- far
+        # below any queue depth, so the host never waits for the device here
+        measure.enqueue_ms = None
+        if not args.no_pipeline and not args.host_sized and \
+                frame_streams_for(args, engine.config_name) > 0 and \
+                args.graph_cus <= 0:
+            n_enq = min(16, per_region)
+            samples = []
+            for _ in range(3):
+                _sync(torch, None)
+                run(warmup * fps, warmup * fps + n_enq)
+                samples.append(engine.last_enqueue_s / n_enq * 1e3)
+            measure.enqueue_ms = _max_over_ranks(
+                torch, dist, dev, [float(np.median(samples))])[0]
+            engine.frame_shapes = []
+        return regions[0], shapes, pool
 
-    elapsed, shapes, pool = measure(args.preset, args.steps, args.warmup)
+    fps_h = max(1, args.frames_per_step)
+    elapsed, shapes, pool = measure(args.preset, args.steps, args.warmup,
+                                    fps=fps_h, repeats=max(1, args.repeats))
+    regions_h, enqueue_ms_h = list(measure.regions), measure.enqueue_ms
     second = None
     if world == 1 and not args.no_secondary and args.preset == "car_600k":
         s2 = max(8, args.steps // 2)
@@ -1128,14 +1271,15 @@ def main(argv=None):
                         "probabilities: thousands of candidates, a stress "
                         "case for the NMS"}
         st = pool_statistics(cfg, shapes)
-        assert st["frames"] == world * args.steps
+        assert st["frames"] == world * args.steps * fps_h
         n_builders = 1 if (args.host_sized or args.graph_cus > 0) else \
             max(1, args.graph_streams)
         n_fs = frame_streams_for(args, args.config)
         frame_sched = (not args.host_sized and n_fs > 0 and
                        args.graph_cus <= 0)
-        fps = world * args.steps / elapsed
+        fps = world * args.steps * fps_h / elapsed
         n_pts = int(x.shape[0])
+        rep_ms = [r / args.steps * 1e3 for r in regions_h]
         res = {
             "metric": "KITTI-shaped frames/sec (%s inference: graph build + "
                       "GNN, %d pts/frame, mean E1 %.0fk)" % (
@@ -1144,16 +1288,33 @@ def main(argv=None):
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32",
+            "data": "synthetic" if not (ONE_GPU and world > 1) else
+                    "synthetic; TEST MODE: %d ranks share ONE GPU under gloo "
+                    "(not a multi-GPU measurement)" % world,
             "config": {
-                "workload": "%s inference, 1 frame/step/GPU, synthetic "
+                "workload": "%s inference, %d frames/step/GPU, synthetic "
                             "HDL-64E-shaped cloud preset '%s' (%d seeded "
                             "frames cycled), seeded Xavier weights"
-                            % (args.config, args.preset, args.frames),
+                            % (args.config, fps_h, args.preset, args.frames),
                 # statistics over exactly the world*steps timed frames
                 "N": n_pts, "K": st["K"], "E0": st["E0"], "E1": st["E1"],
                 "frames_timed": st["frames"],
-                "frames_per_gpu_per_step": 1,
+                "frames_per_gpu_per_step": fps_h,
+                "ms_per_frame_per_gpu": elapsed / (args.steps * fps_h) * 1e3,
+                "timed_region_s": elapsed,
+                # every barrier-bracketed region of exactly --steps steps
+                # (max over ranks each); the headline is the first
+                "repeat_ms_per_step": {
+                    "n": len(rep_ms), "min": min(rep_ms),
+                    "median": float(np.median(rep_ms)), "max": max(rep_ms),
+                    "all": rep_ms},
+                "host_enqueue_ms_per_frame": enqueue_ms_h,
+                "host_enqueue_note": "Python time to enqueue one frame "
+                    "(graph build + GNN, ~110 C-ABI launches) with nothing "
+                    "read back, max over ranks; the device needs "
+                    "ms_per_frame_per_gpu, the ratio is the host's headroom",
+                "cpu_affinity": getattr(args, "cpu_affinity", None),
                 "sizes": "host-read (two waits per frame in the graph "
                          "builder)" if args.host_sized else
                          "capacity form: K, E0, E1 stay on the device, one "

@@ -360,6 +360,7 @@ class InferenceEngine(object):
         for s in streams:
             s.wait_stream(cur)
         pending = []
+        t_enq = time.perf_counter()
         if gnn_priority:
             # tested negative (tools/sessions/r03_s33.sh): frame i's
             # graph build on stream i % n as before, its message passing on a
@@ -402,6 +403,9 @@ class InferenceEngine(object):
                     pending.append(self.run_frame_deferred(xyz, intensity))
         for s in streams:
             cur.wait_stream(s)
+        # host time spent enqueuing (no device wait is part of it unless the
+        # launch queues filled up): bench.py reports it per frame
+        self.last_enqueue_s = time.perf_counter() - t_enq
         live = [f for f in pending if f.counts is not None]
         host = torch.stack([f.counts.tensor for f in live]).tolist() \
             if live else []

@@ -69,3 +69,36 @@ def test_two_ranks_on_one_gpu_gloo_dry_run():
     """The same worker with both ranks on cuda:0 and gloo collectives: what a
     one-GPU box can execute of the two-rank step (everything but RCCL)."""
     _run(1, "gloo")
+
+
+def test_bench_two_ranks_real_engine_on_one_gpu():
+    """`bench.py --gpus 2` with the REAL engine (PGNN_BENCH_ONE_GPU=1: both
+    ranks on cuda:0, gloo for the rank plumbing): frame sharding, the barrier
+    + max-over-ranks timing, the repeat spread, the host-enqueue figure and
+    the per-rank CPU binding all execute on hardware; only RCCL is absent
+    (inference needs no collective on the data path).  The line marks itself
+    as a test-mode line."""
+    env = dict(os.environ, PGNN_BENCH_ONE_GPU="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    root = os.path.dirname(HERE)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2",
+           "--steps", "3", "--warmup", "1", "--frames-per-step", "4",
+           "--repeats", "2", "--preset", "car", "--frames", "2",
+           "--no-roofline", "--no-cpu-baseline", "--no-capture"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    r = lines[0]
+    c = r["config"]
+    assert r["n_gpus"] == 2 and "TEST MODE" in r["data"]
+    assert c["distributed"] == {"world_size": 2, "backend": "gloo"}
+    assert c["frames_per_gpu_per_step"] == 4
+    assert c["frames_timed"] == 2 * 3 * 4          # both ranks' frames
+    assert c["repeat_ms_per_step"]["n"] == 2
+    assert c["host_enqueue_ms_per_frame"] > 0
+    assert c["cpu_affinity"]["bound"]
+    assert r["value"] > 0 and r["dtype"] == "f32"
+    assert abs(r["value"] - 2 * 3 * 4 / (r["ms_per_step"] * 3e-3)) \
+        < 1e-6 * r["value"]

@@ -217,10 +217,50 @@ def test_bench_self_launches_its_ranks():
     r = lines[0]
     assert r["n_gpus"] == 2 and r["steps"] == 6 and r["warmup"] == 2
     assert r["config"]["distributed"] == {"world_size": 2, "backend": "gloo"}
-    assert r["config"]["frames_timed"] == 12          # all ranks' frames
+    # 8 frames per GPU per step at every N (weak scaling), all ranks' frames
+    assert r["config"]["frames_per_gpu_per_step"] == 8
+    assert r["config"]["frames_timed"] == 2 * 6 * 8
     assert r["data"] == "stub" and r["scaling"] == "weak"
-    # whole-job value: 2 ranks x 6 steps over the slowest rank's time
-    assert abs(r["value"] - 2 * 6 / (r["ms_per_step"] * 6e-3)) < 1e-6 * r["value"]
+    # whole-job value: 2 ranks x 6 steps x 8 frames over the slowest rank's
+    # time of the FIRST barrier-bracketed region; the other regions are spread
+    assert abs(r["value"] - 2 * 6 * 8 / (r["ms_per_step"] * 6e-3)) \
+        < 1e-6 * r["value"]
+    rep = r["config"]["repeat_ms_per_step"]
+    assert rep["n"] == 5 and len(rep["all"]) == 5
+    assert rep["all"][0] == pytest.approx(r["ms_per_step"])
+    assert rep["min"] <= rep["median"] <= rep["max"]
+    assert r["config"]["timed_region_s"] == pytest.approx(
+        r["ms_per_step"] * 6e-3)
+
+
+def test_bench_rank_binding_splits_cpus_without_numa_info():
+    """bench.bind_rank_to_numa: with no NUMA node reported for the GPU (this
+    container has none) the allowed CPUs are split evenly by local rank --
+    disjoint, covering sets -- and the process really is bound."""
+    import bench
+
+    class _NoGpu(object):
+        class cuda(object):
+            @staticmethod
+            def get_device_properties(i):
+                raise RuntimeError("no GPU here")
+    before = os.sched_getaffinity(0)
+    try:
+        seen = []
+        for r in range(2):
+            os.sched_setaffinity(0, before)
+            info = bench.bind_rank_to_numa(_NoGpu, r, 2)
+            if len(before) < 2:
+                pytest.skip("one CPU")
+            assert info["bound"] and info["numa_node"] == -1
+            got = os.sched_getaffinity(0)
+            assert len(got) == info["n_cpus"] and got <= before
+            seen.append(got)
+        assert not (seen[0] & seen[1])
+        assert (seen[0] | seen[1]) == before
+        assert bench._parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+    finally:
+        os.sched_setaffinity(0, before)
 
 
 def test_bench_under_an_external_launcher_and_mismatch():
