@@ -480,6 +480,58 @@ int pgnn_vertex_pre_edge_fwd_dyn(const float *h, int64_t ld_h, int32_t c,
                                  const pgnn_dyn_count *n_vertices,
                                  void *stream);
 
+/* Two per-vertex stages in ONE launch (small K: one 8-wave workgroup per
+ * 16-row tile; PGNN_E_UNSUPPORTED -- having done nothing -- above ~32 rows per
+ * CU or for chains wider than 320, the caller then runs the separate entries).
+ * The reference evaluates them as separate TF ops on either side of an
+ * operator boundary: the END of one layer -- PointSetPooling's output MLP
+ * (gnn.py:279-283) or GraphNetAutoCenter's update MLP + residual
+ * (gnn.py:367-372) -- and the START of the next GraphNetAutoCenter
+ * (gnn.py:341-356: offset MLP, Q, P; see pgnn_vertex_pre_edge_fwd).
+ *   y = front chain(x[:, :nx]) (+ residual)      -> [n_vertices, ld_y], always
+ *                                                   written: it is the first
+ *                                                   operator's output
+ *   then pgnn_vertex_pre_edge_fwd on h = y.
+ * Identical arithmetic to pgnn_mlp_fwd followed by pgnn_vertex_pre_edge_fwd
+ * (the same MFMA sequence per output element): bit-identical results.
+ * `agg` (the NEXT edge stage's aggregation buffer) must not alias `x`.       */
+int pgnn_vertex_update_pre_edge_fwd(
+    const float *x, int64_t ld_x, int32_t nx,
+    const pgnn_fc_layer *front_layers_host, int32_t n_front,
+    const float *residual, int64_t ld_res, float *y, int64_t ld_y, int32_t c,
+    const float *xyz, const pgnn_fc_layer *offset_layers_host,
+    int32_t n_offset_layers, const pgnn_fc_layer *p_layer_host, const float *wx,
+    int64_t n_vertices, float *P, float *Q, int64_t ld_pq, float *agg,
+    int64_t ld_agg, void *stream);
+int pgnn_vertex_update_pre_edge_fwd_dyn(
+    const float *x, int64_t ld_x, int32_t nx,
+    const pgnn_fc_layer *front_layers_host, int32_t n_front,
+    const float *residual, int64_t ld_res, float *y, int64_t ld_y, int32_t c,
+    const float *xyz, const pgnn_fc_layer *offset_layers_host,
+    int32_t n_offset_layers, const pgnn_fc_layer *p_layer_host, const float *wx,
+    int64_t vertices_cap, float *P, float *Q, int64_t ld_pq, float *agg,
+    int64_t ld_agg, const pgnn_dyn_count *n_vertices, void *stream);
+
+/* The same for the model's last operator boundary: GraphNetAutoCenter's update
+ * MLP + residual (gnn.py:367-372) followed by a second chain on its output --
+ * the fused ClassAwarePredictor heads (gnn.py:133-163):
+ *   y = front chain(x[:, :nx]) (+ residual)   -> [n_rows, ld_y], always written
+ *   out = back chain(y[:, :ny])               -> [n_rows, ld_out]
+ * = pgnn_mlp_fwd twice, bit-identical.  Same size limits as above.            */
+int pgnn_mlp2_fwd(const float *x, int64_t ld_x, int32_t nx,
+                  const pgnn_fc_layer *front_layers_host, int32_t n_front,
+                  const float *residual, int64_t ld_res, float *y, int64_t ld_y,
+                  int32_t ny, const pgnn_fc_layer *back_layers_host,
+                  int32_t n_back, float *out, int64_t ld_out, int64_t n_rows,
+                  void *stream);
+int pgnn_mlp2_fwd_dyn(const float *x, int64_t ld_x, int32_t nx,
+                      const pgnn_fc_layer *front_layers_host, int32_t n_front,
+                      const float *residual, int64_t ld_res, float *y,
+                      int64_t ld_y, int32_t ny,
+                      const pgnn_fc_layer *back_layers_host, int32_t n_back,
+                      float *out, int64_t ld_out, int64_t rows_cap,
+                      const pgnn_dyn_count *rows, void *stream);
+
 /* ---- training step (config 4: models.py:170-311, train.py:135-171,264-297,
  * 375-405, util/tf_util.py:3-43) ------------------------------------------
  * The backward pass needs the per-edge activations, so the training forward

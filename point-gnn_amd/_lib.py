@@ -201,6 +201,24 @@ _SIGNATURES = {
                                          ctypes.POINTER(FcLayer), c_vp, c_i64,
                                          c_vp, c_vp, c_i64, c_vp, c_i64,
                                          c_vp]),
+    "pgnn_vertex_update_pre_edge_fwd": (c_i32, [
+        c_vp, c_i64, c_i32, ctypes.POINTER(FcLayer), c_i32, c_vp, c_i64, c_vp,
+        c_i64, c_i32, c_vp, ctypes.POINTER(FcLayer), c_i32,
+        ctypes.POINTER(FcLayer), c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64,
+        c_vp]),
+    "pgnn_vertex_update_pre_edge_fwd_dyn": (c_i32, [
+        c_vp, c_i64, c_i32, ctypes.POINTER(FcLayer), c_i32, c_vp, c_i64, c_vp,
+        c_i64, c_i32, c_vp, ctypes.POINTER(FcLayer), c_i32,
+        ctypes.POINTER(FcLayer), c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64,
+        ctypes.POINTER(DynCount), c_vp]),
+    "pgnn_mlp2_fwd": (c_i32, [
+        c_vp, c_i64, c_i32, ctypes.POINTER(FcLayer), c_i32, c_vp, c_i64, c_vp,
+        c_i64, c_i32, ctypes.POINTER(FcLayer), c_i32, c_vp, c_i64, c_i64,
+        c_vp]),
+    "pgnn_mlp2_fwd_dyn": (c_i32, [
+        c_vp, c_i64, c_i32, ctypes.POINTER(FcLayer), c_i32, c_vp, c_i64, c_vp,
+        c_i64, c_i32, ctypes.POINTER(FcLayer), c_i32, c_vp, c_i64, c_i64,
+        ctypes.POINTER(DynCount), c_vp]),
     # training step
     "pgnn_pack_fc_device": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp,
                                     c_vp]),
@@ -353,6 +371,9 @@ def load():
         check(lib.pgnn_set_tunable(k.strip().encode(), int(v)),
               "PGNN_TUNE " + kv)
     return lib
+
+
+E_UNSUPPORTED = -3   # PGNN_E_UNSUPPORTED of include/pointgnn_hip.h
 
 
 def check(rc, what=""):

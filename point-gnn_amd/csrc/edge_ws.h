@@ -530,6 +530,9 @@ __global__ __launch_bounds__(64 * kWsWaves) void edge_ws_kernel(EdgeWsArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int slice = blockIdx.x % a.xcds;
   const int local = blockIdx.x / a.xcds;
+  // profiling builds only: when this wave entered the kernel (constant
+  // 100 MHz clock), i.e. before the weights go to LDS
+  const long long rt_entry = a.ts ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
   int grp = 0;
   while (grp + 1 < a.groups && local >= a.wg0[grp + 1]) ++grp;
   const int t0 = a.tile0[grp];
@@ -537,10 +540,29 @@ __global__ __launch_bounds__(64 * kWsWaves) void edge_ws_kernel(EdgeWsArgs a) {
   // this group's weight fragments -> LDS, [q][t][lane] float4 (1 KiB each),
   // and its bias values
   {
+    // Every wave requests ALL its fragments (<= 17 dwordx4 per lane) before
+    // the first LDS write: as a plain copy loop hipcc emits load ->
+    // s_waitcnt vmcnt(0) -> ds_write per fragment, 17 dependent round trips
+    // to L2 / HBM with 2048 waves asking at once -- ~25 us of a 985 us kernel
+    // in which no SIMD had anything to do (tools/ws_timeline.py: the last wave
+    // ends 40 us before the kernel does).  Unconditional clamped requests,
+    // the validity test at the write.
     const v4f *__restrict__ src = reinterpret_cast<const v4f *>(a.wp);
-    for (int f = wave; f < KQ * ntg; f += kWsWaves) {
-      const int q = f / ntg, t = f - q * ntg;
-      wl[(size_t)f * 64 + lane] = src[((size_t)q * a.nt + t0 + t) * 64 + lane];
+    constexpr int PER = (KQ * NTMAX + kWsWaves - 1) / kWsWaves;
+    const int n_frag = KQ * ntg;
+    v4f tmp[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int f = wave + i * kWsWaves;
+      const int fc = f < n_frag ? f : 0;
+      const int q = fc / ntg, t = fc - q * ntg;
+      tmp[i] = src[((size_t)q * a.nt + t0 + t) * 64 + lane];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int f = wave + i * kWsWaves;
+      if (f < n_frag) wl[(size_t)f * 64 + lane] = tmp[i];
     }
     if ((int)threadIdx.x < 16 * ntg)
       bias_lds[threadIdx.x] =
@@ -577,8 +599,8 @@ __global__ __launch_bounds__(64 * kWsWaves) void edge_ws_kernel(EdgeWsArgs a) {
       tsw[0] = __builtin_readcyclecounter();
       tsw[2] = __builtin_amdgcn_s_memrealtime();  // constant 100 MHz
       tsw[4] = tile_last - tile_first;
-      tsw[5] = ntg;
-      tsw[6] = slice;
+      tsw[5] = ntg + 100 * slice;
+      tsw[6] = rt_entry;
     }
   }
   int stamped = 0;

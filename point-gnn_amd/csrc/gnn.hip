@@ -221,6 +221,70 @@ __device__ __forceinline__ void consume_rows(const float *__restrict__ stage,
   }
 }
 
+// ---- 16-row tiles of the 8-wave K-row kernels (512 threads) -------------------
+// Thread (r = tid >> 5, c0 = tid & 31) owns columns c0, c0 + 32, ... of tile row
+// r: ten steps cover the 320 columns a layer pass can produce.  Every phase
+// that touches HBM issues ALL its loads before its first store.  The plain
+// loops these replace (`y[i] = stage[i] + res[i]` over a strided index) compile
+// to one load -> wait -> store round trip per element -- the compiler cannot
+// move a load of `res` above a store to `y` it cannot prove disjoint -- and ten
+// dependent round trips (~1.5 us each) per phase were most of a 28 us kernel
+// whose MFMA work is 10 us (tools/krow_bench.py).
+constexpr int kRowSteps = 10;  // 10 x 32 = 320 columns = kMaxTilesPerPass tiles
+
+// y[row0 + r][col0 + c] = stage[r][c] (+ res[row0 + r][col0 + c]), c < ncols <= 320
+__device__ __forceinline__ void consume_rows16(const float *__restrict__ stage,
+                                               int ld, int64_t row0,
+                                               int rows_valid, int col0,
+                                               int ncols, const RowsArgs &ra) {
+  const int r = threadIdx.x >> 5, c0 = threadIdx.x & 31;
+  const int64_t row = row0 + (r < rows_valid ? r : rows_valid - 1);
+  float add[kRowSteps];
+  if (ra.res) {
+    const float *__restrict__ rr = ra.res + row * ra.ldres + col0;
+#pragma unroll
+    for (int j = 0; j < kRowSteps; ++j) {
+      const int c = c0 + 32 * j;
+      add[j] = rr[c < ncols ? c : ncols - 1];  // unconditional, clamped
+    }
+  }
+  float *__restrict__ yr = ra.y + row * ra.ldy + col0;
+#pragma unroll
+  for (int j = 0; j < kRowSteps; ++j) {
+    const int c = c0 + 32 * j;
+    if (r < rows_valid && c < ncols) {
+      float v = stage[r * ld + c];
+      if (ra.res) v += add[j];
+      yr[c] = v;
+    }
+  }
+}
+
+// tile[r][c] = c < nx ? x[row0 + r][c] : 0 for c < kc (rows past the end: 0);
+// 320 columns per round, all of a round's loads in flight before its LDS
+// writes (wider inputs -- ped_cyl's 512 -- take a second round)
+__device__ __forceinline__ void load_rows16(const float *__restrict__ x,
+                                            int64_t ldx, int nx, float *tile,
+                                            int ld0, int kc, int64_t row0,
+                                            int rows_valid) {
+  const int r = threadIdx.x >> 5, c0 = threadIdx.x & 31;
+  const float *__restrict__ xr =
+      x + (row0 + (r < rows_valid ? r : rows_valid - 1)) * ldx;
+  for (int cb = 0; cb < kc; cb += 32 * kRowSteps) {
+    float v[kRowSteps];
+#pragma unroll
+    for (int j = 0; j < kRowSteps; ++j) {
+      const int c = cb + c0 + 32 * j;
+      v[j] = xr[c < nx ? c : nx - 1];
+    }
+#pragma unroll
+    for (int j = 0; j < kRowSteps; ++j) {
+      const int c = cb + c0 + 32 * j;
+      if (c < kc) tile[r * ld0 + c] = (r < rows_valid && c < nx) ? v[j] : 0.0f;
+    }
+  }
+}
+
 template <int MSUB, int PRO>
 __global__ __launch_bounds__(256, 2) void fused_mlp_kernel(
     ChainDev chain, int64_t n_rows, RowsArgs ra, PoolArgs pa, EdgeArgs ea,
@@ -843,38 +907,30 @@ __global__ __launch_bounds__(64 * kRowsWaves) void rows_mlp_kernel(
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float *tile = reinterpret_cast<float *>(smem);
   float *stage = stage_off >= 0 ? tile + stage_off : tile;
-  const int lane = threadIdx.x & 63;
+  const int lane_id = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t n_tiles = (n_rows + ROWS - 1) / ROWS;
   const int ld0 = lds_ld(16 * chain.l[0].kq);
   for (int64_t tile_id = blockIdx.x; tile_id < n_tiles; tile_id += gridDim.x) {
+    // (an opaque per-tile copy of the lane id: the per-lane weight addresses
+    // of every layer are loop invariant, and hoisted out of the tile loop they
+    // cost ~100 VGPRs -- spills in the capacity-form kernels)
+    int lane;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(lane) : "v"(lane_id));
     const int64_t row0 = tile_id * ROWS;
     const int rows_valid =
         (int)((n_rows - row0 < ROWS) ? (n_rows - row0) : ROWS);
     const int kc = 16 * chain.l[0].kq;
+    // the first layer's weights and bias travel while the tile is loaded
+    KrowPre pre;
+    krow_prefetch(chain.l[0], 0, wave, lane, pre);
     if (ra.nx2 == 0) {
       // 32 threads per row, columns c0, c0 + 32, ...: every load is
       // UNCONDITIONAL (clamped row / column, select on the value) -- a load
-      // under a predicate is waited for on the spot and the tile's loads
-      // would go out one round trip at a time
+      // under a predicate is waited for on the spot -- and all of them are in
+      // flight before the first LDS write
       static_assert(64 * NW == 32 * ROWS, "one 32-thread group per row");
-      const int r = threadIdx.x >> 5, c0 = threadIdx.x & 31;
-      const float *xr =
-          ra.x + (row0 + (r < rows_valid ? r : rows_valid - 1)) * ra.ldx;
-      for (int cb = 0; cb < kc; cb += 32 * 4) {
-        float v[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int c = cb + c0 + 32 * j;
-          v[j] = xr[c < ra.nx ? c : ra.nx - 1];
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int c = cb + c0 + 32 * j;
-          if (c < kc)
-            tile[r * ld0 + c] = (r < rows_valid && c < ra.nx) ? v[j] : 0.0f;
-        }
-      }
+      load_rows16(ra.x, ra.ldx, ra.nx, tile, ld0, kc, row0, rows_valid);
     } else {
     for (int idx = threadIdx.x; idx < ROWS * kc; idx += 64 * NW) {
       const int r = idx / kc, c = idx - r * kc;
@@ -891,8 +947,8 @@ __global__ __launch_bounds__(64 * kRowsWaves) void rows_mlp_kernel(
     __syncthreads();
     for (int li = 0; li + 1 < chain.n; ++li) {
       const LayerDev &L = chain.l[li];
-      layer_pass_dispatch<1, false, NW>(tile, lds_ld(16 * L.kq), tile,
-                                        lds_ld(16 * L.nt), L, 0, wave, lane);
+      krow_pass(tile, lds_ld(16 * L.kq), tile, lds_ld(16 * L.nt), L, 0, wave,
+                lane, pre, true, chain.l[li + 1], 0);
     }
     const LayerDev &L = chain.l[chain.n - 1];
     const int ld_in = lds_ld(16 * L.kq);
@@ -901,9 +957,10 @@ __global__ __launch_bounds__(64 * kRowsWaves) void rows_mlp_kernel(
       if (tiles > kMaxTilesPerPass) tiles = kMaxTilesPerPass;
       const int ncols = 16 * tiles;
       const int ld_st = lds_ld(ncols);
-      layer_pass_dispatch<1, false, NW>(tile, ld_in, stage, ld_st, L, t0, wave,
-                                        lane);
-      consume_rows<ROWS>(stage, ld_st, row0, rows_valid, 16 * t0, ncols, ra);
+      const bool more = t0 + kMaxTilesPerPass < L.nt;
+      krow_pass(tile, ld_in, stage, ld_st, L, t0, wave, lane, pre, more, L,
+                t0 + kMaxTilesPerPass);
+      consume_rows16(stage, ld_st, row0, rows_valid, 16 * t0, ncols, ra);
       __syncthreads();
     }
   }
@@ -1430,6 +1487,68 @@ struct PreEdgeArgs {
   int ld_tile, ld_scratch;  // LDS leading dimensions
 };
 
+// What vertex_pre_edge_kernel does once the tile holds [h | x | 0] (and the
+// workgroup has met at a barrier): offset chain, Q, P.  Shared with the fused
+// update + pre-edge kernel below.
+__device__ __forceinline__ void pre_edge_tail(const ChainDev &off,
+                                              const LayerDev &pl,
+                                              const PreEdgeArgs &a, float *tile,
+                                              float *scratch, float *stage,
+                                              int64_t row0, int rows_valid,
+                                              int wave, int lane, KrowPre &pre) {
+  // (`pre`: krow_prefetch of the first pass below -- off.l[0], or pl without
+  // an offset chain)
+  // offset chain: first layer reads the h columns of the tile (its packed
+  // weights are zero beyond k_in, so the x columns do not contribute)
+  const float *delta = nullptr;
+  int ld_delta = 0;
+  for (int li = 0; li < off.n; ++li) {
+    const LayerDev &L = off.l[li];
+    const float *in = li == 0 ? tile : scratch;
+    const int ld_in = li == 0 ? a.ld_tile : lds_ld(16 * L.kq);
+    krow_pass(in, ld_in, scratch, lds_ld(16 * L.nt), L, 0, wave, lane, pre,
+              true, li + 1 < off.n ? off.l[li + 1] : pl, 0);
+    delta = scratch;
+    ld_delta = lds_ld(16 * L.nt);
+  }
+  // Q = (x + delta) @ wx, the same expression as offset_apply_kernel; thread
+  // (r, c0) as in consume_rows16, the three wx rows requested up front
+  {
+    const int r = threadIdx.x >> 5, c0 = threadIdx.x & 31;
+    const int ldq = (int)a.ld_pq;  // <= 320
+    const int64_t row = row0 + (r < rows_valid ? r : rows_valid - 1);
+    float x0 = a.xyz[row * 3], x1 = a.xyz[row * 3 + 1], x2 = a.xyz[row * 3 + 2];
+    float w0[kRowSteps], w1[kRowSteps], w2[kRowSteps];
+#pragma unroll
+    for (int j = 0; j < kRowSteps; ++j) {
+      const int c = c0 + 32 * j;
+      const int cc = c < ldq ? c : ldq - 1;
+      w0[j] = a.wx[cc];
+      w1[j] = a.wx[ldq + cc];
+      w2[j] = a.wx[2 * ldq + cc];
+    }
+    if (delta) {
+      x0 = x0 + delta[r * ld_delta];
+      x1 = x1 + delta[r * ld_delta + 1];
+      x2 = x2 + delta[r * ld_delta + 2];
+    }
+    float *__restrict__ qr = a.Q + row * a.ld_pq;
+#pragma unroll
+    for (int j = 0; j < kRowSteps; ++j) {
+      const int c = c0 + 32 * j;
+      if (r < rows_valid && c < ldq)
+        qr[c] = (x0 * w0[j] + x1 * w1[j]) + x2 * w2[j];
+    }
+  }
+  // P = [h, x] @ W1 + b1
+  const int ld_st = lds_ld(16 * pl.nt);
+  krow_pass(tile, a.ld_tile, stage, ld_st, pl, 0, wave, lane, pre, false, pl, 0);
+  RowsArgs ra = {};
+  ra.y = a.P;
+  ra.ldy = a.ld_pq;
+  consume_rows16(stage, ld_st, row0, rows_valid, 0, 16 * pl.nt, ra);
+}
+
 template <bool STRIDE>
 __global__ __launch_bounds__(64 * kRowsWaves) void vertex_pre_edge_kernel(
     ChainDev off, LayerDev pl, PreEdgeArgs a) {
@@ -1438,7 +1557,7 @@ __global__ __launch_bounds__(64 * kRowsWaves) void vertex_pre_edge_kernel(
   float *tile = reinterpret_cast<float *>(smem);      // [16][ld_tile]: [h | x | 0]
   float *scratch = tile + ROWS * a.ld_tile;           // offset-chain activations
   float *stage = scratch + ROWS * a.ld_scratch;       // P before it leaves
-  const int lane = threadIdx.x & 63;
+  const int lane_id = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int64_t n_rows = a.n;
   if (a.n_dev) {
@@ -1450,21 +1569,28 @@ __global__ __launch_bounds__(64 * kRowsWaves) void vertex_pre_edge_kernel(
   // expected count and strides
   for (int64_t row0 = (int64_t)blockIdx.x * ROWS; row0 < n_rows;
        row0 += STRIDE ? (int64_t)gridDim.x * ROWS : n_rows) {
+    // (an opaque per-tile copy of the lane id: the per-lane weight addresses
+    // of every layer are loop invariant, and hoisted out of the tile loop they
+    // cost ~100 VGPRs -- spills in the capacity-form kernels)
+    int lane;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(lane) : "v"(lane_id));
   const int rows_valid =
       (int)((n_rows - row0 < ROWS) ? (n_rows - row0) : ROWS);
   const int kc = 16 * pl.kq;
+  KrowPre pre;
+  krow_prefetch(off.n > 0 ? off.l[0] : pl, 0, wave, lane, pre);
   {
-    // 32 threads per row; unconditional clamped loads, select on the value
-    // (see rows_mlp_kernel)
+    // 32 threads per row; unconditional clamped loads, select on the value,
+    // all in flight before the first LDS write (see load_rows16)
     static_assert(64 * kRowsWaves == 32 * ROWS, "one 32-thread group per row");
     const int r = threadIdx.x >> 5, c0 = threadIdx.x & 31;
     const int64_t rowc = row0 + (r < rows_valid ? r : rows_valid - 1);
-    const float *hr = a.h + rowc * a.ld_h;
-    const float *xr = a.xyz + rowc * 3;
-    for (int cb = 0; cb < kc; cb += 32 * 4) {
-      float v[4];
+    const float *__restrict__ hr = a.h + rowc * a.ld_h;
+    const float *__restrict__ xr = a.xyz + rowc * 3;
+    for (int cb = 0; cb < kc; cb += 32 * kRowSteps) {
+      float v[kRowSteps];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < kRowSteps; ++j) {
         const int c = cb + c0 + 32 * j;
         const int d = c - a.c;
         // the three coordinate columns follow the features
@@ -1473,7 +1599,7 @@ __global__ __launch_bounds__(64 * kRowsWaves) void vertex_pre_edge_kernel(
         v[j] = c < a.c ? hv : xv;
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < kRowSteps; ++j) {
         const int c = cb + c0 + 32 * j;
         if (c < kc)
           tile[r * a.ld_tile + c] =
@@ -1487,41 +1613,246 @@ __global__ __launch_bounds__(64 * kRowsWaves) void vertex_pre_edge_kernel(
       a.agg[row0 * a.ld_agg + idx] = kFloatLowest;
   }
   __syncthreads();
-  // offset chain: first layer reads the h columns of the tile (its packed
-  // weights are zero beyond k_in, so the x columns do not contribute)
-  const float *delta = nullptr;
-  int ld_delta = 0;
-  for (int li = 0; li < off.n; ++li) {
-    const LayerDev &L = off.l[li];
-    const float *in = li == 0 ? tile : scratch;
-    const int ld_in = li == 0 ? a.ld_tile : lds_ld(16 * L.kq);
-    layer_pass_dispatch<1, false, kRowsWaves>(in, ld_in, scratch, lds_ld(16 * L.nt), L, 0,
-                                  wave, lane);
-    delta = scratch;
-    ld_delta = lds_ld(16 * L.nt);
-  }
-  // Q = (x + delta) @ wx, the same expression as offset_apply_kernel
-  for (int idx = threadIdx.x; idx < rows_valid * (int)a.ld_pq; idx += 64 * kRowsWaves) {
-    const int r = idx / (int)a.ld_pq, c = idx - r * (int)a.ld_pq;
-    float x0 = a.xyz[(row0 + r) * 3], x1 = a.xyz[(row0 + r) * 3 + 1],
-          x2 = a.xyz[(row0 + r) * 3 + 2];
-    if (delta) {
-      x0 = x0 + delta[r * ld_delta];
-      x1 = x1 + delta[r * ld_delta + 1];
-      x2 = x2 + delta[r * ld_delta + 2];
-    }
-    a.Q[(row0 + r) * a.ld_pq + c] =
-        (x0 * a.wx[c] + x1 * a.wx[a.ld_pq + c]) + x2 * a.wx[2 * a.ld_pq + c];
-  }
-  // P = [h, x] @ W1 + b1
-  const int ld_st = lds_ld(16 * pl.nt);
-  layer_pass_dispatch<1, false, kRowsWaves>(tile, a.ld_tile, stage, ld_st, pl, 0, wave,
-                                lane);
-  RowsArgs ra = {};
-  ra.y = a.P;
-  ra.ldy = a.ld_pq;
-  consume_rows<ROWS>(stage, ld_st, row0, rows_valid, 0, 16 * pl.nt, ra);
+  pre_edge_tail(off, pl, a, tile, scratch, stage, row0, rows_valid, wave, lane,
+                pre);
   if (STRIDE) __syncthreads();  // the next tile overwrites tile / scratch / stage
+  }
+}
+
+// ---- two vertex stages in ONE launch -------------------------------------------
+// Between two edge stages the per-vertex work is a chain of small K-row MLPs:
+//   update MLP(agg) + h  (gnn.py:367-372, the END of iteration i)
+//   offset MLP, Q, P     (gnn.py:341-356, the START of iteration i + 1)
+// (and, round the model's ends, the pooling stage's output MLP in front of
+// iteration 1 and the predictor heads behind iteration T).  As separate
+// launches each is a 16-row-tile kernel of ~29 us for ~10 us of MFMA work per
+// workgroup -- launch ramp, tile load, result store and drain are paid per
+// launch, and h makes a round trip through HBM in between.  Here ONE 8-wave
+// workgroup per 16-row tile runs the `front` chain (+ residual), writes its
+// result rows y (the operator's output: the next stage's residual, the
+// caller's features) AND keeps them in LDS as the next stage's input.  Every
+// layer pass is the same layer_pass_dispatch call on the same operands as in
+// rows_mlp_kernel / vertex_pre_edge_kernel, so the results are bit for bit
+// those of the separate launches (tested).
+struct FrontArgs {
+  const float *x;   // [n, ldx], nx valid columns: the front chain's input rows
+  int64_t ldx;
+  int nx;
+  const float *res;  // nullable residual, added to the front chain's output
+  int64_t ldres;
+  float *y;          // [n, ldy]: front chain's output rows (padded width)
+  int64_t ldy;
+  int ld_buf;        // floats per row of the LDS tile buffer (max over all passes)
+  int ld_stage;      // ... of the stage buffer
+  long long *ts;     // profiling stamps (tools/krow_timeline.py) or null:
+                     // 16 int64 per workgroup, shader-clock at the phase ends
+};
+
+// front chain on the tile (first layer's input already in `tile` with leading
+// dimension lds_ld(16 kq0)); its last layer's activated output lands in `stage`
+// (`pre`: krow_prefetch of front.l[0]; comes back holding `after`'s, the first
+// layer of whatever follows the front chain)
+__device__ __forceinline__ void front_chain(const ChainDev &front, float *tile,
+                                            float *stage, int ld_stage,
+                                            int wave, int lane, KrowPre &pre,
+                                            const LayerDev after,
+                                            long long *tsw, int &n_stamp) {
+  for (int li = 0; li + 1 < front.n; ++li) {
+    const LayerDev &L = front.l[li];
+    krow_pass(tile, lds_ld(16 * L.kq), tile, lds_ld(16 * L.nt), L, 0, wave,
+              lane, pre, true, front.l[li + 1], 0);
+    if (tsw && n_stamp < 14) {  // profiling: the front chain layer by layer
+      const long long cyc = __builtin_readcyclecounter();
+      if (threadIdx.x == 0) tsw[n_stamp] = cyc;
+      ++n_stamp;
+    }
+  }
+  const LayerDev &L = front.l[front.n - 1];
+  krow_pass(tile, lds_ld(16 * L.kq), stage, ld_stage, L, 0, wave, lane, pre,
+            true, after, 0);
+}
+
+template <bool STRIDE>
+__global__ __launch_bounds__(64 * kRowsWaves) void vertex_update_pre_edge_kernel(
+    ChainDev front, FrontArgs f, ChainDev off, LayerDev pl, PreEdgeArgs a) {
+  constexpr int ROWS = 16;
+  static_assert(64 * kRowsWaves == 32 * ROWS, "one 32-thread group per row");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float *tile = reinterpret_cast<float *>(smem);
+  float *scratch = tile + ROWS * f.ld_buf;
+  float *stage = scratch + ROWS * a.ld_scratch;
+  const int lane_id = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int64_t n_rows = a.n;
+  if (a.n_dev) {
+    const int64_t nd = *a.n_dev;
+    n_rows = nd < n_rows ? nd : n_rows;
+  }
+  const int kc0 = 16 * front.l[0].kq;
+  const int ncols_y = 16 * front.l[front.n - 1].nt;
+  const int kc = 16 * pl.kq;  // >= ncols_y (k_in = c + 3 > c)
+  long long *tsw = f.ts ? f.ts + (int64_t)blockIdx.x * 16 : nullptr;
+  int n_stamp = 0;
+  auto stamp = [&]() {
+    if (tsw && n_stamp < 15) {
+      __builtin_amdgcn_sched_barrier(0);
+      const long long cyc = __builtin_readcyclecounter();
+      if (threadIdx.x == 0) tsw[n_stamp] = cyc;
+      ++n_stamp;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  if (tsw && threadIdx.x == 0) tsw[15] = __builtin_amdgcn_s_memrealtime();
+  for (int64_t row0 = (int64_t)blockIdx.x * ROWS; row0 < n_rows;
+       row0 += STRIDE ? (int64_t)gridDim.x * ROWS : n_rows) {
+    // (an opaque per-tile copy of the lane id: the per-lane weight addresses
+    // of every layer are loop invariant, and hoisted out of the tile loop they
+    // cost ~100 VGPRs -- spills in the capacity-form kernels)
+    int lane;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(lane) : "v"(lane_id));
+    const int rows_valid =
+        (int)((n_rows - row0 < ROWS) ? (n_rows - row0) : ROWS);
+    stamp();  // 0: entry
+    KrowPre pre;
+    krow_prefetch(front.l[0], 0, wave, lane, pre);
+    load_rows16(f.x, f.ldx, f.nx, tile, lds_ld(kc0), kc0, row0, rows_valid);
+    // lowest() rows of the aggregation buffer the NEXT edge kernel maxes into
+    if (a.agg) {
+      for (int idx = threadIdx.x; idx < rows_valid * (int)a.ld_agg;
+           idx += 64 * kRowsWaves)
+        a.agg[row0 * a.ld_agg + idx] = kFloatLowest;
+    }
+    __syncthreads();
+    stamp();  // 1: tile loaded
+    front_chain(front, tile, stage, f.ld_stage, wave, lane, pre,
+                off.n > 0 ? off.l[0] : pl, tsw, n_stamp);
+    stamp();  // front chain done
+    // y = stage (+ residual): out to HBM, and [y[:, :c] | x | 0] into the tile
+    // -- exactly what vertex_pre_edge_kernel would have read back.  Thread
+    // (r, c0) as in consume_rows16; kc <= 320.
+    {
+      const int r = threadIdx.x >> 5, c0 = threadIdx.x & 31;
+      const int64_t row = row0 + (r < rows_valid ? r : rows_valid - 1);
+      float add[kRowSteps];
+      if (f.res) {
+        const float *__restrict__ rr = f.res + row * f.ldres;
+#pragma unroll
+        for (int j = 0; j < kRowSteps; ++j) {
+          const int c = c0 + 32 * j;
+          add[j] = rr[c < ncols_y ? c : ncols_y - 1];
+        }
+      }
+      const float xv0 = a.xyz[row * 3], xv1 = a.xyz[row * 3 + 1],
+                  xv2 = a.xyz[row * 3 + 2];
+      float *__restrict__ yr = f.y + row * f.ldy;
+#pragma unroll
+      for (int j = 0; j < kRowSteps; ++j) {
+        const int c = c0 + 32 * j;
+        if (c < kc) {
+          float v = 0.0f;
+          if (r < rows_valid) {
+            if (c < ncols_y) {
+              float sv = stage[r * f.ld_stage + c];
+              if (f.res) sv += add[j];
+              yr[c] = sv;
+              if (c < a.c) v = sv;
+            }
+            const int d = c - a.c;
+            if (d >= 0 && d < 3) v = d == 0 ? xv0 : (d == 1 ? xv1 : xv2);
+          }
+          tile[r * a.ld_tile + c] = v;
+        }
+      }
+    }
+    __syncthreads();
+    stamp();  // y written, tile refilled
+    pre_edge_tail(off, pl, a, tile, scratch, stage, row0, rows_valid, wave, lane,
+                  pre);
+    stamp();  // offset chain + Q + P
+    if (STRIDE) __syncthreads();
+  }
+  if (tsw && threadIdx.x == 0) tsw[14] = __builtin_amdgcn_s_memrealtime();
+}
+
+// front chain (+ residual) -> y, then a second chain on y -> out (the last
+// update MLP and the predictor heads)
+template <bool STRIDE>
+__global__ __launch_bounds__(64 * kRowsWaves) void vertex_mlp2_kernel(
+    ChainDev front, FrontArgs f, ChainDev back, RowsArgs out, int64_t n_rows,
+    const int32_t *n_dev) {
+  constexpr int ROWS = 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float *tile = reinterpret_cast<float *>(smem);
+  float *stage = tile + ROWS * f.ld_buf;
+  const int lane_id = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (n_dev) {
+    const int64_t nd = *n_dev;
+    n_rows = nd < n_rows ? nd : n_rows;
+  }
+  const int kc0 = 16 * front.l[0].kq;
+  const int ncols_y = 16 * front.l[front.n - 1].nt;
+  const int kcb = 16 * back.l[0].kq;
+  const int ld_b = lds_ld(kcb);
+  for (int64_t row0 = (int64_t)blockIdx.x * ROWS; row0 < n_rows;
+       row0 += STRIDE ? (int64_t)gridDim.x * ROWS : n_rows) {
+    // (an opaque per-tile copy of the lane id: the per-lane weight addresses
+    // of every layer are loop invariant, and hoisted out of the tile loop they
+    // cost ~100 VGPRs -- spills in the capacity-form kernels)
+    int lane;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(lane) : "v"(lane_id));
+    const int rows_valid =
+        (int)((n_rows - row0 < ROWS) ? (n_rows - row0) : ROWS);
+    KrowPre pre;
+    krow_prefetch(front.l[0], 0, wave, lane, pre);
+    load_rows16(f.x, f.ldx, f.nx, tile, lds_ld(kc0), kc0, row0, rows_valid);
+    __syncthreads();
+    int no_stamp = 0;
+    front_chain(front, tile, stage, f.ld_stage, wave, lane, pre, back.l[0],
+                nullptr, no_stamp);
+    // the back chain reads the first out.nx columns of y (its packed weights
+    // are zero beyond k_in; rows_mlp_kernel zero-fills the same way)
+    const int kmax = kcb > ncols_y ? kcb : ncols_y;  // <= 320
+    {
+      const int r = threadIdx.x >> 5, c0 = threadIdx.x & 31;
+      const int64_t row = row0 + (r < rows_valid ? r : rows_valid - 1);
+      float add[kRowSteps];
+      if (f.res) {
+        const float *__restrict__ rr = f.res + row * f.ldres;
+#pragma unroll
+        for (int j = 0; j < kRowSteps; ++j) {
+          const int c = c0 + 32 * j;
+          add[j] = rr[c < ncols_y ? c : ncols_y - 1];
+        }
+      }
+      float *__restrict__ yr = f.y + row * f.ldy;
+#pragma unroll
+      for (int j = 0; j < kRowSteps; ++j) {
+        const int c = c0 + 32 * j;
+        if (c < kmax) {
+          float v = 0.0f;
+          if (r < rows_valid && c < ncols_y) {
+            float sv = stage[r * f.ld_stage + c];
+            if (f.res) sv += add[j];
+            yr[c] = sv;
+            if (c < out.nx) v = sv;
+          }
+          if (c < kcb) tile[r * ld_b + c] = v;
+        }
+      }
+    }
+    __syncthreads();
+    for (int li = 0; li + 1 < back.n; ++li) {
+      const LayerDev &L = back.l[li];
+      krow_pass(tile, lds_ld(16 * L.kq), tile, lds_ld(16 * L.nt), L, 0, wave,
+                lane, pre, true, back.l[li + 1], 0);
+    }
+    const LayerDev &L = back.l[back.n - 1];
+    const int ld_st = lds_ld(16 * L.nt);
+    krow_pass(tile, lds_ld(16 * L.kq), stage, ld_st, L, 0, wave, lane, pre,
+              false, L, 0);
+    consume_rows16(stage, ld_st, row0, rows_valid, 0, 16 * L.nt, out);
+    if (STRIDE) __syncthreads();
   }
 }
 
@@ -1597,6 +1928,239 @@ int pre_edge_impl(
   return 0;
 }
 }  // namespace
+
+namespace {
+// front chain description shared by the two fused entries
+int plan_front(const float *x, int64_t ld_x, int32_t nx,
+               const pgnn_fc_layer *front_layers, int32_t n_front,
+               const float *residual, int64_t ld_res, float *y, int64_t ld_y,
+               Plan &pf, FrontArgs &f) {
+  PGNN_REQUIRE(x && y && nx > 0 && ld_x >= nx, PGNN_E_INVALID,
+               "fused vertex stage: bad front input");
+  int rc = make_plan(front_layers, n_front, nx, pf);
+  if (rc) return rc;
+  const int nt_last = pf.chain.l[n_front - 1].nt;
+  PGNN_REQUIRE(nt_last <= kMaxTilesPerPass, PGNN_E_UNSUPPORTED,
+               "fused vertex stage: front chain wider than 320");
+  PGNN_REQUIRE(ld_y >= 16 * nt_last && (!residual || ld_res >= 16 * nt_last),
+               PGNN_E_INVALID,
+               "fused vertex stage: ld_y / ld_res < padded front width");
+  f.x = x;
+  f.ldx = ld_x;
+  f.nx = nx;
+  f.res = residual;
+  f.ldres = ld_res;
+  f.y = y;
+  f.ldy = ld_y;
+  f.ld_buf = pf.tile_floats_per_row;
+  f.ld_stage = lds_ld(16 * nt_last);
+  f.ts = (long long *)g_mlp_ts;
+  return 0;
+}
+
+int update_pre_edge_impl(
+    const float *x, int64_t ld_x, int32_t nx, const pgnn_fc_layer *front_layers,
+    int32_t n_front, const float *residual, int64_t ld_res, float *y,
+    int64_t ld_y, int32_t c, const float *xyz,
+    const pgnn_fc_layer *offset_layers, int32_t n_offset_layers,
+    const pgnn_fc_layer *p_layer, const float *wx, int64_t n_vertices, float *P,
+    float *Q, int64_t ld_pq, float *agg, int64_t ld_agg, hipStream_t stream,
+    const Dyn &dk) {
+  PGNN_REQUIRE(n_vertices >= 0 && c > 0 && n_offset_layers >= 0 &&
+                   n_offset_layers <= PGNN_MAX_LAYERS && p_layer,
+               PGNN_E_INVALID, "vertex_update_pre_edge: bad argument");
+  if (n_vertices == 0) return 0;
+  PGNN_REQUIRE(xyz && wx && P && Q && (!agg || ld_agg > 0) && agg != x,
+               PGNN_E_INVALID, "vertex_update_pre_edge: null / aliased pointer");
+  // (the 8-wave 16-row kernels are the small-K form: above ~32 rows per CU the
+  // separate launches pick 64-row tiles, which this kernel does not have)
+  PGNN_REQUIRE(expected(dk, n_vertices) <= 32 * (int64_t)device_cu_count(),
+               PGNN_E_UNSUPPORTED, "vertex_update_pre_edge: too many rows");
+  Plan pf;
+  FrontArgs f;
+  int rc = plan_front(x, ld_x, nx, front_layers, n_front, residual, ld_res, y,
+                      ld_y, pf, f);
+  if (rc) return rc;
+  PGNN_REQUIRE(16 * pf.chain.l[n_front - 1].nt >= c &&
+                   16 * pf.chain.l[n_front - 1].nt < c + 16,
+               PGNN_E_INVALID,
+               "vertex_update_pre_edge: front chain must produce c features");
+  Plan pp;
+  rc = make_plan(p_layer, 1, c + 3, pp);
+  if (rc) return rc;
+  const LayerDev pl = pp.chain.l[0];
+  PGNN_REQUIRE(p_layer->k_in == c + 3 && pl.nt <= kMaxTilesPerPass &&
+                   ld_pq == 16 * pl.nt,
+               PGNN_E_INVALID,
+               "vertex_update_pre_edge: P layer must be [c+3 -> n], ld_pq = "
+               "padded n");
+  PGNN_REQUIRE(pl.kq <= kMaxTilesPerPass, PGNN_E_UNSUPPORTED,
+               "vertex_update_pre_edge: more than 317 features");
+  ChainDev off = {};
+  int scratch_ld = lds_ld(16);
+  if (n_offset_layers > 0) {
+    Plan po;
+    rc = make_plan(offset_layers, n_offset_layers, c, po);
+    if (rc) return rc;
+    off = po.chain;
+    PGNN_REQUIRE(offset_layers[0].k_in == c &&
+                     offset_layers[n_offset_layers - 1].n_out >= 3 &&
+                     off.l[0].kq <= pl.kq &&
+                     off.l[n_offset_layers - 1].nt <= kMaxTilesPerPass,
+                 PGNN_E_INVALID,
+                 "vertex_update_pre_edge: offset chain must be [c -> ... -> 3]");
+    for (int i = 0; i < n_offset_layers; ++i) {
+      const int ld = lds_ld(16 * off.l[i].nt);
+      if (ld > scratch_ld) scratch_ld = ld;
+      if (i > 0 && lds_ld(16 * off.l[i].kq) > scratch_ld)
+        scratch_ld = lds_ld(16 * off.l[i].kq);
+    }
+  }
+  PreEdgeArgs a;
+  a.h = nullptr;  // the tile is filled from the front chain, not from HBM
+  a.ld_h = 0;
+  a.c = c;
+  a.xyz = xyz;
+  a.wx = wx;
+  a.n = n_vertices;
+  a.n_dev = dk.dev;
+  a.P = P;
+  a.Q = Q;
+  a.ld_pq = ld_pq;
+  a.agg = agg;
+  a.ld_agg = ld_agg;
+  a.ld_tile = lds_ld(16 * pl.kq);
+  a.ld_scratch = scratch_ld;
+  if (f.ld_buf < a.ld_tile) f.ld_buf = a.ld_tile;
+  if (f.ld_stage < lds_ld(16 * pl.nt)) f.ld_stage = lds_ld(16 * pl.nt);
+  const size_t lds = (size_t)16 * (f.ld_buf + a.ld_scratch + f.ld_stage) * 4;
+  PGNN_REQUIRE(lds <= 160 * 1024, PGNN_E_UNSUPPORTED,
+               "vertex_update_pre_edge: layers too wide for the LDS tile");
+  auto kern = dk.dev ? vertex_update_pre_edge_kernel<true>
+                     : vertex_update_pre_edge_kernel<false>;
+  {
+    const int lrc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
+    if (lrc) return lrc;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)dyn_grid_tiles(dk, n_vertices)),
+                     dim3(64 * kRowsWaves), lds, stream, pf.chain, f, off, pl, a);
+  PGNN_HIP(hipGetLastError());
+  return 0;
+}
+
+int mlp2_impl(const float *x, int64_t ld_x, int32_t nx,
+              const pgnn_fc_layer *front_layers, int32_t n_front,
+              const float *residual, int64_t ld_res, float *y, int64_t ld_y,
+              int32_t ny, const pgnn_fc_layer *back_layers, int32_t n_back,
+              float *out, int64_t ld_out, int64_t n_rows, hipStream_t stream,
+              const Dyn &dk) {
+  PGNN_REQUIRE(n_rows >= 0 && ny > 0, PGNN_E_INVALID, "mlp2: bad sizes");
+  if (n_rows == 0) return 0;
+  PGNN_REQUIRE(out, PGNN_E_INVALID, "mlp2: null output");
+  PGNN_REQUIRE(expected(dk, n_rows) <= 32 * (int64_t)device_cu_count(),
+               PGNN_E_UNSUPPORTED, "mlp2: too many rows for the 16-row kernel");
+  Plan pf;
+  FrontArgs f;
+  int rc = plan_front(x, ld_x, nx, front_layers, n_front, residual, ld_res, y,
+                      ld_y, pf, f);
+  if (rc) return rc;
+  PGNN_REQUIRE(ny <= 16 * pf.chain.l[n_front - 1].nt, PGNN_E_INVALID,
+               "mlp2: ny wider than the front chain's output");
+  Plan pb;
+  rc = make_plan(back_layers, n_back, ny, pb);
+  if (rc) return rc;
+  const int nt_out = pb.chain.l[n_back - 1].nt;
+  PGNN_REQUIRE(nt_out <= kMaxTilesPerPass &&
+                   pb.chain.l[0].kq <= kMaxTilesPerPass,
+               PGNN_E_UNSUPPORTED, "mlp2: back chain wider than 320");
+  PGNN_REQUIRE(ld_out >= 16 * nt_out, PGNN_E_INVALID,
+               "mlp2: ld_out < padded output width");
+  if (f.ld_buf < pb.tile_floats_per_row) f.ld_buf = pb.tile_floats_per_row;
+  if (f.ld_stage < lds_ld(16 * nt_out)) f.ld_stage = lds_ld(16 * nt_out);
+  RowsArgs ro = {};
+  ro.nx = ny;  // columns of y the back chain reads
+  ro.y = out;
+  ro.ldy = ld_out;
+  const size_t lds = (size_t)16 * (f.ld_buf + f.ld_stage) * 4;
+  PGNN_REQUIRE(lds <= 160 * 1024, PGNN_E_UNSUPPORTED,
+               "mlp2: layers too wide for the LDS tile");
+  auto kern = dk.dev ? vertex_mlp2_kernel<true> : vertex_mlp2_kernel<false>;
+  {
+    const int lrc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
+    if (lrc) return lrc;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)dyn_grid_tiles(dk, n_rows)),
+                     dim3(64 * kRowsWaves), lds, stream, pf.chain, f, pb.chain,
+                     ro, n_rows, dk.dev);
+  PGNN_HIP(hipGetLastError());
+  return 0;
+}
+}  // namespace
+
+extern "C" int pgnn_vertex_update_pre_edge_fwd(
+    const float *x, int64_t ld_x, int32_t nx, const pgnn_fc_layer *front_layers,
+    int32_t n_front, const float *residual, int64_t ld_res, float *y,
+    int64_t ld_y, int32_t c, const float *xyz,
+    const pgnn_fc_layer *offset_layers, int32_t n_offset_layers,
+    const pgnn_fc_layer *p_layer, const float *wx, int64_t n_vertices, float *P,
+    float *Q, int64_t ld_pq, float *agg, int64_t ld_agg, void *stream_) {
+  PGNN_GUARD_BEGIN
+  return update_pre_edge_impl(x, ld_x, nx, front_layers, n_front, residual,
+                              ld_res, y, ld_y, c, xyz, offset_layers,
+                              n_offset_layers, p_layer, wx, n_vertices, P, Q,
+                              ld_pq, agg, ld_agg, (hipStream_t)stream_,
+                              dyn_of(nullptr));
+  PGNN_GUARD_END
+}
+
+extern "C" int pgnn_vertex_update_pre_edge_fwd_dyn(
+    const float *x, int64_t ld_x, int32_t nx, const pgnn_fc_layer *front_layers,
+    int32_t n_front, const float *residual, int64_t ld_res, float *y,
+    int64_t ld_y, int32_t c, const float *xyz,
+    const pgnn_fc_layer *offset_layers, int32_t n_offset_layers,
+    const pgnn_fc_layer *p_layer, const float *wx, int64_t vertices_cap,
+    float *P, float *Q, int64_t ld_pq, float *agg, int64_t ld_agg,
+    const pgnn_dyn_count *n_vertices, void *stream_) {
+  PGNN_GUARD_BEGIN
+  PGNN_REQUIRE(n_vertices && n_vertices->dev, PGNN_E_INVALID,
+               "vertex_update_pre_edge_dyn: null count");
+  return update_pre_edge_impl(x, ld_x, nx, front_layers, n_front, residual,
+                              ld_res, y, ld_y, c, xyz, offset_layers,
+                              n_offset_layers, p_layer, wx, vertices_cap, P, Q,
+                              ld_pq, agg, ld_agg, (hipStream_t)stream_,
+                              dyn_of(n_vertices));
+  PGNN_GUARD_END
+}
+
+extern "C" int pgnn_mlp2_fwd(const float *x, int64_t ld_x, int32_t nx,
+                             const pgnn_fc_layer *front_layers, int32_t n_front,
+                             const float *residual, int64_t ld_res, float *y,
+                             int64_t ld_y, int32_t ny,
+                             const pgnn_fc_layer *back_layers, int32_t n_back,
+                             float *out, int64_t ld_out, int64_t n_rows,
+                             void *stream_) {
+  PGNN_GUARD_BEGIN
+  return mlp2_impl(x, ld_x, nx, front_layers, n_front, residual, ld_res, y,
+                   ld_y, ny, back_layers, n_back, out, ld_out, n_rows,
+                   (hipStream_t)stream_, dyn_of(nullptr));
+  PGNN_GUARD_END
+}
+
+extern "C" int pgnn_mlp2_fwd_dyn(const float *x, int64_t ld_x, int32_t nx,
+                                 const pgnn_fc_layer *front_layers,
+                                 int32_t n_front, const float *residual,
+                                 int64_t ld_res, float *y, int64_t ld_y,
+                                 int32_t ny, const pgnn_fc_layer *back_layers,
+                                 int32_t n_back, float *out, int64_t ld_out,
+                                 int64_t rows_cap, const pgnn_dyn_count *rows,
+                                 void *stream_) {
+  PGNN_GUARD_BEGIN
+  PGNN_REQUIRE(rows && rows->dev, PGNN_E_INVALID, "mlp2_dyn: null count");
+  return mlp2_impl(x, ld_x, nx, front_layers, n_front, residual, ld_res, y,
+                   ld_y, ny, back_layers, n_back, out, ld_out, rows_cap,
+                   (hipStream_t)stream_, dyn_of(rows));
+  PGNN_GUARD_END
+}
 
 extern "C" int pgnn_vertex_pre_edge_fwd(
     const float *h, int64_t ld_h, int32_t c, const float *xyz,

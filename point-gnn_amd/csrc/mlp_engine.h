@@ -80,6 +80,17 @@ __device__ __forceinline__ void gemm_tile(const float *__restrict__ tile, int ld
   v4f a[PF][MSUB], b[PF][NT];
   auto fetch = [&](int q, v4f (&fa)[MSUB], v4f (&fb)[NT]) {
     if (q > kq - 1) q = kq - 1;
+#if defined(PGNN_KROW_ABL_NOLOAD)  // timing ablation (wrong results)
+    if constexpr (NW == 8) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) fb[j] = wp[toff[j]];
+    } else
+#elif defined(PGNN_KROW_ABL_SAMEQ)  // timing ablation: every wave the same 1 KiB
+    if constexpr (NW == 8) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) fb[j] = wp[(size_t)q * qstride];
+    } else
+#endif
 #pragma unroll
     for (int j = 0; j < NT; ++j) fb[j] = wp[(size_t)q * qstride + toff[j]];
 #pragma unroll
@@ -104,6 +115,30 @@ __device__ __forceinline__ void gemm_tile(const float *__restrict__ tile, int ld
   // in tools/gemm_loop_bench.hip, but the fused kernels ran 3 % SLOWER with it
   // in a same-box A/B -- 834 -> 863 us for the edge kernel -- so the guarded
   // form stays.)
+  if constexpr (NW == 8) {
+    // The 16-row K-row kernels (rows_mlp_kernel, vertex_*_kernel): 12 MFMAs
+    // per K-group and wave, far less than an L2 round trip, so the prefetch
+    // distance IS the kernel's speed.  With the guarded body below hipcc's
+    // wait-count pass cannot tell how many loads are outstanding at the loop
+    // header (the guards make it path dependent) and emits s_waitcnt vmcnt(0)
+    // there: every PF groups the pipeline drained and a layer pass took ~13 us
+    // for 5 us of MFMA issue.  Branch-free main loop (whole rounds of PF
+    // groups; the prefetch index is clamped, never guarded) + a peeled tail
+    // without loads: the header wait becomes vmcnt(loads of PF - 1 stages).
+    int q = 0;
+    for (; q + PF <= kq; q += PF) {
+#pragma unroll
+      for (int st = 0; st < PF; ++st) {
+        mma(a[st], b[st], 0, 4);
+        fetch(q + st + PF, a[st], b[st]);
+      }
+    }
+    const int rem = kq - q;  // < PF, wave-uniform
+#pragma unroll
+    for (int st = 0; st + 1 < PF; ++st)
+      if (st < rem) mma(a[st], b[st], 0, 4);
+    return;
+  }
   for (int q = 0; q < kq; q += PF) {
 #pragma unroll
     for (int st = 0; st < PF; ++st) {
@@ -702,6 +737,181 @@ __device__ __forceinline__ void layer_pass(const float *in, int ld_in, float *ou
   else
     store_acc<MSUB, NT, NW>(out, ld_out, L, t0, wave, lane, acc);
   __syncthreads();
+}
+
+// ---- layer passes of the 8-wave, 16-row K-row kernels ---------------------------
+// A pass = wait for the first weight fragments (an L2 / HBM round trip),
+// 19 K-groups of MFMAs, barrier, bias loads (another round trip), activated
+// store, barrier.  With 16 rows there are only ~12k cycles of MFMA issue per
+// pass to hide anything behind, and the two exposed round trips were a third
+// of a 24k-cycle pass (tools/krow_timeline.py; ablation without weight loads:
+// 20.7k).  Neither depends on the activations, so both are requested a pass
+// EARLY: `krow_prefetch` asks for a layer's bias values and the weight
+// fragments of its first PGNN_PF1 K-groups; a pass consumes the set requested
+// for it and, right after its own K loop (before its barriers and store),
+// requests the next pass's.  Same MFMA sequence per output element as
+// gemm_tile / store_acc: bit-identical results.
+constexpr int kKrowNT = 3;  // column tiles per wave: 20 tiles over 8 waves
+
+// `b` doubles as the K loop's pipeline registers (stage st, column slot j): a
+// pass consumes and refills it in place and leaves the NEXT pass's first
+// stages in it -- no copies (a member-by-member copy into a local pipeline
+// array is turned into wide vector loads from the struct, which then cannot
+// be promoted out of scratch memory).
+struct KrowPre {
+  v4f b[PGNN_PF1][kKrowNT];
+  float bias[kKrowNT];
+};
+
+__device__ __forceinline__ void krow_prefetch_w(const LayerDev &L, int t0,
+                                                int wave, int lane,
+                                                KrowPre &p) {
+  const v4f *__restrict__ wp = reinterpret_cast<const v4f *>(L.wp) + lane;
+  const int qstride = L.nt * 64;
+#pragma unroll
+  for (int j = 0; j < kKrowNT; ++j) {
+    int t = t0 + wave + 8 * j;
+    if (t > L.nt - 1) t = L.nt - 1;  // clamp: something valid, discarded later
+#pragma unroll
+    for (int st = 0; st < PGNN_PF1; ++st) {
+      const int q = st < L.kq ? st : L.kq - 1;
+      p.b[st][j] = wp[(size_t)q * qstride + t * 64];
+    }
+  }
+}
+
+__device__ __forceinline__ void krow_prefetch_bias(const LayerDev &L, int t0,
+                                                   int wave, int lane,
+                                                   KrowPre &p) {
+  const float *__restrict__ bias = L.wp + (size_t)L.kq * L.nt * 256;
+#pragma unroll
+  for (int j = 0; j < kKrowNT; ++j) {
+    int t = t0 + wave + 8 * j;
+    if (t > L.nt - 1) t = L.nt - 1;
+    p.bias[j] = bias[t * 16 + (lane & 15)];
+  }
+}
+
+__device__ __forceinline__ void krow_prefetch(const LayerDev &L, int t0, int wave,
+                                              int lane, KrowPre &p) {
+  krow_prefetch_w(L, t0, wave, lane, p);
+  krow_prefetch_bias(L, t0, wave, lane, p);
+}
+
+template <int NT>
+__device__ __forceinline__ void layer_pass_krow(const float *in, int ld_in,
+                                                float *out, int ld_out,
+                                                const LayerDev &L, int t0,
+                                                int wave, int lane, KrowPre &pre,
+                                                bool has_next,
+                                                const LayerDev next,
+                                                int next_t0) {
+  constexpr int PF = PGNN_PF1, NW = 8;
+  static_assert(NT <= kKrowNT, "prefetch slots");
+  if constexpr (NT == 0) {
+    // a wave without a column tile in this pass (narrow layers): it only
+    // keeps the workgroup's barriers and the prefetch chain going
+    if (has_next) krow_prefetch_w(next, next_t0, wave, lane, pre);
+    __syncthreads();
+    if (has_next) krow_prefetch_bias(next, next_t0, wave, lane, pre);
+    __syncthreads();
+    return;
+  } else {
+  v4f acc[NT];
+  int toff[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    acc[j] = (v4f){0.f, 0.f, 0.f, 0.f};
+    int t = t0 + wave + NW * j;
+    if (t > L.nt - 1) t = L.nt - 1;
+    toff[j] = t * 64;
+  }
+  const v4f *__restrict__ wp = reinterpret_cast<const v4f *>(L.wp) + lane;
+  const float *arow = in + (lane & 15) * ld_in + 4 * (lane >> 4);
+  const int qstride = L.nt * 64;
+  const int kq = L.kq;
+  v4f a[PF];
+#pragma unroll
+  for (int st = 0; st < PF; ++st)
+    a[st] = *reinterpret_cast<const v4f *>(arow + 16 * (st < kq ? st : kq - 1));
+  int q = 0;
+  for (; q + PF <= kq; q += PF) {
+#pragma unroll
+    for (int st = 0; st < PF; ++st) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+              a[st][s], pre.b[st][j][s], acc[j], 0, 0, 0);
+      int qn = q + st + PF;
+      if (qn > kq - 1) qn = kq - 1;
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        pre.b[st][j] = wp[(size_t)qn * qstride + toff[j]];
+      a[st] = *reinterpret_cast<const v4f *>(arow + 16 * qn);
+    }
+  }
+  const int rem = kq - q;  // < PF, wave-uniform
+#pragma unroll
+  for (int st = 0; st + 1 < PF; ++st) {
+    if (st < rem) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+              a[st][s], pre.b[st][j][s], acc[j], 0, 0, 0);
+    }
+  }
+  // the next pass's first weight fragments: requested now, used two barriers on
+  if (has_next) krow_prefetch_w(next, next_t0, wave, lane, pre);
+  __syncthreads();  // every wave is done reading `in` (in-place overwrite)
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int t = t0 + wave + NW * j;
+    if (t < L.nt && t - t0 < kMaxTilesPerPass) {
+      const int col = t * 16 + (lane & 15);
+      const bool relu = col >= L.relu_from;
+      const float bv = pre.bias[j];
+      float *o = out + (4 * (lane >> 4)) * ld_out + (col - 16 * t0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[j][r] + bv;
+        if (relu) v = v > 0.0f ? v : 0.0f;
+        o[r * ld_out] = v;
+      }
+    }
+  }
+  // ... and its bias values, now that this pass's are used
+  if (has_next) krow_prefetch_bias(next, next_t0, wave, lane, pre);
+  __syncthreads();
+  }
+}
+
+// one pass (<= 320 output columns from column tile t0) of layer L on the
+// 16-row tile; `pre` holds what krow_prefetch requested for (L, t0) and comes
+// back holding the request for (next, next_t0) when has_next.  (`next` by
+// value: a pointer to an element of a by-value kernel argument would force the
+// whole argument struct into scratch memory.)
+__device__ __forceinline__ void krow_pass(const float *in, int ld_in, float *out,
+                                          int ld_out, const LayerDev &L, int t0,
+                                          int wave, int lane, KrowPre &pre,
+                                          bool has_next, const LayerDev next,
+                                          int next_t0) {
+  int tiles = L.nt - t0;
+  if (tiles > kMaxTilesPerPass) tiles = kMaxTilesPerPass;
+  // column tiles of THIS wave (t0 + wave + 8 j < L.nt; wave-uniform): 19 tiles
+  // are 3-3-3-2-2-2-2-2, i.e. 5-5-5-4 per SIMD.  (With ceil(tiles / 8) for
+  // every wave the five waves without a third tile computed a clamped one and
+  // threw it away: 6 tiles of MFMA issue per SIMD instead of 5.)
+  const int ntw = tiles / 8 + (wave < tiles % 8 ? 1 : 0);
+  switch (ntw) {
+    case 0: layer_pass_krow<0>(in, ld_in, out, ld_out, L, t0, wave, lane, pre, has_next, next, next_t0); break;
+    case 1: layer_pass_krow<1>(in, ld_in, out, ld_out, L, t0, wave, lane, pre, has_next, next, next_t0); break;
+    case 2: layer_pass_krow<2>(in, ld_in, out, ld_out, L, t0, wave, lane, pre, has_next, next, next_t0); break;
+    default: layer_pass_krow<3>(in, ld_in, out, ld_out, L, t0, wave, lane, pre, has_next, next, next_t0); break;
+  }
 }
 
 template <int MSUB, bool TRANSPOSED, int NW = 4>

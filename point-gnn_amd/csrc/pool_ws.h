@@ -292,8 +292,22 @@ __global__ __launch_bounds__(64 * kWsWaves) void pool_ws_kernel(PoolWsArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   {
     const v4f *__restrict__ src = reinterpret_cast<const v4f *>(a.wp);
-    for (int f = wave; f < KQ * NT; f += kWsWaves)
-      wl[(size_t)f * 64 + lane] = src[(size_t)f * 64 + lane];
+    // all 19 fragment requests of a wave in flight before the first LDS
+    // write (see edge_ws_kernel: the plain copy loop is 19 dependent round
+    // trips)
+    constexpr int PER = (KQ * NT + kWsWaves - 1) / kWsWaves;
+    v4f tmp[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int f = wave + i * kWsWaves;
+      tmp[i] = src[(size_t)(f < KQ * NT ? f : 0) * 64 + lane];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int f = wave + i * kWsWaves;
+      if (f < KQ * NT) wl[(size_t)f * 64 + lane] = tmp[i];
+    }
     if ((int)threadIdx.x < 16 * NT)
       bias_lds[threadIdx.x] = a.wp[(size_t)KQ * NT * 256 + threadIdx.x];
   }

@@ -30,6 +30,7 @@ from . import _lib
 from .weights import mlp_names
 
 __all__ = ["PointSetPooling", "GraphNetAutoCenter", "ClassAwarePredictor",
+           "fuse_vertex_stages",
            "multi_layer_neural_network_fn", "multi_layer_fc_fn",
            "graph_scatter_max_fn", "ParamStore", "parameters",
            "variable_scope", "padded_width"]
@@ -119,6 +120,8 @@ class _State(threading.local):
     def __init__(self):
         self.store = None
         self.scope = []
+        self.fuse = False      # fuse_vertex_stages() active
+        self.pending = None    # an operator's deferred per-vertex tail
 
 
 _state = _State()
@@ -145,6 +148,78 @@ def variable_scope(name):
 
 def _scope(*suffix):
     return '/'.join(list(_state.scope) + list(suffix))
+
+
+# --------------------------------------------------------------------------
+# fusing the per-vertex stages across operator boundaries
+# --------------------------------------------------------------------------
+class _Pending(object):
+    """The tail of an operator that has not been launched yet:
+    y = chain(x[:, :nx]) (+ residual).  `y` is allocated (and already returned
+    to the caller); the operator that receives it as its input launches the
+    tail TOGETHER with its own per-vertex head
+    (pgnn_vertex_update_pre_edge_fwd / pgnn_mlp2_fwd), anything else launches
+    it on its own (`_flush_pending`)."""
+    __slots__ = ('chain', 'x', 'nx', 'residual', 'count', 'y')
+
+
+@contextlib.contextmanager
+def fuse_vertex_stages(enabled=True):
+    """Inside this context PointSetPooling / GraphNetAutoCenter do not launch
+    their last per-vertex MLP (output MLP; update MLP + residual) themselves:
+    it runs in the same launch as the per-vertex head of the operator that
+    consumes the result (the next GraphNetAutoCenter's offset MLP / Q / P, the
+    predictor's heads) -- half the K-row launches of a frame, and h stays in
+    LDS between the two.  Results are bit-identical.  The returned tensor is
+    written by that later launch: a caller that hands it to anything but the
+    next operator must leave the context first (it flushes on exit).
+    models.MultiLayerFastLocalGraphModelV2.predict wraps its layer loop in
+    it."""
+    prev = _state.fuse
+    _flush_pending()
+    _state.fuse = bool(enabled)
+    try:
+        yield
+    finally:
+        _flush_pending()
+        _state.fuse = prev
+
+
+def _flush_pending():
+    p, _state.pending = _state.pending, None
+    if p is not None:
+        mlp_forward(p.chain, p.x, p.nx, residual=p.residual, count=p.count,
+                    out=p.y)
+
+
+def _take_pending(t):
+    """The deferred tail whose output IS `t` (else None, after launching
+    whatever was pending on its own)."""
+    p = _state.pending
+    if p is not None and p.y is t:
+        _state.pending = None
+        return p
+    _flush_pending()
+    return None
+
+
+def _finish_rows(chain, x, nx, residual=None, count=None):
+    """An operator's last per-vertex MLP: launched now, or deferred to the
+    consumer inside fuse_vertex_stages()."""
+    if not _state.fuse:
+        return mlp_forward(chain, x, nx, residual=residual, count=count)
+    _flush_pending()
+    if count is None:
+        count = _lib.count_of(x)
+    p = _Pending()
+    p.chain, p.x, p.nx, p.residual, p.count = chain, _as_f32(x), int(nx), \
+        residual, count
+    p.y = torch.empty((int(x.shape[0]), padded_width(chain.n_out)),
+                      dtype=torch.float32, device=x.device)
+    if count is not None:
+        _lib.tag_count(p.y, count)
+    _state.pending = p
+    return p.y
 
 
 def _store():
@@ -191,7 +266,8 @@ def _as_i32(t):
     return t
 
 
-def mlp_forward(chain, x, nx, x2=None, nx2=0, residual=None, count=None):
+def mlp_forward(chain, x, nx, x2=None, nx2=0, residual=None, count=None,
+                out=None):
     """y = chain(concat(x[:, :nx], x2[:, :nx2])) (+ residual); returns a
     [rows, padded_width(n_out)] tensor (pad columns are zero).  `count` (a
     _lib.DeviceCount; default: the one `x` is tagged with): capacity form --
@@ -202,7 +278,8 @@ def mlp_forward(chain, x, nx, x2=None, nx2=0, residual=None, count=None):
     x = _as_f32(x)
     rows = int(x.shape[0])
     out_w = padded_width(chain.n_out)
-    y = torch.empty((rows, out_w), dtype=torch.float32, device=x.device)
+    y = out if out is not None else \
+        torch.empty((rows, out_w), dtype=torch.float32, device=x.device)
     if x2 is not None:
         x2 = _as_f32(x2)
     if residual is not None:
@@ -231,6 +308,7 @@ def multi_layer_neural_network_fn(features, Ks=(64, 32, 64), is_logits=False,
     current variable scope.  Returns [rows, padded_width(Ks[-1])]."""
     _check_kinds(activation_type, normalization_type)
     assert features.dim() == 2
+    _flush_pending()
     store = _store()
     chain = _relu_chain(store, _scope(), list(Ks), is_logits)
     return mlp_forward(chain, features, chain.k_in)
@@ -360,6 +438,7 @@ class PointSetPooling(object):
         [K,1], set_indices [S,2] (point, set) -> [K, padded_width(out)]."""
         _check_kinds(point_MLP_activation_type, point_MLP_normalization_type)
         _check_kinds(output_MLP_activation_type, output_MLP_normalization_type)
+        _flush_pending()
         lib = _lib.load()
         store = _store()
         with variable_scope('extract_vertex_features'):
@@ -395,7 +474,7 @@ class PointSetPooling(object):
         with variable_scope('combined_features'):
             out_chain = _relu_chain(store, _scope(),
                                     list(output_MLP_depth_list), False)
-        return mlp_forward(out_chain, agg, point_chain.n_out, count=cnt_k)
+        return _finish_rows(out_chain, agg, point_chain.n_out, count=cnt_k)
 
 
 # when set to a list, every GraphNetAutoCenter call appends its (P, Q) per-vertex
@@ -431,6 +510,9 @@ class GraphNetAutoCenter(object):
         [K, padded_width(C)]."""
         _check_kinds(edge_MLP_activation_type, edge_MLP_normalization_type)
         _check_kinds(update_MLP_activation_type, update_MLP_normalization_type)
+        # the producer's deferred tail (fuse_vertex_stages): launched together
+        # with this operator's per-vertex head below
+        pend = _take_pending(input_vertex_features)
         lib = _lib.load()
         store = _store()
         scope = _scope()
@@ -491,7 +573,29 @@ class GraphNetAutoCenter(object):
                     off_chain.n if off_chain is not None else 0, p_chain.array,
                     _lib.ptr(wx_dev), k, _lib.ptr(p), _lib.ptr(q), wq,
                     _lib.ptr(agg), agg.stride(0))
-        if cnt_k is None:
+        if pend is not None:
+            res = pend.residual
+            front = (_lib.ptr(pend.x), pend.x.stride(0), pend.nx,
+                     pend.chain.array, pend.chain.n, _lib.ptr(res),
+                     res.stride(0) if res is not None else 0, _lib.ptr(h),
+                     h.stride(0))
+            if cnt_k is None:
+                rc = lib.pgnn_vertex_update_pre_edge_fwd(
+                    *(front + pre_args[2:]), st)
+            else:
+                rc = lib.pgnn_vertex_update_pre_edge_fwd_dyn(
+                    *(front + pre_args[2:]), cnt_k.arg(), st)
+            if rc == _lib.E_UNSUPPORTED:
+                # too many rows / too wide for the one-launch form: the
+                # producer's tail on its own, then the plain head below
+                mlp_forward(pend.chain, pend.x, pend.nx, residual=res,
+                            count=pend.count, out=pend.y)
+                pend = None
+            else:
+                _lib.check(rc, "pgnn_vertex_update_pre_edge_fwd")
+        if pend is not None:
+            pass
+        elif cnt_k is None:
             _lib.check(lib.pgnn_vertex_pre_edge_fwd(*pre_args, st),
                        "pgnn_vertex_pre_edge_fwd")
         else:
@@ -520,8 +624,8 @@ class GraphNetAutoCenter(object):
                              device=h.device)
             hp[:, :h.shape[1]] = h
             h = hp
-        return mlp_forward(upd_chain, agg, rest.n_out, residual=h,
-                           count=cnt_k)
+        return _finish_rows(upd_chain, agg, rest.n_out, residual=h,
+                            count=cnt_k)
 
 
 class ClassAwarePredictor(object):
@@ -547,6 +651,7 @@ class ClassAwarePredictor(object):
         """features [K, >=C] -> (logits [K, num_classes], box_encodings
         [K, num_classes, box_encoding_len])."""
         _check_kinds(activation_type, normalization_type)
+        pend = _take_pending(features)
         store = _store()
         scope = _scope('predictor')
         cls_ks, loc_ks = self._ks(self._cls_fn), self._ks(self._loc_fn)
@@ -607,12 +712,45 @@ class ClassAwarePredictor(object):
         boxes = torch.empty((f.shape[0], nc, bl), dtype=torch.float32,
                             device=f.device)
         for has_cls, lids, base, chain in chains:
-            y = mlp_forward(chain, f, c, count=cnt)
+            y = None
+            if pend is not None:
+                # the producer's update MLP + residual and this group of heads
+                # in one launch (pgnn_mlp2_fwd); it writes f as well
+                y = self._fused_heads(pend, f, c, chain, cnt)
+                if y is None:
+                    mlp_forward(pend.chain, pend.x, pend.nx,
+                                residual=pend.residual, count=pend.count,
+                                out=pend.y)
+                pend = None
+            if y is None:
+                y = mlp_forward(chain, f, c, count=cnt)
             if has_cls:
                 logits = y[:, :nc]
             blk = y[:, base:base + 8 * len(lids)].reshape(-1, len(lids), 8)
             boxes[:, lids[0]:lids[0] + len(lids), :] = blk[:, :, :bl]
         return _lib.tag_count(logits, cnt), _lib.tag_count(boxes, cnt)
+
+
+    @staticmethod
+    def _fused_heads(pend, f, c, chain, cnt):
+        lib = _lib.load()
+        res = pend.residual
+        rows = int(f.shape[0])
+        y = torch.empty((rows, padded_width(chain.n_out)),
+                        dtype=torch.float32, device=f.device)
+        args = (_lib.ptr(pend.x), pend.x.stride(0), pend.nx, pend.chain.array,
+                pend.chain.n, _lib.ptr(res),
+                res.stride(0) if res is not None else 0, _lib.ptr(f),
+                f.stride(0), int(c), chain.array, chain.n, _lib.ptr(y),
+                y.stride(0), rows)
+        if cnt is None:
+            rc = lib.pgnn_mlp2_fwd(*args, _lib.stream_ptr())
+        else:
+            rc = lib.pgnn_mlp2_fwd_dyn(*args, cnt.arg(), _lib.stream_ptr())
+        if rc == _lib.E_UNSUPPORTED:
+            return None
+        _lib.check(rc, "pgnn_mlp2_fwd")
+        return y if cnt is None else _lib.tag_count(y, cnt)
 
 
 class ClassAwareSeparatedPredictor(object):
@@ -629,6 +767,7 @@ class ClassAwareSeparatedPredictor(object):
                       normalization_type='fused_BN_center',
                       activation_type='ReLU'):
         _check_kinds(activation_type, normalization_type)
+        _flush_pending()
         f = _as_f32(features)
         nc, bl = int(num_classes), int(box_encoding_len)
         kw = dict(is_logits=True, normalization_type=normalization_type,

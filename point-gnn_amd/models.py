@@ -103,7 +103,10 @@ class MultiLayerFastLocalGraphModelV2(object):
         # `model.feature_list` -- per-layer parity checks
         keep = getattr(self, 'keep_features', False)
         self.feature_list = []
-        with gnn.parameters(self._store):
+        # `model.fuse_vertex_stages = False`: every operator launches its own
+        # per-vertex stages (the unfused reference form the tests compare with)
+        fuse = getattr(self, 'fuse_vertex_stages', True)
+        with gnn.parameters(self._store), gnn.fuse_vertex_stages(fuse):
             feats = t_initial_vertex_features
             *body, head = self._layer_configs
             for cfg in body:

@@ -902,6 +902,160 @@ def test_vertex_pre_edge_equals_unfused_entries(dev, auto_offset, k):
     assert np.all(a[:k] == lowest) and np.all(a[k:] == 0.0)   # fills its rows only
 
 
+@pytest.mark.parametrize("c,auto_offset,residual,k", [
+    (300, True, True, 1000), (300, False, True, 37), (300, True, False, 16),
+    (256, True, True, 531), (300, True, True, 3352)])
+def test_vertex_update_pre_edge_equals_separate_entries(dev, c, auto_offset,
+                                                        residual, k):
+    """pgnn_vertex_update_pre_edge_fwd (the END of one operator and the START
+    of the next in one launch) == pgnn_mlp_fwd (+ residual) followed by
+    pgnn_vertex_pre_edge_fwd, bit for bit -- y, P, Q and the lowest() fill."""
+    import torch
+    from pointgnn_amd import gnn, _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(k + c)
+    wq = gnn.padded_width(c)
+    store = _store({
+        "s/fully_connected/weights": rng.standard_normal((c, 64)).astype(np.float32) * 0.1,
+        "s/fully_connected/biases": rng.standard_normal(64).astype(np.float32),
+        "s/fully_connected_1/weights": rng.standard_normal((64, 3)).astype(np.float32) * 0.1,
+        "s/fully_connected_1/biases": rng.standard_normal(3).astype(np.float32),
+    }, dev)
+    u1 = rng.standard_normal((c, c)).astype(np.float32) / np.sqrt(c)
+    u2 = rng.standard_normal((c, c)).astype(np.float32) / np.sqrt(c)
+    ub1 = rng.standard_normal(c).astype(np.float32) * 0.1
+    ub2 = rng.standard_normal(c).astype(np.float32) * 0.1
+    w1 = rng.standard_normal((c + 3, c)).astype(np.float32) * 0.1
+    b1 = rng.standard_normal(c).astype(np.float32)
+    agg_in = T(np.pad(rng.standard_normal((k, c)).astype(np.float32),
+                      ((0, 0), (0, wq - c))), dev)
+    h_prev = T(np.pad(rng.standard_normal((k, c)).astype(np.float32),
+                      ((0, 0), (0, wq - c))), dev) if residual else None
+    x = T(rng.uniform(-20, 20, (k, 3)).astype(np.float32), dev)
+    with gnn.parameters(store):
+        off = gnn._relu_chain(store, "s", [64, 3], True) if auto_offset else None
+        # update MLP: last layer linear when it carries the residual
+        # (gnn.py:367-372), ReLU on both for the pooling output MLP
+        upd = gnn.Chain(store, [(u1, ub1, 0), (u2, ub2, c if residual else 0)])
+        p_chain = gnn.Chain(store, [(w1, b1, c)])
+        wx = np.zeros((3, wq), np.float32)
+        wx[:, :c] = w1[c:]
+        wx_dev = T(wx, dev)
+        st = _lib.stream_ptr()
+        # separate launches
+        y0 = gnn.mlp_forward(upd, agg_in, c, residual=h_prev)
+        q0 = torch.full((k, wq), 7.0, dtype=torch.float32, device=dev)
+        p0 = torch.full((k, wq), 7.0, dtype=torch.float32, device=dev)
+        a0 = torch.zeros((k + 2, wq), dtype=torch.float32, device=dev)
+        pre = (off.array if off is not None else None,
+               off.n if off is not None else 0, p_chain.array, _lib.ptr(wx_dev),
+               k)
+        _lib.check(lib.pgnn_vertex_pre_edge_fwd(
+            _lib.ptr(y0), y0.stride(0), c, _lib.ptr(x), *pre, _lib.ptr(p0),
+            _lib.ptr(q0), wq, _lib.ptr(a0), wq, st))
+        # one launch
+        y1 = torch.full((k, wq), 7.0, dtype=torch.float32, device=dev)
+        q1 = torch.full((k, wq), 7.0, dtype=torch.float32, device=dev)
+        p1 = torch.full((k, wq), 7.0, dtype=torch.float32, device=dev)
+        a1 = torch.zeros((k + 2, wq), dtype=torch.float32, device=dev)
+        _lib.check(lib.pgnn_vertex_update_pre_edge_fwd(
+            _lib.ptr(agg_in), agg_in.stride(0), c, upd.array, upd.n,
+            _lib.ptr(h_prev), h_prev.stride(0) if residual else 0,
+            _lib.ptr(y1), y1.stride(0), c, _lib.ptr(x), *pre, _lib.ptr(p1),
+            _lib.ptr(q1), wq, _lib.ptr(a1), wq, st),
+            "pgnn_vertex_update_pre_edge_fwd")
+    assert torch.equal(y0, y1)
+    assert torch.equal(q0, q1) and torch.equal(p0, p1)
+    assert torch.equal(a0, a1)
+
+
+@pytest.mark.parametrize("k,residual", [(1000, True), (37, False), (3352, True)])
+def test_mlp2_equals_two_mlp_launches(dev, k, residual):
+    """pgnn_mlp2_fwd == pgnn_mlp_fwd (+ residual) then pgnn_mlp_fwd on its
+    output (the last update MLP and the fused predictor heads), bit for bit."""
+    import torch
+    from pointgnn_amd import gnn, _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(k)
+    c = 300
+    wq = gnn.padded_width(c)
+    store = _store({}, dev)
+    u1 = rng.standard_normal((c, c)).astype(np.float32) / np.sqrt(c)
+    u2 = rng.standard_normal((c, c)).astype(np.float32) / np.sqrt(c)
+    h1 = rng.standard_normal((c, 320)).astype(np.float32) / np.sqrt(c)
+    h2 = rng.standard_normal((320, 272)).astype(np.float32) / np.sqrt(320)
+    h3 = rng.standard_normal((272, 48)).astype(np.float32) / np.sqrt(272)
+    bb = lambda n: rng.standard_normal(n).astype(np.float32) * 0.1
+    x = T(np.pad(rng.standard_normal((k, c)).astype(np.float32),
+                 ((0, 0), (0, wq - c))), dev)
+    res = T(np.pad(rng.standard_normal((k, c)).astype(np.float32),
+                   ((0, 0), (0, wq - c))), dev) if residual else None
+    with gnn.parameters(store):
+        front = gnn.Chain(store, [(u1, bb(c), 0), (u2, bb(c), c)])
+        back = gnn.Chain(store, [(h1, bb(320), 0), (h2, bb(272), 16),
+                                 (h3, bb(48), 48)])
+        y0 = gnn.mlp_forward(front, x, c, residual=res)
+        o0 = gnn.mlp_forward(back, y0, c)
+        y1 = torch.full((k, wq), 7.0, dtype=torch.float32, device=dev)
+        o1 = torch.full((k, 48), 7.0, dtype=torch.float32, device=dev)
+        _lib.check(lib.pgnn_mlp2_fwd(
+            _lib.ptr(x), x.stride(0), c, front.array, front.n, _lib.ptr(res),
+            res.stride(0) if residual else 0, _lib.ptr(y1), y1.stride(0), c,
+            back.array, back.n, _lib.ptr(o1), o1.stride(0), k,
+            _lib.stream_ptr()), "pgnn_mlp2_fwd")
+    assert torch.equal(y0, y1)
+    assert torch.equal(o0, o1)
+
+
+@pytest.mark.parametrize("name,preset,seed", [("car_auto_T3", "tiny", 1),
+                                              ("car_auto_T3", "car", 0),
+                                              ("car_auto_T0", "small", 0),
+                                              ("car_fixed_T3", "tiny", 2),
+                                              ("ped_cyl_auto_T3", "tiny", 3),
+                                              ("ped_cyl_auto_T3", "ped_dense", 0)])
+def test_fused_vertex_stages_are_bit_identical(dev, name, preset, seed):
+    """predict() runs every operator boundary's two per-vertex stages in one
+    launch (gnn.fuse_vertex_stages): logits, box encodings and every layer's
+    output equal, bit for bit, those of the operators launching their own
+    stages -- host-sized and capacity-form graphs (ped_dense, 14 k vertices,
+    falls back to the separate launches: same answer either way)."""
+    import torch
+    from pointgnn_amd import graph_gen, models
+    from pointgnn_amd.engine import InferenceEngine
+    cfg = configs.get_config(name)
+    xyz, inten = synthetic_cloud(seed=seed, preset=preset)
+    params = weights.init_params(cfg, seed=seed, bias_scale=0.05)
+    fn = graph_gen.get_graph_generate_fn(cfg["graph_gen_method"])
+    coords, kps, edges = fn(T(xyz, dev), **cfg["runtime_graph_gen_kwargs"])
+    model = models.get_model(cfg["model_name"])(
+        num_classes=cfg["num_classes"], box_encoding_len=7, mode="test",
+        **cfg["model_kwargs"]).load_state_dict(params)
+    model.keep_features = True
+    f = T(inten, dev)
+    out = {}
+    for fuse in (False, True):
+        model.fuse_vertex_stages = fuse
+        lg, bx = model.predict(f, coords, kps, edges, False)
+        out[fuse] = (lg.clone(), bx.clone(),
+                     [t.clone() for t in model.feature_list])
+    assert torch.equal(out[False][0], out[True][0])
+    assert torch.equal(out[False][1], out[True][1])
+    assert len(out[True][2]) == len(out[False][2])
+    for a, b in zip(out[False][2], out[True][2]):
+        assert torch.equal(a, b)
+    # capacity form (device-side counts) through the engine
+    eng = InferenceEngine(cfg, params, device=dev)
+    x_d = T(xyz, dev)
+    ref = eng.run_frame(x_d, f)
+    eng.model.fuse_vertex_stages = False
+    unf = eng.run_frame_deferred(x_d, f).result()
+    eng.model.fuse_vertex_stages = True
+    fus = eng.run_frame_deferred(x_d, f).result()
+    for a, b in ((ref, unf), (ref, fus)):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert torch.equal(ref[0], out[True][0])
+
+
 @pytest.mark.parametrize("t", [0, 1])
 def test_predict_real_weights_matches_golden(dev, t):
     """configs[0]/[1]: trained car_auto_T0/T1 weights, reference-built graph,

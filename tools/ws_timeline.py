@@ -57,7 +57,10 @@ print("E1 %d K %d; kernel %.1f us (%.1f us with stamps); waves stamped %d" % (
     edges[1].shape[0], n_k, r0["avg_launch_us"], r["avg_launch_us"], live.sum()))
 if not live.any():
     sys.exit("no stamps: the weights-stationary kernel did not run")
-hdr, tiles = hdr[live], tiles[live]
+hdr, tiles = hdr[live].copy(), tiles[live]
+rt_entry = hdr[:, 6].copy()          # wave entered the kernel (100 MHz clock)
+hdr[:, 6] = hdr[:, 5] // 100         # slice
+hdr[:, 5] = hdr[:, 5] % 100          # column tiles of the group
 cyc = hdr[:, 1] - hdr[:, 0]
 rt0, rt1 = hdr[:, 2], hdr[:, 3]
 ghz = cyc / np.maximum(rt1 - rt0, 1) * 0.1
@@ -67,6 +70,15 @@ t_begin = (rt0 - rt0.min()) / 100.0   # us
 t_end = (rt1 - rt0.min()) / 100.0
 print("wave begin (after weights->LDS) us: min %.1f p50 %.1f max %.1f" % (
     t_begin.min(), np.median(t_begin), t_begin.max()))
+t_entry = (rt_entry - rt_entry.min()) / 100.0
+print("wave entry us (first wave of the launch = 0): p50 %.1f max %.1f; "
+      "weights->LDS (entry to begin) us: min %.1f p50 %.1f max %.1f; last "
+      "wave end - first entry = %.1f us (rocprof kernel duration minus this = "
+      "dispatch + drain)" % (
+          np.median(t_entry), t_entry.max(),
+          ((rt0 - rt_entry) / 100.0).min(), np.median((rt0 - rt_entry) / 100.0),
+          ((rt0 - rt_entry) / 100.0).max(),
+          (rt1.max() - rt_entry.min()) / 100.0))
 print("wave end us: min %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f" % (
     t_end.min(), np.percentile(t_end, 10), np.median(t_end),
     np.percentile(t_end, 90), t_end.max()))
@@ -129,3 +141,71 @@ if "--dump" in sys.argv:
               "scatter-max cycles per tile" % (w, hdr[w, 5], hdr[w, 4]))
         print("  " + " ".join("%d/%d/%d" % (t[1] - t[0], t[2] - t[1], t[3] - t[2])
                               for t in tl if t[3] > 0))
+if "--cost-model" in sys.argv:
+    # Is the spread of SIMD end times explained by the segment boundaries in
+    # each wave's static range?  dst is sorted, every vertex has its self
+    # edge: the runs that END inside rows [e0, e1) number dst[e1] - dst[e0].
+    E = int(edges[1].shape[0])
+    dst = edges[1][:, 1].cpu().numpy().astype(np.int64)
+    n_wt = (E + 15) // 16
+    wg0 = {7: (0, 12), 6: None}
+    blk = np.repeat(np.arange(GRID), WAVES)[live]
+    wv = np.tile(np.arange(WAVES), GRID)[live]
+    sl = blk % 8
+    local = blk // 8
+    # groups 7/6/6 own local workgroups [0,12), [12,22), [22,32)
+    g_lo = np.where(local < 12, 0, np.where(local < 22, 12, 22))
+    g_n = np.where(local < 12, 12, 10)
+    s_first = n_wt * sl // 8
+    s_last = n_wt * (sl + 1) // 8
+    nw = g_n * WAVES
+    wi = (local - g_lo) * WAVES + wv
+    span = s_last - s_first
+    t_first = s_first + span * wi // nw
+    t_last = s_first + span * (wi + 1) // nw
+    assert np.array_equal(t_last - t_first, hdr[:, 4]), "partition formula"
+    e0 = np.minimum(t_first * 16, E - 1)
+    e1 = np.minimum(t_last * 16, E - 1)
+    closes = dst[e1] - dst[e0]
+    tiles_n = (t_last - t_first).astype(np.float64)
+    dur = t_end - t_begin
+    ntg = hdr[:, 5].astype(np.float64)
+    # SIMD = waves (w, w + 4) of a workgroup
+    key = blk * 4 + (wv % 4)
+    simd_end = np.zeros(GRID * 4)
+    simd_beg = np.full(GRID * 4, 1e30)
+    simd_tiles = np.zeros(GRID * 4)
+    simd_close = np.zeros(GRID * 4)
+    simd_ntg = np.zeros(GRID * 4)
+    np.maximum.at(simd_end, key, t_end)
+    np.minimum.at(simd_beg, key, t_begin)
+    np.add.at(simd_tiles, key, tiles_n)
+    np.add.at(simd_close, key, closes)
+    simd_ntg[key] = ntg
+    sd = simd_end - simd_beg
+    print("SIMD busy span us: mean %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f "
+          "(kernel %.1f)" % (sd.mean(), np.percentile(sd, 10), np.median(sd),
+                             np.percentile(sd, 90), sd.max(),
+                             r0["avg_launch_us"]))
+    print("SIMD end us: p50 %.1f p90 %.1f max %.1f; all-equal bound = mean "
+          "span %.1f + begin %.1f" % (np.median(simd_end),
+                                      np.percentile(simd_end, 90),
+                                      simd_end.max(), sd.mean(),
+                                      simd_beg.mean()))
+    for g in sorted(set(simd_ntg)):
+        m = simd_ntg == g
+        A = np.stack([simd_tiles[m], simd_close[m], np.ones(m.sum())], 1)
+        coef, res, _, _ = np.linalg.lstsq(A, sd[m], rcond=None)
+        pred = A @ coef
+        print("group of %d column tiles: span ~ %.4f us/tile + %.4f us/closing"
+              " + %.1f; closing = %.2f tiles; residual std %.1f us (span std "
+              "%.1f); closings per SIMD p10 %.0f p50 %.0f p90 %.0f" % (
+                  g, coef[0], coef[1], coef[2], coef[1] / coef[0],
+                  (sd[m] - pred).std(), sd[m].std(),
+                  np.percentile(simd_close[m], 10), np.median(simd_close[m]),
+                  np.percentile(simd_close[m], 90)))
+    print("by XCD slice: mean span " + " ".join(
+        "%d:%.0f" % (x, sd[(np.arange(GRID * 4) // 4) % 8 == x].mean())
+        for x in range(8)) + "; closings " + " ".join(
+        "%d:%.0f" % (x, simd_close[(np.arange(GRID * 4) // 4) % 8 == x].mean())
+        for x in range(8)))
