@@ -701,6 +701,20 @@ int pgnn_loss_fwd_bwd(const float *logits, int64_t ld_logits,
                       float cls_grad_scale, float loc_grad_scale,
                       double *sums4, float *dlogits, float *dpred_box,
                       void *stream);
+/* The same with the GLOBAL endpoint counts of train.py:268-284 on the device
+ * (counts2 = {num_endpoint, num_valid_endpoint} as doubles, e.g. fresh out of
+ * an all-reduce over the ranks): the kernel forms cls_loss_weight /
+ * num_endpoint and loc_loss_weight / num_valid_endpoint itself (0 for a zero
+ * count: tf.math.div_no_nan), so no host read sits between the forward and the
+ * backward pass of a multi-rank step.                                         */
+int pgnn_loss_fwd_bwd_counts(const float *logits, int64_t ld_logits,
+                             const int32_t *labels, const float *pred_box,
+                             int32_t box_len, const float *gt_box,
+                             const float *valid, int64_t n_vertices,
+                             int32_t num_classes, double cls_loss_weight,
+                             double loc_loss_weight, const double *counts2,
+                             double *sums4, float *dlogits, float *dpred_box,
+                             void *stream);
 /* params -= lr * (grad_scale*grads + l1_scale*sign(params)*is_weight)
  * (GradientDescentOptimizer + slim.l1_regularizer on FC weights only).       */
 int pgnn_sgd_step(float *params, const float *grads, const float *is_weight,

@@ -273,6 +273,10 @@ _SIGNATURES = {
     "pgnn_loss_fwd_bwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i32, c_vp, c_vp,
                                   c_i64, c_i32, ctypes.c_float, ctypes.c_float,
                                   c_vp, c_vp, c_vp, c_vp]),
+    "pgnn_loss_fwd_bwd_counts": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i32, c_vp,
+                                         c_vp, c_i64, c_i32, ctypes.c_double,
+                                         ctypes.c_double, c_vp, c_vp, c_vp,
+                                         c_vp, c_vp]),
     "pgnn_sgd_step": (c_i32, [c_vp, c_vp, c_vp, c_i64, ctypes.c_float,
                               ctypes.c_float, ctypes.c_float, c_vp]),
     "pgnn_l1_norm": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp]),

@@ -1018,7 +1018,17 @@ __global__ void loss_kernel(const float *__restrict__ logits, int64_t ldl,
                             float cls_scale, float loc_scale,
                             double *__restrict__ sums,
                             float *__restrict__ dlogits,
-                            float *__restrict__ dpred) {
+                            float *__restrict__ dpred,
+                            const double *__restrict__ counts, double cls_w,
+                            double loc_w) {
+  if (counts) {
+    // the GLOBAL endpoint counts are on the device (all-reduced there): the
+    // scales are formed here as the host form does (double quotient of the
+    // loss weight and the count, rounded to float once)
+    const double nt = counts[0], nv = counts[1];
+    cls_scale = nt > 0.0 ? (float)(cls_w / nt) : 0.0f;
+    loc_scale = nv > 0.0 ? (float)(loc_w / nv) : 0.0f;  // div_no_nan
+  }
   double s_ce = 0.0, s_loc = 0.0, s_n = 0.0, s_v = 0.0;
   for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n;
        v += (int64_t)gridDim.x * blockDim.x) {
@@ -1974,7 +1984,32 @@ extern "C" int pgnn_loss_fwd_bwd(const float *logits, int64_t ld_logits,
   hipLaunchKernelGGL(loss_kernel, dim3(grid_for(n_vertices, 1024)), dim3(256), 0,
                      stream, logits, ld_logits, labels, pred_box, box_len, gt_box,
                      valid, n_vertices, num_classes, cls_grad_scale,
-                     loc_grad_scale, sums4, dlogits, dpred_box);
+                     loc_grad_scale, sums4, dlogits, dpred_box,
+                     (const double *)nullptr, 0.0, 0.0);
+  PGNN_HIP(hipGetLastError());
+  return 0;
+  PGNN_GUARD_END
+}
+
+extern "C" int pgnn_loss_fwd_bwd_counts(
+    const float *logits, int64_t ld_logits, const int32_t *labels,
+    const float *pred_box, int32_t box_len, const float *gt_box,
+    const float *valid, int64_t n_vertices, int32_t num_classes,
+    double cls_loss_weight, double loc_loss_weight, const double *counts2,
+    double *sums4, float *dlogits, float *dpred_box, void *stream_) {
+  PGNN_GUARD_BEGIN
+  hipStream_t stream = (hipStream_t)stream_;
+  PGNN_REQUIRE(n_vertices >= 0 && num_classes > 0 && box_len > 0 && sums4 &&
+                   counts2,
+               PGNN_E_INVALID, "loss_counts: bad argument");
+  PGNN_HIP(hipMemsetAsync(sums4, 0, 4 * sizeof(double), stream));
+  if (n_vertices == 0) return 0;
+  PGNN_REQUIRE(logits && labels && pred_box && gt_box && valid, PGNN_E_INVALID,
+               "loss_counts: null pointer");
+  hipLaunchKernelGGL(loss_kernel, dim3(grid_for(n_vertices, 1024)), dim3(256), 0,
+                     stream, logits, ld_logits, labels, pred_box, box_len, gt_box,
+                     valid, n_vertices, num_classes, 0.0f, 0.0f, sums4, dlogits,
+                     dpred_box, counts2, cls_loss_weight, loc_loss_weight);
   PGNN_HIP(hipGetLastError());
   return 0;
   PGNN_GUARD_END

@@ -29,7 +29,8 @@ from .gnn import padded_width
 from .weights import init_params, mlp_names, variable_specs
 
 __all__ = ["Trainer", "batch_data", "learning_rate", "fetch_data",
-           "train_epochs", "allreduce_endpoint_counts", "allreduce_gradients"]
+           "train_epochs", "allreduce_endpoint_counts",
+           "allreduce_endpoint_counts_device", "allreduce_gradients"]
 
 
 def learning_rate(train_config, step):
@@ -80,16 +81,41 @@ def batch_data(batch_list):
             cat(n_boxes), cat(n_valid))
 
 
+def _world(group=None):
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(group)
+    return 1
+
+
 def allreduce_endpoint_counts(n_local, nv_local, device, group=None):
     """Global (num_endpoint, num_valid_endpoint) over all ranks: the
-    `unify_copies` normalisers of train.py:268-284.  One tiny all-reduce."""
+    `unify_copies` normalisers of train.py:268-284, as Python floats.  One
+    rank: no device work at all.  Several: one tiny all-reduce and its host
+    read (`allreduce_endpoint_counts_device` is the form without the read)."""
+    if _world(group) <= 1:
+        return float(n_local), float(nv_local)
+    c = allreduce_endpoint_counts_device(n_local, nv_local, device, group)
+    c = c.tolist()
+    return float(c[0]), float(c[1])
+
+
+def allreduce_endpoint_counts_device(n_local, nv_local, device, group=None):
+    """The same, left ON THE DEVICE: a float64 [2] tensor the loss kernel
+    reads (pgnn_loss_fwd_bwd_counts), so a multi-rank step has no host wait
+    between its forward and its backward pass.  nv_local may be a Python
+    number (the data loader knows it) or a 0-d device tensor."""
     import torch.distributed as dist
-    counts = torch.tensor([float(n_local), float(nv_local)],
-                          dtype=torch.float64, device=device)
-    if dist.is_available() and dist.is_initialized() and \
-            dist.get_world_size(group) > 1:
+    if isinstance(nv_local, torch.Tensor):
+        counts = torch.stack([
+            torch.full((), float(n_local), dtype=torch.float64, device=device),
+            nv_local.to(device=device, dtype=torch.float64).reshape(())])
+    else:
+        counts = torch.tensor([float(n_local), float(nv_local)],
+                              dtype=torch.float64, device=device)
+    if _world(group) > 1:
         dist.all_reduce(counts, group=group)
-    return float(counts[0].item()), float(counts[1].item())
+    return counts
 
 
 def allreduce_gradients(flat_grad, sums=None, group=None):
@@ -855,9 +881,11 @@ class Trainer(object):
 
     # ---- loss ---------------------------------------------------------------------
     def loss_and_grads(self, logits, pred, labels, gt_box, valid, n_total,
-                       nv_total, want_grads=True):
+                       nv_total, want_grads=True, counts_dev=None):
         """sums4 = [sum CE, sum loc, n, n_valid] (device double tensor),
-        dlogits [K,nc], dpred [K,nc,L] for the globally normalised loss."""
+        dlogits [K,nc], dpred [K,nc,L] for the globally normalised loss.
+        counts_dev: the global (n_total, nv_total) as a device float64 [2]
+        tensor instead of the two host numbers (no host read needed)."""
         dev = self.device
         k = int(logits.shape[0])
         lg = logits if logits.stride(1) == 1 else logits.contiguous()
@@ -870,6 +898,14 @@ class Trainer(object):
             if want_grads else None
         dpred = torch.empty((k, self.nc, self.box_len), dtype=torch.float32,
                             device=dev) if want_grads else None
+        if counts_dev is not None:
+            _lib.check(self.lib.pgnn_loss_fwd_bwd_counts(
+                _lib.ptr(lg), lg.stride(0), _lib.ptr(labels), _lib.ptr(pred),
+                self.box_len, _lib.ptr(gt), _lib.ptr(va), k, self.nc,
+                ctypes.c_double(self.cls_w), ctypes.c_double(self.loc_w),
+                _lib.ptr(counts_dev), _lib.ptr(sums), _lib.ptr(dlog),
+                _lib.ptr(dpred), self._st()), "pgnn_loss_fwd_bwd_counts")
+            return sums, dlog, dpred
         cls_scale = self.cls_w / n_total if n_total > 0 else 0.0
         loc_scale = self.loc_w / nv_total if nv_total > 0 else 0.0  # div_no_nan
         _lib.check(self.lib.pgnn_loss_fwd_bwd(
@@ -1014,23 +1050,31 @@ class Trainer(object):
         self.grad.zero_()
         va = torch.as_tensor(valid).to(self.device, torch.float32).reshape(-1)
         k = int(va.shape[0])
-        counts = None
-        if num_valid is not None:
-            # known up front: exchange the counts BEFORE the forward is queued,
-            # so the tiny collective (and its host read) does not wait for it
-            counts = allreduce_endpoint_counts(k, float(num_valid), self.device,
-                                               self.pg)
+        multi = _world(self.pg) > 1
+        counts = counts_dev = None
+        if multi:
+            # several ranks: the global counts are all-reduced and STAY on the
+            # device (the loss kernel divides by them): nothing is read back
+            # between forward and backward.  Queued before the forward when the
+            # loader knows this rank's count, so the tiny collective overlaps it.
+            if num_valid is not None:
+                counts_dev = allreduce_endpoint_counts_device(
+                    k, float(num_valid), self.device, self.pg)
+        elif num_valid is not None:
+            counts = (float(k), float(num_valid))
         logits, pred = self.forward(input_v, coords, kps, edges)
         self.last_logits = logits   # for the streaming metrics (train.py:299)
         assert int(logits.shape[0]) == k, "labels do not match the vertices"
-        if counts is None:
-            counts = allreduce_endpoint_counts(k, float(va.sum().item()),
-                                               self.device, self.pg)
+        if multi and counts_dev is None:
+            counts_dev = allreduce_endpoint_counts_device(
+                k, va.sum(), self.device, self.pg)
+        elif not multi and counts is None:
+            counts = (float(k), float(va.sum().item()))
         # unify_copies: global endpoint counts (train.py:268-284)
-        n_total, nv_total = counts
+        n_total, nv_total = counts if counts is not None else (None, None)
         sums, dlog, dpred = self.loss_and_grads(
             logits, pred, torch.as_tensor(labels), torch.as_tensor(boxes), va,
-            n_total, nv_total)
+            n_total, nv_total, counts_dev=counts_dev)
         self.backward(dlog, dpred)
         if after_enqueue is not None:
             after_enqueue()
@@ -1044,9 +1088,15 @@ class Trainer(object):
             e1.record()
             ev.append((e0, e1))
         lr = learning_rate(self.train_config, self.global_step)
+        if counts_dev is not None:   # the step's one host read, at its end
+            host = torch.cat([sums, counts_dev]).tolist()
+            s_ce, s_loc, n_total, nv_total = host[0], host[1], host[4], host[5]
+        else:
+            host = sums.tolist()
+            s_ce, s_loc = host[0], host[1]
         out = {
-            'cls_loss': self.cls_w * float(sums[0].item()) / max(n_total, 1.0),
-            'loc_loss': (self.loc_w * float(sums[1].item()) / nv_total)
+            'cls_loss': self.cls_w * float(s_ce) / max(n_total, 1.0),
+            'loc_loss': (self.loc_w * float(s_loc) / nv_total)
             if nv_total > 0 else 0.0,
             'reg_loss': self.reg_loss(),
             'num_endpoint': int(n_total), 'num_valid_endpoint': nv_total,

@@ -258,6 +258,50 @@ def test_model_loss_api_matches_oracle(dev):
     assert abs(tot - 7 * nv * d['loc_loss']) < 1e-3 * max(1.0, tot)
 
 
+def test_loss_with_device_counts_equals_host_scales(dev):
+    """pgnn_loss_fwd_bwd_counts (the global endpoint counts of
+    train.py:268-284 stay on the device: the multi-rank step) gives, bit for
+    bit, the sums and gradients of pgnn_loss_fwd_bwd called with the scales the
+    host would have formed from the same counts -- including a zero valid
+    count (tf.math.div_no_nan)."""
+    import ctypes
+    import torch
+    from pointgnn_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(11)
+    k, nc, bl = 777, 4, 7
+    logits = T(rng.standard_normal((k, nc)).astype(np.float32), dev)
+    pred = T(rng.standard_normal((k, nc, bl)).astype(np.float32) * 2, dev)
+    labels = T(rng.integers(0, nc, k).astype(np.int32), dev)
+    gt = T(rng.standard_normal((k, bl)).astype(np.float32), dev)
+    valid = T((rng.random(k) < 0.4).astype(np.float32), dev)
+    cls_w, loc_w = 0.1, 10.0
+    for n_tot, nv_tot in ((3 * k + 5.0, 912.0), (float(k), 0.0)):
+        outs = []
+        for form in ("host", "device"):
+            sums = torch.zeros(4, dtype=torch.float64, device=dev)
+            dl = torch.full((k, nc), 7.0, device=dev)
+            dp = torch.full((k, nc, bl), 7.0, device=dev)
+            head = (_lib.ptr(logits), logits.stride(0), _lib.ptr(labels),
+                    _lib.ptr(pred), bl, _lib.ptr(gt), _lib.ptr(valid), k, nc)
+            tail = (_lib.ptr(sums), _lib.ptr(dl), _lib.ptr(dp),
+                    _lib.stream_ptr())
+            if form == "host":
+                _lib.check(lib.pgnn_loss_fwd_bwd(
+                    *head, ctypes.c_float(cls_w / n_tot),
+                    ctypes.c_float(loc_w / nv_tot if nv_tot > 0 else 0.0),
+                    *tail))
+            else:
+                counts = torch.tensor([n_tot, nv_tot], dtype=torch.float64,
+                                      device=dev)
+                _lib.check(lib.pgnn_loss_fwd_bwd_counts(
+                    *head, ctypes.c_double(cls_w), ctypes.c_double(loc_w),
+                    _lib.ptr(counts), *tail))
+            outs.append((sums.cpu(), dl.cpu(), dp.cpu()))
+        for a, b in zip(*outs):
+            assert torch.equal(a, b)
+
+
 def _grad_errors(got, ref):
     """(max-abs error / max|ref|, Frobenius error / ||ref||)."""
     scale = np.abs(ref).max() + 1e-12
