@@ -208,8 +208,12 @@ int pgnn_cap_neighbors_fill(const int32_t *offsets, const int32_t *edges,
                             void *stream);
 
 /* ---- keypoints ----------------------------------------------------------
- * 'center' mode = multi_layer_downsampling_select (graph_gen.py:49-90) for one
- * pooling level: open3d-0.7 voxel centroids (origin = min_bound - voxel/2,
+ * 'center' mode = multi_layer_downsampling_select (graph_gen.py:49-90) for ONE
+ * pooling level per call (the reference loops over arbitrary `levels`; every
+ * shipped config has one downsampling level followed by equal scales, which
+ * graph_gen.py:76-81 turns into copies, and the Python mirror
+ * pointgnn_amd.graph_gen raises NotImplementedError for more -- chain calls
+ * of this entry to add levels): open3d-0.7 voxel centroids (origin = min_bound - voxel/2,
  * float64 means in point order) followed by an exact float64 1-NN back to a
  * real point; exact distance ties are broken like scikit-learn's kd-tree
  * query does (see pgnn_kdtree_replica).  Keypoints are emitted in ascending
@@ -220,10 +224,10 @@ int pgnn_cap_neighbors_fill(const int32_t *offsets, const int32_t *edges,
  * in units of metres; NULL = none), RNG keyed by `seed`.
  * Capacity of both outputs is n_points rows.  num_keypoints: device int32[2],
  * [0] = K, [1] = tie-order status of the kd-tree replica ('center' only; 0 =
- * the reference's order; 1 = libstdc++'s heap-select fallback of
- * std::nth_element would have run on this cloud -- it is not replicated, exact
- * 1-NN ties may then be broken differently from the reference; the Python
- * mirror raises on it).
+ * the reference's order -- libstdc++'s introselect INCLUDING its heap-select
+ * fallback is replayed; non-zero = the cloud is outside what the replica
+ * reproduces, exact 1-NN ties may then be broken differently from the
+ * reference; the Python mirror raises on it).
  * Limits of 'center' mode: float32 points only (the replica's keys), at most
  * 524 288 points (PGNN_E_UNSUPPORTED beyond: node records are kept in LDS).
  * The tie rule replicated is scikit-learn >= 1.0's (std::nth_element in

@@ -709,8 +709,13 @@ class ClassAwarePredictor(object):
         c, chains = store.cached(('heads', scope, nc, bl, hw), build)
         cnt = _lib.count_of(features)   # capacity form: rows behind the
         logits = None                   # count are undefined in the outputs
-        boxes = torch.empty((f.shape[0], nc, bl), dtype=torch.float32,
-                            device=f.device)
+        # one group of heads (nc <= 4 at 64 hidden units): the box encodings
+        # are a strided VIEW of the chain's output rows, [K, nc, 8][:, :, :bl]
+        # -- no copy kernel on the frame's path; several groups are gathered
+        # into one tensor
+        boxes = None if len(chains) == 1 else \
+            torch.empty((f.shape[0], nc, bl), dtype=torch.float32,
+                        device=f.device)
         for has_cls, lids, base, chain in chains:
             y = None
             if pend is not None:
@@ -726,8 +731,11 @@ class ClassAwarePredictor(object):
                 y = mlp_forward(chain, f, c, count=cnt)
             if has_cls:
                 logits = y[:, :nc]
-            blk = y[:, base:base + 8 * len(lids)].reshape(-1, len(lids), 8)
-            boxes[:, lids[0]:lids[0] + len(lids), :] = blk[:, :, :bl]
+            blk = y[:, base:base + 8 * len(lids)].unflatten(1, (len(lids), 8))
+            if boxes is None:
+                boxes = blk[:, :, :bl]
+            else:
+                boxes[:, lids[0]:lids[0] + len(lids), :] = blk[:, :, :bl]
         return _lib.tag_count(logits, cnt), _lib.tag_count(boxes, cnt)
 
 
