@@ -68,19 +68,24 @@ def algorithmic_flops_per_frame(cfg, n_k, n_e0, n_e1):
 
 
 def time_kernel(fn, reps, torch):
-    """Average duration (s) of fn() over reps launches, HIP events on the
-    current (launch) stream."""
+    """Average duration (s) of ONE fn() launch over `reps` launches: a HIP
+    event pair round every launch on the current (launch) stream, so the
+    dispatch gap between two launches falls between one pair's stop and the
+    next pair's start and is not counted -- this is the kernel's own duration,
+    the figure rocprofv3's kernel trace reports (an event pair round ALL
+    launches read 30-50 us more per launch than the trace for the 1 ms edge
+    kernel: the gaps, and a fill kernel that is no part of it)."""
     for _ in range(3):
         fn()
-    start = torch.cuda.Event(enable_timing=True)
-    stop = torch.cuda.Event(enable_timing=True)
+    pairs = [(torch.cuda.Event(enable_timing=True),
+              torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
     torch.cuda.synchronize()
-    start.record()
-    for _ in range(reps):
+    for a, b in pairs:
+        a.record()
         fn()
-    stop.record()
-    stop.synchronize()
-    return start.elapsed_time(stop) * 1e-3 / reps
+        b.record()
+    torch.cuda.synchronize()
+    return sum(a.elapsed_time(b) for a, b in pairs) * 1e-3 / reps
 
 
 def live_pmc_scatter(preset, timeout_s=150):
@@ -235,13 +240,17 @@ def roofline_edge_kernel(torch, engine, edges1, n_k, reps=10, frame=None):
         q = torch.randn((n_k, wq), device=dev) * 0.1
         p[:, c:] = 0
         q[:, c:] = 0
-    agg = torch.empty((n_k, gnn.padded_width(rest.n_out)), device=dev)
+    # the aggregation buffer holds lowest() before the first launch, as
+    # vertex_pre_edge leaves it in a frame (flag bit 1: no fill launch inside
+    # the call); later launches max the same values into it again
+    agg = torch.full((n_k, gnn.padded_width(rest.n_out)),
+                     float(np.finfo(np.float32).min), device=dev)
     n_e = int(edges1.shape[0])
 
     def run():
         _lib.check(lib.pgnn_edge_mlp_scatter_max_fwd(
             _lib.ptr(p), _lib.ptr(q), wq, int(rest.k_in), _lib.ptr(edges1),
-            n_e, n_k, rest.array, rest.n, 1, _lib.ptr(agg), agg.stride(0),
+            n_e, n_k, rest.array, rest.n, 1 | 2, _lib.ptr(agg), agg.stride(0),
             _lib.ptr(_lib.sched_ws()), _lib.stream_ptr()), "edge kernel")
     dur = time_kernel(run, reps, torch)
     widths = lc[0]['kwargs']['edge_MLP_depth_list']
@@ -254,7 +263,11 @@ def roofline_edge_kernel(torch, engine, edges1, n_k, reps=10, frame=None):
         "frac": executed / dur / 1e12 / FP32_MFMA_PEAK_TF,
         "executed_flops": executed, "avg_launch_us": dur * 1e6,
         "note": "fp32 MFMA (16x16x4); FLOPs = 2*E*sum(in*out) of the layers "
-                "this kernel executes (first edge layer is factored per vertex)",
+                "this kernel executes (first edge layer is factored per "
+                "vertex); duration = mean of one HIP-event pair per launch, "
+                "the call launches this kernel alone (aggregation buffer "
+                "pre-filled, as in a frame): compare rocprofv3's average for "
+                "edge_ws_kernel in profiles/",
     }
 
 
