@@ -686,6 +686,11 @@ def parse_args(argv=None):
                     help="barrier-bracketed timed regions of exactly --steps "
                          "steps; the FIRST is the headline `value`, the "
                          "spread of all of them is reported beside it")
+    ap.add_argument("--edge-arith", choices=("f32", "bf16x3"), default="f32",
+                    help="arithmetic of the per-edge 300x300 product: f32 = "
+                         "fp32 MFMA (the headline); bf16x3 = the SECONDARY "
+                         "split-bf16 kernel (csrc/edge_ws_bf16.h): the line's "
+                         "dtype and metric then say so")
     ap.add_argument("--no-bind", action="store_true",
                     help="do not pin this rank to the CPUs of its GPU's "
                          "NUMA node")
@@ -1073,6 +1078,8 @@ def main(argv=None):
         from pointgnn_amd import _lib as _pg_lib
         key, val = kv.split("=")
         _pg_lib.set_tunable(key, int(val))
+    from pointgnn_amd import gnn as _pg_gnn
+    _pg_gnn.EDGE_ARITH = args.edge_arith
 
     if args.train:
         run_train(args, torch, dev, rank, world, dist)
@@ -1186,6 +1193,46 @@ def main(argv=None):
             "K": st2["K"], "E0": st2["E0"], "E1": st2["E1"],
             "algorithmic_gflop_per_frame": st2["alg_flops_mean"] / 1e9,
             "algorithmic_tflops": st2["alg_flops_mean"] * s2 / e2 / 1e12}
+
+    # SECONDARY arithmetic (not the headline, whose dtype is f32): the same
+    # frames with the per-edge product on the bf16 matrix pipe, both operands
+    # split exactly into three bf16 parts (csrc/edge_ws_bf16.h), next to how
+    # far its logits are from the fp32-MFMA path's on the pool's first frame
+    b16 = None
+    if world == 1 and not args.no_secondary and args.edge_arith == "f32" \
+            and args.preset == "car_600k" and args.config == "car_auto_T3":
+        first = sorted(pool)[0]
+        x0_, f0_ = pool[first][:2]
+        lg32, bx32 = [t.clone() for t in engine.run_frame(x0_, f0_)]
+        engine.frame_shapes = []
+        _pg_gnn.EDGE_ARITH = "bf16x3"
+        try:
+            lg16, bx16 = [t.clone() for t in engine.run_frame(x0_, f0_)]
+            s3 = max(8, args.steps // 2)
+            e3, sh3, _ = measure(args.preset, s3, 2, fps=fps_h)
+        finally:
+            _pg_gnn.EDGE_ARITH = "f32"
+        engine.frame_shapes = []
+        b16 = {
+            "workload": "%s inference, preset '%s', edge stage on the "
+                        "split-bf16 kernel (3 x 3 bf16 parts, the 6 products "
+                        "of order <= 2, fp32 accumulation; fp32-MFMA "
+                        "everywhere else)" % (args.config, args.preset),
+            "dtype": "bf16x3 split products, f32 accumulate (edge stage only)",
+            "steps": s3, "frames_per_gpu_per_step": fps_h,
+            "frames_per_sec": s3 * fps_h / e3,
+            "ms_per_frame": e3 / (s3 * fps_h) * 1e3,
+            "vs_f32_headline": (s3 * fps_h / e3) /
+                               (args.steps * fps_h / elapsed),
+            "max_abs_dlogit_vs_f32_path_frame_seed%d" % first:
+                float((lg16 - lg32).abs().max()),
+            "max_abs_dbox_vs_f32_path_frame_seed%d" % first:
+                float((bx16 - bx32).abs().max()),
+            "note": "SECONDARY: the headline `value` and `dtype` are the "
+                    "fp32-MFMA path; tests/test_gpu_bf16x3.py holds this "
+                    "path to the float64 oracle on the full-size frames "
+                    "(its distance is not larger than the fp32 path's)",
+        }
 
     # BASELINE configs 5 and 4 in the same line (single-GPU runs of the
     # headline command only; `--config ped_cyl_auto_T3` / `--train` are the
@@ -1301,7 +1348,9 @@ def main(argv=None):
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if args.edge_arith == "f32" else
+                     "bf16x3 split products with f32 accumulation in the edge "
+                     "stage (SECONDARY arithmetic), f32 elsewhere",
             "data": "synthetic" if not (ONE_GPU and world > 1) else
                     "synthetic; TEST MODE: %d ranks share ONE GPU under gloo "
                     "(not a multi-GPU measurement)" % world,
@@ -1369,6 +1418,8 @@ def main(argv=None):
         }
         if second is not None:
             res["config"]["secondary"] = second
+        if b16 is not None:
+            res["config"]["secondary_bf16x3"] = b16
         if ped is not None:
             res["config"]["secondary_ped"] = ped
         if trn is not None:

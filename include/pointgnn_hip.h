@@ -430,6 +430,31 @@ int pgnn_edge_mlp_scatter_max_fwd_dyn(const float *P, const float *Q,
                                       const pgnn_dyn_count *num_vertices,
                                       void *stream);
 
+/* SECONDARY arithmetic for the same stage with ONE remaining edge layer of
+ * 300x300 or 256x256 (csrc/edge_ws_bf16.h): the layer's product runs on the
+ * bf16 matrix pipe with BOTH operands split exactly into three bf16 parts
+ * (8 + 8 + 8 significand bits) and the six products of combined order <= 2
+ * accumulated in fp32 -- the dropped terms are below 2^-26 of a product, a
+ * quarter of one fp32 rounding; results agree with the fp32-MFMA entry to
+ * fp32 rounding noise (not bit for bit) and are no further from a float64
+ * evaluation (tests/test_gpu_bf16x3.py).  The fp32 entry above stays the
+ * default and the parity reference (gnn.py:355-365 is fp32 in the reference).
+ * `image`: device copy of what pgnn_pack_fc_bf16x3 wrote for the layer
+ * (pgnn_packed_fc_bf16x3_bytes of it); width = the layer's k_in, n_out its
+ * width, relu_from as in pgnn_fc_layer.  n_edges / num_vertices: NULL = the
+ * capacities are the counts; else the capacity form (counts on the device).
+ * PGNN_E_UNSUPPORTED, having done nothing, for other shapes or fewer than
+ * ~65k edges: run pgnn_edge_mlp_scatter_max_fwd.                             */
+size_t pgnn_packed_fc_bf16x3_bytes(int32_t k_in, int32_t n_out);
+int pgnn_pack_fc_bf16x3(const float *w_host, const float *b_host, int32_t k_in,
+                        int32_t n_out, void *image_host);
+int pgnn_edge_mlp_scatter_max_bf16x3_fwd(
+    const float *P, const float *Q, int64_t ld_pq, int32_t width,
+    const int32_t *edges, int64_t edges_cap, int32_t vertices_cap,
+    const void *image, int32_t n_out, int32_t relu_from, int32_t edges_sorted,
+    float *out, int64_t ld_out, const pgnn_dyn_count *n_edges,
+    const pgnn_dyn_count *num_vertices, void *stream);
+
 /* Training forward of the same stage with ONE remaining edge layer: the fused
  * kernel also writes that layer's per-edge output rows [n_edges, ld_rows]
  * (the backward compares them with `out` to find the arg-max rows; rows and

@@ -302,6 +302,59 @@ extern "C" size_t pgnn_packed_fc_floats(int32_t k_in, int32_t n_out) {
   return kq * nt * 256 + nt * 16;
 }
 
+// ---- split-bf16 weight image (edge_ws_bf16.h) ----------------------------------
+namespace {
+inline uint16_t bf16_rne(float x) {
+  uint32_t u;
+  memcpy(&u, &x, 4);
+  return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);  // finite inputs
+}
+inline float bf16_as_float(uint16_t h) {
+  const uint32_t u = (uint32_t)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+}  // namespace
+
+extern "C" size_t pgnn_packed_fc_bf16x3_bytes(int32_t k_in, int32_t n_out) {
+  if (k_in <= 0 || n_out <= 0) return 0;
+  const size_t kb = (k_in + 31) / 32, nt = (n_out + 15) / 16;
+  return kb * nt * 3 * 1024 + nt * 16 * sizeof(float);
+}
+
+extern "C" int pgnn_pack_fc_bf16x3(const float *w, const float *b, int32_t k_in,
+                                   int32_t n_out, void *image) {
+  PGNN_GUARD_BEGIN
+  PGNN_REQUIRE(w && image && k_in > 0 && n_out > 0, PGNN_E_INVALID,
+               "pack_fc_bf16x3: bad argument");
+  const int kb_n = (k_in + 31) / 32, nt = (n_out + 15) / 16;
+  uint16_t *img = reinterpret_cast<uint16_t *>(image);
+  for (int kb = 0; kb < kb_n; ++kb)
+    for (int t = 0; t < nt; ++t)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int j = 0; j < 8; ++j) {
+          const int k = 32 * kb + 8 * (lane >> 4) + j;
+          const int n = 16 * t + (lane & 15);
+          const float x = (k < k_in && n < n_out) ? w[(size_t)k * n_out + n] : 0.0f;
+          // x = x0 + x1 + x2 exactly: both residuals are exact in fp32
+          const uint16_t p0 = bf16_rne(x);
+          const float r1 = x - bf16_as_float(p0);
+          const uint16_t p1 = bf16_rne(r1);
+          const float r2 = r1 - bf16_as_float(p1);
+          const uint16_t p2 = bf16_rne(r2);
+          const size_t frag = ((size_t)kb * nt + t) * 3;
+          img[((frag + 0) * 64 + lane) * 8 + j] = p0;
+          img[((frag + 1) * 64 + lane) * 8 + j] = p1;
+          img[((frag + 2) * 64 + lane) * 8 + j] = p2;
+        }
+  float *bias = reinterpret_cast<float *>(reinterpret_cast<char *>(image) +
+                                          (size_t)kb_n * nt * 3 * 1024);
+  for (int n = 0; n < nt * 16; ++n) bias[n] = (b && n < n_out) ? b[n] : 0.0f;
+  return 0;
+  PGNN_GUARD_END
+}
+
 extern "C" int pgnn_pack_fc(const float *w, const float *b, int32_t k_in,
                             int32_t n_out, float *packed) {
   PGNN_GUARD_BEGIN

@@ -14,6 +14,7 @@
 // The E x C activations never reach HBM.
 #include "mlp_engine.h"
 #include "edge_ws.h"
+#include "edge_ws_bf16.h"
 #include "pool_ws.h"
 
 namespace pgnn {
@@ -1400,6 +1401,114 @@ int edge_fwd_impl(const float *P, const float *Q, int64_t ld_pq, int32_t width,
                                    de.dev);
 }
 }  // namespace
+
+namespace {
+// column groups of a weights-stationary launch: tiles as evenly as possible,
+// the slice's workgroups in proportion (largest remainder) -- launch_edge_ws
+int ws_partition(EdgeWsArgs &a, int nt, int ntmax, int cus) {
+  a.groups = (nt + ntmax - 1) / ntmax;
+  const int per_slice = cus / a.xcds;
+  PGNN_REQUIRE(a.groups <= kWsMaxGroups && per_slice >= a.groups,
+               PGNN_E_UNSUPPORTED, "edge_ws: too few CUs for the column groups");
+  const int base = nt / a.groups, extra = nt % a.groups;
+  int size[kWsMaxGroups], cnt[kWsMaxGroups], frac[kWsMaxGroups], used = 0;
+  a.tile0[0] = 0;
+  for (int g = 0; g < a.groups; ++g) {
+    size[g] = base + (g < extra ? 1 : 0);
+    a.tile0[g + 1] = a.tile0[g] + size[g];
+    cnt[g] = per_slice * size[g] / nt;
+    if (cnt[g] < 1) cnt[g] = 1;
+    frac[g] = per_slice * size[g] % nt;
+    used += cnt[g];
+  }
+  PGNN_REQUIRE(base >= ntmax - 1 && base + (extra ? 1 : 0) <= ntmax &&
+                   used <= per_slice,
+               PGNN_E_UNSUPPORTED, "edge_ws: column tiles do not group");
+  while (used < per_slice) {
+    int best = 0;
+    for (int g = 1; g < a.groups; ++g)
+      if (frac[g] > frac[best]) best = g;
+    ++cnt[best];
+    frac[best] = -1;
+    ++used;
+  }
+  a.wg0[0] = 0;
+  for (int g = 0; g < a.groups; ++g) a.wg0[g + 1] = a.wg0[g] + cnt[g];
+  return 0;
+}
+
+template <int KB, int NTMAX>
+int launch_edge_ws3(EdgeWsArgs &a, int nt, int cus, hipStream_t stream) {
+  const int rc = ws_partition(a, nt, NTMAX, cus);
+  if (rc) return rc;
+  const size_t lds = (size_t)KB * NTMAX * 3 * 1024 + 16 * NTMAX * sizeof(float);
+  PGNN_REQUIRE(lds <= device_max_lds(), PGNN_E_UNSUPPORTED,
+               "edge_bf16x3: column group does not fit the LDS");
+  auto kern = edge_ws_bf16x3_kernel<KB, NTMAX>;
+  const int lrc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
+  if (lrc) return lrc;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(cus / a.xcds * a.xcds)),
+                     dim3(64 * kWsWaves), lds, stream, a);
+  PGNN_HIP(hipGetLastError());
+  return 0;
+}
+}  // namespace
+
+extern "C" int pgnn_edge_mlp_scatter_max_bf16x3_fwd(
+    const float *P, const float *Q, int64_t ld_pq, int32_t width,
+    const int32_t *edges, int64_t edges_cap, int32_t vertices_cap,
+    const void *image, int32_t n_out, int32_t relu_from, int32_t edges_sorted,
+    float *out, int64_t ld_out, const pgnn_dyn_count *n_edges,
+    const pgnn_dyn_count *num_vertices, void *stream_) {
+  PGNN_GUARD_BEGIN
+  hipStream_t stream = (hipStream_t)stream_;
+  PGNN_REQUIRE(edges_cap >= 0 && vertices_cap >= 0 && width > 0 && n_out > 0 &&
+                   image,
+               PGNN_E_INVALID, "edge_bf16x3: bad argument");
+  const Dyn de = dyn_of(n_edges), dk = dyn_of(num_vertices);
+  const int kq = (width + 15) / 16, nt = (n_out + 15) / 16;
+  const int kb = (width + 31) / 32;
+  PGNN_REQUIRE(ld_pq == 16 * kq && ld_out >= 16 * nt, PGNN_E_INVALID,
+               "edge_bf16x3: ld_pq / ld_out do not match the padded widths");
+  int cus = stream_cu_count(stream);
+  if (g_ws_reserve > 0 && cus - g_ws_reserve >= 64) cus -= g_ws_reserve;
+  // the shapes the kernel is instantiated for, and enough rows to amortise
+  // 150 KiB of weights per workgroup: otherwise the caller runs the fp32 entry
+  if (!((kb == 10 && nt == 19) || (kb == 8 && nt == 16)) || cus < 64 ||
+      cus % 8 != 0 ||
+      expected(de, edges_cap) < (int64_t)16 * 2 * kWsWaves * cus)
+    return PGNN_E_UNSUPPORTED;  // (no message: an expected answer)
+  if (vertices_cap == 0) return 0;
+  PGNN_REQUIRE(out != nullptr, PGNN_E_INVALID, "edge_bf16x3: null output");
+  if (!(edges_sorted & 2)) {
+    const int rc = fill_lowest_rows(out, ld_out, vertices_cap, dk, stream);
+    if (rc) return rc;
+  }
+  if (edges_cap == 0) return 0;
+  PGNN_REQUIRE(P && Q && edges, PGNN_E_INVALID, "edge_bf16x3: null input");
+  PGNN_REQUIRE(((uintptr_t)P % 16 == 0) && ((uintptr_t)Q % 16 == 0) &&
+                   ((uintptr_t)image % 16 == 0),
+               PGNN_E_INVALID, "edge_bf16x3: P / Q / image must be 16-byte aligned");
+  EdgeWsArgs a = {};
+  a.P = P;
+  a.Q = Q;
+  a.ldv4 = (int)(ld_pq >> 2);
+  a.edges = edges;
+  a.n_edges = edges_cap;
+  a.n_dev = de.dev;
+  a.wp = reinterpret_cast<const float *>(image);
+  a.nt = nt;
+  a.relu_from = relu_from;
+  a.out = out;
+  a.ldo = ld_out;
+  a.num_segments = vertices_cap;
+  a.sorted = edges_sorted & 1;
+  a.xcds = (g_ws_xcds >= 1 && cus % g_ws_xcds == 0) ? g_ws_xcds : 8;
+  a.prio = g_ws_prio;
+  if (kb == 10) return launch_edge_ws3<10, 5>(a, nt, cus, stream);
+  return launch_edge_ws3<8, 5>(a, nt, cus, stream);
+  PGNN_GUARD_END
+}
 
 extern "C" int pgnn_point_set_pooling_fwd(
     const float *point_features, int32_t n_feat, const float *point_xyz,

@@ -481,6 +481,17 @@ class PointSetPooling(object):
 # tensors: bench.py times the edge kernel on a frame's real inputs with it
 EDGE_INPUT_TAP = None
 
+# Arithmetic of the per-edge 300x300 / 256x256 product (gnn.py:355-365):
+#   'f32'    -- fp32 MFMA (default; the parity reference, bit-identical between
+#               its kernel variants);
+#   'bf16x3' -- SECONDARY: both operands split exactly into three bf16 parts,
+#               six bf16 MFMAs per block accumulated in fp32
+#               (csrc/edge_ws_bf16.h, pgnn_edge_mlp_scatter_max_bf16x3_fwd):
+#               agrees with 'f32' to fp32 rounding noise, ~2x faster.  Falls
+#               back to 'f32' where the kernel does not apply (few edges,
+#               other layer shapes).
+EDGE_ARITH = 'f32'
+
 
 class GraphNetAutoCenter(object):
     """gnn.py:285-373."""
@@ -608,7 +619,16 @@ class GraphNetAutoCenter(object):
                      int(e.shape[0]), k, rest.array, rest.n,
                      _edges_sorted_flag(edges) | 2, _lib.ptr(agg),
                      agg.stride(0), _lib.ptr(_lib.sched_ws(h.device)))
-        if cnt_k is None:
+        done = False
+        if EDGE_ARITH == 'bf16x3' and rest.n == 1:
+            done = self._edge_bf16x3(lib, store, edge_scope, edge_widths, p, q,
+                                     wq, rest, e, k, edges, agg, cnt_e, cnt_k,
+                                     st)
+        elif EDGE_ARITH not in ('f32', 'bf16x3'):
+            raise ValueError("gnn.EDGE_ARITH must be 'f32' or 'bf16x3'")
+        if done:
+            pass
+        elif cnt_k is None:
             _lib.check(lib.pgnn_edge_mlp_scatter_max_fwd(*edge_args, st),
                        "pgnn_edge_mlp_scatter_max_fwd")
         else:
@@ -626,6 +646,35 @@ class GraphNetAutoCenter(object):
             h = hp
         return _finish_rows(upd_chain, agg, rest.n_out, residual=h,
                             count=cnt_k)
+
+
+    @staticmethod
+    def _edge_bf16x3(lib, store, edge_scope, edge_widths, p, q, wq, rest, e, k,
+                     edges, agg, cnt_e, cnt_k, st):
+        """The edge stage on the split-bf16 kernel; False (nothing done) where
+        it does not apply."""
+        def build():
+            w, b = store.mlp(edge_scope, len(edge_widths))[1]
+            w = np.ascontiguousarray(w, dtype=np.float32)
+            b = np.ascontiguousarray(b, dtype=np.float32)
+            host = np.empty(lib.pgnn_packed_fc_bf16x3_bytes(*w.shape), np.uint8)
+            _lib.check(lib.pgnn_pack_fc_bf16x3(
+                w.ctypes.data, b.ctypes.data, w.shape[0], w.shape[1],
+                host.ctypes.data), "pgnn_pack_fc_bf16x3")
+            return torch.from_numpy(host).to(store._dev())
+        image = store.cached(('edge_bf16x3', edge_scope, tuple(edge_widths)),
+                             build)
+        rc = lib.pgnn_edge_mlp_scatter_max_bf16x3_fwd(
+            _lib.ptr(p), _lib.ptr(q), wq, int(rest.k_in), _lib.ptr(e),
+            int(e.shape[0]), k, _lib.ptr(image), int(rest.n_out),
+            int(rest.array[0].relu_from), _edges_sorted_flag(edges) | 2,
+            _lib.ptr(agg), agg.stride(0),
+            cnt_e.arg() if cnt_e is not None else None,
+            cnt_k.arg() if cnt_k is not None else None, st)
+        if rc == _lib.E_UNSUPPORTED:
+            return False
+        _lib.check(rc, "pgnn_edge_mlp_scatter_max_bf16x3_fwd")
+        return True
 
 
 class ClassAwarePredictor(object):

@@ -426,3 +426,41 @@ def test_variable_scope_is_thread_local():
     assert seen["store_in_thread"] is None
     assert seen["scope_in_thread"] == "other/x"
     assert gnn._state.scope == [] and gnn._state.store is None
+
+
+def test_bf16x3_weight_image_is_an_exact_split():
+    """pgnn_pack_fc_bf16x3 (host side of csrc/edge_ws_bf16.h): the three bf16
+    parts of every weight sum to the fp32 weight EXACTLY, sit where the
+    kernel's A-operand layout expects them ([kb][t][part][lane][8]), pad with
+    zeros, and the bias follows in fp32."""
+    import numpy as np
+    from pointgnn_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(0)
+    k_in, n_out = 300, 300
+    w = (rng.standard_normal((k_in, n_out)) *
+         np.exp(rng.uniform(-20, 5, (k_in, n_out)))).astype(np.float32)
+    b = rng.standard_normal(n_out).astype(np.float32)
+    nbytes = lib.pgnn_packed_fc_bf16x3_bytes(k_in, n_out)
+    kb, nt = 10, 19
+    assert nbytes == kb * nt * 3 * 1024 + nt * 16 * 4
+    host = np.empty(nbytes, np.uint8)
+    _lib.check(lib.pgnn_pack_fc_bf16x3(w.ctypes.data, b.ctypes.data, k_in,
+                                       n_out, host.ctypes.data))
+    img = host[:kb * nt * 3 * 1024].view(np.uint16).reshape(kb, nt, 3, 64, 8)
+    parts = (img.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+    total = parts.sum(axis=2)                       # [kb, nt, lane, j]
+    lane = np.arange(64)
+    kk = (32 * np.arange(kb)[:, None, None, None] +
+          8 * (lane >> 4)[None, None, :, None] + np.arange(8)[None, None, None])
+    nn = (16 * np.arange(nt)[None, :, None, None] +
+          (lane & 15)[None, None, :, None]) + 0 * kk
+    kk = kk + 0 * nn
+    inside = (kk < k_in) & (nn < n_out)
+    want = np.where(inside, w.astype(np.float64)[np.minimum(kk, k_in - 1),
+                                                 np.minimum(nn, n_out - 1)], 0.0)
+    assert np.array_equal(total, want)              # exact, not approximate
+    # each part is what remains after the ones before it, rounded to 8 bits
+    assert np.all(np.abs(parts[:, :, 1]) <= np.abs(parts[:, :, 0]) * 2.0 ** -8 + 1e-300)
+    bias = host[kb * nt * 3 * 1024:].view(np.float32)
+    assert np.array_equal(bias[:n_out], b) and np.all(bias[n_out:] == 0)

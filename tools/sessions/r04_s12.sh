@@ -1,0 +1,8 @@
+#!/bin/bash
+# round 4, session 12: split-bf16 edge kernel, term-major MFMA order
+cd "$GRAFT_REPO_ROOT"
+mkdir -p gpurun_out
+timeout 300 python tools/bf16x3_bench.py > gpurun_out/r04_s12_bf16.txt 2>&1
+timeout 300 python tools/bf16x3_bench.py --preset ped_dense --config ped_cyl_auto_T3 >> gpurun_out/r04_s12_bf16.txt 2>&1
+grep -v amdgpu.ids gpurun_out/r04_s12_bf16.txt
+timeout 900 python -m pytest tests/test_gpu_bf16x3.py -x -q -m gpu -s -k "edge_stage" 2>&1 | tail -6
