@@ -1194,6 +1194,15 @@ def main(argv=None):
             "algorithmic_gflop_per_frame": st2["alg_flops_mean"] / 1e9,
             "algorithmic_tflops": st2["alg_flops_mean"] * s2 / e2 / 1e12}
 
+    # BASELINE configs 5 and 4 in the same line (single-GPU runs of the
+    # headline command only; `--config ped_cyl_auto_T3` / `--train` are the
+    # full-length forms): the ped_cyl dense-scan stress and the training step
+    ped = trn = None
+    if world == 1 and not args.no_secondary and args.preset == "car_600k" \
+            and args.config == "car_auto_T3":
+        ped = secondary_ped(args, torch, dev, measure)
+        trn = secondary_train(args, torch, dev)
+
     # SECONDARY arithmetic (not the headline, whose dtype is f32): the same
     # frames with the per-edge product on the bf16 matrix pipe, both operands
     # split exactly into three bf16 parts (csrc/edge_ws_bf16.h), next to how
@@ -1234,14 +1243,6 @@ def main(argv=None):
                     "(its distance is not larger than the fp32 path's)",
         }
 
-    # BASELINE configs 5 and 4 in the same line (single-GPU runs of the
-    # headline command only; `--config ped_cyl_auto_T3` / `--train` are the
-    # full-length forms): the ped_cyl dense-scan stress and the training step
-    ped = trn = None
-    if world == 1 and not args.no_secondary and args.preset == "car_600k" \
-            and args.config == "car_auto_T3":
-        ped = secondary_ped(args, torch, dev, measure)
-        trn = secondary_train(args, torch, dev)
 
     if rank == 0:
         # per-phase wall clock of the pool's first frame (outside the timed

@@ -991,7 +991,7 @@ int pgnn_kitti_cam_points_in_image(
 /* Process-wide knobs for benchmarks and tests; see "Conventions".  Keys:
  *   launch shape   scatter_rows_per_wave, scatter_nt, mlp_blocks_per_cu,
  *                  edge_msub, pool_msub, mlp_pool_pct, wgrad_wg_target,
- *                  ws_xcds, ws_prio, ws_pool_pct, ws_chunk, ws_reserve
+ *                  ws_xcds, ws_prio, ws_pool_pct, ws_chunk, ws_balance, ws_reserve
  *   graph builder  graph_max_wgs (cap on the workgroups of one builder launch;
  *                  every builder kernel strides over its work), graph_lds_pad
  *                  (bytes of dynamic LDS every builder launch asks for without

@@ -126,6 +126,7 @@ extern int g_ws_xcds;
 extern int g_ws_prio;
 extern int g_ws_pool_pct;
 extern int g_ws_chunk;
+extern int g_ws_balance;
 extern int g_ws_reserve;
 extern int g_mlp_debug;
 extern void *g_mlp_ts;
@@ -246,6 +247,11 @@ extern "C" int pgnn_set_tunable(const char *key, int value) {
   if (!strcmp(key, "ws_chunk")) {
     if (value < 1 || value > 64) return PGNN_E_INVALID;
     pgnn::g_ws_chunk = value;
+    return 0;
+  }
+  if (!strcmp(key, "ws_balance")) {
+    if (value < 0 || value > 2) return PGNN_E_INVALID;
+    pgnn::g_ws_balance = value;
     return 0;
   }
   if (!strcmp(key, "ws_reserve")) {

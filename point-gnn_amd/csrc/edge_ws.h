@@ -85,6 +85,16 @@ struct EdgeWsArgs {
   int groups;                        // column groups
   int tile0[kWsMaxGroups + 1];       // group g owns column tiles [tile0[g], tile0[g+1])
   int wg0[kWsMaxGroups + 1];         // ... and local workgroups [wg0[g], wg0[g+1]) of a slice
+  // Chip-wide balanced form (used without the tile pool): the workgroup
+  // counts of a group may differ from slice to slice -- 12/10/10 of 32 in
+  // every XCD left the 6-tile groups 4.7 % behind the 7-tile group, 94/81/81
+  // of 256 over the chip balances them to 1.3 % -- and a group's row tiles are
+  // divided over ALL its workgroups in (slice, local) order, so the
+  // workgroups of one XCD still cover one contiguous range per group.
+  int balanced;                               // 1: use the tables below
+  int n_wg[kWsMaxGroups];                     // workgroups of group g on the chip
+  short swg0[kWsMaxSlices][kWsMaxGroups + 1]; // slice s: local [swg0[s][g], swg0[s][g+1])
+  short sbase[kWsMaxSlices][kWsMaxGroups];    // group g's workgroups in slices < s
   // training forward (EMIT kernels only): the layer's per-edge output rows
   // act(h W + b) are ALSO written, [n_edges, ld_rows] -- the backward finds the
   // arg-max rows by comparing them with `out`
@@ -521,6 +531,26 @@ __device__ __forceinline__ void edge_ws_body(const EdgeWsArgs &a,
 }
 
 
+// (group, first column tile, tile count, rank among the group's waves, the
+// group's wave count) of this wave in the balanced partition
+struct WsWho {
+  int grp, t0, ntg;
+  int64_t wi, nw;
+};
+__device__ __forceinline__ WsWho ws_who_balanced(const EdgeWsArgs &a, int slice,
+                                                 int local, int wave) {
+  int grp = 0;
+  while (grp + 1 < a.groups && local >= a.swg0[slice][grp + 1]) ++grp;
+  WsWho w;
+  w.grp = grp;
+  w.t0 = a.tile0[grp];
+  w.ntg = a.tile0[grp + 1] - w.t0;
+  w.nw = (int64_t)a.n_wg[grp] * kWsWaves;
+  w.wi = (int64_t)(a.sbase[slice][grp] + local - a.swg0[slice][grp]) * kWsWaves +
+         wave;
+  return w;
+}
+
 template <int KQ, int NTMAX, bool EMIT = false>
 __global__ __launch_bounds__(64 * kWsWaves) void edge_ws_kernel(EdgeWsArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -534,7 +564,11 @@ __global__ __launch_bounds__(64 * kWsWaves) void edge_ws_kernel(EdgeWsArgs a) {
   // 100 MHz clock), i.e. before the weights go to LDS
   const long long rt_entry = a.ts ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
   int grp = 0;
-  while (grp + 1 < a.groups && local >= a.wg0[grp + 1]) ++grp;
+  if (a.balanced) {
+    grp = ws_who_balanced(a, slice, local, wave).grp;
+  } else {
+    while (grp + 1 < a.groups && local >= a.wg0[grp + 1]) ++grp;
+  }
   const int t0 = a.tile0[grp];
   const int ntg = a.tile0[grp + 1] - t0;
   // this group's weight fragments -> LDS, [q][t][lane] float4 (1 KiB each),
@@ -581,10 +615,17 @@ __global__ __launch_bounds__(64 * kWsWaves) void edge_ws_kernel(EdgeWsArgs a) {
     n_edges = nd < n_edges ? nd : n_edges;
   }
   const int64_t n_wt = (n_edges + 15) / 16;
-  const int64_t s_first = n_wt * slice / a.xcds;
-  const int64_t s_last = n_wt * (slice + 1) / a.xcds;
-  const int64_t nw = (int64_t)(a.wg0[grp + 1] - a.wg0[grp]) * kWsWaves;
-  const int64_t wi = (int64_t)(local - a.wg0[grp]) * kWsWaves + wave;
+  int64_t s_first = n_wt * slice / a.xcds;
+  int64_t s_last = n_wt * (slice + 1) / a.xcds;
+  int64_t nw = (int64_t)(a.wg0[grp + 1] - a.wg0[grp]) * kWsWaves;
+  int64_t wi = (int64_t)(local - a.wg0[grp]) * kWsWaves + wave;
+  if (a.balanced) {  // all row tiles over all the group's waves (no pool)
+    const WsWho w = ws_who_balanced(a, slice, local, wave);
+    s_first = 0;
+    s_last = n_wt;
+    nw = w.nw;
+    wi = w.wi;
+  }
   int64_t span = s_last - s_first;
   int64_t pool = a.sched ? span * a.pool_pct / 100 : 0;
   if (span - pool < 4 * nw) pool = 0;  // too little work to bother

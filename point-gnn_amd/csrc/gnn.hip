@@ -29,6 +29,10 @@ int g_ws_pool_pct = 0;    // edge_ws.h / pool_ws.h: share of the tiles handed ou
                           // range boundaries than it returns; kept as a tested
                           // option for streams that share the GPU)
 int g_ws_chunk = 2;       // edge_ws.h: pool chunk (16-row tiles)
+int g_ws_balance = 1;     // edge_ws.h: chip-wide balanced workgroup counts of the
+                          // column groups (EdgeWsArgs::balanced): 1 = for the
+                          // split-bf16 kernel, 2 = for the fp32 kernel too,
+                          // 0 = the same counts in every XCD slice
 int g_ws_reserve = 0;     // CUs the weights-stationary kernels leave to the
                           // kernels of other streams (multiple of 8)
 void *g_mlp_ts = nullptr;  // device buffer for per-tile timestamps (profiling)
@@ -988,6 +992,8 @@ int launch_rows8(const Plan &p, int64_t n_rows, const RowsArgs &ra,
   return 0;
 }
 
+void ws_balance(EdgeWsArgs &a, int cus, const double *cost);  // below
+
 // Weights-stationary edge kernel (edge_ws.h): one workgroup per CU, the column
 // tiles in groups that fit the LDS, the 16-row tiles in one slice per XCD.
 template <int KQ, int NTMAX>
@@ -1050,6 +1056,17 @@ int launch_edge_ws(const LayerDev &L, const EdgeArgs &ea, int64_t n_edges,
   }
   a.wg0[0] = 0;
   for (int g = 0; g < a.groups; ++g) a.wg0[g + 1] = a.wg0[g] + cnt[g];
+  {
+    // relative cost of a row tile: 4 KQ MFMAs of 32 cycles per column tile +
+    // ~1.9k cycles of gather VALU / running max per tile (tools/ws_timeline.py)
+    double cost[kWsMaxGroups];
+    for (int g = 0; g < a.groups; ++g) cost[g] = 128.0 * KQ * size[g] + 1900.0;
+    // (measured on the fp32 kernel: 977 vs 971 us, no gain -- its 12/10/10
+    // imbalance is smaller than the noise between its XCDs; the split-bf16
+    // kernel, 9/8/8/7 for 5/5/5/4 tiles, gains 1.7 %.  ws_balance = 2 turns it
+    // on here too.)
+    if (g_ws_balance >= 2) ws_balance(a, cus, cost);
+  }
   const size_t lds = (size_t)KQ * NTMAX * 1024 + 16 * NTMAX * sizeof(float);
   if (rows_out) {  // training forward: the rows are written as well
     auto kern = edge_ws_kernel<KQ, NTMAX, true>;
@@ -1403,6 +1420,79 @@ int edge_fwd_impl(const float *P, const float *Q, int64_t ld_pq, int32_t width,
 }  // namespace
 
 namespace {
+// Balanced workgroup counts over the whole chip for the column groups whose
+// tile counts are a.tile0 (see EdgeWsArgs::balanced).  cost[g] = relative time
+// of one row tile in group g (its MFMA issue + the per-tile fixed part).
+void ws_balance(EdgeWsArgs &a, int cus, const double *cost) {
+  const int per_slice = cus / a.xcds, total = per_slice * a.xcds;
+  a.balanced = 0;
+  if (a.xcds > kWsMaxSlices || a.groups < 2 || a.sched) return;
+  double sum = 0;
+  for (int g = 0; g < a.groups; ++g) sum += cost[g];
+  // largest-remainder share of `total` workgroups
+  int n[kWsMaxGroups], used = 0;
+  double frac[kWsMaxGroups];
+  for (int g = 0; g < a.groups; ++g) {
+    const double x = total * cost[g] / sum;
+    n[g] = (int)x;
+    if (n[g] < a.xcds) n[g] = a.xcds;  // at least one per slice
+    frac[g] = x - n[g];
+    used += n[g];
+  }
+  while (used < total) {
+    int best = 0;
+    for (int g = 1; g < a.groups; ++g)
+      if (frac[g] > frac[best]) best = g;
+    ++n[best];
+    frac[best] -= 1.0;
+    ++used;
+  }
+  if (used != total) return;  // (cannot happen for the shipped shapes)
+  // per slice: cumulative rounding, then repair each slice's sum to per_slice
+  int prev[kWsMaxGroups] = {0, 0, 0, 0};
+  for (int s = 0; s < a.xcds; ++s) {
+    int c[kWsMaxGroups], tot = 0;
+    for (int g = 0; g < a.groups; ++g) {
+      const int cum = (int)((int64_t)n[g] * (s + 1) / a.xcds);
+      c[g] = cum - prev[g];
+      tot += c[g];
+    }
+    // (the last slice closes every group exactly; earlier slices borrow from /
+    // lend to the group that is furthest ahead / behind its share)
+    for (int guard = 0; tot != per_slice && guard < 64; ++guard) {
+      int pick = -1;
+      double worst = 0;
+      for (int g = 0; g < a.groups; ++g) {
+        const double ideal = (double)n[g] * (s + 1) / a.xcds;
+        const double ahead = prev[g] + c[g] - ideal;
+        if (tot > per_slice ? (c[g] > 1 && (pick < 0 || ahead > worst))
+                            : (prev[g] + c[g] < n[g] &&
+                               (pick < 0 || -ahead > worst))) {
+          pick = g;
+          worst = tot > per_slice ? ahead : -ahead;
+        }
+      }
+      if (pick < 0) return;
+      c[pick] += tot > per_slice ? -1 : 1;
+      tot += tot > per_slice ? -1 : 1;
+    }
+    if (tot != per_slice) return;
+    a.swg0[s][0] = 0;
+    for (int g = 0; g < a.groups; ++g) {
+      a.sbase[s][g] = (short)prev[g];
+      a.swg0[s][g + 1] = (short)(a.swg0[s][g] + c[g]);
+      prev[g] += c[g];
+    }
+  }
+  for (int g = 0; g < a.groups; ++g) {
+    if (prev[g] != n[g]) return;
+    a.n_wg[g] = n[g];
+  }
+  a.balanced = 1;
+}
+}  // namespace
+
+namespace {
 // column groups of a weights-stationary launch: tiles as evenly as possible,
 // the slice's workgroups in proportion (largest remainder) -- launch_edge_ws
 int ws_partition(EdgeWsArgs &a, int nt, int ntmax, int cus) {
@@ -1441,6 +1531,14 @@ template <int KB, int NTMAX>
 int launch_edge_ws3(EdgeWsArgs &a, int nt, int cus, hipStream_t stream) {
   const int rc = ws_partition(a, nt, NTMAX, cus);
   if (rc) return rc;
+  {
+    // relative cost of a row tile: 60 MFMAs of 16 cycles per column tile +
+    // ~2.4k cycles of gather / split VALU that do not overlap them
+    double cost[kWsMaxGroups];
+    for (int g = 0; g < a.groups; ++g)
+      cost[g] = 960.0 * KB / 10 * (a.tile0[g + 1] - a.tile0[g]) + 2400.0;
+    if (g_ws_balance) ws_balance(a, cus, cost);
+  }
   const size_t lds = (size_t)KB * NTMAX * 3 * 1024 + 16 * NTMAX * sizeof(float);
   PGNN_REQUIRE(lds <= device_max_lds(), PGNN_E_UNSUPPORTED,
                "edge_bf16x3: column group does not fit the LDS");
