@@ -28,3 +28,28 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+# float64 oracle outputs of the BASELINE-size frames, shared by the test
+# modules that compare different device paths with them on the SAME
+# device-built graph (the oracle run of `ped_dense` alone takes ~30 s of host
+# time): key -> (edge digests, logits, boxes, features)
+_FULLSIZE_ORACLE = {}
+
+
+def fullsize_oracle(key, params, cfg, inten, c_np, k_np, e_np):
+    """gn.predict(..., dtype=float64, return_features=True), computed once per
+    (key, graph): the cache entry is only reused for byte-identical edge
+    lists."""
+    import hashlib
+    import numpy as np
+    from oracle import gnn_oracle as gn
+    sig = tuple(hashlib.sha256(np.ascontiguousarray(e).tobytes()).hexdigest()
+                for e in list(e_np) + list(k_np))
+    hit = _FULLSIZE_ORACLE.get(key)
+    if hit is not None and hit[0] == sig:
+        return hit[1:]
+    lg, bx, feats = gn.predict(params, cfg, inten, c_np, k_np, e_np,
+                               dtype=np.float64, return_features=True)
+    _FULLSIZE_ORACLE[key] = (sig, lg, bx, feats)
+    return lg, bx, feats

@@ -169,7 +169,9 @@ def test_bf16x3_full_size_logits_vs_float64_oracle(dev, name, preset):
     c_np = [c.cpu().numpy() for c in coords]
     k_np = [k.cpu().numpy() for k in kps]
     e_np = [e.cpu().numpy() for e in edges]
-    lg, bx = gn.predict(params, cfg, inten, c_np, k_np, e_np, dtype=np.float64)
+    from conftest import fullsize_oracle
+    lg, bx, _ = fullsize_oracle((name, preset), params, cfg, inten, c_np, k_np,
+                                e_np)
     d32 = (np.abs(out["f32"][0] - lg).max(), np.abs(out["f32"][1] - bx).max())
     d16 = (np.abs(out["bf16x3"][0] - lg).max(),
            np.abs(out["bf16x3"][1] - bx).max())

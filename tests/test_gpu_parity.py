@@ -786,6 +786,17 @@ def test_edge_weights_stationary_kernel_is_bit_identical(dev, name, case):
         _lib.set_tunable("mlp_debug", 0)
         _lib.set_tunable("ws_pool_pct", 0)
         _lib.set_tunable("ws_chunk", 2)
+    # chip-wide balanced column groups (EdgeWsArgs::balanced; default only for
+    # the split-bf16 kernel): other workgroup counts per XCD, a group's row
+    # tiles divided over all its workgroups -- same bits
+    try:
+        _lib.set_tunable("mlp_debug", 4096)
+        for bal in (2, 0, 1):
+            _lib.set_tunable("ws_balance", bal)
+            assert np.array_equal(run(), outs[2048], equal_nan=True), bal
+    finally:
+        _lib.set_tunable("mlp_debug", 0)
+        _lib.set_tunable("ws_balance", 1)
 
 
 @pytest.mark.parametrize("case", ["fanins", "shuffled", "ragged", "five_edges",
@@ -1188,8 +1199,9 @@ def test_full_size_logits_match_oracle(dev, name, preset):
     c_np = [c.cpu().numpy() for c in coords]
     k_np = [k.cpu().numpy() for k in kps]
     e_np = [e.cpu().numpy() for e in edges]
-    lg, bx, feats = gn.predict(params, cfg, inten, c_np, k_np, e_np,
-                               dtype=np.float64, return_features=True)
+    from conftest import fullsize_oracle
+    lg, bx, feats = fullsize_oracle((name, preset), params, cfg, inten, c_np,
+                                    k_np, e_np)
     assert len(model.feature_list) == len(feats) - 1
     report = []
     for i, (got, ref) in enumerate(zip(model.feature_list, feats[1:])):
