@@ -68,24 +68,25 @@ def algorithmic_flops_per_frame(cfg, n_k, n_e0, n_e1):
 
 
 def time_kernel(fn, reps, torch):
-    """Average duration (s) of ONE fn() launch over `reps` launches: a HIP
-    event pair round every launch on the current (launch) stream, so the
-    dispatch gap between two launches falls between one pair's stop and the
-    next pair's start and is not counted -- this is the kernel's own duration,
-    the figure rocprofv3's kernel trace reports (an event pair round ALL
-    launches read 30-50 us more per launch than the trace for the 1 ms edge
-    kernel: the gaps, and a fill kernel that is no part of it)."""
+    """Average duration (s) of fn() over `reps` back-to-back launches between
+    ONE pair of HIP events on the current (launch) stream.  Kernels queued back
+    to back start where the previous one ends (rocprofv3 traces show 0.0 us
+    gaps), so this is the kernel's own duration as long as fn() launches that
+    kernel alone -- roofline_edge_kernel does (aggregation buffer pre-filled,
+    no fill launch).  (An event pair round EVERY launch was tried in round 4
+    and reads ~55 us MORE per launch than the trace for the 1 ms edge kernel:
+    the two event records are commands of their own.)"""
     for _ in range(3):
         fn()
-    pairs = [(torch.cuda.Event(enable_timing=True),
-              torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    start = torch.cuda.Event(enable_timing=True)
+    stop = torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
-    for a, b in pairs:
-        a.record()
+    start.record()
+    for _ in range(reps):
         fn()
-        b.record()
-    torch.cuda.synchronize()
-    return sum(a.elapsed_time(b) for a, b in pairs) * 1e-3 / reps
+    stop.record()
+    stop.synchronize()
+    return start.elapsed_time(stop) * 1e-3 / reps
 
 
 def live_pmc_scatter(preset, timeout_s=150):
@@ -264,10 +265,10 @@ def roofline_edge_kernel(torch, engine, edges1, n_k, reps=10, frame=None):
         "executed_flops": executed, "avg_launch_us": dur * 1e6,
         "note": "fp32 MFMA (16x16x4); FLOPs = 2*E*sum(in*out) of the layers "
                 "this kernel executes (first edge layer is factored per "
-                "vertex); duration = mean of one HIP-event pair per launch, "
-                "the call launches this kernel alone (aggregation buffer "
-                "pre-filled, as in a frame): compare rocprofv3's average for "
-                "edge_ws_kernel in profiles/",
+                "vertex); duration = one HIP-event pair round 10 "
+                "back-to-back launches / 10, the call launches this kernel "
+                "alone (aggregation buffer pre-filled, as in a frame): "
+                "compare rocprofv3's average for edge_ws_kernel in profiles/",
     }
 
 
