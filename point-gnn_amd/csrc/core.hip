@@ -49,17 +49,37 @@ int device_cu_count() {
 // (pgnn_stream_create_cu_mask), the whole device for ordinary streams.  The
 // persistent kernels size their grids with it: a grid of 2 workgroups per
 // DEVICE CU on a stream that owns fewer CUs would run in two waves.
+namespace {
+struct StreamCuEntry {
+  hipStream_t s;
+  int n;
+};
+std::mutex g_stream_cu_mu;
+std::vector<StreamCuEntry> g_stream_cu_cache;
+}  // namespace
+
+// (pgnn_stream_destroy: a destroyed handle's address can be handed out again,
+// with another mask or none)
+void stream_cu_forget(hipStream_t stream) {
+  std::lock_guard<std::mutex> lock(g_stream_cu_mu);
+  for (size_t i = 0; i < g_stream_cu_cache.size();) {
+    if (g_stream_cu_cache[i].s == stream) {
+      g_stream_cu_cache[i] = g_stream_cu_cache.back();
+      g_stream_cu_cache.pop_back();
+    } else {
+      ++i;
+    }
+  }
+}
+
 int stream_cu_count(hipStream_t stream) {
   const int total = device_cu_count();
   if (stream == nullptr) return total;
   // the mask of a stream never changes: ask the runtime once per handle (this
   // sits on the launch path of every fused kernel)
-  struct Entry {
-    hipStream_t s;
-    int n;
-  };
-  static std::mutex mu;
-  static std::vector<Entry> cache;
+  typedef StreamCuEntry Entry;
+  std::mutex &mu = g_stream_cu_mu;
+  std::vector<Entry> &cache = g_stream_cu_cache;
   {
     std::lock_guard<std::mutex> lock(mu);
     for (const Entry &e : cache)
@@ -193,6 +213,7 @@ extern "C" int pgnn_stream_create_cu_mask(int32_t cu_first, int32_t cu_count,
 extern "C" int pgnn_stream_destroy(void *stream) {
   PGNN_GUARD_BEGIN
   PGNN_REQUIRE(stream, PGNN_E_INVALID, "stream_destroy: null stream");
+  pgnn::stream_cu_forget((hipStream_t)stream);
   PGNN_HIP(hipStreamDestroy((hipStream_t)stream));
   return 0;
   PGNN_GUARD_END

@@ -1185,6 +1185,27 @@ extern "C" int pgnn_trainer_create(const pgnn_train_model *m, void **handle) {
   for (int j = 0; j < m->num_classes && !rc; ++j)
     for (int i = 0; i < 3 && !rc; ++i)
       rc = make_fc(m->loc[j][i], m->n_params, t->loc[3 * j + i]);
+  // Shapes the orchestration below ASSUMES (every shipped config has them; any
+  // other layer_configs used to give silent garbage): a pooling stage only in
+  // front, one feature width from the first stage's output to the heads'
+  // inputs (the residual adds and the one dh buffer rely on it).
+  if (!rc) {
+    const int hw = t->cls[0].ref.k_in;
+    bool ok = true;
+    for (size_t si = 0; si < t->stages.size(); ++si) {
+      const StageDev &d = t->stages[si];
+      if (d.kind == 0 && si > 0) ok = false;             // pooling at si > 0
+      if (d.b.back().ref.n_out != hw) ok = false;        // stage output width
+      if (d.kind == 1 && d.a[0].ref.k_in != hw + 3) ok = false;
+    }
+    for (int j = 0; j < m->num_classes; ++j)
+      if (t->loc[3 * (size_t)j].ref.k_in != hw) ok = false;
+    if (!ok)
+      rc = fail(PGNN_E_UNSUPPORTED,
+                "trainer_create: the native step needs a pooling stage only "
+                "in front and one feature width from the first stage to the "
+                "heads (use the Python-driven step: Trainer.native = False)");
+  }
   if (rc) {
     delete t;
     return rc;

@@ -316,7 +316,14 @@ class InferenceEngine(object):
         if self._hints is None:
             self.run_frame(xyz, intensity)
             self.frame_shapes.pop()
-        side = torch.cuda.Stream()
+        # ONE capture stream per engine and device: _lib._SCHED_WS, the overlap
+        # and concurrent-stream caches are keyed by the current stream, so a
+        # fresh stream per capture leaked entries and re-ran the stream probes
+        key = ("capture", torch.cuda.current_device())
+        cache = self.__dict__.setdefault("_stream_sets", {})
+        side = cache.get(key)
+        if side is None:
+            side = cache[key] = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             # every lazily built thing (weight images, LDS attributes, CU

@@ -407,6 +407,13 @@ def keypoints_device(points, voxel_size, method='center', jitter=None, seed=0,
         # are float32-representable (a widened float32 cloud) is the same
         # computation, anything else has no device path (no shipped config:
         # training uses 'random', run.py feeds the float32 cloud)
+        if num_out is not None:
+            # capacity form: the representability check below is a blocking
+            # host read, which that form promises not to do (and which would
+            # abort a hipGraph capture)
+            raise NotImplementedError(
+                "downsample_method='center' on a float64 cloud in capacity "
+                "form (deferred_counts): cast the cloud to float32 first")
         narrow = points.to(torch.float32)
         if not bool((narrow.to(torch.float64) == points).all().item()):
             raise NotImplementedError(

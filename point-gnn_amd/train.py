@@ -662,8 +662,18 @@ class Trainer(object):
             for i, n in enumerate(mlp_names(ps + '/loc/cls_%d' % j, 3)):
                 self._fc_ref(m.loc[j][i], n)
         h = ctypes.c_void_p()
-        _lib.check(lib.pgnn_trainer_create(ctypes.byref(m), ctypes.byref(h)),
-                   "pgnn_trainer_create")
+        rc = lib.pgnn_trainer_create(ctypes.byref(m), ctypes.byref(h))
+        if rc == _lib.E_UNSUPPORTED:
+            # layer shapes outside what csrc/trainer.hip orchestrates: the
+            # Python-driven composition of the same primitives takes over
+            import warnings
+            warnings.warn("native training step unavailable for this model "
+                          "(%s); using the Python-driven step" % (
+                              (lib.pgnn_last_error() or b'?').decode(),),
+                          RuntimeWarning)
+            self.native = False
+            return None
+        _lib.check(rc, "pgnn_trainer_create")
         self._native_images = torch.empty(
             int(lib.pgnn_trainer_images_bytes(h)), dtype=torch.uint8,
             device=self.device)
@@ -710,6 +720,9 @@ class Trainer(object):
     def _native_forward(self, input_v, coords, kps, edges):
         lib = self.lib
         h = self._native_handle()
+        if h is None:     # unsupported shapes: Trainer.native was switched off
+            self._py_images_stale = True
+            return self.forward(input_v, coords, kps, edges)
         if self._native_images_stale:
             # weights were updated while native = False (repack() refreshed
             # only the Python-side images then)
