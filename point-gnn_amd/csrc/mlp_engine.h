@@ -115,7 +115,13 @@ __device__ __forceinline__ void gemm_tile(const float *__restrict__ tile, int ld
   // in tools/gemm_loop_bench.hip, but the fused kernels ran 3 % SLOWER with it
   // in a same-box A/B -- 834 -> 863 us for the edge kernel -- so the guarded
   // form stays.)
-  if constexpr (NW == 8) {
+#ifndef PGNN_KLOOP_BRANCHFREE
+#define PGNN_KLOOP_BRANCHFREE 0  // 1: every LDS-tile kernel (A/B builds)
+#endif
+  // (also the 32-row LDS-tile kernels -- ped_cyl's pooling stage: 2 876 ->
+  // 2 813 us in a same-box A/B; the 64-row form measured 3 % SLOWER with it in
+  // round 2 and keeps the guarded loop below)
+  if constexpr (NW == 8 || MSUB == 2 || PGNN_KLOOP_BRANCHFREE) {
     // The 16-row K-row kernels (rows_mlp_kernel, vertex_*_kernel): 12 MFMAs
     // per K-group and wave, far less than an L2 round trip, so the prefetch
     // distance IS the kernel's speed.  With the guarded body below hipcc's
