@@ -58,6 +58,9 @@ __device__ __forceinline__ u32 cvt_pk_bf16(float lo, float hi) {
   return r;
 }
 
+// (A variant that formed the residuals with v_dot2_f32_bf16 -- p . (-1, 0) + c:
+// unpack and subtraction in one instruction -- was 2 % faster and gave wrong
+// values as written; not pursued: session r04_s23.)
 // two floats -> their three bf16 parts, packed pairwise
 __device__ __forceinline__ void split3(float a, float b, u32 &p0, u32 &p1,
                                        u32 &p2) {

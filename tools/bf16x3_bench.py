@@ -76,5 +76,8 @@ print("%s/%s E1 %d K %d C %d" % (config, preset, n_e, n_k, rest.n_out))
 print("  fp32-MFMA edge kernel %8.1f us  %6.1f TFLOP/s" % (t32 * 1e6, flops / t32 / 1e12))
 print("  split-bf16 (6 terms)  %8.1f us  %6.1f TFLOP/s-equivalent (%.2fx)" % (
     t16 * 1e6, flops / t16 / 1e12, t32 / t16))
+import hashlib
+print("  sha256 of the bf16x3 output: %s" % hashlib.sha256(
+    bb.contiguous().cpu().numpy().tobytes()).hexdigest()[:16])
 print("  max |bf16x3 - fp32| %.3g (|out|max %.3g)" % (
     float((a - bb).abs().max()), float(a.abs().max())))
