@@ -466,12 +466,14 @@ def roofline_graph(torch, cfg, coords):
 
 
 def train_measure(torch, dev, rank, world, dist, config_name, preset, steps,
-                  warmup, frames, fpg=2, pipeline=True):
+                  warmup, frames, fpg=2, pipeline=True, deferred=True):
     """BASELINE config 4: `steps` timed training steps of `config_name` --
     per rank and step: training-mode graph build (voxel 0.8 m, random
     keypoints + origin jitter, level-1 fan-in capped at 256) for `fpg` frames,
     frame merge, forward, loss, backward, ONE all-reduce of the flat gradient,
-    SGD.  Returns (elapsed max over ranks, all-reduce ms, trainer, per-step
+    SGD.  `deferred`: each step's losses are read after the NEXT step is
+    queued (Trainer.train_step(deferred=True)); all of them inside the timed
+    region.  Returns (elapsed max over ranks, all-reduce ms, trainer, per-step
     shapes [(K, E0, E1)], last loss dict)."""
     from pointgnn_amd import configs, graph_gen, train
     from pointgnn_amd.synthetic import synthetic_cloud
@@ -527,26 +529,47 @@ def train_measure(torch, dev, rank, world, dist, config_name, preset, steps,
                        int(batch[3][1].shape[0])))
 
     state = {}
+    mode = pipeline if isinstance(pipeline, str) else \
+        ("stream" if pipeline else "off")
+    prebuilt = []
 
     def step(i):
-        if 'next' not in state:
-            state['next'] = make_batch(i)
-        batch, nv = state.pop('next')
+        """Queue step i; returns the loss dict of step i-1 when the losses are
+        read one step late (`deferred`), of step i otherwise."""
+        if mode == "prebuilt":   # diagnostic: the step without its data side
+            if len(prebuilt) < max(1, frames // fpg):
+                prebuilt.append(make_batch(i))
+            batch, nv = prebuilt[i % len(prebuilt)]
+            after = None
+        else:
+            if 'next' not in state:
+                state['next'] = make_batch(i)
+            batch, nv = state.pop('next')
+            after = None if mode == "off" else (
+                lambda: state.__setitem__('next', make_batch(i + 1)))
         use(batch)
-        if not pipeline:
-            return tr.train_step(batch, num_valid=nv)
-        return tr.train_step(
-            batch, num_valid=nv,
-            after_enqueue=lambda: state.__setitem__('next', make_batch(i + 1)))
+        res = tr.train_step(batch, num_valid=nv, after_enqueue=after,
+                            deferred=deferred)
+        if not deferred:
+            return res
+        prev = state.get('result')
+        state['result'] = res
+        return prev.get() if prev is not None else None
+
+    def drain():
+        prev = state.pop('result', None)
+        return prev.get() if prev is not None else None
 
     for i in range(warmup):
         step(i)
+    drain()
     _sync(torch, dist)
     del shapes[:]
     tr.allreduce_events = []
     t0 = time.perf_counter()
     for i in range(warmup, n_steps):
         out = step(i)
+    out = drain() or out     # every step's losses are read inside the region
     _sync(torch, dist)
     elapsed = time.perf_counter() - t0
     ar_ms = (sum(a.elapsed_time(b) for a, b in tr.allreduce_events) /
@@ -587,7 +610,9 @@ def run_train(args, torch, dev, rank, world, dist):
     fpg = args.frames_per_gpu
     elapsed, ar_ms, tr, cfg, shapes, out = train_measure(
         torch, dev, rank, world, dist, args.config, args.preset, args.steps,
-        args.warmup, args.frames, fpg, not args.no_pipeline)
+        args.warmup, args.frames, fpg,
+        "off" if args.no_pipeline else args.train_loader,
+        not args.train_sync_loss)
     if rank == 0:
         res = {
             "metric": "training frames/sec (%s, fwd+loss+bwd+allreduce+SGD, "
@@ -703,6 +728,14 @@ def parse_args(argv=None):
                          "PMC pass of the same workload instead, if any)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the extra `car`-preset measurement")
+    ap.add_argument("--train-loader", default="stream",
+                    choices=["stream", "prebuilt"],
+                    help="--train: 'stream' = the next batch's graph is built "
+                         "on a second stream once the step is enqueued; "
+                         "'prebuilt' = diagnostic, no build in the loop")
+    ap.add_argument("--train-sync-loss", action="store_true",
+                    help="--train: read every step's losses before the next "
+                         "step is queued (default: one step late)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run frames strictly sequentially on one stream")
     ap.add_argument("--no-capture", action="store_true",

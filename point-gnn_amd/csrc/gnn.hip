@@ -75,6 +75,8 @@ struct RowsArgs {
   int64_t ldres;
   float *y;
   int64_t ldy;
+  int res_gate;  // 0: y = rows + res; 1: y = res > 0 ? rows : 0 (ReluGrad of
+                 // the layer below, fused into a backward dX pass)
 };
 struct PoolArgs {
   const float *feat;
@@ -221,7 +223,10 @@ __device__ __forceinline__ void consume_rows(const float *__restrict__ stage,
   for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
     const int r = idx / ncols, c = idx - r * ncols;
     float v = stage[r * ld + c];
-    if (ra.res) v += ra.res[(row0 + r) * ra.ldres + col0 + c];
+    if (ra.res) {
+      const float a = ra.res[(row0 + r) * ra.ldres + col0 + c];
+      v = ra.res_gate ? (a > 0.0f ? v : 0.0f) : v + a;
+    }
     ra.y[(row0 + r) * ra.ldy + col0 + c] = v;
   }
 }
@@ -259,7 +264,7 @@ __device__ __forceinline__ void consume_rows16(const float *__restrict__ stage,
     const int c = c0 + 32 * j;
     if (r < rows_valid && c < ncols) {
       float v = stage[r * ld + c];
-      if (ra.res) v += add[j];
+      if (ra.res) v = ra.res_gate ? (add[j] > 0.0f ? v : 0.0f) : v + add[j];
       yr[c] = v;
     }
   }
@@ -1244,7 +1249,7 @@ int mlp_fwd_impl(const float *x, int64_t ld_x, int32_t nx, const float *x2,
                  int64_t ld_x2, int32_t nx2, int64_t n_rows,
                  const pgnn_fc_layer *layers, int32_t n_layers,
                  const float *residual, int64_t ld_res, float *y, int64_t ld_y,
-                 hipStream_t stream, const Dyn &rows) {
+                 hipStream_t stream, const Dyn &rows, int res_gate = 0) {
   PGNN_REQUIRE(n_rows >= 0 && nx > 0 && nx2 >= 0, PGNN_E_INVALID,
                "mlp_fwd: bad sizes");
   if (n_rows == 0) return 0;
@@ -1256,7 +1261,8 @@ int mlp_fwd_impl(const float *x, int64_t ld_x, int32_t nx, const float *x2,
   const int out_cols = 16 * p.chain.l[n_layers - 1].nt;
   PGNN_REQUIRE(ld_y >= out_cols && (!residual || ld_res >= out_cols),
                PGNN_E_INVALID, "mlp_fwd: ld_y/ld_res < padded output width");
-  RowsArgs ra = {x, ld_x, nx, x2, ld_x2, nx2, residual, ld_res, y, ld_y};
+  RowsArgs ra = {x, ld_x, nx, x2, ld_x2, nx2, residual, ld_res, y, ld_y,
+                 res_gate};
   PoolArgs pa = {};
   EdgeArgs ea = {};
   SegArgs sa = {};
@@ -1276,6 +1282,19 @@ int mlp_fwd_impl(const float *x, int64_t ld_x, int32_t nx, const float *x2,
                                    rows.dev);
 }
 }  // namespace
+
+// Library-internal (the native training step, trainer.hip): y = gate > 0 ?
+// x W : 0 -- a layer's backward dX = dY W^T with the ReluGrad of the layer
+// below applied as the rows leave the kernel (gate = that layer's output).
+namespace pgnn {
+int mlp_rows_gated(const float *x, int64_t ld_x, int32_t nx, int64_t n_rows,
+                   const pgnn_fc_layer *layer, const float *gate, int64_t ld_gate,
+                   float *y, int64_t ld_y, hipStream_t stream) {
+  PGNN_REQUIRE(gate != nullptr, PGNN_E_INVALID, "mlp_rows_gated: null gate");
+  return mlp_fwd_impl(x, ld_x, nx, nullptr, 0, 0, n_rows, layer, 1, gate, ld_gate,
+                      y, ld_y, stream, dyn_of(nullptr), 1);
+}
+}  // namespace pgnn
 
 extern "C" int pgnn_mlp_fwd(const float *x, int64_t ld_x, int32_t nx,
                             const float *x2, int64_t ld_x2, int32_t nx2,

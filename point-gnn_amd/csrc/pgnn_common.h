@@ -141,4 +141,10 @@ size_t device_max_lds();
 // replayed ped_cyl frame then skipped pool tiles, tools/ped_check.py)
 int arm_sched(int32_t *sched, hipStream_t stream);
 
+// gnn.hip, for trainer.hip: y = gate > 0 ? x W : 0 (one layer, rows to HBM) --
+// a backward dX pass with the ReluGrad of the layer below in its epilogue.
+int mlp_rows_gated(const float *x, int64_t ld_x, int32_t nx, int64_t n_rows,
+                   const pgnn_fc_layer *layer, const float *gate, int64_t ld_gate,
+                   float *y, int64_t ld_y, hipStream_t stream);
+
 }  // namespace pgnn

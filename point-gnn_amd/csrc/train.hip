@@ -681,39 +681,34 @@ __global__ void segmax_wgrad_reduce_kernel(const float *__restrict__ partial,
   }
 }
 
-// weight-gradient terms of the further rows of tied positive maxima: one wave
-// per list entry (row r, column c).  Rare (duplicate points): float atomics.
-__global__ __launch_bounds__(256) void segmax_wgrad_tie_list_kernel(
+// weight-gradient terms of the further rows of tied positive maxima (rare:
+// duplicate points; float atomics).  One launch: while the tie list holds them
+// all, one wave per list entry (row r, column c); when it overflowed, a full
+// scan (every tied row except the recorded winner).
+__global__ __launch_bounds__(256) void segmax_wgrad_ties_kernel(
     const int32_t *__restrict__ tie_count, const int32_t *__restrict__ tie_list,
-    int tie_cap, const int32_t *__restrict__ seg, const float *__restrict__ gout,
-    int64_t ldg, const int32_t *__restrict__ cnt, int ldc, XSrc xs, int k_in,
-    int cols, float *__restrict__ dW, float *__restrict__ db) {
-  int n = *tie_count;
-  if (n > tie_cap) return;  // overflow: the scan kernel below does them all
-  const int lane = threadIdx.x & 63;
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int n_waves = (gridDim.x * blockDim.x) >> 6;
-  for (int t = wave; t < n; t += n_waves) {
-    const int r = tie_list[2 * t], c = tie_list[2 * t + 1];
-    const int s = seg[r];
-    const float g = gout[(int64_t)s * ldg + c] / (float)cnt[(int64_t)s * ldc + c];
-    const XRow xr = xs_row(xs, r);
-    for (int k = lane; k < k_in; k += 64)
-      atomicAdd(&dW[(int64_t)k * cols + c], g * xr_at(xr, k));
-    if (db && lane == 0) atomicAdd(&db[c], g);
-  }
-}
-
-// the same by a full scan (every tied row except the recorded winner); runs
-// only when the tie list overflowed
-__global__ void segmax_wgrad_ties_kernel(
-    const int32_t *__restrict__ tie_count, int tie_cap,
-    const float *__restrict__ data, int64_t ld,
+    int tie_cap, const float *__restrict__ data, int64_t ld,
     const int32_t *__restrict__ seg, int64_t rows, int cols, int nseg,
     const float *__restrict__ out, int64_t ldo, const float *__restrict__ gout,
     int64_t ldg, const int32_t *__restrict__ cnt, const int32_t *__restrict__ win,
     int ldc, XSrc xs, int k_in, float *__restrict__ dW, float *__restrict__ db) {
-  if (*tie_count <= tie_cap) return;
+  const int n_ties = *tie_count;
+  if (n_ties <= tie_cap) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (int t = wave; t < n_ties; t += n_waves) {
+      const int r = tie_list[2 * t], c = tie_list[2 * t + 1];
+      const int s = seg[r];
+      const float g =
+          gout[(int64_t)s * ldg + c] / (float)cnt[(int64_t)s * ldc + c];
+      const XRow xr = xs_row(xs, r);
+      for (int k = lane; k < k_in; k += 64)
+        atomicAdd(&dW[(int64_t)k * cols + c], g * xr_at(xr, k));
+      if (db && lane == 0) atomicAdd(&db[c], g);
+    }
+    return;
+  }
   const int64_t total = rows * cols;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
@@ -1113,6 +1108,14 @@ __global__ void l1_norm_kernel(const float *__restrict__ w,
     atomicAdd(out, (part[0] + part[1]) + (part[2] + part[3]));
 }
 
+// dP and dQ zeroed by one fill when the caller laid them out back to back
+// (the trainer does): a fill is a launch, and the step is a chain of them.
+inline hipError_t zero_pair(float *a, float *b, size_t n, hipStream_t stream) {
+  if (b == a + n) return hipMemsetAsync(a, 0, 2 * n * 4, stream);
+  hipError_t e = hipMemsetAsync(a, 0, n * 4, stream);
+  return e != hipSuccess ? e : hipMemsetAsync(b, 0, n * 4, stream);
+}
+
 inline unsigned grid_for(int64_t total, int cap = 4096) {
   int64_t b = (total + 255) / 256;
   if (b > cap) b = cap;
@@ -1227,8 +1230,7 @@ int segfc_bwd_impl(const float *Y, int64_t ld_y, const int32_t *seg_ids,
   if (edges && num_segments > 0) {
     PGNN_REQUIRE(dP && dQ && ld_pq >= k_in, PGNN_E_INVALID,
                  "edge_segmax_fc_bwd: bad dP / dQ");
-    PGNN_HIP(hipMemsetAsync(dP, 0, (size_t)num_segments * ld_pq * 4, stream));
-    PGNN_HIP(hipMemsetAsync(dQ, 0, (size_t)num_segments * ld_pq * 4, stream));
+    PGNN_HIP(zero_pair(dP, dQ, (size_t)num_segments * ld_pq, stream));
   }
   if (n_rows == 0 || num_segments == 0) return 0;
   PGNN_REQUIRE(Y && seg_ids && out && grad_out && WT && dW &&
@@ -1250,7 +1252,9 @@ int segfc_bwd_impl(const float *Y, int64_t ld_y, const int32_t *seg_ids,
                PGNN_E_WORKSPACE, "segmax_fc_bwd: workspace too small");
   SegFcWs w;
   segfc_carve(workspace, n_rows, n_cols, num_segments, k_in, &w);
-  PGNN_HIP(hipMemsetAsync(w.cnt, 0, (size_t)num_segments * w.ldc * 4 + 4, stream));
+  // (counts + the tie flag behind them; a whole number of 16-byte words -- the
+  // region has 256 spare bytes -- so the runtime does not split off a tail fill)
+  PGNN_HIP(hipMemsetAsync(w.cnt, 0, (size_t)num_segments * w.ldc * 4 + 16, stream));
   const int cols4 = (n_cols + 3) / 4;
   hipLaunchKernelGGL(segmax_count_win4_kernel,
                      dim3(grid_for(n_rows * cols4, 8192)), dim3(256), 0, stream, Y,
@@ -1303,14 +1307,11 @@ int segfc_bwd_impl(const float *Y, int64_t ld_y, const int32_t *seg_ids,
                        dim3(grid_for((int64_t)(k_in + 1) * n_cols)), dim3(256), 0,
                        stream, w.partial, w.partial_b, w.slices, n_cols, k_in,
                        w.kin_p, dW, db);
-    hipLaunchKernelGGL(segmax_wgrad_tie_list_kernel, dim3(64), dim3(256), 0,
-                       stream, w.tie, w.tie_list, kTieCap, seg_ids, grad_out,
-                       ld_go, w.cnt, w.ldc, xs, k_in, n_cols, dW, db);
     hipLaunchKernelGGL(segmax_wgrad_ties_kernel,
                        dim3(grid_for(n_rows * n_cols, 2048)), dim3(256), 0,
-                       stream, w.tie, kTieCap, Y, ld_y, seg_ids, n_rows, n_cols,
-                       num_segments, out, ld_out, grad_out, ld_go, w.cnt, w.win,
-                       w.ldc, xs, k_in, dW, db);
+                       stream, w.tie, w.tie_list, kTieCap, Y, ld_y, seg_ids,
+                       n_rows, n_cols, num_segments, out, ld_out, grad_out, ld_go,
+                       w.cnt, w.win, w.ldc, xs, k_in, dW, db);
   }
   PGNN_HIP(hipGetLastError());
   return 0;
@@ -1380,8 +1381,7 @@ extern "C" int pgnn_edge_hidden_bwd(const float *dH1, int64_t ld,
   hipStream_t stream = (hipStream_t)stream_;
   PGNN_REQUIRE(ld > 0 && n_edges >= 0 && n_vertices >= 0 && dP && dQ,
                PGNN_E_INVALID, "edge_hidden_bwd: bad argument");
-  PGNN_HIP(hipMemsetAsync(dP, 0, (size_t)n_vertices * ld * 4, stream));
-  PGNN_HIP(hipMemsetAsync(dQ, 0, (size_t)n_vertices * ld * 4, stream));
+  PGNN_HIP(zero_pair(dP, dQ, (size_t)n_vertices * ld, stream));
   if (n_edges == 0) return 0;
   PGNN_REQUIRE(dH1 && edges, PGNN_E_INVALID, "edge_hidden_bwd: null pointer");
   hipLaunchKernelGGL(edge_hidden_bwd_kernel, dim3(grid_for(n_edges * ld, 8192)),

@@ -40,22 +40,6 @@ __global__ void block_copy_kernel(float *__restrict__ dst, int64_t ldd, int dc0,
   }
 }
 
-// hx = [h[:, :c] | x | 0 ...] (gnn.py:350-352: the vertex part of the concat)
-__global__ void concat_hx_kernel(const float *__restrict__ h, int64_t ldh, int c,
-                                 const float *__restrict__ x, int64_t rows,
-                                 float *__restrict__ hx, int ldhx) {
-  const int64_t total = rows * ldhx;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = idx / ldhx;
-    const int k = (int)(idx - r * ldhx);
-    float v = 0.0f;
-    if (k < c) v = h[r * ldh + k];
-    else if (k < c + 3) v = x[3 * r + (k - c)];
-    hx[idx] = v;
-  }
-}
-
 // pred[r, j, :L] = y[r, :L]
 __global__ void pred_slice_kernel(const float *__restrict__ y, int64_t ldy,
                                   int64_t rows, int L, int nc, int j,
@@ -69,6 +53,30 @@ __global__ void pred_slice_kernel(const float *__restrict__ y, int64_t ldy,
   }
 }
 
+// a fused group's outputs in one pass (the inverse of fused_dy3_kernel):
+// pred[r, lid0 + i, :L] = y[r, base + 8 i : base + 8 i + L], i < n_loc, and,
+// for the group that carries the class head, logits[r, :ncp] = y[r, :ncp]
+__global__ void pred_slices_kernel(const float *__restrict__ y, int64_t ldy,
+                                   int64_t rows, int L, int nc, int lid0,
+                                   int n_loc, int base, float *__restrict__ pred,
+                                   float *__restrict__ logits /* nullable */,
+                                   int ncp) {
+  const int n_box = n_loc * L;
+  const int per_row = n_box + (logits ? ncp : 0);
+  const int64_t total = rows * per_row;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = idx / per_row;
+    const int q = (int)(idx - r * per_row);
+    if (q < n_box) {
+      const int i = q / L, k = q - i * L;
+      pred[(r * nc + lid0 + i) * L + k] = y[r * ldy + base + 8 * i + k];
+    } else {
+      logits[r * ncp + (q - n_box)] = y[r * ldy + (q - n_box)];
+    }
+  }
+}
+
 // dy[r, :] = [dpred[r, j, :L] | 0 ...] (ld = ldy)
 __global__ void dpred_slice_kernel(const float *__restrict__ dpred, int64_t rows,
                                    int L, int nc, int j, float *__restrict__ dy,
@@ -79,6 +87,64 @@ __global__ void dpred_slice_kernel(const float *__restrict__ dpred, int64_t rows
     const int64_t r = idx / ldy;
     const int k = (int)(idx - r * ldy);
     dy[idx] = k < L ? dpred[(r * nc + j) * L + k] : 0.0f;
+  }
+}
+
+// The vertex side of a GNN stage's edge input in one pass (gnn.py:337-352):
+// hx = [h[:, :c] | x | 0 ...] and, with x' = x + delta, x' itself and
+// Q = x' Wx -- pgnn_offset_apply's expression, so Q has the same bits.
+__global__ void pre_edge_prep_kernel(const float *__restrict__ h, int64_t ldh,
+                                     int c, const float *__restrict__ xyz,
+                                     const float *__restrict__ delta,
+                                     int64_t ld_delta, int64_t rows,
+                                     const float *__restrict__ wx,
+                                     float *__restrict__ hx, int ldhx,
+                                     float *__restrict__ xyz_out,
+                                     float *__restrict__ Q, int ld_q) {
+  const int w = ldhx > ld_q ? ldhx : ld_q;
+  const int64_t total = rows * w;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = idx / w;
+    const int k = (int)(idx - r * w);
+    const float p0 = xyz[3 * r], p1 = xyz[3 * r + 1], p2 = xyz[3 * r + 2];
+    if (k < ldhx) {
+      float v = 0.0f;
+      if (k < c) v = h[r * ldh + k];
+      else if (k < c + 3) v = k == c ? p0 : (k == c + 1 ? p1 : p2);
+      hx[r * ldhx + k] = v;
+    }
+    if (k < ld_q) {
+      float x0 = p0, x1 = p1, x2 = p2;
+      if (delta) {
+        x0 = x0 + delta[r * ld_delta];
+        x1 = x1 + delta[r * ld_delta + 1];
+        x2 = x2 + delta[r * ld_delta + 2];
+      }
+      if (k < 3) xyz_out[3 * r + k] = k == 0 ? x0 : (k == 1 ? x1 : x2);
+      Q[r * ld_q + k] = (x0 * wx[k] + x1 * wx[ld_q + k]) + x2 * wx[2 * ld_q + k];
+    }
+  }
+}
+
+// Gradient w.r.t. a GNN stage's input features (gnn.py:372 residual + the two
+// places h enters the stage): dh_in = dh + [dhx[:, :c] + doff[:, :c] | 0]
+__global__ void stage_input_grad_kernel(const float *__restrict__ dh, int ldh,
+                                        const float *__restrict__ dhx, int ldhx,
+                                        const float *__restrict__ doff, int ldo,
+                                        int64_t rows, int c,
+                                        float *__restrict__ dh_in) {
+  const int64_t total = rows * ldh;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = idx / ldh;
+    const int k = (int)(idx - r * ldh);
+    float v = dh[idx];
+    if (k < c) {
+      v += dhx[r * ldhx + k];
+      if (doff) v += doff[r * ldo + k];
+    }
+    dh_in[idx] = v;
   }
 }
 
@@ -361,16 +427,25 @@ int fc_fwd(Ctx &c, const FcDev &f, const float *x, int64_t ldx, int64_t rows,
 }
 
 // dX = dY W^T through the forward engine on the transposed image
+// gate (nullable, [rows, ld_gate]): the layer's forward input when that is a
+// ReLU output -- the ReluGrad of the layer below, dx = gate > 0 ? dx : 0,
+// leaves with the rows instead of taking a launch of its own
 int fc_dx(Ctx &c, const FcDev &f, const float *dy, int64_t lddy, int64_t rows,
-          float *dx) {
+          float *dx, const float *gate = nullptr, int64_t ld_gate = 0) {
   if (c.dry || rows == 0) return 0;
   pgnn_fc_layer L;
   L.packed = f.packed_t;
   L.k_in = f.ref.n_out;
   L.n_out = f.ref.k_in;
   L.relu_from = f.ref.k_in;  // linear
-  return pgnn_mlp_fwd(dy, lddy, f.ref.n_out, nullptr, 0, 0, rows, &L, 1, nullptr,
-                      0, dx, pad16(f.ref.k_in), c.stream);
+  if (gate && ld_gate >= pad16(f.ref.k_in))
+    return mlp_rows_gated(dy, lddy, f.ref.n_out, rows, &L, gate, ld_gate, dx,
+                          pad16(f.ref.k_in), c.stream);
+  int rc = pgnn_mlp_fwd(dy, lddy, f.ref.n_out, nullptr, 0, 0, rows, &L, 1, nullptr,
+                        0, dx, pad16(f.ref.k_in), c.stream);
+  if (rc == 0 && gate)  // (a gate narrower than the padded rows: two launches)
+    rc = pgnn_relu_mask_mul(dx, gate, rows * pad16(f.ref.k_in), c.stream);
+  return rc;
 }
 
 // record dW/db = (x^T dy, column sums) for the end of the backward; x and dy
@@ -410,9 +485,11 @@ int fc_wgrad(Ctx &c, Saved &sv, const FcDev &f, const float *x, int64_t ldx,
 // fc_bwd of the Python mirror: optional ReluGrad (in place on dy), dW/db, dX.
 // defer: the weight gradient is recorded for the end of the backward -- the
 // caller guarantees that x and dy are not written again before that.
+// gate_dx: x is the output of a ReLU layer whose backward comes next: dx leaves
+// already masked (the next fc_bwd is then called with relu = false).
 int fc_bwd(Ctx &c, Saved &sv, const FcDev &f, const float *x, int64_t ldx,
            const float *y, float *dy, int64_t rows, bool relu, float *dx,
-           bool accumulate = true, bool defer = false) {
+           bool accumulate = true, bool defer = false, bool gate_dx = false) {
   if (rows == 0) return 0;
   const int ldy = pad16(f.ref.n_out);
   int rc = 0;
@@ -422,7 +499,8 @@ int fc_bwd(Ctx &c, Saved &sv, const FcDev &f, const float *x, int64_t ldx,
   }
   rc = fc_wgrad(c, sv, f, x, ldx, dy, ldy, rows, accumulate, defer);
   if (rc) return rc;
-  if (dx && !c.dry) rc = fc_dx(c, f, dy, ldy, rows, dx);
+  if (dx && !c.dry)
+    rc = fc_dx(c, f, dy, ldy, rows, dx, gate_dx ? x : nullptr, ldx);
   return rc;
 }
 
@@ -504,6 +582,18 @@ int forward_impl(Ctx &c, Saved &sv) {
   const float *h = nullptr;
   int ld_h = 0;
   int64_t k_h = 0;
+  // the destination column of a level's edge list, extracted once per level
+  // (the three GNN stages of the shipped models share level 1's)
+  int32_t *dst_of[PGNN_TRAIN_MAX_LEVELS] = {nullptr};
+  auto level_dst = [&](int lvl, int64_t E) -> int32_t * {
+    if (dst_of[lvl]) return dst_of[lvl];
+    int32_t *d = c.ws.i32(E > 0 ? E : 1);
+    if (!c.dry && E > 0 && d)
+      hipLaunchKernelGGL(edge_dst_kernel, dim3(blocks_for(E)), dim3(256), 0,
+                         c.stream, b.edges[lvl], E, d);
+    dst_of[lvl] = d;
+    return d;
+  };
   for (size_t si = 0; si < t.stages.size(); ++si) {
     StageDev &s = t.stages[si];
     const int lvl = s.level;
@@ -512,7 +602,7 @@ int forward_impl(Ctx &c, Saved &sv) {
       PoolSaved &p = sv.pool[si];
       p.feat = c.ws.f(E, 16);
       for (size_t i = 0; i < s.a.size(); ++i) p.act[i] = c.ws.f(E, pad16(s.a[i].ref.n_out));
-      p.dst = c.ws.i32(E > 0 ? E : 1);
+      p.dst = level_dst(lvl, E);
       const int wa = pad16(s.a.back().ref.n_out);
       p.agg = c.ws.f(K, wa);
       for (size_t i = 0; i < s.b.size(); ++i) p.oact[i] = c.ws.f(K, pad16(s.b[i].ref.n_out));
@@ -523,9 +613,6 @@ int forward_impl(Ctx &c, Saved &sv) {
                                     b.keypoints[lvl], b.edges[lvl], E, p.feat,
                                     c.stream);
         if (rc) return rc;
-        if (E > 0)
-          hipLaunchKernelGGL(edge_dst_kernel, dim3(blocks_for(E)), dim3(256), 0,
-                             c.stream, b.edges[lvl], E, p.dst);
         const float *x = p.feat;
         int64_t ldx = 16;
         bool fused = false;
@@ -590,7 +677,7 @@ int forward_impl(Ctx &c, Saved &sv) {
       g.p = c.ws.f(K, wq);
       g.eact[0] = c.ws.f(E, wq);
       for (size_t i = 1; i < s.a.size(); ++i) g.eact[i] = c.ws.f(E, pad16(s.a[i].ref.n_out));
-      g.dst = c.ws.i32(E > 0 ? E : 1);
+      g.dst = level_dst(lvl, E);
       const int wa = pad16(s.a.back().ref.n_out);
       g.agg = c.ws.f(K, wa);
       for (size_t i = 0; i < s.b.size(); ++i) g.uact[i] = c.ws.f(K, pad16(s.b[i].ref.n_out));
@@ -616,18 +703,16 @@ int forward_impl(Ctx &c, Saved &sv) {
           delta = x;
           ld_delta = ldx;
         }
-        rc = pgnn_offset_apply(b.coords[lvl], delta, ld_delta, K, s.wx, g.xo, g.q,
-                               wq, c.stream);
-        if (rc) return rc;
-        if (K > 0)
-          hipLaunchKernelGGL(concat_hx_kernel, dim3(blocks_for(K * pad16(cc + 3))),
+        if (K > 0) {
+          const int ldhx = pad16(cc + 3);
+          hipLaunchKernelGGL(pre_edge_prep_kernel,
+                             dim3(blocks_for(K * (ldhx > wq ? ldhx : wq), 8192)),
                              dim3(256), 0, c.stream, h, (int64_t)ld_h, cc,
-                             b.coords[lvl], K, g.hx, pad16(cc + 3));
+                             b.coords[lvl], delta, ld_delta, K, s.wx, g.hx, ldhx,
+                             g.xo, g.q, wq);
+        }
         rc = fc_fwd(c, w1, g.hx, pad16(cc + 3), K, false, nullptr, 0, g.p);
         if (rc) return rc;
-        if (E > 0)
-          hipLaunchKernelGGL(edge_dst_kernel, dim3(blocks_for(E)), dim3(256), 0,
-                             c.stream, b.edges[lvl], E, g.dst);
         bool fused = false;
         if (s.a.size() == 2 && s.a[1].want_wt) {
           // gather + last edge layer + scatter-max in ONE kernel that also
@@ -707,16 +792,29 @@ int forward_impl(Ctx &c, Saved &sv) {
         if (rc) return rc;
         if (K > 0) {
           const int ld3 = pad16(g.f[2].ref.n_out);
-          if (g.has_cls)
-            hipLaunchKernelGGL(block_copy_kernel<false>,
-                               dim3(blocks_for(K * pad16(nc))), dim3(256), 0,
-                               c.stream, hs.logits, (int64_t)pad16(nc), 0,
-                               hs.y3[gi], (int64_t)ld3, 0, K, pad16(nc));
-          for (size_t i = 0; i < g.lids.size(); ++i)
-            hipLaunchKernelGGL(pred_slice_kernel, dim3(blocks_for(K * L)),
-                               dim3(256), 0, c.stream,
-                               hs.y3[gi] + g.base + 8 * (int)i, (int64_t)ld3, K, L,
-                               nc, g.lids[i], hs.pred);
+          bool run = true;  // lids of a group are consecutive
+          for (size_t i = 1; i < g.lids.size(); ++i)
+            run = run && g.lids[i] == g.lids[0] + (int)i;
+          if (run) {
+            const int ncp = pad16(nc);
+            hipLaunchKernelGGL(
+                pred_slices_kernel,
+                dim3(blocks_for(K * (L * (int64_t)g.lids.size() + ncp))),
+                dim3(256), 0, c.stream, hs.y3[gi], (int64_t)ld3, K, L, nc,
+                g.lids.empty() ? 0 : g.lids[0], (int)g.lids.size(), g.base,
+                hs.pred, g.has_cls ? hs.logits : nullptr, ncp);
+          } else {
+            if (g.has_cls)
+              hipLaunchKernelGGL(block_copy_kernel<false>,
+                                 dim3(blocks_for(K * pad16(nc))), dim3(256), 0,
+                                 c.stream, hs.logits, (int64_t)pad16(nc), 0,
+                                 hs.y3[gi], (int64_t)ld3, 0, K, pad16(nc));
+            for (size_t i = 0; i < g.lids.size(); ++i)
+              hipLaunchKernelGGL(pred_slice_kernel, dim3(blocks_for(K * L)),
+                                 dim3(256), 0, c.stream,
+                                 hs.y3[gi] + g.base + 8 * (int)i, (int64_t)ld3, K,
+                                 L, nc, g.lids[i], hs.pred);
+          }
         }
       }
       PGNN_HIP(hipGetLastError());
@@ -846,10 +944,11 @@ int backward_impl(Ctx &c, Saved &sv, const float *dlogits, const float *dpred) {
                              dim3(blocks_for(K * (g.f[1].ref.n_out - g.base))),
                              dim3(256), 0, c.stream, dy2, sv.heads.y2[gi], K, ld2,
                              g.base, g.f[1].ref.n_out);
+        // (dy1 leaves masked by y1 > 0: the first layer's ReluGrad)
         rc = fc_bwd(c, sv, g.f[1], sv.heads.y1[gi], ld1, nullptr, dy2, K, false,
-                    dy1, false, true);
+                    dy1, false, true, true);
         if (rc) return rc;
-        rc = fc_bwd(c, sv, g.f[0], sv.h_final, hw, sv.heads.y1[gi], dy1, K, true,
+        rc = fc_bwd(c, sv, g.f[0], sv.h_final, hw, sv.heads.y1[gi], dy1, K, false,
                     gi == 0 ? dh : dxh, false, true);
         if (rc) return rc;
         if (gi > 0)
@@ -874,9 +973,10 @@ int backward_impl(Ctx &c, Saved &sv, const float *dlogits, const float *dpred) {
     hipLaunchKernelGGL(block_copy_kernel<false>, dim3(blocks_for(K * nc)),
                        dim3(256), 0, c.stream, dy, (int64_t)pad16(nc), 0, dlogits,
                        (int64_t)nc, 0, K, nc);
-    rc = fc_bwd(c, sv, t.cls[1], hs.c1, w64, hs.logits, dy, K, false, d1);
+    rc = fc_bwd(c, sv, t.cls[1], hs.c1, w64, hs.logits, dy, K, false, d1, true,
+                false, true);
     if (rc) return rc;
-    rc = fc_bwd(c, sv, t.cls[0], sv.h_final, hw, hs.c1, d1, K, true, dxh);
+    rc = fc_bwd(c, sv, t.cls[0], sv.h_final, hw, hs.c1, d1, K, false, dxh);
     if (rc) return rc;
     hipLaunchKernelGGL(block_copy_kernel<true>, dim3(blocks_for(K * cw)),
                        dim3(256), 0, c.stream, dh, (int64_t)hw, 0, dxh,
@@ -886,12 +986,14 @@ int backward_impl(Ctx &c, Saved &sv, const float *dlogits, const float *dpred) {
                          dim3(256), 0, c.stream, dpred, K, L, nc, j, dy,
                          pad16(L));
       rc = fc_bwd(c, sv, t.loc[3 * j + 2], hs.l2[j],
-                  pad16(t.loc[3 * j + 1].ref.n_out), hs.l3[j], dy, K, false, d2);
+                  pad16(t.loc[3 * j + 1].ref.n_out), hs.l3[j], dy, K, false, d2,
+                  true, false, true);
       if (rc) return rc;
       rc = fc_bwd(c, sv, t.loc[3 * j + 1], hs.l1[j],
-                  pad16(t.loc[3 * j].ref.n_out), hs.l2[j], d2, K, true, d1);
+                  pad16(t.loc[3 * j].ref.n_out), hs.l2[j], d2, K, false, d1, true,
+                  false, true);
       if (rc) return rc;
-      rc = fc_bwd(c, sv, t.loc[3 * j], sv.h_final, hw, hs.l1[j], d1, K, true, dxh);
+      rc = fc_bwd(c, sv, t.loc[3 * j], sv.h_final, hw, hs.l1[j], d1, K, false, dxh);
       if (rc) return rc;
       hipLaunchKernelGGL(block_copy_kernel<true>, dim3(blocks_for(K * cw)),
                          dim3(256), 0, c.stream, dh, (int64_t)hw, 0, dxh,
@@ -919,7 +1021,8 @@ int backward_impl(Ctx &c, Saved &sv, const float *dlogits, const float *dpred) {
       float *du[PGNN_TRAIN_MAX_FC + 1];
       for (size_t i = 0; i < s.b.size(); ++i)
         du[i] = c.ws.f(Ks, pad16(s.b[i].ref.k_in));
-      float *dp = c.ws.f(Ks, wq), *dq = c.ws.f(Ks, wq);
+      float *dp = c.ws.f(2 * Ks, wq);  // dP | dQ back to back: one fill
+      float *dq = dp ? dp + Ks * wq : nullptr;
       float *dhx = c.ws.f(Ks, pad16(cc + 3));
       float *dxo = c.ws.f(Ks, 16);
       float *doff[PGNN_TRAIN_MAX_FC];
@@ -935,17 +1038,16 @@ int backward_impl(Ctx &c, Saved &sv, const float *dlogits, const float *dpred) {
       int32_t *ties = nullptr;
       if (!s.a.back().want_wt) ties = c.ws.i32(Ks * wa > 0 ? Ks * wa : 1);
       if (!c.dry && Ks > 0) {
-        // residual branch (gnn.py:372): dh_in starts as a copy of dh
-        PGNN_HIP(hipMemcpyAsync(dh2, dh, (size_t)Ks * ld_h * 4,
-                                hipMemcpyDeviceToDevice, c.stream));
+        // (residual branch, gnn.py:372: dh_in = dh + what the edge input and
+        // the offset MLP send back -- summed in one pass at the stage's end)
         // update MLP, last layer linear
         float *d = dh;
         for (int i = (int)s.b.size() - 1; i >= 0; --i) {
-          const bool last = i + 1 == (int)s.b.size();
           const float *xin = i == 0 ? g.agg : g.uact[i - 1];
           const int64_t ldx = i == 0 ? wa : pad16(s.b[i - 1].ref.n_out);
-          rc = fc_bwd(c, sv, s.b[i], xin, ldx, g.uact[i], d, Ks, !last, du[i],
-                      true, true);
+          // (the ReluGrad of layer i - 1 leaves with du[i]: gate = xin)
+          rc = fc_bwd(c, sv, s.b[i], xin, ldx, g.uact[i], d, Ks, false, du[i],
+                      true, true, i > 0);
           if (rc) return rc;
           d = du[i];
         }
@@ -986,10 +1088,7 @@ int backward_impl(Ctx &c, Saved &sv, const float *dlogits, const float *dpred) {
         }
         for (int i = from; i >= 1; --i) {  // dense middle edge layers
           rc = fc_bwd(c, sv, s.a[i], g.eact[i - 1], pad16(s.a[i].ref.k_in),
-                      g.eact[i], gcur, E, false, ge[i - 1]);
-          if (rc) return rc;
-          rc = pgnn_relu_mask_mul(ge[i - 1], g.eact[i - 1],
-                                  E * pad16(s.a[i].ref.k_in), c.stream);
+                      g.eact[i], gcur, E, false, ge[i - 1], true, false, true);
           if (rc) return rc;
           gcur = ge[i - 1];
         }
@@ -1002,9 +1101,6 @@ int backward_impl(Ctx &c, Saved &sv, const float *dlogits, const float *dpred) {
         rc = fc_bwd(c, sv, w1, g.hx, pad16(cc + 3), nullptr, dp, Ks, false, dhx,
                     true, true);
         if (rc) return rc;
-        hipLaunchKernelGGL(block_copy_kernel<true>, dim3(blocks_for(Ks * cc)),
-                           dim3(256), 0, c.stream, dh2, (int64_t)ld_h, 0, dhx,
-                           (int64_t)pad16(cc + 3), 0, Ks, cc);
         // Q = x' Wx, Wx = rows cc..cc+2 of W1 (the minus sign is in dq)
         // (not deferred: it adds into rows of the same dW as the deferred
         // job of w1 above, and jobs of one batch must not share outputs)
@@ -1012,6 +1108,7 @@ int backward_impl(Ctx &c, Saved &sv, const float *dlogits, const float *dpred) {
                                   w1.gw + (int64_t)cc * w1.ref.n_out, nullptr, 1,
                                   sv.scratch, sv.scratch_bytes, c.stream);
         if (rc) return rc;
+        const float *d_off = nullptr;  // grad w.r.t. h through the offset MLP
         if (!s.c.empty()) {
           pgnn_fc_layer Lx;  // dx' = dQ Wx^T
           Lx.packed = s.wx_packed_t;
@@ -1025,15 +1122,17 @@ int backward_impl(Ctx &c, Saved &sv, const float *dlogits, const float *dpred) {
           for (int i = (int)s.c.size() - 1; i >= 0; --i) {
             const float *xin = i == 0 ? g.h_in : g.off_act[i - 1];
             const int64_t ldx = i == 0 ? ld_h : pad16(s.c[i - 1].ref.n_out);
-            rc = fc_bwd(c, sv, s.c[i], xin, ldx, g.off_act[i], d, Ks,
-                        i + 1 < (int)s.c.size(), doff[i], true, true);
+            rc = fc_bwd(c, sv, s.c[i], xin, ldx, g.off_act[i], d, Ks, false,
+                        doff[i], true, true, i > 0);
             if (rc) return rc;
             d = doff[i];
           }
-          hipLaunchKernelGGL(block_copy_kernel<true>, dim3(blocks_for(Ks * cc)),
-                             dim3(256), 0, c.stream, dh2, (int64_t)ld_h, 0, d,
-                             (int64_t)pad16(s.c[0].ref.k_in), 0, Ks, cc);
+          d_off = d;
         }
+        hipLaunchKernelGGL(stage_input_grad_kernel, dim3(blocks_for(Ks * ld_h)),
+                           dim3(256), 0, c.stream, dh, ld_h, dhx, pad16(cc + 3),
+                           d_off, s.c.empty() ? 0 : pad16(s.c[0].ref.k_in), Ks, cc,
+                           dh2);
       }
       c.ws.off = mark;
     } else {
@@ -1057,8 +1156,10 @@ int backward_impl(Ctx &c, Saved &sv, const float *dlogits, const float *dpred) {
         for (int i = (int)s.b.size() - 1; i >= 0; --i) {
           const float *xin = i == 0 ? p.agg : p.oact[i - 1];
           const int64_t ldx = i == 0 ? wa : pad16(s.b[i - 1].ref.n_out);
-          rc = fc_bwd(c, sv, s.b[i], xin, ldx, p.oact[i], d, Ks, true, dob[i],
-                      true, true);
+          // every layer is a ReLU layer: the last one's mask is applied to
+          // dh here, the others' leave with the dX of the layer above
+          rc = fc_bwd(c, sv, s.b[i], xin, ldx, p.oact[i], d, Ks,
+                      i + 1 == (int)s.b.size(), dob[i], true, true, i > 0);
           if (rc) return rc;
           d = dob[i];
         }
@@ -1106,14 +1207,9 @@ int backward_impl(Ctx &c, Saved &sv, const float *dlogits, const float *dpred) {
           const float *xin = i == 0 ? p.feat : p.act[i - 1];
           const int64_t ldx = i == 0 ? 16 : pad16(s.a[i - 1].ref.n_out);
           rc = fc_bwd(c, sv, s.a[i], xin, ldx, p.act[i], gcur, E, false,
-                      i > 0 ? ga[i - 1] : nullptr);
+                      i > 0 ? ga[i - 1] : nullptr, true, false, i > 0);
           if (rc) return rc;
-          if (i > 0) {
-            rc = pgnn_relu_mask_mul(ga[i - 1], p.act[i - 1],
-                                    E * pad16(s.a[i].ref.k_in), c.stream);
-            if (rc) return rc;
-            gcur = ga[i - 1];
-          }
+          if (i > 0) gcur = ga[i - 1];
         }
       }
       c.ws.off = mark;

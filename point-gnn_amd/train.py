@@ -263,6 +263,42 @@ def train_epochs(dataset, config, train_config, trainer=None, max_epoch=None,
     return trainer, results
 
 
+class StepResult(object):
+    """The numbers of one training step ([sum CE, sum loc, -, -, L1 of the
+    weights, (global n, n_valid)] float64), on their way to pinned host memory
+    on the step's stream.  get() waits for that copy -- not for anything queued
+    after it -- and returns the loss dict of models.py:308-311."""
+
+    def __init__(self, trainer, dev_values, counts, lr):
+        self.cls_w, self.loc_w = trainer.cls_w, trainer.loc_w
+        self.l1_scale = trainer.l1_scale
+        self.counts, self.lr = counts, lr
+        self.host = torch.empty(dev_values.shape, dtype=dev_values.dtype,
+                                pin_memory=True)
+        self.host.copy_(dev_values, non_blocking=True)
+        self.done = torch.cuda.Event()
+        self.done.record()
+        self._dev = dev_values      # alive until the copy has run
+        self._out = None
+
+    def get(self):
+        if self._out is None:
+            self.done.synchronize()
+            self._dev = None
+            v = self.host.tolist()
+            n_total, nv_total = self.counts if self.counts is not None \
+                else (v[5], v[6])
+            self._out = {
+                'cls_loss': self.cls_w * float(v[0]) / max(n_total, 1.0),
+                'loc_loss': (self.loc_w * float(v[1]) / nv_total)
+                if nv_total > 0 else 0.0,
+                'reg_loss': self.l1_scale * float(v[4]),
+                'num_endpoint': int(n_total), 'num_valid_endpoint': nv_total,
+                'learning_rate': self.lr,
+            }
+        return self._out
+
+
 class _Fc(object):
     """One fully connected layer of the flat parameter buffer."""
 
@@ -1048,7 +1084,7 @@ class Trainer(object):
 
     # ---- one training step ----------------------------------------------------------
     def train_step(self, batch, apply=True, num_valid=None,
-                   after_enqueue=None):
+                   after_enqueue=None, deferred=False):
         """batch = (input_v, vertex_coord_list, keypoint_indices_list,
         edges_list, cls_labels [K,1], encoded_boxes [K,1,L], valid_boxes
         [K,1,1]) -- what train.py's batch_data returns for this rank.
@@ -1058,7 +1094,13 @@ class Trainer(object):
         host (the data loader does): saves the one device read that otherwise
         sits between forward and backward.  after_enqueue: called once forward,
         loss and backward are all queued and before the host waits for the loss
-        sums -- the place to build the NEXT batch's graph on another stream."""
+        sums (the gradient all-reduce, SGD and the image refresh are queued by
+        then too) -- the place to build the NEXT batch's graph on another stream.
+        deferred (extension): return a StepResult instead of the dict; the
+        step's numbers are copied to pinned host memory behind the step and
+        `.get()` waits for that copy alone, so the caller can queue the next
+        step before it looks at this one's loss (sess.run hands the values
+        back at once, train.py:563-575; the values are the same)."""
         (input_v, coords, kps, edges, labels, boxes, valid) = batch
         self.grad.zero_()
         va = torch.as_tensor(valid).to(self.device, torch.float32).reshape(-1)
@@ -1089,8 +1131,6 @@ class Trainer(object):
             logits, pred, torch.as_tensor(labels), torch.as_tensor(boxes), va,
             n_total, nv_total, counts_dev=counts_dev)
         self.backward(dlog, dpred)
-        if after_enqueue is not None:
-            after_enqueue()
         ev = getattr(self, 'allreduce_events', None)
         if ev is not None:  # bench.py: device time of the collective
             e0 = torch.cuda.Event(enable_timing=True)
@@ -1101,20 +1141,13 @@ class Trainer(object):
             e1.record()
             ev.append((e0, e1))
         lr = learning_rate(self.train_config, self.global_step)
-        if counts_dev is not None:   # the step's one host read, at its end
-            host = torch.cat([sums, counts_dev]).tolist()
-            s_ce, s_loc, n_total, nv_total = host[0], host[1], host[4], host[5]
-        else:
-            host = sums.tolist()
-            s_ce, s_loc = host[0], host[1]
-        out = {
-            'cls_loss': self.cls_w * float(s_ce) / max(n_total, 1.0),
-            'loc_loss': (self.loc_w * float(s_loc) / nv_total)
-            if nv_total > 0 else 0.0,
-            'reg_loss': self.reg_loss(),
-            'num_endpoint': int(n_total), 'num_valid_endpoint': nv_total,
-            'learning_rate': lr,
-        }
+        # Everything the device still has to do is queued BEFORE the host reads
+        # anything: the L1 term of the weights this step used, SGD, the image
+        # refresh.  The step's numbers then come back in one copy.
+        l1 = torch.zeros(1, dtype=torch.float64, device=self.device)
+        _lib.check(self.lib.pgnn_l1_norm(
+            _lib.ptr(self.flat), _lib.ptr(self.is_weight), self.flat.numel(),
+            _lib.ptr(l1), self._st()), "pgnn_l1_norm")
         if apply:
             _lib.check(self.lib.pgnn_sgd_step(
                 _lib.ptr(self.flat), _lib.ptr(self.grad),
@@ -1123,4 +1156,10 @@ class Trainer(object):
                 ctypes.c_float(self.l1_scale), self._st()), "pgnn_sgd_step")
             self.repack()
             self.global_step += 1
-        return out
+        parts = [sums, l1] if counts_dev is None else [sums, l1, counts_dev]
+        res = StepResult(self, torch.cat(parts), counts, lr)
+        if after_enqueue is not None:
+            # (behind the collective and the update: the host reads of a graph
+            # build must not hold back the all-reduce's launch)
+            after_enqueue()
+        return res if deferred else res.get()
