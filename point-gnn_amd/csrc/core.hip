@@ -152,6 +152,7 @@ extern int g_mlp_debug;
 extern void *g_mlp_ts;
 extern int g_scatter_nt;
 extern int g_wgrad_wg_target;
+extern int g_train_h1;
 
 }  // namespace pgnn
 
@@ -273,6 +274,11 @@ extern "C" int pgnn_set_tunable(const char *key, int value) {
   if (!strcmp(key, "ws_balance")) {
     if (value < 0 || value > 2) return PGNN_E_INVALID;
     pgnn::g_ws_balance = value;
+    return 0;
+  }
+  if (!strcmp(key, "train_h1")) {
+    if (value < 0 || value > 1) return PGNN_E_INVALID;
+    pgnn::g_train_h1 = value;
     return 0;
   }
   if (!strcmp(key, "ws_reserve")) {

@@ -77,6 +77,11 @@ struct RowsArgs {
   int64_t ldy;
   int res_gate;  // 0: y = rows + res; 1: y = res > 0 ? rows : 0 (ReluGrad of
                  // the layer below, fused into a backward dX pass)
+  // taps of the chain form (rows_mlp_kernel<true>, the native training step):
+  // the output of layer li < n - 1 is gated in the tile by gate[li] > 0
+  // (nullable) and written to mid[li] (nullable), both [rows, 16 nt(li)]
+  float *mid[PGNN_MAX_LAYERS - 1];
+  const float *gate[PGNN_MAX_LAYERS - 1];
 };
 struct PoolArgs {
   const float *feat;
@@ -268,6 +273,45 @@ __device__ __forceinline__ void consume_rows16(const float *__restrict__ stage,
       yr[c] = v;
     }
   }
+}
+
+// A layer's output rows on their way through the chain: tile[r][c] = gate[row][c]
+// > 0 ? tile[r][c] : 0 (when gated), mid[row][c] = tile[r][c] (when tapped);
+// gate and mid are [rows, ncols].  Same thread layout and the same rule -- all
+// loads of a round before its first store -- as consume_rows16.
+__device__ __forceinline__ void tap_rows16(float *tile, int ld, int64_t row0,
+                                           int rows_valid, int ncols,
+                                           const float *__restrict__ gate,
+                                           float *__restrict__ mid) {
+  const int r = threadIdx.x >> 5, c0 = threadIdx.x & 31;
+  const int64_t row = row0 + (r < rows_valid ? r : rows_valid - 1);
+  for (int cb = 0; cb < ncols; cb += 32 * kRowSteps) {
+    const int left = ncols - cb;
+    float g[kRowSteps];
+    if (gate) {
+      const float *__restrict__ gr = gate + row * ncols + cb;
+#pragma unroll
+      for (int j = 0; j < kRowSteps; ++j) {
+        const int c = c0 + 32 * j;
+        g[j] = gr[c < left ? c : left - 1];  // unconditional, clamped
+      }
+    }
+    float *tr = tile + r * ld + cb;
+    float *__restrict__ mr = mid ? mid + row * ncols + cb : nullptr;
+#pragma unroll
+    for (int j = 0; j < kRowSteps; ++j) {
+      const int c = c0 + 32 * j;
+      if (c < left) {
+        float v = tr[c];
+        if (gate) {
+          v = g[j] > 0.0f ? v : 0.0f;
+          tr[c] = v;
+        }
+        if (mr && r < rows_valid) mr[c] = v;
+      }
+    }
+  }
+  if (gate) __syncthreads();  // the next pass reads the gated tile
 }
 
 // tile[r][c] = c < nx ? x[row0 + r][c] : 0 for c < kc (rows past the end: 0);
@@ -906,6 +950,7 @@ int launch_fused(const Plan &p, int64_t n_rows, const RowsArgs &ra,
 // every SIMD two waves.
 constexpr int kRowsWaves = 8;  // (16 waves: 128 VGPRs, spills, 13 % slower)
 
+template <bool TAPS>
 __global__ __launch_bounds__(64 * kRowsWaves) void rows_mlp_kernel(
     ChainDev chain, int64_t n_rows, RowsArgs ra, int stage_off,
     const int32_t *n_dev /* nullable: capacity form, see fused_mlp_kernel */) {
@@ -959,6 +1004,9 @@ __global__ __launch_bounds__(64 * kRowsWaves) void rows_mlp_kernel(
       const LayerDev &L = chain.l[li];
       krow_pass(tile, lds_ld(16 * L.kq), tile, lds_ld(16 * L.nt), L, 0, wave,
                 lane, pre, true, chain.l[li + 1], 0);
+      if constexpr (TAPS)
+        tap_rows16(tile, lds_ld(16 * L.nt), row0, rows_valid, 16 * L.nt,
+                   ra.gate[li], ra.mid[li]);
     }
     const LayerDev &L = chain.l[chain.n - 1];
     const int ld_in = lds_ld(16 * L.kq);
@@ -976,6 +1024,7 @@ __global__ __launch_bounds__(64 * kRowsWaves) void rows_mlp_kernel(
   }
 }
 
+template <bool TAPS = false>
 int launch_rows8(const Plan &p, int64_t n_rows, const RowsArgs &ra,
                  hipStream_t stream, const int32_t *n_dev = nullptr,
                  int64_t grid_tiles = 0 /* capacity form: workgroups to
@@ -983,7 +1032,7 @@ int launch_rows8(const Plan &p, int64_t n_rows, const RowsArgs &ra,
   const size_t lds = plan_lds_bytes(p, 16);
   PGNN_REQUIRE(lds <= 160 * 1024, PGNN_E_UNSUPPORTED,
                "mlp: layer too wide for the LDS tile");
-  auto kern = rows_mlp_kernel;
+  auto kern = rows_mlp_kernel<TAPS>;
   {
     const int lrc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
     if (lrc) return lrc;
@@ -1293,6 +1342,45 @@ int mlp_rows_gated(const float *x, int64_t ld_x, int32_t nx, int64_t n_rows,
   PGNN_REQUIRE(gate != nullptr, PGNN_E_INVALID, "mlp_rows_gated: null gate");
   return mlp_fwd_impl(x, ld_x, nx, nullptr, 0, 0, n_rows, layer, 1, gate, ld_gate,
                       y, ld_y, stream, dyn_of(nullptr), 1);
+}
+}  // namespace pgnn
+
+// Library-internal (trainer.hip): a chain of layers on few rows in ONE launch
+// of the 8-wave kernel with every intermediate layer's output written out
+// (taps[li].mid, [n_rows, 16 ceil(n_out / 16)]) and, for backward dX chains,
+// gated first (taps[li].gate, same shape: out = gate > 0 ? out : 0).  The last
+// layer leaves through `residual` / res_gate as in mlp_rows_gated / pgnn_mlp_fwd.
+// PGNN_E_UNSUPPORTED, having done nothing, when the row count belongs to the
+// larger-tile kernels or the chain does not fit the LDS: run it layer by layer.
+namespace pgnn {
+int mlp_rows_chain(const float *x, int64_t ld_x, int32_t nx, int64_t n_rows,
+                   const pgnn_fc_layer *layers, int32_t n_layers,
+                   const RowsTap *taps, const float *residual, int64_t ld_res,
+                   int res_gate, float *y, int64_t ld_y, hipStream_t stream) {
+  PGNN_REQUIRE(n_rows >= 0 && nx > 0 && n_layers >= 1 &&
+                   n_layers <= PGNN_MAX_LAYERS && (taps || n_layers == 1),
+               PGNN_E_INVALID, "mlp_rows_chain: bad sizes");
+  if (n_rows == 0) return 0;
+  if (n_rows > 32 * (int64_t)device_cu_count()) return PGNN_E_UNSUPPORTED;
+  PGNN_REQUIRE(x && y && layers && ld_x >= nx, PGNN_E_INVALID,
+               "mlp_rows_chain: bad input");
+  for (int i = 0; i + 1 < n_layers; ++i)  // widths that make_plan refuses
+    if ((layers[i].n_out + 15) / 16 != (layers[i + 1].k_in + 15) / 16 ||
+        (layers[i].n_out + 15) / 16 > kMaxTilesPerPass)
+      return PGNN_E_UNSUPPORTED;
+  Plan p;
+  int rc = make_plan(layers, n_layers, nx, p);
+  if (rc) return rc;
+  if (plan_lds_bytes(p, 16) > 160 * 1024) return PGNN_E_UNSUPPORTED;
+  const int out_cols = 16 * p.chain.l[n_layers - 1].nt;
+  PGNN_REQUIRE(ld_y >= out_cols && (!residual || ld_res >= out_cols),
+               PGNN_E_INVALID, "mlp_rows_chain: ld_y/ld_res < padded output width");
+  RowsArgs ra = {x, ld_x, nx, nullptr, 0, 0, residual, ld_res, y, ld_y, res_gate};
+  for (int li = 0; li + 1 < n_layers; ++li) {
+    ra.mid[li] = taps[li].mid;
+    ra.gate[li] = taps[li].gate;
+  }
+  return launch_rows8<true>(p, n_rows, ra, stream);
 }
 }  // namespace pgnn
 

@@ -146,5 +146,15 @@ int arm_sched(int32_t *sched, hipStream_t stream);
 int mlp_rows_gated(const float *x, int64_t ld_x, int32_t nx, int64_t n_rows,
                    const pgnn_fc_layer *layer, const float *gate, int64_t ld_gate,
                    float *y, int64_t ld_y, hipStream_t stream);
+// gnn.hip, for trainer.hip: a chain of layers on few rows in one launch, every
+// intermediate output gated (backward chains) and written out (see gnn.hip)
+struct RowsTap {
+  float *mid;         // nullable: where layer li's output rows go
+  const float *gate;  // nullable: out = gate > 0 ? out : 0 first
+};
+int mlp_rows_chain(const float *x, int64_t ld_x, int32_t nx, int64_t n_rows,
+                   const pgnn_fc_layer *layers, int32_t n_layers,
+                   const RowsTap *taps, const float *residual, int64_t ld_res,
+                   int res_gate, float *y, int64_t ld_y, hipStream_t stream);
 
 }  // namespace pgnn

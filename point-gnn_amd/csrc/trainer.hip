@@ -18,6 +18,14 @@
 
 #include "pgnn_common.h"
 
+namespace pgnn {
+// 1: the fused training forward of a GNN stage also writes the gathered hidden
+// rows H1 = ReLU(P[src] - Q[dst]) [E, C] and the backward reads them; 0: H1 is
+// never materialised -- the backward recomputes the rows it needs from the
+// K-row tables P and Q (L2-resident)
+int g_train_h1 = 1;
+}  // namespace pgnn
+
 namespace {
 using namespace pgnn;
 
@@ -390,6 +398,9 @@ struct Ctx {
   // backward's critical path.  Recorded in the sizing run too (the partial
   // buffer comes out of the same workspace).
   std::vector<pgnn_wgrad_job> wjobs;
+  // a second batch, run after the first: jobs that add into a dW the first
+  // batch also writes (the Wx rows of a GNN stage's first edge layer)
+  std::vector<pgnn_wgrad_job> wjobs2;
 };
 
 int check_batch(const Trainer &t, const pgnn_train_batch *b) {
@@ -424,6 +435,43 @@ int fc_fwd(Ctx &c, const FcDev &f, const float *x, int64_t ldx, int64_t rows,
            bool relu, const float *residual, int64_t ld_res, float *y) {
   return fc_fwd_from(c, f, x, ldx, rows, relu ? 0 : f.ref.n_out, residual,
                      ld_res, y);
+}
+
+// A chain of FC layers on the K vertex rows with every layer's output kept
+// (the backward needs them): ONE launch of the 8-wave row kernel when it
+// applies (mlp_rows_chain: the intermediate rows stay in LDS and are written
+// out on the way), else layer by layer.  relu_from[i] as in pgnn_fc_layer; the
+// residual is added to the last layer's rows.
+int fc_chain_fwd(Ctx &c, const FcDev *const *f, const int *relu_from, int n,
+                 const float *x, int64_t ldx, int64_t rows, const float *residual,
+                 int64_t ld_res, float *const *outs) {
+  if (c.dry || rows == 0 || n == 0) return 0;
+  if (n >= 2 && n <= PGNN_MAX_LAYERS) {
+    pgnn_fc_layer L[PGNN_MAX_LAYERS];
+    RowsTap taps[PGNN_MAX_LAYERS];
+    for (int i = 0; i < n; ++i) {
+      L[i].packed = f[i]->packed;
+      L[i].k_in = f[i]->ref.k_in;
+      L[i].n_out = f[i]->ref.n_out;
+      L[i].relu_from = relu_from[i];
+      taps[i].mid = outs[i];
+      taps[i].gate = nullptr;
+    }
+    const int rc = mlp_rows_chain(x, ldx, f[0]->ref.k_in, rows, L, n, taps,
+                                  residual, ld_res, 0, outs[n - 1],
+                                  pad16(f[n - 1]->ref.n_out), c.stream);
+    if (rc != PGNN_E_UNSUPPORTED) return rc;
+  }
+  for (int i = 0; i < n; ++i) {
+    const bool last = i + 1 == n;
+    const int rc = fc_fwd_from(c, *f[i], x, ldx, rows, relu_from[i],
+                               last ? residual : nullptr, last ? ld_res : 0,
+                               outs[i]);
+    if (rc) return rc;
+    x = outs[i];
+    ldx = pad16(f[i]->ref.n_out);
+  }
+  return 0;
 }
 
 // dX = dY W^T through the forward engine on the transposed image
@@ -504,6 +552,104 @@ int fc_bwd(Ctx &c, Saved &sv, const FcDev &f, const float *x, int64_t ldx,
   return rc;
 }
 
+// Backward of a chain of K-row layers f[0..n-1] (forward order) whose top
+// gradient dy_top is final: every weight gradient is recorded for the end of
+// the backward, and ALL the dX -- dxs[i] = dy_i W_i^T, masked by xin[i] > 0
+// where gate[i] (xin[i] is then the ReLU output of layer i - 1: its ReluGrad)
+// -- come from one launch when mlp_rows_chain applies (dxs[i] is the dy of
+// layer i - 1: it stays in LDS and is written out on the way).
+// pre (nullable): dy_top itself is a linear map of other rows, dy_top = pre->x
+// pre->W (a dX step without a weight gradient of its own) -- it becomes the
+// chain's first layer.
+struct PreDx {
+  const void *packed;  // device image of W [k_in, n_out]
+  int k_in, n_out;
+  const float *x;
+  int64_t ldx;
+};
+int pre_dx(Ctx &c, const PreDx &p, int64_t rows, float *dy_top) {
+  pgnn_fc_layer L;
+  L.packed = (const float *)p.packed;
+  L.k_in = p.k_in;
+  L.n_out = p.n_out;
+  L.relu_from = p.n_out;
+  return pgnn_mlp_fwd(p.x, p.ldx, p.k_in, nullptr, 0, 0, rows, &L, 1, nullptr, 0,
+                      dy_top, pad16(p.n_out), c.stream);
+}
+int fc_chain_bwd(Ctx &c, Saved &sv, const FcDev *const *f, int n,
+                 const float *const *xin, const int64_t *ldx, float *dy_top,
+                 int64_t rows, float *const *dxs, const bool *gate,
+                 bool accumulate = true, const PreDx *pre = nullptr) {
+  if (rows == 0 || n == 0) return 0;
+  const int np = pre ? 1 : 0;
+  bool chain = n + np >= 2 && n + np <= PGNN_MAX_LAYERS;
+  for (int i = 0; i < n && chain; ++i)
+    chain = f[i]->ref.n_out <= 320 && f[i]->packed_t != nullptr &&
+            (!gate[i] || ldx[i] == pad16(f[i]->ref.k_in));
+  int rc = 0;
+  if (chain) {
+    // (recorded in the sizing run too; a job only holds pointers)
+    const float *dy = dy_top;
+    for (int i = n - 1; i >= 0; --i) {
+      rc = fc_wgrad(c, sv, *f[i], xin[i], ldx[i], dy, pad16(f[i]->ref.n_out), rows,
+                    accumulate, true);
+      if (rc) return rc;
+      dy = dxs[i];
+    }
+    if (c.dry) return 0;
+    pgnn_fc_layer L[PGNN_MAX_LAYERS];
+    RowsTap taps[PGNN_MAX_LAYERS];
+    if (pre) {
+      L[0].packed = (const float *)pre->packed;
+      L[0].k_in = pre->k_in;
+      L[0].n_out = pre->n_out;
+      L[0].relu_from = pre->n_out;
+      taps[0].mid = dy_top;
+      taps[0].gate = nullptr;
+    }
+    for (int j = 0; j < n; ++j) {
+      const FcDev &g = *f[n - 1 - j];
+      L[np + j].packed = g.packed_t;
+      L[np + j].k_in = g.ref.n_out;
+      L[np + j].n_out = g.ref.k_in;
+      L[np + j].relu_from = g.ref.k_in;  // linear
+      taps[np + j].mid = dxs[n - 1 - j];
+      taps[np + j].gate = gate[n - 1 - j] ? xin[n - 1 - j] : nullptr;
+    }
+    rc = mlp_rows_chain(pre ? pre->x : dy_top,
+                        pre ? pre->ldx : (int64_t)pad16(f[n - 1]->ref.n_out),
+                        pre ? pre->k_in : f[n - 1]->ref.n_out, rows, L, n + np, taps,
+                        gate[0] ? xin[0] : nullptr, ldx[0], gate[0] ? 1 : 0,
+                        dxs[0], pad16(f[0]->ref.k_in), c.stream);
+    if (rc != PGNN_E_UNSUPPORTED) return rc;
+    // the dX launches one by one (the weight gradients are already recorded)
+    if (pre) {
+      rc = pre_dx(c, *pre, rows, dy_top);
+      if (rc) return rc;
+    }
+    float *d = dy_top;
+    for (int i = n - 1; i >= 0; --i) {
+      rc = fc_dx(c, *f[i], d, pad16(f[i]->ref.n_out), rows, dxs[i],
+                 gate[i] ? xin[i] : nullptr, ldx[i]);
+      if (rc) return rc;
+      d = dxs[i];
+    }
+    return 0;
+  }
+  if (pre && !c.dry) {
+    rc = pre_dx(c, *pre, rows, dy_top);
+    if (rc) return rc;
+  }
+  float *d = dy_top;
+  for (int i = n - 1; i >= 0; --i) {
+    rc = fc_bwd(c, sv, *f[i], xin[i], ldx[i], nullptr, d, rows, false, dxs[i],
+                accumulate, true, gate[i]);
+    if (rc) return rc;
+    d = dxs[i];
+  }
+  return 0;
+}
+
 // run the recorded weight gradients (one launch pair).  Their partial sums
 // take a fixed slice of the workspace (the sizing run records no jobs: it
 // does not walk the launch code): pgnn_weight_grad_many_f32 aims for 4
@@ -514,26 +660,27 @@ size_t wgrad_many_bound() {
 int flush_wgrads(Ctx &c, Saved &sv) {
   const size_t bound = wgrad_many_bound();
   void *part = c.ws.raw(bound);
-  if (c.dry || c.wjobs.empty()) {
-    c.wjobs.clear();
-    return 0;
-  }
-  PGNN_REQUIRE(part != nullptr, PGNN_E_WORKSPACE, "trainer: workspace too small");
   int rc = 0;
-  const size_t bytes = pgnn_weight_grad_many_workspace_bytes(
-      c.wjobs.data(), (int32_t)c.wjobs.size());
-  if (bytes <= bound) {
-    rc = pgnn_weight_grad_many_f32(c.wjobs.data(), (int32_t)c.wjobs.size(), part,
-                                   bound, c.stream);
-  } else {  // (more jobs than the bound foresees: one by one)
-    for (const pgnn_wgrad_job &j : c.wjobs) {
-      rc = pgnn_weight_grad_f32(j.X, j.ld_x, j.k_in, j.dZ, j.ld_dz, j.n_out,
-                                j.n_rows, j.dW, j.db, j.accumulate, sv.scratch,
-                                sv.scratch_bytes, c.stream);
-      if (rc) break;
+  for (std::vector<pgnn_wgrad_job> *jobs : {&c.wjobs, &c.wjobs2}) {
+    if (!c.dry && !jobs->empty() && rc == 0) {
+      PGNN_REQUIRE(part != nullptr, PGNN_E_WORKSPACE,
+                   "trainer: workspace too small");
+      const size_t bytes =
+          pgnn_weight_grad_many_workspace_bytes(jobs->data(), (int32_t)jobs->size());
+      if (bytes <= bound) {
+        rc = pgnn_weight_grad_many_f32(jobs->data(), (int32_t)jobs->size(), part,
+                                       bound, c.stream);
+      } else {  // (more jobs than the bound foresees: one by one)
+        for (const pgnn_wgrad_job &j : *jobs) {
+          rc = pgnn_weight_grad_f32(j.X, j.ld_x, j.k_in, j.dZ, j.ld_dz, j.n_out,
+                                    j.n_rows, j.dW, j.db, j.accumulate, sv.scratch,
+                                    sv.scratch_bytes, c.stream);
+          if (rc) break;
+        }
+      }
     }
+    jobs->clear();
   }
-  c.wjobs.clear();
   return rc;
 }
 
@@ -648,13 +795,16 @@ int forward_impl(Ctx &c, Saved &sv) {
                                     c.stream);
           if (rc) return rc;
         }
-        x = p.agg;
-        ldx = wa;
-        for (size_t i = 0; i < s.b.size(); ++i) {
-          rc = fc_fwd(c, s.b[i], x, ldx, K, true, nullptr, 0, p.oact[i]);
+        {  // output MLP, every layer a ReLU layer: one launch
+          const FcDev *fs[PGNN_TRAIN_MAX_FC];
+          int rf[PGNN_TRAIN_MAX_FC];
+          for (size_t i = 0; i < s.b.size(); ++i) {
+            fs[i] = &s.b[i];
+            rf[i] = 0;
+          }
+          rc = fc_chain_fwd(c, fs, rf, (int)s.b.size(), p.agg, wa, K, nullptr, 0,
+                            p.oact);
           if (rc) return rc;
-          x = p.oact[i];
-          ldx = pad16(s.b[i].ref.n_out);
         }
       }
       h = p.oact[s.b.size() - 1];
@@ -688,20 +838,20 @@ int forward_impl(Ctx &c, Saved &sv) {
                      "trainer: update MLP must preserve the feature width");
         const float *delta = nullptr;
         int64_t ld_delta = 0;
-        const float *x = h;
-        int64_t ldx = ld_h;
-        for (size_t i = 0; i < s.c.size(); ++i) {
-          rc = fc_fwd(c, s.c[i], x, ldx, K, i + 1 < s.c.size(), nullptr, 0,
-                      g.off_act[i]);
-          if (rc) return rc;
-          x = g.off_act[i];
-          ldx = pad16(s.c[i].ref.n_out);
-        }
-        if (!s.c.empty()) {
+        if (!s.c.empty()) {  // offset MLP, last layer linear: one launch
           PGNN_REQUIRE(s.c.back().ref.n_out == 3, PGNN_E_INVALID,
                        "trainer: the offset MLP must end in 3 outputs");
-          delta = x;
-          ld_delta = ldx;
+          const FcDev *fs[PGNN_TRAIN_MAX_FC];
+          int rf[PGNN_TRAIN_MAX_FC];
+          for (size_t i = 0; i < s.c.size(); ++i) {
+            fs[i] = &s.c[i];
+            rf[i] = i + 1 < s.c.size() ? 0 : s.c[i].ref.n_out;
+          }
+          rc = fc_chain_fwd(c, fs, rf, (int)s.c.size(), h, ld_h, K, nullptr, 0,
+                            g.off_act);
+          if (rc) return rc;
+          delta = g.off_act[s.c.size() - 1];
+          ld_delta = pad16(s.c.back().ref.n_out);
         }
         if (K > 0) {
           const int ldhx = pad16(cc + 3);
@@ -724,8 +874,8 @@ int forward_impl(Ctx &c, Saved &sv) {
           L2.relu_from = 0;
           rc = pgnn_edge_mlp_scatter_max_rows_fwd(
               g.p, g.q, wq, s.a[1].ref.k_in, b.edges[lvl], E, (int32_t)K, &L2,
-              b.edges_sorted[lvl] ? 1 : 0, g.agg, wa, g.eact[1], wa, g.eact[0],
-              c.stream);
+              b.edges_sorted[lvl] ? 1 : 0, g.agg, wa, g.eact[1], wa,
+              g_train_h1 ? g.eact[0] : nullptr, c.stream);
           if (rc == 0) fused = true;
           else if (rc != PGNN_E_UNSUPPORTED) return rc;
         }
@@ -743,15 +893,16 @@ int forward_impl(Ctx &c, Saved &sv) {
                                     b.edges_sorted[lvl] ? 1 : 0, c.stream);
           if (rc) return rc;
         }
-        x = g.agg;
-        ldx = wa;
-        for (size_t i = 0; i < s.b.size(); ++i) {
-          const bool last = i + 1 == s.b.size();
-          rc = fc_fwd(c, s.b[i], x, ldx, K, !last, last ? h : nullptr,
-                      last ? ld_h : 0, g.uact[i]);
+        {  // update MLP, last layer linear, + h (gnn.py:372): one launch
+          const FcDev *fs[PGNN_TRAIN_MAX_FC];
+          int rf[PGNN_TRAIN_MAX_FC];
+          for (size_t i = 0; i < s.b.size(); ++i) {
+            fs[i] = &s.b[i];
+            rf[i] = i + 1 < s.b.size() ? 0 : s.b[i].ref.n_out;
+          }
+          rc = fc_chain_fwd(c, fs, rf, (int)s.b.size(), g.agg, wa, K, h, ld_h,
+                            g.uact);
           if (rc) return rc;
-          x = g.uact[i];
-          ldx = pad16(s.b[i].ref.n_out);
         }
       }
       h = g.uact[s.b.size() - 1];
@@ -782,14 +933,13 @@ int forward_impl(Ctx &c, Saved &sv) {
     if (!c.dry) {
       for (size_t gi = 0; gi < t.groups.size(); ++gi) {
         HeadGroup &g = t.groups[gi];
-        rc = fc_fwd(c, g.f[0], h, ld_h, K, true, nullptr, 0, hs.y1[gi]);
-        if (rc) return rc;
-        rc = fc_fwd_from(c, g.f[1], hs.y1[gi], pad16(g.f[0].ref.n_out), K, g.base,
-                         nullptr, 0, hs.y2[gi]);
-        if (rc) return rc;
-        rc = fc_fwd(c, g.f[2], hs.y2[gi], pad16(g.f[1].ref.n_out), K, false,
-                    nullptr, 0, hs.y3[gi]);
-        if (rc) return rc;
+        {  // the group's three layers (ReLU | ReLU from `base` | linear)
+          const FcDev *fs[3] = {&g.f[0], &g.f[1], &g.f[2]};
+          const int rf[3] = {0, g.base, g.f[2].ref.n_out};
+          float *outs[3] = {hs.y1[gi], hs.y2[gi], hs.y3[gi]};
+          rc = fc_chain_fwd(c, fs, rf, 3, h, ld_h, K, nullptr, 0, outs);
+          if (rc) return rc;
+        }
         if (K > 0) {
           const int ld3 = pad16(g.f[2].ref.n_out);
           bool run = true;  // lids of a group are consecutive
@@ -944,13 +1094,16 @@ int backward_impl(Ctx &c, Saved &sv, const float *dlogits, const float *dpred) {
                              dim3(blocks_for(K * (g.f[1].ref.n_out - g.base))),
                              dim3(256), 0, c.stream, dy2, sv.heads.y2[gi], K, ld2,
                              g.base, g.f[1].ref.n_out);
-        // (dy1 leaves masked by y1 > 0: the first layer's ReluGrad)
-        rc = fc_bwd(c, sv, g.f[1], sv.heads.y1[gi], ld1, nullptr, dy2, K, false,
-                    dy1, false, true, true);
-        if (rc) return rc;
-        rc = fc_bwd(c, sv, g.f[0], sv.h_final, hw, sv.heads.y1[gi], dy1, K, false,
-                    gi == 0 ? dh : dxh, false, true);
-        if (rc) return rc;
+        {  // layers 2 and 1 in one launch (dy1 leaves masked by y1 > 0: the
+           // first layer's ReluGrad)
+          const FcDev *fs[2] = {&g.f[0], &g.f[1]};
+          const float *xin[2] = {sv.h_final, sv.heads.y1[gi]};
+          const int64_t ldx[2] = {hw, ld1};
+          float *dxs[2] = {gi == 0 ? dh : dxh, dy1};
+          const bool gate[2] = {false, true};
+          rc = fc_chain_bwd(c, sv, fs, 2, xin, ldx, dy2, K, dxs, gate, false);
+          if (rc) return rc;
+        }
         if (gi > 0)
           hipLaunchKernelGGL(block_copy_kernel<true>, dim3(blocks_for(K * cw)),
                              dim3(256), 0, c.stream, dh, (int64_t)hw, 0, dxh,
@@ -1041,17 +1194,22 @@ int backward_impl(Ctx &c, Saved &sv, const float *dlogits, const float *dpred) {
         // (residual branch, gnn.py:372: dh_in = dh + what the edge input and
         // the offset MLP send back -- summed in one pass at the stage's end)
         // update MLP, last layer linear
-        float *d = dh;
-        for (int i = (int)s.b.size() - 1; i >= 0; --i) {
-          const float *xin = i == 0 ? g.agg : g.uact[i - 1];
-          const int64_t ldx = i == 0 ? wa : pad16(s.b[i - 1].ref.n_out);
-          // (the ReluGrad of layer i - 1 leaves with du[i]: gate = xin)
-          rc = fc_bwd(c, sv, s.b[i], xin, ldx, g.uact[i], d, Ks, false, du[i],
-                      true, true, i > 0);
+        // (one launch; the ReluGrad of layer i - 1 leaves with du[i])
+        {
+          const FcDev *fs[PGNN_TRAIN_MAX_FC];
+          const float *xin[PGNN_TRAIN_MAX_FC];
+          int64_t ldx[PGNN_TRAIN_MAX_FC];
+          bool gate[PGNN_TRAIN_MAX_FC];
+          for (size_t i = 0; i < s.b.size(); ++i) {
+            fs[i] = &s.b[i];
+            xin[i] = i == 0 ? g.agg : g.uact[i - 1];
+            ldx[i] = i == 0 ? wa : pad16(s.b[i - 1].ref.n_out);
+            gate[i] = i > 0;
+          }
+          rc = fc_chain_bwd(c, sv, fs, (int)s.b.size(), xin, ldx, dh, Ks, du, gate);
           if (rc) return rc;
-          d = du[i];
         }
-        const float *dagg = d;  // [Ks, pad(k_in of b[0])] = [Ks, wa]
+        const float *dagg = du[0];  // [Ks, pad(k_in of b[0])] = [Ks, wa]
         const int na = (int)s.a.size();
         float *gcur = nullptr;  // grad w.r.t. eact[i], ReLU-masked
         int from;
@@ -1061,7 +1219,8 @@ int backward_impl(Ctx &c, Saved &sv, const float *dlogits, const float *dpred) {
           // routing pass: dP / dQ directly, dH1 is never written
           rc = pgnn_edge_segmax_fc_bwd_f32(
               g.eact[1], wa, b.edges[lvl], g.dst, E, s.a[1].ref.n_out,
-              (int32_t)Ks, g.agg, wa, dagg, wa, g.eact[0], wq, g.p, g.q,
+              (int32_t)Ks, g.agg, wa, dagg, wa, g_train_h1 ? g.eact[0] : nullptr,
+              wq, g.p, g.q,
               s.a[1].ref.k_in, s.a[1].wt, pad16(s.a[1].ref.k_in), dp, dq, wq,
               s.a[1].gw, s.a[1].gb, sv.scratch, sv.scratch_bytes, c.stream);
           if (rc) return rc;
@@ -1102,32 +1261,42 @@ int backward_impl(Ctx &c, Saved &sv, const float *dlogits, const float *dpred) {
                     true, true);
         if (rc) return rc;
         // Q = x' Wx, Wx = rows cc..cc+2 of W1 (the minus sign is in dq)
-        // (not deferred: it adds into rows of the same dW as the deferred
-        // job of w1 above, and jobs of one batch must not share outputs)
-        rc = pgnn_weight_grad_f32(g.xo, 3, 3, dq, wq, w1.ref.n_out, Ks,
-                                  w1.gw + (int64_t)cc * w1.ref.n_out, nullptr, 1,
-                                  sv.scratch, sv.scratch_bytes, c.stream);
-        if (rc) return rc;
+        // (it adds into rows of the same dW as the deferred job of w1 above,
+        // and jobs of one batch must not share outputs: the second batch)
+        {
+          pgnn_wgrad_job j = {};
+          j.X = g.xo;
+          j.ld_x = 3;
+          j.dZ = dq;
+          j.ld_dz = wq;
+          j.n_rows = Ks;
+          j.dW = w1.gw + (int64_t)cc * w1.ref.n_out;
+          j.db = nullptr;
+          j.k_in = 3;
+          j.n_out = w1.ref.n_out;
+          j.accumulate = 1;
+          c.wjobs2.push_back(j);
+        }
         const float *d_off = nullptr;  // grad w.r.t. h through the offset MLP
         if (!s.c.empty()) {
-          pgnn_fc_layer Lx;  // dx' = dQ Wx^T
-          Lx.packed = s.wx_packed_t;
-          Lx.k_in = w1.ref.n_out;
-          Lx.n_out = 3;
-          Lx.relu_from = 3;
-          rc = pgnn_mlp_fwd(dq, wq, w1.ref.n_out, nullptr, 0, 0, Ks, &Lx, 1,
-                            nullptr, 0, dxo, 16, c.stream);
-          if (rc) return rc;
-          float *d = dxo;
-          for (int i = (int)s.c.size() - 1; i >= 0; --i) {
-            const float *xin = i == 0 ? g.h_in : g.off_act[i - 1];
-            const int64_t ldx = i == 0 ? ld_h : pad16(s.c[i - 1].ref.n_out);
-            rc = fc_bwd(c, sv, s.c[i], xin, ldx, g.off_act[i], d, Ks, false,
-                        doff[i], true, true, i > 0);
+          // dx' = dQ Wx^T, then the offset MLP's backward: one launch
+          const PreDx pre = {s.wx_packed_t, w1.ref.n_out, 3, dq, wq};
+          {
+            const FcDev *fs[PGNN_TRAIN_MAX_FC];
+            const float *xin[PGNN_TRAIN_MAX_FC];
+            int64_t ldx[PGNN_TRAIN_MAX_FC];
+            bool gate[PGNN_TRAIN_MAX_FC];
+            for (size_t i = 0; i < s.c.size(); ++i) {
+              fs[i] = &s.c[i];
+              xin[i] = i == 0 ? g.h_in : g.off_act[i - 1];
+              ldx[i] = i == 0 ? ld_h : pad16(s.c[i - 1].ref.n_out);
+              gate[i] = i > 0;
+            }
+            rc = fc_chain_bwd(c, sv, fs, (int)s.c.size(), xin, ldx, dxo, Ks, doff,
+                              gate, true, &pre);
             if (rc) return rc;
-            d = doff[i];
           }
-          d_off = d;
+          d_off = doff[0];
         }
         hipLaunchKernelGGL(stage_input_grad_kernel, dim3(blocks_for(Ks * ld_h)),
                            dim3(256), 0, c.stream, dh, ld_h, dhx, pad16(cc + 3),
@@ -1152,17 +1321,26 @@ int backward_impl(Ctx &c, Saved &sv, const float *dlogits, const float *dpred) {
         ties = c.ws.i32(Ks * wa > 0 ? Ks * wa : 1);
       }
       if (!c.dry && Ks > 0) {
-        float *d = dh;
-        for (int i = (int)s.b.size() - 1; i >= 0; --i) {
-          const float *xin = i == 0 ? p.agg : p.oact[i - 1];
-          const int64_t ldx = i == 0 ? wa : pad16(s.b[i - 1].ref.n_out);
-          // every layer is a ReLU layer: the last one's mask is applied to
-          // dh here, the others' leave with the dX of the layer above
-          rc = fc_bwd(c, sv, s.b[i], xin, ldx, p.oact[i], d, Ks,
-                      i + 1 == (int)s.b.size(), dob[i], true, true, i > 0);
+        // every layer is a ReLU layer: the last one's mask is applied to dh
+        // here, the others' leave with the dX of the layer above (one launch)
+        rc = pgnn_relu_mask_mul(dh, p.oact[s.b.size() - 1],
+                                Ks * pad16(s.b.back().ref.n_out), c.stream);
+        if (rc) return rc;
+        {
+          const FcDev *fs[PGNN_TRAIN_MAX_FC];
+          const float *xin[PGNN_TRAIN_MAX_FC];
+          int64_t ldx[PGNN_TRAIN_MAX_FC];
+          bool gate[PGNN_TRAIN_MAX_FC];
+          for (size_t i = 0; i < s.b.size(); ++i) {
+            fs[i] = &s.b[i];
+            xin[i] = i == 0 ? p.agg : p.oact[i - 1];
+            ldx[i] = i == 0 ? wa : pad16(s.b[i - 1].ref.n_out);
+            gate[i] = i > 0;
+          }
+          rc = fc_chain_bwd(c, sv, fs, (int)s.b.size(), xin, ldx, dh, Ks, dob, gate);
           if (rc) return rc;
-          d = dob[i];
         }
+        float *d = dob[0];
         const int na = (int)s.a.size();
         float *gcur;
         int from;
