@@ -211,9 +211,11 @@ int pgnn_cap_neighbors_fill(const int32_t *offsets, const int32_t *edges,
  * 'center' mode = multi_layer_downsampling_select (graph_gen.py:49-90) for ONE
  * pooling level per call (the reference loops over arbitrary `levels`; every
  * shipped config has one downsampling level followed by equal scales, which
- * graph_gen.py:76-81 turns into copies, and the Python mirror
- * pointgnn_amd.graph_gen raises NotImplementedError for more -- chain calls
- * of this entry to add levels): open3d-0.7 voxel centroids (origin = min_bound - voxel/2,
+ * graph_gen.py:76-81 turns into copies.  These entries serve the FIRST
+ * pooling level -- the search set is the voxelised cloud itself; the levels
+ * above it take pgnn_voxel_keypoints_*_from below, and the Python mirror
+ * pointgnn_amd.graph_gen loops over the levels like the reference):
+ * open3d-0.7 voxel centroids (origin = min_bound - voxel/2,
  * float64 means in point order) followed by an exact float64 1-NN back to a
  * real point; exact distance ties are broken like scikit-learn's kd-tree
  * query does (see pgnn_kdtree_replica).  Keypoints are emitted in ascending
@@ -282,6 +284,44 @@ int pgnn_voxel_keypoints_random_f64(const double *points, int64_t n_points,
                                     int32_t *keypoint_indices,
                                     double *keypoint_xyz,
                                     int32_t *num_keypoints, void *stream);
+
+/* The second and later POOLING levels of a frame (graph_gen.py:49-90 and
+ * :92-153 loop over arbitrary `levels`; every shipped config has one pooling
+ * level, which the entries above serve):
+ *   'center' (graph_gen.py:41-45, :78-88): the centroids are still those of
+ *     the ORIGINAL cloud's voxels (`points`, at this level's voxel size), but
+ *     the 1-NN search runs among `search_points` = the previous level's
+ *     keypoint coordinates, with scikit-learn's kd-tree order over THAT set
+ *     deciding exact ties.  keypoint_indices index search_points;
+ *     keypoint_xyz = search_points[keypoint_indices].  num_keypoints as above
+ *     ([1] = the tie-order status of the kd-tree replica of search_points).
+ *   'random' (graph_gen.py:108-110, :121-150): `points` = the previous level's
+ *     keypoints are voxelised on the grid anchored at the minimum of
+ *     `origin_points` = the ORIGINAL cloud (n_origin = 0: of `points`).
+ * Workspace: pgnn_keypoints_from_workspace_bytes(n_points, n_search) for
+ * 'center', pgnn_keypoints_workspace_bytes(n_points) for 'random'.            */
+size_t pgnn_keypoints_from_workspace_bytes(int64_t n_points, int64_t n_search);
+int pgnn_voxel_keypoints_center_from(const float *points, int64_t n_points,
+                                     const float *search_points,
+                                     int64_t n_search, double voxel_size,
+                                     void *workspace, size_t workspace_bytes,
+                                     int32_t *keypoint_indices,
+                                     float *keypoint_xyz,
+                                     int32_t *num_keypoints, void *stream);
+int pgnn_voxel_keypoints_random_from(const float *points, int64_t n_points,
+                                     const float *origin_points,
+                                     int64_t n_origin, double voxel_size,
+                                     const double *jitter3_host, uint64_t seed,
+                                     void *workspace, size_t workspace_bytes,
+                                     int32_t *keypoint_indices,
+                                     float *keypoint_xyz,
+                                     int32_t *num_keypoints, void *stream);
+int pgnn_voxel_keypoints_random_from_f64(
+    const double *points, int64_t n_points, const double *origin_points,
+    int64_t n_origin, double voxel_size, const double *jitter3_host,
+    uint64_t seed, void *workspace, size_t workspace_bytes,
+    int32_t *keypoint_indices, double *keypoint_xyz, int32_t *num_keypoints,
+    void *stream);
 
 /* ---- dense layers --------------------------------------------------------
  * A fully connected layer y = act(x @ W + b) (slim.fully_connected with
@@ -605,6 +645,18 @@ int pgnn_pool_features_fwd(const float *point_features, int32_t n_feat,
                            const int32_t *keypoint_indices,
                            const int32_t *edges, int64_t n_edges, float *F,
                            void *stream);
+/* The same rows for any feature width, [n_edges, ld_f >= n_feat + 3] with zero
+ * pad columns, from features with row stride ld_features: a PointSetPooling
+ * above the first pooling level gathers the previous level's (300-wide)
+ * vertex features, which the fused pooling kernel (n_feat <= 13) does not
+ * take -- pgnn_pool_features_wide_fwd + pgnn_mlp_fwd + pgnn_scatter_max_f32
+ * are the operator then (no shipped config).                                 */
+int pgnn_pool_features_wide_fwd(const float *point_features,
+                                int64_t ld_features, int32_t n_feat,
+                                const float *point_xyz,
+                                const int32_t *keypoint_indices,
+                                const int32_t *edges, int64_t n_edges, float *F,
+                                int64_t ld_f, void *stream);
 /* dY[i] = (Y[i] > 0) ? dY[i] : 0 in place (tf ReluGrad), over `count` floats. */
 int pgnn_relu_mask_mul(float *dY, const float *Y, int64_t count, void *stream);
 /* Gradient of tf.math.unsorted_segment_max (TF's

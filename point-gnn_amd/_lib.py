@@ -141,6 +141,17 @@ _SIGNATURES = {
     "pgnn_voxel_keypoints_random_f64": (c_i32, [c_vp, c_i64, c_f64, c_vp, c_u64,
                                                 c_vp, c_sz, c_vp, c_vp, c_vp,
                                                 c_vp]),
+    "pgnn_keypoints_from_workspace_bytes": (c_sz, [c_i64, c_i64]),
+    "pgnn_voxel_keypoints_center_from": (c_i32, [c_vp, c_i64, c_vp, c_i64,
+                                                 c_f64, c_vp, c_sz, c_vp, c_vp,
+                                                 c_vp, c_vp]),
+    "pgnn_voxel_keypoints_random_from": (c_i32, [c_vp, c_i64, c_vp, c_i64,
+                                                 c_f64, c_vp, c_u64, c_vp, c_sz,
+                                                 c_vp, c_vp, c_vp, c_vp]),
+    "pgnn_voxel_keypoints_random_from_f64": (c_i32, [c_vp, c_i64, c_vp, c_i64,
+                                                     c_f64, c_vp, c_u64, c_vp,
+                                                     c_sz, c_vp, c_vp, c_vp,
+                                                     c_vp]),
     "pgnn_kdtree_shape": (c_i32, [c_i64, c_vp, c_vp]),
     "pgnn_kdtree_workspace_bytes": (c_sz, [c_i64]),
     "pgnn_kdtree_replica": (c_i32, [c_vp, c_i64, c_vp, c_sz, c_vp, c_vp, c_vp,
@@ -257,6 +268,8 @@ _SIGNATURES = {
                                      c_vp]),
     "pgnn_edge_hidden_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_vp,
                                      c_vp, c_vp]),
+    "pgnn_pool_features_wide_fwd": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp,
+                                            c_i64, c_vp, c_i64, c_vp]),
     "pgnn_pool_features_fwd": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i64,
                                        c_vp, c_vp]),
     "pgnn_relu_mask_mul": (c_i32, [c_vp, c_vp, c_i64, c_vp]),

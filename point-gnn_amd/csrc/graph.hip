@@ -660,6 +660,148 @@ __global__ __launch_bounds__(1024) void voxel_nn_kernel(
   }
 }
 
+// voxel_nn_kernel for the SECOND and later pooling levels (graph_gen.py:78-88
+// with i > 1): the centroids are still those of the ORIGINAL cloud's voxels,
+// but the candidates are the points of another set -- `base`, the previous
+// level's keypoints -- so the nearest one need not lie in the 27 surrounding
+// voxels.  A wave searches the (2r+1)^3 voxels round the centroid's for r = 1,
+// 2, 3 (cell grid built over `base` with the same origin and edge) and stops
+// as soon as the best distance is below the distance to the cube's nearest
+// face; a centroid still undecided then (a base set far away) is compared with
+// every base point.  Ties go to the point scikit-learn's query on the kd-tree
+// of `base` meets first (kd); the (distance, kd order) relation is a strict
+// total order, so meeting a candidate twice (the cubes are nested, buckets may
+// be shared) changes nothing.
+__global__ __launch_bounds__(256) void voxel_nn_from_kernel(
+    const SortedPoint *__restrict__ sorted_b, int64_t nb,
+    const double *__restrict__ origin, double voxel, uint32_t mask_b,
+    const int32_t *__restrict__ cell_start_b,
+    const int32_t *__restrict__ cell_end_b, int64_t n,
+    const int32_t *__restrict__ is_leader, const int32_t *__restrict__ slot,
+    const double *__restrict__ centroid, const float *__restrict__ base,
+    KdView kd, int32_t *__restrict__ kp_idx, float *__restrict__ kp_xyz) {
+  graph_prio();
+  constexpr int spw = 4;
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  const int64_t n_waves = (int64_t)gridDim.x * wpb;
+  const double ox = origin[0], oy = origin[1], oz = origin[2];
+  for (int64_t first = ((int64_t)blockIdx.x * wpb + (threadIdx.x >> 6)) * spw;
+       first < n; first += n_waves * spw) {
+    unsigned long long leaders = __ballot(
+        lane < spw && first + lane < n && is_leader[first + lane] != 0);
+    while (leaders) {
+      const int64_t i = first + __builtin_ctzll(leaders);
+      leaders &= leaders - 1;
+      const double cx = centroid[3 * i], cy = centroid[3 * i + 1],
+                   cz = centroid[3 * i + 2];
+      const int vx = cell_of(cx, ox, voxel), vy = cell_of(cy, oy, voxel),
+                vz = cell_of(cz, oz, voxel);
+      double best = 1.0e300;
+      int best_idx = 0x7fffffff;
+      // candidate (x, y, z, idx): keep it if nearer, or as near and met first
+      auto consider = [&](double px, double py, double pz, int idx) {
+        const double ex = px - cx, ey = py - cy, ez = pz - cz;
+        const double d2 = (ex * ex + ey * ey) + ez * ez;
+        if (d2 < best ||
+            (d2 == best && idx != best_idx &&
+             kd_met_before(kd, kd.pos[idx], kd.pos[best_idx], cx, cy, cz))) {
+          best = d2;
+          best_idx = idx;
+        }
+      };
+      // every lane ends up with the wave's best
+      auto reduce = [&]() {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+          const double ob = __shfl_xor(best, d);
+          const int oi = __shfl_xor(best_idx, d);
+          if (ob < best ||
+              (ob == best && oi != best_idx && oi != 0x7fffffff &&
+               (best_idx == 0x7fffffff ||
+                kd_met_before(kd, kd.pos[oi], kd.pos[best_idx], cx, cy, cz)))) {
+            best = ob;
+            best_idx = oi;
+          }
+        }
+      };
+      bool done = false;
+      for (int r = 1; r <= 3 && !done; ++r) {
+        const int side = 2 * r + 1, count = side * side * side;
+        for (int c0 = 0; c0 < count; c0 += 64) {
+          const int ci = c0 + lane;
+          int my_s = 0, my_cnt = 0, my_ix = 0, my_iy = 0, my_iz = 0;
+          if (ci < count) {  // (dz, dy, dx) order
+            my_ix = vx - r + ci % side;
+            my_iy = vy - r + (ci / side) % side;
+            my_iz = vz - r + ci / (side * side);
+            const uint32_t b = cell_hash(my_ix, my_iy, my_iz, mask_b);
+            my_s = cell_start_b[b];
+            my_cnt = cell_end_b[b] - my_s;
+          }
+          int incl = my_cnt;
+#pragma unroll
+          for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(incl, d);
+            if (lane >= d) incl += t;
+          }
+          const int total_cand = __shfl(incl, 63);
+          for (int j0 = 0; j0 < total_cand; j0 += 64) {
+            const bool valid = j0 + lane < total_cand;
+            const int j = valid ? j0 + lane : total_cand - 1;
+            int lo = 0, hi = 63;  // first lane whose inclusive count exceeds j
+#pragma unroll
+            for (int step = 0; step < 6; ++step) {
+              const int mid = (lo + hi) >> 1;
+              const int v = __shfl(incl, mid);
+              if (v > j) hi = mid; else lo = mid + 1;
+            }
+            const int c = lo < 64 ? lo : 63;
+            const int c_incl = __shfl(incl, c), c_cnt = __shfl(my_cnt, c);
+            const int c_s = __shfl(my_s, c);
+            const int ix = __shfl(my_ix, c), iy = __shfl(my_iy, c),
+                      iz = __shfl(my_iz, c);
+            if (valid) {
+              const SortedPoint o = sorted_b[c_s + (j - (c_incl - c_cnt))];
+              if (cell_of(o.x, ox, voxel) == ix && cell_of(o.y, oy, voxel) == iy &&
+                  cell_of(o.z, oz, voxel) == iz)
+                consider(o.x, o.y, o.z, o.idx);
+            }
+          }
+        }
+        reduce();
+        // every point outside the cube is at least `face` away
+        const double fx0 = cx - (ox + (double)(vx - r) * voxel),
+                     fx1 = (ox + (double)(vx + r + 1) * voxel) - cx,
+                     fy0 = cy - (oy + (double)(vy - r) * voxel),
+                     fy1 = (oy + (double)(vy + r + 1) * voxel) - cy,
+                     fz0 = cz - (oz + (double)(vz - r) * voxel),
+                     fz1 = (oz + (double)(vz + r + 1) * voxel) - cz;
+        double face = fx0 < fx1 ? fx0 : fx1;
+        face = fy0 < face ? fy0 : face;
+        face = fy1 < face ? fy1 : face;
+        face = fz0 < face ? fz0 : face;
+        face = fz1 < face ? fz1 : face;
+        face -= 1.0e-9 * voxel;  // (which cell a point on a face lands in)
+        done = best_idx != 0x7fffffff && face > 0.0 && best < face * face;
+      }
+      if (!done) {  // undecided: every base point
+        for (int64_t j = lane; j < nb; j += 64)
+          consider((double)base[3 * j], (double)base[3 * j + 1],
+                   (double)base[3 * j + 2], (int)j);
+        reduce();
+      }
+      if (lane == 0) {
+        const int k = slot[i];
+        kp_idx[k] = best_idx;
+        kp_xyz[3 * k] = base[3 * (int64_t)best_idx];
+        kp_xyz[3 * k + 1] = base[3 * (int64_t)best_idx + 1];
+        kp_xyz[3 * k + 2] = base[3 * (int64_t)best_idx + 2];
+      }
+    }
+  }
+}
+
 // random mode: the leader picks member floor(u * count) of its voxel
 template <typename T>
 __global__ void voxel_random_pick_kernel(
@@ -1313,7 +1455,12 @@ int keypoints_impl(const T *points, int64_t n, double voxel, bool center,
                    const double *jitter3, uint64_t seed, void *workspace,
                    size_t workspace_bytes, int32_t *kp_idx, T *kp_xyz,
                    int32_t *num_kp, hipStream_t stream,
-                   hipStream_t aux = nullptr) {
+                   hipStream_t aux = nullptr,
+                   const T *origin_pts = nullptr /* the cloud whose minimum
+                       anchors the voxel grid (graph_gen.py:108-110: the
+                       ORIGINAL cloud's, also for the second and later pooling
+                       levels); null: `points` */,
+                   int64_t n_origin = 0) {
   constexpr bool kF64 = sizeof(T) == 8;
   PGNN_REQUIRE(n >= 0 && voxel > 0.0 && kp_idx && kp_xyz && num_kp,
                PGNN_E_INVALID, "keypoints: bad argument");
@@ -1394,10 +1541,12 @@ int keypoints_impl(const T *points, int64_t n, double voxel, bool center,
     if (rc) return rc;
   }
   PGNN_HIP((hipError_t)graph_fill32(omin, 0xffffffffu, 8, stream));
-  int mb = (int)((n + 255) / 256);
+  const T *min_pts = origin_pts && n_origin > 0 ? origin_pts : points;
+  const int64_t n_min = origin_pts && n_origin > 0 ? n_origin : n;
+  int mb = (int)((n_min + 255) / 256);
   if (mb > 1024) mb = 1024;
-  hipLaunchKernelGGL(min_bound_kernel<T>, dim3(graph_grid(mb)), dim3(256), graph_lds_pad(), stream, points,
-                     n, omin);
+  hipLaunchKernelGGL(min_bound_kernel<T>, dim3(graph_grid(mb)), dim3(256), graph_lds_pad(), stream, min_pts,
+                     n_min, omin);
   double sx, sy, sz;
   if (center) {
     sx = sy = sz = voxel * 0.5;  // open3d 0.7: origin = min_bound - voxel/2
@@ -1455,6 +1604,147 @@ inline void launch_voxel_nn(const Grid &g, int64_t n, const double *origin,
                      kd, kp_idx, kp_xyz, spw);
 }
 }  // namespace
+
+// workspace layout (keypoints, second and later pooling levels, 'center'):
+//   [Grid(points) | ordered_min | voxel rule | is_leader | slot | members |
+//    centroid | vcell x2 | scan scratch | Grid(base) | vcell(base) x2 | kd(base)]
+extern "C" size_t pgnn_keypoints_from_workspace_bytes(int64_t n_points,
+                                                      int64_t n_base) {
+  if (n_points < 0 || n_base < 0) return 0;
+  const size_t nb = (size_t)(n_base > 0 ? n_base : 1);
+  return pgnn_keypoints_workspace_bytes(n_points) + grid_bytes(n_base) +
+         2 * align_up(3 * nb * 4, 256) + kd_workspace_bytes(n_base) + 2048;
+}
+
+namespace {
+// graph_gen.py:41-45 + :78-88 for a pooling level whose search set is not the
+// voxelised cloud: centroids of `points`' voxels, 1-NN among `base`.
+int keypoints_center_from_impl(const float *points, int64_t n, const float *base,
+                               int64_t nb, double voxel, void *workspace,
+                               size_t workspace_bytes, int32_t *kp_idx,
+                               float *kp_xyz, int32_t *num_kp,
+                               hipStream_t stream) {
+  PGNN_REQUIRE(n >= 0 && nb >= 0 && voxel > 0.0 && kp_idx && kp_xyz && num_kp,
+               PGNN_E_INVALID, "keypoints_from: bad argument");
+  if (n == 0) {
+    PGNN_HIP(hipMemsetAsync(num_kp, 0, 8, stream));
+    return 0;
+  }
+  PGNN_REQUIRE(points && base && nb > 0, PGNN_E_INVALID,
+               "keypoints_from: null points / empty search set");
+  PGNN_REQUIRE(workspace &&
+                   workspace_bytes >= pgnn_keypoints_from_workspace_bytes(n, nb),
+               PGNN_E_WORKSPACE, "keypoints_from: workspace too small");
+  Arena a(workspace, workspace_bytes);
+  Grid g, gb;
+  int rc = grid_carve(a, n, g);
+  if (rc) return rc;
+  unsigned long long *omin = a.take<unsigned long long>(4);
+  double *origin = a.take<double>(kVoxRuleDoubles);
+  int32_t *is_leader = a.take<int32_t>((size_t)n + 1);
+  int32_t *slot = a.take<int32_t>((size_t)n + 1);
+  int32_t *members = a.take<int32_t>((size_t)n + 1);
+  double *centroid = a.take<double>(3 * (size_t)n);
+  int32_t *vcell = a.take<int32_t>(3 * (size_t)n);
+  int32_t *vcell_sorted = a.take<int32_t>(3 * (size_t)n);
+  const size_t scan_bytes = scan_scratch_bytes(n);
+  void *scan_scratch = a.take<char>(scan_bytes);
+  rc = grid_carve(a, nb, gb);
+  if (rc) return rc;
+  int32_t *vcell_b = a.take<int32_t>(3 * (size_t)nb);
+  int32_t *vcell_b_sorted = a.take<int32_t>(3 * (size_t)nb);
+  PGNN_REQUIRE(omin && origin && is_leader && slot && members && centroid &&
+                   vcell && vcell_sorted && scan_scratch && vcell_b &&
+                   vcell_b_sorted,
+               PGNN_E_WORKSPACE, "keypoints_from: workspace too small");
+  // scikit-learn's kd-tree over the SEARCH set decides exact ties
+  KdBuild kb;
+  rc = kd_build(base, nb, a, kb, stream);
+  if (rc) return rc;
+  PGNN_HIP((hipError_t)graph_fill32(omin, 0xffffffffu, 8, stream));
+  int mb = (int)((n + 255) / 256);
+  if (mb > 1024) mb = 1024;
+  hipLaunchKernelGGL(min_bound_kernel<float>, dim3(graph_grid(mb)), dim3(256),
+                     graph_lds_pad(), stream, points, n, omin);
+  // open3d 0.7: origin = min_bound(points) - voxel / 2
+  hipLaunchKernelGGL(grid_origin_kernel, dim3(1), dim3(64), graph_lds_pad(), stream,
+                     omin, voxel * 0.5, voxel * 0.5, voxel * 0.5, 0, origin);
+  Scale3 sc = make_scale(nullptr);
+  rc = grid_build(points, n, sc, 0.0, 0.0, 0.0, origin, voxel, g, stream, vcell,
+                  vcell_sorted);
+  if (rc) return rc;
+  rc = grid_build(base, nb, sc, 0.0, 0.0, 0.0, origin, voxel, gb, stream, vcell_b,
+                  vcell_b_sorted);
+  if (rc) return rc;
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(voxel_leader_kernel, dim3(graph_grid(blocks)), dim3(256),
+                     graph_lds_pad(), stream, g.sorted, g.keys, n,
+                     (const int32_t *)vcell_sorted, g.cell_start, g.cell_end,
+                     is_leader, centroid, members);
+  rc = exclusive_scan_i32(is_leader, slot, n, scan_scratch, scan_bytes, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(copy_total_kernel, dim3(1), dim3(64), graph_lds_pad(), stream,
+                     slot + n, (const int32_t *)kb.status, num_kp);
+  KdView kd;
+  kd.pos = kb.pos;
+  kd.bounds = kb.bounds;
+  kd.n = (int32_t)nb;
+  kd.n_nodes = kb.n_nodes;
+  const int64_t per_wg = 4 * 4;  // 4 waves x 4 sorted slots
+  hipLaunchKernelGGL(voxel_nn_from_kernel,
+                     dim3(graph_grid((n + per_wg - 1) / per_wg)), dim3(256),
+                     graph_lds_pad(), stream, gb.sorted, nb, origin, voxel, gb.mask,
+                     gb.cell_start, gb.cell_end, n, is_leader, slot, centroid, base,
+                     kd, kp_idx, kp_xyz);
+  PGNN_HIP(hipGetLastError());
+  return 0;
+}
+}  // namespace
+
+extern "C" int pgnn_voxel_keypoints_center_from(
+    const float *points, int64_t n_points, const float *search_points,
+    int64_t n_search, double voxel_size, void *workspace, size_t workspace_bytes,
+    int32_t *keypoint_indices, float *keypoint_xyz, int32_t *num_keypoints,
+    void *stream) {
+  PGNN_GUARD_BEGIN
+  return keypoints_center_from_impl(points, n_points, search_points, n_search,
+                                    voxel_size, workspace, workspace_bytes,
+                                    keypoint_indices, keypoint_xyz, num_keypoints,
+                                    (hipStream_t)stream);
+  PGNN_GUARD_END
+}
+
+extern "C" int pgnn_voxel_keypoints_random_from(
+    const float *points, int64_t n_points, const float *origin_points,
+    int64_t n_origin, double voxel_size, const double *jitter3_host,
+    uint64_t seed, void *workspace, size_t workspace_bytes,
+    int32_t *keypoint_indices, float *keypoint_xyz, int32_t *num_keypoints,
+    void *stream) {
+  PGNN_GUARD_BEGIN
+  PGNN_REQUIRE(n_origin >= 0 && (n_origin == 0 || origin_points), PGNN_E_INVALID,
+               "keypoints_random_from: bad origin set");
+  return keypoints_impl(points, n_points, voxel_size, false, jitter3_host, seed,
+                        workspace, workspace_bytes, keypoint_indices,
+                        keypoint_xyz, num_keypoints, (hipStream_t)stream, nullptr,
+                        origin_points, n_origin);
+  PGNN_GUARD_END
+}
+
+extern "C" int pgnn_voxel_keypoints_random_from_f64(
+    const double *points, int64_t n_points, const double *origin_points,
+    int64_t n_origin, double voxel_size, const double *jitter3_host,
+    uint64_t seed, void *workspace, size_t workspace_bytes,
+    int32_t *keypoint_indices, double *keypoint_xyz, int32_t *num_keypoints,
+    void *stream) {
+  PGNN_GUARD_BEGIN
+  PGNN_REQUIRE(n_origin >= 0 && (n_origin == 0 || origin_points), PGNN_E_INVALID,
+               "keypoints_random_from: bad origin set");
+  return keypoints_impl(points, n_points, voxel_size, false, jitter3_host, seed,
+                        workspace, workspace_bytes, keypoint_indices,
+                        keypoint_xyz, num_keypoints, (hipStream_t)stream, nullptr,
+                        origin_points, n_origin);
+  PGNN_GUARD_END
+}
 
 extern "C" int pgnn_voxel_keypoints_center(const float *points, int64_t n_points,
                                            double voxel_size, void *workspace,

@@ -108,6 +108,31 @@ __global__ void pool_features_kernel(const float *__restrict__ feat, int nfeat,
   }
 }
 
+// the same rows for ANY feature width (a pooling level above the first pools
+// the previous level's 300-wide features): F[e] = [f(src)[:nfeat] | xyz(src) -
+// xyz(kp(dst)) | 0 ...], ld_f columns; thread per (edge, column)
+__global__ void pool_features_wide_kernel(
+    const float *__restrict__ feat, int64_t ld_feat, int nfeat,
+    const float *__restrict__ xyz, const int32_t *__restrict__ kp,
+    const int32_t *__restrict__ edges, int64_t n_edges, float *__restrict__ F,
+    int ld_f) {
+  const int64_t total = n_edges * ld_f;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = idx / ld_f;
+    const int i = (int)(idx - e * ld_f);
+    const int s = edges[2 * e];
+    float v = 0.0f;
+    if (i < nfeat) {
+      v = feat[(int64_t)s * ld_feat + i];
+    } else if (i < nfeat + 3) {
+      const int k = kp[edges[2 * e + 1]];
+      v = xyz[3 * (int64_t)s + (i - nfeat)] - xyz[3 * (int64_t)k + (i - nfeat)];
+    }
+    F[idx] = v;
+  }
+}
+
 __global__ void relu_mask_mul_kernel(float *__restrict__ dY,
                                      const float *__restrict__ Y, int64_t total) {
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -1405,6 +1430,28 @@ extern "C" int pgnn_pool_features_fwd(const float *point_features,
   hipLaunchKernelGGL(pool_features_kernel, dim3(grid_for(n_edges)), dim3(256), 0,
                      (hipStream_t)stream_, point_features, n_feat, point_xyz,
                      keypoint_indices, edges, n_edges, F);
+  PGNN_HIP(hipGetLastError());
+  return 0;
+  PGNN_GUARD_END
+}
+
+extern "C" int pgnn_pool_features_wide_fwd(
+    const float *point_features, int64_t ld_features, int32_t n_feat,
+    const float *point_xyz, const int32_t *keypoint_indices,
+    const int32_t *edges, int64_t n_edges, float *F, int64_t ld_f,
+    void *stream_) {
+  PGNN_GUARD_BEGIN
+  PGNN_REQUIRE(n_feat >= 0 && n_feat <= 4093 && ld_features >= n_feat &&
+                   ld_f >= n_feat + 3 && ld_f <= 4096 && n_edges >= 0,
+               PGNN_E_INVALID, "pool_features_wide: bad sizes");
+  if (n_edges == 0) return 0;
+  PGNN_REQUIRE((point_features || n_feat == 0) && point_xyz &&
+                   keypoint_indices && edges && F,
+               PGNN_E_INVALID, "pool_features_wide: null pointer");
+  hipLaunchKernelGGL(pool_features_wide_kernel,
+                     dim3(grid_for(n_edges * ld_f, 8192)), dim3(256), 0,
+                     (hipStream_t)stream_, point_features, ld_features, n_feat,
+                     point_xyz, keypoint_indices, edges, n_edges, F, (int)ld_f);
   PGNN_HIP(hipGetLastError());
   return 0;
   PGNN_GUARD_END

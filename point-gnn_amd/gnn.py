@@ -453,9 +453,36 @@ class PointSetPooling(object):
         kp = _as_i32(keypoint_indices.reshape(-1))
         edges = _as_i32(set_indices)
         n_feat = int(feats.shape[1])
+        if n_feat != point_chain.k_in - 3 and \
+                n_feat == padded_width(point_chain.k_in - 3):
+            # (the zero-padded rows of a previous operator: a pooling level
+            # above the first)
+            n_feat = point_chain.k_in - 3
         assert point_chain.k_in == n_feat + 3, \
             "point MLP expects %d inputs" % point_chain.k_in
         k = int(kp.shape[0])
+        if n_feat > 13:
+            # wider than the fused kernel's gather (the previous level's
+            # features; no shipped config): edge rows, row MLP, scatter-max
+            if cnt_k is not None or cnt_e is not None:
+                raise NotImplementedError(
+                    "PointSetPooling of wide features in capacity form")
+            n_e = int(edges.shape[0])
+            rows_in = torch.empty((n_e, padded_width(n_feat + 3)),
+                                  dtype=torch.float32, device=xyz.device)
+            _lib.check(lib.pgnn_pool_features_wide_fwd(
+                _lib.ptr(feats), feats.stride(0), n_feat, _lib.ptr(xyz),
+                _lib.ptr(kp), _lib.ptr(edges), n_e, _lib.ptr(rows_in),
+                rows_in.stride(0), _lib.stream_ptr()),
+                "pgnn_pool_features_wide_fwd")
+            rows = mlp_forward(point_chain, rows_in, point_chain.k_in)
+            agg = graph_scatter_max_fn(
+                rows, edges[:, 1], k,
+                ids_sorted=_edges_sorted_flag(set_indices) == 1)
+            with variable_scope('combined_features'):
+                out_chain = _relu_chain(store, _scope(),
+                                        list(output_MLP_depth_list), False)
+            return _finish_rows(out_chain, agg, point_chain.n_out)
         agg = torch.empty((k, padded_width(point_chain.n_out)),
                           dtype=torch.float32, device=xyz.device)
         args = (_lib.ptr(feats), n_feat, _lib.ptr(xyz), _lib.ptr(kp),

@@ -391,13 +391,21 @@ def _aux_stream(dev):
 
 
 def keypoints_device(points, voxel_size, method='center', jitter=None, seed=0,
-                     fork_kdtree=False, num_out=None, k_hint=0):
+                     fork_kdtree=False, num_out=None, k_hint=0, base=None):
     """One pooling level.  Returns (coords [K,3] in the dtype of `points`,
     indices int32 [K,1]) as device tensors.  One host sync (reading K and the
     tie-order status together) -- unless `num_out` (an int32 [2] device
     tensor) is given: then K and the status stay there, nothing is read, and
     the two arrays come back in capacity form ([n,3] / [n,1], tagged with the
-    DeviceCount of K)."""
+    DeviceCount of K).
+
+    `base` (the second and later pooling levels, graph_gen.py:49-90, :92-153):
+    the previous level's vertex coordinates, `points` then being the ORIGINAL
+    cloud -- 'center': centroids of the cloud's voxels, nearest neighbour among
+    `base`; 'random': `base` is voxelised on the grid anchored at the cloud's
+    minimum.  The indices refer to `base`."""
+    if base is not None:
+        return _keypoints_from(points, base, voxel_size, method, jitter, seed)
     lib = _lib.load()
     dev = points.device
     n = int(points.shape[0])
@@ -467,6 +475,58 @@ def keypoints_device(points, voxel_size, method='center', jitter=None, seed=0,
     return kp_xyz[:k], kp_idx[:k].reshape(k, 1)
 
 
+def _keypoints_from(cloud, base, voxel_size, method, jitter, seed):
+    """keypoints_device for a pooling level above the first (host-sized form
+    only: the previous level's size is an argument of the call)."""
+    lib = _lib.load()
+    if _lib.count_of(base) is not None or _lib.count_of(cloud) is not None:
+        raise NotImplementedError(
+            "more than one pooling level in capacity form (deferred_counts)")
+    n, nb = int(cloud.shape[0]), int(base.shape[0])
+    dev = cloud.device
+    st = _lib.stream_ptr()
+    num = torch.empty(2, dtype=torch.int32, device=dev)
+    if method == 'center':
+        if cloud.dtype != torch.float32 or base.dtype != torch.float32:
+            raise NotImplementedError(
+                "downsample_method='center' above the first pooling level "
+                "takes float32 coordinates")
+        cloud, base = cloud.contiguous(), base.contiguous()
+        ws_bytes = lib.pgnn_keypoints_from_workspace_bytes(n, nb)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        kp_idx = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        kp_xyz = torch.empty((max(n, 1), 3), dtype=torch.float32, device=dev)
+        _lib.check(lib.pgnn_voxel_keypoints_center_from(
+            _lib.ptr(cloud), n, _lib.ptr(base), nb, float(voxel_size),
+            _lib.ptr(ws), ws_bytes, _lib.ptr(kp_idx), _lib.ptr(kp_xyz),
+            _lib.ptr(num), st), "pgnn_voxel_keypoints_center_from")
+    elif method == 'random':
+        if cloud.dtype != base.dtype:
+            raise ValueError("keypoints: cloud and base differ in dtype")
+        wide = base.dtype == torch.float64
+        cloud, base = cloud.contiguous(), base.contiguous()
+        ws_bytes = lib.pgnn_keypoints_workspace_bytes(nb)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        kp_idx = torch.empty(max(nb, 1), dtype=torch.int32, device=dev)
+        kp_xyz = torch.empty((max(nb, 1), 3), dtype=base.dtype, device=dev)
+        jit = None
+        jp = ctypes.c_void_p(0)
+        if jitter is not None:
+            jit = np.ascontiguousarray(np.asarray(jitter, np.float64).reshape(3))
+            jp = ctypes.c_void_p(jit.ctypes.data)
+        _lib.check((lib.pgnn_voxel_keypoints_random_from_f64 if wide else
+                    lib.pgnn_voxel_keypoints_random_from)(
+            _lib.ptr(base), nb, _lib.ptr(cloud), n, float(voxel_size), jp,
+            int(seed) & 0xFFFFFFFFFFFFFFFF, _lib.ptr(ws), ws_bytes,
+            _lib.ptr(kp_idx), _lib.ptr(kp_xyz), _lib.ptr(num), st),
+            "pgnn_voxel_keypoints_random_from")
+    else:
+        raise ValueError("unknown downsample method %r" % (method,))
+    k, status = num.tolist()   # the one host read
+    check_kd_status(status)
+    return kp_xyz[:k], kp_idx[:k].reshape(k, 1)
+
+
 def check_kd_status(status):
     """The tie-order status of the 'center' keypoints' kd-tree replica
     (num_keypoints[1] of pgnn_voxel_keypoints_center): non-zero means the
@@ -518,8 +578,26 @@ def _multi_layer_downsampling(points_xyz, base_voxel_size, levels, add_rnd3d,
     p, was_np = _to_dev(points_xyz)
     coords = [p]
     kp_list = []
+    # 'random': the origin jitters of the pooling levels are drawn from NumPy's
+    # global RNG in level order, like the reference's (graph_gen.py:126-128 --
+    # its member choice consumes Python's `random`, not NumPy's); the seeds of
+    # the device's member choice are drawn behind them.  (One pooling level:
+    # jitter, then seed.)
+    jitters, seeds = {}, {}
+    if method == 'random':
+        last_level = 0
+        pooling = []
+        for li, level in enumerate(levels):
+            if not np.isclose(last_level, level):
+                pooling.append((li, level))
+            last_level = level
+        if add_rnd3d:
+            for li, level in pooling:
+                jitters[li] = base_voxel_size * level * np.random.random(3)
+        for li, level in pooling:
+            seeds[li] = int(np.random.randint(0, 2 ** 31 - 1))
     last_level = 0
-    for level in levels:
+    for li, level in enumerate(levels):
         base = coords[-1]
         if np.isclose(last_level, level):
             # same scale (a GNN level): same vertices, identity keypoints
@@ -528,10 +606,10 @@ def _multi_layer_downsampling(points_xyz, base_voxel_size, levels, add_rnd3d,
                 _identity_indices(int(base.shape[0]), base.device),
                 _lib.count_of(base)))
         else:
-            if len(coords) != 1:
-                raise NotImplementedError(
-                    "only one pooling level is supported (every shipped "
-                    "config has exactly one)")
+            # (a pooling level above the first: the cloud still anchors the
+            # voxel grid, graph_gen.py:41-45 / :108-110; the previous level's
+            # vertices are searched / voxelised)
+            upper = len(coords) != 1
             voxel = base_voxel_size * level
             if np.ndim(voxel) != 0:
                 raise NotImplementedError("per-axis voxel sizes")
@@ -539,16 +617,21 @@ def _multi_layer_downsampling(points_xyz, base_voxel_size, levels, add_rnd3d,
                 if add_rnd3d:
                     raise NotImplementedError(
                         "add_rnd3d with downsample_method='center'")
-                c, i = keypoints_device(base, voxel, 'center',
-                                        fork_kdtree=fork_kdtree,
-                                        num_out=num_out, k_hint=k_hint)
+                if upper:
+                    c, i = keypoints_device(p, voxel, 'center', base=base)
+                else:
+                    c, i = keypoints_device(base, voxel, 'center',
+                                            fork_kdtree=fork_kdtree,
+                                            num_out=num_out, k_hint=k_hint)
             else:
-                jitter = None
-                if add_rnd3d:  # graph_gen.py:126-128
-                    jitter = voxel * np.random.random(3)
-                seed = int(np.random.randint(0, 2 ** 31 - 1))
-                c, i = keypoints_device(base, voxel, 'random', jitter, seed,
-                                        num_out=num_out, k_hint=k_hint)
+                jitter = jitters.get(li)  # graph_gen.py:126-128
+                seed = seeds[li]
+                if upper:
+                    c, i = keypoints_device(p, voxel, 'random', jitter, seed,
+                                            base=base)
+                else:
+                    c, i = keypoints_device(base, voxel, 'random', jitter, seed,
+                                            num_out=num_out, k_hint=k_hint)
             coords.append(c)
             kp_list.append(i)
         last_level = level

@@ -365,3 +365,69 @@ def test_gnn_oracle_equals_reference_tf_graph_full_size():
         np.abs(bx - g["T1_box_encodings"]).max()))
     np.testing.assert_allclose(lg, g["T1_logits"], atol=1e-4, rtol=0)
     np.testing.assert_allclose(bx, g["T1_box_encodings"], atol=1e-4, rtol=0)
+
+
+# ---- more than one pooling level (graph_gen.py:49-90, :92-153) ---------------
+@pytest.mark.parametrize("preset", ["tiny", "small"])
+def test_multi_level_pooling_center_golden(preset):
+    """Two pooling levels + a same-scale level, 'center': the oracle against
+    what the reference's real gen_multi_level_local_graph_v3 returned
+    (tests/golden/make_golden_multilevel.py; only open3d's voxel means are a
+    restatement): vertex coordinates, keypoint indices -- the second level's
+    index the FIRST level's vertices -- and the edge lists, row for row."""
+    from _multilevel import BASE_VOXEL, LEVEL_CONFIGS
+    g = gold("graph_multilevel.npz")
+    xyz = g["%s_xyz" % preset]
+    coords, kps, edges = go.multi_level_graph(
+        xyz, BASE_VOXEL, LEVEL_CONFIGS, downsample_method='center')
+    assert len(coords) == 4
+    for l in range(3):
+        assert np.array_equal(kps[l], g["%s_center_kp%d" % (preset, l)])
+        assert np.array_equal(coords[l + 1],
+                              g["%s_center_coords%d" % (preset, l + 1)])
+        assert np.array_equal(edges[l], g["%s_center_edges%d" % (preset, l)])
+    # the case is only worth something if the second level really pools
+    assert len(coords[2]) < len(coords[1]) < len(xyz)
+    assert np.array_equal(coords[2], coords[1][kps[1][:, 0]])
+
+
+@pytest.mark.parametrize("tag,rnd", [("rand", False), ("randjit", True)])
+def test_multi_level_pooling_random_golden(tag, rnd):
+    """The same configuration, 'random' (RNGs seeded like the fixture's run):
+    the second level voxelises the FIRST level's vertices on the grid anchored
+    at the ORIGINAL cloud's minimum (graph_gen.py:108-110)."""
+    from _multilevel import BASE_VOXEL, LEVEL_CONFIGS
+    g = gold("graph_multilevel.npz")
+    xyz = g["tiny_xyz"]
+    np.random.seed(0)
+    random.seed(0)
+    coords, kps, edges = go.multi_level_graph(
+        xyz, BASE_VOXEL, LEVEL_CONFIGS, add_rnd3d=rnd,
+        downsample_method='random')
+    for l in range(3):
+        assert np.array_equal(kps[l], g["tiny_%s_kp%d" % (tag, l)])
+    assert [len(c) for c in coords] + [len(e) for e in edges] == \
+        list(g["tiny_%s_counts" % tag])
+
+
+def test_multi_level_pooling_golden_is_the_reference_live():
+    """With /root/reference present: the fixture equals a fresh run of the
+    reference's function (and so does the oracle, by the tests above)."""
+    gg = reference_graph_gen()
+    if gg is None:
+        pytest.skip("reference tree not present (GPU box)")
+    import sys
+    sys.path.insert(0, GOLD)
+    try:
+        import make_golden_multilevel as mk
+    finally:
+        sys.path.remove(GOLD)
+    mk.install_open3d_stand_in()
+    g = gold("graph_multilevel.npz")
+    xyz = g["tiny_xyz"]
+    vc, ki, el = gg.gen_multi_level_local_graph_v3(
+        xyz, mk.BASE_VOXEL, mk.LEVEL_CONFIGS, add_rnd3d=False,
+        downsample_method='center')
+    for l in range(3):
+        assert np.array_equal(np.asarray(ki[l]), g["tiny_center_kp%d" % l])
+        assert np.array_equal(np.asarray(el[l]), g["tiny_center_edges%d" % l])

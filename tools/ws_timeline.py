@@ -38,6 +38,27 @@ if "--local-src" in sys.argv:
     e1 = edges[1].clone()
     e1[:, 0] = torch.clamp(e1[:, 1] + (e1[:, 0] % 128) - 64, 0, n_k - 1)
     edges = [edges[0], e1.contiguous()]
+frame = (x, f)
+if "--train-graph" in sys.argv:
+    # the training step's level-1 graph: two frames built with the TRAINING
+    # graph kwargs (voxel 0.8 m, random keypoints, fan-in capped at 256) and
+    # merged (train.batch_data) -- ~70k edges on ~1.6k vertices: a few tiles
+    # per wave, where the kernel's fixed costs show
+    from pointgnn_amd import graph_gen, train
+    fn = graph_gen.get_graph_generate_fn(cfg['graph_gen_method'])
+    np.random.seed(99)
+    frs = []
+    for sd in (0, 1):
+        xx, ff = synthetic_cloud(seed=sd, preset="car")
+        xx, ff = torch.from_numpy(xx).to(dev), torch.from_numpy(ff).to(dev)
+        cs, ks, es = fn(xx, **cfg['graph_gen_kwargs'])
+        kk = int(cs[1].shape[0])
+        z = torch.zeros((kk, 1), device=dev)
+        frs.append((ff, cs, ks, es, z, z, z))
+    merged = train.batch_data(frs)
+    coords, edges = merged[1], merged[3]
+    n_k = int(coords[1].shape[0])
+    frame = None
 lib = _lib.load()
 for a in sys.argv[1:]:
     if a.startswith("--tune="):
@@ -45,9 +66,9 @@ for a in sys.argv[1:]:
         _lib.set_tunable(k, int(v))
 STAMP, STRIDE, WAVES, GRID = 38, 8 + 4 * 38, 8, 256
 buf = torch.zeros(GRID * WAVES * STRIDE, dtype=torch.int64, device=dev)
-r0 = bench.roofline_edge_kernel(torch, eng, edges[1], n_k, reps=10, frame=(x, f))
+r0 = bench.roofline_edge_kernel(torch, eng, edges[1], n_k, reps=10, frame=frame)
 lib.pgnn_set_debug_buffer(_lib.ptr(buf))
-r = bench.roofline_edge_kernel(torch, eng, edges[1], n_k, reps=1, frame=(x, f))
+r = bench.roofline_edge_kernel(torch, eng, edges[1], n_k, reps=1, frame=frame)
 torch.cuda.synchronize()
 lib.pgnn_set_debug_buffer(None)
 ts = buf.cpu().numpy().reshape(GRID * WAVES, STRIDE)
