@@ -827,6 +827,12 @@ class Trainer(object):
         for lc in self.config['model_kwargs']['layer_configs'][:-1]:
             scope, kw, lvl = lc['scope'], lc['kwargs'], lc['graph_level']
             if lc['type'] == 'scatter_max_point_set_pooling':
+                if h is not None:
+                    # (inference runs it: gnn.PointSetPooling's wide-feature
+                    # path; no shipped config trains one)
+                    raise NotImplementedError(
+                        "training step: a PointSetPooling above the first "
+                        "stage (more than one pooling level)")
                 e = edges[lvl]
                 k = int(kps[lvl].shape[0])
                 feat = torch.empty((int(e.shape[0]), 16), dtype=torch.float32,
