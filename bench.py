@@ -627,7 +627,14 @@ def run_train(args, torch, dev, rank, world, dist):
                             "batch %d), graph build included%s, synthetic labels"
                             % (args.config, fpg, world * fpg,
                                "" if args.no_pipeline else
-                               " (next batch built on a second stream)"),
+                               " (next batch built on a second stream)"
+                               if args.train_loader == "stream" else
+                               " -- DIAGNOSTIC: batches built once, no build "
+                               "in the loop"),
+                "losses": "read before the next step is queued"
+                          if args.train_sync_loss else
+                          "every step's losses read inside the timed region, "
+                          "one step late (train_step(deferred=True))",
                 "last_batch_shape": dict(zip(("K", "E0", "E1"), shapes[-1])),
                 "params": int(tr.flat.numel()),
                 "allreduce_bytes": int(tr.flat.numel()) * 4,
@@ -1077,7 +1084,9 @@ def secondary_train(args, torch, dev):
         "workload": "car_auto_T3 training step, %d frames/step, training "
                     "graph kwargs (voxel 0.8, random keypoints + jitter, "
                     "fan-in cap 256), graph build included (next batch built "
-                    "on a second stream), synthetic labels, preset 'car'" % fpg,
+                    "on a second stream), every step's losses read inside the "
+                    "timed region one step late, synthetic labels, preset "
+                    "'car'" % fpg,
         "steps": steps, "ms_per_step": elapsed / steps * 1e3,
         "training_frames_per_sec": fpg * steps / elapsed,
         "params": int(tr.flat.numel()),
