@@ -684,25 +684,37 @@ __global__ __launch_bounds__(64) void segmax_wgrad_gather_kernel(
   if (lane == 0) partial_b[(int64_t)slice * cols + c] = bsum;
 }
 
-// dW[k, c] += sum_slices partial[slice][c][k]; db[c] += sum_slices pb[slice][c]
+// dW[k, c] += sum_slices partial[slice][c][k]; db[c] += sum_slices pb[slice][c].
+// Thread per (c, k) with k fastest: partial's rows are [c][k], so a wave reads
+// 64 consecutive floats per slice (with c fastest every lane touched a line of
+// its own), four slices in flight; the one store per output is the strided side.
 __global__ void segmax_wgrad_reduce_kernel(const float *__restrict__ partial,
                                            const float *__restrict__ partial_b,
                                            int slices, int cols, int k_in,
                                            int kin_p, float *__restrict__ dW,
                                            float *__restrict__ db) {
-  const int64_t total = (int64_t)(k_in + 1) * cols;
+  const int kk = k_in + 1;
+  const int64_t total = (int64_t)kk * cols;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
-    const int k = (int)(idx / cols), c = (int)(idx - (int64_t)k * cols);
+    const int c = (int)(idx / kk), k = (int)(idx - (int64_t)c * kk);
+    const bool bias = k == k_in;
+    if (bias && !db) continue;
+    const float *__restrict__ src =
+        bias ? partial_b + c : partial + (int64_t)c * kin_p + k;
+    const int64_t step = bias ? (int64_t)cols : (int64_t)cols * kin_p;
     float s = 0.0f;
-    if (k < k_in) {
-      for (int sl = 0; sl < slices; ++sl)
-        s += partial[((int64_t)sl * cols + c) * kin_p + k];
-      dW[(int64_t)k * cols + c] += s;
-    } else if (db) {
-      for (int sl = 0; sl < slices; ++sl) s += partial_b[(int64_t)sl * cols + c];
-      db[c] += s;
+    int sl = 0;
+    for (; sl + 3 < slices; sl += 4) {
+      const float a0 = src[(int64_t)sl * step];
+      const float a1 = src[(int64_t)(sl + 1) * step];
+      const float a2 = src[(int64_t)(sl + 2) * step];
+      const float a3 = src[(int64_t)(sl + 3) * step];
+      s = (((s + a0) + a1) + a2) + a3;
     }
+    for (; sl < slices; ++sl) s += src[(int64_t)sl * step];
+    if (bias) db[c] += s;
+    else dW[(int64_t)k * cols + c] += s;
   }
 }
 
@@ -983,16 +995,20 @@ __global__ __launch_bounds__(256) void weight_grad_reduce_many_kernel(
   }
 }
 
-// 64 outputs x 4 slice groups per workgroup: group g adds slices g, g+4, ...;
-// the four partial sums meet in LDS and are added in a fixed order, so the
-// result does not depend on timing (a thread per output walking all slices
-// serially ran at 1.8 TB/s: too few threads for the ~150 slices)
-__global__ __launch_bounds__(256) void weight_grad_reduce_kernel(
+// 64 outputs x G slice groups per workgroup: group g adds slices g, g+G, ...
+// (four independent loads in flight per thread); the G partial sums meet in
+// LDS and are added in a fixed order, so the result does not depend on timing.
+// (A thread per output walking all slices serially ran at 1.8 TB/s: too few
+// threads for ~150 slices.  G = 4 was still a chain of 192 dependent adds per
+// thread for the 768 slices of pool_narrow_bwd_kernel -- three launches of
+// ~50 us for 33 MB: G = 16 there.)
+template <int G>
+__global__ __launch_bounds__(64 * G) void weight_grad_reduce_kernel(
     const float *__restrict__ partial, int slices, int64_t kin_p, int nout_p,
     int k_in, int n_out, int64_t ld_dw, float *__restrict__ dW,
     float *__restrict__ db, int accumulate,
     const float *__restrict__ bias_partial /* nullable, see the kernel */) {
-  __shared__ float part[4][64];
+  __shared__ float part[G][64];
   const int64_t total = (int64_t)(k_in + 1) * n_out;
   const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
   for (int64_t base = (int64_t)blockIdx.x * 64; base < total;
@@ -1002,18 +1018,26 @@ __global__ __launch_bounds__(256) void weight_grad_reduce_kernel(
     const int j = (int)(idx - i * n_out);
     float s = 0.0f;
     if (idx < total) {
-      if (bias_partial && i == k_in) {
-        for (int sl = g; sl < slices; sl += 4)
-          s += bias_partial[(int64_t)sl * nout_p + j];
-      } else {
-        for (int sl = g; sl < slices; sl += 4)
-          s += partial[((int64_t)sl * kin_p + i) * nout_p + j];
+      const bool bias = bias_partial && i == k_in;
+      const float *__restrict__ src =
+          bias ? bias_partial + j : partial + i * nout_p + j;
+      const int64_t step = bias ? (int64_t)nout_p : kin_p * nout_p;
+      int sl = g;
+      for (; sl + 3 * G < slices; sl += 4 * G) {
+        const float a0 = src[(int64_t)sl * step];
+        const float a1 = src[(int64_t)(sl + G) * step];
+        const float a2 = src[(int64_t)(sl + 2 * G) * step];
+        const float a3 = src[(int64_t)(sl + 3 * G) * step];
+        s = (((s + a0) + a1) + a2) + a3;
       }
+      for (; sl < slices; sl += G) s += src[(int64_t)sl * step];
     }
     part[g][o] = s;
     __syncthreads();
     if (g == 0 && idx < total) {
-      s = ((part[0][o] + part[1][o]) + part[2][o]) + part[3][o];
+      s = part[0][o];
+#pragma unroll
+      for (int q = 1; q < G; ++q) s += part[q][o];
       if (i < k_in) {
         float *w = dW + i * ld_dw + j;
         *w = accumulate ? *w + s : s;
@@ -1591,7 +1615,7 @@ extern "C" int pgnn_weight_grad_f32(const float *X, int64_t ld_x, int32_t k_in,
       default: PGNN_WG(5); break;
     }
 #undef PGNN_WG
-    hipLaunchKernelGGL(weight_grad_reduce_kernel,
+    hipLaunchKernelGGL(weight_grad_reduce_kernel<4>,
                        dim3(grid_for((int64_t)(k_in + 1) * nc * 4)), dim3(256), 0,
                        stream, partial, slices, (int64_t)in_blocks * 64,
                        nt * 16, k_in, nc, (int64_t)n_out, dW + c0,
@@ -1994,16 +2018,20 @@ extern "C" int pgnn_pool_narrow_bwd_f32(
   hipLaunchKernelGGL(pool_narrow_bwd_kernel, dim3((unsigned)slices), dim3(256), 0,
                      stream, a);
   const int acc = accumulate ? 1 : 0;
-  hipLaunchKernelGGL(weight_grad_reduce_kernel, dim3(grid_for((int64_t)65 * 128 * 4)),
-                     dim3(256), 0, stream, (const float *)a.pw2, slices,
+  // (grid_for counts 256-thread blocks of work items: x 4 = one workgroup per
+  // 64 outputs)
+  hipLaunchKernelGGL(weight_grad_reduce_kernel<16>,
+                     dim3(grid_for((int64_t)65 * 128 * 4)), dim3(1024), 0, stream,
+                     (const float *)a.pw2, slices,
                      (int64_t)64, 128, 64, 128, (int64_t)128, dW2, db2, acc,
                      (const float *)a.pb2);
-  hipLaunchKernelGGL(weight_grad_reduce_kernel, dim3(grid_for((int64_t)33 * 64 * 4)),
-                     dim3(256), 0, stream, (const float *)a.pw1, slices,
+  hipLaunchKernelGGL(weight_grad_reduce_kernel<16>,
+                     dim3(grid_for((int64_t)33 * 64 * 4)), dim3(1024), 0, stream,
+                     (const float *)a.pw1, slices,
                      (int64_t)32, 64, 32, 64, (int64_t)64, dW1, db1, acc,
                      (const float *)a.pb1);
-  hipLaunchKernelGGL(weight_grad_reduce_kernel,
-                     dim3(grid_for((int64_t)(k_in0 + 1) * 32 * 4)), dim3(256), 0,
+  hipLaunchKernelGGL(weight_grad_reduce_kernel<16>,
+                     dim3(grid_for((int64_t)(k_in0 + 1) * 32 * 4)), dim3(1024), 0,
                      stream, (const float *)a.pw0, slices, (int64_t)16, 32,
                      (int)k_in0, 32, (int64_t)32, dW0, db0, acc,
                      (const float *)a.pb0);
