@@ -635,6 +635,41 @@ def test_native_step_updates_like_the_python_step(dev):
         assert np.abs(a - b).max() <= 3e-3 * max(np.abs(b).max(), 1e-6) + 1e-7, n
 
 
+def test_deferred_step_results_are_the_step_results(dev):
+    """train_step(deferred=True) hands back a StepResult whose values are read
+    AFTER later steps were queued (bench.py reads every loss one step late):
+    the dicts equal those of the same steps run one by one, the learning-rate
+    and the L1 term are those of the weights each step USED, and reading late
+    changes nothing about the weights."""
+    from pointgnn_amd import train
+    cfg = configs.car_auto_config(3)
+    params = weights.init_params(cfg, seed=8, bias_scale=0.05)
+    batches = [_tiny_batch(seed=s) for s in (1, 2, 3)]
+    a = train.Trainer(cfg, params=params, device=dev)
+    want = [a.train_step(b) for b in batches]
+    b_tr = train.Trainer(cfg, params=params, device=dev)
+    handles = [b_tr.train_step(b, deferred=True) for b in batches]
+    assert all(isinstance(h, train.StepResult) for h in handles)
+    got = [h.get() for h in reversed(handles)][::-1]   # read newest first
+    for w, g in zip(want, got):
+        assert set(w) == set(g)
+        for k in w:
+            # (float atomics in the sparse adjoint: the weights of steps 2 and
+            # 3 differ in the last bits between two runs)
+            assert abs(w[k] - g[k]) <= 1e-3 * max(abs(w[k]), 1e-6), (k, w[k], g[k])
+    # step 1 runs on identical weights: same forward, same sums (the L1 term
+    # is a float64 atomic sum: last-bit order noise)
+    assert want[0]['cls_loss'] == got[0]['cls_loss']
+    assert want[0]['loc_loss'] == got[0]['loc_loss']
+    assert got[0]['reg_loss'] != got[2]['reg_loss']
+    assert handles[0].get() is handles[0].get()
+    sa, sb = a.state_dict(), b_tr.state_dict()
+    for n in sa:
+        # (three updates at lr 0.125 amplify the float atomics' order noise,
+        # see the test above)
+        assert np.abs(sa[n] - sb[n]).max() <= 3e-3 * max(np.abs(sa[n]).max(), 1e-6), n
+
+
 def test_switching_step_paths_never_runs_on_stale_weight_images(dev):
     """A native handle exists, the caller switches to the Python-driven step,
     updates the weights there, then switches back: the native forward must
