@@ -87,30 +87,10 @@ __global__ void edge_hidden_bwd_kernel(const float *__restrict__ dH1, int ld,
   }
 }
 
-__global__ void pool_features_kernel(const float *__restrict__ feat, int nfeat,
-                                     const float *__restrict__ xyz,
-                                     const int32_t *__restrict__ kp,
-                                     const int32_t *__restrict__ edges,
-                                     int64_t n_edges, float *__restrict__ F) {
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_edges;
-       e += (int64_t)gridDim.x * blockDim.x) {
-    const int s = edges[2 * e], d = edges[2 * e + 1];
-    const int k = kp[d];
-    float *o = F + e * 16;
-    for (int i = 0; i < 16; ++i) {
-      float v = 0.0f;
-      if (i < nfeat)
-        v = feat[(int64_t)s * nfeat + i];
-      else if (i < nfeat + 3)
-        v = xyz[3 * (int64_t)s + (i - nfeat)] - xyz[3 * (int64_t)k + (i - nfeat)];
-      o[i] = v;
-    }
-  }
-}
-
-// the same rows for ANY feature width (a pooling level above the first pools
-// the previous level's 300-wide features): F[e] = [f(src)[:nfeat] | xyz(src) -
-// xyz(kp(dst)) | 0 ...], ld_f columns; thread per (edge, column)
+// PointSetPooling's edge rows for any feature width (16 columns for the raw
+// point features; a pooling level above the first pools the previous level's
+// 300-wide features): F[e] = [f(src)[:nfeat] | xyz(src) - xyz(kp(dst)) | 0 ...],
+// ld_f columns; thread per (edge, column)
 __global__ void pool_features_wide_kernel(
     const float *__restrict__ feat, int64_t ld_feat, int nfeat,
     const float *__restrict__ xyz, const int32_t *__restrict__ kp,
@@ -1139,22 +1119,26 @@ __global__ void sgd_kernel(float *__restrict__ w, const float *__restrict__ g,
   }
 }
 
-__global__ void l1_norm_kernel(const float *__restrict__ w,
-                               const float *__restrict__ is_weight, int64_t n,
-                               double *__restrict__ out) {
+__global__ __launch_bounds__(1024) void l1_norm_kernel(
+    const float *__restrict__ w, const float *__restrict__ is_weight, int64_t n,
+    double *__restrict__ out) {
   double s = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * blockDim.x)
     if (is_weight[i] != 0.0f) s += (double)fabsf(w[i]);
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
-  // one fp64 atomic per workgroup (one per wave serialised 23k of them on a
-  // single address: 56 us for 1.5 M parameters)
-  __shared__ double part[4];
+  // one fp64 atomic per 16-wave workgroup, <= 128 of them (one per wave
+  // serialised 23k atomics on a single address: 56 us for 1.5 M parameters;
+  // one per 4-wave workgroup, 1024 of them, still 18 us)
+  __shared__ double part[16];
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0)
-    atomicAdd(out, (part[0] + part[1]) + (part[2] + part[3]));
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int q = 0; q < (int)(blockDim.x >> 6); ++q) t += part[q];
+    atomicAdd(out, t);
+  }
 }
 
 // dP and dQ zeroed by one fill when the caller laid them out back to back
@@ -1451,9 +1435,12 @@ extern "C" int pgnn_pool_features_fwd(const float *point_features,
   if (n_edges == 0) return 0;
   PGNN_REQUIRE(point_xyz && keypoint_indices && edges && F, PGNN_E_INVALID,
                "pool_features: null pointer");
-  hipLaunchKernelGGL(pool_features_kernel, dim3(grid_for(n_edges)), dim3(256), 0,
-                     (hipStream_t)stream_, point_features, n_feat, point_xyz,
-                     keypoint_indices, edges, n_edges, F);
+  // (thread per (edge, column): coalesced 64-byte rows; a thread per edge
+  // writing its 16 floats ran at 0.7 TB/s)
+  hipLaunchKernelGGL(pool_features_wide_kernel, dim3(grid_for(n_edges * 16, 8192)),
+                     dim3(256), 0, (hipStream_t)stream_, point_features,
+                     (int64_t)n_feat, n_feat, point_xyz, keypoint_indices, edges,
+                     n_edges, F, 16);
   PGNN_HIP(hipGetLastError());
   return 0;
   PGNN_GUARD_END
@@ -2113,8 +2100,8 @@ extern "C" int pgnn_l1_norm(const float *params, const float *is_weight,
   PGNN_HIP(hipMemsetAsync(out, 0, sizeof(double), stream));
   if (n <= 0) return 0;
   PGNN_REQUIRE(params && is_weight, PGNN_E_INVALID, "l1_norm: null pointer");
-  hipLaunchKernelGGL(l1_norm_kernel, dim3(grid_for(n, 1024)), dim3(256), 0,
-                     stream, params, is_weight, n, out);
+  hipLaunchKernelGGL(l1_norm_kernel, dim3(grid_for((n + 3) / 4, 128)), dim3(1024),
+                     0, stream, params, is_weight, n, out);
   PGNN_HIP(hipGetLastError());
   return 0;
   PGNN_GUARD_END

@@ -1150,8 +1150,8 @@ class Trainer(object):
         # Everything the device still has to do is queued BEFORE the host reads
         # anything: the L1 term of the weights this step used, SGD, the image
         # refresh.  The step's numbers then come back in one copy.
-        l1 = torch.zeros(1, dtype=torch.float64, device=self.device)
-        _lib.check(self.lib.pgnn_l1_norm(
+        l1 = torch.empty(1, dtype=torch.float64, device=self.device)
+        _lib.check(self.lib.pgnn_l1_norm(         # (the call zeroes `l1` first)
             _lib.ptr(self.flat), _lib.ptr(self.is_weight), self.flat.numel(),
             _lib.ptr(l1), self._st()), "pgnn_l1_norm")
         if apply:
