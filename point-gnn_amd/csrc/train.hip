@@ -331,28 +331,49 @@ __global__ void segmax_count_win4_kernel(
     int ldc, int32_t *__restrict__ tie_count, int32_t *__restrict__ tie_list,
     int tie_cap) {
   const int64_t total = rows * cols4;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = idx / cols4;
-    const int c = 4 * (int)(idx - r * cols4);
-    const int s = seg[r];
-    if (s < 0 || s >= nseg) continue;
-    const v4f d = *reinterpret_cast<const v4f *>(data + r * ld + c);
-    const v4f o = *reinterpret_cast<const v4f *>(out + (int64_t)s * ldo + c);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  // two items per trip: both segment ids, then both (row, maxima) pairs are in
+  // flight together (one item per trip was two dependent round trips per trip)
+  for (int64_t idx0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+       idx0 < total; idx0 += 2 * stride) {
+    int64_t r[2];
+    int c[2], s[2];
+    bool ok[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      if (d[i] == o[i] && d[i] > 0.0f) {
-        const int slot = atomicAdd(&cnt[(int64_t)s * ldc + c + i], 1);
-        if (slot == 0) {
-          win[(int64_t)s * ldc + c + i] = (int32_t)r;
-        } else {  // a further row holding the same positive maximum
-          const int p = atomicAdd(tie_count, 1);
-          if (p < tie_cap) {
-            tie_list[2 * p] = (int32_t)r;
-            tie_list[2 * p + 1] = c + i;
+    for (int u = 0; u < 2; ++u) {
+      const int64_t idx = idx0 + u * stride;
+      ok[u] = idx < total;
+      const int64_t ic = ok[u] ? idx : idx0;  // clamped: an unconditional load
+      r[u] = ic / cols4;
+      c[u] = 4 * (int)(ic - r[u] * cols4);
+      s[u] = seg[r[u]];
+    }
+    v4f d[2], o[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      ok[u] = ok[u] && s[u] >= 0 && s[u] < nseg;
+      const int sc = ok[u] ? s[u] : 0;
+      d[u] = *reinterpret_cast<const v4f *>(data + r[u] * ld + c[u]);
+      o[u] = *reinterpret_cast<const v4f *>(out + (int64_t)sc * ldo + c[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (!ok[u]) continue;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (d[u][i] == o[u][i] && d[u][i] > 0.0f) {
+          const int slot = atomicAdd(&cnt[(int64_t)s[u] * ldc + c[u] + i], 1);
+          if (slot == 0) {
+            win[(int64_t)s[u] * ldc + c[u] + i] = (int32_t)r[u];
+          } else {  // a further row holding the same positive maximum
+            const int p = atomicAdd(tie_count, 1);
+            if (p < tie_cap) {
+              tie_list[2 * p] = (int32_t)r[u];
+              tie_list[2 * p + 1] = c[u] + i;
+            }
           }
         }
-      }
+    }
   }
 }
 
