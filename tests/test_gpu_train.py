@@ -338,8 +338,12 @@ def test_full_gradient_matches_oracle(dev, name):
     for n, ref in g_ref.items():
         e_max, e_fro = _grad_errors(got[n], ref)
         worst_max, worst_fro = max(worst_max, e_max), max(worst_fro, e_fro)
-        assert e_fro < 3e-3, "%s: Frobenius rel err %.3g" % (n, e_fro)
-        assert e_max < (1e-4 if name == "car_auto_T1" else 3e-2), \
+        # (observed worst, stable run to run -- the forward is deterministic:
+        # Frobenius 1.2e-3, max-entry 7.9e-3, both car_auto_T3; with the
+        # device's own decisions replayed the same entries agree to 1.4e-6,
+        # test_full_gradient_matches_mask_matched_oracle)
+        assert e_fro < 2e-3, "%s: Frobenius rel err %.3g" % (n, e_fro)
+        assert e_max < (1e-4 if name == "car_auto_T1" else 1.2e-2), \
             "%s: max-entry rel err %.3g" % (n, e_max)
     print(name, "worst gradient error: max-entry %.3g, Frobenius %.3g" % (
         worst_max, worst_fro))
@@ -502,7 +506,8 @@ def test_two_frame_batch_equals_two_ranks(dev):
     loss, g_ref, _ = to.step_gradients(params, cfg, [b0, b1])
     for n, ref in g_ref.items():
         e_max, e_fro = _grad_errors(g_merged[n], ref)
-        assert e_fro < 3e-3 and e_max < 3e-2, (n, e_max, e_fro)
+        # (observed: max-entry 1.2e-4, Frobenius 3.2e-5 -- a one-GNN-layer model)
+        assert e_fro < 2e-4 and e_max < 1e-3, (n, e_max, e_fro)
 
 
 @pytest.mark.parametrize("rows,k_in,n_cols,nseg,ties", [
