@@ -106,7 +106,10 @@ def test_train_step_matches_reference_tf_graph(dev, name):
         nrm = abs(np.linalg.norm(g) - float(t["gradnorm/" + v])) / \
             (float(t["gradnorm/" + v]) + 1e-12)
         worst = max(worst, fro, nrm)
-        assert fro < 5e-3 and nrm < 5e-3, (v, fro, nrm)
+        # (observed worst over the six graphs: 1.04e-3, car_fixed_T3 -- a few
+        # ReLU masks of the float32 forward differ from the float64 evaluation of
+        # the graph; 2.9e-6 for car_auto_T0, which has no GNN layer)
+        assert fro < 2e-3 and nrm < 2e-3, (v, fro, nrm)
     print(name, "worst relative gradient error vs the reference TF graph "
           "%.3g" % worst)
 
