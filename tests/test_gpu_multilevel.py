@@ -178,17 +178,19 @@ def test_multi_level_random_pooling(dev, rnd):
         assert np.array_equal(go.canonical_edges(edges[l]), ref), l
 
 
-def test_anchor_of_the_second_random_level_is_the_cloud(dev):
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_anchor_of_the_second_random_level_is_the_cloud(dev, dtype):
     """graph_gen.py:108-110: the level-2 grid starts at the minimum of the
     ORIGINAL cloud, not of the level-1 vertices -- a cloud whose minimum point
-    is not a level-1 vertex tells the two apart."""
+    is not a level-1 vertex tells the two apart.  float64: the training path's
+    clouds (train.py:88-90), NumPy's float64 `//`."""
     from pointgnn_amd import graph_gen
     rng = np.random.default_rng(3)
-    xyz = rng.uniform(0.0, 6.0, (3000, 3)).astype(np.float32)
+    xyz = rng.uniform(0.0, 6.0, (3000, 3)).astype(dtype)
     # one cell of level 1 holds the cloud's minimum AND other points: most
     # seeds pick another member, so min(level-1 vertices) > min(cloud)
     xyz[0] = [0.0, 0.0, 0.0]
-    xyz[1:40] = rng.uniform(0.05, 0.39, (39, 3)).astype(np.float32)
+    xyz[1:40] = rng.uniform(0.05, 0.39, (39, 3)).astype(dtype)
     moved = 0
     for seed in range(8):
         np.random.seed(seed)
@@ -199,6 +201,8 @@ def test_anchor_of_the_second_random_level_is_the_cloud(dev):
         c_sel = _voxels(coords[2], origin, BASE_VOXEL * 2.5)
         assert len(np.unique(c_sel, axis=0)) == len(c_sel)
         assert np.array_equal(np.unique(c_sel, axis=0), np.unique(c_all, axis=0))
+        assert coords[1].dtype == dtype and coords[2].dtype == dtype
+        assert np.array_equal(coords[2], coords[1][kps[1][:, 0]])
         moved += int(np.any(np.amin(coords[1], axis=0) > origin[0]))
     assert moved > 0, "the level-1 vertices always contained the minimum"
 
