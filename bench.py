@@ -30,6 +30,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_MFMA_PEAK_TF = 157.3    # MI355X_MICROARCH.md: FP32 matrix peak
+BF16_MFMA_PEAK_TF = 2500.0   # ... dense bf16 matrix peak (no sparsity)
 
 
 def algorithmic_flops_per_frame(cfg, n_k, n_e0, n_e1):
@@ -269,6 +270,53 @@ def roofline_edge_kernel(torch, engine, edges1, n_k, reps=10, frame=None):
                 "back-to-back launches / 10, the call launches this kernel "
                 "alone (aggregation buffer pre-filled, as in a frame): "
                 "compare rocprofv3's average for edge_ws_kernel in profiles/",
+    }
+
+
+def roofline_edge_kernel_bf16x3(torch, engine, edges1, n_k, reps=10, frame=None):
+    """The split-bf16 form of the fused edge kernel (csrc/edge_ws_bf16.h)
+    against ITS bound: the bf16 matrix pipe at six MFMAs per product."""
+    from pointgnn_amd import _lib, gnn
+    lib = _lib.load()
+    store = engine.model._store
+    key = [k for k in store._cache if k[0] == 'edge']
+    img = [k for k in store._cache if k[0] == 'edge_bf16x3']
+    if not key or not img or frame is None:
+        return None
+    c, p_chain, wx_dev, rest = store._cache[key[0]]
+    image = store._cache[img[0]]
+    wq = int(wx_dev.shape[1])
+    dev = edges1.device
+    gnn.EDGE_INPUT_TAP = []
+    engine.run_frame(*frame)
+    p, q = [t.clone() for t in gnn.EDGE_INPUT_TAP[0]]
+    gnn.EDGE_INPUT_TAP = None
+    agg = torch.full((n_k, gnn.padded_width(rest.n_out)),
+                     float(np.finfo(np.float32).min), device=dev)
+    n_e = int(edges1.shape[0])
+
+    def run():
+        _lib.check(lib.pgnn_edge_mlp_scatter_max_bf16x3_fwd(
+            _lib.ptr(p), _lib.ptr(q), wq, int(rest.k_in), _lib.ptr(edges1),
+            n_e, n_k, _lib.ptr(image), int(rest.n_out),
+            int(rest.array[0].relu_from), 1 | 2, _lib.ptr(agg), agg.stride(0),
+            None, None, _lib.stream_ptr()), "bf16x3 edge kernel")
+    dur = time_kernel(run, reps, torch)
+    flops = 2.0 * int(rest.k_in) * int(rest.n_out) * n_e
+    peak = BF16_MFMA_PEAK_TF / 6.0
+    return {
+        "kernel": "edge_ws_bf16x3_kernel (weights-stationary fused gather + "
+                  "3-way exact bf16 split + edge FC2 as 6 bf16 MFMA products "
+                  "+ scatter-max; csrc/edge_ws_bf16.h)",
+        "bound": "mfma", "achieved": flops / dur / 1e12, "peak": peak,
+        "unit": "TFLOP/s (fp32-equivalent)", "frac": flops / dur / 1e12 / peak,
+        "executed_flops": flops, "avg_launch_us": dur * 1e6,
+        "note": "peak = dense bf16 MFMA peak (%.0f TFLOP/s) / 6 products per "
+                "fp32-equivalent product; FLOPs = 2*E*k_in*n_out of the "
+                "layer (the K padding 300 -> 320 and the 16 zero columns are "
+                "not counted); duration as for roofline_mfma: compare "
+                "rocprofv3's average for edge_ws_bf16x3_kernel in profiles/"
+                % BF16_MFMA_PEAK_TF,
     }
 
 
@@ -1067,6 +1115,26 @@ def secondary_ped(args, torch, dev, measure):
         pl = roofline_pool_kernel(torch, eng, frame=(x, f))
         if pl is not None:
             out["roofline_pool"] = pl
+    # the same frames with the edge stage on the split-bf16 kernel (C = 256:
+    # csrc/edge_ws_bf16.h's <8, 5> instance) -- SECONDARY, as in the headline
+    eng.model.edge_arith = "bf16x3"
+    try:
+        eng.frame_shapes = []
+        e16, _, _ = measure("ped_dense", steps, 3, engine=eng, n_frames=4)
+        b16 = {"frames_per_sec": steps / e16,
+               "ms_per_frame": e16 / steps * 1e3,
+               "vs_f32": elapsed / e16,
+               "dtype": "bf16x3 split products, f32 accumulate (edge stage "
+                        "only)"}
+        if not args.no_roofline:
+            rf = roofline_edge_kernel_bf16x3(torch, eng, edges[1], n_k,
+                                             frame=(x, f))
+            if rf is not None:
+                rf["workload"] = out["roofline_mfma"]["workload"]
+                b16["roofline"] = rf
+        out["bf16x3"] = b16
+    finally:
+        eng.model.edge_arith = "f32"
     return out
 
 
@@ -1121,9 +1189,6 @@ def main(argv=None):
         from pointgnn_amd import _lib as _pg_lib
         key, val = kv.split("=")
         _pg_lib.set_tunable(key, int(val))
-    from pointgnn_amd import gnn as _pg_gnn
-    _pg_gnn.EDGE_ARITH = args.edge_arith
-
     if args.train:
         run_train(args, torch, dev, rank, world, dist)
         if dist is not None:
@@ -1133,7 +1198,8 @@ def main(argv=None):
 
     cfg = configs.get_config(args.config)
     params = weights.init_params(cfg, seed=0, bias_scale=0.05)
-    engine = InferenceEngine(cfg, params, device=dev)
+    engine = InferenceEngine(cfg, params, device=dev,
+                             edge_arith=args.edge_arith)
     engine.config_name = args.config
 
     def measure(preset, steps, warmup, engine=engine, n_frames=None, fps=1,
@@ -1257,13 +1323,23 @@ def main(argv=None):
         x0_, f0_ = pool[first][:2]
         lg32, bx32 = [t.clone() for t in engine.run_frame(x0_, f0_)]
         engine.frame_shapes = []
-        _pg_gnn.EDGE_ARITH = "bf16x3"
+        engine.model.edge_arith = "bf16x3"
         try:
             lg16, bx16 = [t.clone() for t in engine.run_frame(x0_, f0_)]
             s3 = max(8, args.steps // 2)
             e3, sh3, _ = measure(args.preset, s3, 2, fps=fps_h)
+            rf16 = None
+            if not args.no_roofline:
+                coords_, _, edges_ = engine.last_graph
+                rf16 = roofline_edge_kernel_bf16x3(
+                    torch, engine, edges_[1], int(coords_[1].shape[0]),
+                    frame=(x0_, f0_))
+                if rf16 is not None:
+                    rf16["workload"] = {"frame_seed": first,
+                                        "E": int(edges_[1].shape[0]),
+                                        "K": int(coords_[1].shape[0])}
         finally:
-            _pg_gnn.EDGE_ARITH = "f32"
+            engine.model.edge_arith = "f32"
         engine.frame_shapes = []
         b16 = {
             "workload": "%s inference, preset '%s', edge stage on the "
@@ -1281,10 +1357,13 @@ def main(argv=None):
             "max_abs_dbox_vs_f32_path_frame_seed%d" % first:
                 float((bx16 - bx32).abs().max()),
             "note": "SECONDARY: the headline `value` and `dtype` are the "
-                    "fp32-MFMA path; tests/test_gpu_bf16x3.py holds this "
-                    "path to the float64 oracle on the full-size frames "
-                    "(its distance is not larger than the fp32 path's)",
+                    "fp32-MFMA path; tests/test_gpu_bf16x3.py and the "
+                    "edge_arith-parametrised parity tests hold this path to "
+                    "the float64 oracle and the reference's TF graphs (its "
+                    "distance is not larger than the fp32 path's)",
         }
+        if rf16 is not None:
+            b16["roofline"] = rf16
 
 
     if rank == 0:

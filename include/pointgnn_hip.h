@@ -474,17 +474,21 @@ int pgnn_edge_mlp_scatter_max_fwd_dyn(const float *P, const float *Q,
  * 300x300 or 256x256 (csrc/edge_ws_bf16.h): the layer's product runs on the
  * bf16 matrix pipe with BOTH operands split exactly into three bf16 parts
  * (8 + 8 + 8 significand bits) and the six products of combined order <= 2
- * accumulated in fp32 -- the dropped terms are below 2^-26 of a product, a
- * quarter of one fp32 rounding; results agree with the fp32-MFMA entry to
- * fp32 rounding noise (not bit for bit) and are no further from a float64
- * evaluation (tests/test_gpu_bf16x3.py).  The fp32 entry above stays the
+ * accumulated in fp32 -- the dropped terms are below 2^-24 of a product, one
+ * fp32 rounding (the weights' parts are rounded to nearest, the gathered
+ * operand's first part too, its residual is cut in two); results agree with
+ * the fp32-MFMA entry to fp32 rounding noise (not bit for bit) and are no
+ * further from a float64 evaluation or from the reference's TF graphs
+ * (tests/test_gpu_bf16x3.py, the edge_arith-parametrised parity tests).  The
+ * fp32 entry above stays the
  * default and the parity reference (gnn.py:355-365 is fp32 in the reference).
  * `image`: device copy of what pgnn_pack_fc_bf16x3 wrote for the layer
  * (pgnn_packed_fc_bf16x3_bytes of it); width = the layer's k_in, n_out its
  * width, relu_from as in pgnn_fc_layer.  n_edges / num_vertices: NULL = the
  * capacities are the counts; else the capacity form (counts on the device).
- * PGNN_E_UNSUPPORTED, having done nothing, for other shapes or fewer than
- * ~65k edges: run pgnn_edge_mlp_scatter_max_fwd.                             */
+ * PGNN_E_UNSUPPORTED, having done nothing, for other shapes, fewer than
+ * ~65k edges (tunable b16_force lifts that) or P / Q of 4 GiB and more (rows
+ * are addressed with 32-bit byte offsets): run pgnn_edge_mlp_scatter_max_fwd. */
 size_t pgnn_packed_fc_bf16x3_bytes(int32_t k_in, int32_t n_out);
 int pgnn_pack_fc_bf16x3(const float *w_host, const float *b_host, int32_t k_in,
                         int32_t n_out, void *image_host);
@@ -1051,7 +1055,10 @@ int pgnn_kitti_cam_points_in_image(
  *                  the weights-stationary kernels); with ws_reserve they put
  *                  the builder on CUs the fused kernels leave free (measured:
  *                  no net gain; default 0 = off)
- *   kernel choice  mlp_debug bits 2048 / 4096 (edge stage: LDS-tile kernel /
+ *   kernel choice  b16_force (1: pgnn_edge_mlp_scatter_max_bf16x3_fwd also
+ *                  takes lists of a few tiles, where it otherwise answers
+ *                  PGNN_E_UNSUPPORTED: the parity tests on small fixtures),
+ *                  mlp_debug bits 2048 / 4096 (edge stage: LDS-tile kernel /
  *                  weights-stationary kernel), 8192 / 16384 (pooling stage),
  *                  1024 (pooling hidden layers through the LDS tile), 32 / 128
  *                  (scatter-max epilogue forms), 512 (4-wave small-row kernel)

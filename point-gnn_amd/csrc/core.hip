@@ -144,6 +144,7 @@ extern int g_graph_debug;
 extern int g_mlp_pool_pct;
 extern int g_ws_xcds;
 extern int g_ws_prio;
+extern int g_b16_force;
 extern int g_ws_pool_pct;
 extern int g_ws_chunk;
 extern int g_ws_balance;
@@ -298,6 +299,10 @@ extern "C" int pgnn_set_tunable(const char *key, int value) {
   }
   if (!strcmp(key, "ws_prio")) {
     pgnn::g_ws_prio = value;
+    return 0;
+  }
+  if (!strcmp(key, "b16_force")) {
+    pgnn::g_b16_force = value != 0;
     return 0;
   }
   if (!strcmp(key, "graph_debug")) {

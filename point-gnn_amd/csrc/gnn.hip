@@ -24,6 +24,7 @@ int g_pool_msub = 0;
 int g_mlp_pool_pct = 12;  // share of the row tiles handed out dynamically
 int g_ws_xcds = 8;        // edge_ws.h: row slices (8 = one per XCD, 1 = none)
 int g_ws_prio = 1;        // edge_ws.h: raised wave priority outside the MFMA loop
+int g_b16_force = 0;      // tests: the split-bf16 edge kernel also for lists of a few tiles
 int g_ws_pool_pct = 0;    // edge_ws.h / pool_ws.h: share of the tiles handed out
                           // dynamically (measured: a pool costs more in extra
                           // range boundaries than it returns; kept as a tested
@@ -1639,8 +1640,10 @@ int launch_edge_ws3(EdgeWsArgs &a, int nt, int cus, hipStream_t stream) {
   const int rc = ws_partition(a, nt, NTMAX, cus);
   if (rc) return rc;
   {
-    // relative cost of a row tile: 60 MFMAs of 16 cycles per column tile +
-    // ~2.4k cycles of gather / split VALU that do not overlap them
+    // relative cost of a row tile: 60 MFMAs of 16 cycles per column tile + the
+    // part of the gather / split / segmented max that does not hide behind them
+    // (round 4's 2.4k cycles, when nothing did; the interleaved body leaves
+    // about a third: tools/sessions/r05_s9.sh)
     double cost[kWsMaxGroups];
     for (int g = 0; g < a.groups; ++g)
       cost[g] = 960.0 * KB / 10 * (a.tile0[g + 1] - a.tile0[g]) + 2400.0;
@@ -1681,7 +1684,10 @@ extern "C" int pgnn_edge_mlp_scatter_max_bf16x3_fwd(
   // 150 KiB of weights per workgroup: otherwise the caller runs the fp32 entry
   if (!((kb == 10 && nt == 19) || (kb == 8 && nt == 16)) || cus < 64 ||
       cus % 8 != 0 ||
-      expected(de, edges_cap) < (int64_t)16 * 2 * kWsWaves * cus)
+      (!g_b16_force &&
+       expected(de, edges_cap) < (int64_t)16 * 2 * kWsWaves * cus) ||
+      // (the kernel addresses P / Q rows with 32-bit byte offsets)
+      (int64_t)vertices_cap * ld_pq * 4 >= ((int64_t)1 << 32))
     return PGNN_E_UNSUPPORTED;  // (no message: an expected answer)
   if (vertices_cap == 0) return 0;
   PGNN_REQUIRE(out != nullptr, PGNN_E_INVALID, "edge_bf16x3: null output");

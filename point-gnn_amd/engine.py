@@ -165,12 +165,16 @@ class CapturedFrame(object):
 
 
 class InferenceEngine(object):
-    def __init__(self, config, params, box_encoding_len=7, device=None):
+    def __init__(self, config, params, box_encoding_len=7, device=None,
+                 edge_arith='f32'):
+        """`edge_arith`: arithmetic of the per-edge product (gnn.EDGE_ARITHS);
+        also settable later through `engine.model.edge_arith`."""
         self.config = config
         self.model = models.get_model(config['model_name'])(
             num_classes=config['num_classes'],
             box_encoding_len=box_encoding_len, mode='test',
             **config['model_kwargs'])
+        self.model.edge_arith = edge_arith
         self.model.load_state_dict(params, device)
         self.graph_fn = graph_gen.get_graph_generate_fn(
             config['graph_gen_method'])

@@ -51,6 +51,19 @@ class ParamStore(object):
         self.params = {k: np.asarray(v) for k, v in params.items()}
         self.device = device
         self._cache = {}
+        self._edge_arith = 'f32'
+
+    @property
+    def edge_arith(self):
+        """Arithmetic of GraphNetAutoCenter's per-edge product: EDGE_ARITHS."""
+        return self._edge_arith
+
+    @edge_arith.setter
+    def edge_arith(self, value):
+        if value not in EDGE_ARITHS:
+            raise ValueError("edge_arith must be one of %r, not %r"
+                             % (EDGE_ARITHS, value))
+        self._edge_arith = value
 
     def _dev(self):
         if self.device is None:
@@ -508,16 +521,20 @@ class PointSetPooling(object):
 # tensors: bench.py times the edge kernel on a frame's real inputs with it
 EDGE_INPUT_TAP = None
 
-# Arithmetic of the per-edge 300x300 / 256x256 product (gnn.py:355-365):
+# Arithmetic of the per-edge 300x300 / 256x256 product (gnn.py:355-365), an
+# attribute of the MODEL (`model.edge_arith`, `InferenceEngine(...,
+# edge_arith=)`; it travels with the model's ParamStore, so two models in one
+# process -- or frames of two engines in flight on different streams -- do not
+# share a switch):
 #   'f32'    -- fp32 MFMA (default; the parity reference, bit-identical between
 #               its kernel variants);
 #   'bf16x3' -- SECONDARY: both operands split exactly into three bf16 parts,
 #               six bf16 MFMAs per block accumulated in fp32
 #               (csrc/edge_ws_bf16.h, pgnn_edge_mlp_scatter_max_bf16x3_fwd):
-#               agrees with 'f32' to fp32 rounding noise, ~2x faster.  Falls
+#               agrees with 'f32' to fp32 rounding noise, ~1.7x faster.  Falls
 #               back to 'f32' where the kernel does not apply (few edges,
 #               other layer shapes).
-EDGE_ARITH = 'f32'
+EDGE_ARITHS = ('f32', 'bf16x3')
 
 
 class GraphNetAutoCenter(object):
@@ -647,12 +664,10 @@ class GraphNetAutoCenter(object):
                      _edges_sorted_flag(edges) | 2, _lib.ptr(agg),
                      agg.stride(0), _lib.ptr(_lib.sched_ws(h.device)))
         done = False
-        if EDGE_ARITH == 'bf16x3' and rest.n == 1:
+        if store.edge_arith == 'bf16x3' and rest.n == 1:
             done = self._edge_bf16x3(lib, store, edge_scope, edge_widths, p, q,
                                      wq, rest, e, k, edges, agg, cnt_e, cnt_k,
                                      st)
-        elif EDGE_ARITH not in ('f32', 'bf16x3'):
-            raise ValueError("gnn.EDGE_ARITH must be 'f32' or 'bf16x3'")
         if done:
             pass
         elif cnt_k is None:

@@ -61,12 +61,30 @@ class MultiLayerFastLocalGraphModelV2(object):
         assert mode in ['train', 'eval', 'test'], 'Unsupported mode'
         self._mode = mode
         self._store = None
+        self._edge_arith = 'f32'
+
+    @property
+    def edge_arith(self):
+        """Arithmetic of the per-edge product of the GraphNetAutoCenter layers
+        (gnn.EDGE_ARITHS): 'f32' (default, the parity reference) or the
+        secondary 'bf16x3'.  Not part of the reference's surface."""
+        return self._edge_arith
+
+    @edge_arith.setter
+    def edge_arith(self, value):
+        if value not in gnn.EDGE_ARITHS:
+            raise ValueError("edge_arith must be one of %r, not %r"
+                             % (gnn.EDGE_ARITHS, value))
+        self._edge_arith = value
+        if self._store is not None:
+            self._store.edge_arith = value
 
     # ---- weights ----------------------------------------------------------
     def load_state_dict(self, params, device=None):
         """params: {TF variable name: ndarray} (extra keys such as the
         global-step `Variable` are ignored)."""
         self._store = gnn.ParamStore(params, device)
+        self._store.edge_arith = self._edge_arith
         return self
 
     def init_weights(self, config, seed=0, **kw):

@@ -53,3 +53,24 @@ def fullsize_oracle(key, params, cfg, inten, c_np, k_np, e_np):
                                dtype=np.float64, return_features=True)
     _FULLSIZE_ORACLE[key] = (sig, lg, bx, feats)
     return lg, bx, feats
+
+
+# The arithmetic of the per-edge product (model.edge_arith): the parity tests
+# that hold the fp32-MFMA path to the reference run a second time on the
+# SECONDARY split-bf16 kernel.  Small fixtures have fewer edges than the
+# kernel's launcher asks for (it would answer "unsupported" and the fp32 entry
+# would run): the `b16_force` tunable lifts that for the duration of the test.
+EDGE_ARITHS = ("f32", "bf16x3")
+
+
+@pytest.fixture(params=EDGE_ARITHS)
+def edge_arith(request):
+    if request.param == "f32":
+        yield "f32"
+        return
+    from pointgnn_amd import _lib
+    _lib.set_tunable("b16_force", 1)
+    try:
+        yield request.param
+    finally:
+        _lib.set_tunable("b16_force", 0)

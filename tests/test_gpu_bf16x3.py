@@ -1,5 +1,5 @@
 """The SECONDARY split-bf16 arithmetic of the per-edge layer
-(csrc/edge_ws_bf16.h, gnn.EDGE_ARITH = 'bf16x3'): both operands of the
+(csrc/edge_ws_bf16.h, model.edge_arith = 'bf16x3'): both operands of the
 300x300 / 256x256 product are split exactly into three bf16 parts and the six
 products of combined order <= 2 accumulate in fp32 on the bf16 matrix pipe.
 
@@ -157,13 +157,10 @@ def test_bf16x3_full_size_logits_vs_float64_oracle(dev, name, preset):
         **cfg["model_kwargs"]).load_state_dict(params)
     f = T(inten, dev)
     out = {}
-    try:
-        for arith in ("f32", "bf16x3"):
-            gnn.EDGE_ARITH = arith
-            lg, bx = model.predict(f, coords, kps, edges, False)
-            out[arith] = (lg.cpu().numpy(), bx.cpu().numpy())
-    finally:
-        gnn.EDGE_ARITH = "f32"
+    for arith in ("f32", "bf16x3"):
+        model.edge_arith = arith
+        lg, bx = model.predict(f, coords, kps, edges, False)
+        out[arith] = (lg.cpu().numpy(), bx.cpu().numpy())
     assert not np.array_equal(out["f32"][0], out["bf16x3"][0]), \
         "the bf16x3 kernel did not run"
     c_np = [c.cpu().numpy() for c in coords]

@@ -126,21 +126,31 @@ def test_deferred_graph_equals_host_sized_graph(dev, cfg_name, preset,
     ("car", "car", 1.0), ("car", "car", 0.01), ("car", "car", 50.0),
     ("car", "small", 1.0), ("car", "small", 100.0),
     ("ped", "small", 1.0), ("ped", "car", 1.0), ("ped", "car", 0.01)])
-def test_deferred_frame_is_bit_identical(dev, cfg_name, preset, hint_scale):
+def test_deferred_frame_is_bit_identical(dev, cfg_name, preset, hint_scale,
+                                         edge_arith):
     """Graph build + model in capacity form == the host-sized frame, bit for
     bit, also when the hints point at the other kernel of a pair (8-wave vs
     4-wave rows kernel, weights-stationary vs LDS-tile edge / pooling
-    kernels): the choice is made on the hint and may not change a result."""
+    kernels): the choice is made on the hint and may not change a result.
+    (edge_arith 'bf16x3': under the fixture's `b16_force` the split-bf16 kernel
+    runs whatever the hint says; without it a low hint sends the frame to the
+    fp32 kernel -- another arithmetic, 1e-6 apart, see gnn.EDGE_ARITHS.)"""
     import torch
     from pointgnn_amd import graph_gen as G
     from pointgnn_amd.engine import InferenceEngine
     cfg = configs.car_auto_config(3) if cfg_name == "car" else \
         configs.ped_cyl_auto_config(3)
     params = weights.init_params(cfg, seed=4, bias_scale=0.05)
-    eng = InferenceEngine(cfg, params, device=dev)
+    eng = InferenceEngine(cfg, params, device=dev, edge_arith=edge_arith)
     xyz, inten = synthetic_cloud(seed=1, preset=preset)
     x, f = T(xyz, dev), T(inten, dev)
     lg, bx = eng.run_frame(x, f)
+    if edge_arith != "f32":
+        eng.model.edge_arith = "f32"
+        assert not torch.equal(eng.run_frame(x, f)[0], lg), \
+            "the split-bf16 kernel did not run"
+        eng.model.edge_arith = edge_arith
+        eng.frame_shapes.pop()
     k, e0, e1 = eng.frame_shapes[-1]
     eng._hints = G.CountHints(
         max(1, int(k * hint_scale)),
@@ -285,15 +295,16 @@ def test_deferred_pipeline_equals_sequential(dev):
             assert torch.equal(l0, l1) and torch.equal(b0, b1)
 
 
-def test_frames_on_streams_equal_sequential(dev):
+def test_frames_on_streams_equal_sequential(dev, edge_arith):
     """run_frames_on_streams: whole frames (graph build + GNN, capacity form)
     round-robin on 1..4 streams == frame-at-a-time execution, bit for bit,
-    for frames of different sizes and for both shipped inference configs."""
+    for frames of different sizes and for both shipped inference configs, on
+    both arithmetics of the edge stage."""
     import torch
     from pointgnn_amd.engine import InferenceEngine
     for cfg in (configs.car_auto_config(2), configs.ped_cyl_auto_config(1)):
         params = weights.init_params(cfg, seed=11, bias_scale=0.05)
-        eng = InferenceEngine(cfg, params, device=dev)
+        eng = InferenceEngine(cfg, params, device=dev, edge_arith=edge_arith)
         frames = []
         for s in range(7):
             xyz, inten = synthetic_cloud(

@@ -101,8 +101,9 @@ def test_full_size_edges_equal_reference_digest(dev, preset):
 
 @pytest.mark.parametrize("preset", ["car", "car_600k"])
 @pytest.mark.parametrize("t", [0, 1])
-def test_predict_real_weights_full_size(dev, preset, t):
-    """BASELINE config 2 at its own size: trained weights x whole frame."""
+def test_predict_real_weights_full_size(dev, preset, t, edge_arith):
+    """BASELINE config 2 at its own size: trained weights x whole frame, on
+    both arithmetics of the edge stage."""
     from pointgnn_amd import graph_gen, models
     g, xyz, inten = _frame(preset)
     cfg = configs.car_auto_config(t)
@@ -123,10 +124,24 @@ def test_predict_real_weights_full_size(dev, preset, t):
         **cfg["model_kwargs"])
     model.load_state_dict(w)
     model.keep_features = True
+    l32 = None
+    if edge_arith != "f32":
+        # the fp32-MFMA path's own distance to the reference graph: the bar of
+        # the secondary arithmetic is 1.5x that
+        l32, b32 = (x.cpu().numpy() for x in model.predict(
+            T(inten, dev), coords, kps, [e0, e1], False))
+    model.edge_arith = edge_arith
     logits, boxes = model.predict(T(inten, dev), coords, kps, [e0, e1], False)
     logits = logits.cpu().numpy()
     boxes = boxes.cpu().numpy()
     ref_l, ref_b = g["T%d_logits" % t], g["T%d_box_encodings" % t]
+    if l32 is not None:
+        assert np.array_equal(l32, logits) == (t == 0), \
+            "the split-bf16 kernel did not run"
+        assert np.abs(logits - ref_l).max() <= \
+            1.5 * np.abs(l32 - ref_l).max() + 2e-7
+        assert np.abs(boxes - ref_b).max() <= \
+            1.5 * np.abs(b32 - ref_b).max() + 2e-7
     assert logits.shape == ref_l.shape and boxes.shape == ref_b.shape
     # float64 oracle on the same (device-built, digest-checked) graph
     c_np = [xyz, kp_xyz, kp_xyz]
@@ -140,10 +155,11 @@ def test_predict_real_weights_full_size(dev, preset, t):
         report.append("layer%d %.2g (|h|max %.3g)" % (
             i + 1, np.abs(got - ref).max(), np.abs(ref).max()))
         np.testing.assert_allclose(got, ref, atol=FP_TOL, rtol=1e-4)
-    print("car_auto_T%d/%s trained weights, K %d E1 %d: max|dlogit| %.3g "
+    print("car_auto_T%d/%s [%s] trained weights, K %d E1 %d: max|dlogit| %.3g "
           "max|dbox| %.3g vs the reference TF graph; %.3g / %.3g vs the "
           "float64 oracle (|logit|max %.3g); %s" % (
-              t, preset, k, len(e_np[1]), np.abs(logits - ref_l).max(),
+              t, preset, edge_arith, k, len(e_np[1]),
+              np.abs(logits - ref_l).max(),
               np.abs(boxes - ref_b).max(), np.abs(logits - lg).max(),
               np.abs(boxes - bx).max(), np.abs(ref_l).max(),
               ", ".join(report)))

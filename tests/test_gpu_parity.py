@@ -1068,9 +1068,10 @@ def test_fused_vertex_stages_are_bit_identical(dev, name, preset, seed):
 
 
 @pytest.mark.parametrize("t", [0, 1])
-def test_predict_real_weights_matches_golden(dev, t):
+def test_predict_real_weights_matches_golden(dev, t, edge_arith):
     """configs[0]/[1]: trained car_auto_T0/T1 weights, reference-built graph,
-    logits and box encodings against the committed oracle output."""
+    logits and box encodings against the committed oracle output (both
+    arithmetics of the edge stage)."""
     from pointgnn_amd import models
     g, coords, kps, edges = _graph_inputs()
     cfg = configs.car_auto_config(t)
@@ -1080,12 +1081,13 @@ def test_predict_real_weights_matches_golden(dev, t):
         num_classes=cfg["num_classes"], box_encoding_len=7, mode="test",
         **cfg["model_kwargs"])
     model.load_state_dict(w)
+    model.edge_arith = edge_arith
     logits, boxes = model.predict(g["intensity"], coords, kps, edges,
                                   is_training=False)
     assert logits.shape == ref["logits32"].shape
     assert boxes.shape == ref["boxes32"].shape
-    print("T%d max|dlogit| vs fp32 oracle %.3g, vs fp64 %.3g; boxes %.3g" % (
-        t, np.abs(logits - ref["logits32"]).max(),
+    print("T%d [%s] max|dlogit| vs fp32 oracle %.3g, vs fp64 %.3g; boxes %.3g" % (
+        t, edge_arith, np.abs(logits - ref["logits32"]).max(),
         np.abs(logits - ref["logits64"]).max(),
         np.abs(boxes - ref["boxes64"]).max()))
     np.testing.assert_allclose(logits, ref["logits32"], atol=FP_TOL, rtol=0)

@@ -40,8 +40,10 @@ def dev():
 
 
 @pytest.mark.parametrize("name", ALL)
-def test_predict_matches_reference_tf_graph(dev, name):
-    """t_logits / t_pred_box / t_probs of tower 0 (train.py:227-230)."""
+def test_predict_matches_reference_tf_graph(dev, name, edge_arith):
+    """t_logits / t_pred_box / t_probs of tower 0 (train.py:227-230), on the
+    fp32-MFMA edge stage and on the split-bf16 one (same bar; the latter's
+    distance to the reference graph at most 1.5x the former's)."""
     from pointgnn_amd import models
     t = gold("tfgraph_%s.npz" % name)
     cfg = configs.get_config(name)
@@ -51,12 +53,25 @@ def test_predict_matches_reference_tf_graph(dev, name):
         **cfg["model_kwargs"])
     model.load_state_dict(w)
     kw = graph_inputs("graph_tiny.npz")
+    model.edge_arith = edge_arith
     logits, boxes = model.predict(kw["features"], kw["coords"],
                                   kw["keypoints"], kw["edges"],
                                   is_training=False)
-    print("%s max|dlogit| %.3g max|dbox| %.3g vs the reference TF graph" % (
-        name, np.abs(logits - t["logits"]).max(),
+    print("%s [%s] max|dlogit| %.3g max|dbox| %.3g vs the reference TF graph" % (
+        name, edge_arith, np.abs(logits - t["logits"]).max(),
         np.abs(boxes - t["box_encodings"]).max()))
+    if edge_arith != "f32":
+        model.edge_arith = "f32"
+        l32, b32 = model.predict(kw["features"], kw["coords"], kw["keypoints"],
+                                 kw["edges"], is_training=False)
+        has_gnn = any(l["type"] == "scatter_max_graph_auto_center_net"
+                      for l in cfg["model_kwargs"]["layer_configs"])
+        assert np.array_equal(l32, logits) != has_gnn, \
+            "the split-bf16 kernel did not run" if has_gnn else "T0 differs"
+        for got, ref32, ref in ((logits, l32, t["logits"]),
+                                (boxes, b32, t["box_encodings"])):
+            assert np.abs(got - ref).max() <= \
+                1.5 * np.abs(ref32 - ref).max() + 2e-7
     np.testing.assert_allclose(logits, t["logits"], atol=FP_TOL, rtol=0)
     np.testing.assert_allclose(boxes, t["box_encodings"], atol=FP_TOL, rtol=0)
     np.testing.assert_allclose(model.postprocess(logits), t["probs"],
