@@ -895,6 +895,11 @@ def _parse_cpulist(text):
     return cpus
 
 
+# where bind_rank_to_numa reads PCI / NUMA topology (tests point it at a tree
+# of their own: tests/test_sharding_cpu.py fakes an 8-GPU, 2-socket node)
+SYS_ROOT = os.environ.get("PGNN_SYS_ROOT", "/sys")
+
+
 def bind_rank_to_numa(torch, local_rank, local_world):
     """Pin this process to the CPUs next to its GPU: the cpulist of the NUMA
     node /sys reports for the GPU's PCI function; when the platform reports
@@ -910,7 +915,7 @@ def bind_rank_to_numa(torch, local_rank, local_world):
             pr = torch.cuda.get_device_properties(local_rank)
             bus = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id,
                                         pr.pci_device_id)
-            with open("/sys/bus/pci/devices/%s/numa_node" % bus) as fh:
+            with open("%s/bus/pci/devices/%s/numa_node" % (SYS_ROOT, bus)) as fh:
                 node = int(fh.read().strip())
         except Exception:
             pass
@@ -918,15 +923,16 @@ def bind_rank_to_numa(torch, local_rank, local_world):
         info["numa_node"] = node
         cpus = None
         if node >= 0:
-            with open("/sys/devices/system/node/node%d/cpulist" % node) as fh:
+            with open("%s/devices/system/node/node%d/cpulist"
+                      % (SYS_ROOT, node)) as fh:
                 cpus = sorted(_parse_cpulist(fh.read()) & set(allowed))
             # ranks whose GPUs share the node split its CPUs
             peers = []
             for r in range(local_world):
                 try:
                     q = torch.cuda.get_device_properties(r)
-                    with open("/sys/bus/pci/devices/%04x:%02x:%02x.0/numa_node"
-                              % (q.pci_domain_id, q.pci_bus_id,
+                    with open("%s/bus/pci/devices/%04x:%02x:%02x.0/numa_node"
+                              % (SYS_ROOT, q.pci_domain_id, q.pci_bus_id,
                                  q.pci_device_id)) as fh:
                         if int(fh.read().strip()) == node:
                             peers.append(r)
@@ -1127,6 +1133,7 @@ def secondary_ped(args, torch, dev, measure):
                "dtype": "bf16x3 split products, f32 accumulate (edge stage "
                         "only)"}
         if not args.no_roofline:
+            eng.run_frame(x, f)     # host-sized: the image is cached by now
             rf = roofline_edge_kernel_bf16x3(torch, eng, edges[1], n_k,
                                              frame=(x, f))
             if rf is not None:
@@ -1330,6 +1337,9 @@ def main(argv=None):
             e3, sh3, _ = measure(args.preset, s3, 2, fps=fps_h)
             rf16 = None
             if not args.no_roofline:
+                # (a host-sized frame: after `measure` last_graph holds the
+                # capacity form, whose rows behind the counts are not a graph)
+                engine.run_frame(x0_, f0_)
                 coords_, _, edges_ = engine.last_graph
                 rf16 = roofline_edge_kernel_bf16x3(
                     torch, engine, edges_[1], int(coords_[1].shape[0]),

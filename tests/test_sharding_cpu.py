@@ -77,6 +77,33 @@ def test_two_process_gloo_sharding():
         assert sum(g[0] for g in gathered) == sum(range(n))
 
 
+def test_eight_process_gloo_sharding():
+    """The driver's widest form: 8 ranks, frames sharded with no data-path
+    collective; every frame is processed exactly once and the timing rule sees
+    the slowest rank."""
+    world, n = 8, 61
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    results.sort()
+    frames = sorted(i for _, mine, _, _ in results for i in mine)
+    assert frames == list(range(n))
+    sizes = [len(mine) for _, mine, _, _ in results]
+    assert max(sizes) - min(sizes) <= 1
+    for rank, mine, elapsed, gathered in results:
+        assert elapsed == 7.5                              # MAX over 8 ranks
+        assert sum(g[1] for g in gathered) == n
+        assert sum(g[0] for g in gathered) == sum(range(n))
+
+
 def _train_worker(rank, world, port, q):
     """Each 'rank' holds one frame.  Gradients are computed by the CPU oracle
     with the GLOBAL normalisers obtained through the product's collective
@@ -100,7 +127,8 @@ def _train_worker(rank, world, port, q):
     rng = np.random.default_rng(10 + rank)
     labels = rng.integers(0, 4, (k, 1)).astype(np.int32)
     boxes = rng.standard_normal((k, 1, 7)).astype(np.float32)
-    valid = (rng.random((k, 1, 1)) < (0.3 + 0.4 * rank)).astype(np.float32)
+    valid = (rng.random((k, 1, 1)) < (0.3 + 0.4 * rank / max(1, world - 1))
+             ).astype(np.float32)
     batch = (g["intensity"] * (1 + rank),
              [g["xyz"], g["kp_xyz"], g["kp_xyz"]],
              [g["kp_idx"], np.arange(k, dtype=np.int32).reshape(-1, 1)],
@@ -123,12 +151,13 @@ def _train_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_gradient_allreduce_equals_global_gradient():
+@pytest.mark.parametrize("world", [2, 8])
+def test_gradient_allreduce_equals_global_gradient(world):
+    """world 2, and 8 = the node's width (config 4: batch 16 over 8 ranks)."""
     import numpy as np
     sys.path.insert(0, ROOT)
     from pointgnn_amd import configs, weights
     from oracle import train_oracle as to
-    world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -145,7 +174,7 @@ def test_two_rank_gradient_allreduce_equals_global_gradient():
     params = weights.init_params(cfg, seed=1, bias_scale=0.1)
     _, g_ref, _ = to.step_gradients(params, cfg, [r[1] for r in results])
     ref = np.concatenate([g_ref[n].reshape(-1) for n in params])
-    assert results[0][2] == results[1][2] == 2 * results[0][1][4].shape[0]
+    assert all(r[2] == world * results[0][1][4].shape[0] for r in results)
     for _, _, _, _, flat in results:          # every rank holds the same sum
         np.testing.assert_allclose(flat, ref, atol=1e-12, rtol=1e-9)
 
@@ -259,6 +288,78 @@ def test_bench_rank_binding_splits_cpus_without_numa_info():
         assert not (seen[0] & seen[1])
         assert (seen[0] | seen[1]) == before
         assert bench._parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+    finally:
+        os.sched_setaffinity(0, before)
+
+
+def test_bench_eight_ranks_json_contract():
+    """`python bench.py --gpus 8` (stub engine, gloo): the JSON line of the
+    driver's 8-GPU run -- n_gpus, world size, frames timed over all ranks,
+    whole-job value over the slowest rank's time."""
+    p, lines = _run_bench(["--gpus", "8", "--steps", "4", "--warmup", "1"],
+                          {"PGNN_BENCH_STUB": "1", "OMP_NUM_THREADS": "1"},
+                          timeout=480)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len(lines) == 1
+    r = lines[0]
+    assert r["n_gpus"] == 8 and r["steps"] == 4 and r["warmup"] == 1
+    assert r["config"]["distributed"] == {"world_size": 8, "backend": "gloo"}
+    assert r["config"]["frames_per_gpu_per_step"] == 8
+    assert r["config"]["frames_timed"] == 8 * 4 * 8
+    assert r["scaling"] == "weak" and r["higher_is_better"] is True
+    assert abs(r["value"] - 8 * 4 * 8 / (r["ms_per_step"] * 4e-3)) \
+        < 1e-6 * r["value"]
+
+
+def test_bench_rank_binding_on_a_faked_eight_gpu_node(tmp_path, monkeypatch):
+    """bench.bind_rank_to_numa on a faked /sys tree: 8 GPUs, four per NUMA
+    node, each node listing half of the allowed CPUs -> 8 disjoint CPU sets,
+    every rank inside its GPU's node, the node's CPUs split over its four
+    ranks."""
+    import bench
+    allowed = sorted(os.sched_getaffinity(0))
+    if len(allowed) < 8:
+        pytest.skip("fewer than 8 CPUs")
+    half = len(allowed) // 2
+    nodes = {0: allowed[:half], 1: allowed[half:]}
+    sys_root = tmp_path / "sys"
+    for node, cpus in nodes.items():
+        d = sys_root / "devices" / "system" / "node" / ("node%d" % node)
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(",".join(str(c) for c in cpus) + "\n")
+    bus_of = {r: 0x10 + 0x11 * r for r in range(8)}
+    for r in range(8):
+        d = sys_root / "bus" / "pci" / "devices" / ("0000:%02x:00.0" % bus_of[r])
+        d.mkdir(parents=True)
+        (d / "numa_node").write_text("%d\n" % (r // 4))
+    monkeypatch.setattr(bench, "SYS_ROOT", str(sys_root))
+
+    class _Prop(object):
+        def __init__(self, r):
+            self.pci_domain_id, self.pci_bus_id, self.pci_device_id = \
+                0, bus_of[r], 0
+
+    class _Eight(object):
+        class cuda(object):
+            @staticmethod
+            def get_device_properties(i):
+                return _Prop(i)
+    before = os.sched_getaffinity(0)
+    try:
+        seen = []
+        for r in range(8):
+            os.sched_setaffinity(0, before)
+            info = bench.bind_rank_to_numa(_Eight, r, 8)
+            assert info["bound"] and info["numa_node"] == r // 4, info
+            got = os.sched_getaffinity(0)
+            assert got and got <= set(nodes[r // 4])
+            assert len(got) == info["n_cpus"]
+            seen.append(got)
+        for i in range(8):
+            for j in range(i + 1, 8):
+                assert not (seen[i] & seen[j]), (i, j)
+        assert set().union(*seen[:4]) == set(nodes[0])
+        assert set().union(*seen[4:]) == set(nodes[1])
     finally:
         os.sched_setaffinity(0, before)
 
