@@ -212,6 +212,10 @@ struct StageDev {
 
 struct Trainer {
   pgnn_train_model m;
+  // the `train_h1` tunable as the most recent pgnn_trainer_forward saw it: the
+  // backward of that step reads (or not) the H1 rows the forward wrote (or
+  // not), whatever the tunable says by then
+  int h1 = 1;
   std::vector<StageDev> stages;
   FcDev cls[2];
   std::vector<FcDev> loc;  // 3 per class
@@ -486,14 +490,16 @@ int fc_dx(Ctx &c, const FcDev &f, const float *dy, int64_t lddy, int64_t rows,
   L.k_in = f.ref.n_out;
   L.n_out = f.ref.k_in;
   L.relu_from = f.ref.k_in;  // linear
-  if (gate && ld_gate >= pad16(f.ref.k_in))
+  if (gate) {
+    // (every caller's gate has the padded rows of the layer's input; a
+    // narrower one would need an ld-aware mask)
+    PGNN_REQUIRE(ld_gate >= pad16(f.ref.k_in), PGNN_E_INVALID,
+                 "fc_dx: gate rows narrower than the padded input width");
     return mlp_rows_gated(dy, lddy, f.ref.n_out, rows, &L, gate, ld_gate, dx,
                           pad16(f.ref.k_in), c.stream);
-  int rc = pgnn_mlp_fwd(dy, lddy, f.ref.n_out, nullptr, 0, 0, rows, &L, 1, nullptr,
-                        0, dx, pad16(f.ref.k_in), c.stream);
-  if (rc == 0 && gate)  // (a gate narrower than the padded rows: two launches)
-    rc = pgnn_relu_mask_mul(dx, gate, rows * pad16(f.ref.k_in), c.stream);
-  return rc;
+  }
+  return pgnn_mlp_fwd(dy, lddy, f.ref.n_out, nullptr, 0, 0, rows, &L, 1, nullptr,
+                      0, dx, pad16(f.ref.k_in), c.stream);
 }
 
 // record dW/db = (x^T dy, column sums) for the end of the backward; x and dy
@@ -875,7 +881,7 @@ int forward_impl(Ctx &c, Saved &sv) {
           rc = pgnn_edge_mlp_scatter_max_rows_fwd(
               g.p, g.q, wq, s.a[1].ref.k_in, b.edges[lvl], E, (int32_t)K, &L2,
               b.edges_sorted[lvl] ? 1 : 0, g.agg, wa, g.eact[1], wa,
-              g_train_h1 ? g.eact[0] : nullptr, c.stream);
+              c.t.h1 ? g.eact[0] : nullptr, c.stream);
           if (rc == 0) fused = true;
           else if (rc != PGNN_E_UNSUPPORTED) return rc;
         }
@@ -1219,7 +1225,7 @@ int backward_impl(Ctx &c, Saved &sv, const float *dlogits, const float *dpred) {
           // routing pass: dP / dQ directly, dH1 is never written
           rc = pgnn_edge_segmax_fc_bwd_f32(
               g.eact[1], wa, b.edges[lvl], g.dst, E, s.a[1].ref.n_out,
-              (int32_t)Ks, g.agg, wa, dagg, wa, g_train_h1 ? g.eact[0] : nullptr,
+              (int32_t)Ks, g.agg, wa, dagg, wa, c.t.h1 ? g.eact[0] : nullptr,
               wq, g.p, g.q,
               s.a[1].ref.k_in, s.a[1].wt, pad16(s.a[1].ref.k_in), dp, dq, wq,
               s.a[1].gw, s.a[1].gb, sv.scratch, sv.scratch_bytes, c.stream);
@@ -1708,6 +1714,7 @@ extern "C" int pgnn_trainer_forward(void *handle, const pgnn_train_batch *batch,
   Bump ws(workspace, workspace_bytes);
   Saved sv;
   memset(&sv, 0, sizeof sv);
+  t->h1 = g_train_h1 ? 1 : 0;
   Ctx c{*t, *batch, ws, (hipStream_t)stream_, false};
   rc = forward_impl(c, sv);
   if (rc) return rc;

@@ -135,6 +135,7 @@ class _State(threading.local):
         self.scope = []
         self.fuse = False      # fuse_vertex_stages() active
         self.pending = None    # an operator's deferred per-vertex tail
+        self.taken = None      # ... taken over by its consumer, not launched yet
 
 
 _state = _State()
@@ -199,21 +200,32 @@ def fuse_vertex_stages(enabled=True):
 
 
 def _flush_pending():
-    p, _state.pending = _state.pending, None
-    if p is not None:
-        mlp_forward(p.chain, p.x, p.nx, residual=p.residual, count=p.count,
-                    out=p.y)
+    """Launches, on its own, whatever tail has not run yet: the parked one and
+    one an operator took (`_take_pending`) but did not get to launch -- it
+    raised in between; its output tensor is already in the caller's hands."""
+    for slot in ('taken', 'pending'):
+        p = getattr(_state, slot)
+        setattr(_state, slot, None)
+        if p is not None:
+            mlp_forward(p.chain, p.x, p.nx, residual=p.residual, count=p.count,
+                        out=p.y)
 
 
 def _take_pending(t):
     """The deferred tail whose output IS `t` (else None, after launching
-    whatever was pending on its own)."""
+    whatever was pending on its own).  The taker calls `_tail_launched()` once
+    the tail has run (inside its own launch or separately)."""
     p = _state.pending
-    if p is not None and p.y is t:
+    if p is not None and p.y is t and _state.taken is None:
         _state.pending = None
+        _state.taken = p
         return p
     _flush_pending()
     return None
+
+
+def _tail_launched():
+    _state.taken = None
 
 
 def _finish_rows(chain, x, nx, residual=None, count=None):
@@ -348,6 +360,7 @@ def graph_scatter_max_fn(point_features, point_centers, num_centers,
                          ids_sorted=False):
     """gnn.py:106-109 = tf.math.unsorted_segment_max.  Standalone kernel
     (csrc/scatter_max.hip); the layers below use the fused epilogue instead."""
+    _flush_pending()   # (a deferred tail may be what writes point_features)
     lib = _lib.load()
     data = _as_f32(point_features)
     ids = _as_i32(point_centers.reshape(-1))
@@ -362,6 +375,7 @@ def graph_scatter_max_fn(point_features, point_centers, num_centers,
 
 
 def _scatter_sum(point_features, point_centers, num_centers, mean):
+    _flush_pending()   # (a deferred tail may be what writes point_features)
     lib = _lib.load()
     data = _as_f32(point_features)
     ids = _as_i32(point_centers.reshape(-1))
@@ -496,6 +510,10 @@ class PointSetPooling(object):
                 out_chain = _relu_chain(store, _scope(),
                                         list(output_MLP_depth_list), False)
             return _finish_rows(out_chain, agg, point_chain.n_out)
+        if int(feats.shape[1]) != n_feat or feats.stride(0) != n_feat:
+            # the fused kernel gathers feat[s * n_feat + i]: a narrow level
+            # above the first hands over zero-padded [N, 16] rows
+            feats = feats[:, :n_feat].contiguous()
         agg = torch.empty((k, padded_width(point_chain.n_out)),
                           dtype=torch.float32, device=xyz.device)
         args = (_lib.ptr(feats), n_feat, _lib.ptr(xyz), _lib.ptr(kp),
@@ -643,11 +661,11 @@ class GraphNetAutoCenter(object):
             if rc == _lib.E_UNSUPPORTED:
                 # too many rows / too wide for the one-launch form: the
                 # producer's tail on its own, then the plain head below
-                mlp_forward(pend.chain, pend.x, pend.nx, residual=res,
-                            count=pend.count, out=pend.y)
+                _flush_pending()
                 pend = None
             else:
                 _lib.check(rc, "pgnn_vertex_update_pre_edge_fwd")
+                _tail_launched()
         if pend is not None:
             pass
         elif cnt_k is None:
@@ -740,7 +758,11 @@ class ClassAwarePredictor(object):
                       normalization_type='fused_BN_center',
                       activation_type='ReLU'):
         """features [K, >=C] -> (logits [K, num_classes], box_encodings
-        [K, num_classes, box_encoding_len])."""
+        [K, num_classes, box_encoding_len]).  With one fused head group (every
+        shipped config) both results are strided VIEWS of the chain's output
+        rows -- box_encodings is [K, nc, 8][:, :, :bl], not contiguous, and
+        shares storage with logits: call .contiguous() before handing a data
+        pointer on or reshaping with .view()."""
         _check_kinds(activation_type, normalization_type)
         pend = _take_pending(features)
         store = _store()
@@ -814,9 +836,9 @@ class ClassAwarePredictor(object):
                 # in one launch (pgnn_mlp2_fwd); it writes f as well
                 y = self._fused_heads(pend, f, c, chain, cnt)
                 if y is None:
-                    mlp_forward(pend.chain, pend.x, pend.nx,
-                                residual=pend.residual, count=pend.count,
-                                out=pend.y)
+                    _flush_pending()
+                else:
+                    _tail_launched()
                 pend = None
             if y is None:
                 y = mlp_forward(chain, f, c, count=cnt)

@@ -17,9 +17,11 @@ LEVEL_CONFIGS = [
 ]
 
 
-def model_config(num_classes=4):
+def model_config(num_classes=4, first_width=300):
     """A model on that graph: PointSetPooling at levels 0 AND 1, one
-    GraphNetAutoCenter iteration at level 2, the class-aware predictor."""
+    GraphNetAutoCenter iteration at level 2, the class-aware predictor.
+    `first_width`: output width of the first pooling level (8: the second level
+    then takes the fused narrow-feature kernel, on zero-padded [K, 16] rows)."""
     def pooling(level, scope, point_mlp, out_mlp):
         return {"graph_level": level, "scope": scope,
                 "type": "scatter_max_point_set_pooling",
@@ -47,8 +49,8 @@ def model_config(num_classes=4):
         "num_classes": num_classes,
         "model_name": "multi_layer_fast_local_graph_model_v2",
         "model_kwargs": {
-            "layer_configs": [pooling(0, "layer1", [32, 64, 128, 300],
-                                      [300, 300]),
+            "layer_configs": [pooling(0, "layer1", [32, 64, 128, first_width],
+                                      [first_width, first_width]),
                               pooling(1, "layer2", [300, 300], [300, 300]),
                               gnn, head],
             "regularizer_kwargs": {"scale": 5e-07}, "regularizer_type": "l1"},

@@ -222,16 +222,18 @@ def test_far_search_set_falls_back_to_every_point(dev):
     assert np.array_equal(np.sort(i.cpu().numpy()[:, 0]), np.sort(ref_i[:, 0]))
 
 
-def test_predict_on_two_pooling_levels(dev):
+@pytest.mark.parametrize("first_width", [300, 8])
+def test_predict_on_two_pooling_levels(dev, first_width):
     """MultiLayerFastLocalGraphModelV2.predict (models.py:79-163) on that
     graph: PointSetPooling at levels 0 AND 1 (the second one pools 300-wide
-    features), one GraphNetAutoCenter iteration, the predictor -- against the
-    float64 oracle, per layer."""
+    features -- or 8-wide ones, through the fused narrow-feature kernel on the
+    first level's zero-padded [K, 16] rows), one GraphNetAutoCenter iteration,
+    the predictor -- against the float64 oracle, per layer."""
     from pointgnn_amd import graph_gen, models, weights
     g = gold()
     xyz = g["small_xyz"]
     _, inten = synthetic_cloud(seed=0, preset="small")
-    cfg = model_config()
+    cfg = model_config(first_width=first_width)
     params = weights.init_params(cfg, seed=2, bias_scale=0.05)
     coords, kps, edges = graph_gen.gen_multi_level_local_graph_v3(
         T(xyz, dev), BASE_VOXEL, LEVEL_CONFIGS, downsample_method='center')
