@@ -155,6 +155,72 @@ def live_pmc_scatter(preset, timeout_s=150):
     }
 
 
+def live_pmc_train_mfma_ops(config, preset, fpg, frames=8, steps=6, warmup=2,
+                            timeout_s=240):
+    """fp32-MFMA work of ONE training step measured in this run: a child
+    `rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F32` replays
+    `bench.py --train` (prebuilt batches: the graph build has no MFMA) for
+    steps + warmup steps; FLOPs = sum of the counter over every dispatch x 512
+    / steps run (one count = 512 FLOP: 2 * 304^2 * E of the edge kernel comes
+    out exactly, profiles/r04_pmc_sq_car_600k.txt).  Returns a dict or None
+    (rocprofv3 missing / failed / timed out)."""
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None
+    tmp = tempfile.mkdtemp(prefix="pgnn_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    counter = "SQ_INSTS_VALU_MFMA_MOPS_F32"
+    try:
+        p = subprocess.run(
+            [rocprof, "--kernel-trace", "--pmc", counter, "-d", tmp, "-o",
+             "pmc", "--", sys.executable, os.path.abspath(__file__), "--train",
+             "--config", config, "--preset", preset, "--frames-per-gpu",
+             str(fpg), "--frames", str(frames), "--steps", str(steps),
+             "--warmup", str(warmup), "--train-loader", "prebuilt",
+             "--no-live-pmc", "--no-bind"],
+            cwd="/tmp", env=env, capture_output=True, text=True,
+            timeout=timeout_s)
+        db = None
+        for root, _, files in os.walk(tmp):
+            for f in files:
+                if f.endswith(".db"):
+                    db = os.path.join(root, f)
+        if p.returncode != 0 or db is None:
+            return None
+        con = sqlite3.connect(db)
+        total, n_disp = con.execute(
+            "select sum(value), count(distinct dispatch_id) from "
+            "counters_collection where counter_name = ?", (counter,)).fetchone()
+        top = con.execute(
+            "select kernel_name, sum(value) from counters_collection where "
+            "counter_name = ? group by kernel_name order by 2 desc limit 6",
+            (counter,)).fetchall()
+        con.close()
+        if not total:
+            return None
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    n = steps + warmup
+    short = lambda k: k.replace("(anonymous namespace)::", "").replace(  # noqa: E731
+        "pgnn::", "").split("(")[0][:60]
+    return {
+        "counter": counter, "steps_profiled": n, "dispatches": int(n_disp),
+        "mfma_flops_per_step": float(total) * 512.0 / n,
+        "by_kernel_gflop_per_step": {short(k): float(v) * 512.0 / n / 1e9
+                                     for k, v in top},
+        "method": "child run of `bench.py --train --train-loader prebuilt` "
+                  "under rocprofv3 --kernel-trace --pmc %s taken by this "
+                  "bench.py invocation; FLOPs = sum over all dispatches x 512 "
+                  "/ %d steps" % (counter, n),
+    }
+
+
 def roofline_scatter_max(torch, edges1, n_k, width, reps=30, live_pmc=None):
     """Standalone scatter-max on an [E1, C] fp32 matrix resident in HBM, dst
     ids of the real level-1 graph (sorted).  Algorithmic bytes per launch =
@@ -627,31 +693,55 @@ def train_measure(torch, dev, rank, world, dist, config_name, preset, steps,
     return elapsed, ar_ms, tr, cfg, list(shapes), out
 
 
-def train_roofline(cfg, shapes, fpg, elapsed, steps):
-    """Whole-step MFMA roofline of the training step.  Algorithmic FLOPs per
-    step = 3 x the forward's algorithmic FLOPs (SURVEY 8d's per-row figures;
-    backward = dX and dW GEMMs of every layer, each the forward's size) at the
-    mean (K, E0, E1) of the timed merged batches; the kernels execute fewer:
-    the first edge layer is evaluated per vertex."""
+def train_roofline(cfg, shapes, fpg, elapsed, steps, live=None):
+    """MFMA roofline of the training step, three ways (peak 157.3 TFLOP/s):
+      frac_equivalent_dense  3 x the forward's ALGORITHMIC FLOPs (SURVEY 8d's
+                             per-row figures; backward = dX and dW GEMMs of
+                             every layer, each the forward's size) / step time:
+                             what a dense, unfactorised implementation would
+                             have to sustain -- not a utilisation;
+      frac_dense_executed    3 x the forward's EXECUTED FLOPs (first edge layer
+                             per vertex) / step time: still dense
+                             (the sparse scatter-max adjoint executes a
+                             fraction of the backward's edge GEMMs);
+      frac_mfma_ops          the fp32-MFMA operations the step's kernels
+                             actually issue (SQ_INSTS_VALU_MFMA_MOPS_F32 x 512
+                             summed over a profiled child run, `live`) / step
+                             time: the utilisation of the matrix pipe.
+    `frac` is the last one when it was measured (else null: the first two are
+    not utilisations)."""
     a = np.asarray(shapes, dtype=np.float64)
     fwd = float(np.mean([algorithmic_flops_per_frame(cfg, *map(int, r))
                          for r in a]))
     exe = float(np.mean([executed_flops_per_frame(cfg, *map(int, r))
                          for r in a]))
     per_step = elapsed / steps
-    return {
+    out = {
         "kernel": "whole training step (forward + loss + backward + SGD)",
-        "bound": "mfma", "achieved": 3 * fwd / per_step / 1e12,
-        "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-        "frac": 3 * fwd / per_step / 1e12 / FP32_MFMA_PEAK_TF,
-        "formula": "3 * algorithmic_forward_flops(K, E0, E1 of the merged "
-                   "%d-frame batch) / step time / 157.3 TFLOP/s" % fpg,
+        "bound": "mfma", "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+        "achieved": None, "frac": None,
+        "frac_equivalent_dense": 3 * fwd / per_step / 1e12 / FP32_MFMA_PEAK_TF,
+        "frac_dense_executed": 3 * exe / per_step / 1e12 / FP32_MFMA_PEAK_TF,
+        "frac_mfma_ops": None,
+        "formula": "frac = frac_mfma_ops = sum(SQ_INSTS_VALU_MFMA_MOPS_F32) x "
+                   "512 per step / step time / 157.3 TFLOP/s; "
+                   "frac_equivalent_dense = 3 x algorithmic_forward_flops(K, "
+                   "E0, E1 of the merged %d-frame batch) / step time / peak; "
+                   "frac_dense_executed likewise on the executed forward" % fpg,
         "algorithmic_forward_gflop": fwd / 1e9,
         "dense_executed_forward_gflop": exe / 1e9,
         "batch_shape_mean": {"K": float(a[:, 0].mean()),
                              "E0": float(a[:, 1].mean()),
                              "E1": float(a[:, 2].mean())},
     }
+    if live is not None:
+        ops = live["mfma_flops_per_step"]
+        out["achieved"] = ops / per_step / 1e12
+        out["frac"] = out["frac_mfma_ops"] = \
+            ops / per_step / 1e12 / FP32_MFMA_PEAK_TF
+        out["mfma_gflop_per_step"] = ops / 1e9
+        out["pmc"] = live
+    return out
 
 
 def run_train(args, torch, dev, rank, world, dist):
@@ -695,8 +785,14 @@ def run_train(args, torch, dev, rank, world, dist):
                                                   'reg_loss')},
                 "parallelism": "dp%d (frames sharded, one flat gradient "
                                "all-reduce per step)" % world},
-            "roofline": train_roofline(cfg, shapes, fpg, elapsed, args.steps),
         }
+        live = None
+        if world == 1 and not args.no_live_pmc:
+            torch.cuda.synchronize()
+            live = live_pmc_train_mfma_ops(args.config, args.preset, fpg,
+                                           frames=args.frames)
+        res["roofline"] = train_roofline(cfg, shapes, fpg, elapsed, args.steps,
+                                         live)
         print(json.dumps(res), flush=True)
 
 
@@ -1166,10 +1262,14 @@ def secondary_train(args, torch, dev):
         "training_frames_per_sec": fpg * steps / elapsed,
         "params": int(tr.flat.numel()),
         "last_loss": {k: out[k] for k in ('cls_loss', 'loc_loss', 'reg_loss')},
-        "roofline": train_roofline(cfg, shapes, fpg, elapsed, steps),
     }
     del tr
     torch.cuda.empty_cache()
+    live = None
+    if not args.no_live_pmc:
+        torch.cuda.synchronize()
+        live = live_pmc_train_mfma_ops("car_auto_T3", "car", fpg, frames=4)
+    res["roofline"] = train_roofline(cfg, shapes, fpg, elapsed, steps, live)
     return res
 
 
