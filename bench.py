@@ -461,7 +461,9 @@ def _host_description():
 
 def cpu_baseline(cfg, params, xyz, inten, budget_s=20.0):
     """The oracle (CPU port of the reference path: scikit-learn ball tree as
-    the reference calls it + NumPy/BLAS GNN) timed on this host with SURVEY
+    the reference calls it + the torch-CPU GNN of oracle/gnn_oracle_torch.py:
+    gather -> GEMM chain -> segment max in cache-sized row chunks, all cores)
+    timed on this host with SURVEY
     8d's protocol: third-party imports before the clock, one warm-up, median
     of 5 for the graph build (single-threaded as the reference ships it,
     graph_gen.py:85,208); the GNN part (BLAS on all cores) is bounded: it runs
@@ -469,8 +471,9 @@ def cpu_baseline(cfg, params, xyz, inten, budget_s=20.0):
     probe so that the whole leg stays near budget_s, one warm-up + median of
     3, scaled by the FLOP fraction."""
     from oracle import graph_oracle as go
-    from oracle import gnn_oracle as gn
+    from oracle import gnn_oracle_torch as gn   # the GEMM-bound host port
     import sklearn.neighbors  # noqa: F401  (imported before the clock starts)
+    import torch as _torch
     host = _host_description()
     kw = cfg['runtime_graph_gen_kwargs']
     coords, kps, edges = go.multi_level_graph(xyz, **kw)      # warm-up
@@ -511,14 +514,15 @@ def cpu_baseline(cfg, params, xyz, inten, budget_s=20.0):
     sub_flops = algorithmic_flops_per_frame(cfg, k_sub, int(m0.sum()),
                                             int(m1.sum()))
     t_gnn_full = t_gnn_sub * total / max(sub_flops, 1)
-    threads = host["blas_threads"]
+    threads = int(_torch.get_num_threads())
     out = {
         "value": 1.0 / (t_graph + t_gnn_full), "unit": "frames/s",
         "cores": int(threads), "kind": "port",
         "sample": "1 frame (%s seed of the headline pool): graph build with "
                   "the reference's sklearn calls, single-threaded as shipped, "
                   "1 warm-up + median of 5 (%.2f s; min %.2f, max %.2f); GNN "
-                  "oracle (NumPy fp32, BLAS threads=%d, %.0f GFLOP/s probe) on "
+                  "oracle (torch-CPU fp32 in 32k-row chunks, %d intra-op "
+                  "threads; NumPy sgemm probe %.0f GFLOP/s) on "
                   "the sub-graph of the first %d of %d keypoints (%.1f%% of "
                   "the frame's FLOPs), 1 warm-up + median of 3 (%.2f s), "
                   "scaled to the full frame (%.1f s)"

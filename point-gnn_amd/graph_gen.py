@@ -108,6 +108,48 @@ class FrameCounts(object):
                 if v[3 + 2 * l] > v[2 + 2 * l]]
 
 
+class _ZeroPool(object):
+    """Zeroed int32 count records for capacity-form frames, handed out from one
+    buffer per device that is zeroed ONCE per `kRecords` frames (a fill launch
+    per frame otherwise: ~4 us of a 2-3 ms frame, and one more node on every
+    frame's dependency chain).  A record is the frame's own until the pool
+    wraps round -- kRecords frames later, behind a device synchronisation; a
+    FrameCounts held longer than that must be read() first."""
+    kRecords, kInts = 4096, 16
+
+    def __init__(self, dev):
+        self.buf = torch.zeros(self.kRecords * self.kInts, dtype=torch.int32,
+                               device=dev)
+        torch.cuda.synchronize(dev)   # records are used on any stream
+        self.next = 0
+
+    def take(self, n_ints):
+        if n_ints > self.kInts:
+            return torch.zeros(n_ints, dtype=torch.int32, device=self.buf.device)
+        if self.next == self.kRecords:
+            torch.cuda.synchronize(self.buf.device)
+            self.buf.zero_()
+            torch.cuda.synchronize(self.buf.device)
+            self.next = 0
+        i = self.next
+        self.next += 1
+        return self.buf[i * self.kInts:i * self.kInts + n_ints]
+
+
+_ZERO_POOLS = {}
+
+
+def _zero_counts(n_ints, dev):
+    # (inside a stream capture the record has to be zeroed by the captured
+    # work itself: every replay reuses it)
+    if torch.cuda.is_current_stream_capturing():
+        return torch.zeros(n_ints, dtype=torch.int32, device=dev)
+    pool = _ZERO_POOLS.get(dev.index)
+    if pool is None:
+        pool = _ZERO_POOLS[dev.index] = _ZeroPool(dev)
+    return pool.take(n_ints)
+
+
 def _device():
     if not torch.cuda.is_available():
         raise _lib.PointGnnHipError(
@@ -730,7 +772,7 @@ def _multi_level_graph_deferred(points_xyz, base_voxel_size, level_configs,
                 "or another generator have no capacity form")
     n_levels = len(level_configs)
     dev = _device()
-    counts = torch.zeros(2 + 2 * n_levels, dtype=torch.int32, device=dev)
+    counts = _zero_counts(2 + 2 * n_levels, dev)
     caps = [hints.cap(l) for l in range(n_levels)]
     frame = FrameCounts(counts, caps)
 

@@ -431,3 +431,29 @@ def test_multi_level_pooling_golden_is_the_reference_live():
     for l in range(3):
         assert np.array_equal(np.asarray(ki[l]), g["tiny_center_kp%d" % l])
         assert np.array_equal(np.asarray(el[l]), g["tiny_center_edges%d" % l])
+
+
+def test_torch_cpu_port_equals_the_numpy_oracle():
+    """oracle/gnn_oracle_torch.py (what bench.py's cpu_baseline times: the same
+    arithmetic in cache-sized row chunks on torch-CPU) against
+    gnn_oracle.predict on the reference-built tiny graph, car and ped shapes."""
+    from oracle import gnn_oracle as gn, gnn_oracle_torch as gt
+    from pointgnn_amd import configs, weights
+    g = dict(np.load(os.path.join(GOLD, "graph_tiny.npz")))
+    k = g["kp_xyz"].shape[0]
+    coords = [g["xyz"], g["kp_xyz"], g["kp_xyz"]]
+    kps = [g["kp_idx"], np.arange(k, dtype=np.int32).reshape(-1, 1)]
+    edges = [g["ref_edges0"], g["ref_edges1"]]
+    old = gt.CHUNK_ROWS
+    try:
+        for name, chunk in (("car_auto_T3", 1 << 15), ("car_auto_T2", 257),
+                            ("ped_cyl_auto_T3", 1000)):
+            gt.CHUNK_ROWS = chunk      # runs cut by chunk boundaries too
+            cfg = configs.get_config(name)
+            params = weights.init_params(cfg, seed=5, bias_scale=0.05)
+            l0, b0 = gn.predict(params, cfg, g["intensity"], coords, kps, edges)
+            l1, b1 = gt.predict(params, cfg, g["intensity"], coords, kps, edges)
+            np.testing.assert_allclose(l1, l0, atol=2e-5, rtol=0)
+            np.testing.assert_allclose(b1, b0, atol=2e-5, rtol=0)
+    finally:
+        gt.CHUNK_ROWS = old

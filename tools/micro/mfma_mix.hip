@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v16f __attribute__((ext_vector_type(16)));
@@ -45,7 +46,8 @@ __device__ __forceinline__ void filler(float (&x)[8], v2f (&y)[4], v4u (&z)[2],
   if constexpr (OP == NOPS) asm volatile("s_nop 0");
 }
 
-// MF: 0 = 16x16x32 bf16 (16 cycles), 1 = 32x32x16 bf16 (32 cycles)
+// MF: 0 = 16x16x32 bf16 (16 cycles), 1 = 32x32x16 bf16 (32 cycles),
+// 2 = 16x16x16 bf16 (the CDNA3 shape: half the K of MF 0 -- half the time?)
 template <int OP, int K, int MF>
 __global__ __launch_bounds__(512) void mix(long long *cyc, float *out, int iters,
                                           float seed, const v4u *glob) {
@@ -59,6 +61,8 @@ __global__ __launch_bounds__(512) void mix(long long *cyc, float *out, int iters
 #pragma unroll
     for (int r = 0; r < 16; ++r) big[i][r] = 0.f;
   v4u a = {threadIdx.x, 1u, 2u, 3u}, b = {5u, threadIdx.x, 7u, 8u};
+  typedef u32 v2u __attribute__((ext_vector_type(2)));
+  v2u a2 = {threadIdx.x, 1u}, b2 = {5u, threadIdx.x};
   float x[8];
   v2f y[4];
   v4u z[2] = {a, b};
@@ -75,6 +79,8 @@ __global__ __launch_bounds__(512) void mix(long long *cyc, float *out, int iters
     for (int m = 0; m < 10; ++m) {
       if constexpr (MF == 0)
         asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[m % 5]) : "v"(a), "v"(b));
+      else if constexpr (MF == 2)
+        asm volatile("v_mfma_f32_16x16x16_bf16 %0, %1, %2, %0" : "+v"(acc[m % 5]) : "v"(a2), "v"(b2));
       else
         asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(big[m % 2]) : "v"(a), "v"(b));
 #pragma unroll
@@ -142,7 +148,7 @@ void row() {
 template <int MF>
 void table() {
   printf("%s: cycles per (MFMA + K fillers); left: 1 wave/SIMD (per wave), right: 2 waves/SIMD (per SIMD = per wave / 2)\n",
-         MF == 0 ? "v_mfma_f32_16x16x32_bf16" : "v_mfma_f32_32x32x16_bf16");
+         MF == 0 ? "v_mfma_f32_16x16x32_bf16" : MF == 1 ? "v_mfma_f32_32x32x16_bf16" : "v_mfma_f32_16x16x16_bf16");
   printf("%-30s |    K=0      1      2      3      4 |    K=0      1      2      3      4\n", "filler");
   row<SUB, MF>(); row<DEPSUB, MF>(); row<MED3, MF>(); row<PERM, MF>(); row<AND, MF>();
   row<PKADD, MF>(); row<PKMUL, MF>(); row<CVTBF, MF>(); row<CVTF16, MF>(); row<FMAMIX, MF>();
@@ -154,6 +160,13 @@ int main() {
   hipMalloc(&g_out, 4);
   hipMalloc(&g_glob, 64 * 8 * 16 + 4096);
   hipMemset(g_glob, 0, 64 * 8 * 16 + 4096);
+  if (getenv("MFMA_MIX_ONLY16")) {
+    printf("v_mfma_f32_16x16x16_bf16 (K = 0 fillers, K = 2 v_sub): 1 wave %.1f %.1f | 2 waves %.1f %.1f\n",
+           run<SUB, 0, 2>(1), run<SUB, 2, 2>(1), run<SUB, 0, 2>(2) / 2, run<SUB, 2, 2>(2) / 2);
+    printf("v_mfma_f32_16x16x32_bf16 (same):                            1 wave %.1f %.1f | 2 waves %.1f %.1f\n",
+           run<SUB, 0, 0>(1), run<SUB, 2, 0>(1), run<SUB, 0, 0>(2) / 2, run<SUB, 2, 0>(2) / 2);
+    return 0;
+  }
   table<0>();
   table<1>();
   return 0;
