@@ -493,7 +493,25 @@ __device__ __forceinline__ float xr_at(const XRow &r, int k) {
 // is grouped by dst, so the dQ sum of a run stays in registers and is flushed
 // with one row of atomics per run instead of one per edge; dP rows are atomic
 // adds (src is unordered).
+//
+// Round 5: what bounds it is L2 -> L1 traffic, not arithmetic (0.36 GFLOP per
+// launch) and not latency: every winner (segment, column) pulls one row of
+// W^T (1.2 KB) from L2 -- K C rows = 730 MB per launch at the training step's
+// shape, beside 128 MB of Y and ~600 MB of per-row P / Q / out / grad / count
+// slices: ~1.5 GB in 160 us = 9 TB/s of gathered 1.2 KB rows.  The traffic is
+// inherent to the routed form (each column's gradient goes to ANOTHER row with
+// its own gate: nothing accumulates across columns, so there is no GEMM to tile
+// W^T for); the dense adjoint it replaces is 18x the FLOPs.  Tried: the chunk's
+// index pairs in one load, row r + 1's slices requested before row r is worked
+// on, a row's winners of ALL column groups compacted into a per-wave list in
+// LDS and taken kWinBatch at a time (one round trip for up to eight W^T rows
+// instead of one per pair and column group): 164.8 -> 159.8 us
+// (tools/sessions/r05_s10.sh) -- kept, for what it is.
 constexpr int kScatterChunk = 16;
+#ifndef PGNN_WIN_BATCH
+#define PGNN_WIN_BATCH 8
+#endif
+constexpr int kWinBatch = PGNN_WIN_BATCH;
 template <int J, int I>
 __global__ __launch_bounds__(256) void segmax_route_scatter_kernel(
     const float *__restrict__ data, int64_t ld, const int32_t *__restrict__ edges,
@@ -501,84 +519,105 @@ __global__ __launch_bounds__(256) void segmax_route_scatter_kernel(
     const float *__restrict__ gout, int64_t ldg, const int32_t *__restrict__ cnt,
     int ldc, const float *__restrict__ WT, int64_t ldwt, int k_in, XSrc xs,
     float *__restrict__ dP, float *__restrict__ dQ, int64_t ldpq) {
+  __shared__ float s_g[4][64 * J];
+  __shared__ int s_c[4][64 * J];
   const int lane = threadIdx.x & 63;
+  float *wg = s_g[threadIdx.x >> 6];
+  int *wc = s_c[threadIdx.x >> 6];
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  int kc[I];
+  int kc[I], cj[J];
 #pragma unroll
   for (int i = 0; i < I; ++i) kc[i] = min(lane + 64 * i, k_in - 1);
+#pragma unroll
+  for (int j = 0; j < J; ++j) cj[j] = min(lane + 64 * j, cols - 1);
+  struct RowIn {
+    float d[J], o[J], go[J], xa[I], xb[I];
+    int cn[J];
+    int src, s, ok;
+  };
   const int64_t n_chunks = (rows + kScatterChunk - 1) / kScatterChunk;
   for (int64_t ch = wave; ch < n_chunks; ch += n_waves) {
     const int64_t r0 = ch * kScatterChunk;
     const int64_t r1 = min(r0 + (int64_t)kScatterChunk, rows);
+    // lane i: (src, dst) of row r0 + i
+    int my_src = 0, my_dst = -1;
+    if (lane < kScatterChunk && r0 + lane < r1) {
+      my_src = edges[2 * (r0 + lane)];
+      my_dst = edges[2 * (r0 + lane) + 1];
+    }
+    auto fetch = [&](int64_t r, RowIn &in) {
+      const int i = (int)(r - r0);
+      const int src = __builtin_amdgcn_readlane(my_src, i);
+      const int s_raw = __builtin_amdgcn_readlane(my_dst, i);
+      in.ok = (s_raw >= 0 && s_raw < nseg && src >= 0 && src < nseg) ? 1 : 0;
+      in.src = src;
+      in.s = in.ok ? s_raw : 0;
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        in.d[j] = data[r * ld + cj[j]];
+        in.o[j] = out[(int64_t)in.s * ldo + cj[j]];
+        in.go[j] = gout[(int64_t)in.s * ldg + cj[j]];
+        in.cn[j] = cnt[(int64_t)in.s * ldc + cj[j]];
+      }
+      if (xs.X) {
+        const float *xa = xs.X + r * xs.ldx;
+#pragma unroll
+        for (int i2 = 0; i2 < I; ++i2) in.xa[i2] = xa[kc[i2]], in.xb[i2] = 0.0f;
+      } else {
+        const float *xa = xs.P + (int64_t)(in.ok ? src : 0) * xs.ldpq;
+        const float *xb = xs.Q + (int64_t)in.s * xs.ldpq;
+#pragma unroll
+        for (int i2 = 0; i2 < I; ++i2) in.xa[i2] = xa[kc[i2]], in.xb[i2] = xb[kc[i2]];
+      }
+    };
     float qacc[I];
 #pragma unroll
     for (int i = 0; i < I; ++i) qacc[i] = 0.0f;
     int q_dst = -1;
+    RowIn cur;
+    fetch(r0, cur);
     for (int64_t r = r0; r < r1; ++r) {
-      const int src = edges[2 * r], s_raw = edges[2 * r + 1];
-      const bool s_ok = s_raw >= 0 && s_raw < nseg && src >= 0 && src < nseg;
-      const int s = s_ok ? s_raw : 0;
-      float d[J], o[J], go[J], xv[I];
-      int cn[J];
+      RowIn nxt = cur;
+      if (r + 1 < r1) fetch(r + 1, nxt);  // in flight while this row is worked on
+      // the row's winning columns, all groups, compacted: (column, g)
+      int n_win = 0;
 #pragma unroll
       for (int j = 0; j < J; ++j) {
-        const int cc = min(lane + 64 * j, cols - 1);
-        d[j] = data[r * ld + cc];
-        o[j] = out[(int64_t)s * ldo + cc];
-        go[j] = gout[(int64_t)s * ldg + cc];
-        cn[j] = cnt[(int64_t)s * ldc + cc];
-      }
-      {
-        // (src, dst are in hand: resolve the row without xs_row's index loads)
-        XRow xr;
-        if (xs.X) {
-          xr.a = xs.X + r * xs.ldx;
-          xr.b = nullptr;
-        } else {
-          xr.a = xs.P + (int64_t)(s_ok ? src : 0) * xs.ldpq;
-          xr.b = xs.Q + (int64_t)s * xs.ldpq;
+        const bool w = cur.ok && (lane + 64 * j) < cols && cur.d[j] > 0.0f &&
+                       cur.d[j] == cur.o[j];
+        const float g = w ? cur.go[j] / (float)max(cur.cn[j], 1) : 0.0f;
+        const unsigned long long m = __ballot(g != 0.0f);
+        if (g != 0.0f) {
+          const int pos = n_win + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+          wg[pos] = g;
+          wc[pos] = lane + 64 * j;
         }
-#pragma unroll
-        for (int i = 0; i < I; ++i) xv[i] = xr_at(xr, kc[i]);
+        n_win += __builtin_popcountll(m);
       }
-      float g[J];
-#pragma unroll
-      for (int j = 0; j < J; ++j) {
-        const bool w = s_ok && (lane + 64 * j) < cols && d[j] > 0.0f && d[j] == o[j];
-        g[j] = w ? go[j] / (float)max(cn[j], 1) : 0.0f;
-      }
+      // (one wave: its LDS operations execute in order; the compiler must not
+      // move the reads below above the writes)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       float acc[I];
 #pragma unroll
       for (int i = 0; i < I; ++i) acc[i] = 0.0f;
-      bool any = false;
+      for (int b = 0; b < n_win; b += kWinBatch) {  // wave-uniform
+        float gv[kWinBatch], a[kWinBatch][I];
 #pragma unroll
-      for (int j = 0; j < J; ++j) {
-        unsigned long long m = __ballot(g[j] != 0.0f);
-        any = any || m != 0ull;
-        while (m) {
-          const int l0 = __builtin_ctzll(m);
-          m &= m - 1;
-          const int l1 = m ? __builtin_ctzll(m) : l0;
-          const float g0 = __shfl(g[j], l0);
-          const float g1 = m ? __shfl(g[j], l1) : 0.0f;
-          m &= m - 1;
-          const float *w0 = WT + (int64_t)(l0 + 64 * j) * ldwt;
-          const float *w1 = WT + (int64_t)(l1 + 64 * j) * ldwt;
-          float a0[I], a1[I];
+        for (int u = 0; u < kWinBatch; ++u) {
+          const int idx = b + u < n_win ? b + u : n_win - 1;
+          gv[u] = b + u < n_win ? wg[idx] : 0.0f;
+          const float *wr = WT + (int64_t)wc[idx] * ldwt;
 #pragma unroll
-          for (int i = 0; i < I; ++i) {
-            a0[i] = w0[kc[i]];
-            a1[i] = w1[kc[i]];
-          }
-#pragma unroll
-          for (int i = 0; i < I; ++i) {
-            acc[i] += g0 * a0[i];
-            acc[i] += g1 * a1[i];
-          }
+          for (int i = 0; i < I; ++i) a[u][i] = wr[kc[i]];
         }
+#pragma unroll
+        for (int u = 0; u < kWinBatch; ++u)
+#pragma unroll
+          for (int i = 0; i < I; ++i) acc[i] += gv[u] * a[u][i];
       }
-      if (s != q_dst) {  // wave-uniform: the dst run ended
+      asm volatile("" ::: "memory");  // the list is rewritten by the next row
+      if (cur.s != q_dst) {  // wave-uniform: the dst run ended
         if (q_dst >= 0) {
 #pragma unroll
           for (int i = 0; i < I; ++i) {
@@ -588,19 +627,22 @@ __global__ __launch_bounds__(256) void segmax_route_scatter_kernel(
             qacc[i] = 0.0f;
           }
         }
-        q_dst = s;
+        q_dst = cur.s;
       }
-      if (any) {  // wave-uniform
+      if (n_win > 0) {  // wave-uniform
 #pragma unroll
         for (int i = 0; i < I; ++i) {
           const int k = lane + 64 * i;
-          const float v = (k < k_in && xv[i] > 0.0f) ? acc[i] : 0.0f;
+          // x = ReLU(a - b) (b = 0 for materialised rows): the gate is x > 0
+          const float x = cur.xa[i] - cur.xb[i];
+          const float v = (k < k_in && x > 0.0f) ? acc[i] : 0.0f;
           if (v != 0.0f) {
-            atomicAdd(&dP[(int64_t)src * ldpq + k], v);
+            atomicAdd(&dP[(int64_t)cur.src * ldpq + k], v);
             qacc[i] += v;
           }
         }
       }
+      cur = nxt;
     }
     if (q_dst >= 0) {
 #pragma unroll
