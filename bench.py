@@ -339,14 +339,16 @@ def roofline_edge_kernel(torch, engine, edges1, n_k, reps=10, frame=None):
     }
 
 
-def roofline_edge_kernel_bf16x3(torch, engine, edges1, n_k, reps=10, frame=None):
-    """The split-bf16 form of the fused edge kernel (csrc/edge_ws_bf16.h)
-    against ITS bound: the bf16 matrix pipe at six MFMAs per product."""
+def roofline_edge_kernel_16bit(torch, engine, edges1, n_k, arith, reps=10,
+                               frame=None):
+    """The 16-bit matrix-pipe forms of the fused edge kernel
+    (csrc/edge_ws_bf16.h: 'bf16x3', csrc/edge_ws_f16.h: 'f16x2') against THEIR
+    bound: the bf16 / fp16 matrix pipe at six / three MFMAs per product."""
     from pointgnn_amd import _lib, gnn
     lib = _lib.load()
     store = engine.model._store
     key = [k for k in store._cache if k[0] == 'edge']
-    img = [k for k in store._cache if k[0] == 'edge_bf16x3']
+    img = [k for k in store._cache if k[0] == 'edge_' + arith]
     if not key or not img or frame is None:
         return None
     c, p_chain, wx_dev, rest = store._cache[key[0]]
@@ -360,29 +362,39 @@ def roofline_edge_kernel_bf16x3(torch, engine, edges1, n_k, reps=10, frame=None)
     agg = torch.full((n_k, gnn.padded_width(rest.n_out)),
                      float(np.finfo(np.float32).min), device=dev)
     n_e = int(edges1.shape[0])
+    head = (_lib.ptr(p), _lib.ptr(q), wq, int(rest.k_in), _lib.ptr(edges1),
+            n_e, n_k, _lib.ptr(image), int(rest.n_out),
+            int(rest.array[0].relu_from), 1 | 2, _lib.ptr(agg), agg.stride(0))
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
 
     def run():
-        _lib.check(lib.pgnn_edge_mlp_scatter_max_bf16x3_fwd(
-            _lib.ptr(p), _lib.ptr(q), wq, int(rest.k_in), _lib.ptr(edges1),
-            n_e, n_k, _lib.ptr(image), int(rest.n_out),
-            int(rest.array[0].relu_from), 1 | 2, _lib.ptr(agg), agg.stride(0),
-            None, None, _lib.stream_ptr()), "bf16x3 edge kernel")
+        if arith == "bf16x3":
+            rc = lib.pgnn_edge_mlp_scatter_max_bf16x3_fwd(
+                *head, None, None, _lib.stream_ptr())
+        else:
+            rc = lib.pgnn_edge_mlp_scatter_max_f16x2_fwd(
+                *head, _lib.ptr(status), None, None, _lib.stream_ptr())
+        _lib.check(rc, arith + " edge kernel")
     dur = time_kernel(run, reps, torch)
     flops = 2.0 * int(rest.k_in) * int(rest.n_out) * n_e
-    peak = BF16_MFMA_PEAK_TF / 6.0
+    terms = 6 if arith == "bf16x3" else 3
+    peak = BF16_MFMA_PEAK_TF / terms
     return {
-        "kernel": "edge_ws_bf16x3_kernel (weights-stationary fused gather + "
-                  "3-way exact bf16 split + edge FC2 as 6 bf16 MFMA products "
-                  "+ scatter-max; csrc/edge_ws_bf16.h)",
+        "kernel": "edge_ws_%s_kernel (weights-stationary fused gather + %s "
+                  "+ edge FC2 as %d 16-bit MFMA products + scatter-max; "
+                  "csrc/edge_ws_%s.h)" % (
+                      arith, "3-way exact bf16 split" if terms == 6 else
+                      "two-part fp16 representation", terms,
+                      "bf16" if terms == 6 else "f16"),
         "bound": "mfma", "achieved": flops / dur / 1e12, "peak": peak,
         "unit": "TFLOP/s (fp32-equivalent)", "frac": flops / dur / 1e12 / peak,
         "executed_flops": flops, "avg_launch_us": dur * 1e6,
-        "note": "peak = dense bf16 MFMA peak (%.0f TFLOP/s) / 6 products per "
-                "fp32-equivalent product; FLOPs = 2*E*k_in*n_out of the "
+        "note": "peak = dense 16-bit MFMA peak (%.0f TFLOP/s) / %d products "
+                "per fp32-equivalent product; FLOPs = 2*E*k_in*n_out of the "
                 "layer (the K padding 300 -> 320 and the 16 zero columns are "
                 "not counted); duration as for roofline_mfma: compare "
-                "rocprofv3's average for edge_ws_bf16x3_kernel in profiles/"
-                % BF16_MFMA_PEAK_TF,
+                "rocprofv3's average for edge_ws_%s_kernel in profiles/"
+                % (BF16_MFMA_PEAK_TF, terms, arith),
     }
 
 
@@ -867,7 +879,7 @@ def parse_args(argv=None):
                     help="barrier-bracketed timed regions of exactly --steps "
                          "steps; the FIRST is the headline `value`, the "
                          "spread of all of them is reported beside it")
-    ap.add_argument("--edge-arith", choices=("f32", "bf16x3"), default="f32",
+    ap.add_argument("--edge-arith", choices=("f32", "bf16x3", "f16x2"), default="f32",
                     help="arithmetic of the per-edge 300x300 product: f32 = "
                          "fp32 MFMA (the headline); bf16x3 = the SECONDARY "
                          "split-bf16 kernel (csrc/edge_ws_bf16.h): the line's "
@@ -1221,27 +1233,29 @@ def secondary_ped(args, torch, dev, measure):
         pl = roofline_pool_kernel(torch, eng, frame=(x, f))
         if pl is not None:
             out["roofline_pool"] = pl
-    # the same frames with the edge stage on the split-bf16 kernel (C = 256:
-    # csrc/edge_ws_bf16.h's <8, 5> instance) -- SECONDARY, as in the headline
-    eng.model.edge_arith = "bf16x3"
-    try:
-        eng.frame_shapes = []
-        e16, _, _ = measure("ped_dense", steps, 3, engine=eng, n_frames=4)
-        b16 = {"frames_per_sec": steps / e16,
-               "ms_per_frame": e16 / steps * 1e3,
-               "vs_f32": elapsed / e16,
-               "dtype": "bf16x3 split products, f32 accumulate (edge stage "
-                        "only)"}
-        if not args.no_roofline:
-            eng.run_frame(x, f)     # host-sized: the image is cached by now
-            rf = roofline_edge_kernel_bf16x3(torch, eng, edges[1], n_k,
-                                             frame=(x, f))
-            if rf is not None:
-                rf["workload"] = out["roofline_mfma"]["workload"]
-                b16["roofline"] = rf
-        out["bf16x3"] = b16
-    finally:
-        eng.model.edge_arith = "f32"
+    # the same frames with the edge stage on the 16-bit matrix-pipe kernels
+    # (C = 256 instances) -- SECONDARY, as in the headline
+    for arith in ("bf16x3", "f16x2"):
+        eng.model.edge_arith = arith
+        try:
+            eng.frame_shapes = []
+            e16, _, _ = measure("ped_dense", steps, 3, engine=eng, n_frames=4)
+            eng.check_edge_range()
+            b16 = {"frames_per_sec": steps / e16,
+                   "ms_per_frame": e16 / steps * 1e3,
+                   "vs_f32": elapsed / e16,
+                   "dtype": arith + " products, f32 accumulate (edge stage "
+                                    "only)"}
+            if not args.no_roofline:
+                eng.run_frame(x, f)   # host-sized: the image is cached by now
+                rf = roofline_edge_kernel_16bit(torch, eng, edges[1], n_k,
+                                                arith, frame=(x, f))
+                if rf is not None:
+                    rf["workload"] = out["roofline_mfma"]["workload"]
+                    b16["roofline"] = rf
+            out[arith] = b16
+        finally:
+            eng.model.edge_arith = "f32"
     return out
 
 
@@ -1423,62 +1437,79 @@ def main(argv=None):
         ped = secondary_ped(args, torch, dev, measure)
         trn = secondary_train(args, torch, dev)
 
-    # SECONDARY arithmetic (not the headline, whose dtype is f32): the same
-    # frames with the per-edge product on the bf16 matrix pipe, both operands
-    # split exactly into three bf16 parts (csrc/edge_ws_bf16.h), next to how
-    # far its logits are from the fp32-MFMA path's on the pool's first frame
-    b16 = None
+    # SECONDARY arithmetics (not the headline, whose dtype is f32): the same
+    # frames with the per-edge product on the matrix pipe's 16-bit formats --
+    # 'bf16x3' (both operands split exactly into three bf16 parts, six
+    # products; csrc/edge_ws_bf16.h) and 'f16x2' (two fp16 parts, 22
+    # significand bits, three products; csrc/edge_ws_f16.h) -- next to how far
+    # their logits are from the fp32-MFMA path's on the pool's first frame
+    sec16 = {}
     if world == 1 and not args.no_secondary and args.edge_arith == "f32" \
             and args.preset == "car_600k" and args.config == "car_auto_T3":
         first = sorted(pool)[0]
         x0_, f0_ = pool[first][:2]
         lg32, bx32 = [t.clone() for t in engine.run_frame(x0_, f0_)]
-        engine.frame_shapes = []
-        engine.model.edge_arith = "bf16x3"
-        try:
-            lg16, bx16 = [t.clone() for t in engine.run_frame(x0_, f0_)]
-            s3 = max(8, args.steps // 2)
-            e3, sh3, _ = measure(args.preset, s3, 2, fps=fps_h)
-            rf16 = None
-            if not args.no_roofline:
-                # (a host-sized frame: after `measure` last_graph holds the
-                # capacity form, whose rows behind the counts are not a graph)
-                engine.run_frame(x0_, f0_)
-                coords_, _, edges_ = engine.last_graph
-                rf16 = roofline_edge_kernel_bf16x3(
-                    torch, engine, edges_[1], int(coords_[1].shape[0]),
-                    frame=(x0_, f0_))
-                if rf16 is not None:
-                    rf16["workload"] = {"frame_seed": first,
-                                        "E": int(edges_[1].shape[0]),
-                                        "K": int(coords_[1].shape[0])}
-        finally:
-            engine.model.edge_arith = "f32"
-        engine.frame_shapes = []
-        b16 = {
-            "workload": "%s inference, preset '%s', edge stage on the "
-                        "split-bf16 kernel (3 x 3 bf16 parts, the 6 products "
-                        "of order <= 2, fp32 accumulation; fp32-MFMA "
-                        "everywhere else)" % (args.config, args.preset),
-            "dtype": "bf16x3 split products, f32 accumulate (edge stage only)",
-            "steps": s3, "frames_per_gpu_per_step": fps_h,
-            "frames_per_sec": s3 * fps_h / e3,
-            "ms_per_frame": e3 / (s3 * fps_h) * 1e3,
-            "vs_f32_headline": (s3 * fps_h / e3) /
-                               (args.steps * fps_h / elapsed),
-            "max_abs_dlogit_vs_f32_path_frame_seed%d" % first:
-                float((lg16 - lg32).abs().max()),
-            "max_abs_dbox_vs_f32_path_frame_seed%d" % first:
-                float((bx16 - bx32).abs().max()),
-            "note": "SECONDARY: the headline `value` and `dtype` are the "
-                    "fp32-MFMA path; tests/test_gpu_bf16x3.py and the "
-                    "edge_arith-parametrised parity tests hold this path to "
-                    "the float64 oracle and the reference's TF graphs (its "
-                    "distance is not larger than the fp32 path's)",
+        what = {
+            "bf16x3": ("split-bf16 kernel (3 x 3 bf16 parts, the 6 products of "
+                       "order <= 2, fp32 accumulation; fp32-MFMA everywhere "
+                       "else)",
+                       "bf16x3 split products, f32 accumulate (edge stage only)",
+                       "its distance is not larger than the fp32 path's"),
+            "f16x2": ("two-part fp16 kernel (both operands as x0 + x1 / 2^11 "
+                      "in fp16 = 22 significand bits, 3 products, fp32 "
+                      "accumulation; fp32-MFMA everywhere else)",
+                      "f16x2 two-part products, f32 accumulate (edge stage "
+                      "only)",
+                      "same bars: its distance grows by a few per cent; "
+                      "activations are clamped at 65504 and flagged from "
+                      "32768 on"),
         }
-        if rf16 is not None:
-            b16["roofline"] = rf16
-
+        for arith in ("bf16x3", "f16x2"):
+            engine.frame_shapes = []
+            engine.model.edge_arith = arith
+            try:
+                lg16, bx16 = [t.clone() for t in engine.run_frame(x0_, f0_)]
+                s3 = max(8, args.steps // 2)
+                e3, sh3, _ = measure(args.preset, s3, 2, fps=fps_h)
+                engine.check_edge_range()
+                rf16 = None
+                if not args.no_roofline:
+                    # (a host-sized frame: after `measure` last_graph holds
+                    # the capacity form, whose rows behind the counts are not
+                    # a graph)
+                    engine.run_frame(x0_, f0_)
+                    coords_, _, edges_ = engine.last_graph
+                    rf16 = roofline_edge_kernel_16bit(
+                        torch, engine, edges_[1], int(coords_[1].shape[0]),
+                        arith, frame=(x0_, f0_))
+                    if rf16 is not None:
+                        rf16["workload"] = {"frame_seed": first,
+                                            "E": int(edges_[1].shape[0]),
+                                            "K": int(coords_[1].shape[0])}
+            finally:
+                engine.model.edge_arith = "f32"
+            engine.frame_shapes = []
+            sec16[arith] = {
+                "workload": "%s inference, preset '%s', edge stage on the %s"
+                            % (args.config, args.preset, what[arith][0]),
+                "dtype": what[arith][1],
+                "steps": s3, "frames_per_gpu_per_step": fps_h,
+                "frames_per_sec": s3 * fps_h / e3,
+                "ms_per_frame": e3 / (s3 * fps_h) * 1e3,
+                "vs_f32_headline": (s3 * fps_h / e3) /
+                                   (args.steps * fps_h / elapsed),
+                "max_abs_dlogit_vs_f32_path_frame_seed%d" % first:
+                    float((lg16 - lg32).abs().max()),
+                "max_abs_dbox_vs_f32_path_frame_seed%d" % first:
+                    float((bx16 - bx32).abs().max()),
+                "note": "SECONDARY: the headline `value` and `dtype` are the "
+                        "fp32-MFMA path; tests/test_gpu_bf16x3.py and the "
+                        "edge_arith-parametrised parity tests hold this path "
+                        "to the float64 oracle and the reference's TF graphs "
+                        "(%s)" % what[arith][2],
+            }
+            if rf16 is not None:
+                sec16[arith]["roofline"] = rf16
 
     if rank == 0:
         # per-phase wall clock of the pool's first frame (outside the timed
@@ -1586,8 +1617,8 @@ def main(argv=None):
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.edge_arith == "f32" else
-                     "bf16x3 split products with f32 accumulation in the edge "
-                     "stage (SECONDARY arithmetic), f32 elsewhere",
+                     "%s products with f32 accumulation in the edge stage "
+                     "(SECONDARY arithmetic), f32 elsewhere" % args.edge_arith,
             "data": "synthetic" if not (ONE_GPU and world > 1) else
                     "synthetic; TEST MODE: %d ranks share ONE GPU under gloo "
                     "(not a multi-GPU measurement)" % world,
@@ -1655,8 +1686,8 @@ def main(argv=None):
         }
         if second is not None:
             res["config"]["secondary"] = second
-        if b16 is not None:
-            res["config"]["secondary_bf16x3"] = b16
+        for arith, line in sec16.items():
+            res["config"]["secondary_" + arith] = line
         if ped is not None:
             res["config"]["secondary_ped"] = ped
         if trn is not None:

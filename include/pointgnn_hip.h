@@ -499,6 +499,30 @@ int pgnn_edge_mlp_scatter_max_bf16x3_fwd(
     float *out, int64_t ld_out, const pgnn_dyn_count *n_edges,
     const pgnn_dyn_count *num_vertices, void *stream);
 
+/* SECONDARY arithmetic 'f16x2' for the same stage and shapes
+ * (csrc/edge_ws_f16.h): both operands of the layer's product are represented
+ * by TWO fp16 values (x ~ x0 + x1' / 2^11, round to nearest, 22 significand
+ * bits), three fp16 MFMAs per block accumulate in fp32 -- half the matrix
+ * instructions of the bf16x3 entry, three column groups instead of four.  Not
+ * exact: each operand is within 2^-22 of its fp32 value (fp32's own rounding
+ * is 2^-24); the stage's distance to a float64 evaluation grows by a few per
+ * cent over the fp32 entry's (tests: the edge_arith-parametrised parity tests,
+ * same bars as bf16x3).  Range: the gathered operand is clamped at 65504, and
+ * bit 0 of *status (device int32, nullable; the caller zeroes it) is raised
+ * when one reached 32768 -- rerun the stage through the fp32 entry then.
+ * `image`: device copy of what pgnn_pack_fc_f16x2 wrote (it refuses weights
+ * of magnitude >= 32768 with PGNN_E_UNSUPPORTED).  Otherwise as the bf16x3
+ * entry, PGNN_E_UNSUPPORTED included.                                        */
+size_t pgnn_packed_fc_f16x2_bytes(int32_t k_in, int32_t n_out);
+int pgnn_pack_fc_f16x2(const float *w_host, const float *b_host, int32_t k_in,
+                       int32_t n_out, void *image_host);
+int pgnn_edge_mlp_scatter_max_f16x2_fwd(
+    const float *P, const float *Q, int64_t ld_pq, int32_t width,
+    const int32_t *edges, int64_t edges_cap, int32_t vertices_cap,
+    const void *image, int32_t n_out, int32_t relu_from, int32_t edges_sorted,
+    float *out, int64_t ld_out, int32_t *status, const pgnn_dyn_count *n_edges,
+    const pgnn_dyn_count *num_vertices, void *stream);
+
 /* Training forward of the same stage with ONE remaining edge layer: the fused
  * kernel also writes that layer's per-edge output rows [n_edges, ld_rows]
  * (the backward compares them with `out` to find the arg-max rows; rows and

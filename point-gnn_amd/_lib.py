@@ -211,6 +211,12 @@ _SIGNATURES = {
         c_vp, c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_i32, c_i32,
         c_i32, c_vp, c_i64, ctypes.POINTER(DynCount), ctypes.POINTER(DynCount),
         c_vp]),
+    "pgnn_packed_fc_f16x2_bytes": (c_sz, [c_i32, c_i32]),
+    "pgnn_pack_fc_f16x2": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp]),
+    "pgnn_edge_mlp_scatter_max_f16x2_fwd": (c_i32, [
+        c_vp, c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_i32, c_i32,
+        c_i32, c_vp, c_i64, c_vp, ctypes.POINTER(DynCount),
+        ctypes.POINTER(DynCount), c_vp]),
     "pgnn_offset_apply": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp,
                                   c_i64, c_vp]),
     "pgnn_vertex_pre_edge_fwd": (c_i32, [c_vp, c_i64, c_i32, c_vp,

@@ -1,3 +1,4 @@
+#include <cmath>
 // Library plumbing: error state, device queries, host-side weight packing.
 #include <string.h>
 
@@ -388,6 +389,44 @@ extern "C" int pgnn_pack_fc_bf16x3(const float *w, const float *b, int32_t k_in,
         }
   float *bias = reinterpret_cast<float *>(reinterpret_cast<char *>(image) +
                                           (size_t)kb_n * nt * 3 * 1024);
+  for (int n = 0; n < nt * 16; ++n) bias[n] = (b && n < n_out) ? b[n] : 0.0f;
+  return 0;
+  PGNN_GUARD_END
+}
+
+extern "C" size_t pgnn_packed_fc_f16x2_bytes(int32_t k_in, int32_t n_out) {
+  if (k_in <= 0 || n_out <= 0) return 0;
+  const size_t kb = (k_in + 31) / 32, nt = (n_out + 15) / 16;
+  return kb * nt * 2 * 1024 + nt * 16 * sizeof(float);
+}
+
+extern "C" int pgnn_pack_fc_f16x2(const float *w, const float *b, int32_t k_in,
+                                  int32_t n_out, void *image) {
+  PGNN_GUARD_BEGIN
+  PGNN_REQUIRE(w && image && k_in > 0 && n_out > 0, PGNN_E_INVALID,
+               "pack_fc_f16x2: bad argument");
+  const int kb_n = (k_in + 31) / 32, nt = (n_out + 15) / 16;
+  for (size_t i = 0; i < (size_t)k_in * n_out; ++i)
+    PGNN_REQUIRE(std::fabs(w[i]) < 32768.0f, PGNN_E_UNSUPPORTED,
+                 "pack_fc_f16x2: a weight outside fp16's range");
+  _Float16 *img = reinterpret_cast<_Float16 *>(image);
+  for (int kb = 0; kb < kb_n; ++kb)
+    for (int t = 0; t < nt; ++t)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int j = 0; j < 8; ++j) {
+          const int k = 32 * kb + 8 * (lane >> 4) + j;
+          const int n = 16 * t + (lane & 15);
+          const float x = (k < k_in && n < n_out) ? w[(size_t)k * n_out + n] : 0.0f;
+          // x ~ w0 + w1' / 2^11: the residual is exact in fp32, the scaling
+          // (a power of two) keeps it out of fp16's subnormals
+          const _Float16 w0 = (_Float16)x;
+          const _Float16 w1 = (_Float16)((x - (float)w0) * 2048.0f);
+          const size_t frag = ((size_t)kb * nt + t) * 2;
+          img[((frag + 0) * 64 + lane) * 8 + j] = w0;
+          img[((frag + 1) * 64 + lane) * 8 + j] = w1;
+        }
+  float *bias = reinterpret_cast<float *>(reinterpret_cast<char *>(image) +
+                                          (size_t)kb_n * nt * 2 * 1024);
   for (int n = 0; n < nt * 16; ++n) bias[n] = (b && n < n_out) ? b[n] : 0.0f;
   return 0;
   PGNN_GUARD_END

@@ -15,6 +15,7 @@
 #include "mlp_engine.h"
 #include "edge_ws.h"
 #include "edge_ws_bf16.h"
+#include "edge_ws_f16.h"
 #include "pool_ws.h"
 
 namespace pgnn {
@@ -1718,6 +1719,89 @@ extern "C" int pgnn_edge_mlp_scatter_max_bf16x3_fwd(
   a.prio = g_ws_prio;
   if (kb == 10) return launch_edge_ws3<10, 5>(a, nt, cus, stream);
   return launch_edge_ws3<8, 5>(a, nt, cus, stream);
+  PGNN_GUARD_END
+}
+
+namespace {
+template <int KB, int NTMAX>
+int launch_edge_ws2(EdgeWsArgs &a, int nt, int cus, int32_t *status,
+                    hipStream_t stream) {
+  const int rc = ws_partition(a, nt, NTMAX, cus);
+  if (rc) return rc;
+  {
+    // relative cost of a row tile: 30 MFMAs of 16 cycles per column tile + the
+    // part of the gather / split / segmented max that does not hide behind them
+    double cost[kWsMaxGroups];
+    for (int g = 0; g < a.groups; ++g)
+      cost[g] = 480.0 * KB / 10 * (a.tile0[g + 1] - a.tile0[g]) + 1600.0;
+    if (g_ws_balance) ws_balance(a, cus, cost);
+  }
+  const size_t lds = (size_t)KB * NTMAX * 2 * 1024 + 16 * NTMAX * sizeof(float);
+  PGNN_REQUIRE(lds <= device_max_lds(), PGNN_E_UNSUPPORTED,
+               "edge_f16x2: column group does not fit the LDS");
+  auto kern = edge_ws_f16x2_kernel<KB, NTMAX>;
+  const int lrc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
+  if (lrc) return lrc;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(cus / a.xcds * a.xcds)),
+                     dim3(64 * kWsWaves), lds, stream, a, status);
+  PGNN_HIP(hipGetLastError());
+  return 0;
+}
+}  // namespace
+
+extern "C" int pgnn_edge_mlp_scatter_max_f16x2_fwd(
+    const float *P, const float *Q, int64_t ld_pq, int32_t width,
+    const int32_t *edges, int64_t edges_cap, int32_t vertices_cap,
+    const void *image, int32_t n_out, int32_t relu_from, int32_t edges_sorted,
+    float *out, int64_t ld_out, int32_t *status, const pgnn_dyn_count *n_edges,
+    const pgnn_dyn_count *num_vertices, void *stream_) {
+  PGNN_GUARD_BEGIN
+  hipStream_t stream = (hipStream_t)stream_;
+  PGNN_REQUIRE(edges_cap >= 0 && vertices_cap >= 0 && width > 0 && n_out > 0 &&
+                   image,
+               PGNN_E_INVALID, "edge_f16x2: bad argument");
+  const Dyn de = dyn_of(n_edges), dk = dyn_of(num_vertices);
+  const int kq = (width + 15) / 16, nt = (n_out + 15) / 16;
+  const int kb = (width + 31) / 32;
+  PGNN_REQUIRE(ld_pq == 16 * kq && ld_out >= 16 * nt, PGNN_E_INVALID,
+               "edge_f16x2: ld_pq / ld_out do not match the padded widths");
+  int cus = stream_cu_count(stream);
+  if (g_ws_reserve > 0 && cus - g_ws_reserve >= 64) cus -= g_ws_reserve;
+  if (!((kb == 10 && nt == 19) || (kb == 8 && nt == 16)) || cus < 64 ||
+      cus % 8 != 0 ||
+      (!g_b16_force &&
+       expected(de, edges_cap) < (int64_t)16 * 2 * kWsWaves * cus) ||
+      (int64_t)vertices_cap * ld_pq * 4 >= ((int64_t)1 << 32))
+    return PGNN_E_UNSUPPORTED;  // (no message: an expected answer)
+  if (vertices_cap == 0) return 0;
+  PGNN_REQUIRE(out != nullptr, PGNN_E_INVALID, "edge_f16x2: null output");
+  if (!(edges_sorted & 2)) {
+    const int rc = fill_lowest_rows(out, ld_out, vertices_cap, dk, stream);
+    if (rc) return rc;
+  }
+  if (edges_cap == 0) return 0;
+  PGNN_REQUIRE(P && Q && edges, PGNN_E_INVALID, "edge_f16x2: null input");
+  PGNN_REQUIRE(((uintptr_t)P % 16 == 0) && ((uintptr_t)Q % 16 == 0) &&
+                   ((uintptr_t)image % 16 == 0),
+               PGNN_E_INVALID, "edge_f16x2: P / Q / image must be 16-byte aligned");
+  EdgeWsArgs a = {};
+  a.P = P;
+  a.Q = Q;
+  a.ldv4 = (int)(ld_pq >> 2);
+  a.edges = edges;
+  a.n_edges = edges_cap;
+  a.n_dev = de.dev;
+  a.wp = reinterpret_cast<const float *>(image);
+  a.nt = nt;
+  a.relu_from = relu_from;
+  a.out = out;
+  a.ldo = ld_out;
+  a.num_segments = vertices_cap;
+  a.sorted = edges_sorted & 1;
+  a.xcds = (g_ws_xcds >= 1 && cus % g_ws_xcds == 0) ? g_ws_xcds : 8;
+  a.prio = 0;
+  if (kb == 10) return launch_edge_ws2<10, 7>(a, nt, cus, status, stream);
+  return launch_edge_ws2<8, 6>(a, nt, cus, status, stream);
   PGNN_GUARD_END
 }
 

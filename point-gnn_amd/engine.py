@@ -426,6 +426,7 @@ class InferenceEngine(object):
         for lg, bx in outs:     # allocated on a side stream, used by the caller
             lg.record_stream(cur)
             bx.record_stream(cur)
+        self.check_edge_range()
         return outs
 
     def _priority_streams(self, n):
@@ -573,7 +574,23 @@ class InferenceEngine(object):
             for lg, bx in outs:
                 lg.record_stream(cur)
                 bx.record_stream(cur)
+        self.check_edge_range()
         return outs
+
+    def check_edge_range(self):
+        """edge_arith 'f16x2' only: raises when an activation of a frame run
+        since the last call left fp16's range (the kernel clamps at 65504 and
+        flags >= 32768; a trained Point-GNN stays below 100) -- such frames
+        must be rerun with edge_arith 'f32'.  One small device-to-host read:
+        the batch entry points (run_frames, run_frames_on_streams) call it
+        once per batch, callers of run_frame / run_frame_deferred call it when
+        they take results."""
+        if self.model.edge_arith == 'f16x2' and not self.model.edge_range_ok():
+            from . import _lib
+            raise _lib.PointGnnHipError(
+                "edge_arith 'f16x2': a gathered activation reached 32768 "
+                "(fp16 ends at 65504): rerun these frames with edge_arith "
+                "'f32'")
 
     def run_frame(self, xyz, intensity, timed=False):
         """xyz [N,3] float32, intensity [N,F] float32 CUDA tensors ->

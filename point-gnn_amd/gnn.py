@@ -65,6 +65,25 @@ class ParamStore(object):
                              % (EDGE_ARITHS, value))
         self._edge_arith = value
 
+    def range_status(self):
+        """Device int32 the 'f16x2' edge kernel raises when an activation left
+        fp16's comfortable range (>= 32768); zeroed when created / read."""
+        if getattr(self, '_range_status', None) is None:
+            self._range_status = torch.zeros(1, dtype=torch.int32,
+                                             device=self._dev())
+        return self._range_status
+
+    def edge_range_ok(self):
+        """Reads (and clears) the flag: one small device-to-host read.  True
+        when every 'f16x2' edge stage since the last call stayed in range."""
+        st = getattr(self, '_range_status', None)
+        if st is None:
+            return True
+        ok = int(st.item()) == 0
+        if not ok:
+            st.zero_()
+        return ok
+
     def _dev(self):
         if self.device is None:
             if not torch.cuda.is_available():
@@ -552,7 +571,15 @@ EDGE_INPUT_TAP = None
 #               agrees with 'f32' to fp32 rounding noise, ~1.7x faster.  Falls
 #               back to 'f32' where the kernel does not apply (few edges,
 #               other layer shapes).
-EDGE_ARITHS = ('f32', 'bf16x3')
+#   'f16x2'  -- SECONDARY: both operands as TWO fp16 values (22 significand
+#               bits, round to nearest), three fp16 MFMAs per block
+#               (csrc/edge_ws_f16.h, pgnn_edge_mlp_scatter_max_f16x2_fwd):
+#               not exact -- the stage's distance to float64 grows by a few per
+#               cent -- ~3x faster than 'f32'.  Activations are clamped at
+#               65504; the kernel flags any that reached 32768 and
+#               `model.edge_range_ok()` (read by the engine with a frame's
+#               results) reports it: rerun such a frame in 'f32'.
+EDGE_ARITHS = ('f32', 'bf16x3', 'f16x2')
 
 
 class GraphNetAutoCenter(object):
@@ -682,10 +709,10 @@ class GraphNetAutoCenter(object):
                      _edges_sorted_flag(edges) | 2, _lib.ptr(agg),
                      agg.stride(0), _lib.ptr(_lib.sched_ws(h.device)))
         done = False
-        if store.edge_arith == 'bf16x3' and rest.n == 1:
-            done = self._edge_bf16x3(lib, store, edge_scope, edge_widths, p, q,
-                                     wq, rest, e, k, edges, agg, cnt_e, cnt_k,
-                                     st)
+        if store.edge_arith != 'f32' and rest.n == 1:
+            done = self._edge_split(lib, store, edge_scope, edge_widths, p, q,
+                                    wq, rest, e, k, edges, agg, cnt_e, cnt_k,
+                                    st)
         if done:
             pass
         elif cnt_k is None:
@@ -709,31 +736,41 @@ class GraphNetAutoCenter(object):
 
 
     @staticmethod
-    def _edge_bf16x3(lib, store, edge_scope, edge_widths, p, q, wq, rest, e, k,
-                     edges, agg, cnt_e, cnt_k, st):
-        """The edge stage on the split-bf16 kernel; False (nothing done) where
-        it does not apply."""
+    def _edge_split(lib, store, edge_scope, edge_widths, p, q, wq, rest, e, k,
+                    edges, agg, cnt_e, cnt_k, st):
+        """The edge stage on the matrix pipe's 16-bit formats ('bf16x3' /
+        'f16x2'); False (nothing done) where the kernel does not apply."""
+        arith = store.edge_arith
+
         def build():
             w, b = store.mlp(edge_scope, len(edge_widths))[1]
             w = np.ascontiguousarray(w, dtype=np.float32)
             b = np.ascontiguousarray(b, dtype=np.float32)
-            host = np.empty(lib.pgnn_packed_fc_bf16x3_bytes(*w.shape), np.uint8)
-            _lib.check(lib.pgnn_pack_fc_bf16x3(
+            nbytes = getattr(lib, "pgnn_packed_fc_%s_bytes" % arith)(*w.shape)
+            host = np.empty(nbytes, np.uint8)
+            name = "pgnn_pack_fc_%s" % arith
+            _lib.check(getattr(lib, name)(
                 w.ctypes.data, b.ctypes.data, w.shape[0], w.shape[1],
-                host.ctypes.data), "pgnn_pack_fc_bf16x3")
+                host.ctypes.data), name)
             return torch.from_numpy(host).to(store._dev())
-        image = store.cached(('edge_bf16x3', edge_scope, tuple(edge_widths)),
+        image = store.cached(('edge_' + arith, edge_scope, tuple(edge_widths)),
                              build)
-        rc = lib.pgnn_edge_mlp_scatter_max_bf16x3_fwd(
-            _lib.ptr(p), _lib.ptr(q), wq, int(rest.k_in), _lib.ptr(e),
-            int(e.shape[0]), k, _lib.ptr(image), int(rest.n_out),
-            int(rest.array[0].relu_from), _edges_sorted_flag(edges) | 2,
-            _lib.ptr(agg), agg.stride(0),
-            cnt_e.arg() if cnt_e is not None else None,
-            cnt_k.arg() if cnt_k is not None else None, st)
+        head = (_lib.ptr(p), _lib.ptr(q), wq, int(rest.k_in), _lib.ptr(e),
+                int(e.shape[0]), k, _lib.ptr(image), int(rest.n_out),
+                int(rest.array[0].relu_from), _edges_sorted_flag(edges) | 2,
+                _lib.ptr(agg), agg.stride(0))
+        tail = (cnt_e.arg() if cnt_e is not None else None,
+                cnt_k.arg() if cnt_k is not None else None, st)
+        if arith == 'bf16x3':
+            name = "pgnn_edge_mlp_scatter_max_bf16x3_fwd"
+            rc = lib.pgnn_edge_mlp_scatter_max_bf16x3_fwd(*(head + tail))
+        else:
+            name = "pgnn_edge_mlp_scatter_max_f16x2_fwd"
+            rc = lib.pgnn_edge_mlp_scatter_max_f16x2_fwd(
+                *(head + (_lib.ptr(store.range_status()),) + tail))
         if rc == _lib.E_UNSUPPORTED:
             return False
-        _lib.check(rc, "pgnn_edge_mlp_scatter_max_bf16x3_fwd")
+        _lib.check(rc, name)
         return True
 
 

@@ -79,6 +79,13 @@ class MultiLayerFastLocalGraphModelV2(object):
         if self._store is not None:
             self._store.edge_arith = value
 
+    def edge_range_ok(self):
+        """edge_arith 'f16x2' only: False when an activation of a frame since
+        the last call reached 32768 (fp16 ends at 65504; the kernel clamps) --
+        such a frame's results are unreliable, rerun it with edge_arith 'f32'.
+        One small device-to-host read; always True for the other arithmetics."""
+        return self._store is None or self._store.edge_range_ok()
+
     # ---- weights ----------------------------------------------------------
     def load_state_dict(self, params, device=None):
         """params: {TF variable name: ndarray} (extra keys such as the

@@ -56,11 +56,11 @@ def fullsize_oracle(key, params, cfg, inten, c_np, k_np, e_np):
 
 
 # The arithmetic of the per-edge product (model.edge_arith): the parity tests
-# that hold the fp32-MFMA path to the reference run a second time on the
-# SECONDARY split-bf16 kernel.  Small fixtures have fewer edges than the
+# that hold the fp32-MFMA path to the reference run again on each SECONDARY
+# arithmetic (split-bf16, two-part fp16).  Small fixtures have fewer edges than the
 # kernel's launcher asks for (it would answer "unsupported" and the fp32 entry
 # would run): the `b16_force` tunable lifts that for the duration of the test.
-EDGE_ARITHS = ("f32", "bf16x3")
+EDGE_ARITHS = ("f32", "bf16x3", "f16x2")
 
 
 @pytest.fixture(params=EDGE_ARITHS)

@@ -1,11 +1,13 @@
-"""The SECONDARY split-bf16 arithmetic of the per-edge layer
-(csrc/edge_ws_bf16.h, model.edge_arith = 'bf16x3'): both operands of the
-300x300 / 256x256 product are split exactly into three bf16 parts and the six
-products of combined order <= 2 accumulate in fp32 on the bf16 matrix pipe.
+"""The SECONDARY arithmetics of the per-edge layer on the matrix pipe's 16-bit
+formats: 'bf16x3' (csrc/edge_ws_bf16.h: both operands of the 300x300 / 256x256
+product split exactly into three bf16 parts, the six products of combined order
+<= 2 accumulated in fp32) and 'f16x2' (csrc/edge_ws_f16.h: both operands as two
+fp16 values, 22 significand bits, three products).
 
-It is NOT bit-identical to the fp32-MFMA kernel (another summation), so the
+Neither is bit-identical to the fp32-MFMA kernel (another summation), so the
 bars are: (i) within fp32 rounding noise of the fp32 kernel, (ii) no further
-from a float64 evaluation than the fp32 kernel is -- at the layer and for whole
+from a float64 evaluation than the fp32 kernel is (x1.25 at the layer, x1.5 on
+whole frames) -- at the layer and for whole
 BASELINE-size frames (both distances are printed), (iii) every other property
 of the stage (foreign ids, unsorted lists, ragged counts, capacity form)
 unchanged.  The fp32 kernel stays the default and the parity reference."""
@@ -67,14 +69,22 @@ def _stage(dev, c, edges, k, seed, arith, unsorted=False):
             chain.array, 1, flag, _lib.ptr(out), wq,
             _lib.ptr(_lib.sched_ws()), _lib.stream_ptr()), "f32 edge stage")
     else:
-        host = np.empty(lib.pgnn_packed_fc_bf16x3_bytes(c, c), np.uint8)
-        _lib.check(lib.pgnn_pack_fc_bf16x3(w.ctypes.data, b.ctypes.data, c, c,
-                                           host.ctypes.data))
+        host = np.empty(getattr(lib, "pgnn_packed_fc_%s_bytes" % arith)(c, c),
+                        np.uint8)
+        _lib.check(getattr(lib, "pgnn_pack_fc_%s" % arith)(
+            w.ctypes.data, b.ctypes.data, c, c, host.ctypes.data))
         image = T(host, dev)
-        _lib.check(lib.pgnn_edge_mlp_scatter_max_bf16x3_fwd(
-            _lib.ptr(pd), _lib.ptr(qd), wq, c, _lib.ptr(ed), len(edges), k,
-            _lib.ptr(image), c, 0, flag, _lib.ptr(out), wq, None, None,
-            _lib.stream_ptr()), "bf16x3 edge stage")
+        head = (_lib.ptr(pd), _lib.ptr(qd), wq, c, _lib.ptr(ed), len(edges), k,
+                _lib.ptr(image), c, 0, flag, _lib.ptr(out), wq)
+        if arith == "bf16x3":
+            _lib.check(lib.pgnn_edge_mlp_scatter_max_bf16x3_fwd(
+                *head, None, None, _lib.stream_ptr()), "bf16x3 edge stage")
+        else:
+            status = torch.zeros(1, dtype=torch.int32, device=dev)
+            _lib.check(lib.pgnn_edge_mlp_scatter_max_f16x2_fwd(
+                *head, _lib.ptr(status), None, None, _lib.stream_ptr()),
+                "f16x2 edge stage")
+            assert int(status.item()) == 0, "range flag raised"
     return out.cpu().numpy()[:, :c], (p, q, w, b)
 
 
@@ -91,25 +101,32 @@ def _stage_f64(p, q, w, b, edges, k, c):
     return out
 
 
+ARITHS = ["bf16x3", "f16x2"]
+
+
+@pytest.mark.parametrize("arith", ARITHS)
 @pytest.mark.parametrize("c", [300, 256])
-def test_bf16x3_edge_stage_is_as_close_to_float64_as_the_fp32_kernel(dev, c):
+def test_bf16x3_edge_stage_is_as_close_to_float64_as_the_fp32_kernel(dev, c,
+                                                                     arith):
     g = gold("graph_small.npz")
     edges = g["ref_edges1"].astype(np.int32)
     k = g["kp_xyz"].shape[0]
     assert len(edges) >= 70000
     f32, ins = _stage(dev, c, edges, k, c, "f32")
-    b16, _ = _stage(dev, c, edges, k, c, "bf16x3")
+    b16, _ = _stage(dev, c, edges, k, c, arith)
     ref = _stage_f64(*ins, edges, k, c)
     scale = np.abs(ref).max()
     e32, e16 = np.abs(f32 - ref).max(), np.abs(b16 - ref).max()
     print("C %d E %d: |out|max %.3g; max error vs float64: fp32-MFMA %.3g, "
-          "bf16x3 %.3g; bf16x3 vs fp32-MFMA %.3g" % (
-              c, len(edges), scale, e32, e16, np.abs(b16 - f32).max()))
+          "%s %.3g; %s vs fp32-MFMA %.3g" % (
+              c, len(edges), scale, e32, arith, e16, arith,
+              np.abs(b16 - f32).max()))
     assert e16 <= 1.25 * e32 + 1e-7 * scale
     np.testing.assert_allclose(b16, f32, atol=2e-6 * scale, rtol=0)
 
 
-def test_bf16x3_edge_stage_edge_cases(dev):
+@pytest.mark.parametrize("arith", ARITHS)
+def test_bf16x3_edge_stage_edge_cases(dev, arith):
     """Unsorted list (all-atomic flush), foreign / negative dst ids, a ragged
     edge count, empty segments: the same answers as the fp32 kernel."""
     g = gold("graph_small.npz")
@@ -130,7 +147,7 @@ def test_bf16x3_edge_stage_edge_cases(dev):
         if len(e) < 70000:
             continue
         f32, _ = _stage(dev, 300, e, k, 5, "f32", unsorted)
-        b16, _ = _stage(dev, 300, e, k, 5, "bf16x3", unsorted)
+        b16, _ = _stage(dev, 300, e, k, 5, arith, unsorted)
         lowest = np.finfo(np.float32).min
         assert np.array_equal(f32 == lowest, b16 == lowest), name
         m = f32 != lowest
@@ -138,10 +155,11 @@ def test_bf16x3_edge_stage_edge_cases(dev):
         assert np.abs(f32[m] - b16[m]).max() <= 2e-6 * scale, name
 
 
+@pytest.mark.parametrize("arith", ARITHS)
 @pytest.mark.parametrize("name,preset", [("car_auto_T3", "car"),
                                          ("car_auto_T3", "car_600k"),
                                          ("ped_cyl_auto_T3", "ped_dense")])
-def test_bf16x3_full_size_logits_vs_float64_oracle(dev, name, preset):
+def test_bf16x3_full_size_logits_vs_float64_oracle(dev, name, preset, arith):
     """BASELINE configs 3 and 5 at full size with the split-bf16 edge stage:
     logits / box encodings against the float64 oracle, beside the fp32-MFMA
     path's distance on the same frame."""
@@ -157,12 +175,14 @@ def test_bf16x3_full_size_logits_vs_float64_oracle(dev, name, preset):
         **cfg["model_kwargs"]).load_state_dict(params)
     f = T(inten, dev)
     out = {}
-    for arith in ("f32", "bf16x3"):
-        model.edge_arith = arith
+    for ar in ("f32", arith):
+        model.edge_arith = ar
         lg, bx = model.predict(f, coords, kps, edges, False)
-        out[arith] = (lg.cpu().numpy(), bx.cpu().numpy())
+        out["f32" if ar == "f32" else "bf16x3"] = (lg.cpu().numpy(),
+                                                   bx.cpu().numpy())
+    assert model.edge_range_ok()
     assert not np.array_equal(out["f32"][0], out["bf16x3"][0]), \
-        "the bf16x3 kernel did not run"
+        "the %s kernel did not run" % arith
     c_np = [c.cpu().numpy() for c in coords]
     k_np = [k.cpu().numpy() for k in kps]
     e_np = [e.cpu().numpy() for e in edges]
@@ -173,9 +193,50 @@ def test_bf16x3_full_size_logits_vs_float64_oracle(dev, name, preset):
     d16 = (np.abs(out["bf16x3"][0] - lg).max(),
            np.abs(out["bf16x3"][1] - bx).max())
     print("%s/%s K %d E1 %d: max|dlogit| / max|dbox| vs float64: fp32-MFMA "
-          "%.3g / %.3g, bf16x3 %.3g / %.3g; bf16x3 vs fp32-MFMA %.3g" % (
-              name, preset, len(c_np[1]), len(e_np[1]), d32[0], d32[1], d16[0],
-              d16[1], np.abs(out["bf16x3"][0] - out["f32"][0]).max()))
+          "%.3g / %.3g, %s %.3g / %.3g; %s vs fp32-MFMA %.3g" % (
+              name, preset, len(c_np[1]), len(e_np[1]), d32[0], d32[1], arith,
+              d16[0], d16[1], arith,
+              np.abs(out["bf16x3"][0] - out["f32"][0]).max()))
     np.testing.assert_allclose(out["bf16x3"][0], lg, atol=FP_TOL, rtol=1e-4)
     np.testing.assert_allclose(out["bf16x3"][1], bx, atol=FP_TOL, rtol=1e-4)
     assert d16[0] <= 1.5 * d32[0] + 2e-7 and d16[1] <= 1.5 * d32[1] + 2e-7
+
+
+def test_f16x2_flags_activations_out_of_range(dev):
+    """fp16 ends at 65504: the f16x2 kernel clamps there and raises the range
+    flag when a gathered activation reached 32768; model.edge_range_ok() reads
+    and clears it."""
+    import torch
+    from pointgnn_amd import _lib, gnn
+    lib = _lib.load()
+    g = gold("graph_small.npz")
+    edges = g["ref_edges1"].astype(np.int32)
+    k = g["kp_xyz"].shape[0]
+    c = 300
+    wq = gnn.padded_width(c)
+    rng = np.random.default_rng(0)
+    w = (rng.standard_normal((c, c)) / np.sqrt(c)).astype(np.float32)
+    b = np.zeros(c, np.float32)
+    host = np.empty(lib.pgnn_packed_fc_f16x2_bytes(c, c), np.uint8)
+    _lib.check(lib.pgnn_pack_fc_f16x2(w.ctypes.data, b.ctypes.data, c, c,
+                                      host.ctypes.data))
+    image = T(host, dev)
+    for big, want in ((100.0, 0), (40000.0, 1)):
+        p = np.zeros((k, wq), np.float32)
+        p[:, :c] = rng.standard_normal((k, c))
+        p[7, 5] = big
+        q = np.zeros((k, wq), np.float32)
+        out = torch.empty((k, wq), dtype=torch.float32, device=dev)
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        pd, qd, ed = T(p, dev), T(q, dev), T(edges, dev)   # (kept alive)
+        _lib.check(lib.pgnn_edge_mlp_scatter_max_f16x2_fwd(
+            _lib.ptr(pd), _lib.ptr(qd), wq, c, _lib.ptr(ed), len(edges), k,
+            _lib.ptr(image), c, 0, 1, _lib.ptr(out), wq, _lib.ptr(status),
+            None, None, _lib.stream_ptr()), "f16x2 edge stage")
+        assert int(status.item()) == want, (big, int(status.item()))
+        assert torch.isfinite(out[:, :c]).all()
+    # a weight outside fp16's range is refused when the image is built
+    w[3, 4] = 70000.0
+    rc = lib.pgnn_pack_fc_f16x2(w.ctypes.data, b.ctypes.data, c, c,
+                                host.ctypes.data)
+    assert rc == _lib.E_UNSUPPORTED

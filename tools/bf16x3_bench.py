@@ -61,6 +61,22 @@ def run_f32():
         _lib.ptr(_lib.sched_ws()), _lib.stream_ptr()))
 
 
+host2 = np.empty(lib.pgnn_packed_fc_f16x2_bytes(*w.shape), np.uint8)
+_lib.check(lib.pgnn_pack_fc_f16x2(np.ascontiguousarray(w).ctypes.data,
+                                  np.ascontiguousarray(b).ctypes.data,
+                                  w.shape[0], w.shape[1], host2.ctypes.data))
+image2 = torch.from_numpy(host2).to(dev)
+out["f16x2"] = torch.full((n_k, gnn.padded_width(rest.n_out)), lowest, device=dev)
+status = torch.zeros(1, dtype=torch.int32, device=dev)
+
+
+def run_f16():
+    _lib.check(lib.pgnn_edge_mlp_scatter_max_f16x2_fwd(
+        _lib.ptr(p), _lib.ptr(q), wq, int(rest.k_in), _lib.ptr(e1), n_e, n_k,
+        _lib.ptr(image2), int(rest.n_out), 0, 1 | 2, _lib.ptr(out["f16x2"]),
+        out["f16x2"].stride(0), _lib.ptr(status), None, None, _lib.stream_ptr()))
+
+
 def run_b16():
     _lib.check(lib.pgnn_edge_mlp_scatter_max_bf16x3_fwd(
         _lib.ptr(p), _lib.ptr(q), wq, int(rest.k_in), _lib.ptr(e1), n_e, n_k,
@@ -81,3 +97,10 @@ print("  sha256 of the bf16x3 output: %s" % hashlib.sha256(
     bb.contiguous().cpu().numpy().tobytes()).hexdigest()[:16])
 print("  max |bf16x3 - fp32| %.3g (|out|max %.3g)" % (
     float((a - bb).abs().max()), float(a.abs().max())))
+
+t_f16 = bench.time_kernel(run_f16, 10, torch)
+cc = out["f16x2"][:, :rest.n_out]
+print("  fp16 x2 (3 terms)     %8.1f us  %6.1f TFLOP/s-equivalent (%.2fx); "
+      "max |f16x2 - fp32| %.3g; range flag %d" % (
+          t_f16 * 1e6, flops / t_f16 / 1e12, t32 / t_f16,
+          float((a - cc).abs().max()), int(status.item())))
