@@ -393,6 +393,13 @@ class Trainer(object):
         # native = False drives the same primitives from Python (the readable
         # composition below; tests hold the two to the same gradients).
         self.native = True
+        n_pool = sum(lc['type'] == 'scatter_max_point_set_pooling'
+                     for lc in config['model_kwargs']['layer_configs'])
+        if n_pool > 1:
+            # csrc/trainer.hip orchestrates ONE pooling stage (every shipped
+            # config); a second one (models.py:119-149 is generic) trains
+            # through the Python-driven composition of the same primitives
+            self.native = False
         self._native = None
         self._native_ws = None
         self._py_images_stale = True
@@ -827,23 +834,35 @@ class Trainer(object):
         for lc in self.config['model_kwargs']['layer_configs'][:-1]:
             scope, kw, lvl = lc['scope'], lc['kwargs'], lc['graph_level']
             if lc['type'] == 'scatter_max_point_set_pooling':
-                if h is not None:
-                    # (inference runs it: gnn.PointSetPooling's wide-feature
-                    # path; no shipped config trains one)
-                    raise NotImplementedError(
-                        "training step: a PointSetPooling above the first "
-                        "stage (more than one pooling level)")
                 e = edges[lvl]
                 k = int(kps[lvl].shape[0])
-                feat = torch.empty((int(e.shape[0]), 16), dtype=torch.float32,
-                                   device=dev)
-                _lib.check(lib.pgnn_pool_features_fwd(
-                    _lib.ptr(input_v), int(input_v.shape[1]),
-                    _lib.ptr(coords[lvl]), _lib.ptr(kps[lvl]), _lib.ptr(e),
-                    int(e.shape[0]), _lib.ptr(feat), st),
-                    "pgnn_pool_features_fwd")
                 names = mlp_names(scope + '/extract_vertex_features',
                                   len(kw['point_MLP_depth_list']))
+                upper = None
+                if h is None:
+                    feat = torch.empty((int(e.shape[0]), 16),
+                                       dtype=torch.float32, device=dev)
+                    _lib.check(lib.pgnn_pool_features_fwd(
+                        _lib.ptr(input_v), int(input_v.shape[1]),
+                        _lib.ptr(coords[lvl]), _lib.ptr(kps[lvl]), _lib.ptr(e),
+                        int(e.shape[0]), _lib.ptr(feat), st),
+                        "pgnn_pool_features_fwd")
+                else:
+                    # a pooling level above the first (models.py:119-149 is
+                    # generic; no shipped config has one): the edge rows
+                    # [h[src], x[src] - x[kp[dst]]] of the previous level's
+                    # features are materialised, as gnn.PointSetPooling's
+                    # wide-feature path does
+                    n_feat = self.fc[names[0]].k_in - 3
+                    feat = torch.empty((int(e.shape[0]),
+                                        padded_width(n_feat + 3)),
+                                       dtype=torch.float32, device=dev)
+                    _lib.check(lib.pgnn_pool_features_wide_fwd(
+                        _lib.ptr(h), h.stride(0), n_feat,
+                        _lib.ptr(coords[lvl]), _lib.ptr(kps[lvl]), _lib.ptr(e),
+                        int(e.shape[0]), _lib.ptr(feat), feat.stride(0), st),
+                        "pgnn_pool_features_wide_fwd")
+                    upper = (e, n_feat, int(h.shape[0]), int(h.shape[1]))
                 acts = [feat]
                 for n in names:
                     acts.append(self.fc_fwd(n, acts[-1], True))
@@ -855,7 +874,8 @@ class Trainer(object):
                 for n in onames:
                     oacts.append(self.fc_fwd(n, oacts[-1], True))
                 h = oacts[-1]
-                saved.append(('pool', names, acts, dst, agg, onames, oacts))
+                saved.append(('pool', names, acts, dst, agg, onames, oacts,
+                              upper))
             elif lc['type'] == 'scatter_max_graph_auto_center_net':
                 e = edges[lvl]
                 x = coords[lvl]
@@ -1068,24 +1088,43 @@ class Trainer(object):
                     dh_in[:, :c] += d[:, :c]
                 dh = dh_in
             else:
-                _, names, acts, dst, agg, onames, oacts = item
+                _, names, acts, dst, agg, onames, oacts, upper = item
                 d = dh
                 for i in range(len(onames) - 1, -1, -1):
                     d = self.fc_bwd(onames[i], oacts[i], oacts[i + 1], d, True)
+                # (the gradient w.r.t. the stage's input rows is wanted only
+                # above the first level; acts[0] is a gathered input, not a
+                # ReLU output: no mask there)
                 if self.sparse_adjoint and self.fc[names[-1]].wt is not None:
-                    g = self._segmax_fc_bwd(names[-1], acts[-1], dst, agg, d,
-                                            acts[-2])
+                    first = len(names) == 1
+                    g = self._segmax_fc_bwd(
+                        names[-1], acts[-1], dst, agg, d, acts[-2],
+                        need_dx=not first or upper is not None,
+                        mask_x=not first)
                     dense_from = len(names) - 2
                 else:
                     g = self._scatter_max_bwd(acts[-1], dst, agg, d)
                     dense_from = len(names) - 1
                 for i in range(dense_from, -1, -1):
                     g = self.fc_bwd(names[i], acts[i], acts[i + 1], g,
-                                    relu=False, need_dx=i > 0)
+                                    relu=False,
+                                    need_dx=i > 0 or upper is not None)
                     if i > 0:
                         _lib.check(lib.pgnn_relu_mask_mul(
                             _lib.ptr(g), _lib.ptr(acts[i]), g.numel(), st),
                             "pgnn_relu_mask_mul")
+                if upper is not None:
+                    # adjoint of the gather h[src]: dh_prev[src] += g[:, :n]
+                    # (the coordinate columns behind them have no parameters
+                    # upstream)
+                    e, n_feat, k_prev, w_prev = upper
+                    src = e[:, 0].contiguous()
+                    dh = torch.zeros((k_prev, w_prev), dtype=torch.float32,
+                                     device=dev)
+                    _lib.check(lib.pgnn_scatter_sum_f32(
+                        _lib.ptr(g), g.stride(0), _lib.ptr(src),
+                        int(src.shape[0]), n_feat, k_prev, _lib.ptr(dh),
+                        dh.stride(0), 0, None, st), "pgnn_scatter_sum_f32")
         self._saved = None
 
     # ---- one training step ----------------------------------------------------------

@@ -47,6 +47,8 @@ def model_config(num_classes=4, first_width=300):
             "kwargs": {"activation_type": "ReLU", "normalization_type": "NONE"}}
     return {
         "num_classes": num_classes,
+        "loss": {"cls_loss_type": "softmax", "cls_loss_weight": 0.1,
+                 "loc_loss_weight": 10.0},
         "model_name": "multi_layer_fast_local_graph_model_v2",
         "model_kwargs": {
             "layer_configs": [pooling(0, "layer1", [32, 64, 128, first_width],

@@ -261,6 +261,60 @@ def test_predict_on_two_pooling_levels(dev, first_width):
         np.abs(logits.cpu().numpy() - lg).max()))
 
 
+@pytest.mark.parametrize("first_width,sparse", [(300, True), (300, False),
+                                                (8, True)])
+def test_training_step_through_two_pooling_levels(dev, first_width, sparse):
+    """The training step (models.py:170-311, train.py:225-234 differentiate
+    whatever models.py:119-149 builds) on the two-pooling-level model: every
+    variable's gradient of (cls + loc) against float64 autograd
+    (oracle/train_oracle.py), for the sparse and the dense scatter-max
+    adjoint, and with a narrow first level.  The second stage's backward goes
+    through the gather's adjoint (scatter-add of the edge rows' gradient to the
+    previous level's vertices)."""
+    from pointgnn_amd import graph_gen, train, weights
+    from oracle import train_oracle as to
+    g = gold()
+    xyz = g["small_xyz"]
+    _, inten = synthetic_cloud(seed=0, preset="small")
+    cfg = model_config(first_width=first_width)
+    params = weights.init_params(cfg, seed=4, bias_scale=0.1)
+    coords, kps, edges = graph_gen.gen_multi_level_local_graph_v3(
+        T(xyz, dev), BASE_VOXEL, LEVEL_CONFIGS, downsample_method='center')
+    c_np = [c.cpu().numpy() for c in coords]
+    k_np = [k.cpu().numpy() for k in kps]
+    e_np = [e.cpu().numpy() for e in edges]
+    k = len(c_np[-1])
+    rng = np.random.default_rng(9)
+    labels = rng.integers(0, cfg["num_classes"], (k, 1)).astype(np.int32)
+    boxes = rng.standard_normal((k, 1, 7)).astype(np.float32)
+    valid = (rng.random((k, 1, 1)) < 0.5).astype(np.float32)
+    batch = (inten, c_np, k_np, e_np, labels, boxes, valid)
+    tr = train.Trainer(cfg, params=params, device=dev)
+    assert not tr.native        # the native step orchestrates ONE pooling stage
+    tr.sparse_adjoint = sparse
+    out = tr.train_step(batch, apply=False)
+    loss, g_ref, _ = to.step_gradients(params, cfg, [batch])
+    assert abs(out['cls_loss'] - loss['cls_loss']) < 1e-4 * max(1, loss['cls_loss'])
+    assert abs(out['loc_loss'] - loss['loc_loss']) < 1e-4 * max(1, loss['loc_loss'])
+    got = tr.grad_dict()
+    worst = (0.0, 0.0, "")
+    for n, ref in g_ref.items():
+        scale = np.abs(ref).max() + 1e-12
+        e_max = np.abs(got[n] - ref).max() / scale
+        e_fro = np.linalg.norm(got[n] - ref) / (np.linalg.norm(ref) + 1e-12)
+        worst = max(worst, (e_fro, e_max, n))
+        assert e_fro < 2e-3, "%s: Frobenius rel err %.3g" % (n, e_fro)
+        assert e_max < 1.2e-2, "%s: max-entry rel err %.3g" % (n, e_max)
+    # the first level's variables get their gradient through the second
+    # level's gather: not zero, not garbage
+    first = [n for n in g_ref if n.startswith("layer1/")]
+    assert first and all(np.abs(got[n]).max() > 0 for n in first)
+    print("two pooling levels (first width %d, %s adjoint): worst Frobenius "
+          "%.3g (max-entry %.3g) at %s" % (
+              first_width, "sparse" if sparse else "dense", worst[0], worst[1],
+              worst[2]))
+
+
 def test_capacity_form_refuses_a_second_pooling_level(dev):
     from pointgnn_amd import graph_gen
     g = gold()
