@@ -114,9 +114,9 @@ inline size_t graph_lds_pad() { return (size_t)g_graph_lds_pad; }
 // launches of at most 8 workgroups are placed on them at once; the
 // dispatcher does not route the later workgroups of a larger grid around
 // CUs that lack the LDS -- they wait for the persistent kernel to end
-// (tools/hog_probe.py) -- and a persistent kernel of (CUs - 8) workgroups
+// (profiles/r03_pipeline_probes.txt) -- and a persistent kernel of (CUs - 8) workgroups
 // starts at once beside up to 8 resident builder workgroups, not beside more
-// (tools/hog_probe2.py).
+// (same file).
 extern int g_graph_max_wgs;
 inline unsigned graph_grid(int64_t natural) {
   if (natural < 1) natural = 1;

@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ counters of the split-bf16 edge kernel (and the fp32 one beside it) on the
+# SQ counters of the 16-bit edge kernels (bf16x3, f16x2; the fp32 one beside them) on the
 # bench frame's first GNN iteration (tools/bf16x3_bench.py): one counter set per
 # rocprofv3 run, kernel-trace only.  usage: tools/pmc_b16.sh <result file> [sets]
 cd "$(dirname "$0")/.."
@@ -23,7 +23,8 @@ for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_M
   python - "$db" >> $RES <<'EOF2'
 import sqlite3, sys
 db = sqlite3.connect(sys.argv[1])
-for pat, tag in (("edge_ws_bf16x3_kernel", "b16x3"), ("edge_ws_kernel", "f32")):
+for pat, tag in (("edge_ws_bf16x3_kernel", "b16x3"), ("edge_ws_f16x2_kernel", "f16x2"),
+                 ("edge_ws_kernel", "f32")):
     rows = db.execute("select counter_name, count(*), avg(value) from counters_collection "
                       "where kernel_name like ? group by counter_name", ("%" + pat + "%",))
     for c, cnt, avg in rows:

@@ -1,10 +1,10 @@
 #!/bin/bash
-# Round-3 evidence session (via gpurun) -> gpurun_out/r03/ (copy the summaries
-# into profiles/r03_*).  usage: tools/r03_final.sh [tests] [bench] [prof] [pmc]
+# Round-5 evidence session (via gpurun) -> gpurun_out/r05/ (copy the summaries
+# into profiles/r05_*).  usage: tools/r05_final.sh [tests] [bench] [prof] [pmc]
 set -u
 cd "$(dirname "$0")/.."
 ROOT=$PWD
-OUT=$ROOT/gpurun_out/r03
+OUT=$ROOT/gpurun_out/r05
 mkdir -p $OUT
 export TMPDIR=/tmp
 MODES=${*:-tests bench prof pmc}
@@ -14,10 +14,10 @@ echo "nproc=$(nproc) mem=$(free -g | awk '/Mem/{print $2}')G $(lscpu | grep 'Mod
 for m in $MODES; do
 case $m in
 tests)
-  timeout 1500 python -m pytest tests -m gpu -q -s -p no:cacheprovider > $OUT/tests.log 2>&1
+  timeout 2400 python -m pytest tests -m gpu -q -s -p no:cacheprovider > $OUT/tests.log 2>&1
   echo "TESTS rc=$? $(tail -1 $OUT/tests.log)" >> $S
   grep -E "^(FAILED|ERROR)" $OUT/tests.log | head -30 >> $S
-  grep -E "reference TF graph|max\|dlogit\||worst" $OUT/tests.log | cut -c1-300 >> $S
+  grep -E "reference TF graph|max\|dlogit\||worst|max error vs float64" $OUT/tests.log | cut -c1-300 >> $S
   timeout 300 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1
   echo "SMOKE rc=$? $(grep '\[smoke\]' $OUT/smoke.log | tail -1)" >> $S
   ;;
@@ -52,6 +52,7 @@ prof)
   done
   ;;
 pmc)
+  bash tools/pmc_b16.sh $OUT/pmc_sq_16bit.txt 4 > $OUT/pmc_sq_16bit.log 2>&1
   PMC_SETS=1 bash tools/pmc_sq.sh car_600k > $OUT/pmc_sq_infer.log 2>&1
   cp gpurun_out/pmc_sq_car_600k.txt $OUT/pmc_sq_infer.txt 2>/dev/null
   PMC_SETS=1 PMC_CMD="python $ROOT/bench.py --train --steps 6 --warmup 3 --frames 4" bash tools/pmc_sq.sh train > $OUT/pmc_sq_train.log 2>&1
