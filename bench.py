@@ -516,24 +516,34 @@ def cpu_baseline(cfg, params, xyz, inten, budget_s=20.0):
     sub_coords = [coords[0], coords[1][:k_sub], coords[2][:k_sub]]
     sub_kps = [kps[0][:k_sub], kps[1][:k_sub]]
     sub_edges = [e0[m0], e1[m1]]
-    gn.predict(params, cfg, inten, sub_coords, sub_kps, sub_edges)  # warm-up
-    t_gnns = []
-    for _ in range(3):
-        t = time.perf_counter()
-        gn.predict(params, cfg, inten, sub_coords, sub_kps, sub_edges)
-        t_gnns.append(time.perf_counter() - t)
+    # torch's CPU kernels stop scaling long before this host's core count
+    # (car_600k frame on 256 hardware threads: 15 s at 128 intra-op threads,
+    # 6.8 at 64, 4.4 at 32, 5.0 at 16; inside a NUMA-bound rank the default
+    # oversubscribes the allowed CPUs): 32 threads, 128k-row chunks
+    n_thr = _torch.get_num_threads()
+    _torch.set_num_threads(min(32, len(os.sched_getaffinity(0))))
+    gn.CHUNK_ROWS = 1 << 17
+    try:
+        gn.predict(params, cfg, inten, sub_coords, sub_kps, sub_edges)  # warm-up
+        t_gnns = []
+        for _ in range(3):
+            t = time.perf_counter()
+            gn.predict(params, cfg, inten, sub_coords, sub_kps, sub_edges)
+            t_gnns.append(time.perf_counter() - t)
+        threads = int(_torch.get_num_threads())
+    finally:
+        _torch.set_num_threads(n_thr)
     t_gnn_sub = float(np.median(t_gnns))
     sub_flops = algorithmic_flops_per_frame(cfg, k_sub, int(m0.sum()),
                                             int(m1.sum()))
     t_gnn_full = t_gnn_sub * total / max(sub_flops, 1)
-    threads = int(_torch.get_num_threads())
     out = {
         "value": 1.0 / (t_graph + t_gnn_full), "unit": "frames/s",
         "cores": int(threads), "kind": "port",
         "sample": "1 frame (%s seed of the headline pool): graph build with "
                   "the reference's sklearn calls, single-threaded as shipped, "
                   "1 warm-up + median of 5 (%.2f s; min %.2f, max %.2f); GNN "
-                  "oracle (torch-CPU fp32 in 32k-row chunks, %d intra-op "
+                  "oracle (torch-CPU fp32 in 128k-row chunks, %d intra-op "
                   "threads; NumPy sgemm probe %.0f GFLOP/s) on "
                   "the sub-graph of the first %d of %d keypoints (%.1f%% of "
                   "the frame's FLOPs), 1 warm-up + median of 3 (%.2f s), "

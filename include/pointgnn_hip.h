@@ -206,6 +206,24 @@ int pgnn_cap_neighbors_fill(const int32_t *offsets, const int32_t *edges,
                             uint64_t seed, const int32_t *new_offsets,
                             int32_t *new_edges, int64_t new_capacity,
                             void *stream);
+/* The cap in capacity form (no host read), for a level built by
+ * pgnn_radius_graph_dyn(_query)(_f64): takes that call's workspace (the CSR
+ * offsets it left there; same points_cap / centers_cap), its edge rows and its
+ * record n_edges_dev[2]; writes new_offsets[centers_cap + 1], the surviving
+ * rows (same rows, same order as _count + _fill with this seed) up to
+ * `new_capacity`, and the capped list's record n_new_dev[2] = {rows written,
+ * rows required}.  If the UNCAPPED list overflowed its own capacity the capped
+ * record reads {0, required}: the level is flagged the usual way (required >
+ * written) and the caller rebuilds it. */
+int pgnn_radius_graph_dyn_cap(const void *workspace, size_t workspace_bytes,
+                              int64_t points_cap, int64_t centers_cap,
+                              const int32_t *edges, int64_t edge_capacity,
+                              const int32_t *n_edges_dev /* [2], device */,
+                              int32_t max_neighbors, uint64_t seed,
+                              int32_t *new_offsets, int32_t *new_edges,
+                              int64_t new_capacity,
+                              int32_t *n_new_dev /* [2], device */,
+                              void *stream);
 
 /* ---- keypoints ----------------------------------------------------------
  * 'center' mode = multi_layer_downsampling_select (graph_gen.py:49-90) for ONE

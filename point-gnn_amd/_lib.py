@@ -132,6 +132,9 @@ _SIGNATURES = {
     "pgnn_cap_neighbors_count": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp]),
     "pgnn_cap_neighbors_fill": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_u64, c_vp,
                                         c_vp, c_i64, c_vp]),
+    "pgnn_radius_graph_dyn_cap": (c_i32, [c_vp, c_sz, c_i64, c_i64, c_vp, c_i64,
+                                          c_vp, c_i32, c_u64, c_vp, c_vp, c_i64,
+                                          c_vp, c_vp]),
     "pgnn_keypoints_workspace_bytes": (c_sz, [c_i64]),
     "pgnn_voxel_keypoints_center": (c_i32, [c_vp, c_i64, c_f64, c_vp, c_sz,
                                             c_vp, c_vp, c_vp, c_vp, c_vp]),

@@ -356,9 +356,28 @@ __global__ void cap_counts_kernel(const int32_t *__restrict__ offsets,
                                   int32_t *__restrict__ counts) {
   graph_prio();
   int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= n) return;
+  if (q > n) return;
+  if (q == n) {  // the scan over n + 1 entries leaves the total here
+    counts[n] = 0;
+    return;
+  }
   int c = offsets[q + 1] - offsets[q];
   counts[q] = c > cap ? cap : c;
+}
+
+// capacity form: the capped list's record {rows written, rows required}.  An
+// uncapped list that did not fit ITS capacity makes the capped one unusable
+// whatever its size: rows written = 0 < rows required flags the level.
+__global__ void cap_total_kernel(const int32_t *__restrict__ new_total,
+                                 const int32_t *__restrict__ n_in,
+                                 int64_t capacity, int32_t *__restrict__ n_out) {
+  graph_prio();
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const int32_t e = *new_total;
+    const bool in_ok = n_in[1] <= n_in[0];
+    n_out[0] = !in_ok ? 0 : ((int64_t)e < capacity ? e : (int32_t)capacity);
+    n_out[1] = e;
+  }
 }
 
 // One wave per centre.  Fan-in <= cap: copy.  Otherwise keep the `cap` edges
@@ -369,12 +388,13 @@ __global__ __launch_bounds__(256) void cap_fill_kernel(
     const int32_t *__restrict__ offsets, const int32_t *__restrict__ edges,
     int64_t n, int32_t cap, uint64_t seed,
     const int32_t *__restrict__ new_offsets, int32_t *__restrict__ new_edges,
-    int64_t capacity) {
+    int64_t capacity, int64_t in_capacity) {
   graph_prio();
   const int lane = threadIdx.x & 63;
   const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q >= n) return;
   const int s = offsets[q], e = offsets[q + 1], cnt = e - s;
+  if ((int64_t)e > in_capacity) return;  // rows the uncapped list does not hold
   int64_t o = new_offsets[q];
   if (cnt <= cap) {
     for (int i = lane; i < cnt; i += 64) {
@@ -1352,10 +1372,8 @@ extern "C" int pgnn_cap_neighbors_count(const int32_t *offsets,
   hipStream_t stream = (hipStream_t)stream_;
   PGNN_REQUIRE(offsets && new_offsets && n_centers >= 0 && max_neighbors > 0,
                PGNN_E_INVALID, "cap_neighbors_count: bad argument");
-  PGNN_HIP(hipMemsetAsync(new_offsets + n_centers, 0, 4, stream));
-  if (n_centers == 0) return 0;
   hipLaunchKernelGGL(cap_counts_kernel,
-                     dim3((unsigned)((n_centers + 255) / 256)), dim3(256), graph_lds_pad(),
+                     dim3((unsigned)((n_centers + 256) / 256)), dim3(256), graph_lds_pad(),
                      stream, offsets, n_centers, max_neighbors, new_offsets);
   PGNN_HIP(hipGetLastError());
   // exclusive scan over n_centers + 1 entries leaves the total in the last one
@@ -1379,7 +1397,53 @@ extern "C" int pgnn_cap_neighbors_fill(const int32_t *offsets,
                "cap_neighbors_fill: null edges");
   hipLaunchKernelGGL(cap_fill_kernel, dim3((unsigned)((n_centers + 3) / 4)),
                      dim3(256), graph_lds_pad(), stream, offsets, edges, n_centers,
-                     max_neighbors, seed, new_offsets, new_edges, new_capacity);
+                     max_neighbors, seed, new_offsets, new_edges, new_capacity,
+                     (int64_t)0x7fffffff);
+  PGNN_HIP(hipGetLastError());
+  return 0;
+  PGNN_GUARD_END
+}
+
+extern "C" int pgnn_radius_graph_dyn_cap(
+    const void *workspace, size_t workspace_bytes, int64_t points_cap,
+    int64_t centers_cap, const int32_t *edges, int64_t edge_capacity,
+    const int32_t *n_edges_dev, int32_t max_neighbors, uint64_t seed,
+    int32_t *new_offsets, int32_t *new_edges, int64_t new_capacity,
+    int32_t *n_new_dev, void *stream_) {
+  PGNN_GUARD_BEGIN
+  hipStream_t stream = (hipStream_t)stream_;
+  PGNN_REQUIRE(points_cap >= 0 && centers_cap >= 0 && edge_capacity >= 0 &&
+                   new_capacity >= 0 && new_capacity <= 0x7fffffff &&
+                   max_neighbors > 0,
+               PGNN_E_INVALID, "radius_graph_dyn_cap: bad argument");
+  PGNN_REQUIRE(workspace && n_edges_dev && new_offsets && n_new_dev &&
+                   (edge_capacity == 0 || edges) &&
+                   (new_capacity == 0 || new_edges),
+               PGNN_E_INVALID, "radius_graph_dyn_cap: null pointer");
+  PGNN_REQUIRE(workspace_bytes >= pgnn_radius_graph_dyn_workspace_bytes(
+                                      points_cap, centers_cap),
+               PGNN_E_WORKSPACE, "radius_graph_dyn_cap: workspace too small");
+  // the CSR offsets pgnn_radius_graph_dyn(_query) left behind its tables
+  const int32_t *offsets = reinterpret_cast<const int32_t *>(
+      (const char *)workspace +
+      pgnn_radius_graph_workspace_bytes(points_cap, centers_cap));
+  hipLaunchKernelGGL(cap_counts_kernel,
+                     dim3((unsigned)((centers_cap + 256) / 256)), dim3(256),
+                     graph_lds_pad(), stream, offsets, centers_cap,
+                     max_neighbors, new_offsets);
+  PGNN_HIP(hipGetLastError());
+  int rc = exclusive_scan_inplace_i32(new_offsets, centers_cap + 1, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(cap_total_kernel, dim3(1), dim3(64), graph_lds_pad(), stream,
+                     (const int32_t *)(new_offsets + centers_cap), n_edges_dev,
+                     new_capacity, n_new_dev);
+  if (centers_cap > 0 && new_capacity > 0 && edge_capacity > 0) {
+    hipLaunchKernelGGL(cap_fill_kernel, dim3((unsigned)((centers_cap + 3) / 4)),
+                       dim3(256), graph_lds_pad(), stream, offsets, edges,
+                       centers_cap, max_neighbors, seed,
+                       (const int32_t *)new_offsets, new_edges, new_capacity,
+                       edge_capacity);
+  }
   PGNN_HIP(hipGetLastError());
   return 0;
   PGNN_GUARD_END

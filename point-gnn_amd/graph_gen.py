@@ -32,6 +32,7 @@ from . import _lib
 __all__ = ["gen_disjointed_rnn_local_graph_v3",
            "gen_multi_level_local_graph_v3", "get_graph_generate_fn",
            "multi_layer_downsampling_select", "multi_layer_downsampling_random",
+           "gen_multi_level_local_graph_v3_one_read",
            "CountHints", "FrameCounts"]
 
 
@@ -42,22 +43,37 @@ class CountHints(object):
     kernel choice and grid sizes -- and `edge_caps[l]` the rows allocated for
     level l's edge list (a frame that needs more reports it, see FrameCounts).
     `update(k, edges)` folds a finished frame's sizes in: hints follow the
-    last frame, capacities keep 2 x the largest list seen (8 bytes a row)."""
+    last frame, capacities keep 2 x the largest list seen (8 bytes a row).
+    Levels with a fan-in cap (training kwargs) also keep `raw_caps[l]`, the
+    rows allocated for the list BEFORE the cap."""
 
     MIN_EDGE_CAP = 1 << 16
 
-    def __init__(self, k=0, edges=(), edge_caps=()):
+    def __init__(self, k=0, edges=(), edge_caps=(), raw_caps=()):
         self.k = int(k)
         self.edges = [int(e) for e in edges]
         self.edge_caps = [int(c) for c in edge_caps]
+        self.raw_caps = [int(c) for c in raw_caps]
 
-    def update(self, k, edges):
+    def _grown(self, caps, sizes):
+        caps = list(caps) + [0] * (len(sizes) - len(caps))
+        return [max(c, self.MIN_EDGE_CAP, 2 * int(e) + 1024)
+                for c, e in zip(caps, sizes)]
+
+    def update(self, k, edges, raw_edges=None):
         self.k = int(k)
         self.edges = [int(e) for e in edges]
-        caps = list(self.edge_caps) + [0] * (len(edges) - len(self.edge_caps))
-        self.edge_caps = [max(c, self.MIN_EDGE_CAP, 2 * int(e) + 1024)
-                          for c, e in zip(caps, edges)]
+        self.edge_caps = self._grown(self.edge_caps, edges)
+        if raw_edges is not None:
+            self.raw_caps = self._grown(self.raw_caps, raw_edges)
         return self
+
+    def raw_cap(self, level):
+        """rows for level's uncapped list: what was seen, else 2 x the capped
+        capacity (most centres of a training graph sit below the cap)"""
+        if level < len(self.raw_caps) and self.raw_caps[level] > 0:
+            return self.raw_caps[level]
+        return 2 * self.cap(level)
 
     def cap(self, level):
         if level < len(self.edge_caps) and self.edge_caps[level] > 0:
@@ -71,7 +87,9 @@ class CountHints(object):
 class FrameCounts(object):
     """The sizes of one capacity-form frame, in device memory until `read()`:
     tensor = int32 [2 + 2 L]: K, kd-tree tie-order status, then per level
-    (rows written, rows required).  `read()` is the frame's ONE host read (it
+    (rows written, rows required); with a fan-in cap on any level L more pairs
+    follow, the same record for every level's list BEFORE the cap (zeros for
+    levels without one).  `read()` is the frame's ONE host read (it
     waits for the stream that built the graph); the caller does it when it
     takes the frame's results, not before the model runs."""
 
@@ -98,6 +116,15 @@ class FrameCounts(object):
         """Edge rows each level needs (== rows written unless overflowed)."""
         v = self.read()
         return [v[3 + 2 * l] for l in range(len(self.edge_caps))]
+
+    @property
+    def raw_edges(self):
+        """Rows each level's uncapped list needs (None without any cap)."""
+        v = self.read()
+        n = len(self.edge_caps)
+        if len(v) < 2 + 4 * n:
+            return None
+        return [v[3 + 2 * n + 2 * l] for l in range(n)]
 
     @property
     def overflowed(self):
@@ -291,16 +318,17 @@ def radius_graphs_device(queries):
 
 
 def radius_graph_dyn_device(points, centers, radius, scale, edge_cap,
-                            n_edges_out, edge_hint=0):
+                            n_edges_out, edge_hint=0, fan_in=None):
     """Capacity form (pgnn_radius_graph_dyn): no host read.  `points` /
     `centers` may be capacity-form tensors (tagged with a DeviceCount);
     `n_edges_out` is the int32 [2] device slice that receives (rows written,
-    rows required).  Returns the [edge_cap, 2] edge tensor tagged with its
-    count."""
+    rows required).  `fan_in` = (num_neighbors, seed, raw_cap, n_raw_out): the
+    training-time cap (graph_gen.py:210-214), also without a read.  Returns
+    the [edge_cap, 2] edge tensor tagged with its count."""
     cp, cc = _lib.count_of(points), _lib.count_of(centers)
     points, centers, _ = _same_precision(points, centers)
     job = _RadiusDynJob(points, cp, int(centers.shape[0]), radius, scale,
-                        edge_cap, n_edges_out, edge_hint)
+                        edge_cap, n_edges_out, edge_hint, fan_in)
     job.grid()
     return job.query(centers, cc)
 
@@ -311,10 +339,13 @@ class _RadiusDynJob(object):
     the stream current at construction; grid() and query() enqueue on the
     stream current at THEIR call, so a caller can put the grid stage -- which
     needs the points only -- on a side stream while the centres are still
-    being computed.  `points` and the later `centers` must have one dtype."""
+    being computed.  `points` and the later `centers` must have one dtype.
+    With `fan_in` = (num_neighbors, seed, raw_cap, n_raw_out) the query stage
+    writes the uncapped list into its own [raw_cap, 2] buffer (record ->
+    n_raw_out) and pgnn_radius_graph_dyn_cap selects from it into `edges`."""
 
     def __init__(self, points, points_count, centers_cap, radius, scale,
-                 edge_cap, n_edges_out, edge_hint=0):
+                 edge_cap, n_edges_out, edge_hint=0, fan_in=None):
         self.lib = _lib.load()
         self.points, self.cp = points, points_count
         self.wide = points.dtype == torch.float64
@@ -331,6 +362,16 @@ class _RadiusDynJob(object):
                                  device=dev)
         self.n_edges_out = n_edges_out
         self.edge_hint = edge_hint
+        self.fan_in = None
+        if fan_in is not None and int(fan_in[0]) > 0:
+            k, seed, raw_cap, n_raw_out = fan_in
+            self.fan_in = (int(k), int(seed) & 0xFFFFFFFFFFFFFFFF)
+            self.raw_cap = int(raw_cap)
+            self.raw = torch.empty((self.raw_cap, 2), dtype=torch.int32,
+                                   device=dev)
+            self.n_raw_out = n_raw_out
+            self.new_off = torch.empty(self.n_c + 1, dtype=torch.int32,
+                                       device=dev)
 
     def grid(self):
         _lib.check((self.lib.pgnn_radius_graph_dyn_grid_f64 if self.wide else
@@ -349,9 +390,19 @@ class _RadiusDynJob(object):
             _lib.ptr(self.points), self.n_p, _lib.ptr(centers), self.n_c,
             _lib.ptr(centers_count.dev if centers_count else None),
             self.radius, self.sp, _lib.ptr(self.ws), self.ws_bytes,
-            _lib.ptr(self.edges), self.edge_cap, _lib.ptr(self.n_edges_out),
+            _lib.ptr(self.raw if self.fan_in else self.edges),
+            self.raw_cap if self.fan_in else self.edge_cap,
+            _lib.ptr(self.n_raw_out if self.fan_in else self.n_edges_out),
             _lib.stream_ptr()),
             "pgnn_radius_graph_dyn_query")
+        if self.fan_in:
+            _lib.check(self.lib.pgnn_radius_graph_dyn_cap(
+                _lib.ptr(self.ws), self.ws_bytes, self.n_p, self.n_c,
+                _lib.ptr(self.raw), self.raw_cap, _lib.ptr(self.n_raw_out),
+                self.fan_in[0], self.fan_in[1], _lib.ptr(self.new_off),
+                _lib.ptr(self.edges), self.edge_cap,
+                _lib.ptr(self.n_edges_out), _lib.stream_ptr()),
+                "pgnn_radius_graph_dyn_cap")
         self.edges._pgnn_sorted = 1
         return _lib.tag_count(
             self.edges,
@@ -765,22 +816,39 @@ def _multi_level_graph_deferred(points_xyz, base_voxel_size, level_configs,
         raise ValueError("deferred_counts needs device tensors (a NumPy "
                          "result has to know its size)")
     for cfg in level_configs:
-        if cfg['graph_gen_method'] != 'disjointed_rnn_local_graph_v3' or \
-                cfg['graph_gen_kwargs'].get('num_neighbors', -1) > 0:
+        if cfg['graph_gen_method'] != 'disjointed_rnn_local_graph_v3':
             raise NotImplementedError(
-                "deferred_counts: levels with a fan-in cap (training kwargs) "
-                "or another generator have no capacity form")
+                "deferred_counts: generator %r has no capacity form"
+                % (cfg['graph_gen_method'],))
     n_levels = len(level_configs)
     dev = _device()
-    counts = _zero_counts(2 + 2 * n_levels, dev)
+    # fan-in caps (training kwargs; any other method name skips the cap like
+    # the reference, graph_gen.py:210): seeds drawn here, on the host, in
+    # level order -- the draws the host-sized calls would make
+    fan_k = [int(cfg['graph_gen_kwargs'].get('num_neighbors', -1) or -1)
+             if cfg['graph_gen_kwargs'].get(
+                 'neighbors_downsample_method', 'random') == 'random' else -1
+             for cfg in level_configs]
+    capped = any(k > 0 for k in fan_k)
+    seeds = [None] * n_levels
+    counts = _zero_counts(2 + (4 if capped else 2) * n_levels, dev)
     caps = [hints.cap(l) for l in range(n_levels)]
     frame = FrameCounts(counts, caps)
+
+    def fan_in(l):
+        if fan_k[l] <= 0:
+            return None
+        if seeds[l] is None:
+            seeds[l] = int(np.random.randint(0, 2 ** 31 - 1))
+        at = 2 + 2 * n_levels + 2 * l
+        return (fan_k[l], seeds[l], hints.raw_cap(l), counts[at:at + 2])
 
     def level_job(l, points, centers_cap):
         kw = level_configs[l]['graph_gen_kwargs']
         return _RadiusDynJob(points, _lib.count_of(points), centers_cap,
                              kw['radius'], kw.get('scale'), caps[l],
-                             counts[2 + 2 * l:4 + 2 * l], hints.edge_hint(l))
+                             counts[2 + 2 * l:4 + 2 * l], hints.edge_hint(l),
+                             fan_in(l))
 
     # Overlapped build (single-frame latency): the level-0 cell grid needs
     # the cloud only, so it runs on a side stream BESIDE the keypoint
@@ -791,8 +859,10 @@ def _multi_level_graph_deferred(points_xyz, base_voxel_size, level_configs,
     # function returns, so the caching allocator's stream rule holds.
     p = _to_dev(points_xyz)[0]
     n = int(p.shape[0])
-    overlap = bool(overlap) and n > 0 and p.dtype == torch.float32 and \
-        n_levels >= 1 and level_configs[0]['graph_level'] == 0 and \
+    # (with a cap the levels' seeds are drawn where the host-sized calls draw
+    # them -- after the keypoints' draws -- so the jobs cannot be made early)
+    overlap = bool(overlap) and not capped and n > 0 and \
+        p.dtype == torch.float32 and n_levels >= 1 and level_configs[0]['graph_level'] == 0 and \
         not np.isclose(scales[0], 0)
     job0 = ov = None
     if overlap:
@@ -837,11 +907,47 @@ def _multi_level_graph_deferred(points_xyz, base_voxel_size, level_configs,
             edges_list[l] = radius_graph_dyn_device(
                 coords[lvl], coords[lvl + 1], cfg['graph_gen_kwargs']['radius'],
                 cfg['graph_gen_kwargs'].get('scale'), caps[l],
-                counts[2 + 2 * l:4 + 2 * l], hints.edge_hint(l))
+                counts[2 + 2 * l:4 + 2 * l], hints.edge_hint(l), fan_in(l))
     for e in edges_list:
         _lib.count_of(e).frame = frame
     # job0 / side_jobs (their workspaces) die here: after the join was enqueued
     return coords, kps, edges_list
+
+
+def gen_multi_level_local_graph_v3_one_read(points_xyz, hints, **kwargs):
+    """gen_multi_level_local_graph_v3 for a caller that needs host-sized
+    tensors (the training fetch: label assignment, box encoding and the batch
+    concatenation all take sizes) but should not wait three times per frame:
+    the graph is built in capacity form -- fan-in cap included -- and ONE read
+    of the frame's record (K, edge counts) cuts the views.  `hints` (a
+    CountHints) is updated; a frame that overflows a capacity is rebuilt
+    host-sized from the same random state, so the result is the one the plain
+    call returns for the same NumPy RNG state either way."""
+    state = np.random.get_state()
+    coords, kps, edges = gen_multi_level_local_graph_v3(
+        points_xyz, deferred_counts=hints, **kwargs)
+    frame = _lib.count_of(edges[0]).frame
+    host = frame.read()
+    check_kd_status(frame.kd_status)
+    hints.update(frame.k, frame.edges, frame.raw_edges)
+    if frame.overflowed:
+        after = np.random.get_state()
+        np.random.set_state(state)
+        out = gen_multi_level_local_graph_v3(points_xyz, **kwargs)
+        np.random.set_state(after)
+        return out
+    base = frame.tensor.storage_offset()
+
+    def cut(t):
+        c = _lib.count_of(t)
+        if c is None:
+            return t
+        v = t[:host[c.dev.storage_offset() - base]]
+        if getattr(t, '_pgnn_sorted', 0):
+            v._pgnn_sorted = 1
+        return v
+    return [cut(t) for t in coords], [cut(t) for t in kps], \
+        [cut(t) for t in edges]
 
 
 def get_graph_generate_fn(method_name):

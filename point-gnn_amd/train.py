@@ -138,7 +138,8 @@ _ASSIGN = {'yaw': 'assign_classaware_label_to_points',
                'assign_classaware_ped_and_cyc_label_to_points'}
 
 
-def fetch_data(dataset, frame_idx, config, train_config, aug_fn=None):
+def fetch_data(dataset, frame_idx, config, train_config, aug_fn=None,
+               graph_hints=None):
     """train.py:78-133 with every per-point step on the device: crop to the
     image, augmentations, training-mode graph, label assignment, box
     encoding.  Returns the 7-tuple `batch_data` / `Trainer.train_step` take
@@ -148,7 +149,12 @@ def fetch_data(dataset, frame_idx, config, train_config, aug_fn=None):
     first `xyz.dot(R.T)` on, and graph generation (voxel keys, radius
     predicate), label assignment and box encoding all see those float64
     coordinates (train.py:88-122); float32 / int32 happen last
-    (train.py:123-130)."""
+    (train.py:123-130).
+
+    `graph_hints` (a graph_gen.CountHints kept by the caller across frames):
+    the graph -- fan-in cap included -- is built in capacity form and its sizes
+    are read ONCE per frame instead of once per keypoint / count / cap stage
+    (same tensors for the same NumPy RNG state)."""
     from . import box_encoding, graph_gen, preprocess
     from .run import _input_features
     points = dataset.get_cam_points_in_image_with_rgb(
@@ -160,8 +166,13 @@ def fetch_data(dataset, frame_idx, config, train_config, aug_fn=None):
         aug_fn = preprocess.get_data_aug(
             train_config.get('data_aug_configs', []))
     points, labels = aug_fn(points, labels)
-    fn = graph_gen.get_graph_generate_fn(config['graph_gen_method'])
-    coords, kps, edges = fn(points.xyz, **config['graph_gen_kwargs'])
+    if graph_hints is not None and isinstance(points.xyz, torch.Tensor) and \
+            config['graph_gen_method'] == 'multi_level_local_graph_v3':
+        coords, kps, edges = graph_gen.gen_multi_level_local_graph_v3_one_read(
+            points.xyz, graph_hints, **config['graph_gen_kwargs'])
+    else:
+        fn = graph_gen.get_graph_generate_fn(config['graph_gen_method'])
+        coords, kps, edges = fn(points.xyz, **config['graph_gen_kwargs'])
     input_v = _input_features(config, points).contiguous()
     level = config['model_kwargs']['layer_configs'][-1]['graph_level']
     last_xyz = coords[level + 1]
@@ -209,6 +220,8 @@ def train_epochs(dataset, config, train_config, trainer=None, max_epoch=None,
     assert per_rank >= 1, "batch_size smaller than the number of ranks"
     meter = metrics_mod.StreamingMetrics(config['num_classes'],
                                          device=trainer.device)
+    from . import graph_gen
+    graph_hints = graph_gen.CountHints()
     if max_epoch is None:
         max_epoch = train_config['max_epoch']
 
@@ -234,8 +247,8 @@ def train_epochs(dataset, config, train_config, trainer=None, max_epoch=None,
         order = order.numpy()
         for b0 in range(0, n_samples - batch_size + 1, batch_size):
             mine = order[b0 + rank * per_rank:b0 + (rank + 1) * per_rank]
-            frames = [fetch_data(dataset, int(i), config, train_config, aug_fn)
-                      for i in mine]
+            frames = [fetch_data(dataset, int(i), config, train_config, aug_fn,
+                                 graph_hints) for i in mine]
             batch = batch_data(frames)
             results = trainer.train_step(batch)
             results['total_loss'] = results['cls_loss'] + \

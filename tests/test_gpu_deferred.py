@@ -82,6 +82,111 @@ def test_radius_graph_dyn_empty_and_zero_counts(dev):
     assert counts[2:4].tolist() == [0, 0]
 
 
+@pytest.mark.parametrize("wide", [False, True])
+def test_fan_in_cap_in_capacity_form_equals_count_fill(dev, wide):
+    """pgnn_radius_graph_dyn + pgnn_radius_graph_dyn_cap (the training-time
+    cap, graph_gen.py:210-214, with every size on the device) == the
+    host-sized radius graph + pgnn_cap_neighbors_count / _fill for the same
+    seed: same surviving rows, same order; an uncapped list that does not fit
+    ITS buffer flags the level."""
+    import torch
+    from pointgnn_amd import _lib, graph_gen as G
+    rng = np.random.default_rng(11)
+    dt = np.float64 if wide else np.float32
+    pts = (rng.random((5000, 3)) * [30, 3, 30]).astype(dt)
+    ctr = pts[rng.permutation(5000)[:700]].copy()
+    for r, k, seed in ((1.5, 8, 1234), (2.5, 64, 7), (1.0, 100000, 3)):
+        want, off = G.radius_graph_device(T(pts, dev), T(ctr, dev), r, None,
+                                          k, seed)
+        raw, _ = G.radius_graph_device(T(pts, dev), T(ctr, dev), r, None)
+        if k < 100:
+            assert want.shape[0] < raw.shape[0]       # the cap bites
+        fan = torch.diff(off.to(torch.int64))
+        assert int(fan.max()) <= k
+        pcap = np.concatenate([pts, rng.random((900, 3)).astype(dt) * 30])
+        ccap = np.concatenate([ctr, rng.random((200, 3)).astype(dt) * 30])
+        counts = torch.tensor([5000, 700, 0, 0, 0, 0], dtype=torch.int32,
+                              device=dev)
+        p = _lib.tag_count(T(pcap, dev), _lib.DeviceCount(counts[0:1], 5000))
+        c = _lib.tag_count(T(ccap, dev), _lib.DeviceCount(counts[1:2], 700))
+        cap = int(want.shape[0]) + 500
+        raw_cap = int(raw.shape[0]) + 300
+        got = G.radius_graph_dyn_device(
+            p, c, r, None, cap, counts[2:4],
+            fan_in=(k, seed, raw_cap, counts[4:6]))
+        assert counts[2:6].tolist() == [want.shape[0], want.shape[0],
+                                        raw.shape[0], raw.shape[0]]
+        assert torch.equal(got[:want.shape[0]], want)
+        # capped list too small: prefix + the size required
+        small = int(want.shape[0]) // 2
+        got = G.radius_graph_dyn_device(
+            p, c, r, None, small, counts[2:4],
+            fan_in=(k, seed, raw_cap, counts[4:6]))
+        assert counts[2:4].tolist() == [small, want.shape[0]]
+        assert torch.equal(got, want[:small])
+        # uncapped list too small: level flagged (rows written 0 < required)
+        got = G.radius_graph_dyn_device(
+            p, c, r, None, cap, counts[2:4],
+            fan_in=(k, seed, int(raw.shape[0]) // 2, counts[4:6]))
+        assert counts[2:6].tolist() == [0, want.shape[0],
+                                        raw.shape[0] // 2, raw.shape[0]]
+
+
+@pytest.mark.parametrize("method", ["center", "random"])
+def test_training_graph_in_capacity_form_equals_host_sized(dev, method):
+    """The training graph kwargs (random keypoints on the float64 cloud,
+    fan-in cap 256 -- tightened to 24 here so that it bites) through
+    deferred_counts == the host-sized call for the same NumPy RNG state; the
+    one-read wrapper returns exactly the host-sized lists, also when its
+    first frame overflows every capacity."""
+    import copy
+    import torch
+    from pointgnn_amd import _lib, graph_gen as G
+    cfg = configs.car_auto_config(3)
+    kw = copy.deepcopy(cfg['graph_gen_kwargs'])
+    kw['downsample_method'] = method
+    for lc in kw['level_configs']:
+        lc['graph_gen_kwargs']['num_neighbors'] = 24
+    xyz, _ = synthetic_cloud(seed=5, preset="car")
+    x = T(xyz.astype(np.float64 if method == "random" else np.float32), dev)
+    np.random.seed(42)
+    coords, kps, edges = G.gen_multi_level_local_graph_v3(x, **kw)
+    after = np.random.get_state()[1][:8].tolist()
+    np.random.seed(42)
+    _, _, uncapped = G.gen_multi_level_local_graph_v3(
+        x, **dict(kw, level_configs=[
+            dict(lc, graph_gen_kwargs=dict(lc['graph_gen_kwargs'],
+                                           num_neighbors=-1))
+            for lc in kw['level_configs']]))
+    assert all(a.shape[0] < b.shape[0] for a, b in zip(edges, uncapped))
+    k = int(coords[1].shape[0])
+    hints = G.CountHints().update(
+        k, [int(e.shape[0]) for e in edges], [int(e.shape[0]) for e in uncapped])
+    np.random.seed(42)
+    c2, k2, e2 = G.gen_multi_level_local_graph_v3(x, deferred_counts=hints, **kw)
+    assert np.random.get_state()[1][:8].tolist() == after   # same draws
+    frame = _lib.count_of(e2[0]).frame
+    assert frame.k == k and not frame.overflowed
+    assert frame.edges == [int(e.shape[0]) for e in edges]
+    assert frame.raw_edges == [int(e.shape[0]) for e in uncapped]
+    for want, got in zip(list(coords) + list(kps) + list(edges),
+                         list(c2) + list(k2) + list(e2)):
+        assert got.dtype == want.dtype
+        assert torch.equal(want, got[:int(want.shape[0])])
+    # one read per frame, from cold hints (everything overflows -> rebuilt
+    # host-sized from the same random state), then from the learned ones
+    cold = G.CountHints()
+    for trial in range(2):
+        np.random.seed(42)
+        c3, k3, e3 = G.gen_multi_level_local_graph_v3_one_read(x, cold, **kw)
+        assert np.random.get_state()[1][:8].tolist() == after
+        for want, got in zip(list(coords) + list(kps) + list(edges),
+                             list(c3) + list(k3) + list(e3)):
+            assert got.shape == want.shape and torch.equal(want, got)
+        assert all(getattr(e, '_pgnn_sorted', 0) for e in e3)
+    assert cold.k == k and cold.raw_caps[0] >= uncapped[0].shape[0]
+
+
 @pytest.mark.parametrize("overlap", [False, True])
 @pytest.mark.parametrize("cfg_name,preset", [
     ("car", "small"), ("car", "car"), ("ped", "small")])

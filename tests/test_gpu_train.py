@@ -368,7 +368,7 @@ def _device_decisions(tr, cfg):
 
     for item in tr._saved:
         if item[0] == 'pool':
-            _, names, acts, dst, agg, onames, oacts = item
+            _, names, acts, dst, agg, onames, oacts = item[:7]
             relu_masks(names, acts, False)
             winners(acts[-1], dst, agg, fc[names[-1]].n_out)
             relu_masks(onames, oacts, False)
