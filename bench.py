@@ -442,6 +442,61 @@ def roofline_pool_kernel(torch, engine, reps=10, frame=None):
     }
 
 
+def roofline_pool_kernel_f16x2(torch, engine, reps=10, frame=None):
+    """The pooling stage of an 'f16x2' model (csrc/pool_ws_f16.h: the 64->128
+    and 128->300 layers as three fp16 products per block, the two narrowest
+    layers fp32 MFMA), priced in fp32-equivalent FLOPs against the 16-bit MFMA
+    peak / 3 like the edge kernel."""
+    from pointgnn_amd import _lib, gnn
+    lib = _lib.load()
+    store = engine.model._store
+    lc = engine.config['model_kwargs']['layer_configs'][0]
+    if lc['type'] != 'scatter_max_point_set_pooling' or frame is None:
+        return None
+    widths = list(lc['kwargs']['point_MLP_depth_list'])
+    scope = lc['scope'] + '/extract_vertex_features'
+    chain = store._cache.get(('mlp', scope, tuple(widths), False))
+    image = store._cache.get(('pool_f16x2', scope, tuple(widths)))
+    hidden = store._cache.get(('pool_f16x2_h', scope, tuple(widths)))
+    if chain is None or image is None:
+        return None
+    x, f = frame
+    engine.run_frame(x, f)
+    coords, kps, edges = engine.last_graph
+    e0 = edges[0]
+    kp = kps[0].reshape(-1).to(torch.int32).contiguous()
+    n_feat = int(f.shape[1])
+    k = int(kp.shape[0])
+    agg = torch.empty((k, gnn.padded_width(chain.n_out)), device=x.device)
+    n_e = int(e0.shape[0])
+    status = store.range_status()
+
+    def run():
+        _lib.check(lib.pgnn_point_set_pooling_f16x2_fwd(
+            _lib.ptr(f), n_feat, _lib.ptr(x), _lib.ptr(kp), _lib.ptr(e0), n_e,
+            k, chain.array, chain.n, _lib.ptr(image), _lib.ptr(hidden), 1,
+            _lib.ptr(agg), agg.stride(0), _lib.ptr(_lib.sched_ws()),
+            _lib.ptr(status), None, None, _lib.stream_ptr()),
+            "f16x2 pooling kernel")
+    dur = time_kernel(run, reps, torch)
+    dims = [n_feat + 3] + widths
+    flops = sum(2 * a * b for a, b in zip(dims[:-1], dims[1:])) * n_e
+    peak = BF16_MFMA_PEAK_TF / 3
+    return {
+        "kernel": "pool_ws_f16x2_kernel (gather + point MLP %s + scatter-max; "
+                  "64->128 and 128->300 as 3 fp16 products, the rest fp32 "
+                  "MFMA; csrc/pool_ws_f16.h)" % "->".join(map(str, dims)),
+        "bound": "mfma", "achieved": flops / dur / 1e12, "peak": peak,
+        "unit": "TFLOP/s (fp32-equivalent)",
+        "frac": flops / dur / 1e12 / peak,
+        "algorithmic_flops": flops, "avg_launch_us": dur * 1e6,
+        "note": "peak = dense 16-bit MFMA peak (%d TFLOP/s) / 3 products per "
+                "fp32-equivalent product; 2 %% of the FLOPs (the 4->32->64 "
+                "layers) run as fp32 MFMA" % BF16_MFMA_PEAK_TF,
+        "workload": {"E0": n_e, "K": k},
+    }
+
+
 def _host_description():
     """CPU model, core count and BLAS backend of this host (SURVEY.md 8d asks
     for them next to the CPU baseline)."""
@@ -1467,9 +1522,11 @@ def main(argv=None):
                        "its distance is not larger than the fp32 path's"),
             "f16x2": ("two-part fp16 kernel (both operands as x0 + x1 / 2^11 "
                       "in fp16 = 22 significand bits, 3 products, fp32 "
-                      "accumulation; fp32-MFMA everywhere else)",
-                      "f16x2 two-part products, f32 accumulate (edge stage "
-                      "only)",
+                      "accumulation) and the pooling stage's 64->128->300 "
+                      "layers in the same representation (fp32-MFMA "
+                      "everywhere else)",
+                      "f16x2 two-part products, f32 accumulate (edge stage + "
+                      "the wide layers of the pooling stage)",
                       "same bars: its distance grows by a few per cent; "
                       "activations are clamped at 65504 and flagged from "
                       "32768 on"),
@@ -1482,7 +1539,7 @@ def main(argv=None):
                 s3 = max(8, args.steps // 2)
                 e3, sh3, _ = measure(args.preset, s3, 2, fps=fps_h)
                 engine.check_edge_range()
-                rf16 = None
+                rf16 = rp16 = None
                 if not args.no_roofline:
                     # (a host-sized frame: after `measure` last_graph holds
                     # the capacity form, whose rows behind the counts are not
@@ -1496,6 +1553,9 @@ def main(argv=None):
                         rf16["workload"] = {"frame_seed": first,
                                             "E": int(edges_[1].shape[0]),
                                             "K": int(coords_[1].shape[0])}
+                    if arith == "f16x2":
+                        rp16 = roofline_pool_kernel_f16x2(torch, engine,
+                                                          frame=(x0_, f0_))
             finally:
                 engine.model.edge_arith = "f32"
             engine.frame_shapes = []
@@ -1520,6 +1580,8 @@ def main(argv=None):
             }
             if rf16 is not None:
                 sec16[arith]["roofline"] = rf16
+            if rp16 is not None:
+                sec16[arith]["roofline_pool"] = rp16
 
     if rank == 0:
         # per-phase wall clock of the pool's first frame (outside the timed

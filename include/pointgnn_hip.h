@@ -541,6 +541,32 @@ int pgnn_edge_mlp_scatter_max_f16x2_fwd(
     float *out, int64_t ld_out, int32_t *status, const pgnn_dyn_count *n_edges,
     const pgnn_dyn_count *num_vertices, void *stream);
 
+/* PointSetPooling (gnn.py:256-277) in the same SECONDARY arithmetic, for the
+ * car point MLP 4 -> 32 -> 64 -> 128 -> 300 (csrc/pool_ws_f16.h): the three
+ * narrow layers stay fp32 MFMA, the last layer's [E, 128] x [128, 300] product
+ * -- 79 % of the stage's matrix time -- runs as three fp16 products per block
+ * with both operands in two fp16 parts.  `layers` as for
+ * pgnn_point_set_pooling_fwd (the last one's fp32 image is not read);
+ * `last_image`: device copy of what pgnn_pack_fc_f16x2_acc wrote for the last
+ * layer (the rows of W in the order a lane of the previous layer's fp32
+ * accumulators holds them; same size as pgnn_packed_fc_f16x2_bytes);
+ * `hidden_image` (nullable): the same for the 64 -> 128 layer below it, which
+ * then runs in this arithmetic too (76 % of the remaining matrix time).  Counts
+ * nullable (host-sized call) or both given (capacity form).  `status` as for
+ * the edge entry.  Returns PGNN_E_UNSUPPORTED -- having done nothing -- for
+ * other layer shapes or too few edges (tunable `b16_force` lifts the size
+ * test): the caller takes pgnn_point_set_pooling_fwd(_dyn) then.            */
+int pgnn_pack_fc_f16x2_acc(const float *w_host, const float *b_host,
+                           int32_t k_in, int32_t n_out, void *image_host);
+int pgnn_point_set_pooling_f16x2_fwd(
+    const float *point_features, int32_t n_feat, const float *point_xyz,
+    const int32_t *keypoint_indices, const int32_t *edges, int64_t edges_cap,
+    int32_t keypoints_cap, const pgnn_fc_layer *layers, int32_t n_layers,
+    const void *last_image, const void *hidden_image, int32_t edges_sorted,
+    float *out, int64_t ld_out, int32_t *sched_ws, int32_t *status,
+    const pgnn_dyn_count *n_edges, const pgnn_dyn_count *num_keypoints,
+    void *stream);
+
 /* Training forward of the same stage with ONE remaining edge layer: the fused
  * kernel also writes that layer's per-edge output rows [n_edges, ld_rows]
  * (the backward compares them with `out` to find the arg-max rows; rows and
@@ -1099,7 +1125,11 @@ int pgnn_kitti_cam_points_in_image(
  *                  no net gain; default 0 = off)
  *   kernel choice  b16_force (1: pgnn_edge_mlp_scatter_max_bf16x3_fwd also
  *                  takes lists of a few tiles, where it otherwise answers
- *                  PGNN_E_UNSUPPORTED: the parity tests on small fixtures),
+ *                  PGNN_E_UNSUPPORTED: the parity tests on small fixtures;
+ *                  likewise the f16x2 edge and pooling entries), f16_pool (0:
+ *                  pgnn_point_set_pooling_f16x2_fwd declines, i.e. 'f16x2'
+ *                  models pool in fp32; 2: it ignores hidden_image: same-box
+ *                  A/Bs; default 1),
  *                  mlp_debug bits 2048 / 4096 (edge stage: LDS-tile kernel /
  *                  weights-stationary kernel), 8192 / 16384 (pooling stage),
  *                  1024 (pooling hidden layers through the LDS tile), 32 / 128

@@ -220,6 +220,11 @@ _SIGNATURES = {
         c_vp, c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_i32, c_i32,
         c_i32, c_vp, c_i64, c_vp, ctypes.POINTER(DynCount),
         ctypes.POINTER(DynCount), c_vp]),
+    "pgnn_pack_fc_f16x2_acc": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp]),
+    "pgnn_point_set_pooling_f16x2_fwd": (c_i32, [
+        c_vp, c_i32, c_vp, c_vp, c_vp, c_i64, c_i32, ctypes.POINTER(FcLayer),
+        c_i32, c_vp, c_vp, c_i32, c_vp, c_i64, c_vp, c_vp, ctypes.POINTER(DynCount),
+        ctypes.POINTER(DynCount), c_vp]),
     "pgnn_offset_apply": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp,
                                   c_i64, c_vp]),
     "pgnn_vertex_pre_edge_fwd": (c_i32, [c_vp, c_i64, c_i32, c_vp,

@@ -146,6 +146,7 @@ extern int g_mlp_pool_pct;
 extern int g_ws_xcds;
 extern int g_ws_prio;
 extern int g_b16_force;
+extern int g_f16_pool;
 extern int g_ws_pool_pct;
 extern int g_ws_chunk;
 extern int g_ws_balance;
@@ -306,6 +307,10 @@ extern "C" int pgnn_set_tunable(const char *key, int value) {
     pgnn::g_b16_force = value != 0;
     return 0;
   }
+  if (!strcmp(key, "f16_pool")) {
+    pgnn::g_f16_pool = value;
+    return 0;
+  }
   if (!strcmp(key, "graph_debug")) {
 #ifndef PGNN_DIAG
     if (value & 1)
@@ -400,9 +405,12 @@ extern "C" size_t pgnn_packed_fc_f16x2_bytes(int32_t k_in, int32_t n_out) {
   return kb * nt * 2 * 1024 + nt * 16 * sizeof(float);
 }
 
-extern "C" int pgnn_pack_fc_f16x2(const float *w, const float *b, int32_t k_in,
-                                  int32_t n_out, void *image) {
-  PGNN_GUARD_BEGIN
+namespace {
+// acc_order: slot (g, j) of block kb holds feature 32 kb + 4 g + j (j < 4) or
+// 32 kb + 16 + 4 g + j - 4 -- the order in which a lane of the fp32 MFMA
+// accumulators of the layer below holds a row's features (pool_ws_f16.h)
+int pack_fc_f16x2(const float *w, const float *b, int32_t k_in, int32_t n_out,
+                  void *image, bool acc_order) {
   PGNN_REQUIRE(w && image && k_in > 0 && n_out > 0, PGNN_E_INVALID,
                "pack_fc_f16x2: bad argument");
   const int kb_n = (k_in + 31) / 32, nt = (n_out + 15) / 16;
@@ -414,7 +422,10 @@ extern "C" int pgnn_pack_fc_f16x2(const float *w, const float *b, int32_t k_in,
     for (int t = 0; t < nt; ++t)
       for (int lane = 0; lane < 64; ++lane)
         for (int j = 0; j < 8; ++j) {
-          const int k = 32 * kb + 8 * (lane >> 4) + j;
+          const int g = lane >> 4;
+          const int k = 32 * kb + (!acc_order ? 8 * g + j
+                                   : j < 4    ? 4 * g + j
+                                              : 16 + 4 * g + (j - 4));
           const int n = 16 * t + (lane & 15);
           const float x = (k < k_in && n < n_out) ? w[(size_t)k * n_out + n] : 0.0f;
           // x ~ w0 + w1' / 2^11: the residual is exact in fp32, the scaling
@@ -429,6 +440,20 @@ extern "C" int pgnn_pack_fc_f16x2(const float *w, const float *b, int32_t k_in,
                                           (size_t)kb_n * nt * 2 * 1024);
   for (int n = 0; n < nt * 16; ++n) bias[n] = (b && n < n_out) ? b[n] : 0.0f;
   return 0;
+}
+}  // namespace
+
+extern "C" int pgnn_pack_fc_f16x2(const float *w, const float *b, int32_t k_in,
+                                  int32_t n_out, void *image) {
+  PGNN_GUARD_BEGIN
+  return pack_fc_f16x2(w, b, k_in, n_out, image, false);
+  PGNN_GUARD_END
+}
+
+extern "C" int pgnn_pack_fc_f16x2_acc(const float *w, const float *b,
+                                      int32_t k_in, int32_t n_out, void *image) {
+  PGNN_GUARD_BEGIN
+  return pack_fc_f16x2(w, b, k_in, n_out, image, true);
   PGNN_GUARD_END
 }
 

@@ -43,6 +43,14 @@ namespace pgnn {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+// request distances of the raw rows, in blocks (edge_ws_bf16.h: PGNN_B16_DP /
+// _DQ); a block here is half as long as there (3 MFMAs per tile, not 6)
+#ifndef PGNN_F16_DP
+#define PGNN_F16_DP PGNN_B16_DP
+#endif
+#ifndef PGNN_F16_DQ
+#define PGNN_F16_DQ PGNN_B16_DQ
+#endif
 constexpr float kF16Scale = 2048.0f;  // 2^11
 constexpr float kF16Max = 65504.0f;
 
@@ -109,7 +117,7 @@ __device__ __forceinline__ void edge_ws2_body(const EdgeWsArgs &a,
                                               int64_t tile_first,
                                               int64_t tile_last, int lane,
                                               const int64_t E, u32 &gmax) {
-  constexpr int DP = PGNN_B16_DP, DQ = PGNN_B16_DQ;
+  constexpr int DP = PGNN_F16_DP, DQ = PGNN_F16_DQ;
   static_assert(DP >= 2 && DQ >= 2 && DP < KB && DQ < KB, "request distances");
   // 36 instructions of the split are visible to the scheduler's groups (the
   // eight v_fma_mix_f32 are asm statements and place themselves)

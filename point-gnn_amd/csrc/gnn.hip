@@ -17,6 +17,7 @@
 #include "edge_ws_bf16.h"
 #include "edge_ws_f16.h"
 #include "pool_ws.h"
+#include "pool_ws_f16.h"
 
 namespace pgnn {
 int g_mlp_blocks_per_cu = 4;  // upper bound; LDS usually allows fewer
@@ -25,6 +26,7 @@ int g_pool_msub = 0;
 int g_mlp_pool_pct = 12;  // share of the row tiles handed out dynamically
 int g_ws_xcds = 8;        // edge_ws.h: row slices (8 = one per XCD, 1 = none)
 int g_ws_prio = 1;        // edge_ws.h: raised wave priority outside the MFMA loop
+int g_f16_pool = 1;       // 0: pgnn_point_set_pooling_f16x2_fwd declines; 2: its 64 -> 128 layer in fp32 (same-box A/Bs)
 int g_b16_force = 0;      // tests: the split-bf16 edge kernel also for lists of a few tiles
 int g_ws_pool_pct = 0;    // edge_ws.h / pool_ws.h: share of the tiles handed out
                           // dynamically (measured: a pool costs more in extra
@@ -1802,6 +1804,79 @@ extern "C" int pgnn_edge_mlp_scatter_max_f16x2_fwd(
   a.prio = 0;
   if (kb == 10) return launch_edge_ws2<10, 7>(a, nt, cus, status, stream);
   return launch_edge_ws2<8, 6>(a, nt, cus, status, stream);
+  PGNN_GUARD_END
+}
+
+extern "C" int pgnn_point_set_pooling_f16x2_fwd(
+    const float *point_features, int32_t n_feat, const float *point_xyz,
+    const int32_t *keypoint_indices, const int32_t *edges, int64_t edges_cap,
+    int32_t keypoints_cap, const pgnn_fc_layer *layers, int32_t n_layers,
+    const void *last_image, const void *hidden_image, int32_t edges_sorted,
+    float *out, int64_t ld_out, int32_t *sched_ws, int32_t *status,
+    const pgnn_dyn_count *n_edges, const pgnn_dyn_count *num_keypoints,
+    void *stream_) {
+  PGNN_GUARD_BEGIN
+  hipStream_t stream = (hipStream_t)stream_;
+  PGNN_REQUIRE(edges_cap >= 0 && keypoints_cap >= 0 && n_feat >= 0 &&
+                   n_feat <= 13 && layers && last_image,
+               PGNN_E_INVALID, "pooling_f16x2: bad argument");
+  const Dyn de = dyn_of(n_edges), dk = dyn_of(num_keypoints);
+  Plan p;
+  int rc = make_plan(layers, n_layers, n_feat + 3, p);
+  if (rc) return rc;
+  int cus = stream_cu_count(stream);
+  if (g_ws_reserve > 0 && cus - g_ws_reserve >= 64) cus -= g_ws_reserve;
+  // the shapes and sizes of pool_ws_kernel (car's 4-32-64-128-300 chain)
+  if (!g_f16_pool ||
+      !pool_ws_applies(p, g_b16_force ? ((int64_t)1 << 40)
+                                      : expected(de, edges_cap), cus))
+    return PGNN_E_UNSUPPORTED;  // (no message: an expected answer)
+  PGNN_REQUIRE(ld_out >= 16 * 19, PGNN_E_INVALID,
+               "pooling_f16x2: ld_out < padded output width");
+  if (keypoints_cap == 0) return 0;
+  PGNN_REQUIRE(out != nullptr, PGNN_E_INVALID, "pooling_f16x2: null output");
+  rc = fill_lowest_rows(out, ld_out, keypoints_cap, dk, stream);
+  if (rc) return rc;
+  if (edges_cap == 0) return 0;
+  PGNN_REQUIRE((n_feat == 0 || point_features) && point_xyz &&
+                   keypoint_indices && edges,
+               PGNN_E_INVALID, "pooling_f16x2: null input");
+  PGNN_REQUIRE((uintptr_t)last_image % 16 == 0 &&
+                   (uintptr_t)hidden_image % 16 == 0,
+               PGNN_E_INVALID,
+               "pooling_f16x2: the images must be 16-byte aligned");
+  PoolWsArgs a = {};
+  a.n_dev = de.dev;
+  a.feat = point_features;
+  a.nfeat = n_feat;
+  a.xyz = point_xyz;
+  a.kp = keypoint_indices;
+  a.edges = edges;
+  a.n_edges = edges_cap;
+  a.l0 = p.chain.l[0];
+  a.l1 = p.chain.l[1];
+  a.l2 = p.chain.l[2];
+  a.wp = reinterpret_cast<const float *>(last_image);
+  a.kq = 8;
+  a.nt = 19;
+  a.relu_from = p.chain.l[3].relu_from;
+  a.out = out;
+  a.ldo = ld_out;
+  a.num_segments = keypoints_cap;
+  a.sorted = edges_sorted & 1;
+  a.sched = g_ws_pool_pct > 0 ? sched_ws : nullptr;
+  PGNN_HIP((hipError_t)arm_sched(a.sched, stream));
+  a.pool_pct = g_ws_pool_pct;
+  a.chunk = 1;
+  const size_t lds = (size_t)4 * 19 * 2 * 1024 + 16 * 19 * sizeof(float);
+  a.l2_f16 = g_f16_pool >= 2 ? nullptr : hidden_image;
+  auto kern = a.l2_f16 ? pool_ws_f16x2_kernel<true> : pool_ws_f16x2_kernel<false>;
+  rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
+  if (rc) return rc;
+  hipLaunchKernelGGL(kern, dim3((unsigned)cus), dim3(64 * kWsWaves), lds, stream,
+                     a, status);
+  PGNN_HIP(hipGetLastError());
+  return 0;
   PGNN_GUARD_END
 }
 

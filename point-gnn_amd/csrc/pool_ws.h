@@ -48,6 +48,9 @@ struct PoolWsArgs {
   // come from the same accumulators)
   float *a1_out, *a2_out, *a3_out, *a4_out;
   int64_t ld4;
+  // pool_ws_f16.h only: the 64 -> 128 layer's two-part fp16 image (nullable:
+  // that layer in fp32 through l2)
+  const void *l2_f16;
 };
 
 // acc[t] = sum_q W[q][tb + t]^T h[q]  for the NTB column tiles from tb on

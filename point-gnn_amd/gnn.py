@@ -539,12 +539,53 @@ class PointSetPooling(object):
                 _lib.ptr(edges), int(edges.shape[0]), k, point_chain.array,
                 point_chain.n, _edges_sorted_flag(set_indices), _lib.ptr(agg),
                 agg.stride(0), _lib.ptr(_lib.sched_ws(xyz.device)))
-        if cnt_k is None and cnt_e is None:
+        if cnt_k is not None or cnt_e is not None:
+            cnt_k, cnt_e = _both_counts(cnt_k, k, cnt_e, int(edges.shape[0]),
+                                        xyz.device)
+        done = False
+        if store.edge_arith == 'f16x2' and point_chain.n == 4:
+            # the model's 16-bit arithmetic covers this stage's wide layer too
+            # (csrc/pool_ws_f16.h); other shapes / few edges: the fp32 kernel
+            with variable_scope('extract_vertex_features'):
+                pscope = _scope()
+
+            def build(li=-1):
+                w, b = store.mlp(pscope, point_chain.n)[li]
+                w = np.ascontiguousarray(w, dtype=np.float32)
+                b = np.ascontiguousarray(b, dtype=np.float32)
+                host = np.empty(lib.pgnn_packed_fc_f16x2_bytes(*w.shape),
+                                np.uint8)
+                _lib.check(lib.pgnn_pack_fc_f16x2_acc(
+                    w.ctypes.data, b.ctypes.data, w.shape[0], w.shape[1],
+                    host.ctypes.data), "pgnn_pack_fc_f16x2_acc")
+                return torch.from_numpy(host).to(store._dev())
+            try:
+                image = store.cached(
+                    ('pool_f16x2', pscope, tuple(point_MLP_depth_list)), build)
+                hidden = store.cached(
+                    ('pool_f16x2_h', pscope, tuple(point_MLP_depth_list)),
+                    lambda: build(-2))
+            except _lib.PointGnnHipError as err:
+                if "code %d" % _lib.E_UNSUPPORTED not in str(err):
+                    raise
+                image = None     # a weight outside fp16's range
+            if image is not None:
+                rc = lib.pgnn_point_set_pooling_f16x2_fwd(
+                    *(args[:9] + (_lib.ptr(image), _lib.ptr(hidden)) +
+                      args[9:] +
+                      (_lib.ptr(store.range_status()),
+                       cnt_e.arg() if cnt_e is not None else None,
+                       cnt_k.arg() if cnt_k is not None else None,
+                       _lib.stream_ptr())))
+                if rc != _lib.E_UNSUPPORTED:
+                    _lib.check(rc, "pgnn_point_set_pooling_f16x2_fwd")
+                    done = True
+        if done:
+            pass
+        elif cnt_k is None and cnt_e is None:
             _lib.check(lib.pgnn_point_set_pooling_fwd(
                 *args, _lib.stream_ptr()), "pgnn_point_set_pooling_fwd")
         else:
-            cnt_k, cnt_e = _both_counts(cnt_k, k, cnt_e, int(edges.shape[0]),
-                                        xyz.device)
             _lib.check(lib.pgnn_point_set_pooling_fwd_dyn(
                 *args, cnt_e.arg(), cnt_k.arg(), _lib.stream_ptr()),
                 "pgnn_point_set_pooling_fwd_dyn")
@@ -578,7 +619,10 @@ EDGE_INPUT_TAP = None
 #               cent -- ~3x faster than 'f32'.  Activations are clamped at
 #               65504; the kernel flags any that reached 32768 and
 #               `model.edge_range_ok()` (read by the engine with a frame's
-#               results) reports it: rerun such a frame in 'f32'.
+#               results) reports it: rerun such a frame in 'f32'.  Also covers
+#               the wide last layer of PointSetPooling's point MLP
+#               (csrc/pool_ws_f16.h, pgnn_point_set_pooling_f16x2_fwd; car's
+#               4-32-64-128-300 chain), same representation, same guard.
 EDGE_ARITHS = ('f32', 'bf16x3', 'f16x2')
 
 

@@ -2,7 +2,9 @@
 formats: 'bf16x3' (csrc/edge_ws_bf16.h: both operands of the 300x300 / 256x256
 product split exactly into three bf16 parts, the six products of combined order
 <= 2 accumulated in fp32) and 'f16x2' (csrc/edge_ws_f16.h: both operands as two
-fp16 values, 22 significand bits, three products).
+fp16 values, 22 significand bits, three products; with it the wide last layer
+of PointSetPooling's point MLP runs in the same representation,
+csrc/pool_ws_f16.h).
 
 Neither is bit-identical to the fp32-MFMA kernel (another summation), so the
 bars are: (i) within fp32 rounding noise of the fp32 kernel, (ii) no further
@@ -200,6 +202,139 @@ def test_bf16x3_full_size_logits_vs_float64_oracle(dev, name, preset, arith):
     np.testing.assert_allclose(out["bf16x3"][0], lg, atol=FP_TOL, rtol=1e-4)
     np.testing.assert_allclose(out["bf16x3"][1], bx, atol=FP_TOL, rtol=1e-4)
     assert d16[0] <= 1.5 * d32[0] + 2e-7 and d16[1] <= 1.5 * d32[1] + 2e-7
+
+
+def _pool_stage(dev, g, edges, arith, seed=0, unsorted=False, big=None):
+    """PointSetPooling's fused stage (gather, point MLP 4-32-64-128-300,
+    scatter-max) through the C ABI; returns (out [K, 300], weights, status)."""
+    import torch
+    from pointgnn_amd import _lib, gnn
+    lib = _lib.load()
+    rng = np.random.default_rng(seed)
+    widths = [4, 32, 64, 128, 300]
+    layers = []
+    for a, b_ in zip(widths[:-1], widths[1:]):
+        w = (rng.standard_normal((a, b_)) * np.sqrt(2.0 / a)).astype(np.float32)
+        layers.append((w, (0.1 * rng.standard_normal(b_)).astype(np.float32), 0))
+    if big is not None:     # blow one hidden activation up (a 32 -> 64 column)
+        layers[1][0][:, 5] *= big
+    store = gnn.ParamStore({}, device=dev)
+    chain = gnn.Chain(store, layers)
+    k = int(g["kp_idx"].shape[0])
+    feat, xyz = T(g["intensity"], dev), T(g["xyz"], dev)
+    kp, ed = T(g["kp_idx"].reshape(-1), dev), T(edges, dev)
+    out = torch.empty((k, 304), dtype=torch.float32, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    head = (_lib.ptr(feat), 1, _lib.ptr(xyz), _lib.ptr(kp), _lib.ptr(ed),
+            len(edges), k, chain.array, 4)
+    tail = (0 if unsorted else 1, _lib.ptr(out), 304, _lib.ptr(_lib.sched_ws()))
+    if arith == "f32":
+        _lib.check(lib.pgnn_point_set_pooling_fwd(
+            *head, *tail, _lib.stream_ptr()), "f32 pooling stage")
+    else:
+        w, b_ = layers[-1][0], layers[-1][1]
+        host = np.empty(lib.pgnn_packed_fc_f16x2_bytes(128, 300), np.uint8)
+        _lib.check(lib.pgnn_pack_fc_f16x2_acc(
+            w.ctypes.data, b_.ctypes.data, 128, 300, host.ctypes.data))
+        image = T(host, dev)
+        hidden = None
+        if arith == "f16x2":      # ("f16x2_last": the 64 -> 128 layer in fp32)
+            w, b_ = layers[-2][0], layers[-2][1]
+            host = np.empty(lib.pgnn_packed_fc_f16x2_bytes(64, 128), np.uint8)
+            _lib.check(lib.pgnn_pack_fc_f16x2_acc(
+                w.ctypes.data, b_.ctypes.data, 64, 128, host.ctypes.data))
+            hidden = T(host, dev)
+        _lib.check(lib.pgnn_point_set_pooling_f16x2_fwd(
+            *head, _lib.ptr(image), _lib.ptr(hidden), *tail, _lib.ptr(status),
+            None, None, _lib.stream_ptr()), "f16x2 pooling stage")
+    return out.cpu().numpy()[:, :300], layers, int(status.item())
+
+
+def _pool_f64(g, edges, layers):
+    src, dst = edges[:, 0].astype(np.int64), edges[:, 1].astype(np.int64)
+    k = int(g["kp_idx"].shape[0])
+    ok = (dst >= 0) & (dst < k)
+    xyz, kp = g["xyz"], g["kp_idx"].reshape(-1)
+    d = np.where(ok, dst, 0)
+    x = np.concatenate([g["intensity"][src], xyz[src] - xyz[kp[d]]],
+                       axis=1).astype(np.float64)        # fp32 inputs
+    for w, b_, _ in layers:
+        x = np.maximum(x @ w.astype(np.float64) + b_.astype(np.float64), 0)
+    out = np.full((k, 300), np.finfo(np.float32).min, np.float64)
+    np.maximum.at(out, dst[ok], x[ok])
+    return out
+
+
+def test_f16x2_pooling_stage_vs_fp32_kernel_and_float64(dev):
+    """The f16x2 form of the pooling stage (last layer in two fp16 parts per
+    operand, hidden layers fp32 as before) against the fp32 kernel and a
+    float64 evaluation, on the reference's own level-0 edge list."""
+    g = gold("graph_small.npz")
+    edges = g["ref_edges0"].astype(np.int32)
+    assert len(edges) >= 70000
+    f32, layers, _ = _pool_stage(dev, g, edges, "f32")
+    ref = _pool_f64(g, edges, layers)
+    lowest = np.finfo(np.float32).min
+    m = f32 != lowest
+    scale = np.abs(ref[m]).max()
+    e32 = np.abs(f32 - ref)[m].max()
+    for arith in ("f16x2_last", "f16x2"):   # last layer only / 64->128 as well
+        f16, _, status = _pool_stage(dev, g, edges, arith)
+        assert status == 0
+        assert not np.array_equal(f32, f16), "the f16x2 kernel did not run"
+        assert np.array_equal(f32 == lowest, f16 == lowest)
+        e16 = np.abs(f16 - ref)[m].max()
+        print("pooling E %d: |out|max %.3g; max error vs float64: fp32-MFMA "
+              "%.3g, %s %.3g; %s vs fp32-MFMA %.3g" % (
+                  len(edges), scale, e32, arith, e16, arith,
+                  np.abs(f16 - f32)[m].max()))
+        assert e16 <= 1.5 * e32 + 1e-7 * scale
+        np.testing.assert_allclose(f16[m], f32[m], atol=2e-6 * scale, rtol=0)
+
+
+def test_f16x2_pooling_stage_edge_cases(dev):
+    """Ragged edge count, foreign / negative set ids, a shuffled list, empty
+    sets: the answers of the fp32 kernel; a hidden activation beyond fp16's
+    range raises the flag; below the size threshold the entry declines."""
+    import torch
+    from pointgnn_amd import _lib
+    lib = _lib.load()
+    g = gold("graph_small.npz")
+    edges = g["ref_edges0"].astype(np.int32)
+    k = int(g["kp_idx"].shape[0])
+    rng = np.random.default_rng(4)
+    lowest = np.finfo(np.float32).min
+    cases = {"ragged": (edges[:len(edges) - 5].copy(), False)}
+    e = edges.copy()
+    e[rng.choice(len(e), 400, replace=False), 1] = k + 3
+    e[rng.choice(len(e), 400, replace=False), 1] = -1
+    cases["foreign"] = (e, True)
+    cases["shuffled"] = (edges[rng.permutation(len(edges))], True)
+    cases["empty_sets"] = (edges[edges[:, 1] % 7 != 0], False)
+    for name, (e, unsorted) in cases.items():
+        f32, _, _ = _pool_stage(dev, g, e, "f32", unsorted=unsorted)
+        f16, _, st = _pool_stage(dev, g, e, "f16x2", unsorted=unsorted)
+        assert st == 0, name
+        assert np.array_equal(f32 == lowest, f16 == lowest), name
+        m = f32 != lowest
+        assert np.abs(f32[m] - f16[m]).max() <= 2e-6 * np.abs(f32[m]).max(), name
+    _, _, st = _pool_stage(dev, g, edges, "f16x2", big=3e5)
+    assert st == 1
+    # few edges: the entry declines (the caller takes the fp32 entry) unless
+    # the size test is lifted
+    few = edges[:3000]
+    _lib.set_tunable("b16_force", 0)
+    with pytest.raises(_lib.PointGnnHipError, match="code -3"):
+        _pool_stage(dev, g, few, "f16x2")
+    _lib.set_tunable("b16_force", 1)
+    try:
+        f32, _, _ = _pool_stage(dev, g, few, "f32")
+        f16, _, _ = _pool_stage(dev, g, few, "f16x2")
+    finally:
+        _lib.set_tunable("b16_force", 0)
+    m = f32 != lowest
+    assert np.array_equal(m, f16 != lowest)
+    assert np.abs(f32[m] - f16[m]).max() <= 2e-6 * np.abs(f32[m]).max()
 
 
 def test_f16x2_flags_activations_out_of_range(dev):

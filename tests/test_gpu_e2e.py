@@ -250,6 +250,19 @@ def test_train_epochs_on_kitti_files(tmp_path):
     assert sample[0].shape[1] == 1 and sample[4].shape == (k, 1)
     assert sample[5].shape == (k, 1, 7) and sample[6].shape == (k, 1, 1)
     assert sample[5].dtype == torch.float32 and sample[4].dtype == torch.int32
+    # the same sample with its graph built in capacity form (one host read per
+    # frame; train_epochs fetches this way): identical tensors for the same
+    # RNG state, from cold hints (overflow -> host-sized rebuild) and learned
+    from pointgnn_amd import graph_gen
+    hints = graph_gen.CountHints()
+    for trial in range(2):
+        np.random.seed(3)
+        again = train.fetch_data(ds, 1, cfg, tcfg, graph_hints=hints)
+        for a, b in zip(sample, again):
+            for x, y in zip(a if isinstance(a, (list, tuple)) else [a],
+                            b if isinstance(b, (list, tuple)) else [b]):
+                assert x.dtype == y.dtype and torch.equal(x, y)
+    assert hints.k == int(sample[1][1].shape[0])
     lines = []
     tr, res = train.train_epochs(ds, cfg, tcfg, log=lines.append)
     assert tr.global_step == 6 and res['step'] == 6

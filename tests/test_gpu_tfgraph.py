@@ -64,10 +64,13 @@ def test_predict_matches_reference_tf_graph(dev, name, edge_arith):
         model.edge_arith = "f32"
         l32, b32 = model.predict(kw["features"], kw["coords"], kw["keypoints"],
                                  kw["edges"], is_training=False)
-        has_gnn = any(l["type"] == "scatter_max_graph_auto_center_net"
-                      for l in cfg["model_kwargs"]["layer_configs"])
-        assert np.array_equal(l32, logits) != has_gnn, \
-            "the split-bf16 kernel did not run" if has_gnn else "T0 differs"
+        # 'bf16x3' changes the edge stage of the GNN layers only; 'f16x2'
+        # also the wide layers of the pooling stage (every config has one)
+        has_16 = edge_arith == "f16x2" or any(
+            l["type"] == "scatter_max_graph_auto_center_net"
+            for l in cfg["model_kwargs"]["layer_configs"])
+        assert np.array_equal(l32, logits) != has_16, \
+            "the 16-bit kernel did not run" if has_16 else "T0 differs"
         for got, ref32, ref in ((logits, l32, t["logits"]),
                                 (boxes, b32, t["box_encodings"])):
             assert np.abs(got - ref).max() <= \
