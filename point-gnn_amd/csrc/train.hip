@@ -1701,27 +1701,49 @@ struct PoolNarrowArgs {
 };
 
 // tile[r][c] <- src[(r0 + r) * ld + c] for 32 rows x W columns (W = 16..128),
-// zero for rows past r_end; unconditional clamped loads
+// zero for rows past r_end; unconditional clamped loads.  In two halves --
+// global -> registers (pn_load), registers -> LDS (pn_store) -- so that the
+// NEXT tile's rows are in flight while this tile is computed: the kernel was a
+// chain of (HBM round trip, barrier, ~2 us of MFMAs) per 32 rows and ran at
+// 1.75 TB/s / 40 TFLOP/s, bound by neither.
+#ifndef PGNN_PN_PREFETCH
+#define PGNN_PN_PREFETCH 1
+#endif
 template <int W>
-__device__ __forceinline__ void pn_stage(float *tile, int ldt, const float *src,
-                                         int64_t r0, int64_t r_end) {
-  constexpr int TPR = W < 64 ? W : 64;     // threads per row
-  constexpr int RPS = 256 / TPR;            // rows per sweep
+struct PnRegs {
+  static constexpr int TPR = W < 64 ? W : 64;  // threads per row
+  static constexpr int RPS = 256 / TPR;        // rows per sweep
+  static constexpr int N = (W / TPR) * (kPnRows / RPS);
+  float v[N];
+};
+template <int W>
+__device__ __forceinline__ void pn_load(PnRegs<W> &g, const float *src, int64_t r0,
+                                        int64_t r_end) {
+  constexpr int TPR = PnRegs<W>::TPR, RPS = PnRegs<W>::RPS;
   const int c0 = threadIdx.x % TPR, rs = threadIdx.x / TPR;
 #pragma unroll
-  for (int cb = 0; cb < W; cb += TPR) {
-    float v[kPnRows / RPS];
+  for (int cb = 0; cb < W; cb += TPR)
 #pragma unroll
     for (int i = 0; i < kPnRows / RPS; ++i) {
-      const int64_t row = r0 + rs + RPS * i;
-      v[i] = src[(row < r_end ? row : r_end - 1) * W + cb + c0];
+      int64_t row = r0 + rs + RPS * i;
+      row = row < r_end ? row : r_end - 1;
+      row = row > 0 ? row : 0;
+      g.v[(cb / TPR) * (kPnRows / RPS) + i] = src[row * W + cb + c0];
     }
+}
+template <int W>
+__device__ __forceinline__ void pn_store(float *tile, int ldt, const PnRegs<W> &g,
+                                         int64_t r0, int64_t r_end) {
+  constexpr int TPR = PnRegs<W>::TPR, RPS = PnRegs<W>::RPS;
+  const int c0 = threadIdx.x % TPR, rs = threadIdx.x / TPR;
+#pragma unroll
+  for (int cb = 0; cb < W; cb += TPR)
 #pragma unroll
     for (int i = 0; i < kPnRows / RPS; ++i) {
       const int r = rs + RPS * i;
-      tile[r * ldt + cb + c0] = (r0 + r < r_end) ? v[i] : 0.0f;
+      tile[r * ldt + cb + c0] =
+          (r0 + r < r_end) ? g.v[(cb / TPR) * (kPnRows / RPS) + i] : 0.0f;
     }
-  }
 }
 
 // acc[m][j] += X^T Z over the tile's 32 rows: X [32][ldx] (MT input tiles of
@@ -1780,13 +1802,35 @@ __global__ __launch_bounds__(256) void pool_narrow_bwd_kernel(PoolNarrowArgs a) 
   for (int m = 0; m < 2; ++m) w1[m][0] = (v4f){0.f, 0.f, 0.f, 0.f};
   w0[0][0] = (v4f){0.f, 0.f, 0.f, 0.f};
   float b2 = 0.0f, b1 = 0.0f, b0 = 0.0f;  // thread t: column t of db2 / db1 / db0
+  PnRegs<16> gf;
+  PnRegs<32> g0;
+  PnRegs<64> g1;
+  PnRegs<128> gz;
+  if (PGNN_PN_PREFETCH && r_begin < r_end) {
+    pn_load<16>(gf, a.feat, r_begin, r_end);
+    pn_load<32>(g0, a.act0, r_begin, r_end);
+    pn_load<64>(g1, a.act1, r_begin, r_end);
+    pn_load<128>(gz, a.dz2, r_begin, r_end);
+  }
   for (int64_t r0 = r_begin; r0 < r_end; r0 += kPnRows) {
+    if (!PGNN_PN_PREFETCH) {  // (A/B builds: the rows when they are needed)
+      pn_load<16>(gf, a.feat, r0, r_end);
+      pn_load<32>(g0, a.act0, r0, r_end);
+      pn_load<64>(g1, a.act1, r0, r_end);
+      pn_load<128>(gz, a.dz2, r0, r_end);
+    }
     __syncthreads();  // the previous tile's buffers are free
-    pn_stage<16>(F, LF, a.feat, r0, r_end);
-    pn_stage<32>(A0, LA0, a.act0, r0, r_end);
-    pn_stage<64>(A1, LA1, a.act1, r0, r_end);
-    pn_stage<128>(Z2, LZ2, a.dz2, r0, r_end);
+    pn_store<16>(F, LF, gf, r0, r_end);
+    pn_store<32>(A0, LA0, g0, r0, r_end);
+    pn_store<64>(A1, LA1, g1, r0, r_end);
+    pn_store<128>(Z2, LZ2, gz, r0, r_end);
     __syncthreads();
+    if (PGNN_PN_PREFETCH && r0 + kPnRows < r_end) {  // the next tile's rows, under this tile's work
+      pn_load<16>(gf, a.feat, r0 + kPnRows, r_end);
+      pn_load<32>(g0, a.act0, r0 + kPnRows, r_end);
+      pn_load<64>(g1, a.act1, r0 + kPnRows, r_end);
+      pn_load<128>(gz, a.dz2, r0 + kPnRows, r_end);
+    }
     // layer 2 (64 -> 128)
     pn_wgrad<4, 2>(A1, LA1, Z2, LZ2, 8, wave, lane, w2);
     if (threadIdx.x < 128) {

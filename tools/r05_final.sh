@@ -32,11 +32,12 @@ bench)
   echo "BENCH_TRAIN(8-frame pool) rc=$? $(head -c 400 $OUT/bench_train8.json)" >> $S
   ;;
 prof)
-  for what in bench infer infer_seed0 train; do
+  for what in bench infer infer_seed0 infer_seed0_f16x2 train; do
     case $what in
       bench) CMD="python $ROOT/bench.py --no-cpu-baseline --no-secondary --no-live-pmc";;
       infer) CMD="python $ROOT/bench.py --steps 16 --warmup 2 --no-cpu-baseline --no-secondary --no-live-pmc --no-pipeline";;
       infer_seed0) CMD="python $ROOT/bench.py --steps 8 --warmup 2 --frames 1 --no-cpu-baseline --no-secondary --no-live-pmc --no-pipeline --no-roofline";;
+      infer_seed0_f16x2) CMD="python $ROOT/bench.py --edge-arith f16x2 --steps 8 --warmup 2 --frames 1 --no-cpu-baseline --no-secondary --no-live-pmc --no-pipeline --no-roofline";;
       train) CMD="python $ROOT/bench.py --train --steps 8 --warmup 4 --frames 4";;
     esac
     rm -rf $OUT/prof_$what
