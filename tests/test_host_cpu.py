@@ -237,7 +237,23 @@ def test_capacity_form_host_logic():
     c._host = [7, 0, 100, 130, 40, 40]        # level 0 needed 130 rows, had 100
     assert (c.k, c.kd_status, c.edges, c.overflowed) == (7, 0, [130, 40], [0])
     c._host = [7, 0, 90, 90, 40, 40]
-    assert c.overflowed == []
+    assert c.overflowed == [] and c.raw_edges is None
+    # levels with a fan-in cap (training kwargs): the uncapped list has its
+    # own capacity and its own record behind the levels' (written, required)
+    assert h.raw_cap(1) == 2 * h.cap(1)       # nothing seen yet
+    h.update(2500, [900000, 20], raw_edges=[900000, 5000])
+    assert h.raw_cap(0) >= 1800000 and h.raw_cap(1) == G.CountHints.MIN_EDGE_CAP
+    c._host = [7, 0, 90, 90, 0, 40, 0, 0, 300, 500]   # level 1: uncapped list cut
+    assert c.raw_edges == [0, 500] and c.edges == [90, 40]
+    assert c.overflowed == [1]                # flagged as {0, required}
+    assert lib.pgnn_radius_graph_dyn_cap(None, 0, 10, 10, None, 0, None, 8, 1,
+                                         None, None, 0, None, None) == -1
+    assert lib.pgnn_radius_graph_dyn_cap(None, 0, 10, 10, None, 0, None, 0, 1,
+                                         None, None, 0, None, None) == -1
+    # the f16x2 pooling entry: null layers / image are argument errors
+    assert lib.pgnn_point_set_pooling_f16x2_fwd(
+        None, 1, None, None, None, 0, 0, None, 4, None, None, 1, None, 304,
+        None, None, None, None, None) == -1
     # the capacity-form entries validate before any HIP call
     assert lib.pgnn_radius_graph_dyn_workspace_bytes(-1, 5) == 0
     assert lib.pgnn_radius_graph_dyn_workspace_bytes(20000, 20000) > \
@@ -464,3 +480,54 @@ def test_bf16x3_weight_image_is_an_exact_split():
     assert np.all(np.abs(parts[:, :, 1]) <= np.abs(parts[:, :, 0]) * 2.0 ** -8 + 1e-300)
     bias = host[kb * nt * 3 * 1024:].view(np.float32)
     assert np.array_equal(bias[:n_out], b) and np.all(bias[n_out:] == 0)
+
+
+def test_f16x2_weight_images_natural_and_accumulator_order():
+    """pgnn_pack_fc_f16x2 / _acc (host side of csrc/edge_ws_f16.h and
+    pool_ws_f16.h): w0 = fp16(w), w1' = fp16((w - w0) 2^11) at
+    [kb][t][part][lane][8]; the two entries differ only in WHICH row of W slot
+    (g, j) of a block holds -- 8 g + j, or the order in which a lane of the
+    previous layer's fp32 accumulators holds a row's features (4 g + j for
+    j < 4, 16 + 4 g + j - 4 otherwise); w0 + w1' / 2^11 is within 2^-22 of w."""
+    import numpy as np
+    from pointgnn_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(1)
+    for k_in, n_out in ((64, 128), (128, 300), (300, 300)):
+        w = rng.standard_normal((k_in, n_out)).astype(np.float32)
+        b = rng.standard_normal(n_out).astype(np.float32)
+        kb, nt = (k_in + 31) // 32, (n_out + 15) // 16
+        nbytes = lib.pgnn_packed_fc_f16x2_bytes(k_in, n_out)
+        assert nbytes == kb * nt * 2 * 1024 + nt * 16 * 4
+        lane, j = np.arange(64)[:, None], np.arange(8)[None, :]
+        g = lane >> 4
+        slot = {"pgnn_pack_fc_f16x2": 8 * g + j,
+                "pgnn_pack_fc_f16x2_acc":
+                    np.where(j < 4, 4 * g + j, 16 + 4 * g + (j - 4))}
+        for name, within in slot.items():
+            assert sorted(set(within.reshape(-1).tolist())) == list(range(32))
+            host = np.empty(nbytes, np.uint8)
+            _lib.check(getattr(lib, name)(w.ctypes.data, b.ctypes.data, k_in,
+                                          n_out, host.ctypes.data))
+            img = host[:kb * nt * 2 * 1024].view(np.float16).reshape(
+                kb, nt, 2, 64, 8).astype(np.float64)
+            kk = 32 * np.arange(kb)[:, None, None, None] + within[None, None]
+            nn = 16 * np.arange(nt)[None, :, None, None] + \
+                (lane & 15)[None, None] + 0 * kk
+            kk = kk + 0 * nn
+            inside = (kk < k_in) & (nn < n_out)
+            want = np.where(inside, w[np.minimum(kk, k_in - 1),
+                                      np.minimum(nn, n_out - 1)], 0.0)
+            w0 = want.astype(np.float16).astype(np.float64)
+            assert np.array_equal(img[:, :, 0], w0)
+            assert np.array_equal(
+                img[:, :, 1],
+                ((want - w0) * 2048.0).astype(np.float16).astype(np.float64))
+            err = np.abs(img[:, :, 0] + img[:, :, 1] / 2048.0 - want)
+            assert np.all(err <= np.abs(want) * 2.0 ** -22 + 2.0 ** -36)
+            bias = host[kb * nt * 2 * 1024:].view(np.float32)
+            assert np.array_equal(bias[:n_out], b) and np.all(bias[n_out:] == 0)
+    w = np.full((32, 16), 70000.0, np.float32)
+    host = np.empty(lib.pgnn_packed_fc_f16x2_bytes(32, 16), np.uint8)
+    assert lib.pgnn_pack_fc_f16x2_acc(w.ctypes.data, None, 32, 16,
+                                      host.ctypes.data) == _lib.E_UNSUPPORTED
