@@ -19,17 +19,20 @@ from . import graph_gen, kitti_output, models, nms, tf_bundle
 BOX_ENCODING_LEN = 7
 
 
-def build_model(config, checkpoint_dir=None, params=None):
+def build_model(config, checkpoint_dir=None, params=None, edge_arith='f32'):
     """run.py:135-141 + :192-201: the model in 'test' mode with the weights of
     the latest checkpoint under `checkpoint_dir` (or a ready name->array
-    mapping)."""
+    mapping).  `edge_arith` (extension): gnn.EDGE_ARITHS, default the fp32
+    path."""
     model = models.get_model(config['model_name'])(
         num_classes=config['num_classes'], box_encoding_len=BOX_ENCODING_LEN,
         mode='test', **config['model_kwargs'])
     if params is None:
         params = tf_bundle.load_checkpoint(checkpoint_dir)
     params = {k: v for k, v in params.items() if k != 'Variable'}
-    return model.load_state_dict(params)
+    model.load_state_dict(params)
+    model.edge_arith = edge_arith
+    return model
 
 
 def _input_features(config, points):
@@ -81,6 +84,16 @@ def detect_frame(dataset, frame_idx, model, config, use_box_merge=True,
     t = lap('gen graph', t)
     input_v = _input_features(config, points)
     logits, box_encodings = model.predict(input_v, coords, kps, edges, False)
+    if model.edge_arith == 'f16x2' and not model.edge_range_ok():
+        # an activation left fp16's safe range (gnn.EDGE_ARITHS): this frame
+        # in fp32 (the results are read below anyway: no extra wait)
+        td['f16x2 range reruns'] = td.get('f16x2 range reruns', 0) + 1
+        model.edge_arith = 'f32'
+        try:
+            logits, box_encodings = model.predict(input_v, coords, kps, edges,
+                                                  False)
+        finally:
+            model.edge_arith = 'f16x2'
     probs = model.postprocess(logits)
     t = lap('gnn inference', t)
     label_map = kitti_output.LABEL_MAPS[config['label_method']]
@@ -106,11 +119,11 @@ def detect_frame(dataset, frame_idx, model, config, use_box_merge=True,
 
 def run_dataset(dataset, config, checkpoint_dir, output_dir,
                 frame_indices=None, use_box_merge=True, use_box_score=True,
-                params=None, log=None, image_reader=None):
+                params=None, log=None, image_reader=None, edge_arith='f32'):
     """run.py:203-433 over `frame_indices` (default: the whole dataset).
     Writes `<output_dir>/data/<frame name>.txt` in the reference's format and
     returns the accumulated `time_dict` (seconds per stage, plus 'frames')."""
-    model = build_model(config, checkpoint_dir, params)
+    model = build_model(config, checkpoint_dir, params, edge_arith)
     if frame_indices is None:
         frame_indices = range(dataset.num_files)
     time_dict = {}

@@ -138,6 +138,54 @@ def test_files_to_kitti_txt(tmp_path, weights_kind):
         len(o_xyz), len(c_np[-1]), len(w_idx), len(want[3]), len(rows)))
 
 
+def test_frame_loop_with_the_f16x2_arithmetic(tmp_path):
+    """run.py's frame loop with edge_arith='f16x2' (extension of build_model /
+    run_dataset): the same detections as the fp32 loop to fp32 noise, and a
+    frame whose activations leave fp16's safe range is rerun in fp32."""
+    import torch
+    from test_ingest_cpu import _write_png_header_only
+    from pointgnn_amd import _lib, kitti_dataset as KD, tf_bundle
+    from pointgnn_amd import run as RUN
+    cfg = configs.get_config("car_auto_T1")
+    for d in ("image_2", "velodyne", "calib", "ckpt"):
+        (tmp_path / d).mkdir()
+    _velodyne_scan(21).tofile(str(tmp_path / "velodyne" / "000042.bin"))
+    (tmp_path / "calib" / "000042.txt").write_text("".join(IO.CALIB_LINES))
+    _write_png_header_only(str(tmp_path / "image_2" / "000042.png"), 375, 1242)
+    gold_w = np.load(os.path.join(GOLD, "weights_car_auto_T1.npz"))
+    tf_bundle.save_checkpoint(str(tmp_path / "ckpt"),
+                              {k: gold_w[k] for k in gold_w.files},
+                              global_step=1400000)
+    ds = KD.KittiDataset(str(tmp_path / "image_2"), str(tmp_path / "velodyne"),
+                         str(tmp_path / "calib"))
+    m32 = RUN.build_model(cfg, str(tmp_path / "ckpt"))
+    m16 = RUN.build_model(cfg, str(tmp_path / "ckpt"), edge_arith="f16x2")
+    assert m16.edge_arith == "f16x2" and m32.edge_arith == "f32"
+    _lib.set_tunable("b16_force", 1)      # (a small frame: below the kernels'
+    try:                                  # size threshold otherwise)
+        rows32, st32 = RUN.detect_frame(ds, 0, m32, cfg)
+        td = {}
+        rows16, st16 = RUN.detect_frame(ds, 0, m16, cfg, time_dict=td)
+        assert 'f16x2 range reruns' not in td
+        l32, l16 = st32['logits'], st16['logits']
+        assert not torch.equal(l32, l16), "the f16x2 kernels did not run"
+        assert float((l32 - l16).abs().max()) <= 2e-5 * float(l32.abs().max())
+        assert [r[0] for r in rows16] == [r[0] for r in rows32]
+        if rows32:
+            np.testing.assert_allclose(
+                np.array([r[4:] for r in rows16], np.float64),
+                np.array([r[4:] for r in rows32], np.float64), rtol=2e-3,
+                atol=2e-3)
+        # a frame flagged by the range guard: rerun in fp32, model unchanged
+        m16.edge_range_ok = lambda: False
+        td = {}
+        _, st = RUN.detect_frame(ds, 0, m16, cfg, time_dict=td)
+        assert td['f16x2 range reruns'] == 1 and m16.edge_arith == "f16x2"
+        assert torch.equal(st['logits'], l32)
+    finally:
+        _lib.set_tunable("b16_force", 0)
+
+
 def test_training_sample_from_kitti_files(tmp_path):
     """train.py:78-133 (`fetch_data`) on the device: KITTI files + label file
     -> crop -> augmentations -> training-mode graph -> label assignment ->
