@@ -51,6 +51,12 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 #ifndef PGNN_F16_DQ
 #define PGNN_F16_DQ PGNN_B16_DQ
 #endif
+// timing ablations (WRONG results; A/B builds only, tools/sessions/r05_s18.sh):
+// 1 no split arithmetic, 2 every row request to row 0, 4 fragments read once
+// per tile, 8 no segmented max
+#ifndef PGNN_F16_ABL
+#define PGNN_F16_ABL 0
+#endif
 constexpr float kF16Scale = 2048.0f;  // 2^11
 constexpr float kF16Max = 65504.0f;
 
@@ -84,6 +90,11 @@ __device__ __forceinline__ float sub_half_hi(float a, u32 pk) {
 // (44 instructions, stage by stage); gmax: running packed-u16 maximum of x0
 __device__ __forceinline__ void split_block_f16(const v4f (&p)[2], const v4f (&q)[2],
                                                 v4u &x0, v4u &x1, u32 &gmax) {
+#if PGNN_F16_ABL & 1
+  x0 = __builtin_bit_cast(v4u, p[0]) ^ __builtin_bit_cast(v4u, q[0]);
+  x1 = __builtin_bit_cast(v4u, p[1]) ^ __builtin_bit_cast(v4u, q[1]);
+  return;
+#endif
   float a[8], r[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) a[e] = p[e >> 2][e & 3] - q[e >> 2][e & 3];
@@ -155,9 +166,13 @@ __device__ __forceinline__ void edge_ws2_body(const EdgeWsArgs &a,
     u32 p, pt, q, qt;
   };
   auto rows_of = [&](int2 e, bool ok, int g, int toff) -> Rows {
+#if PGNN_F16_ABL & 2
+    const int s = 0, dq = 0;
+#else
     const int s = ok ? e.x : 0;
     const int d = ok ? e.y : -1;
     const int dq = ((unsigned)d < (unsigned)a.num_segments) ? d : 0;
+#endif
     Rows r;
     r.p = ((u32)s * (u32)a.ldv4 + 2u * g) * 16u;
     r.q = ((u32)dq * (u32)a.ldv4 + 2u * g) * 16u;
@@ -266,14 +281,23 @@ __device__ __forceinline__ void edge_ws2_body(const EdgeWsArgs &a,
         // registers were last read by the previous block's last term), w0 of
         // the next block (block 0 again behind the last) under the last term.
         const int kn = kb + 1 < KB ? kb + 1 : 0;
+#if PGNN_F16_ABL & 4
+        if (kb == 0) {
+#pragma unroll
+          for (int t = 0; t < NTG; ++t) w1[t] = frag(kb, t, 1);
+        }
+#else
 #pragma unroll
         for (int t = 0; t < NTG; ++t) w1[t] = frag(kb, t, 1);
+#endif
 #pragma unroll
         for (int t = 0; t < NTG; ++t) acc[t] = mfma_f16(w0[t], X0[kb], acc[t]);
 #pragma unroll
         for (int t = 0; t < NTG; ++t) alo[t] = mfma_f16(w0[t], X1[kb], alo[t]);
+#if !(PGNN_F16_ABL & 4)
 #pragma unroll
         for (int t = 0; t < NTG; ++t) w0[t] = frag(kn, t, 0);
+#endif
 #pragma unroll
         for (int t = 0; t < NTG; ++t) alo[t] = mfma_f16(w1[t], X0[kb], alo[t]);
         // issue order: MFMA, kValuPerMfma VALU; a fragment request after every
@@ -282,7 +306,7 @@ __device__ __forceinline__ void edge_ws2_body(const EdgeWsArgs &a,
         for (int m = 0; m < 3 * NTG; ++m) {
           __builtin_amdgcn_sched_group_barrier(0x8 /*MFMA*/, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x2 /*VALU*/, kValuPerMfma, 0);
-          if (m < NTG || m >= 2 * NTG)
+          if (!(PGNN_F16_ABL & 4) && (m < NTG || m >= 2 * NTG))
             __builtin_amdgcn_sched_group_barrier(0x100 /*DS read*/, 1, 0);
           if (m % kLoadEvery == 1 && m / kLoadEvery < 4)
             __builtin_amdgcn_sched_group_barrier(0x20 /*VMEM read*/, 1, 0);
@@ -313,8 +337,21 @@ __device__ __forceinline__ void edge_ws2_body(const EdgeWsArgs &a,
       starts = (unsigned)(__ballot(my_d != prev) & 0xFFFFull);
     }  // !fin
     WsRun st = {cur_d, cur_left_closed, cur_has};
+#if PGNN_F16_ABL & 8
+#pragma unroll
+    for (int t = 0; t < NTG; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) carry[t][r] = fmaxf(carry[t][r], acc[t][r]);
+    if (fin && a.relu_from == -12345) {  // (never true; keeps every tile live)
+#pragma unroll
+      for (int t = 0; t < NTG; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a.out[(t * 4 + r) * 64 + lane] = carry[t][r];
+    }
+#else
     ws_epilogue<NTG>(a, bias_lds, t0, lane, acc, carry, starts, my_d, st, fin,
                      d_after, inf);
+#endif
     cur_d = st.cur_d;
     cur_left_closed = st.left_closed;
     cur_has = st.has;
