@@ -324,6 +324,10 @@ __global__ __launch_bounds__(256) void pack_many_kernel(
 // points) are rare; they are routed exactly (route sees every tied row; a
 // separate pass adds their weight-gradient terms and runs only when the
 // count pass raised the tie flag).
+#ifndef PGNN_CW_ITEMS
+#define PGNN_CW_ITEMS 4
+#endif
+constexpr int kCwItems = PGNN_CW_ITEMS;
 __global__ void segmax_count_win4_kernel(
     const float *__restrict__ data, int64_t ld, const int32_t *__restrict__ seg,
     int64_t rows, int cols4, int nseg, const float *__restrict__ out,
@@ -332,15 +336,17 @@ __global__ void segmax_count_win4_kernel(
     int tie_cap) {
   const int64_t total = rows * cols4;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  // two items per trip: both segment ids, then both (row, maxima) pairs are in
-  // flight together (one item per trip was two dependent round trips per trip)
+  // kCwItems items per trip: all segment ids, then all (row, maxima) pairs are
+  // in flight together (one item per trip was two dependent round trips per
+  // trip: 55 us; two: 52; four: see DESIGN 5)
+  constexpr int U = kCwItems;
   for (int64_t idx0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-       idx0 < total; idx0 += 2 * stride) {
-    int64_t r[2];
-    int c[2], s[2];
-    bool ok[2];
+       idx0 < total; idx0 += U * stride) {
+    int64_t r[U];
+    int c[U], s[U];
+    bool ok[U];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < U; ++u) {
       const int64_t idx = idx0 + u * stride;
       ok[u] = idx < total;
       const int64_t ic = ok[u] ? idx : idx0;  // clamped: an unconditional load
@@ -348,16 +354,16 @@ __global__ void segmax_count_win4_kernel(
       c[u] = 4 * (int)(ic - r[u] * cols4);
       s[u] = seg[r[u]];
     }
-    v4f d[2], o[2];
+    v4f d[U], o[U];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < U; ++u) {
       ok[u] = ok[u] && s[u] >= 0 && s[u] < nseg;
       const int sc = ok[u] ? s[u] : 0;
       d[u] = *reinterpret_cast<const v4f *>(data + r[u] * ld + c[u]);
       o[u] = *reinterpret_cast<const v4f *>(out + (int64_t)sc * ldo + c[u]);
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < U; ++u) {
       if (!ok[u]) continue;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
