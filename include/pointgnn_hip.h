@@ -527,7 +527,9 @@ int pgnn_edge_mlp_scatter_max_bf16x3_fwd(
  * cent over the fp32 entry's (tests: the edge_arith-parametrised parity tests,
  * same bars as bf16x3).  Range: the gathered operand is clamped at 65504, and
  * bit 0 of *status (device int32, nullable; the caller zeroes it) is raised
- * when one reached 32768 -- rerun the stage through the fp32 entry then.
+ * when one COULD have reached 32768 (an element of the first num_vertices
+ * rows of P or Q at or above 16384 in magnitude, or not a number: checked in
+ * the kernel's prologue) -- rerun the stage through the fp32 entry then.
  * `image`: device copy of what pgnn_pack_fc_f16x2 wrote (it refuses weights
  * of magnitude >= 32768 with PGNN_E_UNSUPPORTED).  Otherwise as the bf16x3
  * entry, PGNN_E_UNSUPPORTED included.                                        */

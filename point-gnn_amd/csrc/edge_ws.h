@@ -104,6 +104,9 @@ struct EdgeWsArgs {
   // [n_edges, 4 * ldv4] (written by the workgroups of column group 0 only:
   // every group gathers the same rows)
   float *h1_out;
+  // edge_ws_f16.h only: the vertex count of a capacity-form call (nullable;
+  // min(*nv_dev, num_segments) rows of P / Q exist) for the range guard
+  const int32_t *nv_dev;
 };
 
 // max(a, b) as ONE instruction: fmaxf() first canonicalises operands the

@@ -25,9 +25,10 @@
 //
 // Range.  fp16 ends at 65504.  The gathered operand h = ReLU(P[s] - Q[d]) is
 // clamped there by the v_med3_f32 that is its ReLU (no extra instruction), and
-// the kernel raises bit 0 of `status` when any h reached 32768: results are
-// then unreliable and the caller reruns the stage in fp32 (gnn.py does; a
-// trained Point-GNN's activations are below 100).  The weights' image is built
+// the kernel raises bit 0 of `status` when some h COULD have reached 32768 (an
+// element of P or Q at or above 16384 in magnitude, or not a number: checked
+// in the kernel's prologue): the caller reruns the stage in fp32 (run.py's
+// frame loop does; a trained Point-GNN's activations are below 100).  The weights' image is built
 // on the host, which refuses weights outside fp16's range.
 //
 // Layouts: v_mfma_f32_16x16x32_f16 has the operand layouts of the bf16 form
@@ -53,7 +54,7 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 #endif
 // timing ablations (WRONG results; A/B builds only, tools/sessions/r05_s18.sh):
 // 1 no split arithmetic, 2 every row request to row 0, 4 fragments read once
-// per tile, 8 no segmented max
+// per tile, 8 no segmented max, 32 no v_ldexp
 #ifndef PGNN_F16_ABL
 #define PGNN_F16_ABL 0
 #endif
@@ -88,6 +89,7 @@ __device__ __forceinline__ float sub_half_hi(float a, u32 pk) {
 
 // min(ReLU(p - q), 65504) of 8 consecutive features -> two packed fp16 parts
 // (44 instructions, stage by stage); gmax: running packed-u16 maximum of x0
+template <bool TRACK = true>
 __device__ __forceinline__ void split_block_f16(const v4f (&p)[2], const v4f (&q)[2],
                                                 v4u &x0, v4u &x1, u32 &gmax) {
 #if PGNN_F16_ABL & 1
@@ -107,15 +109,19 @@ __device__ __forceinline__ void split_block_f16(const v4f (&p)[2], const v4f (&q
     r[2 * j] = sub_half_lo(a[2 * j], x0[j]);
     r[2 * j + 1] = sub_half_hi(a[2 * j + 1], x0[j]);
   }
+#if !(PGNN_F16_ABL & 32)
 #pragma unroll
   for (int e = 0; e < 8; ++e) r[e] = __builtin_ldexpf(r[e], 11);  // v_ldexp_f32
+#endif
 #pragma unroll
   for (int j = 0; j < 4; ++j) x1[j] = cvt_pk_f16(r[2 * j], r[2 * j + 1]);
   // (an asm statement: written with __builtin_elementwise_max on two-half
   // vectors, hipcc 7.2 keeps ONE of the four maxima)
+  if constexpr (TRACK) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
-    asm("v_pk_max_u16 %0, %0, %1" : "+v"(gmax) : "v"(x0[j]));
+    for (int j = 0; j < 4; ++j)
+      asm("v_pk_max_u16 %0, %0, %1" : "+v"(gmax) : "v"(x0[j]));
+  }
 }
 
 // tiles [tile_first, tile_last) of 16 edge rows, column tiles t0 .. t0+NTG-1
@@ -210,7 +216,7 @@ __device__ __forceinline__ void edge_ws2_body(const EdgeWsArgs &a,
     for (int k = 1; k < DQ; ++k) load_blk(Q4, rc.q, rc.qt, k, qc[k - 1]);
 #pragma unroll
     for (int k = 1; k < DP; ++k) load_blk(P4, rc.p, rc.pt, k, pc[k - 1]);
-    split_block_f16(p0, q0, X0c, X1c, gmax);
+    split_block_f16<false>(p0, q0, X0c, X1c, gmax);
   }
   v4u w0[NTG], w1[NTG];
   {
@@ -274,7 +280,8 @@ __device__ __forceinline__ void edge_ws2_body(const EdgeWsArgs &a,
         else
           load_blk(P4, rn.p, rn.pt, kb + DP - KB, Pb[kb + DP]);
         // parts of the next block (block 0 of the next tile behind the last)
-        split_block_f16(Pb[kb + 1], Qb[kb + 1], X0[kb + 1], X1[kb + 1], gmax);
+        split_block_f16<false>(Pb[kb + 1], Qb[kb + 1], X0[kb + 1], X1[kb + 1],
+                               gmax);
         // the three terms of this block, term-major (consecutive MFMAs hit
         // different accumulators): (w0 x0) -> hi | (w0 x1') -> lo | (w1' x0)
         // -> lo.  w1' of THIS block is requested under the first term (its
@@ -361,7 +368,7 @@ __device__ __forceinline__ void edge_ws2_body(const EdgeWsArgs &a,
 
 // a.wp: the f16x2 image (pgnn_pack_fc_f16x2) of the layer; static partition of
 // the 16-row tiles as in edge_ws_kernel (no tile pool).  status (nullable):
-// bit 0 is set when a gathered activation reached 32768 (see the header)
+// bit 0 is set when a gathered activation could reach 32768 (see the header)
 template <int KB, int NTMAX>
 __global__ __launch_bounds__(64 * kWsWaves) void edge_ws_f16x2_kernel(EdgeWsArgs a, int32_t *status) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -379,6 +386,37 @@ __global__ __launch_bounds__(64 * kWsWaves) void edge_ws_f16x2_kernel(EdgeWsArgs
   }
   const int t0 = a.tile0[grp];
   const int ntg = a.tile0[grp + 1] - t0;
+  // ---- range guard, before anything else (its loads overlap the weights'):
+  // workgroup b scans rows b, b + gridDim.x, ... of P and Q.  No |P| or |Q| at
+  // or above 16384 => every gathered ReLU(P[s] - Q[d]) is below 32768.  (One
+  // pass over 8 MB shared by all workgroups instead of a running maximum of
+  // the first parts in the MFMA loop: 4 instructions per block, 4 % of the
+  // kernel, tools/sessions/r05_s20.sh.)
+  if (status) {
+    int nv = a.num_segments;
+    if (a.nv_dev) {
+      const int d = *a.nv_dev;
+      nv = d < nv ? d : nv;
+    }
+    const v4f *__restrict__ P4 = reinterpret_cast<const v4f *>(a.P);
+    const v4f *__restrict__ Q4 = reinterpret_cast<const v4f *>(a.Q);
+    float m = 0.0f;
+    bool bad = false;
+    const int mine = nv > (int)blockIdx.x
+                         ? (nv - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x
+                         : 0;   // rows blockIdx.x + j * gridDim.x, j < mine
+    for (int it = threadIdx.x; it < mine * a.ldv4; it += 64 * kWsWaves) {
+      const int j = it / a.ldv4, c = it - j * a.ldv4;
+      const size_t at = ((size_t)blockIdx.x + (size_t)j * gridDim.x) * a.ldv4 + c;
+      const v4f p = P4[at], q = Q4[at];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        m = fmaxf(m, fmaxf(fabsf(p[i]), fabsf(q[i])));
+        bad |= !(p[i] == p[i]) || !(q[i] == q[i]);   // NaN: fmaxf drops it
+      }
+    }
+    if (bad || !(m < 16384.0f)) atomicOr(status, 1);
+  }
   {
     // fragments (kb, t, part) of this group -> LDS [kb][t][part][lane]; all of
     // a wave's requests in flight before its first LDS write (edge_ws_kernel)
@@ -431,10 +469,7 @@ __global__ __launch_bounds__(64 * kWsWaves) void edge_ws_f16x2_kernel(EdgeWsArgs
   else
     edge_ws2_body<KB, NTMAX - 1>(a, wl, t0, bias_lds, tile_first, tile_last,
                                  lane, n_edges, gmax);
-  // an fp16 half >= 0x7800 is a value >= 32768 (the operands are >= 0: their
-  // bit patterns order like the values)
-  if (status && ((gmax & 0xffffu) >= 0x7800u || (gmax >> 16) >= 0x7800u))
-    atomicOr(status, 1);
+  (void)gmax;  // (the running maximum is pool_ws_f16.h's guard; here: above)
 }
 
 }  // namespace pgnn

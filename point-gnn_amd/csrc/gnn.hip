@@ -1802,6 +1802,7 @@ extern "C" int pgnn_edge_mlp_scatter_max_f16x2_fwd(
   a.sorted = edges_sorted & 1;
   a.xcds = (g_ws_xcds >= 1 && cus % g_ws_xcds == 0) ? g_ws_xcds : 8;
   a.prio = 0;
+  a.nv_dev = dk.dev;
   if (kb == 10) return launch_edge_ws2<10, 7>(a, nt, cus, status, stream);
   return launch_edge_ws2<8, 6>(a, nt, cus, status, stream);
   PGNN_GUARD_END

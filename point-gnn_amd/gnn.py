@@ -617,7 +617,7 @@ EDGE_INPUT_TAP = None
 #               (csrc/edge_ws_f16.h, pgnn_edge_mlp_scatter_max_f16x2_fwd):
 #               not exact -- the stage's distance to float64 grows by a few per
 #               cent -- ~3x faster than 'f32'.  Activations are clamped at
-#               65504; the kernel flags any that reached 32768 and
+#               65504; the kernel flags frames in which one could reach 32768 and
 #               `model.edge_range_ok()` (read by the engine with a frame's
 #               results) reports it: rerun such a frame in 'f32'.  Also covers
 #               the wide last layer of PointSetPooling's point MLP
