@@ -875,6 +875,19 @@ int pgnn_loss_fwd_bwd_counts(const float *logits, int64_t ld_logits,
 int pgnn_sgd_step(float *params, const float *grads, const float *is_weight,
                   int64_t n, float lr, float grad_scale, float l1_scale,
                   void *stream);
+/* The other optimizers train.py:380-391 offers, TF 1.x update rules on the same
+ * flat buffers (gradient = grad_scale*grads + l1_scale*sign(params)*is_weight
+ * as above; slot0 / slot1: optimizer state with the parameters' layout):
+ *   kind 1 MomentumOptimizer (h0 = momentum, no Nesterov): slot0 = accumulator
+ *   kind 2 RMSPropOptimizer (h0 = momentum, h1 = decay, h2 = epsilon; not
+ *          centered): slot0 = ms (TF initialises it to ONES), slot1 = mom
+ *   kind 3 AdamOptimizer (h0 = beta1, h1 = beta2, h2 = epsilon): slot0 = m,
+ *          slot1 = v; `lr` is the caller's bias-corrected
+ *          lr * sqrt(1 - beta2^t) / (1 - beta1^t), t = 1, 2, ...            */
+int pgnn_optimizer_step(int32_t kind, float *params, const float *grads,
+                        const float *is_weight, float *slot0, float *slot1,
+                        int64_t n, float lr, float grad_scale, float l1_scale,
+                        float h0, float h1, float h2, void *stream);
 /* *out (device double) = sum |params| over is_weight entries (reg_loss/scale). */
 int pgnn_l1_norm(const float *params, const float *is_weight, int64_t n,
                  double *out, void *stream);

@@ -312,6 +312,8 @@ _SIGNATURES = {
                                          c_vp, c_vp]),
     "pgnn_sgd_step": (c_i32, [c_vp, c_vp, c_vp, c_i64, ctypes.c_float,
                               ctypes.c_float, ctypes.c_float, c_vp]),
+    "pgnn_optimizer_step": (c_i32, [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64] +
+                            [ctypes.c_float] * 6 + [c_vp]),
     "pgnn_l1_norm": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp]),
     # detection post-processing
     "pgnn_box_decode_f32": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i64,

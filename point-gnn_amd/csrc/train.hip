@@ -1188,6 +1188,48 @@ __global__ void sgd_kernel(float *__restrict__ w, const float *__restrict__ g,
   }
 }
 
+// The other optimizers of train.py:380-391 on the flat parameter buffer, with
+// TF 1.x's update rules (training_ops.cc: ApplyMomentum without Nesterov,
+// ApplyRMSProp (not centered), ApplyAdam): the gradient is the one sgd_kernel
+// applies (scaled batch gradient + the L1 regulariser's sign term), the slot
+// buffers have the parameters' layout.
+//   kind 1 momentum: a = h0 a + g;                  w -= lr a
+//   kind 2 rmsprop : ms = h1 ms + (1 - h1) g^2;
+//                    mom = h0 mom + lr g / sqrt(ms + h2);   w -= mom
+//   kind 3 adam    : m = h0 m + (1 - h0) g;  v = h1 v + (1 - h1) g^2;
+//                    w -= lr m / (sqrt(v) + h2)     (lr: bias-corrected by the caller)
+__global__ void optimizer_kernel(int kind, float *__restrict__ w,
+                                 const float *__restrict__ g,
+                                 const float *__restrict__ is_weight,
+                                 float *__restrict__ s0, float *__restrict__ s1,
+                                 int64_t n, float lr, float grad_scale, float l1,
+                                 float h0, float h1, float h2) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float wi = w[i];
+    float gi = g[i] * grad_scale;
+    if (is_weight[i] != 0.0f)
+      gi += l1 * (wi > 0.0f ? 1.0f : (wi < 0.0f ? -1.0f : 0.0f));
+    if (kind == 1) {
+      const float a = h0 * s0[i] + gi;
+      s0[i] = a;
+      w[i] = wi - lr * a;
+    } else if (kind == 2) {
+      const float ms = h1 * s0[i] + (1.0f - h1) * gi * gi;
+      const float mom = h0 * s1[i] + lr * gi / sqrtf(ms + h2);
+      s0[i] = ms;
+      s1[i] = mom;
+      w[i] = wi - mom;
+    } else {
+      const float m = h0 * s0[i] + (1.0f - h0) * gi;
+      const float v = h1 * s1[i] + (1.0f - h1) * gi * gi;
+      s0[i] = m;
+      s1[i] = v;
+      w[i] = wi - lr * m / (sqrtf(v) + h2);
+    }
+  }
+}
+
 __global__ __launch_bounds__(1024) void l1_norm_kernel(
     const float *__restrict__ w, const float *__restrict__ is_weight, int64_t n,
     double *__restrict__ out) {
@@ -2200,6 +2242,25 @@ extern "C" int pgnn_sgd_step(float *params, const float *grads,
   hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n)), dim3(256), 0,
                      (hipStream_t)stream_, params, grads, is_weight, n, lr,
                      grad_scale, l1_scale);
+  PGNN_HIP(hipGetLastError());
+  return 0;
+  PGNN_GUARD_END
+}
+
+extern "C" int pgnn_optimizer_step(int32_t kind, float *params,
+                                   const float *grads, const float *is_weight,
+                                   float *slot0, float *slot1, int64_t n,
+                                   float lr, float grad_scale, float l1_scale,
+                                   float h0, float h1, float h2, void *stream_) {
+  PGNN_GUARD_BEGIN
+  PGNN_REQUIRE(kind >= 1 && kind <= 3, PGNN_E_INVALID,
+               "optimizer_step: kind must be 1 (momentum), 2 (rmsprop) or 3 (adam)");
+  if (n <= 0) return 0;
+  PGNN_REQUIRE(params && grads && is_weight && slot0 && (kind == 1 || slot1),
+               PGNN_E_INVALID, "optimizer_step: null pointer");
+  hipLaunchKernelGGL(optimizer_kernel, dim3(grid_for(n)), dim3(256), 0,
+                     (hipStream_t)stream_, kind, params, grads, is_weight, slot0,
+                     slot1, n, lr, grad_scale, l1_scale, h0, h1, h2);
   PGNN_HIP(hipGetLastError());
   return 0;
   PGNN_GUARD_END

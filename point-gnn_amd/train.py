@@ -8,7 +8,7 @@ TF towers:
   * unify_copies re-weighting                train.py:264-288  -> global 1/N, 1/N_valid
   * average_gradients over towers            util/tf_util.py:3-43 -> ONE all-reduce(sum)
     of the flat fp32 gradient buffer (RCCL over xGMI; 5.96 MB for car_auto_T3)
-  * GradientDescentOptimizer + staircase decay  train.py:375-405 -> pgnn_sgd_step
+  * GradientDescentOptimizer (and momentum / rmsprop / adam) + staircase decay  train.py:375-405 -> pgnn_sgd_step / pgnn_optimizer_step
 
 Every arithmetic step runs in a HIP kernel behind the C ABI; torch is used for
 allocation, views/concatenation and the three residual-style tensor adds of the
@@ -323,6 +323,18 @@ class _Fc(object):
         self.wt = None        # plain W^T [n_out, pad16(k_in)] (sparse adjoint)
 
 
+# train.py:380-391: name -> (pgnn_optimizer_step kind, TF 1.x default kwargs,
+# TF slot names in a checkpoint: '<variable>/<slot>')
+_OPTIMIZERS = {
+    'sgd': (0, {}, ()),
+    'momentum': (1, {'momentum': 0.9, 'use_nesterov': False}, ('Momentum',)),
+    'rmsprop': (2, {'momentum': 0.9, 'decay': 0.9, 'epsilon': 1.0,
+                    'centered': False}, ('RMSProp', 'RMSProp_1')),
+    'adam': (3, {'beta1': 0.9, 'beta2': 0.999, 'epsilon': 1e-8},
+             ('Adam', 'Adam_1')),
+}
+
+
 class Trainer(object):
     def __init__(self, config, train_config=None, params=None, seed=0,
                  device=None, box_encoding_len=7, process_group=None):
@@ -330,8 +342,20 @@ class Trainer(object):
         self.train_config = train_config or {
             'initial_lr': 0.125, 'decay_step': 400000, 'decay_factor': 0.1,
             'optimizer': 'sgd', 'unify_copies': True}
-        if self.train_config.get('optimizer', 'sgd') != 'sgd':
-            raise NotImplementedError("only the shipped 'sgd' optimizer")
+        # train.py:380-391: optimizer class + default kwargs, overridden by
+        # train_config['optimizer_kwargs']
+        opt = self.train_config.get('optimizer', 'sgd')
+        if opt not in _OPTIMIZERS:
+            raise ValueError("optimizer %r (train.py:380-385 knows %s)"
+                             % (opt, sorted(_OPTIMIZERS)))
+        self.optimizer = opt
+        self.opt_kwargs = dict(_OPTIMIZERS[opt][1])
+        self.opt_kwargs.update(self.train_config.get('optimizer_kwargs') or {})
+        unknown = set(self.opt_kwargs) - set(_OPTIMIZERS[opt][1])
+        if unknown or self.opt_kwargs.get('use_nesterov') or \
+                self.opt_kwargs.get('centered'):
+            raise NotImplementedError(
+                "optimizer_kwargs %s of %r" % (sorted(self.opt_kwargs), opt))
         if not self.train_config.get('unify_copies', True):
             # train.py:264-288: without it every tower normalises by its OWN
             # endpoint counts; the step below always uses the global ones
@@ -388,6 +412,11 @@ class Trainer(object):
         self.flat = torch.from_numpy(flat).to(self.device)
         self.grad = torch.zeros_like(self.flat)
         self.is_weight = torch.from_numpy(mask).to(self.device)
+        # optimizer slots (TF: zeros, RMSProp's mean square ones), parameter layout
+        self.slots = [torch.zeros_like(self.flat)
+                      for _ in _OPTIMIZERS[self.optimizer][2]]
+        if self.optimizer == 'rmsprop':
+            self.slots[0].fill_(1.0)
         self.fc = {}
         for name, shape in self.specs:
             if not name.endswith('/weights'):
@@ -429,13 +458,61 @@ class Trainer(object):
         return {name: self._view(self.flat, name).cpu().numpy()
                 for name, _ in self.specs}
 
+    def _apply_gradients(self, lr):
+        """optimizer.apply_gradients (train.py:392-405) on the flat buffers;
+        `lr` is the decayed learning rate of this step."""
+        kind = _OPTIMIZERS[self.optimizer][0]
+        kw = self.opt_kwargs
+        if kind == 0:
+            _lib.check(self.lib.pgnn_sgd_step(
+                _lib.ptr(self.flat), _lib.ptr(self.grad),
+                _lib.ptr(self.is_weight), self.flat.numel(),
+                ctypes.c_float(lr), ctypes.c_float(1.0),
+                ctypes.c_float(self.l1_scale), self._st()), "pgnn_sgd_step")
+            return
+        if kind == 1:
+            h = (kw['momentum'], 0.0, 0.0)
+        elif kind == 2:
+            h = (kw['momentum'], kw['decay'], kw['epsilon'])
+        else:
+            # AdamOptimizer: lr_t = lr sqrt(1 - beta2^t) / (1 - beta1^t), t
+            # counting this optimizer's own steps from 1 (its beta*_power
+            # variables; global_step counts the same here)
+            t = self.global_step + 1
+            lr = lr * np.sqrt(1.0 - kw['beta2'] ** t) / (1.0 - kw['beta1'] ** t)
+            h = (kw['beta1'], kw['beta2'], kw['epsilon'])
+        _lib.check(self.lib.pgnn_optimizer_step(
+            kind, _lib.ptr(self.flat), _lib.ptr(self.grad),
+            _lib.ptr(self.is_weight), _lib.ptr(self.slots[0]),
+            _lib.ptr(self.slots[1]) if len(self.slots) > 1 else None,
+            self.flat.numel(), ctypes.c_float(lr), ctypes.c_float(1.0),
+            ctypes.c_float(self.l1_scale), ctypes.c_float(h[0]),
+            ctypes.c_float(h[1]), ctypes.c_float(h[2]), self._st()),
+            "pgnn_optimizer_step")
+
+    def optimizer_state_dict(self):
+        """The optimizer's slot variables under TF's names ('<variable>/<slot>',
+        plus Adam's beta1_power / beta2_power): what tf.train.Saver writes next
+        to the weights."""
+        out = {}
+        for slot, buf in zip(_OPTIMIZERS[self.optimizer][2], self.slots):
+            for name, _ in self.specs:
+                out[name + '/' + slot] = self._view(buf, name).cpu().numpy()
+        if self.optimizer == 'adam':
+            t = self.global_step + 1      # TF keeps beta^(steps taken + 1)
+            out['beta1_power'] = np.float32(self.opt_kwargs['beta1'] ** t)
+            out['beta2_power'] = np.float32(self.opt_kwargs['beta2'] ** t)
+        return out
+
     def save_checkpoint(self, train_dir):
         """train.py:625-638: TF-bundle checkpoint `model-<global_step>` (weights
         under their TF names + the int32 step `Variable`) that the reference's
         run.py / train.py restore unchanged."""
         from . import tf_bundle
+        state = self.state_dict()
+        state.update(self.optimizer_state_dict())
         return tf_bundle.save_checkpoint(
-            train_dir, self.state_dict(), global_step=self.global_step,
+            train_dir, state, global_step=self.global_step,
             name=self.train_config.get('checkpoint_path', 'model'))
 
     def load_checkpoint(self, train_dir):
@@ -447,6 +524,14 @@ class Trainer(object):
         for name, _ in self.specs:
             self._view(self.flat, name).copy_(
                 torch.from_numpy(np.ascontiguousarray(ck[name], np.float32)))
+            # optimizer slots, when the checkpoint has them (one written by
+            # another optimizer restores the weights only, like a Saver built
+            # for these variables would fail -- here: fresh slots)
+            for slot, buf in zip(_OPTIMIZERS[self.optimizer][2], self.slots):
+                key = name + '/' + slot
+                if key in ck:
+                    self._view(buf, name).copy_(torch.from_numpy(
+                        np.ascontiguousarray(ck[key], np.float32)))
         self.repack()
         return self
 
@@ -1207,11 +1292,7 @@ class Trainer(object):
             _lib.ptr(self.flat), _lib.ptr(self.is_weight), self.flat.numel(),
             _lib.ptr(l1), self._st()), "pgnn_l1_norm")
         if apply:
-            _lib.check(self.lib.pgnn_sgd_step(
-                _lib.ptr(self.flat), _lib.ptr(self.grad),
-                _lib.ptr(self.is_weight), self.flat.numel(),
-                ctypes.c_float(lr), ctypes.c_float(1.0),
-                ctypes.c_float(self.l1_scale), self._st()), "pgnn_sgd_step")
+            self._apply_gradients(lr)
             self.repack()
             self.global_step += 1
         parts = [sums, l1] if counts_dev is None else [sums, l1, counts_dev]

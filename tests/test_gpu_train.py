@@ -462,6 +462,90 @@ def test_sgd_step_and_loss_decrease(dev):
     assert losses[-1] < losses[0], losses
 
 
+@pytest.mark.parametrize("opt,kwargs", [
+    ("momentum", {}), ("rmsprop", {}), ("adam", {}),
+    ("momentum", {"momentum": 0.5}), ("adam", {"beta1": 0.8, "epsilon": 1e-6})])
+def test_other_optimizers_follow_tf_update_rules(dev, opt, kwargs, tmp_path):
+    """train.py:380-391: 'momentum' / 'rmsprop' / 'adam' with the reference's
+    default kwargs (and train_config['optimizer_kwargs'] overrides): three
+    steps against TF 1.x's update rules (ApplyMomentum, ApplyRMSProp,
+    ApplyAdam) replayed in NumPy on the device's own gradients; slots travel
+    through a checkpoint under TF's names and a resumed trainer continues bit
+    for bit."""
+    import torch
+    from pointgnn_amd import tf_bundle, train
+    cfg = configs.car_auto_config(1)
+    params = weights.init_params(cfg, seed=6, bias_scale=0.05)
+    batch = _tiny_batch(seed=4)
+    tcfg = {'initial_lr': 0.01, 'decay_step': 2, 'decay_factor': 0.5,
+            'optimizer': opt, 'optimizer_kwargs': kwargs, 'unify_copies': True}
+    tr = train.Trainer(cfg, train_config=tcfg, params=params, device=dev)
+    scale = cfg['model_kwargs']['regularizer_kwargs']['scale']
+    f = np.float32
+    kw = dict({'momentum': {'momentum': 0.9},
+               'rmsprop': {'momentum': 0.9, 'decay': 0.9, 'epsilon': 1.0},
+               'adam': {'beta1': 0.9, 'beta2': 0.999, 'epsilon': 1e-8}}[opt],
+              **kwargs)
+    s0 = {n: np.full_like(v, 1.0 if opt == 'rmsprop' else 0.0)
+          for n, v in tr.state_dict().items()}
+    s1 = {n: np.zeros_like(v) for n, v in s0.items()}
+    for step in range(3):
+        before = tr.state_dict()
+        tr.train_step(batch)
+        g, after = tr.grad_dict(), tr.state_dict()
+        lr = f(train.learning_rate(tcfg, step))
+        for n in before:
+            gi = g[n] + (f(scale) * np.sign(before[n])
+                         if n.endswith('/weights') else 0)
+            gi = gi.astype(f)
+            if opt == 'momentum':
+                s0[n] = f(kw['momentum']) * s0[n] + gi
+                want = before[n] - lr * s0[n]
+            elif opt == 'rmsprop':
+                s0[n] = f(kw['decay']) * s0[n] + f(1 - kw['decay']) * gi * gi
+                s1[n] = f(kw['momentum']) * s1[n] + \
+                    lr * gi / np.sqrt(s0[n] + f(kw['epsilon']))
+                want = before[n] - s1[n]
+            else:
+                t = step + 1
+                lr_t = f(lr * np.sqrt(1 - kw['beta2'] ** t) /
+                         (1 - kw['beta1'] ** t))
+                s0[n] = f(kw['beta1']) * s0[n] + f(1 - kw['beta1']) * gi
+                s1[n] = f(kw['beta2']) * s1[n] + f(1 - kw['beta2']) * gi * gi
+                want = before[n] - lr_t * s0[n] / (np.sqrt(s1[n]) +
+                                                  f(kw['epsilon']))
+            np.testing.assert_allclose(after[n], want, atol=2e-7, rtol=2e-5,
+                                       err_msg="%s step %d %s" % (opt, step, n))
+    # slots in the checkpoint under TF's names; resume == uninterrupted
+    tr.save_checkpoint(str(tmp_path))
+    ck = tf_bundle.load_checkpoint(str(tmp_path))
+    slot_names = {'momentum': ['Momentum'], 'rmsprop': ['RMSProp', 'RMSProp_1'],
+                  'adam': ['Adam', 'Adam_1']}[opt]
+    some = next(n for n in s0 if n.endswith('/weights'))
+    for i, sl in enumerate(slot_names):
+        np.testing.assert_allclose(ck[some + '/' + sl], (s0, s1)[i][some],
+                                   atol=2e-7, rtol=2e-5)
+    if opt == 'adam':
+        assert np.isclose(float(np.asarray(ck['beta1_power']).reshape(-1)[0]),
+                          kw['beta1'] ** 4)
+    b = train.Trainer(cfg, train_config=tcfg, seed=99, device=dev)
+    b.load_checkpoint(str(tmp_path))
+    assert b.global_step == 3 and torch.equal(tr.flat, b.flat)
+    for sa, sb in zip(tr.slots, b.slots):
+        assert torch.equal(sa, sb)
+    tr.train_step(batch)
+    b.train_step(batch)
+    # (the gradient's float atomics make two runs of a step differ in the last
+    # bits; a resumed trainer WITHOUT its slots would be off by ~lr * slot)
+    assert torch.allclose(tr.flat, b.flat, rtol=1e-5, atol=1e-7)
+    with pytest.raises(ValueError):
+        train.Trainer(cfg, train_config=dict(tcfg, optimizer='lion'), device=dev)
+    with pytest.raises(NotImplementedError):
+        train.Trainer(cfg, train_config=dict(
+            tcfg, optimizer='momentum',
+            optimizer_kwargs={'use_nesterov': True}), device=dev)
+
+
 def test_trainer_checkpoint_resume(dev, tmp_path):
     """train.py:512-516, 625-638: save after a few steps, resume in a fresh
     Trainer, and continue identically; the saved weights also drive inference
