@@ -250,7 +250,10 @@ def train_epochs(dataset, config, train_config, trainer=None, max_epoch=None,
             frames = [fetch_data(dataset, int(i), config, train_config, aug_fn,
                                  graph_hints) for i in mine]
             batch = batch_data(frames)
-            results = trainer.train_step(batch)
+            if train_config.get('is_pseudo_batch', False):
+                results, _ = trainer.pseudo_batch_step(batch)
+            else:
+                results = trainer.train_step(batch)
             results['total_loss'] = results['cls_loss'] + \
                 results['loc_loss'] + results['reg_loss']
             probs = torch.softmax(
@@ -361,16 +364,22 @@ class Trainer(object):
             # endpoint counts; the step below always uses the global ones
             raise NotImplementedError(
                 "unify_copies=False (every shipped train config sets it True)")
-        if self.train_config.get('is_pseudo_batch', False):
-            # train.py:559-575: gradient accumulation over tower-sized
-            # sub-batches; no shipped train config sets it
-            raise NotImplementedError(
-                "is_pseudo_batch (train.py:559-575): no shipped config uses it")
-        if int(self.train_config.get('COPY_PER_GPU', 1)) != 1:
-            # train.py:174-182: several towers per GPU; here one process per
-            # GPU takes batch_size / world frames in one merged batch
-            raise NotImplementedError(
-                "COPY_PER_GPU != 1 (train.py:174-182): no shipped config sets it")
+        # train.py:559-575 (is_pseudo_batch): gradients of `pseudo_batch_factor`
+        # batches are summed before one optimizer step -- pseudo_batch_step().
+        # train.py:174-182 (COPY_PER_GPU): several towers per GPU.  With
+        # unify_copies (required above) every tower's loss is re-weighted to the
+        # GLOBAL per-vertex means (train.py:264-288), so how a batch's frames
+        # are grouped into towers does not change its gradient: one process per
+        # GPU takes its batch_size / world frames as one merged batch whatever
+        # COPY_PER_GPU says.
+        self._pseudo_sum = None
+        self._pseudo_n = 0
+        self._pseudo_ctr = 0
+        if int(self.train_config.get('COPY_PER_GPU', 1)) < 1:
+            raise ValueError("COPY_PER_GPU must be >= 1")
+        if self.train_config.get('is_pseudo_batch', False) and \
+                int(self.train_config.get('pseudo_batch_factor', 0)) < 1:
+            raise ValueError("is_pseudo_batch needs pseudo_batch_factor >= 1")
         if not torch.cuda.is_available():
             raise _lib.PointGnnHipError("Trainer needs a GPU (no CPU fallback)")
         self.device = device or torch.device("cuda",
@@ -458,17 +467,47 @@ class Trainer(object):
         return {name: self._view(self.flat, name).cpu().numpy()
                 for name, _ in self.specs}
 
-    def _apply_gradients(self, lr):
+    def pseudo_batch_step(self, batch, **kw):
+        """train.py:559-575 (`is_pseudo_batch`): this batch's gradients are
+        computed (all-reduced over ranks) and ADDED to the pending sum; when the
+        reference's counter says so -- `batch_ctr % pseudo_batch_factor == 0`,
+        counting from 0: the very first batch alone, then every `factor`
+        batches -- the sum is applied in one optimizer step.  Every batch's
+        gradient includes the regulariser's (it is part of each tower loss,
+        train.py:286-288), so the sum carries it once per summed batch.
+        Returns (loss dict of this batch, whether a step was applied)."""
+        out = self.train_step(batch, apply=False, **kw)
+        if self._pseudo_sum is None:
+            self._pseudo_sum = torch.zeros_like(self.grad)
+        self._pseudo_sum += self.grad
+        self._pseudo_n += 1
+        factor = int(self.train_config['pseudo_batch_factor'])
+        applied = self._pseudo_ctr % factor == 0
+        self._pseudo_ctr += 1
+        if applied:
+            self.grad.copy_(self._pseudo_sum)
+            self._apply_gradients(
+                learning_rate(self.train_config, self.global_step),
+                l1_mult=self._pseudo_n)
+            self.repack()
+            self.global_step += 1
+            self._pseudo_sum.zero_()
+            self._pseudo_n = 0
+        return out, applied
+
+    def _apply_gradients(self, lr, l1_mult=1):
         """optimizer.apply_gradients (train.py:392-405) on the flat buffers;
-        `lr` is the decayed learning rate of this step."""
+        `lr` is the decayed learning rate of this step; `l1_mult`: how many
+        batches' regulariser gradients the buffer stands for."""
         kind = _OPTIMIZERS[self.optimizer][0]
         kw = self.opt_kwargs
+        l1 = self.l1_scale * l1_mult
         if kind == 0:
             _lib.check(self.lib.pgnn_sgd_step(
                 _lib.ptr(self.flat), _lib.ptr(self.grad),
                 _lib.ptr(self.is_weight), self.flat.numel(),
                 ctypes.c_float(lr), ctypes.c_float(1.0),
-                ctypes.c_float(self.l1_scale), self._st()), "pgnn_sgd_step")
+                ctypes.c_float(l1), self._st()), "pgnn_sgd_step")
             return
         if kind == 1:
             h = (kw['momentum'], 0.0, 0.0)
@@ -486,7 +525,7 @@ class Trainer(object):
             _lib.ptr(self.is_weight), _lib.ptr(self.slots[0]),
             _lib.ptr(self.slots[1]) if len(self.slots) > 1 else None,
             self.flat.numel(), ctypes.c_float(lr), ctypes.c_float(1.0),
-            ctypes.c_float(self.l1_scale), ctypes.c_float(h[0]),
+            ctypes.c_float(l1), ctypes.c_float(h[0]),
             ctypes.c_float(h[1]), ctypes.c_float(h[2]), self._st()),
             "pgnn_optimizer_step")
 

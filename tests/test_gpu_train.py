@@ -546,6 +546,53 @@ def test_other_optimizers_follow_tf_update_rules(dev, opt, kwargs, tmp_path):
             optimizer_kwargs={'use_nesterov': True}), device=dev)
 
 
+def test_pseudo_batch_accumulates_like_the_reference(dev):
+    """train.py:559-575 (`is_pseudo_batch`, `pseudo_batch_factor` 2): the first
+    batch is applied alone (the reference's counter starts at 0), then the
+    gradients of two batches -- each with the regulariser's -- are summed into
+    one step; COPY_PER_GPU is accepted (with unify_copies the tower grouping
+    does not change a batch's gradient)."""
+    from pointgnn_amd import train
+    cfg = configs.car_auto_config(1)
+    params = weights.init_params(cfg, seed=6, bias_scale=0.05)
+    A, B, C = (_tiny_batch(seed=s) for s in (4, 5, 6))
+    tcfg = {'initial_lr': 0.01, 'decay_step': 1000, 'decay_factor': 0.5,
+            'optimizer': 'sgd', 'unify_copies': True, 'is_pseudo_batch': True,
+            'pseudo_batch_factor': 2, 'COPY_PER_GPU': 2}
+    tr = train.Trainer(cfg, train_config=tcfg, params=params, device=dev)
+    scale = cfg['model_kwargs']['regularizer_kwargs']['scale']
+
+    def reg(w, n):
+        return n.endswith('/weights') * scale * np.sign(w)
+    w0 = tr.state_dict()
+    out, applied = tr.pseudo_batch_step(A)
+    assert applied and tr.global_step == 1 and np.isfinite(out['cls_loss'])
+    g, w1 = tr.grad_dict(), tr.state_dict()
+    for n in w0:
+        np.testing.assert_allclose(w1[n], w0[n] - 0.01 * (g[n] + reg(w0[n], n)),
+                                   atol=1e-7, rtol=1e-5)
+    _, applied = tr.pseudo_batch_step(B)
+    assert not applied and tr.global_step == 1
+    g_b = tr.grad_dict()
+    assert all(np.array_equal(tr.state_dict()[n], w1[n]) for n in w1)
+    _, applied = tr.pseudo_batch_step(C)
+    assert applied and tr.global_step == 2
+    g_sum, w2 = tr.grad_dict(), tr.state_dict()
+    ref = train.Trainer(cfg, train_config=dict(tcfg, is_pseudo_batch=False),
+                        params=w1, device=dev)
+    ref.train_step(C, apply=False)
+    g_c = ref.grad_dict()
+    for n in w1:
+        np.testing.assert_allclose(g_sum[n], g_b[n] + g_c[n], atol=2e-6,
+                                   rtol=1e-4)
+        np.testing.assert_allclose(
+            w2[n], w1[n] - 0.01 * (g_sum[n] + 2 * reg(w1[n], n)), atol=1e-7,
+            rtol=1e-5)
+    with pytest.raises(ValueError):
+        train.Trainer(cfg, train_config=dict(tcfg, pseudo_batch_factor=0),
+                      device=dev)
+
+
 def test_trainer_checkpoint_resume(dev, tmp_path):
     """train.py:512-516, 625-638: save after a few steps, resume in a fresh
     Trainer, and continue identically; the saved weights also drive inference
