@@ -870,6 +870,26 @@ int pgnn_loss_fwd_bwd_counts(const float *logits, int64_t ld_logits,
                              double loc_loss_weight, const double *counts2,
                              double *sums4, float *dlogits, float *dpred_box,
                              void *stream);
+/* The same pass with the other per-vertex classification losses of
+ * models.py:210-228 and the per-class localisation weights of :240-246:
+ * cls_kind 0 'softmax' (as above), 1 'focal_softmax' (models/loss.py:31-48:
+ * (1 - p_label)^gamma * CE), 2 'focal_sigmoid' (models/loss.py:5-29: per-class
+ * sigmoid CE * (1 - p_t)^gamma * (alpha | 1 - alpha), averaged over the classes
+ * as well, models.py:229).  class_loc_weight (nullable, device float
+ * [num_classes]): 'classwise_loc_loss_weight' of loc_loss_kwargs, applied to a
+ * vertex's Huber terms by its label.  counts2 nullable: null = the host-scale
+ * form (cls_grad_scale / loc_grad_scale used), else the _counts form.
+ * 'top_k_softmax' / 'top_k_huber_loss' have no device path.                  */
+int pgnn_loss_fwd_bwd_ex(const float *logits, int64_t ld_logits,
+                         const int32_t *labels, const float *pred_box,
+                         int32_t box_len, const float *gt_box,
+                         const float *valid, int64_t n_vertices,
+                         int32_t num_classes, float cls_grad_scale,
+                         float loc_grad_scale, const double *counts2,
+                         double cls_loss_weight, double loc_loss_weight,
+                         int32_t cls_kind, float alpha, float gamma,
+                         const float *class_loc_weight, double *sums4,
+                         float *dlogits, float *dpred_box, void *stream);
 /* params -= lr * (grad_scale*grads + l1_scale*sign(params)*is_weight)
  * (GradientDescentOptimizer + slim.l1_regularizer on FC weights only).       */
 int pgnn_sgd_step(float *params, const float *grads, const float *is_weight,

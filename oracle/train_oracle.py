@@ -147,11 +147,36 @@ def loss_terms(config, logits, pred_box, labels, gt_box, valid,
         lab.shape[0], -1)
     va = torch.as_tensor(np.asarray(valid), dtype=dtype).reshape(-1)
     ce = torch.logsumexp(logits, dim=1) - logits[torch.arange(len(lab)), lab]
+    kind = config['loss'].get('cls_loss_type', 'softmax')
+    kw = config['loss'].get('cls_loss_kwargs', {}) or {}
+    if kind == 'focal_softmax':
+        # models/loss.py:31-48: (1 - softmax(z)[label])^gamma * CE
+        py = torch.softmax(logits, dim=1)[torch.arange(len(lab)), lab]
+        ce = (1.0 - py) ** kw.get('gamma', 2) * ce
+    elif kind == 'focal_sigmoid':
+        # models/loss.py:5-29: per (vertex, class) sigmoid CE, modulated by
+        # (1 - p_t)^gamma and weighted alpha / 1 - alpha; models.py:229 takes
+        # the mean over vertices AND classes
+        t = torch.nn.functional.one_hot(lab, logits.shape[1]).to(dtype)
+        p = torch.sigmoid(logits)
+        xent = torch.clamp(logits, min=0) - logits * t + \
+            torch.log1p(torch.exp(-logits.abs()))
+        pt = t * p + (1 - t) * (1 - p)
+        alpha = kw.get('alpha', 0.5)
+        aw = t * alpha + (1 - t) * (1 - alpha)
+        ce = ((1 - pt) ** kw.get('gamma', 2) * aw * xent).mean(dim=1)
+    elif kind != 'softmax':
+        raise NotImplementedError(kind)
     pb = pred_box[torch.arange(len(lab)), lab]
     err = pb - gt
     ae = err.abs()
     quad = torch.clamp(ae, max=1.0)
     hub = (0.5 * quad * quad + (ae - quad)) * va[:, None]
+    lkw = config['loss'].get('loc_loss_kwargs', {}) or {}
+    if 'classwise_loc_loss_weight' in lkw:   # models.py:240-246 (train mode)
+        cw = torch.as_tensor(np.asarray(lkw['classwise_loc_loss_weight']),
+                             dtype=dtype)
+        hub = hub * cw[lab][:, None]
     loc = hub.mean(dim=1)
     return ce.sum(), loc.sum(), float(len(lab)), float(va.sum())
 

@@ -310,6 +310,12 @@ _SIGNATURES = {
                                          c_vp, c_i64, c_i32, ctypes.c_double,
                                          ctypes.c_double, c_vp, c_vp, c_vp,
                                          c_vp, c_vp]),
+    "pgnn_loss_fwd_bwd_ex": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i32, c_vp, c_vp,
+                                     c_i64, c_i32, ctypes.c_float,
+                                     ctypes.c_float, c_vp, ctypes.c_double,
+                                     ctypes.c_double, c_i32, ctypes.c_float,
+                                     ctypes.c_float, c_vp, c_vp, c_vp, c_vp,
+                                     c_vp]),
     "pgnn_sgd_step": (c_i32, [c_vp, c_vp, c_vp, c_i64, ctypes.c_float,
                               ctypes.c_float, ctypes.c_float, c_vp]),
     "pgnn_optimizer_step": (c_i32, [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64] +

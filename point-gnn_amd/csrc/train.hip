@@ -1099,7 +1099,8 @@ __global__ __launch_bounds__(64 * G) void weight_grad_reduce_kernel(
 }
 
 // ---------------------------------------------------------------- loss
-// models.py:212-255 with cls_loss_type 'softmax', loc_loss_type 'huber_loss'.
+// models.py:212-255 with loc_loss_type 'huber_loss' and cls_loss_type 'softmax'
+// (cls_kind 0), 'focal_softmax' (1) or 'focal_sigmoid' (2).
 // Per vertex: ce = logsumexp(z) - z[label]; loc = mean_7 huber(pred[label] - gt)
 // * valid.  sums[0] += ce, sums[1] += loc, sums[2] += 1, sums[3] += valid.
 // Gradients of (cls_scale * sum ce + loc_scale * sum loc) are written out.
@@ -1113,7 +1114,8 @@ __global__ void loss_kernel(const float *__restrict__ logits, int64_t ldl,
                             float *__restrict__ dlogits,
                             float *__restrict__ dpred,
                             const double *__restrict__ counts, double cls_w,
-                            double loc_w) {
+                            double loc_w, int cls_kind, float alpha, float gamma,
+                            const float *__restrict__ class_loc_w) {
   if (counts) {
     // the GLOBAL endpoint counts are on the device (all-reduced there): the
     // scales are formed here as the host form does (double quotient of the
@@ -1132,12 +1134,53 @@ __global__ void loss_kernel(const float *__restrict__ logits, int64_t ldl,
     float se = 0.0f;
     for (int c = 0; c < nc; ++c) se += expf(z[c] - zmax);
     const float lse = logf(se) + zmax;
-    s_ce += (double)(lse - z[lab]);
-    if (dlogits)
-      for (int c = 0; c < nc; ++c)
-        dlogits[v * nc + c] =
-            cls_scale * (expf(z[c] - lse) - (c == lab ? 1.0f : 0.0f));
-    const float w = valid[v];
+    if (cls_kind == 0) {
+      s_ce += (double)(lse - z[lab]);
+      if (dlogits)
+        for (int c = 0; c < nc; ++c)
+          dlogits[v * nc + c] =
+              cls_scale * (expf(z[c] - lse) - (c == lab ? 1.0f : 0.0f));
+    } else if (cls_kind == 1) {
+      // focal_loss_softmax (models/loss.py:31-48): L = (1 - p_y)^gamma * CE
+      const float ce = lse - z[lab];
+      const float py = expf(z[lab] - lse);
+      const float om = fmaxf(1.0f - py, 0.0f);
+      const float mod = om > 0.0f ? powf(om, gamma) : 0.0f;
+      s_ce += (double)(mod * ce);
+      if (dlogits) {
+        // dL/dp_y = -gamma (1-p_y)^(gamma-1) CE - (1-p_y)^gamma / p_y;
+        // dp_y/dz_c = p_y ([c == y] - p_c)
+        const float dm = om > 0.0f ? gamma * powf(om, gamma - 1.0f) : 0.0f;
+        const float a = -(dm * ce * py + mod);
+        for (int c = 0; c < nc; ++c)
+          dlogits[v * nc + c] = cls_scale * a *
+                                ((c == lab ? 1.0f : 0.0f) - expf(z[c] - lse));
+      }
+    } else {
+      // focal_loss_sigmoid (models/loss.py:5-29), mean over the classes too
+      // (models.py:229 reduce_mean over [N, nc])
+      float sum = 0.0f;
+      for (int c = 0; c < nc; ++c) {
+        const float zc = z[c];
+        const bool t = c == lab;
+        const float p = 1.0f / (1.0f + expf(-zc));
+        const float xent = fmaxf(zc, 0.0f) - (t ? zc : 0.0f) +
+                           log1pf(expf(-fabsf(zc)));
+        const float om = t ? 1.0f - p : p;            // 1 - p_t
+        const float mod = om > 0.0f ? powf(om, gamma) : 0.0f;
+        const float aw = t ? alpha : 1.0f - alpha;
+        sum += mod * aw * xent;
+        if (dlogits) {
+          // d(1 - p_t)/dz = -(2t - 1) p (1 - p)
+          const float dm = (om > 0.0f ? gamma * powf(om, gamma - 1.0f) : 0.0f) *
+                           (t ? -1.0f : 1.0f) * p * (1.0f - p);
+          dlogits[v * nc + c] = cls_scale / (float)nc * aw *
+                                (dm * xent + mod * (p - (t ? 1.0f : 0.0f)));
+        }
+      }
+      s_ce += (double)(sum / (float)nc);
+    }
+    const float w = valid[v] * (class_loc_w ? class_loc_w[lab] : 1.0f);
     const float *p = pred + (v * nc + lab) * box_len;
     const float *g = gt + v * box_len;
     float acc = 0.0f;
@@ -1157,7 +1200,7 @@ __global__ void loss_kernel(const float *__restrict__ logits, int64_t ldl,
     }
     s_loc += (double)(acc / (float)box_len);
     s_n += 1.0;
-    s_v += (double)w;
+    s_v += (double)valid[v];
   }
   // block reduction (fp64 atomics at the end: 4 per wave)
 #pragma unroll
@@ -2202,7 +2245,8 @@ extern "C" int pgnn_loss_fwd_bwd(const float *logits, int64_t ld_logits,
                      stream, logits, ld_logits, labels, pred_box, box_len, gt_box,
                      valid, n_vertices, num_classes, cls_grad_scale,
                      loc_grad_scale, sums4, dlogits, dpred_box,
-                     (const double *)nullptr, 0.0, 0.0);
+                     (const double *)nullptr, 0.0, 0.0, 0, 0.0f, 0.0f,
+                     (const float *)nullptr);
   PGNN_HIP(hipGetLastError());
   return 0;
   PGNN_GUARD_END
@@ -2226,7 +2270,36 @@ extern "C" int pgnn_loss_fwd_bwd_counts(
   hipLaunchKernelGGL(loss_kernel, dim3(grid_for(n_vertices, 1024)), dim3(256), 0,
                      stream, logits, ld_logits, labels, pred_box, box_len, gt_box,
                      valid, n_vertices, num_classes, 0.0f, 0.0f, sums4, dlogits,
-                     dpred_box, counts2, cls_loss_weight, loc_loss_weight);
+                     dpred_box, counts2, cls_loss_weight, loc_loss_weight, 0, 0.0f,
+                     0.0f, (const float *)nullptr);
+  PGNN_HIP(hipGetLastError());
+  return 0;
+  PGNN_GUARD_END
+}
+
+extern "C" int pgnn_loss_fwd_bwd_ex(
+    const float *logits, int64_t ld_logits, const int32_t *labels,
+    const float *pred_box, int32_t box_len, const float *gt_box,
+    const float *valid, int64_t n_vertices, int32_t num_classes,
+    float cls_grad_scale, float loc_grad_scale, const double *counts2,
+    double cls_loss_weight, double loc_loss_weight, int32_t cls_kind,
+    float alpha, float gamma, const float *class_loc_weight, double *sums4,
+    float *dlogits, float *dpred_box, void *stream_) {
+  PGNN_GUARD_BEGIN
+  hipStream_t stream = (hipStream_t)stream_;
+  PGNN_REQUIRE(n_vertices >= 0 && num_classes > 0 && box_len > 0 && sums4 &&
+                   cls_kind >= 0 && cls_kind <= 2 && gamma >= 0.0f,
+               PGNN_E_INVALID, "loss_ex: bad argument");
+  PGNN_HIP(hipMemsetAsync(sums4, 0, 4 * sizeof(double), stream));
+  if (n_vertices == 0) return 0;
+  PGNN_REQUIRE(logits && labels && pred_box && gt_box && valid, PGNN_E_INVALID,
+               "loss_ex: null pointer");
+  hipLaunchKernelGGL(loss_kernel, dim3(grid_for(n_vertices, 1024)), dim3(256), 0,
+                     stream, logits, ld_logits, labels, pred_box, box_len, gt_box,
+                     valid, n_vertices, num_classes, cls_grad_scale,
+                     loc_grad_scale, sums4, dlogits, dpred_box, counts2,
+                     cls_loss_weight, loc_loss_weight, cls_kind, alpha, gamma,
+                     class_loc_weight);
   PGNN_HIP(hipGetLastError());
   return 0;
   PGNN_GUARD_END

@@ -18,7 +18,22 @@ import torch
 from . import gnn
 from .weights import init_params
 
-__all__ = ["MultiLayerFastLocalGraphModelV2", "get_model"]
+__all__ = ["MultiLayerFastLocalGraphModelV2", "get_model", "cls_loss_kind"]
+
+
+def cls_loss_kind(cls_loss_type, cls_loss_kwargs=None):
+    """models.py:210-228 -> (cls_kind of pgnn_loss_fwd_bwd_ex, alpha, gamma)
+    with the defaults of models/loss.py:5,31."""
+    kw = cls_loss_kwargs or {}
+    if cls_loss_type == 'softmax':
+        return 0, 0.0, 0.0
+    if cls_loss_type == 'focal_softmax':
+        return 1, 0.0, float(kw.get('gamma', 2))
+    if cls_loss_type == 'focal_sigmoid':
+        return 2, float(kw.get('alpha', 0.5)), float(kw.get('gamma', 2))
+    raise NotImplementedError(
+        "cls_loss_type %r: 'top_k_softmax' has no device path (a per-batch "
+        "top-k selection; no shipped config uses it)" % (cls_loss_type,))
 
 
 class MultiLayerFastLocalGraphModelV2(object):
@@ -172,8 +187,9 @@ class MultiLayerFastLocalGraphModelV2(object):
              cls_loss_type='focal_sigmoid', cls_loss_kwargs={},
              loc_loss_type='huber_loss', loc_loss_kwargs={},
              loc_loss_weight=1.0, cls_loss_weight=1.0):
-        """models.py:170-311 for the loss types every shipped config uses
-        (cls 'softmax', loc 'huber_loss').  Same keys as the reference's
+        """models.py:170-311: cls 'softmax' (every shipped config),
+        'focal_softmax', 'focal_sigmoid'; loc 'huber_loss' with the optional
+        'classwise_loc_loss_weight' (train mode).  Same keys as the reference's
         loss_dict; values are Python floats (classwise_loc_loss: list of
         [box_len] tensors).  Device tensors in; the per-vertex arithmetic runs
         in pgnn_loss_fwd_bwd.  Gradients: see pointgnn_amd.train.Trainer."""
@@ -183,17 +199,17 @@ class MultiLayerFastLocalGraphModelV2(object):
             loc_loss_weight = loc_loss_weight[self._mode]
         if isinstance(cls_loss_weight, dict):
             cls_loss_weight = cls_loss_weight[self._mode]
-        if isinstance(cls_loss_type, dict):
+        if isinstance(cls_loss_type, dict):      # models.py:203-208
             cls_loss_type = cls_loss_type[self._mode]
+            cls_loss_kwargs = cls_loss_kwargs[self._mode]
         if isinstance(loc_loss_type, dict):
             loc_loss_type = loc_loss_type[self._mode]
-        if cls_loss_type != 'softmax' or loc_loss_type != 'huber_loss':
+            loc_loss_kwargs = loc_loss_kwargs[self._mode]
+        kind, alpha, gamma = cls_loss_kind(cls_loss_type, cls_loss_kwargs)
+        if loc_loss_type != 'huber_loss':
             raise NotImplementedError(
-                "loss types %r / %r: only 'softmax' + 'huber_loss' (all "
-                "shipped configs) have a device path"
-                % (cls_loss_type, loc_loss_type))
-        if 'classwise_loc_loss_weight' in loc_loss_kwargs:
-            raise NotImplementedError("classwise_loc_loss_weight")
+                "loc_loss_type %r: 'top_k_huber_loss' has no device path"
+                % (loc_loss_type,))
         lib = _lib.load()
         dev = logits.device
         k, nc = int(logits.shape[0]), int(logits.shape[1])
@@ -204,11 +220,26 @@ class MultiLayerFastLocalGraphModelV2(object):
         gt = gt_box.to(device=dev, dtype=torch.float32).reshape(k, bl).contiguous()
         va = valid_box.to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
         sums = torch.zeros(4, dtype=torch.float64, device=dev)
-        _lib.check(lib.pgnn_loss_fwd_bwd(
-            _lib.ptr(lg), lg.stride(0), _lib.ptr(lab), _lib.ptr(pb), bl,
-            _lib.ptr(gt), _lib.ptr(va), k, nc, ctypes.c_float(0.0),
-            ctypes.c_float(0.0), _lib.ptr(sums), None, None,
-            _lib.stream_ptr()), "pgnn_loss_fwd_bwd")
+        # models.py:240-246: the per-class weights apply in 'train' mode only
+        cw = None
+        if 'classwise_loc_loss_weight' in (loc_loss_kwargs or {}) and \
+                self._mode == 'train':
+            cw = torch.tensor(loc_loss_kwargs['classwise_loc_loss_weight'],
+                              dtype=torch.float32, device=dev)
+        if kind == 0 and cw is None:
+            _lib.check(lib.pgnn_loss_fwd_bwd(
+                _lib.ptr(lg), lg.stride(0), _lib.ptr(lab), _lib.ptr(pb), bl,
+                _lib.ptr(gt), _lib.ptr(va), k, nc, ctypes.c_float(0.0),
+                ctypes.c_float(0.0), _lib.ptr(sums), None, None,
+                _lib.stream_ptr()), "pgnn_loss_fwd_bwd")
+        else:
+            _lib.check(lib.pgnn_loss_fwd_bwd_ex(
+                _lib.ptr(lg), lg.stride(0), _lib.ptr(lab), _lib.ptr(pb), bl,
+                _lib.ptr(gt), _lib.ptr(va), k, nc, ctypes.c_float(0.0),
+                ctypes.c_float(0.0), None, 0.0, 0.0, kind,
+                ctypes.c_float(alpha), ctypes.c_float(gamma), _lib.ptr(cw),
+                _lib.ptr(sums), None, None, _lib.stream_ptr()),
+                "pgnn_loss_fwd_bwd_ex")
         s_ce, s_loc, n, nv = [float(v) for v in sums.cpu()]
         reg = 0.0
         if self._regularizer_type == 'l1' and self._store is not None:
@@ -222,6 +253,8 @@ class MultiLayerFastLocalGraphModelV2(object):
         ae = err.abs()
         quad = torch.clamp(ae, max=1.0)
         all_loc = loc_loss_weight * (0.5 * quad * quad + (ae - quad)) * va[:, None]
+        if cw is not None:
+            all_loc = all_loc * cw[lab.long()][:, None]
         classwise = [all_loc[lab == c].sum(dim=0) for c in range(self.num_classes)]
         return {
             'cls_loss': cls_loss_weight * s_ce / max(n, 1.0),

@@ -400,8 +400,16 @@ class Trainer(object):
             if mk.get('regularizer_type') == 'l1' else 0.0
         self.cls_w = float(config['loss']['cls_loss_weight'])
         self.loc_w = float(config['loss']['loc_loss_weight'])
-        if config['loss'].get('cls_loss_type', 'softmax') != 'softmax':
-            raise NotImplementedError("cls_loss_type")
+        from .models import cls_loss_kind
+        self.cls_kind = cls_loss_kind(
+            config['loss'].get('cls_loss_type', 'softmax'),
+            config['loss'].get('cls_loss_kwargs'))
+        if config['loss'].get('loc_loss_type', 'huber_loss') != 'huber_loss':
+            raise NotImplementedError(
+                "loc_loss_type %r" % (config['loss']['loc_loss_type'],))
+        self._class_loc_w_host = (config['loss'].get('loc_loss_kwargs') or {}
+                                  ).get('classwise_loc_loss_weight')
+        self._class_loc_w = None
         # ---- flat parameter / gradient buffers --------------------------
         self.specs = variable_specs(config, box_encoding_len=box_encoding_len)
         if params is None:
@@ -1110,6 +1118,25 @@ class Trainer(object):
             if want_grads else None
         dpred = torch.empty((k, self.nc, self.box_len), dtype=torch.float32,
                             device=dev) if want_grads else None
+        if self.cls_kind[0] != 0 or self._class_loc_w_host is not None:
+            if self._class_loc_w is None and self._class_loc_w_host is not None:
+                self._class_loc_w = torch.tensor(
+                    self._class_loc_w_host, dtype=torch.float32, device=dev)
+            cls_scale = self.cls_w / n_total \
+                if counts_dev is None and n_total > 0 else 0.0
+            loc_scale = self.loc_w / nv_total \
+                if counts_dev is None and nv_total > 0 else 0.0
+            _lib.check(self.lib.pgnn_loss_fwd_bwd_ex(
+                _lib.ptr(lg), lg.stride(0), _lib.ptr(labels), _lib.ptr(pred),
+                self.box_len, _lib.ptr(gt), _lib.ptr(va), k, self.nc,
+                ctypes.c_float(cls_scale), ctypes.c_float(loc_scale),
+                _lib.ptr(counts_dev), ctypes.c_double(self.cls_w),
+                ctypes.c_double(self.loc_w), self.cls_kind[0],
+                ctypes.c_float(self.cls_kind[1]),
+                ctypes.c_float(self.cls_kind[2]), _lib.ptr(self._class_loc_w),
+                _lib.ptr(sums), _lib.ptr(dlog), _lib.ptr(dpred), self._st()),
+                "pgnn_loss_fwd_bwd_ex")
+            return sums, dlog, dpred
         if counts_dev is not None:
             _lib.check(self.lib.pgnn_loss_fwd_bwd_counts(
                 _lib.ptr(lg), lg.stride(0), _lib.ptr(labels), _lib.ptr(pred),

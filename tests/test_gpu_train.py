@@ -221,6 +221,78 @@ def test_loss_kernel_matches_oracle(dev):
                                rtol=1e-4)
 
 
+@pytest.mark.parametrize("kind,kwargs,classwise", [
+    ("focal_softmax", {}, None), ("focal_softmax", {"gamma": 1.5}, None),
+    ("focal_sigmoid", {}, None),
+    ("focal_sigmoid", {"alpha": 0.25, "gamma": 3}, [1.0, 2.0, 0.5, 4.0]),
+    ("softmax", {}, [1.0, 2.0, 0.5, 4.0])])
+def test_loss_variants_match_oracle(dev, kind, kwargs, classwise):
+    """models.py:210-228 / models/loss.py: 'focal_softmax', 'focal_sigmoid'
+    (mean over vertices AND classes), and loc_loss_kwargs'
+    'classwise_loc_loss_weight' (models.py:240-246): sums and gradients
+    against float64 autograd of the reference's formulas, through the trainer
+    (host scales and device counts) and through model.loss; a whole training
+    step with such a loss follows the oracle's gradient."""
+    import copy
+    import torch
+    from pointgnn_amd import models, train
+    cfg = copy.deepcopy(configs.car_auto_config(1))
+    cfg['loss']['cls_loss_type'] = kind
+    cfg['loss']['cls_loss_kwargs'] = kwargs
+    if classwise is not None:
+        cfg['loss']['loc_loss_kwargs'] = {'classwise_loc_loss_weight': classwise}
+    tr = train.Trainer(cfg, seed=0, device=dev)
+    rng = np.random.default_rng(2)
+    k = 300
+    logits = rng.standard_normal((k, 4)).astype(np.float32) * 3
+    logits[:5] *= 20                      # saturated probabilities
+    pred = rng.standard_normal((k, 4, 7)).astype(np.float32) * 2
+    labels = rng.integers(0, 4, (k, 1)).astype(np.int32)
+    gt = rng.standard_normal((k, 1, 7)).astype(np.float32) * 2
+    valid = (rng.random((k, 1, 1)) < 0.6).astype(np.float32)
+    nv = float(valid.sum())
+    tl = torch.tensor(logits, dtype=torch.float64, requires_grad=True)
+    tp = torch.tensor(pred, dtype=torch.float64, requires_grad=True)
+    ce, loc, n, nvv = to.loss_terms(cfg, tl, tp, labels, gt, valid)
+    (0.1 * ce / n + 10.0 * loc / nvv).backward()
+    counts = torch.tensor([float(k), nv], dtype=torch.float64, device=dev)
+    for counts_dev in (None, counts):
+        sums, dlog, dpred = tr.loss_and_grads(
+            T(logits, dev), T(pred, dev), T(labels, dev), T(gt, dev),
+            T(valid, dev), float(k), nv, counts_dev=counts_dev)
+        np.testing.assert_allclose(sums.cpu().numpy(),
+                                   [float(ce), float(loc), k, nv], rtol=2e-5)
+        scale = np.abs(tl.grad.numpy()).max()
+        np.testing.assert_allclose(dlog.cpu().numpy(), tl.grad.numpy(),
+                                   atol=2e-6 * scale, rtol=2e-4)
+        np.testing.assert_allclose(dpred.cpu().numpy(), tp.grad.numpy(),
+                                   atol=1e-7, rtol=1e-4)
+    model = models.get_model(cfg["model_name"])(
+        num_classes=4, box_encoding_len=7, mode="train", **cfg["model_kwargs"])
+    out = model.loss(T(logits, dev), T(labels, dev), T(pred, dev), T(gt, dev),
+                     T(valid, dev), **cfg['loss'])
+    assert out['cls_loss'] == pytest.approx(0.1 * float(ce) / k, rel=2e-5)
+    assert out['loc_loss'] == pytest.approx(10.0 * float(loc) / nv, rel=2e-5)
+    # a whole step: device gradient vs the oracle's for this loss
+    params = weights.init_params(cfg, seed=6, bias_scale=0.05)
+    batch = _tiny_batch(seed=4)
+    tr = train.Trainer(cfg, params=params, device=dev)
+    res = tr.train_step(batch, apply=False)
+    want, g_data, _ = to.step_gradients(params, cfg, [batch])
+    assert res['cls_loss'] == pytest.approx(want['cls_loss'], rel=1e-3)
+    got = tr.grad_dict()
+    for name in got:
+        den = np.linalg.norm(g_data[name]) + 1e-12
+        # (un-matched comparison: ReLU / arg-max decisions at fp32 ties differ
+        # from the float64 oracle's, DESIGN 2; the loss itself is held to 2e-4
+        # above -- this checks the wiring of the whole step)
+        assert np.linalg.norm(got[name] - g_data[name]) <= 2e-2 * den + 1e-7, name
+    with pytest.raises(NotImplementedError):
+        train.Trainer(dict(cfg, loss=dict(cfg['loss'],
+                                          cls_loss_type='top_k_softmax')),
+                      device=dev)
+
+
 def test_model_loss_api_matches_oracle(dev):
     """models.MultiLayerFastLocalGraphModelV2.loss keeps the reference's
     signature and loss_dict keys (models.py:170-175, 308-311)."""
