@@ -458,7 +458,8 @@ def test_deferred_frame_on_degenerate_clouds(dev, n_points):
 
 @pytest.mark.parametrize("cfg_name,overlap", [
     ("car", False), ("ped", False), ("car", True)])
-def test_captured_frame_replays_bit_identically(dev, cfg_name, overlap):
+def test_captured_frame_replays_bit_identically(dev, cfg_name, overlap,
+                                                edge_arith):
     """A whole frame in ONE hipGraph (engine.capture_frame; `overlap`: with the
     graph build's side streams as branches of the graph): replays give the
     eager results bit for bit, for the captured cloud and for other clouds of
@@ -471,7 +472,7 @@ def test_captured_frame_replays_bit_identically(dev, cfg_name, overlap):
     cfg = configs.car_auto_config(3) if cfg_name == "car" else \
         configs.ped_cyl_auto_config(3)
     params = weights.init_params(cfg, seed=5, bias_scale=0.05)
-    eng = InferenceEngine(cfg, params, device=dev)
+    eng = InferenceEngine(cfg, params, device=dev, edge_arith=edge_arith)
     clouds = []
     for s in (0, 1, 2):
         xyz, inten = synthetic_cloud(seed=s, preset="car")
@@ -486,6 +487,7 @@ def test_captured_frame_replays_bit_identically(dev, cfg_name, overlap):
             lg2, bx2 = out.result()
             assert eng.frame_shapes[-1] == sh
             assert torch.equal(lg, lg2) and torch.equal(bx, bx2)
+    eng.check_edge_range()      # (f16x2: the range flag survives replays)
     small = synthetic_cloud(seed=0, preset="small")
     with pytest.raises(ValueError):
         cap.replay(T(small[0], dev), T(small[1], dev))
