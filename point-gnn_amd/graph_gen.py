@@ -23,6 +23,8 @@ is the capacity form: no read at all, capacity-sized outputs tagged with their
 device-side counts (CountHints, FrameCounts, _lib.DeviceCount).
 """
 import ctypes
+import threading
+import weakref
 
 import numpy as np
 import torch
@@ -136,34 +138,70 @@ class FrameCounts(object):
 
 
 class _ZeroPool(object):
-    """Zeroed int32 count records for capacity-form frames, handed out from one
-    buffer per device that is zeroed ONCE per `kRecords` frames (a fill launch
-    per frame otherwise: ~4 us of a 2-3 ms frame, and one more node on every
-    frame's dependency chain).  A record is the frame's own until the pool
-    wraps round -- kRecords frames later, behind a device synchronisation; a
-    FrameCounts held longer than that must be read() first."""
-    kRecords, kInts = 4096, 16
+    """Zeroed int32 count records for capacity-form frames, handed out from
+    segments of `kRecords` records that are zeroed ONCE per segment (a fill
+    launch per frame otherwise: ~4 us of a 2-3 ms frame, and one more node on
+    every frame's dependency chain).
+
+    A record stays the frame's own for as long as the tensor `take()`
+    returned is alive (FrameCounts holds it, and every graph tensor of the
+    frame holds the FrameCounts): a segment is zeroed again only when all the
+    records it served are dead AND the device has been synchronised since, so
+    neither an unread FrameCounts nor a kernel that has yet to be enqueued
+    (a lookahead builder runs frames ahead of the GNN) can meet a wiped
+    record.  A segment with live records is left alone and a fresh one is
+    allocated instead.  Thread-safe: builder threads share the pool."""
+    kRecords, kInts = 512, 16
+
+    class _Segment(object):
+        def __init__(self, dev, n_records, n_ints):
+            self.buf = torch.zeros(n_records * n_ints, dtype=torch.int32,
+                                   device=dev)
+            self.owners = []
+
+        def idle(self):
+            return all(w() is None for w in self.owners)
 
     def __init__(self, dev):
-        self.buf = torch.zeros(self.kRecords * self.kInts, dtype=torch.int32,
-                               device=dev)
+        self.dev = dev
+        self.lock = threading.Lock()
+        self.cur = self._Segment(dev, self.kRecords, self.kInts)
         torch.cuda.synchronize(dev)   # records are used on any stream
+        self.retired = []
         self.next = 0
+
+    def _rotate(self):
+        # everything enqueued so far has run once this returns: a retired
+        # segment whose records are all dead has no reader left anywhere
+        torch.cuda.synchronize(self.dev)
+        self.retired.append(self.cur)
+        seg = None
+        for i, s in enumerate(self.retired):
+            if s.idle():
+                seg = self.retired.pop(i)
+                seg.owners = []
+                seg.buf.zero_()
+                break
+        if seg is None:
+            seg = self._Segment(self.dev, self.kRecords, self.kInts)
+        torch.cuda.synchronize(self.dev)
+        self.cur, self.next = seg, 0
 
     def take(self, n_ints):
         if n_ints > self.kInts:
-            return torch.zeros(n_ints, dtype=torch.int32, device=self.buf.device)
-        if self.next == self.kRecords:
-            torch.cuda.synchronize(self.buf.device)
-            self.buf.zero_()
-            torch.cuda.synchronize(self.buf.device)
-            self.next = 0
-        i = self.next
-        self.next += 1
-        return self.buf[i * self.kInts:i * self.kInts + n_ints]
+            return torch.zeros(n_ints, dtype=torch.int32, device=self.dev)
+        with self.lock:
+            if self.next == self.kRecords:
+                self._rotate()
+            i = self.next
+            self.next += 1
+            rec = self.cur.buf[i * self.kInts:i * self.kInts + n_ints]
+            self.cur.owners.append(weakref.ref(rec))
+            return rec
 
 
 _ZERO_POOLS = {}
+_ZERO_POOLS_LOCK = threading.Lock()
 
 
 def _zero_counts(n_ints, dev):
@@ -171,9 +209,10 @@ def _zero_counts(n_ints, dev):
     # work itself: every replay reuses it)
     if torch.cuda.is_current_stream_capturing():
         return torch.zeros(n_ints, dtype=torch.int32, device=dev)
-    pool = _ZERO_POOLS.get(dev.index)
-    if pool is None:
-        pool = _ZERO_POOLS[dev.index] = _ZeroPool(dev)
+    with _ZERO_POOLS_LOCK:
+        pool = _ZERO_POOLS.get(dev.index)
+        if pool is None:
+            pool = _ZERO_POOLS[dev.index] = _ZeroPool(dev)
     return pool.take(n_ints)
 
 

@@ -401,6 +401,52 @@ def test_deferred_pipeline_equals_sequential(dev):
             assert torch.equal(l0, l1) and torch.equal(b0, b1)
 
 
+def test_count_record_pool_wraps_inside_a_deferred_batch(dev, monkeypatch):
+    """The pool of zeroed count records rotates its segments while frames of
+    the batch are still unread (a bulk re-zero handed K = 0 / E = 0
+    to every frame built before the wrap).  Segments of 3 records, batches of
+    7 frames: every batch crosses two rotations, and the lookahead builders
+    run ahead of the GNN.  A live record is never wiped; idle segments are
+    the ones reused."""
+    import torch
+    from pointgnn_amd import graph_gen as G
+    from pointgnn_amd.engine import InferenceEngine
+    monkeypatch.setattr(G._ZeroPool, "kRecords", 3)
+    monkeypatch.setattr(G, "_ZERO_POOLS", {})
+    cfg = configs.car_auto_config(1)
+    params = weights.init_params(cfg, seed=5, bias_scale=0.05)
+    eng = InferenceEngine(cfg, params, device=dev)
+    frames = []
+    for s in range(7):
+        xyz, inten = synthetic_cloud(seed=s, preset=("small", "tiny")[s % 2])
+        frames.append((T(xyz, dev), T(inten, dev)))
+    seq = [eng.run_frame(x, f) for x, f in frames]
+    torch.cuda.synchronize()
+    for rep in range(3):
+        got = eng.run_frames_on_streams(frames, 3)
+        pip = eng.run_frames_pipelined(frames, compute_streams=2,
+                                       deferred=True, graph_streams=2)
+        torch.cuda.synchronize()
+        for (l0, b0), (l1, b1), (l2, b2) in zip(seq, got, pip):
+            assert l0.shape[0] > 0
+            assert torch.equal(l0, l1) and torch.equal(b0, b1)
+            assert torch.equal(l0, l2) and torch.equal(b0, b2)
+    pool = G._ZERO_POOLS[dev.index]
+    assert pool.kRecords == 3
+    # rotations happened, and dead segments were recycled rather than leaked
+    assert len(pool.retired) <= 8
+    # held records survive any number of later rotations
+    held = [G._zero_counts(6, dev) for _ in range(4)]
+    for h in held:
+        h[0] = 77
+    for _ in range(20):
+        G._zero_counts(6, dev)
+    torch.cuda.synchronize()
+    assert all(int(h[0]) == 77 for h in held)
+    fresh = G._zero_counts(6, dev)
+    assert fresh.tolist() == [0] * 6
+
+
 def test_frames_on_streams_equal_sequential(dev, edge_arith):
     """run_frames_on_streams: whole frames (graph build + GNN, capacity form)
     round-robin on 1..4 streams == frame-at-a-time execution, bit for bit,
