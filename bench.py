@@ -660,8 +660,66 @@ def roofline_graph(torch, cfg, coords):
             "GB_per_s": sum(o["algorithmic_bytes"] for o in out) / tot_t / 1e9}
 
 
+def make_communicator(torch, dist):
+    """The training step's communicator: RCCL behind the C ABI
+    (pgnn_comm_* / pgnn_allreduce_step), its 128 id bytes handed out through
+    the process group the launcher already formed.  None for one rank, and in
+    the one-GPU test mode (two ranks on cuda:0: RCCL refuses two ranks per
+    device; the step's collectives then ride on the gloo group)."""
+    if dist is None or STUB or ONE_GPU:
+        return None
+    from pointgnn_amd.comm import Communicator
+    return Communicator.from_torch(dist.group.WORLD)
+
+
+def collective_fixed_cost(torch, dev, n_params, reps=30):
+    """What the step's two collectives cost on THIS stack when nobody has to be
+    waited for: a world-1 RCCL communicator (a valid one: unique id,
+    ncclCommInitRank, the reduction kernels) reducing the flat gradient + the
+    four loss sums as one group (pgnn_allreduce_step) and the two endpoint
+    counts (pgnn_allreduce_sum_f64), timed by events round `reps` calls on the
+    current stream.  At N ranks the call additionally moves 2(N-1)/N x the
+    buffer over xGMI and waits for the slowest rank."""
+    from pointgnn_amd.comm import Communicator
+    comm = Communicator.single()
+    grad = torch.randn(n_params, dtype=torch.float32, device=dev)
+    sums = torch.ones(4, dtype=torch.float64, device=dev)
+    counts = torch.ones(2, dtype=torch.float64, device=dev)
+
+    def timed(fn):
+        for _ in range(5):
+            fn()
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / reps
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        comm.allreduce_step(grad, sums)
+    host = (time.perf_counter() - t0) / reps * 1e3
+    torch.cuda.synchronize()
+    out = {
+        "what": "world-1 RCCL communicator behind the C ABI: the call's fixed "
+                "cost on this stack (no peer to wait for, nothing crosses "
+                "xGMI); HIP events round %d back-to-back calls" % reps,
+        "allreduce_ms": timed(lambda: comm.allreduce_step(grad, sums)),
+        "counts_allreduce_ms": timed(lambda: comm.allreduce_sum(counts)),
+        "host_enqueue_ms": host,
+        "allreduce_bytes": int(n_params) * 4 + 32,
+        "rccl_version": Communicator.rccl_version(),
+        "rccl_library": Communicator.library(),
+    }
+    comm.destroy()
+    return out
+
+
 def train_measure(torch, dev, rank, world, dist, config_name, preset, steps,
-                  warmup, frames, fpg=2, pipeline=True, deferred=True):
+                  warmup, frames, fpg=2, pipeline=True, deferred=True,
+                  force_collective=False):
     """BASELINE config 4: `steps` timed training steps of `config_name` --
     per rank and step: training-mode graph build (voxel 0.8 m, random
     keypoints + origin jitter, level-1 fan-in capped at 256) for `fpg` frames,
@@ -673,9 +731,16 @@ def train_measure(torch, dev, rank, world, dist, config_name, preset, steps,
     from pointgnn_amd import configs, graph_gen, train
     from pointgnn_amd.synthetic import synthetic_cloud
     cfg = configs.get_config(config_name)
-    # the gradient all-reduce runs on the default group (RCCL over xGMI)
+    # the gradient all-reduce: RCCL over xGMI through the C ABI's communicator
+    # (pgnn_trainer_backward_sync enqueues it behind the last gradient kernel);
+    # force_collective: a world-1 communicator, every collective issued
     pg = dist.group.WORLD if dist is not None else None
-    tr = train.Trainer(cfg, seed=0, device=dev, process_group=pg)
+    comm = make_communicator(torch, dist)
+    if comm is None and force_collective:
+        from pointgnn_amd.comm import Communicator
+        comm = Communicator.single()
+    tr = train.Trainer(cfg, seed=0, device=dev, process_group=pg, comm=comm,
+                       force_collective=force_collective)
     n_steps = steps + warmup
     pool = {}
     for s in range(frames):
@@ -760,17 +825,29 @@ def train_measure(torch, dev, rank, world, dist, config_name, preset, steps,
     drain()
     _sync(torch, dist)
     del shapes[:]
-    tr.allreduce_events = []
     t0 = time.perf_counter()
     for i in range(warmup, n_steps):
         out = step(i)
     out = drain() or out     # every step's losses are read inside the region
     _sync(torch, dist)
     elapsed = time.perf_counter() - t0
-    ar_ms = (sum(a.elapsed_time(b) for a, b in tr.allreduce_events) /
-             max(1, len(tr.allreduce_events)))
-    tr.allreduce_events = None
+    # the collective alone, AFTER the timed region (bracketing it with events
+    # keeps it out of pgnn_trainer_backward_sync): a few more steps
+    ar_ms = 0.0
+    if tr._multi():
+        tr.allreduce_events = []
+        for i in range(n_steps, n_steps + 6):
+            step(i)
+        drain()
+        _sync(torch, dist)
+        ar_ms = (sum(a.elapsed_time(b) for a, b in tr.allreduce_events) /
+                 max(1, len(tr.allreduce_events)))
+        tr.allreduce_events = None
     elapsed, ar_ms = _max_over_ranks(torch, dist, dev, [elapsed, ar_ms])
+    tr.collective = "none" if not tr._multi() else (
+        "pgnn_allreduce_step (RCCL behind the C ABI, world %d)" % comm.world
+        if comm is not None else "torch.distributed all_reduce (%s)"
+        % dist.get_backend())
     return elapsed, ar_ms, tr, cfg, list(shapes), out
 
 
@@ -858,9 +935,12 @@ def run_train(args, torch, dev, rank, world, dist):
                 "params": int(tr.flat.numel()),
                 "allreduce_bytes": int(tr.flat.numel()) * 4,
                 # device time between the events that bracket the gradient
-                # all-reduce (+ the 2-scalar loss all-reduce); includes any
-                # wait for the slowest rank to arrive; 0 at world 1 (no call)
+                # all-reduce (+ the loss sums, one RCCL group), measured on six
+                # steps AFTER the timed region; includes any wait for the
+                # slowest rank to arrive; at world 1 no call is made inside
+                # the step: `collective_fixed_cost` is the forced world-1 call
                 "allreduce_ms": ar_ms,
+                "collective": tr.collective,
                 "distributed": dist_info(dist, world),
                 "last_loss": {k: out[k] for k in ('cls_loss', 'loc_loss',
                                                   'reg_loss')},
@@ -868,6 +948,9 @@ def run_train(args, torch, dev, rank, world, dist):
                                "all-reduce per step)" % world},
         }
         live = None
+        if world == 1:
+            res["config"]["collective_fixed_cost"] = collective_fixed_cost(
+                torch, dev, int(tr.flat.numel()))
         if world == 1 and not args.no_live_pmc:
             torch.cuda.synchronize()
             live = live_pmc_train_mfma_ops(args.config, args.preset, fpg,
@@ -1346,7 +1429,28 @@ def secondary_train(args, torch, dev):
         "params": int(tr.flat.numel()),
         "last_loss": {k: out[k] for k in ('cls_loss', 'loc_loss', 'reg_loss')},
     }
+    n_params = int(tr.flat.numel())
     del tr
+    torch.cuda.empty_cache()
+    # the step's collectives on one GPU: their fixed cost alone, and the same
+    # timed loop with a world-1 RCCL communicator and every collective issued
+    # (counts before the forward, gradient + sums behind the backward)
+    fixed = collective_fixed_cost(torch, dev, n_params)
+    el_f, ar_f, tr_f, _, _, out_f = train_measure(
+        torch, dev, 0, 1, None, "car_auto_T3", "car", steps, 8, 4, fpg, True,
+        force_collective=True)
+    res.update({
+        "allreduce_ms": fixed["allreduce_ms"],
+        "counts_allreduce_ms": fixed["counts_allreduce_ms"],
+        "collective_fixed_cost": fixed,
+        "collectives_forced_world1": {
+            "collective": tr_f.collective,
+            "ms_per_step": el_f / steps * 1e3,
+            "allreduce_ms_inside_step": ar_f,
+            "last_loss": {k: out_f[k] for k in ('cls_loss', 'loc_loss',
+                                                'reg_loss')}},
+    })
+    del tr_f
     torch.cuda.empty_cache()
     live = None
     if not args.no_live_pmc:

@@ -42,6 +42,7 @@ extern "C" {
 #define PGNN_E_WORKSPACE (-2) /* workspace too small                          */
 #define PGNN_E_UNSUPPORTED (-3) /* shape outside the implemented range        */
 #define PGNN_E_CAPACITY (-4)  /* output capacity too small                    */
+#define PGNN_E_COMM (-5)      /* RCCL missing / a collective call failed       */
 
 /* ---- library ---------------------------------------------------------- */
 int pgnn_version(void);
@@ -990,6 +991,63 @@ int pgnn_trainer_backward(void *handle, const pgnn_train_batch *batch,
                           void *workspace, size_t workspace_bytes,
                           const float *dlogits, const float *dpred_box,
                           void *stream);
+
+/* Backward + the step's collectives in one call: pgnn_trainer_backward, then
+ * -- when `comm` is not null -- pgnn_allreduce_step(comm, <bound gradient
+ * buffer>, n_params, sums, n_sums) on the same stream: nothing of the host
+ * between the last gradient kernel and the all-reduce's launch.  comm null:
+ * exactly pgnn_trainer_backward. */
+int pgnn_trainer_backward_sync(void *handle, const pgnn_train_batch *batch,
+                               void *workspace, size_t workspace_bytes,
+                               const float *dlogits, const float *dpred_box,
+                               void *comm, double *sums, int64_t n_sums,
+                               void *stream);
+
+/* ---- collectives (config 4) ---------------------------------
+ * One process per GPU.  Replaces the reference's in-process towers:
+ * `average_gradients` (util/tf_util.py:3-43: concat the towers' gradients on a
+ * new axis, reduce_mean over it) behind `unify_copies` (train.py:264-288:
+ * every tower's cls / loc loss re-weighted by the GLOBAL endpoint counts) and
+ * the single apply_gradients (train.py:397-405).  With every rank's loss
+ * already divided by the global counts, the towers' mean x world = the SUM of
+ * the ranks' gradients: one all-reduce(sum) of the flat fp32 gradient buffer
+ * (1 489 609 floats = 5.96 MB for car_auto_T3; latency-bound on xGMI, hence
+ * one call and no bucketing), and one of the counts / loss sums (float64).
+ *
+ * The communicator is RCCL's, bound at run time (dlopen of the RCCL image the
+ * process already holds, else the system's librccl.so.1; PGNN_RCCL_LIB names
+ * another).  Rank 0 calls pgnn_comm_unique_id and hands the
+ * PGNN_COMM_ID_BYTES bytes to the other ranks by whatever the launcher offers
+ * (a file, a torch.distributed store, MPI); then EVERY rank calls
+ * pgnn_comm_init_rank (collective, blocking; uses the calling thread's current
+ * HIP device).  The collectives are in place, asynchronous, ordered on
+ * `stream` like every other entry; a world of one rank is valid (and still
+ * enters RCCL).  Errors: PGNN_E_COMM with RCCL's message in pgnn_last_error. */
+#define PGNN_COMM_ID_BYTES 128
+int pgnn_comm_unique_id(void *id_host);
+int pgnn_comm_init_rank(const void *id_host, int32_t world, int32_t rank,
+                        void **comm_out);
+int pgnn_comm_destroy(void *comm);
+/* world / rank of `comm` (nullable: version only) and RCCL's version code
+ * (e.g. 22606); each output nullable. */
+int pgnn_comm_info(void *comm, int32_t *world, int32_t *rank,
+                   int32_t *rccl_version);
+/* Which RCCL image is bound (path or "<soname> (already loaded)"), or why none. */
+const char *pgnn_comm_library(void);
+/* 0, or PGNN_E_COMM with the asynchronous error RCCL recorded for `comm`. */
+int pgnn_comm_async_error(void *comm);
+/* buf[i] = sum over ranks of buf[i], in place. */
+int pgnn_allreduce_sum_f32(void *comm, float *buf, int64_t n, void *stream);
+int pgnn_allreduce_sum_f64(void *comm, double *buf, int64_t n, void *stream);
+/* The step's two reductions as ONE RCCL group (one launch): the flat gradient
+ * (fp32) and the loss sums / endpoint counts (float64).  Either may be empty. */
+int pgnn_allreduce_step(void *comm, float *grads, int64_t n_grads, double *sums,
+                        int64_t n_sums, void *stream);
+/* buf of `root` -> every rank (initial weights of a run that was not resumed
+ * from one checkpoint: the reference's towers share ONE set of variables,
+ * train.py:225-227 under `reuse`). */
+int pgnn_broadcast_f32(void *comm, float *buf, int64_t n, int32_t root,
+                       void *stream);
 
 /* ---- detection post-processing (the step right after
  * the path; run.py:264-326).  All arrays are device pointers.

@@ -278,6 +278,21 @@ _SIGNATURES = {
                                      ctypes.POINTER(c_vp), c_vp]),
     "pgnn_trainer_backward": (c_i32, [c_vp, ctypes.POINTER(TrainBatch), c_vp,
                                       c_sz, c_vp, c_vp, c_vp]),
+    "pgnn_trainer_backward_sync": (c_i32, [c_vp, ctypes.POINTER(TrainBatch),
+                                           c_vp, c_sz, c_vp, c_vp, c_vp, c_vp,
+                                           c_i64, c_vp]),
+    # collectives (RCCL)
+    "pgnn_comm_unique_id": (c_i32, [c_vp]),
+    "pgnn_comm_init_rank": (c_i32, [c_vp, c_i32, c_i32, ctypes.POINTER(c_vp)]),
+    "pgnn_comm_destroy": (c_i32, [c_vp]),
+    "pgnn_comm_info": (c_i32, [c_vp, ctypes.POINTER(c_i32),
+                               ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)]),
+    "pgnn_comm_library": (ctypes.c_char_p, []),
+    "pgnn_comm_async_error": (c_i32, [c_vp]),
+    "pgnn_allreduce_sum_f32": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
+    "pgnn_allreduce_sum_f64": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
+    "pgnn_allreduce_step": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp]),
+    "pgnn_broadcast_f32": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp]),
     "pgnn_edge_hidden_fwd": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp,
                                      c_vp]),
     "pgnn_edge_hidden_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_vp,

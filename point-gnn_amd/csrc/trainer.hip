@@ -1748,3 +1748,15 @@ extern "C" int pgnn_trainer_backward(void *handle, const pgnn_train_batch *batch
   return backward_impl(c, sv, dlogits, dpred_box);
   PGNN_GUARD_END
 }
+
+extern "C" int pgnn_trainer_backward_sync(void *handle, const pgnn_train_batch *batch,
+                                          void *workspace, size_t workspace_bytes,
+                                          const float *dlogits, const float *dpred_box,
+                                          void *comm, double *sums, int64_t n_sums,
+                                          void *stream_) {
+  int rc = pgnn_trainer_backward(handle, batch, workspace, workspace_bytes,
+                                 dlogits, dpred_box, stream_);
+  if (rc || !comm) return rc;
+  Trainer *t = (Trainer *)handle;
+  return pgnn_allreduce_step(comm, t->grads, t->m.n_params, sums, n_sums, stream_);
+}

@@ -88,23 +88,30 @@ def _world(group=None):
     return 1
 
 
-def allreduce_endpoint_counts(n_local, nv_local, device, group=None):
+def allreduce_endpoint_counts(n_local, nv_local, device, group=None,
+                              comm=None):
     """Global (num_endpoint, num_valid_endpoint) over all ranks: the
     `unify_copies` normalisers of train.py:268-284, as Python floats.  One
     rank: no device work at all.  Several: one tiny all-reduce and its host
     read (`allreduce_endpoint_counts_device` is the form without the read)."""
-    if _world(group) <= 1:
+    if (comm.world if comm is not None else _world(group)) <= 1:
         return float(n_local), float(nv_local)
-    c = allreduce_endpoint_counts_device(n_local, nv_local, device, group)
+    c = allreduce_endpoint_counts_device(n_local, nv_local, device, group,
+                                         comm=comm)
     c = c.tolist()
     return float(c[0]), float(c[1])
 
 
-def allreduce_endpoint_counts_device(n_local, nv_local, device, group=None):
+def allreduce_endpoint_counts_device(n_local, nv_local, device, group=None,
+                                     force=False, comm=None):
     """The same, left ON THE DEVICE: a float64 [2] tensor the loss kernel
     reads (pgnn_loss_fwd_bwd_counts), so a multi-rank step has no host wait
     between its forward and its backward pass.  nv_local may be a Python
-    number (the data loader knows it) or a 0-d device tensor."""
+    number (the data loader knows it) or a 0-d device tensor.  `comm` (a
+    comm.Communicator): the reduction is pgnn_allreduce_sum_f64 on the current
+    stream (RCCL behind the C ABI) instead of torch.distributed's; `force`:
+    issue the collective for a world of one rank too (its fixed cost, and the
+    proof that the path runs, on a 1-GPU box)."""
     import torch.distributed as dist
     if isinstance(nv_local, torch.Tensor):
         counts = torch.stack([
@@ -113,19 +120,32 @@ def allreduce_endpoint_counts_device(n_local, nv_local, device, group=None):
     else:
         counts = torch.tensor([float(n_local), float(nv_local)],
                               dtype=torch.float64, device=device)
-    if _world(group) > 1:
+    if comm is not None:
+        if comm.world > 1 or force:
+            comm.allreduce_sum(counts)
+    elif _world(group) > 1 or (force and dist.is_available() and
+                               dist.is_initialized()):
         dist.all_reduce(counts, group=group)
     return counts
 
 
-def allreduce_gradients(flat_grad, sums=None, group=None):
+def allreduce_gradients(flat_grad, sums=None, group=None, force=False,
+                        comm=None):
     """The one data-path collective of a training step: SUM of the flat fp32
-    gradient buffer over ranks (RCCL on GPUs, gloo in the CPU tests).  Because
-    every rank already scaled its loss by the GLOBAL 1/N and 1/N_valid, the
-    sum equals util/tf_util.py:average_gradients of the re-weighted towers."""
+    gradient buffer over ranks.  Because every rank already scaled its loss by
+    the GLOBAL 1/N and 1/N_valid, the sum equals
+    util/tf_util.py:average_gradients of the re-weighted towers.  With `comm`
+    (a comm.Communicator) it is pgnn_allreduce_step -- gradient and loss sums
+    as ONE RCCL group on the current stream, behind the C ABI; without, a
+    torch.distributed all_reduce (`nccl` = RCCL on GPUs, `gloo` in the CPU
+    tests).  `force`: also for a world of one rank."""
+    if comm is not None:
+        if comm.world > 1 or force:
+            comm.allreduce_step(flat_grad, sums)
+        return flat_grad
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and \
-            dist.get_world_size(group) > 1:
+            (dist.get_world_size(group) > 1 or force):
         dist.all_reduce(flat_grad, group=group)
         if sums is not None:
             dist.all_reduce(sums, group=group)
@@ -206,7 +226,20 @@ def train_epochs(dataset, config, train_config, trainer=None, max_epoch=None,
         world, rank = dist.get_world_size(process_group), \
             dist.get_rank(process_group)
     if trainer is None:
-        trainer = Trainer(config, train_config, process_group=process_group)
+        # several ranks on GPUs of their own (`nccl` group): the step's
+        # collectives go through the C ABI's RCCL communicator, its id handed
+        # out over the group; any other group (gloo) carries them itself
+        comm = None
+        if world > 1 and dist.get_backend(process_group) == 'nccl':
+            from .comm import Communicator
+            comm = Communicator.from_torch(process_group)
+        trainer = Trainer(config, train_config, process_group=process_group,
+                          comm=comm)
+        if comm is not None:
+            # the reference's towers share ONE set of variables
+            # (train.py:225-227): rank 0's initial weights on every rank
+            comm.broadcast(trainer.flat, 0)
+            trainer.repack()
     train_dir = train_config['train_dir']
     if os.path.isdir(train_dir) and any(
             f.endswith('.index') for f in os.listdir(train_dir)):
@@ -340,7 +373,13 @@ _OPTIMIZERS = {
 
 class Trainer(object):
     def __init__(self, config, train_config=None, params=None, seed=0,
-                 device=None, box_encoding_len=7, process_group=None):
+                 device=None, box_encoding_len=7, process_group=None,
+                 comm=None, force_collective=False):
+        """process_group: a torch.distributed group whose all_reduce carries the
+        step's collectives; comm: a comm.Communicator instead -- RCCL behind
+        the C ABI (pgnn_allreduce_*), enqueued by the native step itself
+        (pgnn_trainer_backward_sync); force_collective: issue the collectives
+        for a world of ONE rank too (they are skipped otherwise)."""
         self.config = config
         self.train_config = train_config or {
             'initial_lr': 0.125, 'decay_step': 400000, 'decay_factor': 0.1,
@@ -392,6 +431,8 @@ class Trainer(object):
         self.box_len = box_encoding_len
         self.nc = config['num_classes']
         self.pg = process_group
+        self.comm = comm
+        self.force_collective = bool(force_collective)
         self.global_step = 0
         mk = config['model_kwargs']
         if mk.get('regularizer_type') not in (None, 'l1'):
@@ -946,15 +987,20 @@ class Trainer(object):
             '/predictor/cls', 2)[0]].k_in)
         return logits[:, :self.nc], pred
 
-    def _native_backward(self, dlogits, dpred):
+    def _native_backward(self, dlogits, dpred, sync_sums=None):
         _, batch, keep = self._saved
         dl = dlogits.contiguous()
         dp = dpred.contiguous()
-        _lib.check(self.lib.pgnn_trainer_backward(
+        sync = sync_sums is not None and self.comm is not None
+        _lib.check(self.lib.pgnn_trainer_backward_sync(
             self._native_handle(), ctypes.byref(batch),
             _lib.ptr(self._native_ws), self._native_ws.numel(), _lib.ptr(dl),
-            _lib.ptr(dp), self._st()), "pgnn_trainer_backward")
+            _lib.ptr(dp), self.comm.handle if sync else None,
+            _lib.ptr(sync_sums) if sync else None,
+            sync_sums.numel() if sync else 0, self._st()),
+            "pgnn_trainer_backward_sync")
         self._saved = None
+        return sync
 
     # ---- forward with saved activations ------------------------------------------
     def forward(self, input_v, coords, kps, edges):
@@ -1163,9 +1209,24 @@ class Trainer(object):
         return self.l1_scale * float(out.item())
 
     # ---- backward -----------------------------------------------------------------
-    def backward(self, dlogits, dpred):
+    def _multi(self):
+        """Does a step issue its collectives?  More than one rank, or one rank
+        with force_collective."""
+        if self.comm is not None:
+            return self.comm.world > 1 or self.force_collective
+        if _world(self.pg) > 1:
+            return True
+        import torch.distributed as dist
+        return self.force_collective and dist.is_available() and \
+            dist.is_initialized()
+
+    def backward(self, dlogits, dpred, sync_sums=None):
+        """Gradients of the last forward into self.grad.  sync_sums (the loss
+        sums of a multi-rank step): with a Communicator and the native step the
+        all-reduce of (self.grad, sync_sums) is enqueued by the same C call;
+        returns True when that happened (the caller reduces otherwise)."""
         if self._saved and self._saved[0] == 'native':
-            return self._native_backward(dlogits, dpred)
+            return self._native_backward(dlogits, dpred, sync_sums)
         lib, st, dev = self.lib, self._st(), self.device
         saved = list(self._saved)
         kind, cls_names, cacts, loc = saved.pop()
@@ -1314,7 +1375,7 @@ class Trainer(object):
         self.grad.zero_()
         va = torch.as_tensor(valid).to(self.device, torch.float32).reshape(-1)
         k = int(va.shape[0])
-        multi = _world(self.pg) > 1
+        multi = self._multi()
         counts = counts_dev = None
         if multi:
             # several ranks: the global counts are all-reduced and STAY on the
@@ -1323,7 +1384,8 @@ class Trainer(object):
             # loader knows this rank's count, so the tiny collective overlaps it.
             if num_valid is not None:
                 counts_dev = allreduce_endpoint_counts_device(
-                    k, float(num_valid), self.device, self.pg)
+                    k, float(num_valid), self.device, self.pg,
+                    self.force_collective, self.comm)
         elif num_valid is not None:
             counts = (float(k), float(num_valid))
         logits, pred = self.forward(input_v, coords, kps, edges)
@@ -1331,7 +1393,8 @@ class Trainer(object):
         assert int(logits.shape[0]) == k, "labels do not match the vertices"
         if multi and counts_dev is None:
             counts_dev = allreduce_endpoint_counts_device(
-                k, va.sum(), self.device, self.pg)
+                k, va.sum(), self.device, self.pg, self.force_collective,
+                self.comm)
         elif not multi and counts is None:
             counts = (float(k), float(va.sum().item()))
         # unify_copies: global endpoint counts (train.py:268-284)
@@ -1339,13 +1402,19 @@ class Trainer(object):
         sums, dlog, dpred = self.loss_and_grads(
             logits, pred, torch.as_tensor(labels), torch.as_tensor(boxes), va,
             n_total, nv_total, counts_dev=counts_dev)
-        self.backward(dlog, dpred)
         ev = getattr(self, 'allreduce_events', None)
+        # with a Communicator the native step enqueues the all-reduce itself,
+        # right behind its last gradient kernel (pgnn_trainer_backward_sync);
+        # bench.py's timing keeps the two apart to see the collective alone
+        synced = self.backward(
+            dlog, dpred, sync_sums=sums if multi and ev is None else None)
         if ev is not None:  # bench.py: device time of the collective
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
-        allreduce_gradients(self.grad, sums, self.pg)  # no-op for world 1
+        if multi and not synced:
+            allreduce_gradients(self.grad, sums, self.pg,
+                                self.force_collective, self.comm)
         if ev is not None:
             e1.record()
             ev.append((e0, e1))

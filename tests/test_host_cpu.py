@@ -198,6 +198,16 @@ def test_error_reporting_without_gpu():
         None, 10, None, None, 1242.0, 375.0, None, 0, 0, None, 0, None, None,
         1, 10, None, None) == -1                       # no count pointer
     assert lib.pgnn_kitti_ingest_workspace_bytes(120000) > 0
+    # collectives: arguments are checked before RCCL is entered
+    import ctypes
+    h = ctypes.c_void_p()
+    assert lib.pgnn_comm_unique_id(None) == -1
+    assert lib.pgnn_comm_init_rank(None, 1, 0, ctypes.byref(h)) == -1
+    assert lib.pgnn_comm_init_rank(b"\0" * 128, 2, 2, ctypes.byref(h)) == -1
+    assert lib.pgnn_allreduce_sum_f32(None, None, 4, None) == -1
+    assert lib.pgnn_allreduce_step(None, None, 0, None, 0, None) == -1
+    assert lib.pgnn_comm_destroy(None) == 0
+    assert b"rccl" in lib.pgnn_comm_library().lower()
     assert lib.pgnn_assign_box_labels(None, -1, None, 0, None, None, None,
                                       None, None) == -1
     assert lib.pgnn_vertex_pre_edge_fwd(None, 0, 0, None, None, 0, None, None,

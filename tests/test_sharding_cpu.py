@@ -104,7 +104,32 @@ def test_eight_process_gloo_sharding():
         assert sum(g[0] for g in gathered) == sum(range(n))
 
 
-def _train_worker(rank, world, port, q):
+class _StoreComm(object):
+    """Stand-in for comm.Communicator on a box without GPUs: the same three
+    methods the product's helpers call (`world`, allreduce_sum,
+    allreduce_step), the reductions carried by the process group instead of
+    RCCL -- so the `comm=` branch of the helpers runs at 2 and 8 ranks here,
+    and only the fabric differs on the GPUs."""
+
+    def __init__(self):
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        self.calls = []
+
+    def allreduce_sum(self, t):
+        self.calls.append(("sum", t.dtype, t.numel()))
+        dist.all_reduce(t)
+        return t
+
+    def allreduce_step(self, grads, sums=None):
+        self.calls.append(("step", grads.numel(),
+                           0 if sums is None else sums.numel()))
+        dist.all_reduce(grads)
+        if sums is not None:
+            dist.all_reduce(sums)
+        return grads
+
+
+def _train_worker(rank, world, port, q, use_comm=False):
     """Each 'rank' holds one frame.  Gradients are computed by the CPU oracle
     with the GLOBAL normalisers obtained through the product's collective
     helpers (gloo here, RCCL on GPUs); their all-reduce SUM must equal the
@@ -133,8 +158,9 @@ def _train_worker(rank, world, port, q):
              [g["xyz"], g["kp_xyz"], g["kp_xyz"]],
              [g["kp_idx"], np.arange(k, dtype=np.int32).reshape(-1, 1)],
              [g["ref_edges0"], g["ref_edges1"]], labels, boxes, valid)
+    comm = _StoreComm() if use_comm else None
     n_tot, nv_tot = allreduce_endpoint_counts(k, float(valid.sum()),
-                                              torch.device("cpu"))
+                                              torch.device("cpu"), comm=comm)
     tp = {kk: torch.tensor(v, dtype=torch.float64, requires_grad=True)
           for kk, v in params.items()}
     logits, pred = to.forward(tp, cfg, *batch[:4])
@@ -145,15 +171,25 @@ def _train_worker(rank, world, port, q):
                                 allow_unused=True)
     flat = torch.cat([(torch.zeros_like(tp[n_]) if g_ is None else g_).reshape(-1)
                       for n_, g_ in zip(names, grads)])
-    allreduce_gradients(flat)
+    sums = torch.tensor([float(ce), float(loc), float(n), float(nv)],
+                        dtype=torch.float64)
+    allreduce_gradients(flat, sums if use_comm else None, comm=comm)
+    if use_comm:
+        # the Communicator branch: one f64[2] reduction for the counts, one
+        # grouped (gradient, sums) reduction -- and nothing else
+        assert comm.calls == [("sum", torch.float64, 2),
+                              ("step", flat.numel(), 4)], comm.calls
+        assert float(sums[2]) == n_tot and float(sums[3]) == nv_tot
     q.put((rank, batch, n_tot, nv_tot, flat.numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 8])
-def test_gradient_allreduce_equals_global_gradient(world):
-    """world 2, and 8 = the node's width (config 4: batch 16 over 8 ranks)."""
+@pytest.mark.parametrize("world,use_comm", [(2, False), (8, False), (8, True)])
+def test_gradient_allreduce_equals_global_gradient(world, use_comm):
+    """world 2, and 8 = the node's width (config 4: batch 16 over 8 ranks);
+    use_comm: through the helpers' Communicator branch (pgnn_allreduce_* on
+    the GPUs; here a stand-in whose reductions ride on gloo)."""
     import numpy as np
     sys.path.insert(0, ROOT)
     from pointgnn_amd import configs, weights
@@ -161,7 +197,8 @@ def test_gradient_allreduce_equals_global_gradient(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_train_worker, args=(r, world, port, q))
+    procs = [ctx.Process(target=_train_worker,
+                         args=(r, world, port, q, use_comm))
              for r in range(world)]
     for p in procs:
         p.start()
