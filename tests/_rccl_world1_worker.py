@@ -38,7 +38,11 @@ def main():
         out2 = tr.train_step(batch, apply=True)
         return tr, out, g, out2
 
+    def rel(a, b):
+        return float((a - b).norm() / a.norm())
+
     plain, o0, g0, _ = run()
+    plain2, _, g0b, _ = run()
     assert not plain._multi()
     # torch.distributed's nccl all_reduce, the world-1 short-circuit bypassed
     tpg, o1, g1, _ = run(process_group=dist.group.WORLD, force_collective=True)
@@ -47,6 +51,10 @@ def main():
     c = pcomm.Communicator.from_torch(dist.group.WORLD)
     tc, o2, g2, _ = run(comm=c, force_collective=True)
     assert tc._multi()
+    again = g2.clone()
+    c.allreduce_step(again, None)
+    dist.all_reduce(again)
+    torch.cuda.synchronize()
     keys = ("cls_loss", "loc_loss", "reg_loss", "num_endpoint",
             "num_valid_endpoint")
     res = {
@@ -54,10 +62,13 @@ def main():
         "rccl_version": pcomm.Communicator.rccl_version(),
         "rccl_library": pcomm.Communicator.library(),
         "grad_norm": float(g0.norm()),
-        "pg_grad_bit_identical": bool(torch.equal(g0, g1)),
-        "comm_grad_bit_identical": bool(torch.equal(g0, g2)),
-        "pg_weights_bit_identical": bool(torch.equal(plain.flat, tpg.flat)),
-        "comm_weights_bit_identical": bool(torch.equal(plain.flat, tc.flat)),
+        "plain_step_repeats_bit_for_bit": bool(
+            torch.equal(g0, g0b) and torch.equal(plain.flat, plain2.flat)),
+        "pg_grad_rel_err": rel(g0, g1), "comm_grad_rel_err": rel(g0, g2),
+        "pg_weights_rel_err": rel(plain.flat, tpg.flat),
+        "comm_weights_rel_err": rel(plain.flat, tc.flat),
+        "real_gradient_allreduce_is_identity": bool(
+            torch.equal(again.view(torch.int32), g2.view(torch.int32))),
         "loss_plain": {k: o0[k] for k in keys},
         "loss_pg": {k: o1[k] for k in keys},
         "loss_comm": {k: o2[k] for k in keys},

@@ -431,6 +431,7 @@ def test_count_record_pool_wraps_inside_a_deferred_batch(dev, monkeypatch):
             assert l0.shape[0] > 0
             assert torch.equal(l0, l1) and torch.equal(b0, b1)
             assert torch.equal(l0, l2) and torch.equal(b0, b2)
+    dev = G._device()
     pool = G._ZERO_POOLS[dev.index]
     assert pool.kRecords == 3
     # rotations happened, and dead segments were recycled rather than leaked

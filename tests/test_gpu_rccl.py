@@ -4,9 +4,11 @@ enters the library -- unique id, ncclCommInitRank, the all-reduce kernels on
 the step's stream, destroy.  What it replaces: util/tf_util.py:3-43
 (average_gradients), train.py:264-288 (unify_copies), train.py:397-405.
 
-Bars: an all-reduce(sum) over one rank is the identity, BIT for bit; a
-training step with its collectives forced at world 1 leaves the gradient, the
-loss values and the updated weights bit-identical to the step without them."""
+Bars: an all-reduce(sum) over one rank is the identity, BIT for bit -- on
+random data and on the step's real gradient; a training step with its
+collectives forced at world 1 equals the same step with the fabric taken out
+(bit for bit where the box repeats a step bit for bit: the adjoint's scatter
+kernels use float atomics) and the plain step to rounding (2e-5 Frobenius)."""
 import ctypes
 import json
 import os
@@ -129,13 +131,31 @@ def test_communicator_argument_errors(dev, comm, tmp_path):
     assert lib.pgnn_comm_destroy(None) == 0
 
 
+class _NullComm(object):
+    """The Communicator's interface with the fabric taken out (world 1: every
+    reduction is the identity): the step takes exactly the code path of a
+    multi-rank step -- counts on the device, pgnn_trainer_backward_sync -- and
+    only RCCL is missing.  What the RCCL step is compared against."""
+    world, rank, handle = 1, 0, None
+
+    def allreduce_sum(self, t):
+        return t
+
+    def allreduce_step(self, grads, sums=None):
+        return grads
+
+
 @pytest.mark.parametrize("t_config,native", [(1, True), (3, True), (1, False)])
-def test_trainer_step_with_world1_rccl_is_bit_identical(dev, comm, t_config,
-                                                        native):
+def test_trainer_step_with_world1_rccl_equals_step_without(dev, comm, t_config,
+                                                           native):
     """The real flat gradient and the counts all-reduced in place by RCCL
     (pgnn_trainer_backward_sync for the native step, pgnn_allreduce_step
-    behind the Python composition): the no-collective step, bit for bit --
-    gradient, losses, weights after the update."""
+    behind the Python composition) against the same step with the fabric
+    taken out (_NullComm) and against the plain single-rank step.  The
+    adjoint's scatter kernels add with float atomics, so two runs of ONE step
+    agree to rounding only; where this box happens to repeat a step bit for
+    bit, the RCCL step must too.  The all-reduce itself is checked exactly:
+    the step's real gradient reduced once more, in place, does not change."""
     import torch
     sys.path.insert(0, HERE)
     from _multirank_worker import make_frame
@@ -143,6 +163,7 @@ def test_trainer_step_with_world1_rccl_is_bit_identical(dev, comm, t_config,
     cfg = configs.car_auto_config(t_config)
     batch = train.batch_data([make_frame(cfg, i, dev) for i in range(2)])
     nv = float(batch[6].sum().item())
+    keys = ("cls_loss", "loc_loss", "reg_loss")
 
     def run(num_valid, **kw):
         tr = train.Trainer(cfg, seed=3, device=dev, **kw)
@@ -152,20 +173,37 @@ def test_trainer_step_with_world1_rccl_is_bit_identical(dev, comm, t_config,
         tr.train_step(batch, apply=True, num_valid=num_valid)
         return tr, out, g
 
+    def close(a, b):
+        return float((a - b).norm() / a.norm())
+
     plain, o0, g0 = run(None)
-    assert not plain._multi()
+    assert not plain._multi() and float(g0.norm()) > 0
     for num_valid in (None, nv):      # counts reduced after / before forward
+        null, on, gn = run(num_valid, comm=_NullComm(), force_collective=True)
+        null2, _, gn2 = run(num_valid, comm=_NullComm(), force_collective=True)
         tr, o1, g1 = run(num_valid, comm=comm, force_collective=True)
-        assert tr._multi()
-        assert float(g0.norm()) > 0
-        assert torch.equal(g0, g1)
-        assert torch.equal(plain.flat, tr.flat)
-        for k in ("cls_loss", "loc_loss", "reg_loss", "num_endpoint",
-                  "num_valid_endpoint"):
-            assert o0[k] == o1[k], (k, o0[k], o1[k])
+        assert tr._multi() and null._multi()
+        repeatable = torch.equal(gn, gn2) and torch.equal(null.flat, null2.flat)
+        if repeatable:
+            assert torch.equal(gn, g1)
+            assert torch.equal(null.flat, tr.flat)
+            assert all(on[k] == o1[k] for k in keys)
+        assert close(gn, g1) < 2e-5 and close(g0, g1) < 2e-5
+        assert close(plain.flat, tr.flat) < 1e-6
+        for k in keys:
+            assert abs(o0[k] - o1[k]) <= 1e-6 * max(1.0, abs(o0[k])), k
+        assert o0["num_endpoint"] == o1["num_endpoint"]
+        assert o0["num_valid_endpoint"] == o1["num_valid_endpoint"]
+        # the collective on the step's own gradient: exact identity
+        again = g1.clone()
+        sums = torch.tensor([1.0, 2.0, 3.0, 4.0], dtype=torch.float64,
+                            device=dev)
+        comm.allreduce_step(again, sums)
+        torch.cuda.synchronize()
+        assert torch.equal(again.view(torch.int32), g1.view(torch.int32))
     # a Communicator without force_collective at world 1: no collective at all
     tr, o2, g2 = run(None, comm=comm)
-    assert not tr._multi() and torch.equal(g0, g2)
+    assert not tr._multi() and close(g0, g2) < 2e-5
     comm.check_async_error()
 
 
@@ -181,7 +219,7 @@ def test_world1_nccl_process_group_and_communicator_from_it():
     """init_process_group('nccl', world_size=1, device_id=cuda:0) in its own
     process: the torch.distributed variant of the step (world-1 short-circuits
     bypassed) and a Communicator whose id travelled through that group, both
-    bit-identical to the plain step."""
+    equal to the plain step (bit for bit when a step repeats bit for bit)."""
     env = dict(os.environ, PGNN_PORT=str(_free_port()), PGNN_TEST_T="1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     p = subprocess.run([sys.executable,
@@ -193,7 +231,13 @@ def test_world1_nccl_process_group_and_communicator_from_it():
     assert rec["backend"] == "nccl" and rec["world"] == 1
     assert rec["rccl_version"] >= 20000 and "rccl" in rec["rccl_library"]
     assert rec["grad_norm"] > 0
-    for k in ("pg_grad_bit_identical", "comm_grad_bit_identical",
-              "pg_weights_bit_identical", "comm_weights_bit_identical"):
-        assert rec[k], (k, rec)
-    assert rec["loss_plain"] == rec["loss_pg"] == rec["loss_comm"]
+    assert rec["pg_grad_rel_err"] < 2e-5 and rec["comm_grad_rel_err"] < 2e-5
+    assert rec["pg_weights_rel_err"] < 1e-6
+    assert rec["comm_weights_rel_err"] < 1e-6
+    assert rec["real_gradient_allreduce_is_identity"]
+    for k in ("cls_loss", "loc_loss", "reg_loss"):
+        for other in ("loss_pg", "loss_comm"):
+            assert abs(rec["loss_plain"][k] - rec[other][k]) <= \
+                1e-6 * max(1.0, abs(rec["loss_plain"][k])), (k, other)
+    for other in ("loss_pg", "loss_comm"):
+        assert rec[other]["num_endpoint"] == rec["loss_plain"]["num_endpoint"]
