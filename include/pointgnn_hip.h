@@ -1077,6 +1077,15 @@ int pgnn_detection_candidates(const float *probs, int64_t n_vertices,
                               int32_t num_classes, int32_t *out_index,
                               int32_t *out_label, int64_t capacity,
                               int32_t *out_count, void *stream);
+/* The same for a capacity-form frame (the frame loop keeps frames in flight
+ * and reads nothing between the GNN and this call): probs has n_vertices_cap
+ * rows of which the first *n_vertices_dev (a device int32, the K of the
+ * frame's count record) exist. */
+int pgnn_detection_candidates_dyn(const float *probs, int64_t n_vertices_cap,
+                                  const int32_t *n_vertices_dev,
+                                  int32_t num_classes, int32_t *out_index,
+                                  int32_t *out_label, int64_t capacity,
+                                  int32_t *out_count, void *stream);
 /* nms.py:241-300.  mode: 0 = nms_boxes_3d (plain; integer corners scaled by
  * appr_factor, nms.py:113-115), 1 = nms_boxes_3d_uncertainty (median merge +
  * score accumulation, what run.py uses), 2 = nms_boxes_3d_merge_only,

@@ -343,6 +343,8 @@ _SIGNATURES = {
                                     c_i32, c_vp, c_vp]),
     "pgnn_detection_candidates": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp,
                                           c_i64, c_vp, c_vp]),
+    "pgnn_detection_candidates_dyn": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_vp,
+                                              c_vp, c_i64, c_vp, c_vp]),
     "pgnn_nms_workspace_bytes": (c_sz, [c_i64]),
     "pgnn_nms_boxes_3d": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64,
                                   c_f64, c_i32, ctypes.c_float, c_i64,

@@ -48,6 +48,21 @@ def class_table(label_map, dtype=np.float32):
     return table
 
 
+_TABLES = {}
+
+
+def _device_table(label_map, dtype, dev):
+    """class_table(label_map) on `dev`, uploaded once per (map, dtype, device):
+    the frame loop decodes every frame with the same table."""
+    import torch
+    key = (tuple(sorted(label_map.items())), np.dtype(dtype).str, str(dev))
+    t = _TABLES.get(key)
+    if t is None:
+        t = _TABLES[key] = torch.from_numpy(class_table(label_map, dtype)).to(dev)
+        torch.cuda.current_stream(dev).synchronize()   # used on any stream
+    return t
+
+
 def _run(entry, cls_labels, points_xyz, boxes, label_map):
     import torch
     lib = _lib.load()
@@ -75,7 +90,7 @@ def _run(entry, cls_labels, points_xyz, boxes, label_map):
         xyz64 = (np.asarray(points_xyz).dtype == np.float64) if not isinstance(
             points_xyz, torch.Tensor) else points_xyz.dtype == torch.float64
         xyz = to(points_xyz, torch.float64 if xyz64 else torch.float32)
-        table = torch.from_numpy(class_table(label_map, np.float64)).to(dev)
+        table = _device_table(label_map, np.float64, dev)
         out = torch.empty(tuple(b.shape), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             _lib.check((lib.pgnn_box_encode_f64_xyz64 if xyz64 else
@@ -92,7 +107,7 @@ def _run(entry, cls_labels, points_xyz, boxes, label_map):
     xyz = to(points_xyz, torch.float32)
     if lab.numel() != rows or tuple(xyz.shape) != (rows, 3):
         raise ValueError("cls_labels [R,1] / points_xyz [R,3] do not match boxes")
-    table = torch.from_numpy(class_table(label_map)).to(dev)
+    table = _device_table(label_map, np.float32, dev)
     out = torch.empty_like(b)
     with torch.cuda.device(dev):
         _lib.check(getattr(lib, entry)(

@@ -260,9 +260,14 @@ __global__ void box_encode_kernel(const int32_t *__restrict__ labels,
 // ordered compaction with a running base.
 __global__ __launch_bounds__(kScanThreads) void candidates_kernel(
     const float *__restrict__ probs, int64_t n, int nc, int32_t *out_index,
-    int32_t *out_label, int32_t *out_count, int64_t capacity) {
+    int32_t *out_label, int32_t *out_count, int64_t capacity,
+    const int32_t *__restrict__ n_vertices_dev) {
   __shared__ int wave_tot[kScanThreads / 64];
   __shared__ int base_s;
+  if (n_vertices_dev) {  // capacity form: the rows that exist
+    const int64_t live = (int64_t)max(*n_vertices_dev, 0) * nc;
+    n = live < n ? live : n;
+  }
   const float thr = (float)(1.0 / (double)nc);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (threadIdx.x == 0) base_s = 0;
@@ -746,7 +751,37 @@ extern "C" int pgnn_detection_candidates(const float *probs,
                PGNN_E_INVALID, "detection_candidates: null pointer");
   hipLaunchKernelGGL(candidates_kernel, dim3(1), dim3(kScanThreads), 0, stream,
                      probs, n_vertices * num_classes, num_classes, out_index,
-                     out_label, out_count, capacity);
+                     out_label, out_count, capacity, (const int32_t *)nullptr);
+  PGNN_HIP(hipGetLastError());
+  return 0;
+  PGNN_GUARD_END
+}
+
+extern "C" int pgnn_detection_candidates_dyn(const float *probs,
+                                             int64_t n_vertices_cap,
+                                             const int32_t *n_vertices_dev,
+                                             int32_t num_classes,
+                                             int32_t *out_index,
+                                             int32_t *out_label,
+                                             int64_t capacity,
+                                             int32_t *out_count,
+                                             void *stream_) {
+  PGNN_GUARD_BEGIN
+  hipStream_t stream = (hipStream_t)stream_;
+  PGNN_REQUIRE(n_vertices_cap >= 0 && num_classes > 0 && capacity >= 0 &&
+                   out_count && n_vertices_dev,
+               PGNN_E_INVALID, "detection_candidates_dyn: bad argument");
+  PGNN_REQUIRE(n_vertices_cap * num_classes < (int64_t)1 << 31, PGNN_E_INVALID,
+               "detection_candidates_dyn: index range exceeds int32");
+  if (n_vertices_cap == 0) {
+    PGNN_HIP(hipMemsetAsync(out_count, 0, 4, stream));
+    return 0;
+  }
+  PGNN_REQUIRE(probs && (capacity == 0 || (out_index && out_label)),
+               PGNN_E_INVALID, "detection_candidates_dyn: null pointer");
+  hipLaunchKernelGGL(candidates_kernel, dim3(1), dim3(kScanThreads), 0, stream,
+                     probs, n_vertices_cap * num_classes, num_classes,
+                     out_index, out_label, out_count, capacity, n_vertices_dev);
   PGNN_HIP(hipGetLastError());
   return 0;
   PGNN_GUARD_END

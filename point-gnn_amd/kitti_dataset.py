@@ -83,7 +83,8 @@ def cam_points_in_image(velo_data, calib, image_shape, image=None,
     import torch
     lib = _lib.load()
     dev = velo_data.device if isinstance(velo_data, torch.Tensor) and \
-        velo_data.is_cuda else torch.device("cuda", 0)
+        velo_data.is_cuda else torch.device("cuda",
+                                            torch.cuda.current_device())
     v = torch.as_tensor(velo_data).to(device=dev, dtype=torch.float32)
     v = v.reshape(-1, 4).contiguous()
     n = int(v.shape[0])

@@ -63,22 +63,42 @@ def occlusion(label, xyz):
     return rate
 
 
+def inside_box_host(label, xyz):
+    """kitti_dataset.sel_xyz_in_box3d on the HOST, bit for bit what the
+    device kernel computes (csrc/labels.hip assign_labels_kernel: float32
+    points widened, p = (x n0 + y n1) + z n2 in float64 without contraction,
+    strictly inside): the frame loop with frames in flight has the candidates
+    on the host already and must not go back to the device once per box."""
+    normals, lower, upper = kitti_dataset.box3d_to_normals(label)
+    x, y, z = (xyz[:, i].astype(np.float64) for i in range(3))
+    inside = np.ones(xyz.shape[0], bool)
+    for k in range(3):
+        p = (x * normals[k, 0] + y * normals[k, 1]) + z * normals[k, 2]
+        inside &= (p > lower[k]) & (p < upper[k])
+    return inside
+
+
 def detections_to_kitti_labels(class_labels, detection_boxes_3d, box_probs,
                                calib, label_method, candidate_xyz=None,
                                use_box_score=True,
-                               image_size=(1242.0, 375.0)):
+                               image_size=(1242.0, 375.0), host_only=False):
     """run.py:360-412.  class_labels [M], detection_boxes_3d [M,7], box_probs
     [M] = the NMS outputs; candidate_xyz [n_candidates,3] = the vertices of
     ALL candidates that entered the NMS (`last_layer_points_xyz[box_indices]`),
     needed for the occlusion rescoring when use_box_score.  Returns the list
-    of 16-field tuples the reference writes."""
+    of 16-field tuples the reference writes.  host_only: every argument is a
+    NumPy array and nothing touches the device (inside_box_host)."""
     labels = _host(class_labels)
     boxes = _host(detection_boxes_3d)
     probs = _host(box_probs)
     names = CLASS_NAMES[label_method]
     width, height = float(image_size[0]), float(image_size[1])
     cand_dev = None
-    if use_box_score:
+    if use_box_score and host_only:
+        if candidate_xyz is None:
+            raise ValueError("use_box_score needs candidate_xyz")
+        cand_host = np.asarray(candidate_xyz)
+    elif use_box_score:
         if candidate_xyz is None:
             raise ValueError("use_box_score needs candidate_xyz")
         import torch
@@ -104,7 +124,8 @@ def detections_to_kitti_labels(class_labels, detection_boxes_3d, box_probs,
         if use_box_score:
             tmp = {"x3d": x3d, "y3d": y3d, "z3d": z3d, "yaw": yaw,
                    "height": h, "width": w, "length": l}
-            inside = _host(kitti_dataset.sel_xyz_in_box3d(tmp, cand_dev))
+            inside = inside_box_host(tmp, cand_host) if host_only else \
+                _host(kitti_dataset.sel_xyz_in_box3d(tmp, cand_dev))
             score = (1 + occlusion(tmp, cand_host[inside])) * score
         out.append((names[int(labels[i])], -1, -1, 0, clip_xmin, clip_ymin,
                     clip_xmax, clip_ymax, h, w, l, x3d, y3d, z3d, yaw, score))

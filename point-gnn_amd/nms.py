@@ -106,8 +106,11 @@ def overlapped_boxes_3d(single_box, box_list):
     return out.cpu().numpy() if as_numpy else out
 
 
-def _nms(mode, class_labels, detection_boxes_3d, detection_scores,
-         overlapped_thres, overlapped_fn, appr_factor, top_k, attributes):
+def _nms_launch(mode, class_labels, detection_boxes_3d, detection_scores,
+                overlapped_thres, overlapped_fn, appr_factor, top_k,
+                attributes):
+    """Enqueue pgnn_nms_boxes_3d: -> (as_numpy, dtypes, n-row output tensors,
+    the device count of kept rows); nothing is read back."""
     import torch
     if overlapped_fn is not overlapped_boxes_3d_fast_poly:
         raise NotImplementedError(
@@ -144,9 +147,18 @@ def _nms(mode, class_labels, detection_boxes_3d, detection_scores,
             int(top_k), _lib.ptr(ws), ws_bytes, _lib.ptr(o_lab),
             _lib.ptr(o_box), _lib.ptr(o_sco), _lib.ptr(o_att), _lib.ptr(o_cnt),
             _lib.stream_ptr()), "pgnn_nms_boxes_3d")
-        kept = int(o_cnt.item())
-    res = (o_lab[:kept], o_box[:kept], o_sco[:kept],
-           o_att[:kept] if attributes is not None else None)
+    return (as_numpy, label_dtype, attr_dtype,
+            (o_lab, o_box, o_sco, o_att if attributes is not None else None),
+            o_cnt)
+
+
+def _nms(mode, class_labels, detection_boxes_3d, detection_scores,
+         overlapped_thres, overlapped_fn, appr_factor, top_k, attributes):
+    as_numpy, label_dtype, attr_dtype, out, o_cnt = _nms_launch(
+        mode, class_labels, detection_boxes_3d, detection_scores,
+        overlapped_thres, overlapped_fn, appr_factor, top_k, attributes)
+    kept = int(o_cnt.item())
+    res = tuple(None if t is None else t[:kept] for t in out)
     if as_numpy:
         return (res[0].cpu().numpy().astype(label_dtype),
                 res[1].cpu().numpy(), res[2].cpu().numpy(),
@@ -213,6 +225,62 @@ def select_candidates(probs):
             _lib.ptr(cnt), _lib.stream_ptr()), "pgnn_detection_candidates")
         n = int(cnt.item())
     return idx[:n], lab[:n]
+
+
+def select_candidates_dyn(probs, k_dev):
+    """select_candidates for a capacity-form frame: probs [cap, nc] of which
+    the first `k_dev` (device int32 [1]) rows exist.  Nothing is read back:
+    -> (flat indices [cap*nc], labels [cap*nc], count [1]) on the device."""
+    import torch
+    lib = _lib.load()
+    dev = _device_of(probs)
+    p = _to(probs, torch.float32, dev)
+    cap_rows, nc = int(p.shape[0]), int(p.shape[1])
+    cap = cap_rows * nc
+    idx = torch.empty((cap,), dtype=torch.int32, device=dev)
+    lab = torch.empty((cap,), dtype=torch.int32, device=dev)
+    cnt = torch.zeros((1,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.pgnn_detection_candidates_dyn(
+            _lib.ptr(p), cap_rows, _lib.ptr(k_dev), nc, _lib.ptr(idx),
+            _lib.ptr(lab), cap, _lib.ptr(cnt), _lib.stream_ptr()),
+            "pgnn_detection_candidates_dyn")
+    return idx, lab, cnt
+
+
+def detect_candidates_deferred(probs, box_encodings, last_layer_points_xyz,
+                               idx, labels, label_map, overlapped_thres,
+                               box_encoding_method=
+                               'classaware_all_class_box_encoding',
+                               use_box_merge=True, use_box_score=True,
+                               appr_factor=100.0, top_k=-1):
+    """The tail of detect_boxes for candidates that are already selected
+    (idx, labels: the first n entries select_candidates[_dyn] wrote, n known
+    to the host), with nothing read back: decode the candidates' boxes -- the
+    codec is per box, so decoding the selection equals selecting from the
+    decoded whole --, run the NMS variant, and return ((class_labels,
+    boxes_3d, scores, nms_indices) with n rows each, kept count [1] on the
+    device, candidate_xyz [n,3])."""
+    import torch
+    dev = _device_of(probs, box_encodings)
+    p = _to(probs, torch.float32, dev)
+    nc = int(p.shape[1])
+    sel = idx.long()
+    vert = sel // nc
+    cand_xyz = _to(last_layer_points_xyz, torch.float32, dev)[vert]
+    enc = _to(box_encodings, torch.float32, dev).reshape(-1, 1, 7)[sel]
+    decode = box_encoding.get_box_decoding_fn(box_encoding_method)
+    decoded = decode((sel % nc).to(torch.int32).reshape(-1, 1), cand_xyz, enc,
+                     label_map)
+    cand_scores = p.reshape(-1)[sel]
+    mode = {(True, True): "uncertainty", (True, False): "merge_only",
+            (False, True): "score_only", (False, False): "plain"}[
+        (bool(use_box_merge), bool(use_box_score))]
+    attrs = torch.arange(idx.numel(), dtype=torch.int32, device=dev)
+    _, _, _, out, cnt = _nms_launch(
+        mode, labels, decoded[:, 0], cand_scores, overlapped_thres,
+        overlapped_boxes_3d_fast_poly, appr_factor, top_k, attrs)
+    return out, cnt, cand_xyz
 
 
 def detect_boxes(probs, box_encodings, last_layer_points_xyz, label_map,

@@ -160,3 +160,81 @@ def synthetic_cloud(seed=0, n_points=20000, fov_deg=81.0, az_step_deg=0.1728,
     xyz = np.ascontiguousarray(cam[sel].astype(np.float32))
     intensity = rng2.random((n, 1)).astype(np.float32)
     return xyz, intensity
+
+
+# ---- synthetic KITTI-object directories (the frame loop's input format) --------
+def synthetic_calib(xyz_cam, margin_px=8.0, focal=721.5377):
+    """A KITTI-style calibration under which every point of the camera-frame
+    cloud `xyz_cam` projects inside the image: (calib file lines, (height,
+    width)).  P2 has KITTI's focal length; the principal point and the image
+    size are fitted to the cloud (the synthetic scene spans the HDL-64E's
+    26.8 deg of elevation, more than a 375-row KITTI image sees, and a frame
+    cropped to 375 rows would not be the BASELINE workload any more);
+    R0_rect = I; Tr_velo_to_cam is KITTI's axis permutation (x_cam = -y_velo,
+    y_cam = -z_velo, z_cam = x_velo) with KITTI's nominal lever arm."""
+    x, y, z = (xyz_cam[:, i].astype(np.float64) for i in range(3))
+    u, v = focal * x / z, focal * y / z
+    cx = float(np.ceil(margin_px - u.min()))
+    cy = float(np.ceil(margin_px - v.min()))
+    width = int(np.ceil(u.max() + cx + margin_px))
+    height = int(np.ceil(v.max() + cy + margin_px))
+    p2 = [focal, 0.0, cx, 0.0, 0.0, focal, cy, 0.0, 0.0, 0.0, 1.0, 0.0]
+    r0 = [1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0]
+    tr = [0.0, -1.0, 0.0, -0.004, 0.0, 0.0, -1.0, -0.076, 1.0, 0.0, 0.0, -0.272]
+    fmt = lambda vals: " ".join("%.12e" % t for t in vals)
+    lines = ["P0: %s\n" % fmt(p2), "P1: %s\n" % fmt(p2), "P2: %s\n" % fmt(p2),
+             "P3: %s\n" % fmt(p2), "R0_rect: %s\n" % fmt(r0),
+             "Tr_velo_to_cam: %s\n" % fmt(tr),
+             "Tr_imu_to_velo: %s\n" % fmt(tr)]
+    return lines, (height, width)
+
+
+def write_png_header(path, height, width):
+    """A file that starts like a PNG (signature + IHDR): all the frame loop
+    ever reads of the image without an `image_reader` is its size."""
+    import struct
+    import zlib
+    ihdr = struct.pack(">IIBBBBB", int(width), int(height), 8, 2, 0, 0, 0)
+    chunk = b"IHDR" + ihdr
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + struct.pack(">I", len(ihdr)) + chunk +
+                struct.pack(">I", zlib.crc32(chunk) & 0xffffffff))
+
+
+def write_kitti_frames(root, seeds, preset="car_600k", behind_points=95000):
+    """A KITTI-object directory tree under `root` (image_2/, velodyne/,
+    calib/; frame names %06d of the seeds) holding, per seed, the synthetic
+    scene of `synthetic_cloud(seed, preset)` as a velodyne scan: the camera-FOV
+    returns mapped into the lidar frame plus `behind_points` returns outside
+    the image (a real HDL-64E sweep has ~120 k points of which ~20 k fall in
+    the camera image: the file size and the crop's work are then KITTI's).
+    Returns (image_dir, point_dir, calib_dir)."""
+    import os
+    dirs = [os.path.join(root, d) for d in ("image_2", "velodyne", "calib")]
+    for d in dirs:
+        os.makedirs(d, exist_ok=True)
+    for seed in seeds:
+        xyz_cam, inten = synthetic_cloud(seed=seed, preset=preset)
+        lines, (height, width) = synthetic_calib(xyz_cam)
+        # cam -> velo: inverse of Tr (R0 = I): x_v = z_c + 0.272, y_v = -x_c
+        # - 0.004, z_v = -y_c - 0.076
+        xc, yc, zc = (xyz_cam[:, i].astype(np.float64) for i in range(3))
+        front = np.stack([zc + 0.272, -xc - 0.004, -yc - 0.076], axis=1)
+        rng = np.random.default_rng(100000 + seed)
+        n_b = int(behind_points)
+        az = rng.uniform(0.75 * np.pi, 1.25 * np.pi, n_b)   # behind the car
+        el = np.deg2rad(rng.uniform(-24.8, 2.0, n_b))
+        r = np.minimum(rng.uniform(3.0, 70.0, n_b),
+                       1.73 / np.maximum(np.sin(-el), 1e-3))
+        back = np.stack([r * np.cos(el) * np.cos(az),
+                         r * np.cos(el) * np.sin(az), r * np.sin(el)], axis=1)
+        scan = np.vstack([
+            np.hstack([front, inten[:, :1].astype(np.float64)]),
+            np.hstack([back, rng.random((n_b, 1))])]).astype(np.float32)
+        scan = scan[rng.permutation(len(scan))]
+        name = "%06d" % seed
+        scan.tofile(os.path.join(dirs[1], name + ".bin"))
+        with open(os.path.join(dirs[2], name + ".txt"), "w") as f:
+            f.write("".join(lines))
+        write_png_header(os.path.join(dirs[0], name + ".png"), height, width)
+    return tuple(dirs)
