@@ -1066,6 +1066,9 @@ def parse_args(argv=None):
                     help="build the graphs with host-read sizes (two host "
                          "waits per frame) instead of the capacity form")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--e2e", action="store_true",
+                    help="only the files-to-files frame loop (secondary_e2e)")
+    ap.add_argument("--e2e-bias", type=float, default=None)
     ap.add_argument("--train", action="store_true",
                     help="BASELINE config 4: training step instead of inference")
     ap.add_argument("--frames-per-gpu", type=int, default=2)
@@ -1407,6 +1410,96 @@ def secondary_ped(args, torch, dev, measure):
     return out
 
 
+def secondary_e2e(args, torch, dev, headline_fps=None, n_files=8, passes=20,
+                  background_bias=None):
+    """The drop-in frame loop (run.py:203-433 -> pointgnn_amd.run.run_dataset's
+    FramePipeline) from FILES to FILES: a synthetic KITTI-object tree (the
+    headline preset's scenes as 115 k-point velodyne sweeps + calib + image
+    headers, written by pointgnn_amd.synthetic.write_kitti_frames) -> crop ->
+    graph -> GNN -> softmax -> decode + NMS -> KITTI rows -> txt, frames kept in
+    flight.  Timed: `passes` passes over the `n_files` files (page cache) by
+    one FramePipeline.run(), wall clock, after one warm-up pass.
+
+    Synthetic weights classify at random; a trained model marks a few percent
+    of the vertices as objects.  `background_bias` is added to the background
+    logit's bias so that the candidate rate is a trained model's (the line
+    reports candidates / kept boxes / rows per frame): the NMS and the
+    host-side rows stage then do a real frame's amount of work."""
+    import shutil
+    import tempfile
+    from pointgnn_amd import configs, kitti_dataset, run as RUN, weights
+    from pointgnn_amd.synthetic import write_kitti_frames
+    cfg = configs.get_config("car_auto_T3")
+    params = weights.init_params(cfg, seed=0, bias_scale=0.05)
+    bias_name = "output/predictor/cls/fully_connected_1/biases"
+    if background_bias is None:
+        background_bias = E2E_BACKGROUND_BIAS
+    params[bias_name] = params[bias_name].copy()
+    params[bias_name][0] += background_bias
+    root = tempfile.mkdtemp(prefix="pgnn_e2e_")
+    try:
+        dirs = write_kitti_frames(root, range(n_files), preset="car_600k")
+        ds = kitti_dataset.KittiDataset(*dirs)
+        model = RUN.build_model(cfg, params=params)
+        out_dir = os.path.join(root, "out")
+
+        def run(indices, seq=False):
+            td = {}
+            t0 = time.perf_counter()
+            if seq:
+                for i in indices:
+                    RUN._frame_sequential(ds, i, model, cfg, out_dir, True,
+                                          True, td, None, None)
+                pipe = None
+            else:
+                pipe = RUN.FramePipeline(ds, cfg, model, out_dir, True, True,
+                                         None, None, 3, 4, td)
+                pipe.run(list(indices))
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0, td, pipe
+        files = list(range(n_files))
+        run(files)                                  # warm-up pass
+        n = n_files * passes
+        wall, td, pipe = run(files * passes)
+        seq_wall, seq_td, _ = run(files * 2, seq=True)
+        names = ('fetch input', 'gen graph', 'gnn inference',
+                 'decode box + nms', 'kitti rows', 'write txt')
+        res = {
+            "workload": "run_dataset's frame loop, files to files: %d "
+                        "synthetic KITTI frames (car_600k scenes as 115 k-point "
+                        "velodyne sweeps, %.1f MB each) x %d passes, "
+                        "car_auto_T3, 3 frames in flight, loader + writer "
+                        "threads; background-logit bias %+.1f on the synthetic "
+                        "weights" % (n_files, 115000 * 16 / 1e6, passes,
+                                     background_bias),
+            "frames": n, "frames_per_sec": n / wall,
+            "ms_per_frame": wall / n * 1e3,
+            "vs_headline": (n / wall / headline_fps) if headline_fps else None,
+            "phase_ms_per_frame": {k: td.get(k, 0.0) / n * 1e3 for k in names},
+            "phase_note": "device stages: time between events on the frame's "
+                          "stream (frames overlap: the sum exceeds "
+                          "ms_per_frame); host stages: wall time in their "
+                          "thread",
+            "per_frame": {k: v / max(1, n - 1) for k, v in pipe.stats.items()},
+            "sequential_fallbacks": pipe.fallbacks,
+            "sequential_loop": {
+                "frames_per_sec": 2 * n_files / seq_wall,
+                "ms_per_frame": seq_wall / (2 * n_files) * 1e3,
+                "phase_ms_per_frame": {
+                    k: seq_td.get(k, 0.0) / (2 * n_files) * 1e3
+                    for k in names}},
+        }
+        return res
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
+# added to the background logit's bias of the synthetic weights in the
+# files-to-files loop (secondary_e2e): ~2 % of the vertices then pass
+# run.py:266-290's prob > 1/nc test, a trained model's rate
+E2E_BACKGROUND_BIAS = 0.6
+
+
 def secondary_train(args, torch, dev):
     """BASELINE config 4 on one GPU (`car_auto_T3` training step, 2 frames per
     step, training graph kwargs): >= 10 timed steps and the whole-step MFMA
@@ -1488,6 +1581,10 @@ def main(argv=None):
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
+        return
+    if args.e2e:
+        print(json.dumps({"secondary_e2e": secondary_e2e(
+            args, torch, dev, background_bias=args.e2e_bias)}), flush=True)
         return
 
     cfg = configs.get_config(args.config)
@@ -1600,11 +1697,13 @@ def main(argv=None):
     # BASELINE configs 5 and 4 in the same line (single-GPU runs of the
     # headline command only; `--config ped_cyl_auto_T3` / `--train` are the
     # full-length forms): the ped_cyl dense-scan stress and the training step
-    ped = trn = None
+    ped = trn = e2e = None
     if world == 1 and not args.no_secondary and args.preset == "car_600k" \
             and args.config == "car_auto_T3":
         ped = secondary_ped(args, torch, dev, measure)
         trn = secondary_train(args, torch, dev)
+        e2e = secondary_e2e(args, torch, dev,
+                            headline_fps=args.steps * fps_h / elapsed)
 
     # SECONDARY arithmetics (not the headline, whose dtype is f32): the same
     # frames with the per-edge product on the matrix pipe's 16-bit formats --
@@ -1868,6 +1967,8 @@ def main(argv=None):
             res["config"]["secondary_ped"] = ped
         if trn is not None:
             res["config"]["secondary_train"] = trn
+        if e2e is not None:
+            res["config"]["secondary_e2e"] = e2e
         if not args.no_roofline:
             width = cfg['model_kwargs']['layer_configs'][1]['kwargs'][
                 'edge_MLP_depth_list'][-1] if len(

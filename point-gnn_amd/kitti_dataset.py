@@ -73,8 +73,42 @@ def png_size(path):
     return int(height), int(width)
 
 
+def _stage_upload(arr, dev):
+    """Host float32 array -> device tensor through pinned memory (an
+    asynchronous copy-engine transfer instead of the runtime's pageable
+    staging path).  The block comes from torch's caching host allocator, which
+    hands it out again only after the copy has run."""
+    import torch
+    host = torch.empty(int(arr.size), dtype=torch.float32, pin_memory=True)
+    host.numpy()[:] = arr.reshape(-1)
+    return host.to(dev, non_blocking=True)
+
+
+class PendingPoints(object):
+    """cam_points_in_image(..., deferred=True): the crop is enqueued, the
+    number of points inside the image is on its way to pinned memory, nothing
+    has been waited for.  `event` orders a consumer stream behind the crop;
+    result() waits for the count (not for the device) and returns Points --
+    call it with the consuming stream current and after
+    `stream.wait_event(pending.event)`."""
+
+    def __init__(self, xyz, attr, count_host, event, pad_rgb):
+        self.xyz, self.attr, self.count_host = xyz, attr, count_host
+        self.event, self.pad_rgb = event, pad_rgb
+
+    def result(self):
+        import torch
+        self.event.synchronize()
+        m = int(self.count_host[0])
+        xyz, attr = self.xyz[:m], self.attr[:m]
+        if self.pad_rgb:
+            zeros = torch.zeros((m, 3), dtype=torch.float32, device=attr.device)
+            attr = torch.cat([attr, zeros], dim=1)
+        return Points(xyz=xyz, attr=attr)
+
+
 def cam_points_in_image(velo_data, calib, image_shape, image=None,
-                        with_rgb=False):
+                        with_rgb=False, deferred=False):
     """velo_data [n,4] float32 (x,y,z,reflectance; NumPy or CUDA tensor) ->
     Points(xyz [m,3], attr [m,1] or [m,4]) as CUDA tensors:
     kitti_dataset.py:666-689 (`get_cam_points_in_image`) / :691-716 (`..._with_
@@ -85,7 +119,11 @@ def cam_points_in_image(velo_data, calib, image_shape, image=None,
     dev = velo_data.device if isinstance(velo_data, torch.Tensor) and \
         velo_data.is_cuda else torch.device("cuda",
                                             torch.cuda.current_device())
-    v = torch.as_tensor(velo_data).to(device=dev, dtype=torch.float32)
+    if isinstance(velo_data, np.ndarray) and velo_data.dtype == np.float32 \
+            and velo_data.flags.c_contiguous and velo_data.size:
+        v = _stage_upload(velo_data, dev)
+    else:
+        v = torch.as_tensor(velo_data).to(device=dev, dtype=torch.float32)
     v = v.reshape(-1, 4).contiguous()
     n = int(v.shape[0])
     height, width = int(image_shape[0]), int(image_shape[1])
@@ -115,6 +153,12 @@ def cam_points_in_image(velo_data, calib, image_shape, image=None,
             _lib.ptr(ws), ws_bytes, _lib.ptr(out_xyz), _lib.ptr(out_attr),
             attr_dim, n, _lib.ptr(count), _lib.stream_ptr()),
             "pgnn_kitti_cam_points_in_image")
+        if deferred:
+            count_host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+            count_host.copy_(count, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            return PendingPoints(out_xyz, out_attr, count_host, ev, False)
         m = int(count.item())
     return Points(xyz=out_xyz[:m], attr=out_attr[:m])
 
@@ -186,28 +230,38 @@ class KittiDataset(object):
     def get_cam_points_in_image_with_rgb(self, frame_idx,
                                          downsample_voxel_size=None,
                                          calib=None, xyz_range=None,
-                                         image=None):
+                                         image=None, deferred=False):
         """With `image` (decoded BGR array) the attributes are
         [reflectance, r, g, b]; without one (PNG decoding is not part of this
         package) the colour channels are zero -- enough for the 'i' / 'i000' /
-        '0' input features of the shipped configs (run.py:226-241)."""
+        '0' input features of the shipped configs (run.py:226-241).
+        deferred (extension): enqueue only and return a PendingPoints."""
         if downsample_voxel_size is not None:
             raise NotImplementedError(
                 "downsample_by_voxel_size is null in every shipped config")
         if calib is None:
             calib = self.get_calib(frame_idx)
-        pts = self.get_velo_points(frame_idx, xyz_range=xyz_range)
-        velo = np.concatenate([pts.xyz, pts.attr], axis=1)
+        if xyz_range is None:
+            # the file's [n,4] rows as they are (no split + re-join)
+            velo = np.fromfile(os.path.join(
+                self._point_dir, self._file_list[frame_idx]) + '.bin',
+                dtype=np.float32).reshape(-1, 4)
+        else:
+            pts = self.get_velo_points(frame_idx, xyz_range=xyz_range)
+            velo = np.concatenate([pts.xyz, pts.attr], axis=1)
         shape = image.shape[:2] if image is not None \
             else self._image_shape(frame_idx)
         if image is None:
             import torch
-            p = cam_points_in_image(velo, calib, shape)
+            p = cam_points_in_image(velo, calib, shape, deferred=deferred)
+            if deferred:
+                p.pad_rgb = True
+                return p
             zeros = torch.zeros((p.attr.shape[0], 3), dtype=torch.float32,
                                 device=p.attr.device)
             return Points(xyz=p.xyz, attr=torch.cat([p.attr, zeros], dim=1))
         return cam_points_in_image(velo, calib, shape, image=image,
-                                   with_rgb=True)
+                                   with_rgb=True, deferred=deferred)
 
     # ---- labels and training targets (kitti_dataset.py:703-751, 1132-1284)
     def get_label(self, frame_idx, no_orientation=False):

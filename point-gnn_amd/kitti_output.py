@@ -49,12 +49,14 @@ def box_corners_in_image(box, calib):
     return (img / img[:, [2]])[:, :2]
 
 
-def occlusion(label, xyz):
+def occlusion(label, xyz, _nlu=None):
     """run.py:88-99: product over the three box axes of the fraction of the
-    box extent covered by the points inside it."""
+    box extent covered by the points inside it.  (_nlu: the label's
+    box3d_to_normals when the caller has it already.)"""
     if xyz.shape[0] == 0:
         return 0
-    normals, lower, upper = kitti_dataset.box3d_to_normals(label)
+    normals, lower, upper = _nlu if _nlu is not None else \
+        kitti_dataset.box3d_to_normals(label)
     projected = np.matmul(xyz, np.transpose(normals))
     rate = 1.0
     for k in range(3):
@@ -63,14 +65,18 @@ def occlusion(label, xyz):
     return rate
 
 
-def inside_box_host(label, xyz):
+def inside_box_host(label, xyz, _nlu=None, _xyz64=None):
     """kitti_dataset.sel_xyz_in_box3d on the HOST, bit for bit what the
     device kernel computes (csrc/labels.hip assign_labels_kernel: float32
     points widened, p = (x n0 + y n1) + z n2 in float64 without contraction,
     strictly inside): the frame loop with frames in flight has the candidates
-    on the host already and must not go back to the device once per box."""
-    normals, lower, upper = kitti_dataset.box3d_to_normals(label)
-    x, y, z = (xyz[:, i].astype(np.float64) for i in range(3))
+    on the host already and must not go back to the device once per box.
+    (_nlu / _xyz64: the label's box3d_to_normals / the widened columns when
+    the caller has them already.)"""
+    normals, lower, upper = _nlu if _nlu is not None else \
+        kitti_dataset.box3d_to_normals(label)
+    x, y, z = _xyz64 if _xyz64 is not None else \
+        tuple(xyz[:, i].astype(np.float64) for i in range(3))
     inside = np.ones(xyz.shape[0], bool)
     for k in range(3):
         p = (x * normals[k, 0] + y * normals[k, 1]) + z * normals[k, 2]
@@ -94,10 +100,12 @@ def detections_to_kitti_labels(class_labels, detection_boxes_3d, box_probs,
     names = CLASS_NAMES[label_method]
     width, height = float(image_size[0]), float(image_size[1])
     cand_dev = None
+    xyz64 = None
     if use_box_score and host_only:
         if candidate_xyz is None:
             raise ValueError("use_box_score needs candidate_xyz")
         cand_host = np.asarray(candidate_xyz)
+        xyz64 = tuple(cand_host[:, i].astype(np.float64) for i in range(3))
     elif use_box_score:
         if candidate_xyz is None:
             raise ValueError("use_box_score needs candidate_xyz")
@@ -124,9 +132,11 @@ def detections_to_kitti_labels(class_labels, detection_boxes_3d, box_probs,
         if use_box_score:
             tmp = {"x3d": x3d, "y3d": y3d, "z3d": z3d, "yaw": yaw,
                    "height": h, "width": w, "length": l}
-            inside = inside_box_host(tmp, cand_host) if host_only else \
+            nlu = kitti_dataset.box3d_to_normals(tmp)
+            inside = inside_box_host(tmp, cand_host, nlu, xyz64) \
+                if host_only else \
                 _host(kitti_dataset.sel_xyz_in_box3d(tmp, cand_dev))
-            score = (1 + occlusion(tmp, cand_host[inside])) * score
+            score = (1 + occlusion(tmp, cand_host[inside], nlu)) * score
         out.append((names[int(labels[i])], -1, -1, 0, clip_xmin, clip_ymin,
                     clip_xmax, clip_ymax, h, w, l, x3d, y3d, z3d, yaw, score))
     return out

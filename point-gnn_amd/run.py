@@ -187,10 +187,11 @@ class FramePipeline(object):
     """run.py's frame loop with frames in flight (see run_dataset).
 
     Per frame, in order, and who waits for what:
-      loader thread   files -> upload -> crop kernel -> ONE read (points in
-                      the image: it sizes everything after it) on the loader's
-                      own stream, `prefetch` frames ahead;
-      stage A         (main thread, stream i % in_flight) graph build in
+      loader thread   files -> upload -> crop kernel on the loader's own
+                      stream, `prefetch` frames ahead, the crop's point count
+                      on its way to pinned memory (no wait);
+      stage A         (main thread, stream i % in_flight) read the point count
+                      (it sizes every launch after it), graph build in
                       capacity form, GNN, softmax, candidate selection bounded
                       by the device-side K; the frame's count record + the
                       candidate count go to pinned memory;
@@ -217,6 +218,8 @@ class FramePipeline(object):
         self.label_map = kitti_output.LABEL_MAPS[config['label_method']]
         self.hints = None
         self.fallbacks = 0
+        # per-run totals: candidates that entered the NMS, boxes it kept
+        self.stats = {'candidates': 0, 'kept': 0, 'rows': 0}
 
     def _add(self, key, seconds):
         self.td[key] = self.td.get(key, 0.0) + seconds
@@ -230,11 +233,9 @@ class FramePipeline(object):
             calib = self.dataset.get_calib(frame_idx)
             points = self.dataset.get_cam_points_in_image_with_rgb(
                 frame_idx, self.config['downsample_by_voxel_size'],
-                calib=calib, image=image)
-            ev = torch.cuda.Event()
-            ev.record(stream)
+                calib=calib, image=image, deferred=True)
         f = _Frame()
-        f.idx, f.points, f.calib, f.ev = frame_idx, points, calib, ev
+        f.idx, f.points, f.calib, f.ev = frame_idx, points, calib, points.event
         f.rerun = False
         f.t_fetch = time.time() - t0
         return f
@@ -247,6 +248,9 @@ class FramePipeline(object):
         with torch.cuda.stream(stream):
             f.points.xyz.record_stream(stream)
             f.points.attr.record_stream(stream)
+            # the frame's one early read: how many points the crop kept (it
+            # sizes every launch after it); enqueued `prefetch` frames ago
+            f.points = f.points.result()
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
             ev[0].record()
             graph = graph_gen.gen_multi_level_local_graph_v3(
@@ -342,9 +346,11 @@ class FramePipeline(object):
         self._add('decode box + nms', f.ev[0].elapsed_time(f.ev[1]) * 1e-3)
         self._add('fetch input', f.t_fetch)
         n = f.n_cand
+        self.stats['candidates'] += n
         if n > 0:
             h = f.host_b.numpy()
             kept = int(h[:1].view('int32')[0])
+            self.stats['kept'] += kept
             res = (h[1:1 + n].view('int32')[:kept].copy(),
                    h[1 + n:1 + 8 * n].reshape(n, 7)[:kept].copy(),
                    h[1 + 8 * n:1 + 9 * n][:kept].copy(),
@@ -469,5 +475,6 @@ class FramePipeline(object):
         for n_rows, t_rows, t_txt in written:
             self._add('kitti rows', t_rows)
             self._add('write txt', t_txt)
+            self.stats['rows'] += n_rows
         self.td['sequential fallbacks'] = self.fallbacks
         return 1 + len(rest)
