@@ -1495,9 +1495,9 @@ def secondary_e2e(args, torch, dev, headline_fps=None, n_files=8, passes=20,
 
 
 # added to the background logit's bias of the synthetic weights in the
-# files-to-files loop (secondary_e2e): ~2 % of the vertices then pass
+# files-to-files loop (secondary_e2e): ~3 % of the vertices (~190 candidates, ~14 kept boxes, ~10 rows per frame) then pass
 # run.py:266-290's prob > 1/nc test, a trained model's rate
-E2E_BACKGROUND_BIAS = 0.6
+E2E_BACKGROUND_BIAS = 2.0
 
 
 def secondary_train(args, torch, dev):
