@@ -155,6 +155,94 @@ def live_pmc_scatter(preset, timeout_s=150):
     }
 
 
+def live_kernel_trace(config, preset, edge_arith="f32", steps=8, warmup=2,
+                      timeout_s=240):
+    """Average kernel durations of ONE frame alone, measured in THIS run by a
+    child `rocprofv3 --kernel-trace` of `bench.py --frames 1 --no-pipeline`
+    (seed 0 of `preset`, frames strictly one after the other: the command
+    behind profiles/*_infer_seed0_kernel_stats).  Returns {short kernel name:
+    {"avg_us", "calls", "total_us"}} plus "_command", or None (rocprofv3
+    missing / failed / timed out)."""
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import pmc_scatter_json as pj
+    finally:
+        sys.path.pop(0)
+    tmp = tempfile.mkdtemp(prefix="pgnn_trace_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", config,
+           "--preset", preset, "--edge-arith", edge_arith, "--steps",
+           str(steps), "--warmup", str(warmup), "--frames", "1",
+           "--frames-per-step", "1", "--repeats", "1", "--no-pipeline",
+           "--no-cpu-baseline", "--no-secondary", "--no-live-pmc",
+           "--no-roofline", "--no-capture"]
+    try:
+        p = subprocess.run([rocprof, "--kernel-trace", "-d", tmp, "-o", "run",
+                            "--"] + cmd, cwd="/tmp", env=env,
+                           capture_output=True, text=True, timeout=timeout_s)
+        db = None
+        for root, _, files in os.walk(tmp):
+            for f in files:
+                if f.endswith(".db"):
+                    db = os.path.join(root, f)
+        if p.returncode != 0 or db is None:
+            return None
+        con = sqlite3.connect(db)
+        cols = [c[1] for c in con.execute("pragma table_info(kernels)")]
+        c_name = "name" if "name" in cols else "kernel_name"
+        c_s = "start" if "start" in cols else "start_time"
+        c_e = "end" if "end" in cols else "end_time"
+        out = {}
+        for name, avg, n, tot in con.execute(
+                "select %s, avg(%s - %s), count(*), sum(%s - %s) from kernels "
+                "group by %s" % (c_name, c_e, c_s, c_e, c_s, c_name)):
+            out[pj.short_kernel_name(name)] = {
+                "avg_us": avg / 1e3, "calls": int(n), "total_us": tot / 1e3}
+        out["_command"] = "rocprofv3 --kernel-trace -- python bench.py " + \
+            " ".join(cmd[2:])
+        return out
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def apply_kernel_trace(line, trace, prefix):
+    """`line` (a roofline dict timed by HIP events) re-priced with the child
+    pass's average duration of the kernel whose short name starts with
+    `prefix`: avg_launch_us / achieved / frac follow rocprofv3 (what profiles/
+    holds), the event figures stay beside them."""
+    if line is None or not trace:
+        return line
+    hits = [(k, v) for k, v in trace.items()
+            if k.startswith(prefix) and isinstance(v, dict)]
+    if not hits:
+        return line
+    name, v = max(hits, key=lambda kv: kv[1]["total_us"])
+    ev_us = line["avg_launch_us"]
+    work = line["achieved"] * ev_us          # TFLOP/s x us
+    line["avg_launch_us_events"] = ev_us
+    line["frac_events"] = line["frac"]
+    line["avg_launch_us"] = v["avg_us"]
+    line["achieved"] = work / v["avg_us"]
+    line["frac"] = line["achieved"] / line["peak"]
+    line["duration_source"] = {
+        "kernel": name, "launches_averaged": v["calls"],
+        "method": "average kernel duration in a rocprofv3 --kernel-trace "
+                  "child pass of this bench.py invocation (" +
+                  trace.get("_command", "") + "); avg_launch_us_events / "
+                  "frac_events: one HIP-event pair round 10 back-to-back "
+                  "launches on the launch stream"}
+    return line
+
+
 def live_pmc_train_mfma_ops(config, preset, fpg, frames=8, steps=6, warmup=2,
                             timeout_s=240):
     """fp32-MFMA work of ONE training step measured in this run: a child
@@ -1981,14 +2069,40 @@ def main(argv=None):
                                                    live_pmc=live)
             res["roofline"]["workload"] = {
                 "frame_seed": first, "E": n_e1, "C": width, "K": n_k}
+            trace = None
+            if world == 1 and not args.no_live_pmc:
+                torch.cuda.synchronize()
+                trace = live_kernel_trace(args.config, args.preset,
+                                          args.edge_arith)
             mf = roofline_edge_kernel(torch, engine, edges[1], n_k,
                                       frame=(x, f))
             if mf is not None:
                 mf["workload"] = {"frame_seed": first, "E": n_e1, "K": n_k}
-                res["roofline_mfma"] = mf
+                res["roofline_mfma"] = apply_kernel_trace(mf, trace,
+                                                          "edge_ws_kernel")
             pl = roofline_pool_kernel(torch, engine, frame=(x, f))
             if pl is not None:
-                res["roofline_pool"] = pl
+                res["roofline_pool"] = apply_kernel_trace(
+                    pl, trace, "pool_ws_kernel")
+            if trace:
+                # one frame alone, per kernel family (us per frame)
+                per_frame = {}
+                n_gnn = sum(l['type'] == 'scatter_max_graph_auto_center_net'
+                            for l in cfg['model_kwargs']['layer_configs'])
+                n_tr = sum(v["calls"] for k, v in trace.items()
+                           if isinstance(v, dict) and
+                           k.startswith("edge_ws_kernel")) / max(1, n_gnn)
+                n_tr = n_tr or 10.0
+                for k, v in trace.items():
+                    if isinstance(v, dict):
+                        fam = k.split("<")[0]
+                        per_frame[fam] = per_frame.get(fam, 0.0) + \
+                            v["total_us"] / n_tr
+                top = sorted(per_frame.items(), key=lambda kv: -kv[1])[:14]
+                res["config"]["kernel_us_per_frame_seed%d" % first] = {
+                    "source": trace["_command"] + " (%g frames)" % n_tr,
+                    "total": sum(per_frame.values()),
+                    "top": {k: round(v, 1) for k, v in top}}
             res["roofline_graph"] = roofline_graph(torch, cfg, coords)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, params, xyz_np, inten_np,

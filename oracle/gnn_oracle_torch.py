@@ -3,7 +3,11 @@ oracle/gnn_oracle.py (models/gnn.py:222-283, 298-373, 133-163;
 models/models.py:79-163), written for SPEED on the host: torch-CPU, every
 per-edge stage evaluated in row chunks that stay in the last-level cache
 (gather -> GEMM chain -> segment max per chunk; nothing of size E x C is ever
-materialised), all cores through torch's intra-op threads.
+materialised).  Two ways to use the cores: torch's intra-op threads inside
+every op (WORKERS = 0), or -- what scales on a many-core host -- WORKERS
+Python threads that each take whole chunks through gather -> GEMM chain ->
+segment max with single-threaded ops (torch releases the GIL inside an op; the
+chunks are independent up to the final maximum(), which is taken under a lock).
 
 Only `bench.py`'s `cpu_baseline` leg times it (the "CPU port of the reference
 path" of the bench contract: the NumPy oracle spends its time in concatenate /
@@ -17,6 +21,26 @@ import numpy as np
 import torch
 
 CHUNK_ROWS = 1 << 15
+WORKERS = 0          # > 0: chunk-parallel worker threads (see module docstring)
+_POOL = {}
+
+
+def _pool(n):
+    from concurrent.futures import ThreadPoolExecutor
+    p = _POOL.get(n)
+    if p is None:
+        p = _POOL[n] = ThreadPoolExecutor(max_workers=n)
+    return p
+
+
+def _map_chunks(fn, n_rows):
+    """fn(lo, hi) over row chunks: in order on this thread, or on WORKERS
+    threads."""
+    spans = [(lo, min(n_rows, lo + CHUNK_ROWS))
+             for lo in range(0, n_rows, CHUNK_ROWS)]
+    if WORKERS > 0 and len(spans) > 1:
+        return list(_pool(WORKERS).map(lambda s: fn(*s), spans))
+    return [fn(lo, hi) for lo, hi in spans]
 
 
 def _layers(params, scope):
@@ -46,17 +70,30 @@ def _mlp(x, layers, is_logits):
 def _edge_mlp_segment_max(gather, layers, dst, num_segments):
     """max over the runs of equal dst of MLP(gather(rows)), chunk by chunk.
     dst ascending; a run cut by a chunk boundary is merged with maximum()."""
+    import threading
     lowest = float(np.finfo(np.float32).min)
     width = layers[-1][0].shape[1]
     out = torch.full((num_segments, width), lowest, dtype=torch.float32)
     n = int(dst.shape[0])
-    for lo in range(0, n, CHUNK_ROWS):
-        hi = min(n, lo + CHUNK_ROWS)
+    lock = threading.Lock()
+
+    def chunk(lo, hi):
         rows = _mlp(gather(lo, hi), layers, is_logits=False)
         seg, counts = torch.unique_consecutive(dst[lo:hi], return_counts=True)
         red = torch.segment_reduce(rows, 'max', lengths=counts)
-        out[seg] = torch.maximum(out[seg], red)
+        with lock:   # a run cut by a chunk boundary meets its other half here
+            out[seg] = torch.maximum(out[seg], red)
+    _map_chunks(chunk, n)
     return out
+
+
+def _mlp_rows(x, layers, is_logits):
+    """_mlp over row chunks (the per-vertex stages on the worker threads)."""
+    if WORKERS <= 0 or x.shape[0] <= CHUNK_ROWS:
+        return _mlp(x, layers, is_logits)
+    parts = _map_chunks(lambda lo, hi: _mlp(x[lo:hi], layers, is_logits),
+                        int(x.shape[0]))
+    return torch.cat(parts, dim=0)
 
 
 def predict(params, config, initial_vertex_features, vertex_coord_list,
@@ -87,13 +124,15 @@ def predict(params, config, initial_vertex_features, vertex_coord_list,
                 agg = _edge_mlp_segment_max(
                     gather, _layers(params, scope + '/extract_vertex_features'),
                     dst, int(kp.shape[0]))
-                feats = _mlp(agg, _layers(params, scope + '/combined_features'),
-                             is_logits=False)
+                feats = _mlp_rows(agg, _layers(params,
+                                               scope + '/combined_features'),
+                                  is_logits=False)
             elif lc['type'] == 'scatter_max_graph_auto_center_net':
                 h, x = feats, coords[lvl]
                 x_dst = x
                 if lc['kwargs']['auto_offset']:
-                    x_dst = x + _mlp(h, _layers(params, scope), is_logits=True)
+                    x_dst = x + _mlp_rows(h, _layers(params, scope),
+                                          is_logits=True)
 
                 def gather(lo, hi, h=h, x=x, x_dst=x_dst, src=src, dst=dst):
                     s = src[lo:hi]
@@ -101,8 +140,9 @@ def predict(params, config, initial_vertex_features, vertex_coord_list,
                 agg = _edge_mlp_segment_max(
                     gather, _layers(params, scope + '/extract_vertex_features'),
                     dst, int(h.shape[0]))
-                feats = _mlp(agg, _layers(params, scope + '/combined_features'),
-                             is_logits=True) + h
+                feats = _mlp_rows(agg, _layers(params,
+                                               scope + '/combined_features'),
+                                  is_logits=True) + h
             else:
                 raise NotImplementedError(lc['type'])
         pc_ = layer_configs[-1]

@@ -444,11 +444,14 @@ def test_torch_cpu_port_equals_the_numpy_oracle():
     coords = [g["xyz"], g["kp_xyz"], g["kp_xyz"]]
     kps = [g["kp_idx"], np.arange(k, dtype=np.int32).reshape(-1, 1)]
     edges = [g["ref_edges0"], g["ref_edges1"]]
-    old = gt.CHUNK_ROWS
+    old = gt.CHUNK_ROWS, gt.WORKERS
     try:
-        for name, chunk in (("car_auto_T3", 1 << 15), ("car_auto_T2", 257),
-                            ("ped_cyl_auto_T3", 1000)):
+        for name, chunk, workers in (("car_auto_T3", 1 << 15, 0),
+                                     ("car_auto_T2", 257, 0),
+                                     ("car_auto_T3", 129, 4),
+                                     ("ped_cyl_auto_T3", 1000, 3)):
             gt.CHUNK_ROWS = chunk      # runs cut by chunk boundaries too
+            gt.WORKERS = workers       # ... and chunks on worker threads
             cfg = configs.get_config(name)
             params = weights.init_params(cfg, seed=5, bias_scale=0.05)
             l0, b0 = gn.predict(params, cfg, g["intensity"], coords, kps, edges)
@@ -456,4 +459,4 @@ def test_torch_cpu_port_equals_the_numpy_oracle():
             np.testing.assert_allclose(l1, l0, atol=2e-5, rtol=0)
             np.testing.assert_allclose(b1, b0, atol=2e-5, rtol=0)
     finally:
-        gt.CHUNK_ROWS = old
+        gt.CHUNK_ROWS, gt.WORKERS = old
