@@ -659,13 +659,17 @@ def cpu_baseline(cfg, params, xyz, inten, budget_s=20.0):
     sub_coords = [coords[0], coords[1][:k_sub], coords[2][:k_sub]]
     sub_kps = [kps[0][:k_sub], kps[1][:k_sub]]
     sub_edges = [e0[m0], e1[m1]]
-    # torch's CPU kernels stop scaling long before this host's core count
-    # (car_600k frame on 256 hardware threads: 15 s at 128 intra-op threads,
-    # 6.8 at 64, 4.4 at 32, 5.0 at 16; inside a NUMA-bound rank the default
-    # oversubscribes the allowed CPUs): 32 threads, 128k-row chunks
+    # torch's intra-op threading stops scaling long before this host's core
+    # count (car_600k frame, 256 hardware threads: 178 GFLOP/s at 32 intra-op
+    # threads, 147 at 64 = 5-6 % of the sgemm probe): the port runs
+    # chunk-parallel instead -- one worker thread per CPU the rank's affinity
+    # mask allows, single-threaded ops, 2048-row chunks -- which reaches
+    # 1.1-1.3 TFLOP/s = 0.39-0.48 of the probe, flat from 16 to 256 workers
+    # (the ceiling: profiles/r06_cpu_baseline_sweep.txt)
     n_thr = _torch.get_num_threads()
-    _torch.set_num_threads(min(32, len(os.sched_getaffinity(0))))
-    gn.CHUNK_ROWS = 1 << 17
+    allowed = len(os.sched_getaffinity(0))
+    _torch.set_num_threads(1)
+    gn.CHUNK_ROWS, gn.WORKERS = 2048, min(256, allowed)
     try:
         gn.predict(params, cfg, inten, sub_coords, sub_kps, sub_edges)  # warm-up
         t_gnns = []
@@ -673,9 +677,10 @@ def cpu_baseline(cfg, params, xyz, inten, budget_s=20.0):
             t = time.perf_counter()
             gn.predict(params, cfg, inten, sub_coords, sub_kps, sub_edges)
             t_gnns.append(time.perf_counter() - t)
-        threads = int(_torch.get_num_threads())
+        threads = int(gn.WORKERS)
     finally:
         _torch.set_num_threads(n_thr)
+        gn.WORKERS = 0
     t_gnn_sub = float(np.median(t_gnns))
     sub_flops = algorithmic_flops_per_frame(cfg, k_sub, int(m0.sum()),
                                             int(m1.sum()))
@@ -686,8 +691,9 @@ def cpu_baseline(cfg, params, xyz, inten, budget_s=20.0):
         "sample": "1 frame (%s seed of the headline pool): graph build with "
                   "the reference's sklearn calls, single-threaded as shipped, "
                   "1 warm-up + median of 5 (%.2f s; min %.2f, max %.2f); GNN "
-                  "oracle (torch-CPU fp32 in 128k-row chunks, %d intra-op "
-                  "threads; NumPy sgemm probe %.0f GFLOP/s) on "
+                  "oracle (torch-CPU fp32, 2048-row chunks on %d worker "
+                  "threads = every CPU of the rank's affinity mask; NumPy "
+                  "sgemm probe %.0f GFLOP/s) on "
                   "the sub-graph of the first %d of %d keypoints (%.1f%% of "
                   "the frame's FLOPs), 1 warm-up + median of 3 (%.2f s), "
                   "scaled to the full frame (%.1f s)"
@@ -695,6 +701,13 @@ def cpu_baseline(cfg, params, xyz, inten, budget_s=20.0):
                      gflops, k_sub, n_k, 100.0 * sub_flops / total, t_gnn_sub,
                      t_gnn_full),
         "gen_graph_s": t_graph, "gnn_inference_s_scaled": t_gnn_full,
+        # the GNN port against this host's own sgemm rate ("BLAS
+        # threads = all host cores"); the thread-count x chunk sweep behind
+        # the choice is profiles/r06_cpu_baseline_sweep.txt
+        "achieved_gflops": sub_flops / t_gnn_sub / 1e9,
+        "probe_gflops": gflops,
+        "frac_of_probe": sub_flops / t_gnn_sub / 1e9 / gflops,
+        "allowed_cpus": allowed,
     }
     out.update(host)
     return out
