@@ -880,7 +880,9 @@ int pgnn_loss_fwd_bwd_counts(const float *logits, int64_t ld_logits,
  * [num_classes]): 'classwise_loc_loss_weight' of loc_loss_kwargs, applied to a
  * vertex's Huber terms by its label.  counts2 nullable: null = the host-scale
  * form (cls_grad_scale / loc_grad_scale used), else the _counts form.
- * 'top_k_softmax' / 'top_k_huber_loss' have no device path.                  */
+ * gamma == 0 is plain CE / sigmoid CE (TF's pow(0, 0) = 1); for 0 < gamma < 1
+ * the derivative's (1 - p_t)^(gamma - 1) is evaluated at max(1 - p_t, 1e-6).
+ * 'top_k_softmax' / 'top_k_huber_loss': pgnn_loss_fwd_bwd_sel below.         */
 int pgnn_loss_fwd_bwd_ex(const float *logits, int64_t ld_logits,
                          const int32_t *labels, const float *pred_box,
                          int32_t box_len, const float *gt_box,
@@ -891,6 +893,40 @@ int pgnn_loss_fwd_bwd_ex(const float *logits, int64_t ld_logits,
                          int32_t cls_kind, float alpha, float gamma,
                          const float *class_loc_weight, double *sums4,
                          float *dlogits, float *dpred_box, void *stream);
+/* The top-k variants (models.py:222-228 'top_k_softmax', :266-291
+ * 'top_k_huber_loss') in three steps, all on the device:
+ *   1. pgnn_loss_fwd_bwd_sel with point_cls / point_loc set (no gradients):
+ *      the per-vertex classification loss and the per-vertex mean Huber loss
+ *      (valid and class weights applied) -- what the reference hands to
+ *      tf.math.top_k;
+ *   2. pgnn_topk_mask_f32: mask[i] = 1 for the k largest values (equal values:
+ *      lower index first, like tf.math.top_k), 0 elsewhere; k > n is an error
+ *      as in TF;
+ *   3. pgnn_loss_fwd_bwd_sel with select_cls / select_loc = those masks: a
+ *      vertex outside a selection adds no loss and gets no gradient;
+ *      sums4[3] counts the valid vertices INSIDE the loc selection
+ *      (models.py:283-285); cls_sum_weight scales the classification sum and
+ *      its gradient -- n / k turns the mean over n the callers divide by into
+ *      the reference's mean over the k selected values (with towers /
+ *      unify_copies, train.py:268-284: n_rank / k on every rank).
+ * Every pointer after class_loc_weight is nullable; with all of them null and
+ * cls_sum_weight 1 this is pgnn_loss_fwd_bwd_ex. */
+int pgnn_loss_fwd_bwd_sel(const float *logits, int64_t ld_logits,
+                          const int32_t *labels, const float *pred_box,
+                          int32_t box_len, const float *gt_box,
+                          const float *valid, int64_t n_vertices,
+                          int32_t num_classes, float cls_grad_scale,
+                          float loc_grad_scale, const double *counts2,
+                          double cls_loss_weight, double loc_loss_weight,
+                          int32_t cls_kind, float alpha, float gamma,
+                          const float *class_loc_weight,
+                          const float *select_cls, const float *select_loc,
+                          float cls_sum_weight, float *point_cls,
+                          float *point_loc, double *sums4, float *dlogits,
+                          float *dpred_box, void *stream);
+size_t pgnn_topk_mask_workspace_bytes(int64_t n);
+int pgnn_topk_mask_f32(const float *values, int64_t n, int64_t k, float *mask,
+                       void *workspace, size_t workspace_bytes, void *stream);
 /* params -= lr * (grad_scale*grads + l1_scale*sign(params)*is_weight)
  * (GradientDescentOptimizer + slim.l1_regularizer on FC weights only).       */
 int pgnn_sgd_step(float *params, const float *grads, const float *is_weight,

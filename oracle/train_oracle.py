@@ -165,6 +165,17 @@ def loss_terms(config, logits, pred_box, labels, gt_box, valid,
         alpha = kw.get('alpha', 0.5)
         aw = t * alpha + (1 - t) * (1 - alpha)
         ce = ((1 - pt) ** kw.get('gamma', 2) * aw * xent).mean(dim=1)
+    elif kind == 'top_k_softmax':
+        # models.py:222-228: mean of the k largest per-vertex CE values.  The
+        # callers divide the returned sum by n (and the towers re-weight by
+        # n_tower / n_total, train.py:268-284), so the k selected values are
+        # returned scaled by n / k.  Stable descending sort = tf.math.top_k's
+        # order (equal values: lower index first).
+        k = int(kw['k'])
+        order = torch.sort(ce.detach(), descending=True, stable=True)[1][:k]
+        pick = torch.zeros_like(ce)
+        pick[order] = 1.0
+        ce = ce * pick * (float(len(lab)) / k)
     elif kind != 'softmax':
         raise NotImplementedError(kind)
     pb = pred_box[torch.arange(len(lab)), lab]
@@ -178,6 +189,15 @@ def loss_terms(config, logits, pred_box, labels, gt_box, valid,
                              dtype=dtype)
         hub = hub * cw[lab][:, None]
     loc = hub.mean(dim=1)
+    if config['loss'].get('loc_loss_type', 'huber_loss') == 'top_k_huber_loss':
+        # models.py:266-291: the k largest per-vertex means; num_valid_endpoint
+        # counts the valid vertices among them
+        k = int(lkw['k'])
+        order = torch.sort(loc.detach(), descending=True, stable=True)[1][:k]
+        pick = torch.zeros_like(loc)
+        pick[order] = 1.0
+        return (ce.sum(), (loc * pick).sum(), float(len(lab)),
+                float((va * pick).sum()))
     return ce.sum(), loc.sum(), float(len(lab)), float(va.sum())
 
 

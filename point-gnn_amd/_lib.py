@@ -331,6 +331,15 @@ _SIGNATURES = {
                                      ctypes.c_double, c_i32, ctypes.c_float,
                                      ctypes.c_float, c_vp, c_vp, c_vp, c_vp,
                                      c_vp]),
+    "pgnn_loss_fwd_bwd_sel": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i32, c_vp,
+                                      c_vp, c_i64, c_i32, ctypes.c_float,
+                                      ctypes.c_float, c_vp, ctypes.c_double,
+                                      ctypes.c_double, c_i32, ctypes.c_float,
+                                      ctypes.c_float, c_vp, c_vp, c_vp,
+                                      ctypes.c_float, c_vp, c_vp, c_vp, c_vp,
+                                      c_vp, c_vp]),
+    "pgnn_topk_mask_workspace_bytes": (c_sz, [c_i64]),
+    "pgnn_topk_mask_f32": (c_i32, [c_vp, c_i64, c_i64, c_vp, c_vp, c_sz, c_vp]),
     "pgnn_sgd_step": (c_i32, [c_vp, c_vp, c_vp, c_i64, ctypes.c_float,
                               ctypes.c_float, ctypes.c_float, c_vp]),
     "pgnn_optimizer_step": (c_i32, [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64] +

@@ -12,6 +12,7 @@
 //   softmax-CE + Huber                           loss_fwd_bwd   (models.py:170-311)
 //   w -= lr (g + l1 sign(w))                     sgd_step       (train.py:375-405)
 #include "mlp_engine.h"
+#include "sort.h"
 
 namespace {
 using namespace pgnn;
@@ -1104,6 +1105,21 @@ __global__ __launch_bounds__(64 * G) void weight_grad_reduce_kernel(
 // Per vertex: ce = logsumexp(z) - z[label]; loc = mean_7 huber(pred[label] - gt)
 // * valid.  sums[0] += ce, sums[1] += loc, sums[2] += 1, sums[3] += valid.
 // Gradients of (cls_scale * sum ce + loc_scale * sum loc) are written out.
+// (1 - p_t)^gamma and its derivative gamma (1 - p_t)^(gamma - 1) at om = 1 - p_t
+// >= 0.  TF's pow(0, 0) is 1: gamma == 0 turns the focal losses into plain CE /
+// sigmoid CE (factor 1, derivative 0).  For 0 < gamma < 1 the derivative is
+// unbounded as om -> 0; om is held at 1e-6 there (a vertex classified that
+// surely carries no loss either way).
+__device__ __forceinline__ float focal_mod(float om, float gamma) {
+  if (gamma == 0.0f) return 1.0f;
+  return om > 0.0f ? powf(om, gamma) : 0.0f;
+}
+__device__ __forceinline__ float focal_dmod(float om, float gamma) {
+  if (gamma == 0.0f) return 0.0f;
+  if (gamma < 1.0f) return gamma * powf(fmaxf(om, 1e-6f), gamma - 1.0f);
+  return om > 0.0f ? gamma * powf(om, gamma - 1.0f) : 0.0f;
+}
+
 __global__ void loss_kernel(const float *__restrict__ logits, int64_t ldl,
                             const int32_t *__restrict__ labels,
                             const float *__restrict__ pred, int box_len,
@@ -1115,13 +1131,17 @@ __global__ void loss_kernel(const float *__restrict__ logits, int64_t ldl,
                             float *__restrict__ dpred,
                             const double *__restrict__ counts, double cls_w,
                             double loc_w, int cls_kind, float alpha, float gamma,
-                            const float *__restrict__ class_loc_w) {
+                            const float *__restrict__ class_loc_w,
+                            const float *__restrict__ sel_cls,
+                            const float *__restrict__ sel_loc, float ce_weight,
+                            float *__restrict__ point_cls,
+                            float *__restrict__ point_loc) {
   if (counts) {
     // the GLOBAL endpoint counts are on the device (all-reduced there): the
     // scales are formed here as the host form does (double quotient of the
     // loss weight and the count, rounded to float once)
     const double nt = counts[0], nv = counts[1];
-    cls_scale = nt > 0.0 ? (float)(cls_w / nt) : 0.0f;
+    cls_scale = nt > 0.0 ? (float)(cls_w * (double)ce_weight / nt) : 0.0f;
     loc_scale = nv > 0.0 ? (float)(loc_w / nv) : 0.0f;  // div_no_nan
   }
   double s_ce = 0.0, s_loc = 0.0, s_n = 0.0, s_v = 0.0;
@@ -1134,23 +1154,30 @@ __global__ void loss_kernel(const float *__restrict__ logits, int64_t ldl,
     float se = 0.0f;
     for (int c = 0; c < nc; ++c) se += expf(z[c] - zmax);
     const float lse = logf(se) + zmax;
+    // top-k selections (models.py:222-228, 266-291): a vertex outside the
+    // selection contributes nothing -- no loss, no gradient
+    const float pick_c = sel_cls ? sel_cls[v] : 1.0f;
+    const float pick_l = sel_loc ? sel_loc[v] : 1.0f;
     if (cls_kind == 0) {
-      s_ce += (double)(lse - z[lab]);
+      const float ce = lse - z[lab];
+      if (point_cls) point_cls[v] = ce;
+      s_ce += (double)(pick_c * ce_weight * ce);
       if (dlogits)
         for (int c = 0; c < nc; ++c)
-          dlogits[v * nc + c] =
-              cls_scale * (expf(z[c] - lse) - (c == lab ? 1.0f : 0.0f));
+          dlogits[v * nc + c] = pick_c * cls_scale *
+              (expf(z[c] - lse) - (c == lab ? 1.0f : 0.0f));
     } else if (cls_kind == 1) {
       // focal_loss_softmax (models/loss.py:31-48): L = (1 - p_y)^gamma * CE
       const float ce = lse - z[lab];
       const float py = expf(z[lab] - lse);
       const float om = fmaxf(1.0f - py, 0.0f);
-      const float mod = om > 0.0f ? powf(om, gamma) : 0.0f;
+      const float mod = focal_mod(om, gamma);
       s_ce += (double)(mod * ce);
+      if (point_cls) point_cls[v] = mod * ce;
       if (dlogits) {
         // dL/dp_y = -gamma (1-p_y)^(gamma-1) CE - (1-p_y)^gamma / p_y;
         // dp_y/dz_c = p_y ([c == y] - p_c)
-        const float dm = om > 0.0f ? gamma * powf(om, gamma - 1.0f) : 0.0f;
+        const float dm = focal_dmod(om, gamma);
         const float a = -(dm * ce * py + mod);
         for (int c = 0; c < nc; ++c)
           dlogits[v * nc + c] = cls_scale * a *
@@ -1167,20 +1194,21 @@ __global__ void loss_kernel(const float *__restrict__ logits, int64_t ldl,
         const float xent = fmaxf(zc, 0.0f) - (t ? zc : 0.0f) +
                            log1pf(expf(-fabsf(zc)));
         const float om = t ? 1.0f - p : p;            // 1 - p_t
-        const float mod = om > 0.0f ? powf(om, gamma) : 0.0f;
+        const float mod = focal_mod(om, gamma);
         const float aw = t ? alpha : 1.0f - alpha;
         sum += mod * aw * xent;
         if (dlogits) {
           // d(1 - p_t)/dz = -(2t - 1) p (1 - p)
-          const float dm = (om > 0.0f ? gamma * powf(om, gamma - 1.0f) : 0.0f) *
+          const float dm = focal_dmod(om, gamma) *
                            (t ? -1.0f : 1.0f) * p * (1.0f - p);
           dlogits[v * nc + c] = cls_scale / (float)nc * aw *
                                 (dm * xent + mod * (p - (t ? 1.0f : 0.0f)));
         }
       }
       s_ce += (double)(sum / (float)nc);
+      if (point_cls) point_cls[v] = sum / (float)nc;
     }
-    const float w = valid[v] * (class_loc_w ? class_loc_w[lab] : 1.0f);
+    const float w = pick_l * valid[v] * (class_loc_w ? class_loc_w[lab] : 1.0f);
     const float *p = pred + (v * nc + lab) * box_len;
     const float *g = gt + v * box_len;
     float acc = 0.0f;
@@ -1199,8 +1227,9 @@ __global__ void loss_kernel(const float *__restrict__ logits, int64_t ldl,
       }
     }
     s_loc += (double)(acc / (float)box_len);
+    if (point_loc) point_loc[v] = acc / (float)box_len;
     s_n += 1.0;
-    s_v += (double)valid[v];
+    s_v += (double)(pick_l * valid[v]);
   }
   // block reduction (fp64 atomics at the end: 4 per wave)
 #pragma unroll
@@ -2246,7 +2275,9 @@ extern "C" int pgnn_loss_fwd_bwd(const float *logits, int64_t ld_logits,
                      valid, n_vertices, num_classes, cls_grad_scale,
                      loc_grad_scale, sums4, dlogits, dpred_box,
                      (const double *)nullptr, 0.0, 0.0, 0, 0.0f, 0.0f,
-                     (const float *)nullptr);
+                     (const float *)nullptr, (const float *)nullptr,
+                     (const float *)nullptr, 1.0f, (float *)nullptr,
+                     (float *)nullptr);
   PGNN_HIP(hipGetLastError());
   return 0;
   PGNN_GUARD_END
@@ -2271,7 +2302,9 @@ extern "C" int pgnn_loss_fwd_bwd_counts(
                      stream, logits, ld_logits, labels, pred_box, box_len, gt_box,
                      valid, n_vertices, num_classes, 0.0f, 0.0f, sums4, dlogits,
                      dpred_box, counts2, cls_loss_weight, loc_loss_weight, 0, 0.0f,
-                     0.0f, (const float *)nullptr);
+                     0.0f, (const float *)nullptr, (const float *)nullptr,
+                     (const float *)nullptr, 1.0f, (float *)nullptr,
+                     (float *)nullptr);
   PGNN_HIP(hipGetLastError());
   return 0;
   PGNN_GUARD_END
@@ -2299,7 +2332,111 @@ extern "C" int pgnn_loss_fwd_bwd_ex(
                      valid, n_vertices, num_classes, cls_grad_scale,
                      loc_grad_scale, sums4, dlogits, dpred_box, counts2,
                      cls_loss_weight, loc_loss_weight, cls_kind, alpha, gamma,
-                     class_loc_weight);
+                     class_loc_weight, (const float *)nullptr,
+                     (const float *)nullptr, 1.0f, (float *)nullptr,
+                     (float *)nullptr);
+  PGNN_HIP(hipGetLastError());
+  return 0;
+  PGNN_GUARD_END
+}
+
+extern "C" int pgnn_loss_fwd_bwd_sel(
+    const float *logits, int64_t ld_logits, const int32_t *labels,
+    const float *pred_box, int32_t box_len, const float *gt_box,
+    const float *valid, int64_t n_vertices, int32_t num_classes,
+    float cls_grad_scale, float loc_grad_scale, const double *counts2,
+    double cls_loss_weight, double loc_loss_weight, int32_t cls_kind,
+    float alpha, float gamma, const float *class_loc_weight,
+    const float *select_cls, const float *select_loc, float cls_sum_weight,
+    float *point_cls, float *point_loc, double *sums4, float *dlogits,
+    float *dpred_box, void *stream_) {
+  PGNN_GUARD_BEGIN
+  hipStream_t stream = (hipStream_t)stream_;
+  PGNN_REQUIRE(n_vertices >= 0 && num_classes > 0 && box_len > 0 && sums4 &&
+                   cls_kind >= 0 && cls_kind <= 2 && gamma >= 0.0f,
+               PGNN_E_INVALID, "loss_sel: bad argument");
+  PGNN_HIP(hipMemsetAsync(sums4, 0, 4 * sizeof(double), stream));
+  if (n_vertices == 0) return 0;
+  PGNN_REQUIRE(logits && labels && pred_box && gt_box && valid, PGNN_E_INVALID,
+               "loss_sel: null pointer");
+  hipLaunchKernelGGL(loss_kernel, dim3(grid_for(n_vertices, 1024)), dim3(256), 0,
+                     stream, logits, ld_logits, labels, pred_box, box_len, gt_box,
+                     valid, n_vertices, num_classes, cls_grad_scale,
+                     loc_grad_scale, sums4, dlogits, dpred_box, counts2,
+                     cls_loss_weight, loc_loss_weight, cls_kind, alpha, gamma,
+                     class_loc_weight, select_cls, select_loc, cls_sum_weight,
+                     point_cls, point_loc);
+  PGNN_HIP(hipGetLastError());
+  return 0;
+  PGNN_GUARD_END
+}
+
+// ---- tf.math.top_k membership (models.py:227, 281): mask[i] = 1 for the k
+// largest values, equal values in ascending index order (TF: "if two elements
+// are equal, the lower-index element appears first"); 0 elsewhere.  A stable
+// LSD radix sort of (descending-order key, index) puts exactly that
+// selection in the first k places.
+namespace pgnn {
+namespace {
+__global__ void topk_keys_kernel(const float *__restrict__ v, int64_t n,
+                                 uint32_t *__restrict__ keys,
+                                 uint32_t *__restrict__ vals,
+                                 float *__restrict__ mask) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float x = v[i];
+    if (x == 0.0f) x = 0.0f;            // -0 and +0 compare equal
+    uint32_t u = __float_as_uint(x);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // ascending order key
+    keys[i] = ~u;                                    // ... descending
+    vals[i] = (uint32_t)i;
+    mask[i] = 0.0f;
+  }
+}
+__global__ void topk_mark_kernel(const uint32_t *__restrict__ order, int64_t k,
+                                 float *__restrict__ mask) {
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < k;
+       j += (int64_t)gridDim.x * blockDim.x)
+    mask[order[j]] = 1.0f;
+}
+}  // namespace
+}  // namespace pgnn
+
+extern "C" size_t pgnn_topk_mask_workspace_bytes(int64_t n) {
+  if (n < 0) return 0;
+  return align_up((size_t)n * 4, 256) * 4 + radix_sort_scratch_bytes(n) + 256;
+}
+
+extern "C" int pgnn_topk_mask_f32(const float *values, int64_t n, int64_t k,
+                                  float *mask, void *workspace,
+                                  size_t workspace_bytes, void *stream_) {
+  PGNN_GUARD_BEGIN
+  hipStream_t stream = (hipStream_t)stream_;
+  PGNN_REQUIRE(n >= 0 && k >= 0, PGNN_E_INVALID, "topk_mask: bad argument");
+  // tf.math.top_k: "input must have at least k columns"
+  PGNN_REQUIRE(k <= n, PGNN_E_INVALID,
+               "topk_mask: k exceeds the number of values (tf.math.top_k "
+               "fails the same way)");
+  if (n == 0) return 0;
+  PGNN_REQUIRE(values && mask && workspace, PGNN_E_INVALID,
+               "topk_mask: null pointer");
+  PGNN_REQUIRE(workspace_bytes >= pgnn_topk_mask_workspace_bytes(n),
+               PGNN_E_WORKSPACE, "topk_mask: workspace too small");
+  Arena ar(workspace, workspace_bytes);
+  uint32_t *ka = ar.take<uint32_t>(n), *va = ar.take<uint32_t>(n);
+  uint32_t *kb = ar.take<uint32_t>(n), *vb = ar.take<uint32_t>(n);
+  const size_t sb = radix_sort_scratch_bytes(n);
+  void *scratch = ar.take<char>(sb);
+  PGNN_REQUIRE(scratch, PGNN_E_WORKSPACE, "topk_mask: workspace too small");
+  hipLaunchKernelGGL(topk_keys_kernel, dim3(grid_for(n, 1024)), dim3(256), 0,
+                     stream, values, n, ka, va, mask);
+  uint32_t *keys = nullptr, *order = nullptr;
+  int rc = radix_sort_pairs(ka, va, kb, vb, n, 32, scratch, sb, &keys, &order,
+                            stream, nullptr);
+  if (rc) return rc;
+  if (k > 0)
+    hipLaunchKernelGGL(topk_mark_kernel, dim3(grid_for(k, 1024)), dim3(256), 0,
+                       stream, order, k, mask);
   PGNN_HIP(hipGetLastError());
   return 0;
   PGNN_GUARD_END

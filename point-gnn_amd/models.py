@@ -18,7 +18,8 @@ import torch
 from . import gnn
 from .weights import init_params
 
-__all__ = ["MultiLayerFastLocalGraphModelV2", "get_model", "cls_loss_kind"]
+__all__ = ["MultiLayerFastLocalGraphModelV2", "get_model", "cls_loss_kind",
+           "loss_top_k", "top_k_selection"]
 
 
 def cls_loss_kind(cls_loss_type, cls_loss_kwargs=None):
@@ -31,9 +32,72 @@ def cls_loss_kind(cls_loss_type, cls_loss_kwargs=None):
         return 1, 0.0, float(kw.get('gamma', 2))
     if cls_loss_type == 'focal_sigmoid':
         return 2, float(kw.get('alpha', 0.5)), float(kw.get('gamma', 2))
-    raise NotImplementedError(
-        "cls_loss_type %r: 'top_k_softmax' has no device path (a per-batch "
-        "top-k selection; no shipped config uses it)" % (cls_loss_type,))
+    if cls_loss_type == 'top_k_softmax':     # softmax CE of the k worst vertices
+        return 0, 0.0, 0.0
+    raise ValueError("cls_loss_type %r (models.py:210-211 knows softmax, "
+                     "top_k_softmax, focal_sigmoid, focal_softmax)"
+                     % (cls_loss_type,))
+
+
+def loss_top_k(cls_loss_type, cls_loss_kwargs, loc_loss_type, loc_loss_kwargs):
+    """(k of 'top_k_softmax' or 0, k of 'top_k_huber_loss' or 0):
+    models.py:222-228, 266-291."""
+    if loc_loss_type not in ('huber_loss', 'top_k_huber_loss'):
+        raise ValueError("loc_loss_type %r (models.py:237,266 knows "
+                         "huber_loss, top_k_huber_loss)" % (loc_loss_type,))
+    k_cls = int((cls_loss_kwargs or {})['k']) \
+        if cls_loss_type == 'top_k_softmax' else 0
+    k_loc = int((loc_loss_kwargs or {})['k']) \
+        if loc_loss_type == 'top_k_huber_loss' else 0
+    if (cls_loss_type == 'top_k_softmax' and k_cls < 1) or \
+            (loc_loss_type == 'top_k_huber_loss' and k_loc < 1):
+        raise ValueError("top-k losses need k >= 1")
+    return k_cls, k_loc
+
+
+def top_k_selection(lg, lab, pb, bl, gt, va, kind, alpha, gamma, cw, k_cls,
+                    k_loc):
+    """The vertices tf.math.top_k picks (models.py:227, 281) as float masks
+    [K] on the device: (sel_cls or None, sel_loc or None).  lg [K, >= nc]
+    logits (row stride lg.stride(0)), lab int32 [K], pb [K, nc, bl], gt [K,
+    bl], va [K], cw the class-wise loc weights or None -- contiguous CUDA
+    tensors.  Per-vertex losses from pgnn_loss_fwd_bwd_sel, membership from
+    pgnn_topk_mask_f32; nothing is read back."""
+    import ctypes
+    from . import _lib
+    if not (k_cls or k_loc):
+        return None, None
+    lib = _lib.load()
+    dev = lg.device
+    k, nc = int(lab.shape[0]), int(pb.shape[1])
+    if max(k_cls, k_loc) > k:
+        raise ValueError("top-k loss: k = %d exceeds the batch's %d vertices "
+                         "(tf.math.top_k fails the same way)"
+                         % (max(k_cls, k_loc), k))
+    point_c = torch.empty(k, dtype=torch.float32, device=dev)
+    point_l = torch.empty(k, dtype=torch.float32, device=dev)
+    sums = torch.empty(4, dtype=torch.float64, device=dev)
+    st = _lib.stream_ptr()
+    _lib.check(lib.pgnn_loss_fwd_bwd_sel(
+        _lib.ptr(lg), lg.stride(0), _lib.ptr(lab), _lib.ptr(pb), bl,
+        _lib.ptr(gt), _lib.ptr(va), k, nc, ctypes.c_float(0.0),
+        ctypes.c_float(0.0), None, 0.0, 0.0, kind, ctypes.c_float(alpha),
+        ctypes.c_float(gamma), _lib.ptr(cw), None, None, ctypes.c_float(1.0),
+        _lib.ptr(point_c), _lib.ptr(point_l), _lib.ptr(sums), None, None, st),
+        "pgnn_loss_fwd_bwd_sel")
+    ws_bytes = int(lib.pgnn_topk_mask_workspace_bytes(k))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    out = []
+    for values, kk in ((point_c, k_cls), (point_l, k_loc)):
+        if not kk:
+            out.append(None)
+            continue
+        mask = torch.empty(k, dtype=torch.float32, device=dev)
+        _lib.check(lib.pgnn_topk_mask_f32(
+            _lib.ptr(values), k, kk, _lib.ptr(mask), _lib.ptr(ws), ws_bytes,
+            st), "pgnn_topk_mask_f32")
+        out.append(mask)
+    return out[0], out[1]
 
 
 class MultiLayerFastLocalGraphModelV2(object):
@@ -188,8 +252,9 @@ class MultiLayerFastLocalGraphModelV2(object):
              loc_loss_type='huber_loss', loc_loss_kwargs={},
              loc_loss_weight=1.0, cls_loss_weight=1.0):
         """models.py:170-311: cls 'softmax' (every shipped config),
-        'focal_softmax', 'focal_sigmoid'; loc 'huber_loss' with the optional
-        'classwise_loc_loss_weight' (train mode).  Same keys as the reference's
+        'top_k_softmax', 'focal_softmax', 'focal_sigmoid'; loc 'huber_loss' /
+        'top_k_huber_loss' with the optional 'classwise_loc_loss_weight'
+        (train mode).  Same keys as the reference's
         loss_dict; values are Python floats (classwise_loc_loss: list of
         [box_len] tensors).  Device tensors in; the per-vertex arithmetic runs
         in pgnn_loss_fwd_bwd.  Gradients: see pointgnn_amd.train.Trainer."""
@@ -206,10 +271,8 @@ class MultiLayerFastLocalGraphModelV2(object):
             loc_loss_type = loc_loss_type[self._mode]
             loc_loss_kwargs = loc_loss_kwargs[self._mode]
         kind, alpha, gamma = cls_loss_kind(cls_loss_type, cls_loss_kwargs)
-        if loc_loss_type != 'huber_loss':
-            raise NotImplementedError(
-                "loc_loss_type %r: 'top_k_huber_loss' has no device path"
-                % (loc_loss_type,))
+        k_cls, k_loc = loss_top_k(cls_loss_type, cls_loss_kwargs,
+                                  loc_loss_type, loc_loss_kwargs)
         lib = _lib.load()
         dev = logits.device
         k, nc = int(logits.shape[0]), int(logits.shape[1])
@@ -226,7 +289,20 @@ class MultiLayerFastLocalGraphModelV2(object):
                 self._mode == 'train':
             cw = torch.tensor(loc_loss_kwargs['classwise_loc_loss_weight'],
                               dtype=torch.float32, device=dev)
-        if kind == 0 and cw is None:
+        sel_c = sel_l = None
+        if k_cls or k_loc:
+            sel_c, sel_l = top_k_selection(lg, lab, pb, bl, gt, va, kind,
+                                           alpha, gamma, cw, k_cls, k_loc)
+            _lib.check(lib.pgnn_loss_fwd_bwd_sel(
+                _lib.ptr(lg), lg.stride(0), _lib.ptr(lab), _lib.ptr(pb), bl,
+                _lib.ptr(gt), _lib.ptr(va), k, nc, ctypes.c_float(0.0),
+                ctypes.c_float(0.0), None, 0.0, 0.0, kind,
+                ctypes.c_float(alpha), ctypes.c_float(gamma), _lib.ptr(cw),
+                _lib.ptr(sel_c), _lib.ptr(sel_l),
+                ctypes.c_float(k / k_cls if k_cls else 1.0), None, None,
+                _lib.ptr(sums), None, None, _lib.stream_ptr()),
+                "pgnn_loss_fwd_bwd_sel")
+        elif kind == 0 and cw is None:
             _lib.check(lib.pgnn_loss_fwd_bwd(
                 _lib.ptr(lg), lg.stride(0), _lib.ptr(lab), _lib.ptr(pb), bl,
                 _lib.ptr(gt), _lib.ptr(va), k, nc, ctypes.c_float(0.0),
@@ -255,6 +331,8 @@ class MultiLayerFastLocalGraphModelV2(object):
         all_loc = loc_loss_weight * (0.5 * quad * quad + (ae - quad)) * va[:, None]
         if cw is not None:
             all_loc = all_loc * cw[lab.long()][:, None]
+        if sel_l is not None:        # models.py:286-299: the selected rows only
+            all_loc = all_loc * sel_l[:, None]
         classwise = [all_loc[lab == c].sum(dim=0) for c in range(self.num_classes)]
         return {
             'cls_loss': cls_loss_weight * s_ce / max(n, 1.0),

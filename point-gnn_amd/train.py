@@ -439,16 +439,26 @@ class Trainer(object):
             raise NotImplementedError("regularizer %r" % mk['regularizer_type'])
         self.l1_scale = float(mk['regularizer_kwargs']['scale']) \
             if mk.get('regularizer_type') == 'l1' else 0.0
-        self.cls_w = float(config['loss']['cls_loss_weight'])
-        self.loc_w = float(config['loss']['loc_loss_weight'])
-        from .models import cls_loss_kind
-        self.cls_kind = cls_loss_kind(
-            config['loss'].get('cls_loss_type', 'softmax'),
-            config['loss'].get('cls_loss_kwargs'))
-        if config['loss'].get('loc_loss_type', 'huber_loss') != 'huber_loss':
-            raise NotImplementedError(
-                "loc_loss_type %r" % (config['loss']['loc_loss_type'],))
-        self._class_loc_w_host = (config['loss'].get('loc_loss_kwargs') or {}
+        from .models import cls_loss_kind, loss_top_k
+        # models.py:198-208: the loss entries may be dicts keyed by mode
+        lcfg = {key: (val['train'] if isinstance(val, dict) and 'train' in val
+                      and key in ('cls_loss_type', 'cls_loss_kwargs',
+                                  'loc_loss_type', 'loc_loss_kwargs',
+                                  'cls_loss_weight', 'loc_loss_weight')
+                      else val)
+                for key, val in config['loss'].items()}
+        self.cls_w = float(lcfg['cls_loss_weight'])
+        self.loc_w = float(lcfg['loc_loss_weight'])
+        self.cls_kind = cls_loss_kind(lcfg.get('cls_loss_type', 'softmax'),
+                                      lcfg.get('cls_loss_kwargs'))
+        # 'top_k_softmax' / 'top_k_huber_loss' (models.py:222-228, 266-291):
+        # the loss of the k worst vertices of THIS rank's batch (a tower's, in
+        # the reference)
+        self.cls_topk, self.loc_topk = loss_top_k(
+            lcfg.get('cls_loss_type', 'softmax'), lcfg.get('cls_loss_kwargs'),
+            lcfg.get('loc_loss_type', 'huber_loss'),
+            lcfg.get('loc_loss_kwargs'))
+        self._class_loc_w_host = (lcfg.get('loc_loss_kwargs') or {}
                                   ).get('classwise_loc_loss_weight')
         self._class_loc_w = None
         # ---- flat parameter / gradient buffers --------------------------
@@ -1146,12 +1156,42 @@ class Trainer(object):
         return logits[:, :self.nc], pred
 
     # ---- loss ---------------------------------------------------------------------
+    def _loss_inputs(self, logits, labels, gt_box, valid):
+        dev = self.device
+        k = int(logits.shape[0])
+        lg = logits if logits.stride(1) == 1 else logits.contiguous()
+        labels = labels.to(device=dev, dtype=torch.int32).reshape(-1).contiguous()
+        gt = gt_box.to(device=dev, dtype=torch.float32).reshape(
+            k, self.box_len).contiguous()
+        va = valid.to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
+        if self._class_loc_w is None and self._class_loc_w_host is not None:
+            self._class_loc_w = torch.tensor(
+                self._class_loc_w_host, dtype=torch.float32, device=dev)
+        return lg, labels, gt, va
+
+    def top_k_selection(self, logits, pred, labels, gt_box, valid):
+        """(sel_cls, sel_loc): float masks [K] of the vertices the top-k losses
+        keep (None where the loss is not a top-k one)."""
+        from .models import top_k_selection
+        lg, labels, gt, va = self._loss_inputs(logits, labels, gt_box, valid)
+        return top_k_selection(lg, labels, pred.contiguous(), self.box_len, gt,
+                               va, self.cls_kind[0], self.cls_kind[1],
+                               self.cls_kind[2], self._class_loc_w,
+                               self.cls_topk, self.loc_topk)
+
     def loss_and_grads(self, logits, pred, labels, gt_box, valid, n_total,
-                       nv_total, want_grads=True, counts_dev=None):
+                       nv_total, want_grads=True, counts_dev=None, sel=None):
         """sums4 = [sum CE, sum loc, n, n_valid] (device double tensor),
         dlogits [K,nc], dpred [K,nc,L] for the globally normalised loss.
         counts_dev: the global (n_total, nv_total) as a device float64 [2]
-        tensor instead of the two host numbers (no host read needed)."""
+        tensor instead of the two host numbers (no host read needed).
+        sel: top_k_selection()'s masks (computed here when omitted and the
+        loss is a top-k one); with 'top_k_huber_loss' nv_total / counts_dev[1]
+        must count the valid vertices INSIDE the selection (models.py:283)."""
+        if self.cls_topk or self.loc_topk:
+            return self._loss_and_grads_top_k(
+                logits, pred, labels, gt_box, valid, n_total, nv_total,
+                want_grads, counts_dev, sel)
         dev = self.device
         k = int(logits.shape[0])
         lg = logits if logits.stride(1) == 1 else logits.contiguous()
@@ -1199,6 +1239,39 @@ class Trainer(object):
             ctypes.c_float(cls_scale), ctypes.c_float(loc_scale),
             _lib.ptr(sums), _lib.ptr(dlog), _lib.ptr(dpred), self._st()),
             "pgnn_loss_fwd_bwd")
+        return sums, dlog, dpred
+
+    def _loss_and_grads_top_k(self, logits, pred, labels, gt_box, valid,
+                              n_total, nv_total, want_grads, counts_dev, sel):
+        dev = self.device
+        k = int(logits.shape[0])
+        lg, labels, gt, va = self._loss_inputs(logits, labels, gt_box, valid)
+        pred = pred.contiguous()
+        if sel is None:
+            sel = self.top_k_selection(lg, pred, labels, gt, va)
+        sel_c, sel_l = sel
+        sums = torch.zeros(4, dtype=torch.float64, device=dev)
+        dlog = torch.empty((k, self.nc), dtype=torch.float32, device=dev) \
+            if want_grads else None
+        dpred = torch.empty((k, self.nc, self.box_len), dtype=torch.float32,
+                            device=dev) if want_grads else None
+        # the reference's mean over the k selected values, written as the
+        # callers' sum / n_total: every selected vertex weighs n_rank / k
+        ce_w = float(k) / self.cls_topk if self.cls_topk else 1.0
+        cls_scale = self.cls_w * ce_w / n_total \
+            if counts_dev is None and n_total > 0 else 0.0
+        loc_scale = self.loc_w / nv_total \
+            if counts_dev is None and nv_total > 0 else 0.0
+        _lib.check(self.lib.pgnn_loss_fwd_bwd_sel(
+            _lib.ptr(lg), lg.stride(0), _lib.ptr(labels), _lib.ptr(pred),
+            self.box_len, _lib.ptr(gt), _lib.ptr(va), k, self.nc,
+            ctypes.c_float(cls_scale), ctypes.c_float(loc_scale),
+            _lib.ptr(counts_dev), ctypes.c_double(self.cls_w),
+            ctypes.c_double(self.loc_w), self.cls_kind[0],
+            ctypes.c_float(self.cls_kind[1]), ctypes.c_float(self.cls_kind[2]),
+            _lib.ptr(self._class_loc_w), _lib.ptr(sel_c), _lib.ptr(sel_l),
+            ctypes.c_float(ce_w), None, None, _lib.ptr(sums), _lib.ptr(dlog),
+            _lib.ptr(dpred), self._st()), "pgnn_loss_fwd_bwd_sel")
         return sums, dlog, dpred
 
     def reg_loss(self):
@@ -1377,6 +1450,11 @@ class Trainer(object):
         k = int(va.shape[0])
         multi = self._multi()
         counts = counts_dev = None
+        if self.loc_topk:
+            # 'top_k_huber_loss': num_valid_endpoint counts the valid vertices
+            # among the k worst (models.py:283-285) -- known after the forward
+            # only, and left on the device
+            num_valid = None
         if multi:
             # several ranks: the global counts are all-reduced and STAY on the
             # device (the loss kernel divides by them): nothing is read back
@@ -1391,7 +1469,15 @@ class Trainer(object):
         logits, pred = self.forward(input_v, coords, kps, edges)
         self.last_logits = logits   # for the streaming metrics (train.py:299)
         assert int(logits.shape[0]) == k, "labels do not match the vertices"
-        if multi and counts_dev is None:
+        sel = None
+        if self.cls_topk or self.loc_topk:
+            sel = self.top_k_selection(logits, pred, torch.as_tensor(labels),
+                                       torch.as_tensor(boxes), va)
+        if self.loc_topk:
+            counts_dev = allreduce_endpoint_counts_device(
+                k, (va * sel[1]).sum(), self.device, self.pg,
+                self.force_collective and multi, self.comm if multi else None)
+        elif multi and counts_dev is None:
             counts_dev = allreduce_endpoint_counts_device(
                 k, va.sum(), self.device, self.pg, self.force_collective,
                 self.comm)
@@ -1401,7 +1487,7 @@ class Trainer(object):
         n_total, nv_total = counts if counts is not None else (None, None)
         sums, dlog, dpred = self.loss_and_grads(
             logits, pred, torch.as_tensor(labels), torch.as_tensor(boxes), va,
-            n_total, nv_total, counts_dev=counts_dev)
+            n_total, nv_total, counts_dev=counts_dev, sel=sel)
         ev = getattr(self, 'allreduce_events', None)
         # with a Communicator the native step enqueues the all-reduce itself,
         # right behind its last gradient kernel (pgnn_trainer_backward_sync);

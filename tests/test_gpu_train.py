@@ -287,10 +287,130 @@ def test_loss_variants_match_oracle(dev, kind, kwargs, classwise):
         # from the float64 oracle's; the loss itself is held to 2e-4
         # above -- this checks the wiring of the whole step)
         assert np.linalg.norm(got[name] - g_data[name]) <= 2e-2 * den + 1e-7, name
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):
         train.Trainer(dict(cfg, loss=dict(cfg['loss'],
-                                          cls_loss_type='top_k_softmax')),
+                                          cls_loss_type='no_such_loss')),
                       device=dev)
+
+
+def test_topk_mask_is_tf_top_k_membership(dev):
+    """pgnn_topk_mask_f32 == the first k places of a STABLE descending sort
+    (tf.math.top_k: equal values keep ascending index order), for values full
+    of duplicates, both zeros, infinities and negative numbers; k > n fails
+    like TF does."""
+    import torch
+    from pointgnn_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(8)
+    for n in (1, 5, 1000, 70001):
+        vals = rng.integers(-3, 4, n).astype(np.float32) * 0.5
+        vals[rng.random(n) < 0.1] = -0.0
+        vals[rng.random(n) < 0.05] = 0.0
+        if n > 4:
+            vals[1], vals[n - 2], vals[2] = np.inf, np.inf, -np.inf
+        v = T(vals, dev)
+        ws = torch.empty(int(lib.pgnn_topk_mask_workspace_bytes(n)),
+                         dtype=torch.uint8, device=dev)
+        for k in sorted({0, 1, n // 3, n - 1, n} - {-1}):
+            mask = torch.full((n,), 7.0, dtype=torch.float32, device=dev)
+            _lib.check(lib.pgnn_topk_mask_f32(
+                _lib.ptr(v), n, k, _lib.ptr(mask), _lib.ptr(ws), ws.numel(),
+                _lib.stream_ptr()), "pgnn_topk_mask_f32")
+            order = np.argsort(-(vals + 0.0), kind="stable")[:k]
+            want = np.zeros(n, np.float32)
+            want[order] = 1.0
+            assert np.array_equal(mask.cpu().numpy(), want), (n, k)
+        assert lib.pgnn_topk_mask_f32(_lib.ptr(v), n, n + 1, _lib.ptr(mask),
+                                      _lib.ptr(ws), ws.numel(), None) == -1
+        assert b"top_k" in lib.pgnn_last_error()
+
+
+@pytest.mark.parametrize("cls_k,loc_k,classwise", [
+    (40, 0, None), (0, 25, None), (300, 300, None),
+    (17, 33, [1.0, 2.0, 0.5, 4.0])])
+def test_top_k_losses_match_oracle(dev, cls_k, loc_k, classwise):
+    """models.py:222-228 'top_k_softmax' and :266-291 'top_k_huber_loss': loss
+    sums, the valid count inside the selection and both gradients against
+    float64 autograd of the reference's formulas -- through the trainer (host
+    scales and device counts), through model.loss, and as a whole training
+    step."""
+    import copy
+    import torch
+    from pointgnn_amd import models, train
+    cfg = copy.deepcopy(configs.car_auto_config(1))
+    if cls_k:
+        cfg['loss']['cls_loss_type'] = 'top_k_softmax'
+        cfg['loss']['cls_loss_kwargs'] = {'k': cls_k}
+    lkw = {}
+    if loc_k:
+        cfg['loss']['loc_loss_type'] = 'top_k_huber_loss'
+        lkw['k'] = loc_k
+    if classwise is not None:
+        lkw['classwise_loc_loss_weight'] = classwise
+    cfg['loss']['loc_loss_kwargs'] = lkw
+    tr = train.Trainer(cfg, seed=0, device=dev)
+    assert (tr.cls_topk, tr.loc_topk) == (cls_k, loc_k)
+    rng = np.random.default_rng(12)
+    k = 300
+    logits = rng.standard_normal((k, 4)).astype(np.float32) * 3
+    pred = rng.standard_normal((k, 4, 7)).astype(np.float32) * 2
+    labels = rng.integers(0, 4, (k, 1)).astype(np.int32)
+    gt = rng.standard_normal((k, 1, 7)).astype(np.float32) * 2
+    valid = (rng.random((k, 1, 1)) < 0.6).astype(np.float32)
+    tl = torch.tensor(logits, dtype=torch.float64, requires_grad=True)
+    tp = torch.tensor(pred, dtype=torch.float64, requires_grad=True)
+    ce, loc, n, nvv = to.loss_terms(cfg, tl, tp, labels, gt, valid)
+    assert n == k and 0 < nvv <= valid.sum()
+    if loc_k and loc_k < k:
+        assert nvv <= loc_k
+    (0.1 * ce / n + 10.0 * loc / nvv).backward()
+    counts = torch.tensor([float(k), nvv], dtype=torch.float64, device=dev)
+    for counts_dev in (None, counts):
+        sums, dlog, dpred = tr.loss_and_grads(
+            T(logits, dev), T(pred, dev), T(labels, dev), T(gt, dev),
+            T(valid, dev), float(k), nvv, counts_dev=counts_dev)
+        np.testing.assert_allclose(sums.cpu().numpy(),
+                                   [float(ce), float(loc), k, nvv], rtol=2e-5)
+        scale = np.abs(tl.grad.numpy()).max()
+        np.testing.assert_allclose(dlog.cpu().numpy(), tl.grad.numpy(),
+                                   atol=2e-6 * scale, rtol=2e-4)
+        np.testing.assert_allclose(dpred.cpu().numpy(), tp.grad.numpy(),
+                                   atol=1e-7, rtol=1e-4)
+        if cls_k and cls_k < k:      # vertices outside the selection: nothing
+            assert int((dlog.abs().sum(dim=1) > 0).sum()) == cls_k
+    model = models.get_model(cfg["model_name"])(
+        num_classes=4, box_encoding_len=7, mode="train", **cfg["model_kwargs"])
+    out = model.loss(T(logits, dev), T(labels, dev), T(pred, dev), T(gt, dev),
+                     T(valid, dev), **cfg['loss'])
+    assert out['cls_loss'] == pytest.approx(0.1 * float(ce) / k, rel=2e-5)
+    assert out['loc_loss'] == pytest.approx(10.0 * float(loc) / nvv, rel=2e-5)
+    assert out['num_valid_endpoint'] == nvv
+    tot = sum(float(c.sum()) for c in out['classwise_loc_loss'])
+    assert tot == pytest.approx(7 * nvv * out['loc_loss'], rel=1e-3)
+    # k beyond the batch: tf.math.top_k raises, so does the device path
+    big = copy.deepcopy(cfg)
+    big['loss']['cls_loss_type'] = 'top_k_softmax'
+    big['loss']['cls_loss_kwargs'] = {'k': k + 1}
+    with pytest.raises(ValueError):
+        train.Trainer(big, seed=0, device=dev).loss_and_grads(
+            T(logits, dev), T(pred, dev), T(labels, dev), T(gt, dev),
+            T(valid, dev), float(k), nvv)
+    # a whole step: device gradient vs the oracle's for this loss
+    params = weights.init_params(cfg, seed=6, bias_scale=0.05)
+    batch = _tiny_batch(seed=4)
+    n_b = int(np.asarray(batch[4]).shape[0])
+    if max(cls_k, loc_k) > n_b:
+        return
+    tr = train.Trainer(cfg, params=params, device=dev)
+    res = tr.train_step(batch, apply=False)
+    want, g_data, _ = to.step_gradients(params, cfg, [batch])
+    assert res['cls_loss'] == pytest.approx(want['cls_loss'], rel=1e-3)
+    assert res['loc_loss'] == pytest.approx(want['loc_loss'], rel=1e-3)
+    assert res['num_valid_endpoint'] == want['num_valid_endpoint']
+    got = tr.grad_dict()
+    for name in got:
+        den = np.linalg.norm(g_data[name]) + 1e-12
+        assert np.linalg.norm(got[name] - g_data[name]) <= 2e-2 * den + 1e-7, name
 
 
 def test_model_loss_api_matches_oracle(dev):
