@@ -434,6 +434,11 @@ class Trainer(object):
         self.comm = comm
         self.force_collective = bool(force_collective)
         self.global_step = 0
+        # optimizer steps taken with THIS optimizer's slots (Adam's bias
+        # correction counts them, not global_step: resuming another
+        # optimizer's checkpoint starts fresh slots and fresh beta powers,
+        # as TF's beta1_power / beta2_power variables would)
+        self.opt_step = 0
         mk = config['model_kwargs']
         if mk.get('regularizer_type') not in (None, 'l1'):
             raise NotImplementedError("regularizer %r" % mk['regularizer_type'])
@@ -550,6 +555,7 @@ class Trainer(object):
                 l1_mult=self._pseudo_n)
             self.repack()
             self.global_step += 1
+            self.opt_step += 1
             self._pseudo_sum.zero_()
             self._pseudo_n = 0
         return out, applied
@@ -575,8 +581,8 @@ class Trainer(object):
         else:
             # AdamOptimizer: lr_t = lr sqrt(1 - beta2^t) / (1 - beta1^t), t
             # counting this optimizer's own steps from 1 (its beta*_power
-            # variables; global_step counts the same here)
-            t = self.global_step + 1
+            # variables: opt_step, restored from a checkpoint's beta1_power)
+            t = self.opt_step + 1
             lr = lr * np.sqrt(1.0 - kw['beta2'] ** t) / (1.0 - kw['beta1'] ** t)
             h = (kw['beta1'], kw['beta2'], kw['epsilon'])
         _lib.check(self.lib.pgnn_optimizer_step(
@@ -597,7 +603,7 @@ class Trainer(object):
             for name, _ in self.specs:
                 out[name + '/' + slot] = self._view(buf, name).cpu().numpy()
         if self.optimizer == 'adam':
-            t = self.global_step + 1      # TF keeps beta^(steps taken + 1)
+            t = self.opt_step + 1         # TF keeps beta^(steps taken + 1)
             out['beta1_power'] = np.float32(self.opt_kwargs['beta1'] ** t)
             out['beta2_power'] = np.float32(self.opt_kwargs['beta2'] ** t)
         return out
@@ -619,6 +625,17 @@ class Trainer(object):
         ck = tf_bundle.load_checkpoint(train_dir)
         if 'Variable' in ck:
             self.global_step = int(ck['Variable'])
+        self.opt_step = 0
+        if self.optimizer == 'adam' and 'beta1_power' in ck:
+            # beta1_power = beta1 ^ (steps taken + 1)
+            b1 = float(self.opt_kwargs['beta1'])
+            p = float(np.asarray(ck['beta1_power']).reshape(-1)[0])
+            if 0.0 < p < 1.0 and 0.0 < b1 < 1.0:
+                self.opt_step = max(0, int(round(np.log(p) / np.log(b1))) - 1)
+        elif self.optimizer != 'adam' and any(
+                (name + '/' + slot) in ck for name, _ in self.specs[:1]
+                for slot in _OPTIMIZERS[self.optimizer][2]):
+            self.opt_step = self.global_step
         for name, _ in self.specs:
             self._view(self.flat, name).copy_(
                 torch.from_numpy(np.ascontiguousarray(ck[name], np.float32)))
@@ -1516,6 +1533,7 @@ class Trainer(object):
             self._apply_gradients(lr)
             self.repack()
             self.global_step += 1
+            self.opt_step += 1
         parts = [sums, l1] if counts_dev is None else [sums, l1, counts_dev]
         res = StepResult(self, torch.cat(parts), counts, lr)
         if after_enqueue is not None:

@@ -723,8 +723,21 @@ def test_other_optimizers_follow_tf_update_rules(dev, opt, kwargs, tmp_path):
     b = train.Trainer(cfg, train_config=tcfg, seed=99, device=dev)
     b.load_checkpoint(str(tmp_path))
     assert b.global_step == 3 and torch.equal(tr.flat, b.flat)
+    assert b.opt_step == 3        # adam: from beta1_power; others: the slots
     for sa, sb in zip(tr.slots, b.slots):
         assert torch.equal(sa, sb)
+    if opt == 'adam':
+        # another optimizer's checkpoint: weights and step resume, Adam's
+        # slots AND its bias-correction clock start fresh
+        sgd_dir = tmp_path / "sgd"
+        sgd = train.Trainer(cfg, train_config=dict(tcfg, optimizer='sgd'),
+                            seed=1, device=dev)
+        sgd.global_step = 1000
+        sgd.save_checkpoint(str(sgd_dir))
+        c = train.Trainer(cfg, train_config=tcfg, seed=99, device=dev)
+        c.load_checkpoint(str(sgd_dir))
+        assert c.global_step == 1000 and c.opt_step == 0
+        assert all(float(sl.abs().max()) == 0.0 for sl in c.slots)
     tr.train_step(batch)
     b.train_step(batch)
     # (the gradient's float atomics make two runs of a step differ in the last
