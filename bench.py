@@ -847,13 +847,16 @@ def train_measure(torch, dev, rank, world, dist, config_name, preset, steps,
     for s in range(frames):
         xyz, inten = synthetic_cloud(seed=s, preset=preset)
         pool[s] = (torch.from_numpy(xyz).to(dev), torch.from_numpy(inten).to(dev))
-    fn = graph_gen.get_graph_generate_fn(cfg['graph_gen_method'])
     gen = torch.Generator(device='cpu').manual_seed(1234 + rank)
     np.random.seed(99 + rank)
+    hints = graph_gen.CountHints()
 
     def make_frame(i):
         x, f = pool[i % frames]
-        coords, kps, edges = fn(x, **cfg['graph_gen_kwargs'])
+        # the training graph in capacity form, ONE size read per frame (what
+        # train.fetch_data does with its graph_hints)
+        coords, kps, edges = graph_gen.gen_multi_level_local_graph_v3_one_read(
+            x, hints, **cfg['graph_gen_kwargs'])
         k = int(coords[1].shape[0])
         lab = (torch.rand(k, generator=gen) < 0.2).to(torch.int32) * \
             torch.randint(1, 3, (k,), generator=gen, dtype=torch.int32)
@@ -891,8 +894,20 @@ def train_measure(torch, dev, rank, world, dist, config_name, preset, steps,
 
     state = {}
     mode = pipeline if isinstance(pipeline, str) else \
-        ("stream" if pipeline else "off")
+        ("thread" if pipeline else "off")
     prebuilt = []
+    loader = None
+    if mode == "thread":
+        # the data side on a loader thread with the stream `sg` (the
+        # reference: a 16-process loader pool, train.py:430-440): the stepping
+        # thread only enqueues steps and reads their losses
+        def make_in_thread(i):
+            fr = [make_frame((rank + i) * fpg + j) for j in range(fpg)]
+            batch = train.batch_data(fr)
+            nv = float(sum(float(x[6].sum().item()) for x in fr))
+            return batch, nv
+        loader = train.BatchPrefetcher(make_in_thread, range(n_steps + 6),
+                                       depth=2, device=dev, stream=sg)
 
     def step(i):
         """Queue step i; returns the loss dict of step i-1 when the losses are
@@ -902,6 +917,17 @@ def train_measure(torch, dev, rank, world, dist, config_name, preset, steps,
                 prebuilt.append(make_batch(i))
             batch, nv = prebuilt[i % len(prebuilt)]
             after = None
+        elif mode == "thread":
+            batch, nv = next(loader)
+            after = None
+            shapes.append((int(batch[1][1].shape[0]), int(batch[3][0].shape[0]),
+                           int(batch[3][1].shape[0])))
+            res = tr.train_step(batch, num_valid=nv, deferred=deferred)
+            if not deferred:
+                return res
+            prev = state.get('result')
+            state['result'] = res
+            return prev.get() if prev is not None else None
         else:
             if 'next' not in state:
                 state['next'] = make_batch(i)
@@ -945,6 +971,8 @@ def train_measure(torch, dev, rank, world, dist, config_name, preset, steps,
                  max(1, len(tr.allreduce_events)))
         tr.allreduce_events = None
     elapsed, ar_ms = _max_over_ranks(torch, dist, dev, [elapsed, ar_ms])
+    if loader is not None:
+        loader.close()
     tr.collective = "none" if not tr._multi() else (
         "pgnn_allreduce_step (RCCL behind the C ABI, world %d)" % comm.world
         if comm is not None else "torch.distributed all_reduce (%s)"
@@ -1024,7 +1052,11 @@ def run_train(args, torch, dev, rank, world, dist):
                             "batch %d), graph build included%s, synthetic labels"
                             % (args.config, fpg, world * fpg,
                                "" if args.no_pipeline else
-                               " (next batch built on a second stream)"
+                               " (batches built by a loader thread on a "
+                               "second stream, two ahead)"
+                               if args.train_loader == "thread" else
+                               " (next batch built on a second stream by the "
+                               "stepping thread)"
                                if args.train_loader == "stream" else
                                " -- DIAGNOSTIC: batches built once, no build "
                                "in the loop"),
@@ -1144,11 +1176,14 @@ def parse_args(argv=None):
                          "PMC pass of the same workload instead, if any)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the extra `car`-preset measurement")
-    ap.add_argument("--train-loader", default="stream",
-                    choices=["stream", "prebuilt"],
-                    help="--train: 'stream' = the next batch's graph is built "
-                         "on a second stream once the step is enqueued; "
-                         "'prebuilt' = diagnostic, no build in the loop")
+    ap.add_argument("--train-loader", default="thread",
+                    choices=["thread", "stream", "prebuilt"],
+                    help="--train: 'thread' = batches come from a loader "
+                         "thread with its own stream, two ahead "
+                         "(train.BatchPrefetcher); 'stream' = the stepping "
+                         "thread builds the next batch on a second stream once "
+                         "the step is enqueued; 'prebuilt' = diagnostic, no "
+                         "build in the loop")
     ap.add_argument("--train-sync-loss", action="store_true",
                     help="--train: read every step's losses before the next "
                          "step is queued (default: one step late)")
@@ -1614,8 +1649,8 @@ def secondary_train(args, torch, dev):
     res = {
         "workload": "car_auto_T3 training step, %d frames/step, training "
                     "graph kwargs (voxel 0.8, random keypoints + jitter, "
-                    "fan-in cap 256), graph build included (next batch built "
-                    "on a second stream), every step's losses read inside the "
+                    "fan-in cap 256), graph build included (batches built "
+                    "by a loader thread on a second stream, two ahead), every step's losses read inside the "
                     "timed region one step late, synthetic labels, preset "
                     "'car'" % fpg,
         "steps": steps, "ms_per_step": elapsed / steps * 1e3,

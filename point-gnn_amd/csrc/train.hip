@@ -1899,7 +1899,7 @@ __device__ __forceinline__ void pn_wgrad(const float *Xs, int ldx, const float *
   }
 }
 
-__global__ __launch_bounds__(256) void pool_narrow_bwd_kernel(PoolNarrowArgs a) {
+__global__ __launch_bounds__(256, 2) void pool_narrow_bwd_kernel(PoolNarrowArgs a) {
   constexpr int LZ2 = 128 + 8, LA1 = 64 + 8, LA0 = 32 + 8, LF = 16 + 8;
   __shared__ __attribute__((aligned(16))) float Z2[kPnRows * LZ2];
   __shared__ __attribute__((aligned(16))) float A1[kPnRows * LA1];
@@ -1959,7 +1959,10 @@ __global__ __launch_bounds__(256) void pool_narrow_bwd_kernel(PoolNarrowArgs a) 
       for (int r = 0; r < kPnRows; ++r) sum += Z2[r * LZ2 + threadIdx.x];
       b2 += sum;
     }
-    layer_pass_dispatch<2, false, 4>(Z2, LZ2, D1, LA1, a.t2, 0, wave, lane);
+    // (64 and 32 output columns: one column tile per wave -- the fixed form,
+    // not layer_pass_dispatch's run-time switch, whose widest case sets the
+    // kernel's register count)
+    layer_pass<2, 1, false, 4>(Z2, LZ2, D1, LA1, a.t2, 0, wave, lane, false);
     for (int idx = threadIdx.x; idx < kPnRows * 64; idx += 256) {
       const int r = idx >> 6, c = idx & 63;
       if (!(A1[r * LA1 + c] > 0.0f)) D1[r * LA1 + c] = 0.0f;
@@ -1973,7 +1976,7 @@ __global__ __launch_bounds__(256) void pool_narrow_bwd_kernel(PoolNarrowArgs a) 
       for (int r = 0; r < kPnRows; ++r) sum += D1[r * LA1 + threadIdx.x];
       b1 += sum;
     }
-    layer_pass_dispatch<2, false, 4>(D1, LA1, D0, LA0, a.t1, 0, wave, lane);
+    layer_pass<2, 1, false, 4>(D1, LA1, D0, LA0, a.t1, 0, wave, lane, false);
     for (int idx = threadIdx.x; idx < kPnRows * 32; idx += 256) {
       const int r = idx >> 5, c = idx & 31;
       if (!(A0[r * LA0 + c] > 0.0f)) D0[r * LA0 + c] = 0.0f;
