@@ -713,6 +713,22 @@ int pgnn_edge_hidden_fwd(const float *P, const float *Q, int64_t ld_pq,
 int pgnn_edge_hidden_bwd(const float *dH1, int64_t ld, const int32_t *edges,
                          int64_t n_edges, int64_t n_vertices, float *dP,
                          float *dQ, void *stream);
+/* batch_data (train.py:135-171): the frames of a batch merged into one
+ * disjoint graph -- every array the concatenation of the frames' arrays,
+ * keypoint indices and edge rows moved up by the points / centres of the
+ * frames before them (`:150-160`) -- as ONE launch: job j copies n_words 4-byte
+ * words from src to dst (device pointers; dst points INTO the merged array),
+ * adding add0 to even and add1 to odd words as int32 (keypoint indices [k,1]:
+ * add0 = add1 = points before; edge rows [E,2]: add0 = points before, add1 =
+ * centres before; float arrays: 0, 0).  jobs_host is a HOST array. */
+typedef struct pgnn_merge_job {
+  const void *src;
+  void *dst;
+  int64_t n_words;
+  int32_t add0, add1;
+} pgnn_merge_job;
+int pgnn_merge_rows(const pgnn_merge_job *jobs_host, int32_t n_jobs,
+                    void *stream);
 /* PointSetPooling edge features [f(src), xyz(src) - xyz(kp(dst)), 0...] as a
  * [n_edges, 16] matrix (gnn.py:256-267).                                     */
 int pgnn_pool_features_fwd(const float *point_features, int32_t n_feat,

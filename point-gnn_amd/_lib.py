@@ -40,6 +40,12 @@ class WgradJob(ctypes.Structure):
                 ("n_out", c_i32), ("accumulate", c_i32), ("reserved", c_i32)]
 
 
+class MergeJob(ctypes.Structure):
+    """struct pgnn_merge_job (pgnn_merge_rows)"""
+    _fields_ = [("src", c_vp), ("dst", c_vp), ("n_words", c_i64),
+                ("add0", c_i32), ("add1", c_i32)]
+
+
 class PackJob(ctypes.Structure):
     """One record of pgnn_pack_fc_many's job table."""
     _fields_ = [("w", c_vp), ("b", c_vp), ("dst", c_vp), ("k_in", c_i32),
@@ -302,6 +308,7 @@ _SIGNATURES = {
     "pgnn_pool_features_fwd": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i64,
                                        c_vp, c_vp]),
     "pgnn_relu_mask_mul": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
+    "pgnn_merge_rows": (c_i32, [ctypes.POINTER(MergeJob), c_i32, c_vp]),
     "pgnn_scatter_max_bwd_f32": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32,
                                          c_i32, c_vp, c_i64, c_vp, c_i64, c_vp,
                                          c_vp, c_i64, c_i32, c_vp]),

@@ -1651,6 +1651,57 @@ extern "C" int pgnn_pool_features_wide_fwd(
   PGNN_GUARD_END
 }
 
+// ---- batch_data (train.py:135-171): frames merged into one disjoint graph ------
+// Every array of the batch is a concatenation of the frames' arrays; index
+// arrays (keypoint indices, edge rows) move up by the points / centres of the
+// frames before them.  One launch for the whole batch instead of a concatenate
+// and an add per array and frame: job j copies n_words 4-byte words, adding
+// add[w & 1] to int32 words (add = {0, 0}: plain copy).
+namespace {
+constexpr int kMergeJobs = 48;
+struct MergeJobsDev {
+  pgnn_merge_job j[kMergeJobs];
+  int n;
+};
+__global__ void merge_rows_kernel(MergeJobsDev js) {
+  const pgnn_merge_job &job = js.j[blockIdx.y];
+  const int32_t *src = (const int32_t *)job.src;
+  int32_t *dst = (int32_t *)job.dst;
+  const int32_t a0 = job.add0, a1 = job.add1;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+       i < job.n_words; i += (int64_t)gridDim.x * blockDim.x)
+    dst[i] = src[i] + ((i & 1) ? a1 : a0);
+}
+}  // namespace
+
+extern "C" int pgnn_merge_rows(const pgnn_merge_job *jobs_host, int32_t n_jobs,
+                               void *stream_) {
+  PGNN_GUARD_BEGIN
+  hipStream_t stream = (hipStream_t)stream_;
+  PGNN_REQUIRE(n_jobs >= 0 && (n_jobs == 0 || jobs_host), PGNN_E_INVALID,
+               "merge_rows: bad argument");
+  for (int first = 0; first < n_jobs; first += kMergeJobs) {
+    MergeJobsDev js;
+    js.n = 0;
+    int64_t longest = 0;
+    for (int i = first; i < n_jobs && js.n < kMergeJobs; ++i) {
+      const pgnn_merge_job &j = jobs_host[i];
+      PGNN_REQUIRE(j.n_words >= 0 && (j.n_words == 0 || (j.src && j.dst)),
+                   PGNN_E_INVALID, "merge_rows: bad job");
+      if (j.n_words == 0) continue;
+      js.j[js.n++] = j;
+      if (j.n_words > longest) longest = j.n_words;
+    }
+    if (js.n == 0) continue;
+    hipLaunchKernelGGL(merge_rows_kernel,
+                       dim3(grid_for(longest, 256), (unsigned)js.n), dim3(256), 0,
+                       stream, js);
+  }
+  PGNN_HIP(hipGetLastError());
+  return 0;
+  PGNN_GUARD_END
+}
+
 extern "C" int pgnn_relu_mask_mul(float *dY, const float *Y, int64_t count,
                                   void *stream_) {
   PGNN_GUARD_BEGIN

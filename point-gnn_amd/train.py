@@ -48,6 +48,11 @@ def batch_data(batch_list):
     (n_input_v, n_coords, n_kps, n_edges, n_labels, n_boxes,
      n_valid) = zip(*batch_list)
     is_torch = isinstance(n_input_v[0], torch.Tensor)
+    if is_torch and n_input_v[0].is_cuda:
+        merged = _batch_data_device(n_input_v, n_coords, n_kps, n_edges,
+                                    n_labels, n_boxes, n_valid)
+        if merged is not None:
+            return merged
     cat = (lambda xs: torch.cat(list(xs), dim=0)) if is_torch else \
         (lambda xs: np.concatenate(list(xs), axis=0))
     level_num = len(n_coords[0])
@@ -81,6 +86,77 @@ def batch_data(batch_list):
             cat(n_boxes), cat(n_valid))
 
 
+def _batch_data_device(n_input_v, n_coords, n_kps, n_edges, n_labels, n_boxes,
+                       n_valid):
+    """batch_data for CUDA tensors of 4-byte elements as ONE launch
+    (pgnn_merge_rows): the merged arrays are allocated, every frame's piece is
+    a copy job, index arrays carry their offsets in the job.  None when an
+    array is not 4-byte / contiguous-izable that way (the caller concatenates
+    with torch then)."""
+    ok4 = (torch.float32, torch.int32)
+    frames = len(n_input_v)
+    levels = len(n_coords[0])
+    groups = []       # (list of per-frame tensors, add0s, add1s)
+    zeros = [0] * frames
+    groups.append((list(n_input_v), zeros, zeros))
+    for lvl in range(levels):
+        groups.append(([n_coords[b][lvl] for b in range(frames)], zeros, zeros))
+    for lvl in range(levels - 1):
+        pts = np.cumsum([0] + [int(n_coords[b][lvl].shape[0])
+                               for b in range(frames)])[:-1].tolist()
+        ctr = np.cumsum([0] + [int(n_kps[b][lvl].shape[0])
+                               for b in range(frames)])[:-1].tolist()
+        if int(np.max(pts + ctr + [0])) >= 2 ** 31:
+            return None
+        groups.append(([n_kps[b][lvl] for b in range(frames)], pts, pts))
+        groups.append(([n_edges[b][lvl] for b in range(frames)], pts, ctr))
+    for arrs in (n_labels, n_boxes, n_valid):
+        groups.append((list(arrs), zeros, zeros))
+    outs, jobs, keep = [], [], []
+    for tensors, a0, a1 in groups:
+        t0 = tensors[0]
+        if any((not t.is_cuda) or t.dtype not in ok4 or t.dtype != t0.dtype or
+               t.shape[1:] != t0.shape[1:] for t in tensors):
+            return None
+        is_idx = any(a0) or any(a1)
+        if is_idx and (t0.dtype != torch.int32 or
+                       int(np.prod(t0.shape[1:])) not in (1, 2)):
+            return None
+        rows = sum(int(t.shape[0]) for t in tensors)
+        out = torch.empty((rows,) + tuple(t0.shape[1:]), dtype=t0.dtype,
+                          device=t0.device)
+        at = 0
+        width = int(np.prod(t0.shape[1:])) if t0.dim() > 1 else 1
+        for t, x0, x1 in zip(tensors, a0, a1):
+            t = t.contiguous()
+            keep.append(t)
+            n = int(t.numel())
+            if n:
+                jobs.append((t.data_ptr(), out.data_ptr() + 4 * at, n,
+                             int(x0), int(x1) if width == 2 else int(x0)))
+            at += n
+        outs.append(out)
+    arr = (_lib.MergeJob * max(1, len(jobs)))()
+    for i, (src, dst, n, x0, x1) in enumerate(jobs):
+        arr[i].src, arr[i].dst, arr[i].n_words = src, dst, n
+        arr[i].add0, arr[i].add1 = x0, x1
+    _lib.check(_lib.load().pgnn_merge_rows(arr, len(jobs), _lib.stream_ptr()),
+               "pgnn_merge_rows")
+    del keep
+    it = iter(outs)
+    input_v = next(it)
+    coords = [next(it) for _ in range(levels)]
+    kp_out, edge_out = [], []
+    for lvl in range(levels - 1):
+        kp_out.append(next(it))
+        merged = next(it)
+        if all(getattr(n_edges[b][lvl], "_pgnn_sorted", 0) == 1
+               for b in range(frames)):
+            merged._pgnn_sorted = 1
+        edge_out.append(merged)
+    return (input_v, coords, kp_out, edge_out, next(it), next(it), next(it))
+
+
 def _world(group=None):
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
@@ -103,7 +179,7 @@ def allreduce_endpoint_counts(n_local, nv_local, device, group=None,
 
 
 def allreduce_endpoint_counts_device(n_local, nv_local, device, group=None,
-                                     force=False, comm=None):
+                                     force=False, comm=None, out=None):
     """The same, left ON THE DEVICE: a float64 [2] tensor the loss kernel
     reads (pgnn_loss_fwd_bwd_counts), so a multi-rank step has no host wait
     between its forward and its backward pass.  nv_local may be a Python
@@ -111,15 +187,18 @@ def allreduce_endpoint_counts_device(n_local, nv_local, device, group=None,
     comm.Communicator): the reduction is pgnn_allreduce_sum_f64 on the current
     stream (RCCL behind the C ABI) instead of torch.distributed's; `force`:
     issue the collective for a world of one rank too (its fixed cost, and the
-    proof that the path runs, on a 1-GPU box)."""
+    proof that the path runs, on a 1-GPU box); `out`: a float64 [2] device
+    buffer to use (the step's result record)."""
     import torch.distributed as dist
+    counts = out if out is not None else torch.empty(
+        2, dtype=torch.float64, device=device)
+    # (fills, not an upload: nothing of the host's pageable memory on the
+    # step's stream)
+    counts[0:1].fill_(float(n_local))
     if isinstance(nv_local, torch.Tensor):
-        counts = torch.stack([
-            torch.full((), float(n_local), dtype=torch.float64, device=device),
-            nv_local.to(device=device, dtype=torch.float64).reshape(())])
+        counts[1:2].copy_(nv_local.reshape(1))
     else:
-        counts = torch.tensor([float(n_local), float(nv_local)],
-                              dtype=torch.float64, device=device)
+        counts[1:2].fill_(float(nv_local))
     if comm is not None:
         if comm.world > 1 or force:
             comm.allreduce_sum(counts)
@@ -1295,7 +1374,8 @@ class Trainer(object):
                                self.cls_topk, self.loc_topk)
 
     def loss_and_grads(self, logits, pred, labels, gt_box, valid, n_total,
-                       nv_total, want_grads=True, counts_dev=None, sel=None):
+                       nv_total, want_grads=True, counts_dev=None, sel=None,
+                       sums_out=None):
         """sums4 = [sum CE, sum loc, n, n_valid] (device double tensor),
         dlogits [K,nc], dpred [K,nc,L] for the globally normalised loss.
         counts_dev: the global (n_total, nv_total) as a device float64 [2]
@@ -1306,7 +1386,7 @@ class Trainer(object):
         if self.cls_topk or self.loc_topk:
             return self._loss_and_grads_top_k(
                 logits, pred, labels, gt_box, valid, n_total, nv_total,
-                want_grads, counts_dev, sel)
+                want_grads, counts_dev, sel, sums_out)
         dev = self.device
         k = int(logits.shape[0])
         lg = logits if logits.stride(1) == 1 else logits.contiguous()
@@ -1314,7 +1394,8 @@ class Trainer(object):
         gt = gt_box.to(device=dev, dtype=torch.float32).reshape(
             k, self.box_len).contiguous()
         va = valid.to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
-        sums = torch.zeros(4, dtype=torch.float64, device=dev)
+        sums = sums_out if sums_out is not None else torch.empty(
+            4, dtype=torch.float64, device=dev)   # (zeroed by the entries)
         dlog = torch.empty((k, self.nc), dtype=torch.float32, device=dev) \
             if want_grads else None
         dpred = torch.empty((k, self.nc, self.box_len), dtype=torch.float32,
@@ -1357,7 +1438,8 @@ class Trainer(object):
         return sums, dlog, dpred
 
     def _loss_and_grads_top_k(self, logits, pred, labels, gt_box, valid,
-                              n_total, nv_total, want_grads, counts_dev, sel):
+                              n_total, nv_total, want_grads, counts_dev, sel,
+                              sums_out=None):
         dev = self.device
         k = int(logits.shape[0])
         lg, labels, gt, va = self._loss_inputs(logits, labels, gt_box, valid)
@@ -1365,7 +1447,8 @@ class Trainer(object):
         if sel is None:
             sel = self.top_k_selection(lg, pred, labels, gt, va)
         sel_c, sel_l = sel
-        sums = torch.zeros(4, dtype=torch.float64, device=dev)
+        sums = sums_out if sums_out is not None else torch.empty(
+            4, dtype=torch.float64, device=dev)   # (zeroed by the entry)
         dlog = torch.empty((k, self.nc), dtype=torch.float32, device=dev) \
             if want_grads else None
         dpred = torch.empty((k, self.nc, self.box_len), dtype=torch.float32,
@@ -1561,6 +1644,10 @@ class Trainer(object):
         back at once, train.py:563-575; the values are the same)."""
         (input_v, coords, kps, edges, labels, boxes, valid) = batch
         self.grad.zero_()
+        # the step's numbers, written in place by their kernels: [sum CE, sum
+        # loc, n, n_valid | L1 of the weights | global n, n_valid] -- no
+        # concatenate at the end
+        rec = torch.empty(7, dtype=torch.float64, device=self.device)
         va = torch.as_tensor(valid).to(self.device, torch.float32).reshape(-1)
         k = int(va.shape[0])
         multi = self._multi()
@@ -1578,7 +1665,7 @@ class Trainer(object):
             if num_valid is not None:
                 counts_dev = allreduce_endpoint_counts_device(
                     k, float(num_valid), self.device, self.pg,
-                    self.force_collective, self.comm)
+                    self.force_collective, self.comm, out=rec[5:7])
         elif num_valid is not None:
             counts = (float(k), float(num_valid))
         logits, pred = self.forward(input_v, coords, kps, edges)
@@ -1591,18 +1678,20 @@ class Trainer(object):
         if self.loc_topk:
             counts_dev = allreduce_endpoint_counts_device(
                 k, (va * sel[1]).sum(), self.device, self.pg,
-                self.force_collective and multi, self.comm if multi else None)
+                self.force_collective and multi, self.comm if multi else None,
+                out=rec[5:7])
         elif multi and counts_dev is None:
             counts_dev = allreduce_endpoint_counts_device(
                 k, va.sum(), self.device, self.pg, self.force_collective,
-                self.comm)
+                self.comm, out=rec[5:7])
         elif not multi and counts is None:
             counts = (float(k), float(va.sum().item()))
         # unify_copies: global endpoint counts (train.py:268-284)
         n_total, nv_total = counts if counts is not None else (None, None)
         sums, dlog, dpred = self.loss_and_grads(
             logits, pred, torch.as_tensor(labels), torch.as_tensor(boxes), va,
-            n_total, nv_total, counts_dev=counts_dev, sel=sel)
+            n_total, nv_total, counts_dev=counts_dev, sel=sel,
+            sums_out=rec[0:4])
         ev = getattr(self, 'allreduce_events', None)
         # with a Communicator the native step enqueues the all-reduce itself,
         # right behind its last gradient kernel (pgnn_trainer_backward_sync);
@@ -1623,7 +1712,7 @@ class Trainer(object):
         # Everything the device still has to do is queued BEFORE the host reads
         # anything: the L1 term of the weights this step used, SGD, the image
         # refresh.  The step's numbers then come back in one copy.
-        l1 = torch.empty(1, dtype=torch.float64, device=self.device)
+        l1 = rec[4:5]
         _lib.check(self.lib.pgnn_l1_norm(         # (the call zeroes `l1` first)
             _lib.ptr(self.flat), _lib.ptr(self.is_weight), self.flat.numel(),
             _lib.ptr(l1), self._st()), "pgnn_l1_norm")
@@ -1632,8 +1721,8 @@ class Trainer(object):
             self.repack()
             self.global_step += 1
             self.opt_step += 1
-        parts = [sums, l1] if counts_dev is None else [sums, l1, counts_dev]
-        res = StepResult(self, torch.cat(parts), counts, lr)
+        res = StepResult(self, rec[:5] if counts_dev is None else rec, counts,
+                         lr)
         if after_enqueue is not None:
             # (behind the collective and the update: the host reads of a graph
             # build must not hold back the all-reduce's launch)

@@ -730,7 +730,8 @@ def test_other_optimizers_follow_tf_update_rules(dev, opt, kwargs, tmp_path):
         # another optimizer's checkpoint: weights and step resume, Adam's
         # slots AND its bias-correction clock start fresh
         sgd_dir = tmp_path / "sgd"
-        sgd = train.Trainer(cfg, train_config=dict(tcfg, optimizer='sgd'),
+        sgd = train.Trainer(cfg, train_config=dict(tcfg, optimizer='sgd',
+                                                   optimizer_kwargs={}),
                             seed=1, device=dev)
         sgd.global_step = 1000
         sgd.save_checkpoint(str(sgd_dir))
@@ -844,6 +845,46 @@ def test_two_frame_batch_equals_two_ranks(dev):
         e_max, e_fro = _grad_errors(g_merged[n], ref)
         # (observed: max-entry 1.2e-4, Frobenius 3.2e-5 -- a one-GNN-layer model)
         assert e_fro < 2e-4 and e_max < 1e-3, (n, e_max, e_fro)
+
+
+def test_batch_data_on_the_device_equals_the_numpy_merge(dev):
+    """train.py:135-171 as one launch (pgnn_merge_rows, CUDA tensors in) ==
+    the NumPy concatenate / offset loop, bit for bit: two, three and five
+    frames, a frame without edges at a level, the sorted flag carried over."""
+    import torch
+    from pointgnn_amd import train
+
+    def to_dev(b):
+        f = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        out = (f(b[0]), [f(c) for c in b[1]], [f(k) for k in b[2]],
+               [f(e) for e in b[3]], f(b[4]), f(b[5]), f(b[6]))
+        for e in out[3]:
+            e._pgnn_sorted = 1
+        return out
+    frames = [_tiny_batch(seed=5), _tiny_batch(seed=6, fixture="graph_small.npz"),
+              _tiny_batch(seed=7), _tiny_batch(seed=8, fixture="graph_small.npz"),
+              _tiny_batch(seed=9)]
+    hollow = list(_tiny_batch(seed=3))
+    hollow[3] = [hollow[3][0], hollow[3][1][:0]]        # no level-1 edges
+    frames.insert(2, tuple(hollow))
+    for n in (2, 3, 6):
+        want = train.batch_data(frames[:n])
+        got = train.batch_data([to_dev(b) for b in frames[:n]])
+        flat_w = [want[0]] + list(want[1]) + list(want[2]) + list(want[3]) + \
+            list(want[4:])
+        flat_g = [got[0]] + list(got[1]) + list(got[2]) + list(got[3]) + \
+            list(got[4:])
+        assert len(flat_w) == len(flat_g)
+        for w, g in zip(flat_w, flat_g):
+            assert g.is_cuda and tuple(g.shape) == tuple(w.shape)
+            assert np.array_equal(g.cpu().numpy(), w), n
+        assert all(getattr(e, "_pgnn_sorted", 0) == 1 for e in got[3])
+    # an array the launch does not take (float64 coordinates): torch's path
+    wide = to_dev(frames[0])
+    wide = (wide[0], [c.double() for c in wide[1]]) + wide[2:]
+    out = train.batch_data([wide, wide])
+    assert out[1][0].dtype == torch.float64
+    assert out[1][0].shape[0] == 2 * wide[1][0].shape[0]
 
 
 @pytest.mark.parametrize("rows,k_in,n_cols,nseg,ties", [
