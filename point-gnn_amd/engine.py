@@ -426,7 +426,10 @@ class InferenceEngine(object):
         for lg, bx in outs:     # allocated on a side stream, used by the caller
             lg.record_stream(cur)
             bx.record_stream(cur)
-        self.check_edge_range()
+        if not self._edge_range_clean():
+            return self._rerun_batch_f32(
+                lambda: self.run_frames_on_streams(frames, n_streams,
+                                                   gnn_priority))
         return outs
 
     def _priority_streams(self, n):
@@ -574,8 +577,33 @@ class InferenceEngine(object):
             for lg, bx in outs:
                 lg.record_stream(cur)
                 bx.record_stream(cur)
-        self.check_edge_range()
+        if not self._edge_range_clean():
+            return self._rerun_batch_f32(
+                lambda: self.run_frames_pipelined(
+                    frames, compute_streams, graph_cus, lookahead, deferred,
+                    graph_streams))
         return outs
+
+    def _edge_range_clean(self):
+        """edge_arith 'f16x2': True when no frame since the last look left
+        fp16's safe range (always True for the other arithmetics)."""
+        return self.model.edge_arith != 'f16x2' or self.model.edge_range_ok()
+
+    def _rerun_batch_f32(self, run):
+        """The range guard of 'f16x2' tripped somewhere in a batch (the flag is
+        the model's, not a frame's): the batch again with the fp32 edge stage
+        -- correct results instead of an exception and a discarded batch.
+        `f16x2_batch_reruns` counts how often."""
+        self.f16x2_batch_reruns = getattr(self, "f16x2_batch_reruns", 0) + 1
+        shapes = len(self.frame_shapes)
+        self.model.edge_arith = 'f32'
+        try:
+            # (the first pass noted the batch's shapes already)
+            outs = run()
+            del self.frame_shapes[shapes:]
+            return outs
+        finally:
+            self.model.edge_arith = 'f16x2'
 
     def check_edge_range(self):
         """edge_arith 'f16x2' only: raises when an activation of a frame run

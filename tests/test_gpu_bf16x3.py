@@ -375,3 +375,41 @@ def test_f16x2_flags_activations_out_of_range(dev):
     rc = lib.pgnn_pack_fc_f16x2(w.ctypes.data, b.ctypes.data, c, c,
                                 host.ctypes.data)
     assert rc == _lib.E_UNSUPPORTED
+
+
+def test_engine_reruns_a_flagged_f16x2_batch_in_fp32(dev):
+    """A batch in which the 'f16x2' range guard trips (the batch
+    entry points raised and threw every output away): the engine runs the
+    batch again with the fp32 edge stage and returns those results -- the
+    fp32 engine's, bit for bit -- instead."""
+    import torch
+    from pointgnn_amd import configs, weights
+    from pointgnn_amd.engine import InferenceEngine
+    from pointgnn_amd.synthetic import synthetic_cloud
+    cfg = configs.car_auto_config(1)
+    params = weights.init_params(cfg, seed=4, bias_scale=0.05)
+    name = "layer1/combined_features/fully_connected_1/biases"
+    params[name] = params[name] + np.float32(40000.0)   # h ~ 4e4 > 16384
+    frames = []
+    for s in range(4):
+        xyz, inten = synthetic_cloud(seed=s, preset="small")
+        frames.append((T(xyz, dev), T(inten, dev)))
+    ref = InferenceEngine(cfg, params, device=dev, edge_arith="f32")
+    want = ref.run_frames_on_streams(frames, 2)
+    eng = InferenceEngine(cfg, params, device=dev, edge_arith="f16x2")
+    got = eng.run_frames_on_streams(frames, 2)
+    assert eng.f16x2_batch_reruns == 1 and eng.model.edge_arith == "f16x2"
+    assert len(eng.frame_shapes) == len(frames)
+    pip = eng.run_frames_pipelined(frames, compute_streams=2, deferred=True,
+                                   graph_streams=2)
+    torch.cuda.synchronize()
+    assert eng.f16x2_batch_reruns == 2
+    for (l0, b0), (l1, b1), (l2, b2) in zip(want, got, pip):
+        assert torch.isfinite(l0).all()
+        assert torch.equal(l0, l1) and torch.equal(b0, b1)
+        assert torch.equal(l0, l2) and torch.equal(b0, b2)
+    # in range: no rerun
+    ok = InferenceEngine(cfg, weights.init_params(cfg, seed=4, bias_scale=0.05),
+                         device=dev, edge_arith="f16x2")
+    ok.run_frames_on_streams(frames, 2)
+    assert getattr(ok, "f16x2_batch_reruns", 0) == 0
