@@ -51,7 +51,6 @@ prof)
     db=$(find $OUT/prof_$what -name "*.db" | head -1)
     python tools/prof_summary.py "$db" $OUT/${what}_kernel_stats > /dev/null 2>> $S
     if [ $what = train ]; then
-      python tools/trace_dump.py "$db" --last-ms 11 --out $OUT/train_trace.txt
     fi
     rm -rf $OUT/prof_$what
     head -12 $OUT/${what}_kernel_stats.md | cut -c1-160 >> $S
