@@ -51,6 +51,7 @@ prof)
     db=$(find $OUT/prof_$what -name "*.db" | head -1)
     python tools/prof_summary.py "$db" $OUT/${what}_kernel_stats > /dev/null 2>> $S
     if [ $what = train ]; then
+      python tools/train_step_trace.py "$db" --out $OUT/train_step_trace.txt > $OUT/train_step_summary.txt
     fi
     rm -rf $OUT/prof_$what
     head -12 $OUT/${what}_kernel_stats.md | cut -c1-160 >> $S
