@@ -977,6 +977,14 @@ def train_measure(torch, dev, rank, world, dist, config_name, preset, steps,
         "pgnn_allreduce_step (RCCL behind the C ABI, world %d)" % comm.world
         if comm is not None else "torch.distributed all_reduce (%s)"
         % dist.get_backend())
+    if comm is not None:
+        # (explicitly, while the runtime is alive; the trainer keeps no other
+        # use for it after the measurement)
+        torch.cuda.synchronize()
+        tr.comm = None
+        if tr.force_collective:
+            tr.force_collective = False
+        comm.destroy()
     return elapsed, ar_ms, tr, cfg, list(shapes), out
 
 

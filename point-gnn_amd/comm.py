@@ -172,6 +172,11 @@ class Communicator(object):
             _lib.check(self.lib.pgnn_comm_destroy(h), "pgnn_comm_destroy")
 
     def __del__(self):
+        # (not at interpreter shutdown: the HIP runtime and RCCL may be gone
+        # by then, and a communicator dies with its process anyway)
+        import sys
+        if sys is None or sys.is_finalizing():
+            return
         try:
             self.destroy()
         except Exception:
