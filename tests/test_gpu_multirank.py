@@ -9,6 +9,7 @@ import socket
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -102,3 +103,30 @@ def test_bench_two_ranks_real_engine_on_one_gpu():
     assert r["value"] > 0 and r["dtype"] == "f32"
     assert abs(r["value"] - 2 * 3 * 4 / (r["ms_per_step"] * 3e-3)) \
         < 1e-6 * r["value"]
+
+
+def test_bench_train_two_ranks_on_one_gpu():
+    """`bench.py --train --gpus 2` in the same test mode: the loader thread,
+    the counts' and the gradient's collectives (through the gloo group here:
+    RCCL refuses two ranks per device), the max-over-ranks timing and the
+    post-region all-reduce timing of the training line."""
+    env = dict(os.environ, PGNN_BENCH_ONE_GPU="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    root = os.path.dirname(HERE)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--train", "--gpus",
+           "2", "--steps", "4", "--warmup", "3", "--frames", "4",
+           "--no-live-pmc"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    r = lines[0]
+    c = r["config"]
+    assert r["n_gpus"] == 2 and r["steps"] == 4
+    assert c["distributed"] == {"world_size": 2, "backend": "gloo"}
+    assert "all_reduce (gloo)" in c["collective"]
+    assert c["allreduce_ms"] > 0 and c["allreduce_bytes"] == 4 * c["params"]
+    assert abs(r["value"] - 2 * 2 * 4 / (r["ms_per_step"] * 4e-3)) \
+        < 1e-6 * r["value"]
+    assert all(np.isfinite(v) for v in c["last_loss"].values())
