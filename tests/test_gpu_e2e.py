@@ -439,3 +439,29 @@ def test_inside_box_host_equals_device_kernel():
         host = KO.inside_box_host(label, pts)
         assert np.array_equal(dev.cpu().numpy(), host)
         assert 0 < host.sum() < len(pts)
+
+
+def test_pipelined_frame_loop_propagates_a_loader_failure(tmp_path):
+    """A frame the loader cannot read (truncated velodyne file) ends the
+    pipelined loop with that error -- no hang, no half-alive threads -- and the
+    frames before it are on disk."""
+    import threading
+    from pointgnn_amd import kitti_dataset as KD, run as RUN, weights
+    cfg = configs.get_config("car_auto_T1")
+    dirs = _kitti_tree(tmp_path, ["tiny"] * 8)
+    ds = KD.KittiDataset(*dirs)
+    bad = os.path.join(dirs[1], ds.get_filename(5) + ".bin")
+    with open(bad, "r+b") as f:
+        f.truncate(4 * 4 * 100 + 6)          # not a whole number of points
+    params = weights.init_params(cfg, seed=3, bias_scale=0.05)
+    before = threading.active_count()
+    with pytest.raises(ValueError):
+        RUN.run_dataset(ds, cfg, None, str(tmp_path / "out"), params=params,
+                        in_flight=2, prefetch=2)
+    assert threading.active_count() == before
+    assert os.path.exists(os.path.join(str(tmp_path / "out"), "data",
+                                       ds.get_filename(0) + ".txt"))
+    # the same tree without the bad frame runs through
+    td = RUN.run_dataset(ds, cfg, None, str(tmp_path / "out2"), params=params,
+                         frame_indices=[0, 1, 2, 3, 4, 6, 7], in_flight=2)
+    assert td['frames'] == 7
