@@ -448,7 +448,10 @@ int pgnn_point_set_pooling_fwd_dyn(const float *point_features, int32_t n_feat,
  * against `out` gives the arg-max rows: rows and maxima come from the same
  * accumulators).  PGNN_E_UNSUPPORTED, having done nothing, for other chains
  * or fewer than ~65k edges: run pgnn_pool_features_fwd + pgnn_mlp_fwd per
- * layer + pgnn_scatter_max_f32 instead.                                     */
+ * layer + pgnn_scatter_max_f32 instead.  edges_sorted: bit 0 = grouped by
+ * ascending dst; bit 1 = `out` already holds lowest() (the native trainer
+ * fills it in the launch before: no fill launch inside the call); the same
+ * two bits on pgnn_edge_mlp_scatter_max_rows_fwd.                            */
 int pgnn_point_set_pooling_rows_fwd(const float *point_features, int32_t n_feat,
                                     const float *point_xyz,
                                     const int32_t *keypoint_indices,

@@ -2700,8 +2700,10 @@ extern "C" int pgnn_point_set_pooling_rows_fwd(
     PGNN_REQUIRE(acts_host[i] && (uintptr_t)acts_host[i] % 16 == 0, PGNN_E_INVALID,
                  "point_set_pooling_rows: activation buffers must be 16-byte "
                  "aligned");
-  rc = fill_lowest(out, (int64_t)num_keypoints * ld_out, stream);
-  if (rc) return rc;
+  if (!(edges_sorted & 2)) {  // bit 1: `out` holds lowest() already
+    rc = fill_lowest(out, (int64_t)num_keypoints * ld_out, stream);
+    if (rc) return rc;
+  }
   PoolArgs pa = {point_features, n_feat, point_xyz, keypoint_indices, edges};
   SegArgs sa = {out, ld_out, num_keypoints, edges_sorted & 1};
   return launch_pool_ws(p, pa, n_edges, sa, cus, nullptr, stream, acts_host,
@@ -2741,8 +2743,10 @@ extern "C" int pgnn_edge_mlp_scatter_max_rows_fwd(
   PGNN_REQUIRE(((uintptr_t)P % 16 == 0) && ((uintptr_t)Q % 16 == 0) &&
                    ((uintptr_t)h1_out % 16 == 0),
                PGNN_E_INVALID, "edge_mlp_rows: P/Q/H1 must be 16-byte aligned");
-  rc = fill_lowest(out, (int64_t)num_vertices * ld_out, stream);
-  if (rc) return rc;
+  if (!(edges_sorted & 2)) {  // bit 1: `out` holds lowest() already
+    rc = fill_lowest(out, (int64_t)num_vertices * ld_out, stream);
+    if (rc) return rc;
+  }
   EdgeArgs ea = {P, Q, ld_pq, edges};
   SegArgs sa = {out, ld_out, num_vertices, edges_sorted & 1};
   if (p.chain.l[0].nt == 19)

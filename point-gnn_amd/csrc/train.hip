@@ -1324,6 +1324,17 @@ __global__ __launch_bounds__(1024) void l1_norm_kernel(
   }
 }
 
+// two 16-byte-aligned regions zeroed by ONE launch (n0, n1 in 16-byte words)
+__global__ void zero2_kernel(uint4 *__restrict__ a, int64_t n0,
+                             uint4 *__restrict__ b, int64_t n1) {
+  const uint4 z = {0u, 0u, 0u, 0u};
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n0 + n1;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    if (i < n0) a[i] = z;
+    else b[i - n0] = z;
+  }
+}
+
 // dP and dQ zeroed by one fill when the caller laid them out back to back
 // (the trainer does): a fill is a launch, and the step is a chain of them.
 inline hipError_t zero_pair(float *a, float *b, size_t n, hipStream_t stream) {
@@ -1443,10 +1454,14 @@ int segfc_bwd_impl(const float *Y, int64_t ld_y, const int32_t *seg_ids,
   PGNN_REQUIRE(n_rows >= 0 && n_cols > 0 && n_cols <= 512 && num_segments >= 0 &&
                    k_in > 0 && k_in <= 512,
                PGNN_E_INVALID, "segmax_fc_bwd: bad sizes");
+  bool pair_pending = false;  // dP / dQ zeroed together with the counts below
   if (edges && num_segments > 0) {
     PGNN_REQUIRE(dP && dQ && ld_pq >= k_in, PGNN_E_INVALID,
                  "edge_segmax_fc_bwd: bad dP / dQ");
-    PGNN_HIP(zero_pair(dP, dQ, (size_t)num_segments * ld_pq, stream));
+    if (n_rows == 0 || dQ != dP + (size_t)num_segments * ld_pq)
+      PGNN_HIP(zero_pair(dP, dQ, (size_t)num_segments * ld_pq, stream));
+    else
+      pair_pending = true;
   }
   if (n_rows == 0 || num_segments == 0) return 0;
   PGNN_REQUIRE(Y && seg_ids && out && grad_out && WT && dW &&
@@ -1469,8 +1484,21 @@ int segfc_bwd_impl(const float *Y, int64_t ld_y, const int32_t *seg_ids,
   SegFcWs w;
   segfc_carve(workspace, n_rows, n_cols, num_segments, k_in, &w);
   // (counts + the tie flag behind them; a whole number of 16-byte words -- the
-  // region has 256 spare bytes -- so the runtime does not split off a tail fill)
-  PGNN_HIP(hipMemsetAsync(w.cnt, 0, (size_t)num_segments * w.ldc * 4 + 16, stream));
+  // region has 256 spare bytes)
+  if (pair_pending) {
+    // ... and the back-to-back dP | dQ in the SAME launch: a fill is a launch,
+    // and the step is a chain of them
+    const int64_t w0 = ((int64_t)num_segments * w.ldc * 4 + 16) / 16;
+    const int64_t w1 = (int64_t)num_segments * ld_pq * 2 * 4 / 16;
+    PGNN_REQUIRE(((uintptr_t)w.cnt % 16 == 0) && ((uintptr_t)dP % 16 == 0) &&
+                     ((int64_t)num_segments * ld_pq * 8 % 16 == 0),
+                 PGNN_E_INVALID, "edge_segmax_fc_bwd: dP must be 16-byte aligned");
+    hipLaunchKernelGGL(zero2_kernel, dim3(grid_for(w0 + w1, 2048)), dim3(256), 0,
+                       stream, (uint4 *)w.cnt, w0, (uint4 *)dP, w1);
+  } else {
+    PGNN_HIP(hipMemsetAsync(w.cnt, 0, (size_t)num_segments * w.ldc * 4 + 16,
+                            stream));
+  }
   const int cols4 = (n_cols + 3) / 4;
   hipLaunchKernelGGL(segmax_count_win4_kernel,
                      dim3(grid_for(n_rows * cols4, 8192)), dim3(256), 0, stream, Y,

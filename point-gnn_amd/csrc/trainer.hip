@@ -108,7 +108,14 @@ __global__ void pre_edge_prep_kernel(const float *__restrict__ h, int64_t ldh,
                                      const float *__restrict__ wx,
                                      float *__restrict__ hx, int ldhx,
                                      float *__restrict__ xyz_out,
-                                     float *__restrict__ Q, int ld_q) {
+                                     float *__restrict__ Q, int ld_q,
+                                     float *__restrict__ fill,
+                                     int64_t fill_count) {
+  // (the stage's aggregation buffer starts from lowest(): filled here instead
+  // of by a launch of its own in front of the fused edge kernel)
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+       idx < fill_count; idx += (int64_t)gridDim.x * blockDim.x)
+    fill[idx] = kFloatLowest;
   const int w = ldhx > ld_q ? ldhx : ld_q;
   const int64_t total = rows * w;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -157,10 +164,15 @@ __global__ void stage_input_grad_kernel(const float *__restrict__ dh, int ldh,
 }
 
 __global__ void edge_dst_kernel(const int32_t *__restrict__ edges, int64_t n,
-                                int32_t *__restrict__ dst) {
+                                int32_t *__restrict__ dst,
+                                float *__restrict__ fill, int64_t fill_count) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * blockDim.x)
     dst[i] = edges[2 * i + 1];
+  // (optional: a pooling stage's aggregation buffer starts from lowest())
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < fill_count;
+       i += (int64_t)gridDim.x * blockDim.x)
+    fill[i] = kFloatLowest;
 }
 
 inline unsigned blocks_for(int64_t total, int cap = 2048) {
@@ -738,12 +750,20 @@ int forward_impl(Ctx &c, Saved &sv) {
   // the destination column of a level's edge list, extracted once per level
   // (the three GNN stages of the shipped models share level 1's)
   int32_t *dst_of[PGNN_TRAIN_MAX_LEVELS] = {nullptr};
-  auto level_dst = [&](int lvl, int64_t E) -> int32_t * {
+  // (fill / fill_count: a buffer the same launch sets to lowest(); *filled
+  // says whether that happened -- not when the level's column existed already)
+  auto level_dst = [&](int lvl, int64_t E, float *fill = nullptr,
+                       int64_t fill_count = 0,
+                       bool *filled = nullptr) -> int32_t * {
+    if (filled) *filled = false;
     if (dst_of[lvl]) return dst_of[lvl];
     int32_t *d = c.ws.i32(E > 0 ? E : 1);
-    if (!c.dry && E > 0 && d)
+    if (!c.dry && E > 0 && d) {
       hipLaunchKernelGGL(edge_dst_kernel, dim3(blocks_for(E)), dim3(256), 0,
-                         c.stream, b.edges[lvl], E, d);
+                         c.stream, b.edges[lvl], E, d, fill,
+                         fill ? fill_count : (int64_t)0);
+      if (filled && fill) *filled = true;
+    }
     dst_of[lvl] = d;
     return d;
   };
@@ -755,9 +775,12 @@ int forward_impl(Ctx &c, Saved &sv) {
       PoolSaved &p = sv.pool[si];
       p.feat = c.ws.f(E, 16);
       for (size_t i = 0; i < s.a.size(); ++i) p.act[i] = c.ws.f(E, pad16(s.a[i].ref.n_out));
-      p.dst = level_dst(lvl, E);
       const int wa = pad16(s.a.back().ref.n_out);
       p.agg = c.ws.f(K, wa);
+      // (the launch that extracts the level's dst column also sets the
+      // aggregation buffer to lowest(): no fill launch of its own)
+      bool agg_filled = false;
+      p.dst = level_dst(lvl, E, p.agg, (int64_t)K * wa, &agg_filled);
       for (size_t i = 0; i < s.b.size(); ++i) p.oact[i] = c.ws.f(K, pad16(s.b[i].ref.n_out));
       if (!c.dry) {
         PGNN_REQUIRE(s.a[0].ref.k_in == b.n_feat + 3, PGNN_E_INVALID,
@@ -784,8 +807,9 @@ int forward_impl(Ctx &c, Saved &sv) {
           float *acts[4] = {p.act[0], p.act[1], p.act[2], p.act[3]};
           rc = pgnn_point_set_pooling_rows_fwd(
               b.input_v, b.n_feat, b.coords[lvl], b.keypoints[lvl], b.edges[lvl],
-              E, (int32_t)K, Ls, 4, b.edges_sorted[lvl] ? 1 : 0, p.agg, wa, acts,
-              wa, c.stream);
+              E, (int32_t)K, Ls, 4,
+              (b.edges_sorted[lvl] ? 1 : 0) | (agg_filled ? 2 : 0), p.agg, wa,
+              acts, wa, c.stream);
           if (rc == 0) fused = true;
           else if (rc != PGNN_E_UNSUPPORTED) return rc;
         }
@@ -865,7 +889,7 @@ int forward_impl(Ctx &c, Saved &sv) {
                              dim3(blocks_for(K * (ldhx > wq ? ldhx : wq), 8192)),
                              dim3(256), 0, c.stream, h, (int64_t)ld_h, cc,
                              b.coords[lvl], delta, ld_delta, K, s.wx, g.hx, ldhx,
-                             g.xo, g.q, wq);
+                             g.xo, g.q, wq, g.agg, (int64_t)K * wa);
         }
         rc = fc_fwd(c, w1, g.hx, pad16(cc + 3), K, false, nullptr, 0, g.p);
         if (rc) return rc;
@@ -880,8 +904,8 @@ int forward_impl(Ctx &c, Saved &sv) {
           L2.relu_from = 0;
           rc = pgnn_edge_mlp_scatter_max_rows_fwd(
               g.p, g.q, wq, s.a[1].ref.k_in, b.edges[lvl], E, (int32_t)K, &L2,
-              b.edges_sorted[lvl] ? 1 : 0, g.agg, wa, g.eact[1], wa,
-              c.t.h1 ? g.eact[0] : nullptr, c.stream);
+              (b.edges_sorted[lvl] ? 1 : 0) | (K > 0 ? 2 : 0), g.agg, wa,
+              g.eact[1], wa, c.t.h1 ? g.eact[0] : nullptr, c.stream);
           if (rc == 0) fused = true;
           else if (rc != PGNN_E_UNSUPPORTED) return rc;
         }
