@@ -221,11 +221,24 @@ def apply_kernel_trace(line, trace, prefix):
     holds), the event figures stay beside them."""
     if line is None or not trace:
         return line
-    hits = [(k, v) for k, v in trace.items()
-            if k.startswith(prefix) and isinstance(v, dict)]
-    if not hits:
-        return line
-    name, v = max(hits, key=lambda kv: kv[1]["total_us"])
+    if isinstance(prefix, (tuple, list)):
+        # a stage of several launches: the sum of its kernels' averages
+        parts = []
+        for pre in prefix:
+            hits = [(k, v) for k, v in trace.items()
+                    if k.startswith(pre) and isinstance(v, dict)]
+            if not hits:
+                return line
+            parts.append(max(hits, key=lambda kv: kv[1]["total_us"]))
+        name = " + ".join(k for k, _ in parts)
+        v = {"avg_us": sum(p["avg_us"] for _, p in parts),
+             "calls": min(p["calls"] for _, p in parts)}
+    else:
+        hits = [(k, v) for k, v in trace.items()
+                if k.startswith(prefix) and isinstance(v, dict)]
+        if not hits:
+            return line
+        name, v = max(hits, key=lambda kv: kv[1]["total_us"])
     ev_us = line["avg_launch_us"]
     work = line["achieved"] * ev_us          # TFLOP/s x us
     line["avg_launch_us_events"] = ev_us
@@ -511,17 +524,33 @@ def roofline_pool_kernel(torch, engine, reps=10, frame=None):
     agg = torch.empty((k, gnn.padded_width(chain.n_out)), device=x.device)
     n_e = int(e0.shape[0])
 
+    import ctypes
+    ws_bytes = ctypes.c_size_t(0)
+    _lib.check(lib.pgnn_point_set_pooling_workspace_bytes(
+        chain.array, chain.n, n_feat, n_e, 0, ctypes.byref(ws_bytes)),
+        "pooling workspace query")
+    work = torch.empty(max(ws_bytes.value // 4, 1), device=x.device)
+
     def run():
-        _lib.check(lib.pgnn_point_set_pooling_fwd(
+        # (with a workspace of 0 bytes: exactly pgnn_point_set_pooling_fwd)
+        _lib.check(lib.pgnn_point_set_pooling_fwd_ws(
             _lib.ptr(f), n_feat, _lib.ptr(x), _lib.ptr(kp), _lib.ptr(e0), n_e,
             k, chain.array, chain.n, 1, _lib.ptr(agg), agg.stride(0),
-            _lib.ptr(_lib.sched_ws()), _lib.stream_ptr()), "pooling kernel")
+            _lib.ptr(_lib.sched_ws()), None, None,
+            _lib.ptr(work) if ws_bytes.value else None, ws_bytes.value,
+            _lib.stream_ptr()), "pooling kernel")
     dur = time_kernel(run, reps, torch)
     dims = [n_feat + 3] + widths
     flops = sum(2 * a * b for a, b in zip(dims[:-1], dims[1:])) * n_e
     return {
-        "kernel": "pool_ws_kernel / fused_mlp_kernel<POOL> (gather + point "
+        "kernel": ("pool_hidden_kernel + edge_ws_kernel<16, 8, false, true> "
+                   "(two launches, hidden rows [E0, 256] through a %.2f GB "
+                   "workspace: gather + point MLP %s + scatter-max)"
+                   % (ws_bytes.value / 1e9, "->".join(map(str, dims))))
+        if ws_bytes.value else
+                  "pool_ws_kernel / fused_mlp_kernel<POOL> (gather + point "
                   "MLP %s + scatter-max)" % "->".join(map(str, dims)),
+        "launches": 2 if ws_bytes.value else 1,
         "bound": "mfma", "achieved": flops / dur / 1e12,
         "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
         "frac": flops / dur / 1e12 / FP32_MFMA_PEAK_TF,
@@ -2139,7 +2168,9 @@ def main(argv=None):
             pl = roofline_pool_kernel(torch, engine, frame=(x, f))
             if pl is not None:
                 res["roofline_pool"] = apply_kernel_trace(
-                    pl, trace, "pool_ws_kernel")
+                    pl, trace, ("pool_hidden_kernel",
+                                "edge_ws_kernel<16, 8, false, true>")
+                    if pl.get("launches") == 2 else "pool_ws_kernel")
             if trace:
                 # one frame alone, per kernel family (us per frame)
                 per_frame = {}

@@ -441,6 +441,39 @@ int pgnn_point_set_pooling_fwd_dyn(const float *point_features, int32_t n_feat,
                                    const pgnn_dyn_count *num_keypoints,
                                    void *stream);
 
+/* The same with a caller-provided workspace (gnn.py:256-277; the reference
+ * materialises every layer's [E, C] tensor, this entry at most one of them).
+ * Point MLPs whose last layer does not fit one CU's LDS -- ped_cyl's
+ * 4-32-64-128-256-512 (configs/ped_cyl_auto_T3_trainval_config) -- run as TWO
+ * launches: the chain up to the 256-wide hidden layer, its rows written to
+ * `workspace` ([edges_cap, 256] floats), then the last layer weights-stationary
+ * in four column groups with the segmented max (csrc/pool_split.h): 0.78 of
+ * the fp32-MFMA peak against the one-launch LDS-tile kernel's 0.67, the maxima
+ * bit-identical.  pgnn_point_set_pooling_workspace_bytes says how much
+ * workspace a chain / edge count asks for (0: the one-launch kernels are used
+ * and `workspace` may be NULL; edges_hint as pgnn_dyn_count.hint, 0 = none).
+ * n_edges / num_keypoints: both NULL (host-sized form: edges_cap and
+ * keypoints_cap are the counts) or both given (capacity form).  `workspace`:
+ * 16-byte aligned, owned by the caller, free for reuse once the call's work on
+ * `stream` is done; NULL or a chain the split form does not cover: exactly
+ * pgnn_point_set_pooling_fwd(_dyn).                                          */
+int pgnn_point_set_pooling_workspace_bytes(const pgnn_fc_layer *layers_host,
+                                           int32_t n_layers, int32_t n_feat,
+                                           int64_t edges_cap,
+                                           int64_t edges_hint, size_t *bytes);
+int pgnn_point_set_pooling_fwd_ws(const float *point_features, int32_t n_feat,
+                                  const float *point_xyz,
+                                  const int32_t *keypoint_indices,
+                                  const int32_t *edges, int64_t edges_cap,
+                                  int32_t keypoints_cap,
+                                  const pgnn_fc_layer *layers_host,
+                                  int32_t n_layers, int32_t edges_sorted,
+                                  float *out, int64_t ld_out, int32_t *sched_ws,
+                                  const pgnn_dyn_count *n_edges,
+                                  const pgnn_dyn_count *num_keypoints,
+                                  void *workspace, size_t workspace_bytes,
+                                  void *stream);
+
 /* Training forward of the same: the fused kernel also writes the point MLP's
  * activations -- acts_host[0..3] (a HOST array of four DEVICE pointers):
  * [n_edges, 32], [n_edges, 64], [n_edges, 128] and [n_edges, ld_last] for the

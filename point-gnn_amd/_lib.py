@@ -180,6 +180,16 @@ _SIGNATURES = {
                                                ctypes.POINTER(DynCount),
                                                ctypes.POINTER(DynCount),
                                                c_vp]),
+    "pgnn_point_set_pooling_workspace_bytes": (c_i32, [
+        ctypes.POINTER(FcLayer), c_i32, c_i32, c_i64, c_i64,
+        ctypes.POINTER(c_sz)]),
+    "pgnn_point_set_pooling_fwd_ws": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp,
+                                              c_i64, c_i32,
+                                              ctypes.POINTER(FcLayer), c_i32,
+                                              c_i32, c_vp, c_i64, c_vp,
+                                              ctypes.POINTER(DynCount),
+                                              ctypes.POINTER(DynCount),
+                                              c_vp, c_sz, c_vp]),
     "pgnn_edge_mlp_scatter_max_fwd_dyn": (c_i32, [c_vp, c_vp, c_i64, c_i32,
                                                   c_vp, c_i64, c_i32,
                                                   ctypes.POINTER(FcLayer),

@@ -70,7 +70,7 @@ struct EdgeWsArgs {
   // is its upper bound -- min(*n_dev, n_edges) rows are processed
   const int32_t *n_dev;
   const float *wp;  // packed weights (pgnn_pack_fc), bias follows
-  int nt;           // column tiles of the layer (= its K groups)
+  int nt;           // column tiles of the layer (= its K groups, except ROWS)
   int relu_from;
   float *out;
   int64_t ldo;
@@ -291,7 +291,12 @@ __device__ __forceinline__ void ws_epilogue(const ARGS &a, const float *bias_lds
 
 // tiles [tile_first, tile_last) of 16 edge rows, column tiles t0 .. t0+NTG-1
 // whose fragments sit in `wl` ([KQ][NTG][64] float4)
-template <int KQ, int NTG, bool EMIT>
+//
+// ROWS: the B operands are not gathered but READ -- `P` holds one ready row of
+// 16 KQ floats per edge ([n_edges, 4 * ldv4]; `Q` and the edges' src column are
+// not read): the second half of the split pooling stage (pool_split.h), where
+// the rows are the point MLP's hidden activations.
+template <int KQ, int NTG, bool EMIT, bool ROWS = false>
 __device__ __forceinline__ void edge_ws_body(const EdgeWsArgs &a,
                                              const v4f *__restrict__ wl, int t0,
                                              const float *bias_lds,
@@ -379,7 +384,7 @@ __device__ __forceinline__ void edge_ws_body(const EdgeWsArgs &a,
 #pragma unroll
       for (int t = 0; t < NTG; ++t) acc[t] = (v4f){0.f, 0.f, 0.f, 0.f};
     } else {
-    const int my_s = nxt_ok ? nxt.x : 0;
+    [[maybe_unused]] const int my_s = nxt_ok ? nxt.x : 0;
     my_d = nxt_ok ? nxt.y : -1;
     nxt_ok = tile + 1 < tile_last && e0 + 16 + n < E;
     nxt = e2[nxt_ok ? e0 + 16 + n : 0];
@@ -387,7 +392,14 @@ __device__ __forceinline__ void edge_ws_body(const EdgeWsArgs &a,
     // rows past the end / foreign ids gather row 0 (finite values in rows the
     // epilogue never reads)
     v4f in[KQ];
-    {
+    if constexpr (ROWS) {
+      const int64_t row = e0 + n < E ? e0 + n : 0;
+      const v4f *__restrict__ hr = P4 + row * a.ldv4 + g;
+#pragma unroll
+      for (int q = 0; q < KQ; ++q) in[q] = hr[4 * q];
+      // all KQ loads in flight before the first use
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
       const int dq = ((unsigned)my_d < (unsigned)a.num_segments) ? my_d : 0;
       const v4f *__restrict__ pr = P4 + (int64_t)my_s * a.ldv4 + g;
       const v4f *__restrict__ qr = Q4 + (int64_t)dq * a.ldv4 + g;
@@ -554,7 +566,7 @@ __device__ __forceinline__ WsWho ws_who_balanced(const EdgeWsArgs &a, int slice,
   return w;
 }
 
-template <int KQ, int NTMAX, bool EMIT = false>
+template <int KQ, int NTMAX, bool EMIT = false, bool ROWS = false>
 __global__ __launch_bounds__(64 * kWsWaves) void edge_ws_kernel(EdgeWsArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   v4f *wl = reinterpret_cast<v4f *>(smem);
@@ -603,7 +615,7 @@ __global__ __launch_bounds__(64 * kWsWaves) void edge_ws_kernel(EdgeWsArgs a) {
     }
     if ((int)threadIdx.x < 16 * ntg)
       bias_lds[threadIdx.x] =
-          a.wp[(size_t)a.nt * a.nt * 256 + 16 * t0 + threadIdx.x];
+          a.wp[(size_t)KQ * a.nt * 256 + 16 * t0 + threadIdx.x];
   }
   __syncthreads();
   // 16-row tiles of this slice.  The first (100 - pool_pct) % of them are
@@ -651,11 +663,13 @@ __global__ __launch_bounds__(64 * kWsWaves) void edge_ws_kernel(EdgeWsArgs a) {
   int32_t *counter = a.sched ? a.sched + 2 + slice * kWsMaxGroups + grp : nullptr;
   for (;;) {
     if (ntg == NTMAX)
-      edge_ws_body<KQ, NTMAX, EMIT>(a, wl, t0, bias_lds, tile_first, tile_last,
-                                    lane, tsw, stamped, n_edges);
+      edge_ws_body<KQ, NTMAX, EMIT, ROWS>(a, wl, t0, bias_lds, tile_first,
+                                          tile_last, lane, tsw, stamped,
+                                          n_edges);
     else
-      edge_ws_body<KQ, NTMAX - 1, EMIT>(a, wl, t0, bias_lds, tile_first,
-                                        tile_last, lane, tsw, stamped, n_edges);
+      edge_ws_body<KQ, NTMAX - 1, EMIT, ROWS>(a, wl, t0, bias_lds, tile_first,
+                                              tile_last, lane, tsw, stamped,
+                                              n_edges);
     if (pool == 0) break;
     int c = 0;
     if (lane == 0)

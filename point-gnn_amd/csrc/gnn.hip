@@ -17,6 +17,7 @@
 #include "edge_ws_bf16.h"
 #include "edge_ws_f16.h"
 #include "pool_ws.h"
+#include "pool_split.h"
 #include "pool_ws_f16.h"
 
 namespace pgnn {
@@ -1054,7 +1055,8 @@ void ws_balance(EdgeWsArgs &a, int cus, const double *cost);  // below
 
 // Weights-stationary edge kernel (edge_ws.h): one workgroup per CU, the column
 // tiles in groups that fit the LDS, the 16-row tiles in one slice per XCD.
-template <int KQ, int NTMAX>
+// ROWS: `ea.P` holds one ready input row per edge (pool_split.h).
+template <int KQ, int NTMAX, bool ROWS = false>
 int launch_edge_ws(const LayerDev &L, const EdgeArgs &ea, int64_t n_edges,
                    const SegArgs &sa, int cus, int32_t *sched,
                    hipStream_t stream, float *rows_out = nullptr,
@@ -1126,16 +1128,18 @@ int launch_edge_ws(const LayerDev &L, const EdgeArgs &ea, int64_t n_edges,
     if (g_ws_balance >= 2) ws_balance(a, cus, cost);
   }
   const size_t lds = (size_t)KQ * NTMAX * 1024 + 16 * NTMAX * sizeof(float);
-  if (rows_out) {  // training forward: the rows are written as well
-    auto kern = edge_ws_kernel<KQ, NTMAX, true>;
-    const int lrc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
-    if (lrc) return lrc;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(per_slice * a.xcds)),
-                       dim3(64 * kWsWaves), lds, stream, a);
-    PGNN_HIP(hipGetLastError());
-    return 0;
+  if constexpr (!ROWS) {
+    if (rows_out) {  // training forward: the rows are written as well
+      auto kern = edge_ws_kernel<KQ, NTMAX, true>;
+      const int lrc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
+      if (lrc) return lrc;
+      hipLaunchKernelGGL(kern, dim3((unsigned)(per_slice * a.xcds)),
+                         dim3(64 * kWsWaves), lds, stream, a);
+      PGNN_HIP(hipGetLastError());
+      return 0;
+    }
   }
-  auto kern = edge_ws_kernel<KQ, NTMAX>;
+  auto kern = edge_ws_kernel<KQ, NTMAX, false, ROWS>;
   {
     const int lrc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
     if (lrc) return lrc;
@@ -1234,6 +1238,60 @@ int launch_pool_ws(const Plan &p, const PoolArgs &pa, int64_t n_edges,
                      a);
   PGNN_HIP(hipGetLastError());
   return 0;
+}
+
+// Split pooling stage (pool_split.h): ped_cyl's 4-32-64-128-256-512 chain, the
+// hidden rows [n_edges, 256] through a caller-provided workspace.
+constexpr int kPoolSplitHidden = 256;
+bool pool_split_applies(const Plan &p, int64_t n_edges, int cus) {
+  if (g_mlp_debug & (8192 | 1024)) return false;
+  const ChainDev &c = p.chain;
+  if (c.n != 5 || c.l[0].kq != 1 || c.l[0].nt != 2 || c.l[1].nt != 4 ||
+      c.l[2].nt != 8 || c.l[3].kq != 8 || c.l[3].nt != 16 || c.l[4].kq != 16 ||
+      c.l[4].nt != 32)
+    return false;
+  if (cus < 64 || cus % 8 != 0) return false;
+  if ((size_t)16 * 8 * 1024 + 16 * 16 * sizeof(float) > device_max_lds())
+    return false;
+  if (g_mlp_debug & 16384) return true;
+  return n_edges >= (int64_t)16 * 2 * kWsWaves * cus;
+}
+
+int launch_pool_split(const Plan &p, const PoolArgs &pa, int64_t n_edges,
+                      const SegArgs &sa, int cus, int32_t *sched,
+                      hipStream_t stream, const int32_t *n_dev, float *hidden) {
+  PoolWsArgs a = {};
+  a.n_dev = n_dev;
+  a.feat = pa.feat;
+  a.nfeat = pa.nfeat;
+  a.xyz = pa.xyz;
+  a.kp = pa.kp;
+  a.edges = pa.edges;
+  a.n_edges = n_edges;
+  a.l0 = p.chain.l[0];
+  a.l1 = p.chain.l[1];
+  a.l2 = p.chain.l[2];
+  a.wp = p.chain.l[3].wp;
+  a.kq = p.chain.l[3].kq;
+  a.nt = p.chain.l[3].nt;
+  a.relu_from = p.chain.l[3].relu_from;
+  a.num_segments = sa.num_segments;
+  a.prio = g_ws_prio;
+  a.a4_out = hidden;
+  a.ld4 = kPoolSplitHidden;
+  a.slices = 8;
+  const size_t lds = (size_t)8 * 16 * 1024 + 16 * 16 * sizeof(float);
+  auto kern = pool_hidden_kernel;
+  {
+    const int lrc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
+    if (lrc) return lrc;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)cus), dim3(64 * kWsWaves), lds, stream,
+                     a);
+  PGNN_HIP(hipGetLastError());
+  const EdgeArgs ea = {hidden, nullptr, kPoolSplitHidden, pa.edges};
+  return launch_edge_ws<16, 8, true>(p.chain.l[4], ea, n_edges, sa, cus, sched,
+                                     stream, nullptr, 0, nullptr, n_dev);
 }
 
 int fill_lowest(float *out, int64_t count, hipStream_t stream) {
@@ -1422,7 +1480,8 @@ int pooling_fwd_impl(const float *point_features, int32_t n_feat,
                      int32_t num_keypoints, const pgnn_fc_layer *layers,
                      int32_t n_layers, int32_t edges_sorted, float *out,
                      int64_t ld_out, int32_t *sched_ws, hipStream_t stream,
-                     const Dyn &de, const Dyn &dk) {
+                     const Dyn &de, const Dyn &dk, void *workspace = nullptr,
+                     size_t workspace_bytes = 0) {
   PGNN_REQUIRE(n_edges >= 0 && num_keypoints >= 0 && n_feat >= 0 && n_feat <= 13,
                PGNN_E_INVALID, "pooling: bad sizes (n_feat <= 13)");
   Plan p;
@@ -1465,6 +1524,15 @@ int pooling_fwd_impl(const float *point_features, int32_t n_feat,
     if (pool_ws_applies(p, expected(de, n_edges), cus))
       return launch_pool_ws(p, pa, n_edges, sa, cus, sched_ws, stream, nullptr,
                             0, de.dev);
+    // (likewise bit-identical; needs the hidden rows' workspace)
+    if (workspace && pool_split_applies(p, expected(de, n_edges), cus)) {
+      PGNN_REQUIRE((uintptr_t)workspace % 16 == 0 &&
+                       workspace_bytes >= (size_t)n_edges * kPoolSplitHidden *
+                                              sizeof(float),
+                   PGNN_E_INVALID, "pooling: workspace too small / unaligned");
+      return launch_pool_split(p, pa, n_edges, sa, cus, sched_ws, stream, de.dev,
+                               static_cast<float *>(workspace));
+    }
   }
   if (msub == 4 && pa.reg_hidden == 1)
     return launch_fused<4, PRO_POOL_R3>(p, n_edges, ra, pa, ea, sa, stream,
@@ -1911,6 +1979,45 @@ extern "C" int pgnn_point_set_pooling_fwd_dyn(
                           edges_sorted, out, ld_out, sched_ws,
                           (hipStream_t)stream_, dyn_of(n_edges),
                           dyn_of(num_keypoints));
+  PGNN_GUARD_END
+}
+
+extern "C" int pgnn_point_set_pooling_workspace_bytes(
+    const pgnn_fc_layer *layers, int32_t n_layers, int32_t n_feat,
+    int64_t edges_cap, int64_t edges_hint, size_t *bytes) {
+  PGNN_GUARD_BEGIN
+  PGNN_REQUIRE(bytes && layers && edges_cap >= 0 && n_feat >= 0 && n_feat <= 13,
+               PGNN_E_INVALID, "pooling_workspace_bytes: bad arguments");
+  *bytes = 0;
+  Plan p;
+  int rc = make_plan(layers, n_layers, n_feat + 3, p);
+  if (rc) return rc;
+  int cus = device_cu_count();
+  if (g_ws_reserve > 0 && cus - g_ws_reserve >= 64) cus -= g_ws_reserve;
+  const int64_t n_sel =
+      (edges_hint > 0 && edges_hint < edges_cap) ? edges_hint : edges_cap;
+  if (pool_split_applies(p, n_sel, cus))
+    *bytes = (size_t)edges_cap * kPoolSplitHidden * sizeof(float);
+  return 0;
+  PGNN_GUARD_END
+}
+
+extern "C" int pgnn_point_set_pooling_fwd_ws(
+    const float *point_features, int32_t n_feat, const float *point_xyz,
+    const int32_t *keypoint_indices, const int32_t *edges, int64_t edges_cap,
+    int32_t keypoints_cap, const pgnn_fc_layer *layers, int32_t n_layers,
+    int32_t edges_sorted, float *out, int64_t ld_out, int32_t *sched_ws,
+    const pgnn_dyn_count *n_edges, const pgnn_dyn_count *num_keypoints,
+    void *workspace, size_t workspace_bytes, void *stream_) {
+  PGNN_GUARD_BEGIN
+  PGNN_REQUIRE((n_edges == nullptr) == (num_keypoints == nullptr) &&
+                   (!n_edges || (n_edges->dev && num_keypoints->dev)),
+               PGNN_E_INVALID, "pooling_ws: counts come as a pair");
+  return pooling_fwd_impl(point_features, n_feat, point_xyz, keypoint_indices,
+                          edges, edges_cap, keypoints_cap, layers, n_layers,
+                          edges_sorted, out, ld_out, sched_ws,
+                          (hipStream_t)stream_, dyn_of(n_edges),
+                          dyn_of(num_keypoints), workspace, workspace_bytes);
   PGNN_GUARD_END
 }
 

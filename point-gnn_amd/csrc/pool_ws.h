@@ -42,6 +42,7 @@ struct PoolWsArgs {
   int32_t *sched;
   int pool_pct;
   int chunk;
+  int slices;  // pool_split.h only: row slices (workgroup b -> slice b % slices)
   // training forward (EMIT kernel only): the activations of the four layers
   // are ALSO written -- a1 [E,32], a2 [E,64], a3 [E,128], a4 [E, ld4] -- for
   // the backward (a4 against `out` gives the arg-max rows; rows and maxima

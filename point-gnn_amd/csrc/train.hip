@@ -1789,7 +1789,7 @@ namespace pgnn {
 // workgroups (in-blocks x row slices) one weight-gradient launch aims for
 // (768 = 256 CUs x 3 resident workgroups of 48 KB LDS: exactly one wave of
 // workgroups; 1024 left a quarter-filled second wave and cost 6 % of the step)
-int g_wgrad_wg_target = 768;
+int g_wgrad_wg_target = 512;
 }  // namespace pgnn
 
 namespace {
@@ -2126,9 +2126,11 @@ int wg_many_target_slices(const pgnn_wgrad_job *jobs, int32_t n_jobs) {
   for (int i = 0; i < n_jobs; ++i)
     in_blocks += ((int64_t)jobs[i].k_in + 1 + 63) / 64;
   if (in_blocks < 1) in_blocks = 1;
-  // one full wave of workgroups over the whole batch of jobs: 3 per CU (48 KB
-  // of LDS each); a fourth per CU would start a second, quarter-filled round
-  int t = (int)((int64_t)3 * device_cu_count() / in_blocks);
+  // one full wave of workgroups over the whole batch of jobs: TWO per CU --
+  // 184 registers a wave (104 + 80 accumulators) allow two 4-wave workgroups
+  // per CU, whatever the 48 KB of LDS would admit: with three per CU a third of
+  // the grid ran as a second round (`wgrad_wg_target`, default 2 x 256)
+  int t = (int)((int64_t)g_wgrad_wg_target * device_cu_count() / 256 / in_blocks);
   return t < 1 ? 1 : t;
 }
 }  // namespace

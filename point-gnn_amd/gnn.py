@@ -580,8 +580,28 @@ class PointSetPooling(object):
                 if rc != _lib.E_UNSUPPORTED:
                     _lib.check(rc, "pgnn_point_set_pooling_f16x2_fwd")
                     done = True
+        ws_bytes = ctypes.c_size_t(0)
+        if not done:
+            # chains whose last layer does not fit one CU's LDS (ped_cyl's
+            # 4-32-64-128-256-512) run as two launches through a workspace of
+            # hidden rows (csrc/pool_split.h); everything else asks for none
+            _lib.check(lib.pgnn_point_set_pooling_workspace_bytes(
+                point_chain.array, point_chain.n, n_feat, int(edges.shape[0]),
+                int(cnt_e.hint) if cnt_e is not None else 0,
+                ctypes.byref(ws_bytes)),
+                "pgnn_point_set_pooling_workspace_bytes")
         if done:
             pass
+        elif ws_bytes.value:
+            # (a stream-ordered allocation of the caching allocator: the next
+            # frame on this stream gets the same block back)
+            work = torch.empty(ws_bytes.value // 4, dtype=torch.float32,
+                               device=xyz.device)
+            _lib.check(lib.pgnn_point_set_pooling_fwd_ws(
+                *args, cnt_e.arg() if cnt_e is not None else None,
+                cnt_k.arg() if cnt_k is not None else None, _lib.ptr(work),
+                ws_bytes.value, _lib.stream_ptr()),
+                "pgnn_point_set_pooling_fwd_ws")
         elif cnt_k is None and cnt_e is None:
             _lib.check(lib.pgnn_point_set_pooling_fwd(
                 *args, _lib.stream_ptr()), "pgnn_point_set_pooling_fwd")

@@ -860,6 +860,92 @@ def test_pool_weights_stationary_kernel_is_bit_identical(dev, case):
                                rtol=1e-4)
 
 
+@pytest.mark.parametrize("case", ["fanins", "shuffled", "ragged", "five_edges",
+                                  "one_segment", "capacity"])
+def test_pool_split_kernels_are_bit_identical(dev, case):
+    """PointSetPooling with ped_cyl's 4-32-64-128-256-512 point MLP: the
+    two-launch form (csrc/pool_split.h: chain up to the 256-wide hidden layer,
+    its rows through a workspace, last layer weights-stationary with the
+    segmented max; `mlp_debug` 16384 forces it below its size threshold) and
+    the one-launch LDS-tile kernel (8192) agree bit for bit and match the
+    float64 oracle; `capacity`: the counts on the device, buffers larger than
+    the graph."""
+    import ctypes
+    from pointgnn_amd import _lib, gnn
+    rng = np.random.default_rng(13)
+    cfg = configs.get_config("ped_cyl_auto_T3")
+    kw = cfg["model_kwargs"]["layer_configs"][0]["kwargs"]
+    assert list(kw["point_MLP_depth_list"]) == [32, 64, 128, 256, 512]
+    k, n_pts = 700, 6000
+    if case == "five_edges":
+        dst = np.array([3, 3, 3, 9, 600], np.int32)
+    elif case == "one_segment":
+        dst = np.full(70001, 5, np.int32)
+    else:
+        deg = rng.choice([1, 2, 3, 5, 9, 16, 17, 40, 64, 65, 130, 300], size=k)
+        dst = np.repeat(np.arange(k), deg).astype(np.int32)
+        if case == "ragged":
+            dst = dst[:len(dst) - len(dst) % 16 - 3]
+    src = rng.integers(0, n_pts, dst.shape[0]).astype(np.int32)
+    edges = np.stack([src, dst], axis=1)
+    if case == "shuffled":
+        edges = edges[rng.permutation(len(edges))]
+    xyz = rng.standard_normal((n_pts, 3)).astype(np.float32)
+    inten = rng.random((n_pts, 1)).astype(np.float32)
+    kp = rng.choice(n_pts, k, replace=False).astype(np.int32).reshape(-1, 1)
+    params = weights.init_params(cfg, seed=2, bias_scale=0.1)
+    store = _store(params, dev)
+
+    def run():
+        e_dev, kp_dev = T(edges, dev), T(kp, dev)
+        if case == "capacity":
+            import torch
+            pad_e = torch.full((len(edges) + 1000, 2), -7, dtype=torch.int32,
+                               device=dev)
+            pad_e[:len(edges)] = e_dev
+            pad_k = torch.zeros((k + 50, 1), dtype=torch.int32, device=dev)
+            pad_k[:k] = kp_dev
+            kp_dev = _lib.tag_count(pad_k, _lib.DeviceCount(
+                torch.tensor([k], dtype=torch.int32, device=dev), k))
+            e_dev = _lib.tag_count(pad_e, _lib.DeviceCount(
+                torch.tensor([len(edges)], dtype=torch.int32, device=dev),
+                len(edges)))
+        with gnn.parameters(store), gnn.variable_scope("layer1"):
+            return gnn.PointSetPooling().apply_regular(
+                T(inten, dev), T(xyz, dev), kp_dev, e_dev,
+                **kw).cpu().numpy()[:k]
+    # the forced form asks for a workspace, the tile kernel for none
+    chain = None
+    outs = {}
+    try:
+        for bits in (8192, 16384):
+            _lib.set_tunable("mlp_debug", bits)
+            outs[bits] = run()
+            with gnn.parameters(store), gnn.variable_scope("layer1"), \
+                    gnn.variable_scope("extract_vertex_features"):
+                chain = gnn._relu_chain(store, gnn._scope(),
+                                        list(kw["point_MLP_depth_list"]), False)
+            nbytes = ctypes.c_size_t(123)
+            _lib.check(_lib.load().pgnn_point_set_pooling_workspace_bytes(
+                chain.array, chain.n, 1, len(edges), 0, ctypes.byref(nbytes)),
+                "pgnn_point_set_pooling_workspace_bytes")
+            assert nbytes.value == (len(edges) * 256 * 4 if bits == 16384 else 0)
+        for pct in (0, 60):
+            _lib.set_tunable("ws_pool_pct", pct)
+            assert np.array_equal(run(), outs[8192], equal_nan=True), pct
+            assert int(_lib.sched_ws(dev).abs().sum().item()) == 0
+    finally:
+        _lib.set_tunable("mlp_debug", 0)
+        _lib.set_tunable("ws_pool_pct", 0)
+    assert np.array_equal(outs[8192], outs[16384], equal_nan=True)
+    with np.errstate(all="ignore"):
+        ref = gn.point_set_pooling(params, "layer1", inten, xyz, kp, edges,
+                                   dtype=np.float64)
+    fed = np.unique(dst)
+    np.testing.assert_allclose(outs[16384][fed, :256], ref[fed], atol=FP_TOL,
+                               rtol=1e-4)
+
+
 @pytest.mark.parametrize("auto_offset,k", [(True, 1000), (False, 37), (True, 16)])
 def test_vertex_pre_edge_equals_unfused_entries(dev, auto_offset, k):
     """pgnn_vertex_pre_edge_fwd == pgnn_mlp_fwd (offset chain) +
