@@ -1677,7 +1677,9 @@ def secondary_train(args, torch, dev):
     """BASELINE config 4 on one GPU (`car_auto_T3` training step, 2 frames per
     step, training graph kwargs): >= 10 timed steps and the whole-step MFMA
     roofline.  The 8-GPU form is `bench.py --train --gpus 8`."""
-    steps = max(16, min(24, args.steps))
+    # (48-64 steps = 0.15-0.2 s: a 20-step region is 60 ms, in which one slow
+    # phase of the loader thread against the stepping thread reads as 5 %)
+    steps = max(48, min(64, args.steps))
     fpg = 2
     # (8 warm-up steps: the first few size the trainer's workspace and the
     # allocator's pools for the graph tensors)
@@ -1697,6 +1699,13 @@ def secondary_train(args, torch, dev):
     }
     n_params = int(tr.flat.numel())
     del tr
+    torch.cuda.empty_cache()
+    # the same loop over the headline's 8-frame pool (frames 4-7 carry smaller
+    # training graphs than 0-3: what `bench.py --train` runs by default)
+    el8, _, tr8, _, _, _ = train_measure(
+        torch, dev, 0, 1, None, "car_auto_T3", "car", steps, 8, 8, fpg, True)
+    res["ms_per_step_8frame_pool"] = el8 / steps * 1e3
+    del tr8
     torch.cuda.empty_cache()
     # the step's collectives on one GPU: their fixed cost alone, and the same
     # timed loop with a world-1 RCCL communicator and every collective issued

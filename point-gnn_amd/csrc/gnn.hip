@@ -1241,7 +1241,11 @@ int launch_pool_ws(const Plan &p, const PoolArgs &pa, int64_t n_edges,
 }
 
 // Split pooling stage (pool_split.h): ped_cyl's 4-32-64-128-256-512 chain, the
-// hidden rows [n_edges, 256] through a caller-provided workspace.
+// hidden rows [n_edges, 256] through a caller-provided workspace.  (car's
+// 4-32-64-128-300 chain on the same form -- 64 -> 128 in LDS, rows [n_edges,
+// 128], 128 -> 300 as edge_ws_kernel<8, 7, ROWS> -- measured 310 us against
+// pool_ws.h's 296: its last layer is only 8 K groups deep, so a row tile
+// carries half the MFMA work over the same per-tile cost; not kept.)
 constexpr int kPoolSplitHidden = 256;
 bool pool_split_applies(const Plan &p, int64_t n_edges, int cus) {
   if (g_mlp_debug & (8192 | 1024)) return false;
