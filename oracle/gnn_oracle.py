@@ -27,9 +27,26 @@ FLOAT32_LOWEST = np.finfo(np.float32).min
 
 
 # ------------------------------------------------------------------ MLPs
+BATCH_NORM_EPSILON = 0.001   # slim.batch_norm's default
+
+
 def fully_connected(x, w, b, relu):
-    """slim.fully_connected with normalizer 'NONE' (gnn.py:93-103)."""
-    y = x @ w + b
+    """slim.fully_connected (gnn.py:93-103).  `b` an array: normalizer 'NONE',
+    act(x W + b).  `b` a tuple (moving_mean, moving_variance, beta or None,
+    gamma or None): the batch-norm normalizers of gnn.py:17-23 at inference
+    (slim creates no biases then) -- tf.nn.batch_normalization's documented
+    (y - mean) * rsqrt(var + eps) [* gamma] [+ beta], NOT folded, so that the
+    product's folded weights are checked against the unfolded expression.
+    UNPINNED: no shipped config or checkpoint uses a normalizer."""
+    if isinstance(b, tuple):
+        mean, var, beta, gamma = b
+        y = (x @ w - mean) / np.sqrt(var + x.dtype.type(BATCH_NORM_EPSILON))
+        if gamma is not None:
+            y = y * gamma
+        if beta is not None:
+            y = y + beta
+    else:
+        y = x @ w + b
     if relu:
         y = np.maximum(y, 0)
     return y
@@ -89,8 +106,17 @@ def _layers(params, scope, dtype):
         name = scope + '/fully_connected' + ('' if i == 0 else '_%d' % i)
         if name + '/weights' not in params:
             break
-        out.append((params[name + '/weights'].astype(dtype),
-                    params[name + '/biases'].astype(dtype)))
+        if name + '/biases' in params:
+            b = params[name + '/biases'].astype(dtype)
+        else:   # a batch-norm normalizer (see fully_connected)
+            bn = name + '/BatchNorm/'
+            b = (params[bn + 'moving_mean'].astype(dtype),
+                 params[bn + 'moving_variance'].astype(dtype),
+                 params[bn + 'beta'].astype(dtype)
+                 if bn + 'beta' in params else None,
+                 params[bn + 'gamma'].astype(dtype)
+                 if bn + 'gamma' in params else None)
+        out.append((params[name + '/weights'].astype(dtype), b))
         i += 1
     return out
 

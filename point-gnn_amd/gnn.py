@@ -96,8 +96,31 @@ class ParamStore(object):
         return name + '/weights' in self.params
 
     def fc(self, name):
-        return (self.params[name + '/weights'].astype(np.float32),
-                self.params[name + '/biases'].astype(np.float32))
+        """(W [in,out], b [out]) of one slim.fully_connected.  A layer built
+        with a batch-norm normalizer (gnn.py:17-23: 'fused_BN_center', 'BN',
+        'BN_center' -- slim then creates no biases but
+        `BatchNorm/{beta,moving_mean,moving_variance}`, gamma only with
+        scale=True) is returned FOLDED: at inference slim.batch_norm is the
+        per-column affine map (y - mean) / sqrt(var + 0.001) [* gamma] [+ beta]
+        of y = x W, i.e. the layer x W' + b' with W' = W s, b' = beta - mean s
+        (s in float64, rounded once)."""
+        w = self.params[name + '/weights']
+        if name + '/biases' in self.params:
+            return (w.astype(np.float32),
+                    self.params[name + '/biases'].astype(np.float32))
+        bn = name + '/BatchNorm/'
+        if bn + 'moving_mean' not in self.params:
+            raise KeyError("%s: neither biases nor BatchNorm statistics"
+                           % name)
+        mean = self.params[bn + 'moving_mean'].astype(np.float64)
+        var = self.params[bn + 'moving_variance'].astype(np.float64)
+        s = 1.0 / np.sqrt(var + BATCH_NORM_EPSILON)
+        if bn + 'gamma' in self.params:
+            s = s * self.params[bn + 'gamma'].astype(np.float64)
+        beta = self.params[bn + 'beta'].astype(np.float64) \
+            if bn + 'beta' in self.params else 0.0
+        return ((w.astype(np.float64) * s).astype(np.float32),
+                (beta - mean * s).astype(np.float32))
 
     def mlp(self, scope, n_layers):
         return [self.fc(n) for n in mlp_names(scope, n_layers)]
@@ -273,11 +296,24 @@ def _store():
     return _state.store
 
 
+# slim.batch_norm's default epsilon (the reference never overrides it)
+BATCH_NORM_EPSILON = 0.001
+# normalization_fn_dict keys (gnn.py:17-23) these INFERENCE operators accept:
+# the batch-norm kinds run on their moving statistics (is_training=False), a
+# per-column affine map that ParamStore.fc folds into the layer.  'IN'
+# (instance_normalization, gnn.py:9-15) takes its moments over all rows of the
+# tensor at run time -- a reduction over every edge between two layers of a
+# fused stage -- and has no device path; training with batch statistics has
+# none either (train.Trainer refuses such configs).
+FOLDED_NORMALIZATIONS = ('fused_BN_center', 'BN', 'BN_center')
+
+
 def _check_kinds(activation_type, normalization_type):
-    if normalization_type not in ('NONE', None):
+    if normalization_type not in ('NONE', None) + FOLDED_NORMALIZATIONS:
         raise NotImplementedError(
-            "normalization %r: only 'NONE' (what every shipped config uses) "
-            "has a device path" % (normalization_type,))
+            "normalization %r: 'NONE' (what every shipped config uses) and "
+            "the batch-norm kinds at inference have a device path"
+            % (normalization_type,))
     if activation_type != 'ReLU':
         raise NotImplementedError(
             "activation %r: only 'ReLU' has a device path" % (activation_type,))

@@ -187,6 +187,18 @@ class MultiLayerFastLocalGraphModelV2(object):
         [K, num_classes, box_encoding_len])."""
         if self._store is None:
             raise RuntimeError("call load_state_dict()/init_weights() first")
+        if is_training:
+            # slim.batch_norm(is_training=True) normalizes with the batch's own
+            # statistics (models.py:112 arg_scope): only the moving-statistics
+            # form is folded into the layers here
+            for cfg in self._layer_configs:
+                for key, val in (cfg.get('kwargs') or {}).items():
+                    if key.endswith('normalization_type') and \
+                            val in gnn.FOLDED_NORMALIZATIONS:
+                        raise NotImplementedError(
+                            "%s: %s = %r with is_training=True (batch "
+                            "statistics) has no device path" % (
+                                cfg['scope'], key, val))
         was_np = not isinstance(t_initial_vertex_features, torch.Tensor)
         if was_np:
             dev = self._store._dev()

@@ -548,6 +548,23 @@ _OPTIMIZERS = {
 }
 
 
+def check_trainable_kinds(config):
+    """gnn.py:17-32: the training step differentiates act = ReLU, normalizer =
+    NONE (every shipped config).  A config that asks for batch statistics or
+    another activation is refused -- it would otherwise be trained as if they
+    were absent."""
+    for lc in config['model_kwargs']['layer_configs']:
+        for key, val in (lc.get('kwargs') or {}).items():
+            if key.endswith('normalization_type') and \
+                    val not in ('NONE', None):
+                raise NotImplementedError(
+                    "%s: %s = %r has no training path (batch statistics are "
+                    "not differentiated)" % (lc['scope'], key, val))
+            if key.endswith('activation_type') and val != 'ReLU':
+                raise NotImplementedError(
+                    "%s: %s = %r has no training path" % (lc['scope'], key, val))
+
+
 class Trainer(object):
     def __init__(self, config, train_config=None, params=None, seed=0,
                  device=None, box_encoding_len=7, process_group=None,
@@ -619,8 +636,7 @@ class Trainer(object):
         mk = config['model_kwargs']
         if mk.get('regularizer_type') not in (None, 'l1'):
             raise NotImplementedError("regularizer %r" % mk['regularizer_type'])
-        self.l1_scale = float(mk['regularizer_kwargs']['scale']) \
-            if mk.get('regularizer_type') == 'l1' else 0.0
+        check_trainable_kinds(config)
         from .models import cls_loss_kind, loss_top_k
         # models.py:198-208: the loss entries may be dicts keyed by mode
         lcfg = {key: (val['train'] if isinstance(val, dict) and 'train' in val

@@ -1217,6 +1217,97 @@ def test_predict_end_to_end_device_graph(dev, name, preset, seed):
     np.testing.assert_allclose(boxes.cpu().numpy(), bx, atol=FP_TOL, rtol=1e-4)
 
 
+def batch_norm_variant(cfg, params, kind, seed=0):
+    """`cfg` with every *_normalization_type = `kind` and `params` rewritten
+    the way slim builds such layers (gnn.py:60-103): a normalized
+    fully_connected has no biases but BatchNorm/{moving_mean, moving_variance}
+    (+ beta when the kind centers); the last layer of an `is_logits` chain --
+    auto-offset MLP, update MLP (gnn.py:341-346, 367-372), predictor heads
+    (:150-160) -- keeps normalizer None and its biases."""
+    import copy
+    import re
+    cfg = copy.deepcopy(cfg)
+    for lc in cfg["model_kwargs"]["layer_configs"]:
+        for key in list(lc["kwargs"]):
+            if key.endswith("normalization_type"):
+                lc["kwargs"][key] = kind
+    rng = np.random.default_rng(seed)
+    chains = {}
+    for name in params:
+        m = re.match(r"(.*)/fully_connected(?:_(\d+))?/weights$", name)
+        if m:
+            chains.setdefault(m.group(1), []).append(int(m.group(2) or 0))
+    pooling = {lc["scope"] for lc in cfg["model_kwargs"]["layer_configs"]
+               if lc["type"] == "scatter_max_point_set_pooling"}
+    out = dict(params)
+    for scope, idx in chains.items():
+        top = scope.split("/")[0]
+        logits_chain = (scope.endswith("/combined_features") and
+                        top not in pooling) or scope.startswith("output/") \
+            or "/" not in scope
+        for i in idx:
+            if logits_chain and i == max(idx):
+                continue
+            fc = scope + "/fully_connected" + ("" if i == 0 else "_%d" % i)
+            n = params[fc + "/weights"].shape[1]
+            del out[fc + "/biases"]
+            out[fc + "/BatchNorm/moving_mean"] = \
+                (0.1 * rng.standard_normal(n)).astype(np.float32)
+            out[fc + "/BatchNorm/moving_variance"] = \
+                rng.uniform(0.5, 2.0, n).astype(np.float32)
+            if kind != "BN":          # center=False: no beta
+                out[fc + "/BatchNorm/beta"] = \
+                    (0.05 * rng.standard_normal(n)).astype(np.float32)
+    return cfg, out
+
+
+@pytest.mark.parametrize("kind", ["fused_BN_center", "BN", "BN_center"])
+def test_predict_batch_norm_kinds_at_inference(dev, kind):
+    """normalization_fn_dict's batch-norm kinds (gnn.py:17-23) at inference:
+    slim.batch_norm on its moving statistics is a per-column affine map, folded
+    into the layers when they are packed (ParamStore.fc); the float64 oracle
+    evaluates the UNfolded (y - mean) / sqrt(var + 0.001) + beta.  'IN' has no
+    device path and says so."""
+    from pointgnn_amd import graph_gen, models
+    cfg0 = configs.get_config("car_auto_T3")
+    cfg, params = batch_norm_variant(
+        cfg0, weights.init_params(cfg0, seed=4, bias_scale=0.05), kind)
+    assert not any(k.endswith("extract_vertex_features/fully_connected/biases")
+                   for k in params)
+    assert "layer2/fully_connected_1/biases" in params       # offset's logits
+    xyz, inten = synthetic_cloud(seed=4, preset="tiny")
+    fn = graph_gen.get_graph_generate_fn(cfg["graph_gen_method"])
+    coords, kps, edges = fn(T(xyz, dev), **cfg["runtime_graph_gen_kwargs"])
+    model = models.get_model(cfg["model_name"])(
+        num_classes=cfg["num_classes"], box_encoding_len=7, mode="test",
+        **cfg["model_kwargs"]).load_state_dict(params)
+    logits, boxes = model.predict(T(inten, dev), coords, kps, edges, False)
+    lg, bx = gn.predict(params, cfg, inten, [c.cpu().numpy() for c in coords],
+                        [k.cpu().numpy() for k in kps],
+                        [e.cpu().numpy() for e in edges], dtype=np.float64)
+    assert np.abs(lg).max() > 1e-3
+    np.testing.assert_allclose(logits.cpu().numpy(), lg, atol=FP_TOL, rtol=1e-4)
+    np.testing.assert_allclose(boxes.cpu().numpy(), bx, atol=FP_TOL, rtol=1e-4)
+    # the statistics matter: the same weights without them give other logits
+    plain = {k: v for k, v in params.items() if "/BatchNorm/" not in k}
+    for k in list(params):
+        if k.endswith("/BatchNorm/moving_mean"):
+            plain[k[:-len("/BatchNorm/moving_mean")] + "/biases"] = \
+                np.zeros_like(params[k])
+    lg0, _ = gn.predict(plain, cfg, inten, [c.cpu().numpy() for c in coords],
+                        [k.cpu().numpy() for k in kps],
+                        [e.cpu().numpy() for e in edges], dtype=np.float64)
+    assert np.abs(lg0 - lg).max() > 10 * FP_TOL
+    # instance normalization: moments over all rows at run time
+    cfg_in, _ = batch_norm_variant(
+        cfg0, weights.init_params(cfg0, seed=4, bias_scale=0.05), "IN")
+    bad = models.get_model(cfg_in["model_name"])(
+        num_classes=cfg["num_classes"], box_encoding_len=7, mode="test",
+        **cfg_in["model_kwargs"]).load_state_dict(params)
+    with pytest.raises(NotImplementedError, match="normalization 'IN'"):
+        bad.predict(T(inten, dev), coords, kps, edges, False)
+
+
 @pytest.mark.parametrize("name,preset", [("car_auto_T3", "car"),
                                          ("ped_cyl_auto_T3", "ped_dense")])
 def test_full_size_properties(dev, name, preset):

@@ -541,3 +541,48 @@ def test_f16x2_weight_images_natural_and_accumulator_order():
     host = np.empty(lib.pgnn_packed_fc_f16x2_bytes(32, 16), np.uint8)
     assert lib.pgnn_pack_fc_f16x2_acc(w.ctypes.data, None, 32, 16,
                                       host.ctypes.data) == _lib.E_UNSUPPORTED
+
+
+def test_batch_norm_layers_are_folded_and_training_refuses_them():
+    """ParamStore.fc folds slim.batch_norm's inference map into a layer that
+    has BatchNorm statistics instead of biases (gnn.py:17-23, 60-103); the
+    folded layer equals the unfolded expression in float64.  A Trainer given
+    such a config refuses it instead of training without the normalizer."""
+    import copy
+    from pointgnn_amd import gnn, train
+    from oracle import gnn_oracle as gn
+    rng = np.random.default_rng(0)
+    w = rng.standard_normal((7, 5)).astype(np.float32)
+    mean = rng.standard_normal(5).astype(np.float32)
+    var = rng.uniform(0.3, 3.0, 5).astype(np.float32)
+    beta = rng.standard_normal(5).astype(np.float32)
+    x = rng.standard_normal((11, 7))
+    for with_beta in (True, False):
+        params = {"s/fully_connected/weights": w,
+                  "s/fully_connected/BatchNorm/moving_mean": mean,
+                  "s/fully_connected/BatchNorm/moving_variance": var}
+        if with_beta:
+            params["s/fully_connected/BatchNorm/beta"] = beta
+        wf, bf = gnn.ParamStore(params).fc("s/fully_connected")
+        assert wf.dtype == np.float32 and bf.dtype == np.float32
+        (w64, b64), = gn._layers(params, "s", np.float64)
+        ref = gn.fully_connected(x, w64, b64, relu=False)
+        np.testing.assert_allclose(x @ wf.astype(np.float64) + bf, ref,
+                                   rtol=0, atol=5e-6)
+    with pytest.raises(KeyError, match="neither biases nor BatchNorm"):
+        gnn.ParamStore({"s/fully_connected/weights": w}).fc("s/fully_connected")
+    gnn._check_kinds("ReLU", "fused_BN_center")
+    with pytest.raises(NotImplementedError, match="normalization 'IN'"):
+        gnn._check_kinds("ReLU", "IN")
+    with pytest.raises(NotImplementedError, match="activation 'ELU'"):
+        gnn._check_kinds("ELU", "NONE")
+    cfg = copy.deepcopy(configs.get_config("car_auto_T3"))
+    cfg["model_kwargs"]["layer_configs"][1]["kwargs"][
+        "edge_MLP_normalization_type"] = "BN"
+    import torch
+    if not torch.cuda.is_available():
+        # the check sits behind the Trainer's no-CPU-fallback guard: call it on
+        # the config the way __init__ does
+        with pytest.raises(NotImplementedError, match="no training path"):
+            train.check_trainable_kinds(cfg)
+    train.check_trainable_kinds(configs.get_config("car_auto_T3"))
