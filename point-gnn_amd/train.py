@@ -636,6 +636,8 @@ class Trainer(object):
         mk = config['model_kwargs']
         if mk.get('regularizer_type') not in (None, 'l1'):
             raise NotImplementedError("regularizer %r" % mk['regularizer_type'])
+        self.l1_scale = float(mk['regularizer_kwargs']['scale']) \
+            if mk.get('regularizer_type') == 'l1' else 0.0
         check_trainable_kinds(config)
         from .models import cls_loss_kind, loss_top_k
         # models.py:198-208: the loss entries may be dicts keyed by mode
