@@ -92,9 +92,14 @@ __device__ __forceinline__ void pool_hidden_body(const PoolWsArgs &a,
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(0);
     v4f h1[2], h2[4], h3[KQ];
+#ifdef PGNN_POOL_ABL_NO_HIDDEN  // timing ablation (wrong results): no hidden layers
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) h3[q] = x[0];
+#else
     reg_layer<1, 2>(a.l0, lane, x, h1);
     reg_layer<2, 4>(a.l1, lane, h1, h2);
     reg_layer<4, 8>(a.l2, lane, h2, h3);
+#endif
     __builtin_amdgcn_sched_barrier(0);
     {
       const int dn = nxt_ok ? nxt.y : 0;

@@ -202,9 +202,17 @@ __device__ __forceinline__ void pool_ws_body(const PoolWsArgs &a,
       __builtin_amdgcn_s_setprio(0);
       // hidden layers in registers
       v4f h1[2], h2[4];
+#ifdef PGNN_POOL_ABL_NO_HIDDEN  // timing ablation (wrong results): no hidden layers
+#pragma unroll
+      for (int q = 0; q < KQ; ++q) h3[q] = x[0];
+      h1[0] = h1[1] = x[0];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) h2[q] = x[0];
+#else
       reg_layer<1, 2>(a.l0, lane, x, h1);
       reg_layer<2, 4>(a.l1, lane, h1, h2);
       reg_layer<4, 8>(a.l2, lane, h2, h3);
+#endif
       if constexpr (EMIT) {
         // hidden activations: lane (g, n) holds features 16 q + 4 g .. + 3 of
         // row n -- one 16-byte store per K group

@@ -6,7 +6,7 @@ python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "pool_split or pool_we
 for rep in 1 2; do
 for t in 0 1; do
   echo "== pool_split_car=$t"
-  timeout 300 python bench.py --no-cpu-baseline --no-secondary --no-live-pmc --steps 32 --tune pool_split_car=$t 2>gpurun_out/s16.err \
+  timeout 300 python bench.py --no-cpu-baseline --no-secondary --no-live-pmc --steps 32 --tune pool_split_car=$t  # (tunable of the session's tree; the form was not kept) 2>gpurun_out/s16.err \
     | python -c "import json,sys; b=json.loads(sys.stdin.readline()); print('frames/s %.1f edge_us %.1f (frac %.3f) pool_us %.1f (frac %.3f)' % (b['value'], b['roofline_mfma']['avg_launch_us'], b['roofline_mfma']['frac'], b['roofline_pool']['avg_launch_us'], b['roofline_pool']['frac']))" || tail -5 gpurun_out/s16.err
 done; done
 echo "== ped pooling stage under rocprofv3"
