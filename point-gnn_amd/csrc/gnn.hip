@@ -1290,8 +1290,8 @@ int launch_pool_split(const Plan &p, const PoolArgs &pa, int64_t n_edges,
     const int lrc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
     if (lrc) return lrc;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)cus), dim3(64 * kWsWaves), lds, stream,
-                     a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)cus), dim3(64 * kPoolHWaves), lds,
+                     stream, a);
   PGNN_HIP(hipGetLastError());
   const EdgeArgs ea = {hidden, nullptr, kPoolSplitHidden, pa.edges};
   return launch_edge_ws<16, 8, true>(p.chain.l[4], ea, n_edges, sa, cus, sched,

@@ -10,8 +10,8 @@
 // chain's MFMAs and has the shape of the GNN's edge stage -- rows in, a wide
 // product, a segmented max --, so it takes that stage's kernel:
 //
-//   1. `pool_hidden_kernel` (here): pool_ws.h's wave-autonomous form up to the
-//      256-wide hidden layer.  The three narrow layers run in registers
+//   1. `pool_hidden_kernel` (here): pool_ws.h's wave-autonomous form (12 waves
+//      per workgroup) up to the 256-wide hidden layer.  The three narrow layers run in registers
 //      (reg_layer), the 128 -> 256 layer's 8 x 16 fragments (128 KiB) stay in
 //      LDS for the life of the kernel, and the activated rows go to a
 //      workspace in HBM, [n_edges, 256] (one 16-byte store per column tile and
@@ -134,8 +134,18 @@ __device__ __forceinline__ void pool_hidden_body(const PoolWsArgs &a,
   __builtin_amdgcn_s_setprio(0);
 }
 
-__global__ __launch_bounds__(64 * kWsWaves) void pool_hidden_kernel(PoolWsArgs a) {
+// Waves per workgroup: the body needs ~160 VGPRs (no carried segment state),
+// so THREE waves per SIMD fit where pool_ws.h / edge_ws.h run two -- a third
+// wave covers more of a tile's dependent gather chain (edge -> point ->
+// keypoint -> coordinates) with the others' MFMAs: 2 254 -> 2 215 us for the
+// ped_dense stage; 16 waves (128 VGPRs) spill: 2 315 us.
+#ifndef PGNN_POOLH_WAVES
+#define PGNN_POOLH_WAVES 12
+#endif
+constexpr int kPoolHWaves = PGNN_POOLH_WAVES;
+__global__ __launch_bounds__(64 * kPoolHWaves) void pool_hidden_kernel(PoolWsArgs a) {
   constexpr int KQ = 8, NT = 16;
+  constexpr int kWsWaves = kPoolHWaves;  // (shadows the 8-wave constant below)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   v4f *wl = reinterpret_cast<v4f *>(smem);
   float *bias_lds = reinterpret_cast<float *>(wl + KQ * NT * 64);
@@ -145,15 +155,19 @@ __global__ __launch_bounds__(64 * kWsWaves) void pool_hidden_kernel(PoolWsArgs a
     // all 16 fragment requests of a wave in flight before the first LDS write
     // (edge_ws_kernel)
     const v4f *__restrict__ src = reinterpret_cast<const v4f *>(a.wp);
-    constexpr int PER = KQ * NT / kWsWaves;
+    constexpr int PER = (KQ * NT + kWsWaves - 1) / kWsWaves;
     v4f tmp[PER];
 #pragma unroll
-    for (int i = 0; i < PER; ++i)
-      tmp[i] = src[(size_t)(wave + i * kWsWaves) * 64 + lane];
+    for (int i = 0; i < PER; ++i) {
+      const int f = wave + i * kWsWaves;
+      tmp[i] = src[(size_t)(f < KQ * NT ? f : 0) * 64 + lane];
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 0; i < PER; ++i)
-      wl[(size_t)(wave + i * kWsWaves) * 64 + lane] = tmp[i];
+    for (int i = 0; i < PER; ++i) {
+      const int f = wave + i * kWsWaves;
+      if (f < KQ * NT) wl[(size_t)f * 64 + lane] = tmp[i];
+    }
     if ((int)threadIdx.x < 16 * NT)
       bias_lds[threadIdx.x] = a.wp[(size_t)KQ * NT * 256 + threadIdx.x];
   }
