@@ -447,7 +447,7 @@ int pgnn_point_set_pooling_fwd_dyn(const float *point_features, int32_t n_feat,
  * 4-32-64-128-256-512 (configs/ped_cyl_auto_T3_trainval_config) -- run as TWO
  * launches: the chain up to the 256-wide hidden layer, its rows written to
  * `workspace` ([edges_cap, 256] floats), then the last layer weights-stationary
- * in four column groups with the segmented max (csrc/pool_split.h): 0.83 of
+ * in four column groups with the segmented max (csrc/pool_split.h): 0.85 of
  * the fp32-MFMA peak against the one-launch LDS-tile kernel's 0.67, the maxima
  * bit-identical.  pgnn_point_set_pooling_workspace_bytes says how much
  * workspace a chain / edge count asks for (0: the one-launch kernels are used
