@@ -417,6 +417,58 @@ def test_pipelined_frame_loop_writes_the_sequential_loops_files(tmp_path,
                     atol=1e-3)
 
 
+def test_pipelined_frame_loop_ped_cyl_split_pooling(tmp_path):
+    """The same for `ped_cyl_auto_T3` (configs/ped_cyl_auto_T3_*: two classes
+    with their own box codec, 4-32-64-128-256-512 point MLP): its pooling stage
+    runs as two launches through a workspace of hidden rows
+    (csrc/pool_split.h; forced below its size threshold here), in the
+    sequential loop with host-sized counts and in the pipelined one in capacity
+    form -- every output file byte for byte."""
+    import torch
+    from pointgnn_amd import _lib, kitti_dataset as KD, run as RUN, weights
+    cfg = configs.get_config("ped_cyl_auto_T3")
+    presets = ["small", "tiny", "car", "small", "car"]
+    dirs = _kitti_tree(tmp_path, presets)
+    ds = KD.KittiDataset(*dirs)
+    params = weights.init_params(cfg, seed=5, bias_scale=0.05)
+    try:
+        _lib.set_tunable("mlp_debug", 16384)
+        seq_dir = str(tmp_path / "seq")
+        td0 = RUN.run_dataset(ds, cfg, None, seq_dir, params=params,
+                              pipelined=False)
+        assert td0['frames'] == len(presets)
+        out = str(tmp_path / "pipe")
+        td = RUN.run_dataset(ds, cfg, None, out, params=params, in_flight=3,
+                             prefetch=2)
+        torch.cuda.synchronize()
+        assert td['frames'] == len(presets)
+    finally:
+        _lib.set_tunable("mlp_debug", 0)
+    rows = 0
+    for i in range(ds.num_files):
+        name = ds.get_filename(i) + ".txt"
+        with open(os.path.join(seq_dir, "data", name), "rb") as f:
+            want = f.read()
+        with open(os.path.join(out, "data", name), "rb") as f:
+            assert f.read() == want, i
+        rows += want.count(b"\n")
+        assert all(l.split()[0] in (b"Pedestrian", b"Cyclist")
+                   for l in want.split(b"\n") if l.strip())
+    assert rows >= 3, "no detections at all"
+    # the tile kernel writes the same files
+    try:
+        _lib.set_tunable("mlp_debug", 8192)
+        ref_dir = str(tmp_path / "tile")
+        RUN.run_dataset(ds, cfg, None, ref_dir, params=params, pipelined=False)
+    finally:
+        _lib.set_tunable("mlp_debug", 0)
+    for i in range(ds.num_files):
+        name = ds.get_filename(i) + ".txt"
+        with open(os.path.join(ref_dir, "data", name), "rb") as f, \
+                open(os.path.join(seq_dir, "data", name), "rb") as g:
+            assert f.read() == g.read(), i
+
+
 def test_inside_box_host_equals_device_kernel():
     """kitti_output.inside_box_host (the pipelined loop's occlusion test) ==
     kitti_dataset.sel_xyz_in_box3d on the device, including points placed ON

@@ -569,6 +569,16 @@ def test_batch_norm_layers_are_folded_and_training_refuses_them():
         ref = gn.fully_connected(x, w64, b64, relu=False)
         np.testing.assert_allclose(x @ wf.astype(np.float64) + bf, ref,
                                    rtol=0, atol=5e-6)
+    # scale=True (not one of the registry's kinds, but what a checkpoint of
+    # slim.batch_norm(scale=True) would hold): gamma multiplies the scale
+    gamma = rng.uniform(0.5, 1.5, 5).astype(np.float32)
+    params["s/fully_connected/BatchNorm/beta"] = beta
+    params["s/fully_connected/BatchNorm/gamma"] = gamma
+    wf, bf = gnn.ParamStore(params).fc("s/fully_connected")
+    (w64, b64), = gn._layers(params, "s", np.float64)
+    np.testing.assert_allclose(x @ wf.astype(np.float64) + bf,
+                               gn.fully_connected(x, w64, b64, relu=False),
+                               rtol=0, atol=5e-6)
     with pytest.raises(KeyError, match="neither biases nor BatchNorm"):
         gnn.ParamStore({"s/fully_connected/weights": w}).fc("s/fully_connected")
     gnn._check_kinds("ReLU", "fused_BN_center")
