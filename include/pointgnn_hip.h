@@ -455,8 +455,8 @@ int pgnn_point_set_pooling_fwd_dyn(const float *point_features, int32_t n_feat,
  * n_edges / num_keypoints: both NULL (host-sized form: edges_cap and
  * keypoints_cap are the counts) or both given (capacity form).  `workspace`:
  * 16-byte aligned, owned by the caller, free for reuse once the call's work on
- * `stream` is done; NULL or a chain the split form does not cover: exactly
- * pgnn_point_set_pooling_fwd(_dyn).                                          */
+ * `stream` is done (too small: PGNN_E_WORKSPACE, nothing launched); NULL or a
+ * chain the split form does not cover: exactly pgnn_point_set_pooling_fwd(_dyn). */
 int pgnn_point_set_pooling_workspace_bytes(const pgnn_fc_layer *layers_host,
                                            int32_t n_layers, int32_t n_feat,
                                            int64_t edges_cap,

@@ -461,7 +461,9 @@ def load():
     return lib
 
 
-E_UNSUPPORTED = -3   # PGNN_E_UNSUPPORTED of include/pointgnn_hip.h
+E_INVALID = -1       # PGNN_E_* of include/pointgnn_hip.h
+E_WORKSPACE = -2
+E_UNSUPPORTED = -3
 
 
 def check(rc, what=""):

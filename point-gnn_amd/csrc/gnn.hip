@@ -1530,10 +1530,11 @@ int pooling_fwd_impl(const float *point_features, int32_t n_feat,
                             0, de.dev);
     // (likewise bit-identical; needs the hidden rows' workspace)
     if (workspace && pool_split_applies(p, expected(de, n_edges), cus)) {
-      PGNN_REQUIRE((uintptr_t)workspace % 16 == 0 &&
-                       workspace_bytes >= (size_t)n_edges * kPoolSplitHidden *
-                                              sizeof(float),
-                   PGNN_E_INVALID, "pooling: workspace too small / unaligned");
+      PGNN_REQUIRE((uintptr_t)workspace % 16 == 0, PGNN_E_INVALID,
+                   "pooling: workspace not 16-byte aligned");
+      PGNN_REQUIRE(workspace_bytes >=
+                       (size_t)n_edges * kPoolSplitHidden * sizeof(float),
+                   PGNN_E_WORKSPACE, "pooling: workspace too small");
       return launch_pool_split(p, pa, n_edges, sa, cus, sched_ws, stream, de.dev,
                                static_cast<float *>(workspace));
     }

@@ -946,6 +946,69 @@ def test_pool_split_kernels_are_bit_identical(dev, case):
                                rtol=1e-4)
 
 
+def test_pool_split_workspace_contract(dev):
+    """pgnn_point_set_pooling_fwd_ws: a workspace that is too small
+    (PGNN_E_WORKSPACE) or not 16-byte aligned, or a lone device count
+    (PGNN_E_INVALID), is refused with nothing launched; without a workspace, or for a chain the split form does not
+    cover, the call IS pgnn_point_set_pooling_fwd."""
+    import ctypes
+    import torch
+    from pointgnn_amd import _lib, gnn
+    lib = _lib.load()
+    rng = np.random.default_rng(21)
+    cfg = configs.get_config("ped_cyl_auto_T3")
+    kw = cfg["model_kwargs"]["layer_configs"][0]["kwargs"]
+    k, n_pts = 300, 4000
+    dst = np.repeat(np.arange(k), 40).astype(np.int32)
+    edges = np.stack([rng.integers(0, n_pts, len(dst)).astype(np.int32), dst], 1)
+    xyz = T(rng.standard_normal((n_pts, 3)).astype(np.float32), dev)
+    inten = T(rng.random((n_pts, 1)).astype(np.float32), dev)
+    kp = T(rng.choice(n_pts, k, replace=False).astype(np.int32), dev)
+    e_dev = T(edges, dev)
+    store = _store(weights.init_params(cfg, seed=2, bias_scale=0.1), dev)
+    with gnn.parameters(store), gnn.variable_scope("layer1"), \
+            gnn.variable_scope("extract_vertex_features"):
+        chain = gnn._relu_chain(store, gnn._scope(),
+                                list(kw["point_MLP_depth_list"]), False)
+    out = torch.empty((k, 512), dtype=torch.float32, device=dev)
+
+    def call(work, nbytes, ne=None, nk=None):
+        return lib.pgnn_point_set_pooling_fwd_ws(
+            _lib.ptr(inten), 1, _lib.ptr(xyz), _lib.ptr(kp), _lib.ptr(e_dev),
+            len(edges), k, chain.array, chain.n, 1, _lib.ptr(out),
+            out.stride(0), _lib.ptr(_lib.sched_ws(dev)), ne, nk,
+            ctypes.c_void_p(work), nbytes, _lib.stream_ptr())
+    need = len(edges) * 256 * 4
+    work = torch.empty(need // 4 + 8, dtype=torch.float32, device=dev)
+    try:
+        _lib.set_tunable("mlp_debug", 16384)
+        assert call(work.data_ptr(), need) == 0
+        good = out.clone()
+        assert call(work.data_ptr(), need - 4) == _lib.E_WORKSPACE
+        assert b"workspace too small" in lib.pgnn_last_error()
+        assert call(work.data_ptr() + 4, need) == _lib.E_INVALID
+        cnt = _lib.DeviceCount(torch.tensor([len(edges)], dtype=torch.int32,
+                                            device=dev), len(edges))
+        assert call(work.data_ptr(), need, ne=cnt.arg()) == _lib.E_INVALID
+        out.fill_(7.0)
+        assert call(None, 0) == 0            # no workspace: the one-launch kernel
+        assert torch.equal(out, good)
+    finally:
+        _lib.set_tunable("mlp_debug", 0)
+    # a chain the split form does not cover asks for nothing
+    car = configs.get_config("car_auto_T3")
+    ckw = car["model_kwargs"]["layer_configs"][0]["kwargs"]
+    cstore = _store(weights.init_params(car, seed=2, bias_scale=0.1), dev)
+    with gnn.parameters(cstore), gnn.variable_scope("layer1"), \
+            gnn.variable_scope("extract_vertex_features"):
+        cchain = gnn._relu_chain(cstore, gnn._scope(),
+                                 list(ckw["point_MLP_depth_list"]), False)
+    nbytes = ctypes.c_size_t(99)
+    _lib.check(lib.pgnn_point_set_pooling_workspace_bytes(
+        cchain.array, cchain.n, 1, 10 ** 6, 0, ctypes.byref(nbytes)), "query")
+    assert nbytes.value == 0
+
+
 @pytest.mark.parametrize("auto_offset,k", [(True, 1000), (False, 37), (True, 16)])
 def test_vertex_pre_edge_equals_unfused_entries(dev, auto_offset, k):
     """pgnn_vertex_pre_edge_fwd == pgnn_mlp_fwd (offset chain) +
