@@ -169,3 +169,38 @@ def test_predict_real_weights_full_size(dev, preset, t, edge_arith):
     np.testing.assert_allclose(boxes, ref_b, atol=FP_TOL, rtol=0)
     np.testing.assert_allclose(logits, lg, atol=FP_TOL, rtol=0)
     np.testing.assert_allclose(boxes, bx, atol=FP_TOL, rtol=0)
+
+
+def test_full_size_ped_pooling_split_equals_tile_kernel(dev):
+    """BASELINE config 5's pooling stage at full size (N 50 000, E0 853 873):
+    the two-launch form (csrc/pool_split.h -- what a frame of this size takes
+    by itself) and the one-launch LDS-tile kernel (`mlp_debug` 8192) write the
+    same bits; shuffled edges (every run flushed with atomic max) too.  The
+    hidden rows' workspace is 0.87 GB here."""
+    import torch
+    from pointgnn_amd import _lib, gnn, graph_gen, weights
+    cfg = configs.get_config("ped_cyl_auto_T3")
+    xyz, inten = synthetic_cloud(seed=0, preset="ped_dense")
+    fn = graph_gen.get_graph_generate_fn(cfg["graph_gen_method"])
+    coords, kps, edges = fn(T(xyz, dev), **cfg["runtime_graph_gen_kwargs"])
+    assert edges[0].shape[0] > 800000
+    kw = cfg["model_kwargs"]["layer_configs"][0]["kwargs"]
+    store = gnn.ParamStore(weights.init_params(cfg, seed=0, bias_scale=0.05),
+                           dev)
+    f = T(inten, dev)
+
+    def run(e):
+        with gnn.parameters(store), gnn.variable_scope("layer1"):
+            return gnn.PointSetPooling().apply_regular(f, coords[0], kps[0], e,
+                                                       **kw)
+    g = torch.Generator(device="cpu").manual_seed(0)
+    shuf = edges[0][torch.randperm(edges[0].shape[0], generator=g).to(dev)]
+    split, split_shuf = run(edges[0]), run(shuf)
+    try:
+        _lib.set_tunable("mlp_debug", 8192)
+        tile = run(edges[0])
+    finally:
+        _lib.set_tunable("mlp_debug", 0)
+    assert torch.isfinite(split).all()
+    assert torch.equal(split, tile)
+    assert torch.equal(split, split_shuf)
